@@ -1,0 +1,92 @@
+"""Deterministic synthetic clouds for the ICP hot path (SURVEY.md section 8(d) spec).
+
+"Gaussian surface": eight asymmetric bumps on [-1,1]^2 (a single radial Gaussian is a surface of
+revolution, which leaves yaw unobservable and makes the 6x6 normal system singular).  Points are
+drawn with a counter-based RNG (splitmix64) so any shard [start, start+n) can be generated
+independently by any rank -- this is what the multi-GPU bench uses.
+"""
+import numpy as np
+
+_BUMPS = np.array([  # cx, cy, s, a
+    (-.60, -.45, .22, .30), (.35, -.65, .18, -.20), (.70, .10, .25, .25), (-.15, .55, .30, .35),
+    (-.75, .35, .15, -.15), (.10, -.10, .20, .20), (.55, .70, .17, -.25), (-.30, -.80, .12, .15),
+], dtype=np.float64)
+
+TARGET_SEED = 1001
+SOURCE_SEED = 2002
+
+
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15))
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def _u01(seed, i, c):
+    with np.errstate(over="ignore"):
+        h = _splitmix64(np.uint64(seed) ^ _splitmix64(np.uint64(4) * i + np.uint64(c)))
+    return (h >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
+
+
+def surface_height(x, y):
+    """S(x, y) in float64."""
+    x = np.asarray(x, np.float64)
+    y = np.asarray(y, np.float64)
+    z = np.zeros_like(x)
+    for cx, cy, s, a in _BUMPS:
+        z += a * np.exp(-((x - cx) ** 2 + (y - cy) ** 2) / (2.0 * s * s))
+    return z
+
+
+def gaussian_surface(n, seed=TARGET_SEED, start=0, noise=1e-4, chunk=1 << 22):
+    """(n, 4) float32 cloud x,y,z,1 -- points [start, start+n) of the stream for `seed`."""
+    out = np.empty((n, 4), np.float32)
+    for b in range(0, n, chunk):
+        e = min(n, b + chunk)
+        i = np.arange(start + b, start + e, dtype=np.uint64)
+        x = np.float32(2.0) * _u01(seed, i, 0) - np.float32(1.0)
+        y = np.float32(2.0) * _u01(seed, i, 1) - np.float32(1.0)
+        u1 = _u01(seed, i, 2).astype(np.float64) + 2.0 ** -25
+        u2 = _u01(seed, i, 3).astype(np.float64)
+        g = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+        z = surface_height(x, y) + noise * g
+        out[b:e, 0] = x
+        out[b:e, 1] = y
+        out[b:e, 2] = z.astype(np.float32)
+        out[b:e, 3] = 1.0
+    return out
+
+
+def ground_truth_transform():
+    """T_gt: rotation 2 deg about (0.3,-0.5,0.81)/|.|, translation (0.012,-0.009,0.015); float64 4x4."""
+    axis = np.array([0.3, -0.5, 0.81])
+    axis /= np.linalg.norm(axis)
+    th = np.deg2rad(2.0)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = (0.012, -0.009, 0.015)
+    return T
+
+
+def apply_rigid(T, pts):
+    """float64 application of a 4x4 to an (n,>=3) float32 cloud; returns (n,4) float32, w=1."""
+    T = np.asarray(T, np.float64)
+    p = pts[:, :3].astype(np.float64)
+    q = p @ T[:3, :3].T + T[:3, 3]
+    out = np.empty((len(pts), 4), np.float32)
+    out[:, :3] = q.astype(np.float32)
+    out[:, 3] = 1.0
+    return out
+
+
+def icp_pair(n, start=0, n_target=None, target_start=0):
+    """(target, source, T_gt): source = independent resample moved by T_gt^-1, so ICP returns ~T_gt."""
+    tgt = gaussian_surface(n_target if n_target is not None else n, TARGET_SEED, target_start)
+    src = gaussian_surface(n, SOURCE_SEED, start)
+    T = ground_truth_transform()
+    src = apply_rigid(np.linalg.inv(T), src)
+    return tgt, src, T
