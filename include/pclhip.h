@@ -1,0 +1,213 @@
+/*
+ * pclhip.h -- C ABI of the MI355X-native ICP hot path (k-NN correspondence search, normal
+ * estimation, point-to-point / point-to-plane ICP, VoxelGrid prefilter).
+ *
+ * PCL has no FFI: the path sits behind C++ virtual plugin points.  Each entry point below names
+ * the reference interface it replaces (file:line relative to the PCL tree); the adapter classes
+ * in include/pclhip/pcl_compat.hpp (and the real-PCL subclasses shown in INTEGRATION.md) are the
+ * only intended callers.
+ *
+ * Conventions
+ *  - plain C, opaque handles, no exceptions across the boundary; every function returns
+ *    PCLHIP_OK (0) or a negative pclhip_status; pclhip_last_error() gives the message.
+ *  - point buffers are arrays of records with a byte stride; x,y,z are three consecutive floats
+ *    at byte 0 of each record (pcl::PointXYZ = 16 B, pcl::PointNormal = 48 B with the normal at
+ *    +16, common/include/pcl/impl/point_types.hpp:315-321,843-853).  Buffers may live in host OR
+ *    device memory -- the library detects which (hipPointerGetAttributes) and stages host data.
+ *  - index_t is int32 (common/include/pcl/types.h:110-133); "no neighbour" is -1, distance +inf.
+ *  - a handle is not thread-safe; distinct contexts may be used concurrently.  All work of a
+ *    context is issued on its HIP stream; entry points that return host results synchronise it.
+ *  - results: k-NN indices/distances are bit-exact w.r.t. the CPU oracle (float L2_Simple
+ *    ((dx*dx)+dy*dy)+dz*dz, ascending (distance, index), ties -> lower index).
+ */
+#ifndef PCLHIP_H_
+#define PCLHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define PCLHIP_API __attribute__((visibility("default")))
+#else
+#define PCLHIP_API
+#endif
+
+typedef int pclhip_status;
+enum {
+  PCLHIP_OK = 0,
+  PCLHIP_ERR_INVALID = -1,  /* bad argument */
+  PCLHIP_ERR_HIP = -2,      /* HIP runtime failure (message has hipGetErrorString) */
+  PCLHIP_ERR_NO_DEVICE = -3,
+  PCLHIP_ERR_STATE = -4,    /* call order (e.g. point-to-plane without target normals) */
+  PCLHIP_ERR_OVERFLOW = -5  /* VoxelGrid: leaf too small, int32 voxel index would overflow */
+};
+
+typedef struct pclhip_ctx pclhip_ctx;
+typedef struct pclhip_index pclhip_index;
+typedef struct pclhip_icp pclhip_icp;
+
+/* ---- context --------------------------------------------------------------------------------
+ * stream: a hipStream_t to issue work on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
+ * to let the context create its own non-blocking stream. */
+PCLHIP_API pclhip_status pclhip_ctx_create(int device, void* stream, pclhip_ctx** out);
+PCLHIP_API void pclhip_ctx_destroy(pclhip_ctx* ctx);
+PCLHIP_API const char* pclhip_last_error(const pclhip_ctx* ctx /* may be NULL */);
+PCLHIP_API pclhip_status pclhip_ctx_synchronize(pclhip_ctx* ctx);
+PCLHIP_API const char* pclhip_version(void);
+
+/* ---- spatial index over the target cloud ------------------------------------------------------
+ * Replaces pcl::KdTreeFLANN<PointT>::setInputCloud (kdtree/include/pcl/kdtree/impl/
+ * kdtree_flann.hpp:99-136) as called from pcl::search::KdTree<PointT>::setInputCloud
+ * (search/include/pcl/search/impl/kdtree.hpp:87-97) and Registration::initCompute
+ * (registration/include/pcl/registration/impl/registration.hpp:84-87).
+ * Non-finite points are dropped (kdtree_flann.hpp:443-452).  `indices` (optional) selects a subset
+ * exactly like the (cloud, indices) overload (:428-498): returned neighbour indices are indices
+ * into the ORIGINAL cloud. */
+PCLHIP_API pclhip_status pclhip_index_build(pclhip_ctx* ctx, const void* points, size_t stride_bytes,
+                                            uint64_t n, const int32_t* indices, uint64_t n_indices,
+                                            pclhip_index** out);
+PCLHIP_API void pclhip_index_destroy(pclhip_index* index);
+/* number of finite points indexed */
+PCLHIP_API uint64_t pclhip_index_size(const pclhip_index* index);
+/* milliseconds of GPU time spent in the last build (bbox + Morton + radix sort + gather + boxes) */
+PCLHIP_API double pclhip_index_build_ms(const pclhip_index* index);
+
+/* Exact k nearest neighbours of nq query points.
+ * Replaces pcl::KdTreeFLANN<PointT>::nearestKSearch (kdtree_flann.hpp:234-274) and the batch
+ * overloads of pcl::search::Search<PointT>::nearestKSearch (search/include/pcl/search/impl/
+ * search.hpp:113-136).  k is clamped to the index size (:241-242); unused slots get -1 / +inf.
+ * out_idx: nq*k int32, out_d2: nq*k float (squared L2), both host or device memory.
+ * Non-finite queries return no neighbours. */
+PCLHIP_API pclhip_status pclhip_knn(pclhip_index* index, const void* queries, size_t stride_bytes,
+                                    uint64_t nq, int k, int32_t* out_idx, float* out_d2);
+
+/* Surface normals + curvature of every indexed point from its k nearest neighbours in the index.
+ * Replaces pcl::NormalEstimation<PointInT,PointOutT>::computeFeature (features/include/pcl/
+ * features/impl/normal_3d.hpp:48-95) with setKSearch(k), search surface == input:
+ * computeMeanAndCovarianceMatrix (common/include/pcl/common/impl/centroid.hpp:581-650) ->
+ * solvePlaneParameters/eigen33 (features/include/pcl/features/impl/feature.hpp:64-89,
+ * common/include/pcl/common/impl/eigen.hpp:295-325) -> flipNormalTowardsViewpoint
+ * (features/include/pcl/features/normal_3d.h:169-188).
+ * out (optional, host or device): one record per ORIGINAL cloud point (n of pclhip_index_build):
+ * 4 floats nx,ny,nz,curvature at byte 0 of each out_stride_bytes record; NaN for dropped points.
+ * The normals are also retained inside the index for point-to-plane ICP.  out_nan_count optional. */
+PCLHIP_API pclhip_status pclhip_normals(pclhip_index* index, int k, const float viewpoint[3],
+                                        void* out, size_t out_stride_bytes, uint64_t* out_nan_count);
+/* Supply target normals computed elsewhere (e.g. a pcl::PointNormal target: normals = points + 16,
+ * stride 48).  One record per ORIGINAL cloud point. */
+PCLHIP_API pclhip_status pclhip_index_set_normals(pclhip_index* index, const void* normals,
+                                                  size_t stride_bytes);
+
+/* ---- ICP --------------------------------------------------------------------------------------*/
+enum { PCLHIP_ICP_POINT_TO_POINT = 0, /* TransformationEstimationSVD, icp.h:149-151 */
+       PCLHIP_ICP_POINT_TO_PLANE = 1  /* TransformationEstimationPointToPlaneLLS, icp.h:395-398 */ };
+
+/* number of doubles in the per-iteration reduction record */
+#define PCLHIP_ICP_NSUMS 32
+/* layout of sums[]:
+ *   point-to-plane: [0..20] upper triangle of ATA (row-major, order of impl/
+ *                   transformation_estimation_point_to_plane_lls.hpp:213-233), [21..26] ATb
+ *   point-to-point: [0..2] sum s, [3..5] sum t, [6..14] sum t_i*s_j (row-major), rest 0
+ *   [27] sum of squared correspondence distances, [28] number of correspondences,
+ *   [29] number of pairs skipped for non-finite normals, [30..31] reserved */
+
+typedef struct {
+  int max_iterations;                     /* registration.h:566, default 10 */
+  double max_correspondence_distance;     /* registration.h:117, default sqrt(DBL_MAX) */
+  double transformation_epsilon;          /* registration.h:588, default 0 */
+  double transformation_rotation_epsilon; /* registration.h:592, default 0 = unset */
+  double euclidean_fitness_epsilon;       /* registration.h:116, default -DBL_MAX */
+  int min_number_correspondences;         /* registration.h:621, default 3 */
+  int mode;                               /* PCLHIP_ICP_POINT_TO_POINT / _PLANE */
+  int failure_after_max_iterations;       /* default_convergence_criteria.h:294 */
+  int max_iterations_similar_transforms;  /* default_convergence_criteria.h:318 */
+  double mse_threshold_absolute;          /* default_convergence_criteria.h:310, 1e-12 */
+} pclhip_icp_params;
+
+typedef struct {
+  float final_transformation[16];   /* row-major 4x4 */
+  float last_transformation[16];    /* transformation_ of the last iteration */
+  int nr_iterations;
+  int converged;
+  int convergence_state;            /* DefaultConvergenceCriteria::ConvergenceState values */
+  uint64_t num_correspondences;     /* of the last iteration */
+  double mse;                       /* mean squared correspondence distance, last iteration */
+  double gpu_ms;                    /* GPU time of all iterate launches (events on ctx stream) */
+  double gpu_ms_search_kernel;      /* ... of which the fused search+accumulate kernel */
+} pclhip_icp_result;
+
+/* Optional hook run on the 32-double DEVICE record of every iteration before the host reads it:
+ * multi-GPU runs all-reduce (sum) it over RCCL here.  `stream` is the context's hipStream_t on
+ * which the record was produced.  Return 0 on success. */
+typedef int (*pclhip_allreduce_fn)(void* user, double* device_sums, int count, void* stream);
+
+PCLHIP_API void pclhip_icp_params_default(pclhip_icp_params* p);
+
+/* Registration object bound to a target index.  Replaces the state held by
+ * pcl::IterativeClosestPoint (registration/include/pcl/registration/icp.h:98-347). */
+PCLHIP_API pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out);
+PCLHIP_API void pclhip_icp_destroy(pclhip_icp* icp);
+/* Registration::setInputSource (registration.h:195-196): uploads + Morton-orders the source. */
+PCLHIP_API pclhip_status pclhip_icp_set_source(pclhip_icp* icp, const void* points,
+                                               size_t stride_bytes, uint64_t n);
+PCLHIP_API pclhip_status pclhip_icp_set_allreduce(pclhip_icp* icp, pclhip_allreduce_fn fn, void* user);
+/* Rewind the working copy of the source to the input cloud (start of computeTransformation). */
+PCLHIP_API pclhip_status pclhip_icp_reset(pclhip_icp* icp);
+
+/* One fused iteration on the device-resident working source cloud:
+ *   cur <- T_prev * cur   (transformCloud, impl/icp.hpp:49-111 / transforms.hpp:109-123)
+ *   1-NN of every cur point in the target, drop d2 > max_dist^2
+ *        (CorrespondenceEstimation::determineCorrespondences, impl/correspondence_estimation.hpp:145-218)
+ *   accumulate the normal system (TransformationEstimationPointToPlaneLLS::estimateRigidTransformation,
+ *        impl/transformation_estimation_point_to_plane_lls.hpp:165-245) or the umeyama sums.
+ * T_prev: row-major 4x4 float (identity on the first iteration, or the guess).
+ * sums: PCLHIP_ICP_NSUMS doubles on the host. */
+PCLHIP_API pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[16], double max_dist,
+                                            int mode, double sums[PCLHIP_ICP_NSUMS]);
+
+/* Host-side closed forms on a reduction record (exposed for the adapters and for tests):
+ * 6x6 solve + constructTransformationMatrix (…point_to_plane_lls.hpp:132-163,264-268) or umeyama
+ * (common/include/pcl/common/impl/eigen.hpp:675-738). */
+PCLHIP_API pclhip_status pclhip_solve_transformation(const double sums[PCLHIP_ICP_NSUMS], int mode,
+                                                     float T[16]);
+
+/* The whole loop of IterativeClosestPoint::computeTransformation (impl/icp.hpp:113-268) with
+ * DefaultConvergenceCriteria (impl/default_convergence_criteria.hpp:49-140).  The criteria's
+ * previous-MSE memory persists across calls on the same object, as in the reference.
+ * guess: row-major 4x4 or NULL. */
+PCLHIP_API pclhip_status pclhip_icp_align(pclhip_icp* icp, const pclhip_icp_params* params,
+                                          const float guess[16], pclhip_icp_result* result);
+
+/* Correspondences of the LAST iteration, materialised lazily as pcl::Correspondences
+ * (common/include/pcl/correspondence.h:60-89): sorted by index_query, entries beyond max_dist
+ * omitted.  Buffers (host or device) must hold n_source entries; *out_n receives the count. */
+PCLHIP_API pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_query,
+                                                          int32_t* index_match, float* distance,
+                                                          uint64_t* out_n);
+
+/* out = T * in for n records (x,y,z at byte 0; other bytes of the record untouched);
+ * order 0: Eigen Matrix4f*Vector4f order (icp.hpp:49-111); order 1: Transformer::se3 order
+ * (transforms.hpp:117-123).  If normals_offset_bytes != 0 the 3 floats there are rotated too. */
+PCLHIP_API pclhip_status pclhip_transform_cloud(pclhip_ctx* ctx, const float T[16], int order,
+                                                const void* in, void* out, size_t stride_bytes,
+                                                uint64_t n, size_t normals_offset_bytes);
+
+/* ---- VoxelGrid ----------------------------------------------------------------------------------
+ * Replaces pcl::VoxelGrid<pcl::PointXYZ>::applyFilter (filters/include/pcl/filters/impl/
+ * voxel_grid.hpp:597-814) with downsample_all_data, optional z-field limits
+ * (setFilterFieldName("z") + setFilterLimits).  Output: ascending voxel id, records x,y,z,1
+ * (16 B).  out must hold n records; *out_n receives the count.  Returns PCLHIP_ERR_OVERFLOW when
+ * the reference would refuse (:620-629). */
+PCLHIP_API pclhip_status pclhip_voxelgrid(pclhip_ctx* ctx, const void* points, size_t stride_bytes,
+                                          uint64_t n, const float leaf[3], uint32_t min_points_per_voxel,
+                                          int has_z_limits, double z_min, double z_max,
+                                          void* out_xyzw, uint64_t* out_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCLHIP_H_ */

@@ -1,0 +1,111 @@
+"""ctypes binding of the C ABI in include/pclhip.h (the drop-in boundary).
+
+The shared library is built in-tree by `__graft_entry__.build()` / `make -C pcl_amd/csrc`.  There is
+deliberately NO CPU fallback: if the HIP library cannot be loaded, importing the product API fails
+loudly with PclHipUnavailable.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpclhip.so")
+
+NSUMS = 32
+POINT_TO_POINT = 0
+POINT_TO_PLANE = 1
+
+CONVERGENCE_STATES = ("NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE",
+                      "NO_CORRESPONDENCES", "FAILURE_AFTER_MAX_ITERATIONS")
+
+
+class PclHipUnavailable(RuntimeError):
+    pass
+
+
+class PclHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("pclhip status %d: %s" % (status, message))
+        self.status = status
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("max_correspondence_distance", C.c_double),
+                ("transformation_epsilon", C.c_double),
+                ("transformation_rotation_epsilon", C.c_double),
+                ("euclidean_fitness_epsilon", C.c_double), ("min_number_correspondences", C.c_int),
+                ("mode", C.c_int), ("failure_after_max_iterations", C.c_int),
+                ("max_iterations_similar_transforms", C.c_int),
+                ("mse_threshold_absolute", C.c_double)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("final_transformation", C.c_float * 16), ("last_transformation", C.c_float * 16),
+                ("nr_iterations", C.c_int), ("converged", C.c_int), ("convergence_state", C.c_int),
+                ("num_correspondences", C.c_uint64), ("mse", C.c_double), ("gpu_ms", C.c_double),
+                ("gpu_ms_search_kernel", C.c_double)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+# every symbol include/pclhip.h declares: (restype, argtypes)
+_vp, _sz, _u64 = C.c_void_p, C.c_size_t, C.c_uint64
+SIGNATURES = {
+    "pclhip_version": (C.c_char_p, []),
+    "pclhip_last_error": (C.c_char_p, [_vp]),
+    "pclhip_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "pclhip_ctx_destroy": (None, [_vp]),
+    "pclhip_ctx_synchronize": (C.c_int, [_vp]),
+    "pclhip_index_build": (C.c_int, [_vp, _vp, _sz, _u64, _vp, _u64, C.POINTER(_vp)]),
+    "pclhip_index_destroy": (None, [_vp]),
+    "pclhip_index_size": (_u64, [_vp]),
+    "pclhip_index_build_ms": (C.c_double, [_vp]),
+    "pclhip_knn": (C.c_int, [_vp, _vp, _sz, _u64, C.c_int, _vp, _vp]),
+    "pclhip_normals": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), _vp, _sz, C.POINTER(_u64)]),
+    "pclhip_index_set_normals": (C.c_int, [_vp, _vp, _sz]),
+    "pclhip_icp_params_default": (None, [C.POINTER(IcpParams)]),
+    "pclhip_icp_create": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "pclhip_icp_destroy": (None, [_vp]),
+    "pclhip_icp_set_source": (C.c_int, [_vp, _vp, _sz, _u64]),
+    "pclhip_icp_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),
+    "pclhip_icp_reset": (C.c_int, [_vp]),
+    "pclhip_icp_iterate": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_double, C.c_int,
+                                     C.POINTER(C.c_double)]),
+    "pclhip_solve_transformation": (C.c_int, [C.POINTER(C.c_double), C.c_int,
+                                              C.POINTER(C.c_float)]),
+    "pclhip_icp_align": (C.c_int, [_vp, C.POINTER(IcpParams), C.POINTER(C.c_float),
+                                   C.POINTER(IcpResult)]),
+    "pclhip_icp_fetch_correspondences": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "pclhip_transform_cloud": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int, _vp, _vp, _sz, _u64,
+                                         _sz]),
+    "pclhip_voxelgrid": (C.c_int, [_vp, _vp, _sz, _u64, C.POINTER(C.c_float), C.c_uint32, C.c_int,
+                                   C.c_double, C.c_double, _vp, C.POINTER(_u64)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libpclhip.so and bind every declared symbol (no compute, works without a GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PclHipUnavailable(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C pcl_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise PclHipUnavailable("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, ctx_handle=None):
+    if status != 0:
+        msg = load().pclhip_last_error(ctx_handle)
+        raise PclHipError(status, msg.decode() if msg else "")

@@ -1,0 +1,460 @@
+"""Python mirror of the PCL plugin surface for the ICP hot path, over the C ABI (include/pclhip.h).
+
+Class and method names follow the reference so parity tests read like PCL's own tests:
+  pcl::search::KdTree<PointT>                         search/include/pcl/search/kdtree.h:61-168
+  pcl::registration::CorrespondenceEstimation          registration/include/pcl/registration/correspondence_estimation.h
+  pcl::IterativeClosestPoint / ...WithNormals          registration/include/pcl/registration/icp.h:98-347,360-440
+  pcl::NormalEstimation                                features/include/pcl/features/normal_3d.h:243-420
+  pcl::VoxelGrid                                       filters/include/pcl/filters/voxel_grid.h:221-533
+Clouds are (n, c>=3) float32 arrays: numpy (host) or torch CUDA tensors (device-resident; only the
+pointer crosses the boundary).  All compute happens in libpclhip.so; there is no CPU fallback.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import POINT_TO_PLANE, POINT_TO_POINT, IcpParams, IcpResult, check
+
+_SQRT_DBL_MAX = math.sqrt(np.finfo(np.float64).max)
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _cloud(a):
+    """-> (pointer, stride_bytes, n, keepalive)."""
+    if _is_torch(a):
+        assert a.dtype.is_floating_point and a.element_size() == 4 and a.dim() == 2 and a.shape[1] >= 3
+        a = a.contiguous()
+        return C.c_void_p(a.data_ptr()), a.shape[1] * 4, a.shape[0], a
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] >= 3
+    return C.c_void_p(a.ctypes.data), a.shape[1] * 4, a.shape[0], a
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Context:
+    """One device + one HIP stream (pclhip_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.pclhip_ctx_create(int(device), C.c_void_p(stream) if stream else None,
+                                         C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def synchronize(self):
+        check(self.lib.pclhip_ctx_synchronize(self.h), self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pclhip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class KdTree:
+    """pcl::search::KdTree<PointT> backed by the GPU Morton BVH (pclhip_index)."""
+
+    def __init__(self, ctx=None, sorted_results=True):
+        self.ctx = ctx or default_context()
+        self.lib = self.ctx.lib
+        self.h = None
+        self._cloud_id = None
+        self.n_cloud = 0
+
+    def setInputCloud(self, cloud, indices=None):
+        # registration.h:214-221 / registration.hpp:84-87: rebuilding for the same cloud is a no-op
+        key = (id(cloud), None if indices is None else id(indices))
+        if self.h is not None and key == self._cloud_id:
+            return True
+        self._free()
+        ptr, stride, n, keep = _cloud(cloud)
+        h = C.c_void_p()
+        if indices is not None:
+            ind = np.ascontiguousarray(indices, np.int32)
+            check(self.lib.pclhip_index_build(self.ctx.h, ptr, stride, n, C.c_void_p(ind.ctypes.data),
+                                              len(ind), C.byref(h)), self.ctx.h)
+        else:
+            check(self.lib.pclhip_index_build(self.ctx.h, ptr, stride, n, None, 0, C.byref(h)),
+                  self.ctx.h)
+        self.h = h
+        self._cloud_id = key
+        self._keep = (cloud, indices)
+        self.n_cloud = n
+        return True
+
+    def size(self):
+        return int(self.lib.pclhip_index_size(self.h))
+
+    def build_ms(self):
+        return float(self.lib.pclhip_index_build_ms(self.h))
+
+    def nearestKSearch(self, queries, k, out=None):
+        """Batch overload (search.h:216-219).  Returns (indices int32 [nq,k], sqr_distances [nq,k])."""
+        ptr, stride, nq, keep = _cloud(queries)
+        if _is_torch(queries):
+            import torch
+            idx = torch.empty((nq, k), dtype=torch.int32, device=queries.device)
+            d2 = torch.empty((nq, k), dtype=torch.float32, device=queries.device)
+            check(self.lib.pclhip_knn(self.h, ptr, stride, nq, int(k), C.c_void_p(idx.data_ptr()),
+                                      C.c_void_p(d2.data_ptr())), self.ctx.h)
+            return idx, d2
+        idx = np.empty((nq, k), np.int32)
+        d2 = np.empty((nq, k), np.float32)
+        check(self.lib.pclhip_knn(self.h, ptr, stride, nq, int(k), C.c_void_p(idx.ctypes.data),
+                                  C.c_void_p(d2.ctypes.data)), self.ctx.h)
+        return idx, d2
+
+    def setNormals(self, normals):
+        ptr, stride, n, keep = _cloud(normals)
+        assert n == self.n_cloud
+        check(self.lib.pclhip_index_set_normals(self.h, ptr, stride), self.ctx.h)
+
+    def _free(self):
+        if getattr(self, "h", None):
+            self.lib.pclhip_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+
+class NormalEstimation:
+    """pcl::NormalEstimation<PointInT, pcl::Normal> with setKSearch (k-NN mode)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+        self.lib = self.ctx.lib
+        self.tree = None
+        self.k = 0
+        self.vp = np.zeros(3, np.float32)  # sensor_origin_ default (normal_3d.h:328-351)
+        self.cloud = None
+        self.nan_count = 0
+
+    def setInputCloud(self, cloud):
+        self.cloud = cloud
+
+    def setSearchMethod(self, tree):
+        self.tree = tree
+
+    def setKSearch(self, k):
+        self.k = int(k)
+
+    def setViewPoint(self, x, y, z):
+        self.vp = np.asarray([x, y, z], np.float32)
+
+    def compute(self, want_output=True):
+        """-> (n,4) float32 [nx,ny,nz,curvature]; also retains the normals inside the tree."""
+        assert self.k > 0, "only k-NN mode (setKSearch) is on the accelerated path"
+        if self.tree is None:
+            self.tree = KdTree(self.ctx)
+        self.tree.setInputCloud(self.cloud)  # feature.hpp:125-130
+        n = self.tree.n_cloud
+        nan = C.c_uint64(0)
+        out = None
+        if want_output:
+            if _is_torch(self.cloud):
+                import torch
+                out = torch.empty((n, 4), dtype=torch.float32, device=self.cloud.device)
+                optr = C.c_void_p(out.data_ptr())
+            else:
+                out = np.empty((n, 4), np.float32)
+                optr = C.c_void_p(out.ctypes.data)
+            check(self.lib.pclhip_normals(self.tree.h, self.k, _fp(self.vp), optr, 16, C.byref(nan)),
+                  self.ctx.h)
+        else:
+            check(self.lib.pclhip_normals(self.tree.h, self.k, _fp(self.vp), None, 0, C.byref(nan)),
+                  self.ctx.h)
+        self.nan_count = int(nan.value)
+        return out
+
+
+class CorrespondenceEstimation:
+    """pcl::registration::CorrespondenceEstimation (determineCorrespondences only)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+        self.lib = self.ctx.lib
+        self.tree = KdTree(self.ctx)
+        self.icp = None
+        self.src = None
+
+    def setInputTarget(self, cloud):
+        self.tree.setInputCloud(cloud)
+
+    def setSearchMethodTarget(self, tree, force_no_recompute=False):
+        self.tree = tree
+
+    def setInputSource(self, cloud):
+        self.src = cloud
+
+    def determineCorrespondences(self, max_distance=_SQRT_DBL_MAX):
+        """-> (index_query, index_match, distance) sorted by index_query."""
+        ptr, stride, n, keep = _cloud(self.src)
+        h = C.c_void_p()
+        check(self.lib.pclhip_icp_create(self.tree.h, C.byref(h)), self.ctx.h)
+        try:
+            check(self.lib.pclhip_icp_set_source(h, ptr, stride, n), self.ctx.h)
+            I = np.eye(4, dtype=np.float32).reshape(16)
+            sums = np.zeros(_lib.NSUMS, np.float64)
+            check(self.lib.pclhip_icp_iterate(h, _fp(I), float(max_distance), POINT_TO_POINT,
+                                              sums.ctypes.data_as(C.POINTER(C.c_double))), self.ctx.h)
+            q = np.empty(n, np.int32)
+            m = np.empty(n, np.int32)
+            d = np.empty(n, np.float32)
+            cnt = C.c_uint64(0)
+            check(self.lib.pclhip_icp_fetch_correspondences(
+                h, C.c_void_p(q.ctypes.data), C.c_void_p(m.ctypes.data), C.c_void_p(d.ctypes.data),
+                C.byref(cnt)), self.ctx.h)
+            c = int(cnt.value)
+            assert c == int(sums[28])
+            return q[:c].copy(), m[:c].copy(), d[:c].copy()
+        finally:
+            self.lib.pclhip_icp_destroy(h)
+
+
+class IterativeClosestPoint:
+    """pcl::IterativeClosestPoint<PointXYZ, PointXYZ> (TransformationEstimationSVD)."""
+    MODE = POINT_TO_POINT
+    ORDER = 0
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+        self.lib = self.ctx.lib
+        self.p = IcpParams()
+        self.lib.pclhip_icp_params_default(C.byref(self.p))
+        self.p.mode = self.MODE
+        self.tree = KdTree(self.ctx)
+        self.h = None
+        self.src = None
+        self._src_id = None
+        self.result = None
+        self._allreduce = None
+
+    # --- setters named after registration.h:276-415 ---
+    def setInputTarget(self, cloud):
+        self.tree.setInputCloud(cloud)
+        self._drop_icp()
+
+    def setSearchMethodTarget(self, tree, force_no_recompute=False):
+        self.tree = tree
+        self._drop_icp()
+
+    def setInputSource(self, cloud):
+        self.src = cloud
+
+    def setMaximumIterations(self, n):
+        self.p.max_iterations = int(n)
+
+    def setMaxCorrespondenceDistance(self, d):
+        self.p.max_correspondence_distance = float(d)
+
+    def setTransformationEpsilon(self, e):
+        self.p.transformation_epsilon = float(e)
+
+    def setTransformationRotationEpsilon(self, e):
+        self.p.transformation_rotation_epsilon = float(e)
+
+    def setEuclideanFitnessEpsilon(self, e):
+        self.p.euclidean_fitness_epsilon = float(e)
+
+    def setAllReduce(self, fn):
+        """fn(device_ptr:int, count:int, stream:int) -> 0 ; sums the 32 doubles across ranks."""
+        def tramp(user, ptr, count, stream):
+            try:
+                return int(fn(ptr, count, stream) or 0)
+            except Exception:  # never raise through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._allreduce = _lib.ALLREDUCE_FN(tramp)
+        if self.h:
+            check(self.lib.pclhip_icp_set_allreduce(self.h, self._allreduce, None), self.ctx.h)
+
+    def _drop_icp(self):
+        if self.h:
+            self.lib.pclhip_icp_destroy(self.h)
+            self.h = None
+            self._src_id = None
+
+    def _ensure(self):
+        if self.h is None:
+            h = C.c_void_p()
+            check(self.lib.pclhip_icp_create(self.tree.h, C.byref(h)), self.ctx.h)
+            self.h = h
+            if self._allreduce is not None:
+                check(self.lib.pclhip_icp_set_allreduce(self.h, self._allreduce, None), self.ctx.h)
+        if self._src_id != id(self.src):
+            ptr, stride, n, keep = _cloud(self.src)
+            check(self.lib.pclhip_icp_set_source(self.h, ptr, stride, n), self.ctx.h)
+            self._src_id = id(self.src)
+
+    def iterate(self, T_prev=None, max_dist=None):
+        """One fused device iteration; returns the 32-double reduction record."""
+        self._ensure()
+        T = np.eye(4, dtype=np.float32) if T_prev is None else np.ascontiguousarray(T_prev, np.float32)
+        sums = np.zeros(_lib.NSUMS, np.float64)
+        md = self.p.max_correspondence_distance if max_dist is None else float(max_dist)
+        check(self.lib.pclhip_icp_iterate(self.h, _fp(T.reshape(16)), md, self.MODE,
+                                          sums.ctypes.data_as(C.POINTER(C.c_double))), self.ctx.h)
+        return sums
+
+    def reset(self):
+        self._ensure()
+        check(self.lib.pclhip_icp_reset(self.h), self.ctx.h)
+
+    def solve(self, sums):
+        T = np.zeros(16, np.float32)
+        s = np.ascontiguousarray(sums, np.float64)
+        check(self.lib.pclhip_solve_transformation(s.ctypes.data_as(C.POINTER(C.c_double)), self.MODE,
+                                                   _fp(T)))
+        return T.reshape(4, 4)
+
+    def fetchCorrespondences(self):
+        n = _cloud(self.src)[2]
+        q = np.empty(n, np.int32)
+        m = np.empty(n, np.int32)
+        d = np.empty(n, np.float32)
+        cnt = C.c_uint64(0)
+        check(self.lib.pclhip_icp_fetch_correspondences(
+            self.h, C.c_void_p(q.ctypes.data), C.c_void_p(m.ctypes.data), C.c_void_p(d.ctypes.data),
+            C.byref(cnt)), self.ctx.h)
+        c = int(cnt.value)
+        return q[:c].copy(), m[:c].copy(), d[:c].copy()
+
+    def align(self, guess=None, want_output=False):
+        """Registration::align (registration.hpp:170-221).  Returns the registered source when
+        want_output, else None; results via getFinalTransformation()/hasConverged()."""
+        self._ensure()
+        r = IcpResult()
+        g = None
+        if guess is not None:
+            g = np.ascontiguousarray(guess, np.float32).reshape(16)
+        check(self.lib.pclhip_icp_align(self.h, C.byref(self.p), _fp(g) if g is not None else None,
+                                        C.byref(r)), self.ctx.h)
+        self.result = r
+        if want_output:
+            return self.transformCloud(self.src, self.getFinalTransformation())
+        return None
+
+    def transformCloud(self, cloud, T):
+        ptr, stride, n, keep = _cloud(cloud)
+        Tm = np.ascontiguousarray(T, np.float32).reshape(16)
+        if _is_torch(cloud):
+            out = keep.clone()
+            optr = C.c_void_p(out.data_ptr())
+        else:
+            out = keep.copy()
+            optr = C.c_void_p(out.ctypes.data)
+        check(self.lib.pclhip_transform_cloud(self.ctx.h, _fp(Tm), self.ORDER, ptr, optr, stride, n, 0),
+              self.ctx.h)
+        return out
+
+    def getFinalTransformation(self):
+        return np.array(self.result.final_transformation, np.float32).reshape(4, 4)
+
+    def getLastIncrementalTransformation(self):
+        return np.array(self.result.last_transformation, np.float32).reshape(4, 4)
+
+    def hasConverged(self):
+        return bool(self.result.converged)
+
+    def getConvergenceState(self):
+        return _lib.CONVERGENCE_STATES[self.result.convergence_state]
+
+    @property
+    def nr_iterations_(self):
+        return int(self.result.nr_iterations)
+
+    def __del__(self):
+        try:
+            self._drop_icp()
+        except Exception:
+            pass
+
+
+class IterativeClosestPointWithNormals(IterativeClosestPoint):
+    """pcl::IterativeClosestPointWithNormals<PointNormal, PointNormal>
+    (TransformationEstimationPointToPlaneLLS, icp.h:395-398).  Target normals come either from
+    setInputTarget(cloud with >= 7 columns: x,y,z,_,nx,ny,nz) or from setTargetNormals()/a
+    NormalEstimation run on the same KdTree."""
+    MODE = POINT_TO_PLANE
+    ORDER = 1
+
+    def setInputTarget(self, cloud):
+        super().setInputTarget(cloud)
+        ncol = cloud.shape[1]
+        if ncol >= 7:  # pcl::PointNormal layout: normal at floats 4..6 (point_types.hpp:843-853)
+            self.tree.setNormals(cloud[:, 4:7])
+
+    def setTargetNormals(self, normals):
+        self.tree.setNormals(normals)
+
+
+class VoxelGrid:
+    """pcl::VoxelGrid<pcl::PointXYZ> (downsample_all_data, optional z limits)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+        self.lib = self.ctx.lib
+        self.leaf = np.zeros(3, np.float32)
+        self.min_pts = 0
+        self.limits = None
+        self.cloud = None
+
+    def setInputCloud(self, cloud):
+        self.cloud = cloud
+
+    def setLeafSize(self, lx, ly=None, lz=None):
+        self.leaf = np.asarray([lx, lx if ly is None else ly, lx if lz is None else lz], np.float32)
+
+    def setMinimumPointsNumberPerVoxel(self, n):
+        self.min_pts = int(n)
+
+    def setFilterFieldName(self, name):
+        assert name == "z", "only the z field is supported on the accelerated path"
+
+    def setFilterLimits(self, lo, hi):
+        self.limits = (float(lo), float(hi))
+
+    def filter(self):
+        ptr, stride, n, keep = _cloud(self.cloud)
+        cnt = C.c_uint64(0)
+        has = self.limits is not None
+        lo, hi = self.limits if has else (0.0, 0.0)
+        if _is_torch(self.cloud):
+            import torch
+            out = torch.empty((max(n, 1), 4), dtype=torch.float32, device=self.cloud.device)
+            optr = C.c_void_p(out.data_ptr())
+        else:
+            out = np.empty((max(n, 1), 4), np.float32)
+            optr = C.c_void_p(out.ctypes.data)
+        check(self.lib.pclhip_voxelgrid(self.ctx.h, ptr, stride, n, _fp(self.leaf), self.min_pts, int(has),
+                                        lo, hi, optr, C.byref(cnt)), self.ctx.h)
+        return out[:int(cnt.value)]

@@ -1,0 +1,761 @@
+// api.hip -- the C ABI (include/pclhip.h) over the HIP kernels, plus the host ICP loop.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "pclhip_internal.hpp"
+
+using namespace pclhip;
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+namespace pclhip {
+
+void set_error(pclhip_ctx* ctx, const std::string& msg) {
+  g_last_error = msg;
+  if (ctx) ctx->last_error = msg;
+}
+
+bool is_device_pointer(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // unregistered host memory: clear the sticky error
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+pclhip_status to_device(pclhip_ctx* ctx, const void* p, size_t bytes, const void** dev, void** owned) {
+  *owned = nullptr;
+  *dev = nullptr;
+  if (bytes == 0 || p == nullptr) return PCLHIP_OK;
+  if (is_device_pointer(p)) {
+    *dev = p;
+    return PCLHIP_OK;
+  }
+  void* d = nullptr;
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&d, bytes));
+  hipError_t e = hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    PCLHIP_CHECK_HIP(ctx, e);
+  }
+  *owned = d;
+  *dev = d;
+  return PCLHIP_OK;
+}
+
+pclhip_status ensure_scratch(pclhip_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_bytes) return PCLHIP_OK;
+  if (ctx->scratch) {
+    PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->scratch);
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+  }
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&ctx->scratch, bytes));
+  ctx->scratch_bytes = bytes;
+  return PCLHIP_OK;
+}
+
+namespace {
+
+struct DeviceGuard {  // frees staged copies on scope exit (after the stream has been synchronised)
+  std::vector<void*> ptrs;
+  ~DeviceGuard() {
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+  }
+  void add(void* p) { ptrs.push_back(p); }
+};
+
+// write `bytes_per_rec` bytes per record from a dense device array to a strided user buffer
+pclhip_status copy_out_strided(pclhip_ctx* ctx, void* user, size_t stride, const void* dev_dense, size_t rec_bytes,
+                               uint64_t n) {
+  if (n == 0) return PCLHIP_OK;
+  const hipMemcpyKind kind = is_device_pointer(user) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  PCLHIP_CHECK_HIP(ctx, hipMemcpy2DAsync(user, stride, dev_dense, rec_bytes, rec_bytes, n, kind, ctx->stream));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLHIP_OK;
+}
+
+__global__ void scatter_normals_kernel(const float4* __restrict__ nrm_sorted, const uint32_t* __restrict__ rank,
+                                       uint64_t n_orig, float4* __restrict__ out) {
+  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  if (i >= n_orig) return;
+  const uint32_t r = rank[i];
+  const float qn = __builtin_nanf("");
+  out[i] = (r == NO_INDEX) ? make_float4(qn, qn, qn, qn) : nrm_sorted[r];
+}
+
+__global__ void gather_normals_kernel(const void* normals, size_t stride, const float4* __restrict__ pts_sorted,
+                                      uint32_t n, uint32_t n_pad, float4* __restrict__ nrm_sorted) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_pad) return;
+  const float qn = __builtin_nanf("");
+  if (j < n) {
+    const uint32_t rec = __float_as_uint(pts_sorted[j].w);
+    const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(normals) + size_t(rec) * stride);
+    nrm_sorted[j] = make_float4(p[0], p[1], p[2], 0.0f);
+  } else {
+    nrm_sorted[j] = make_float4(qn, qn, qn, qn);
+  }
+}
+
+struct Mat44 {
+  float m[16];
+};
+
+__global__ void transform_cloud_kernel(Mat44 T, int order, const void* in, void* out, size_t stride, uint64_t n,
+                                       size_t nrm_off) {
+  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(in) + i * stride);
+  float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + i * stride);
+  const float x = p[0], y = p[1], z = p[2];
+  if (!(isfinite(x) && isfinite(y) && isfinite(z))) return;
+  float r[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float* row = T.m + 4 * k;
+    if (order == 0)
+      r[k] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(row[0], x), __fmul_rn(row[1], y)), __fmul_rn(row[2], z)),
+                       __fmul_rn(row[3], 1.0f));
+    else
+      r[k] = __fadd_rn(__fmul_rn(row[0], x), __fadd_rn(__fmul_rn(row[1], y), __fadd_rn(__fmul_rn(row[2], z), row[3])));
+  }
+  o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
+  if (nrm_off) {
+    const float* np = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + nrm_off);
+    float* no = reinterpret_cast<float*>(reinterpret_cast<char*>(o) + nrm_off);
+    const float a = np[0], b = np[1], c = np[2];
+    if (order == 0 && !(isfinite(a) && isfinite(b) && isfinite(c))) return;
+    float s[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float* row = T.m + 4 * k;
+      if (order == 0)
+        s[k] = __fadd_rn(__fadd_rn(__fmul_rn(row[0], a), __fmul_rn(row[1], b)), __fmul_rn(row[2], c));
+      else
+        s[k] = __fadd_rn(__fmul_rn(row[0], a), __fadd_rn(__fmul_rn(row[1], b), __fmul_rn(row[2], c)));
+    }
+    no[0] = s[0]; no[1] = s[1]; no[2] = s[2];
+  }
+}
+
+// dense per-original-source arrays of the last iteration's matches
+__global__ void scatter_matches_kernel(const float4* __restrict__ cur, const uint32_t* __restrict__ match,
+                                       const float* __restrict__ d2, uint32_t n, int32_t* __restrict__ out_m,
+                                       float* __restrict__ out_d) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t oq = __float_as_uint(cur[i].w);
+  const uint32_t m = match[i];
+  out_m[oq] = (m == NO_INDEX) ? -1 : int32_t(m);
+  out_d[oq] = d2[i];
+}
+
+float float_at_most(double v) {  // largest float <= v  (v >= 0)
+  if (!(v < double(FLT_MAX))) return FLT_MAX;
+  float f = float(v);
+  if (double(f) > v) f = std::nextafterf(f, 0.0f);
+  return f;
+}
+
+}  // namespace
+}  // namespace pclhip
+
+extern "C" {
+
+const char* pclhip_version(void) { return "pclhip 0.1 (gfx950)"; }
+
+const char* pclhip_last_error(const pclhip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
+
+pclhip_status pclhip_ctx_create(int device, void* stream, pclhip_ctx** out) {
+  if (!out) return PCLHIP_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    set_error(nullptr, "no HIP device visible");
+    return PCLHIP_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= count) {
+    set_error(nullptr, "device ordinal out of range");
+    return PCLHIP_ERR_INVALID;
+  }
+  pclhip_ctx* ctx = new pclhip_ctx();
+  ctx->device = device;
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(device));
+  hipDeviceProp_t prop;
+  PCLHIP_CHECK_HIP(ctx, hipGetDeviceProperties(&prop, device));
+  ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (stream) {
+    ctx->stream = static_cast<hipStream_t>(stream);
+  } else {
+    PCLHIP_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  *out = ctx;
+  return PCLHIP_OK;
+}
+
+void pclhip_ctx_destroy(pclhip_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->staging) (void)hipFree(ctx->staging);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+pclhip_status pclhip_ctx_synchronize(pclhip_ctx* ctx) {
+  if (!ctx) return PCLHIP_ERR_INVALID;
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+pclhip_status pclhip_index_build(pclhip_ctx* ctx, const void* points, size_t stride, uint64_t n,
+                                 const int32_t* indices, uint64_t n_indices, pclhip_index** out) {
+  if (!ctx || !out) return PCLHIP_ERR_INVALID;
+  *out = nullptr;
+  PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
+  PCLHIP_REQUIRE(ctx, n < 0x7FFFFFFFull, "cloud too large for int32 indices");
+  PCLHIP_REQUIRE(ctx, n == 0 || points != nullptr, "null point buffer");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard;
+  const void* dpts = nullptr;
+  void* owned = nullptr;
+  pclhip_status st = to_device(ctx, points, size_t(n) * stride, &dpts, &owned);
+  if (st != PCLHIP_OK) return st;
+  guard.add(owned);
+  const void* dsel = nullptr;
+  if (indices) {
+    st = to_device(ctx, indices, size_t(n_indices) * sizeof(int32_t), &dsel, &owned);
+    if (st != PCLHIP_OK) return st;
+    guard.add(owned);
+  }
+  const uint64_t m = indices ? n_indices : n;
+  pclhip_index* ix = new pclhip_index();
+  ix->ctx = ctx;
+  ix->n_orig = n;
+  hipEvent_t e0, e1;
+  PCLHIP_CHECK_HIP(ctx, hipEventCreate(&e0));
+  PCLHIP_CHECK_HIP(ctx, hipEventCreate(&e1));
+  (void)hipEventRecord(e0, ctx->stream);
+  const uint32_t cap = uint32_t(((m + LEAF - 1) / LEAF) * LEAF) + LEAF;
+  auto fail = [&](pclhip_status s) {
+    pclhip_index_destroy(ix);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return s;
+  };
+  if (hipMalloc(&ix->pts, size_t(cap) * sizeof(float4)) != hipSuccess ||
+      hipMalloc(&ix->rank, size_t(n > 0 ? n : 1) * sizeof(uint32_t)) != hipSuccess) {
+    set_error(ctx, "hipMalloc failed for the index");
+    return fail(PCLHIP_ERR_HIP);
+  }
+  uint32_t nf = 0;
+  st = morton_order(ctx, dpts, stride, n, static_cast<const int32_t*>(dsel), n_indices, ix->pts, cap, &nf, ix->bbox_lo,
+                    ix->bbox_hi, false, ix->rank);
+  if (st != PCLHIP_OK) return fail(st);
+  ix->n = nf;
+  ix->n_pad = ((nf + LEAF - 1) / LEAF) * LEAF;
+  if (ix->n_pad == 0) ix->n_pad = LEAF;
+  st = build_boxes(ix);
+  if (st != PCLHIP_OK) return fail(st);
+  (void)hipEventRecord(e1, ctx->stream);
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  ix->build_ms = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *out = ix;
+  return PCLHIP_OK;
+}
+
+void pclhip_index_destroy(pclhip_index* ix) {
+  if (!ix) return;
+  if (ix->ctx) {
+    (void)hipSetDevice(ix->ctx->device);
+    (void)hipStreamSynchronize(ix->ctx->stream);
+  }
+  if (ix->pts) (void)hipFree(ix->pts);
+  if (ix->nrm) (void)hipFree(ix->nrm);
+  if (ix->rank) (void)hipFree(ix->rank);
+  for (int l = 0; l < MAX_LEVELS; ++l)
+    if (ix->box[l]) (void)hipFree(ix->box[l]);
+  delete ix;
+}
+
+uint64_t pclhip_index_size(const pclhip_index* ix) { return ix ? ix->n : 0; }
+double pclhip_index_build_ms(const pclhip_index* ix) { return ix ? ix->build_ms : 0.0; }
+
+pclhip_status pclhip_knn(pclhip_index* ix, const void* queries, size_t stride, uint64_t nq, int k, int32_t* out_idx,
+                         float* out_d2) {
+  if (!ix) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = ix->ctx;
+  PCLHIP_REQUIRE(ctx, k >= 1, "k must be >= 1");
+  PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
+  PCLHIP_REQUIRE(ctx, nq < 0x7FFFFFFFull, "too many queries");
+  if (nq == 0) return PCLHIP_OK;
+  PCLHIP_REQUIRE(ctx, queries && out_idx && out_d2, "null buffer");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard;
+  const void* dq = nullptr;
+  void* owned = nullptr;
+  pclhip_status st = to_device(ctx, queries, size_t(nq) * stride, &dq, &owned);
+  if (st != PCLHIP_OK) return st;
+  guard.add(owned);
+  float4* qs = nullptr;
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&qs, size_t(nq) * sizeof(float4)));
+  guard.add(qs);
+  uint32_t nf = 0;
+  float lo[3], hi[3];
+  st = morton_order(ctx, dq, stride, nq, nullptr, 0, qs, uint32_t(nq), &nf, lo, hi, true, nullptr);
+  if (st != PCLHIP_OK) return st;
+  const size_t cnt = size_t(nq) * size_t(k);
+  int32_t* d_idx = out_idx;
+  float* d_d2 = out_d2;
+  const bool idx_dev = is_device_pointer(out_idx), d2_dev = is_device_pointer(out_d2);
+  if (!idx_dev) {
+    PCLHIP_CHECK_HIP(ctx, hipMalloc(&d_idx, cnt * sizeof(int32_t)));
+    guard.add(d_idx);
+  }
+  if (!d2_dev) {
+    PCLHIP_CHECK_HIP(ctx, hipMalloc(&d_d2, cnt * sizeof(float)));
+    guard.add(d_d2);
+  }
+  st = launch_knn(ix, qs, uint32_t(nq), k, d_idx, d_d2);
+  if (st != PCLHIP_OK) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return st;
+  }
+  if (!idx_dev)
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out_idx, d_idx, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (!d2_dev)
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out_d2, d_d2, cnt * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_normals(pclhip_index* ix, int k, const float viewpoint[3], void* out, size_t out_stride,
+                             uint64_t* out_nan_count) {
+  if (!ix) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = ix->ctx;
+  PCLHIP_REQUIRE(ctx, k >= 1, "k must be >= 1");
+  PCLHIP_REQUIRE(ctx, !out || (out_stride >= 16 && out_stride % 4 == 0), "out stride must be >= 16 bytes");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  const float zero[3] = {0, 0, 0};
+  const float* vp = viewpoint ? viewpoint : zero;
+  uint64_t nan = 0;
+  pclhip_status st = launch_normals(ix, k, vp, &nan);
+  if (st != PCLHIP_OK) return st;
+  // points that were dropped from the index have NaN normals as well
+  if (out_nan_count) *out_nan_count = nan + (ix->n_orig - ix->n);
+  if (out && ix->n_orig > 0) {
+    float4* dense = nullptr;
+    PCLHIP_CHECK_HIP(ctx, hipMalloc(&dense, size_t(ix->n_orig) * sizeof(float4)));
+    DeviceGuard guard;
+    guard.add(dense);
+    hipLaunchKernelGGL(scatter_normals_kernel, dim3(unsigned((ix->n_orig + 255) / 256)), dim3(256), 0, ctx->stream,
+                       ix->nrm, ix->rank, ix->n_orig, dense);
+    PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+    st = copy_out_strided(ctx, out, out_stride, dense, sizeof(float4), ix->n_orig);
+    if (st != PCLHIP_OK) return st;
+  }
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_index_set_normals(pclhip_index* ix, const void* normals, size_t stride) {
+  if (!ix) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = ix->ctx;
+  PCLHIP_REQUIRE(ctx, normals != nullptr || ix->n_orig == 0, "null normals");
+  PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard;
+  const void* dn = nullptr;
+  void* owned = nullptr;
+  pclhip_status st = to_device(ctx, normals, size_t(ix->n_orig) * stride, &dn, &owned);
+  if (st != PCLHIP_OK) return st;
+  guard.add(owned);
+  if (!ix->nrm) PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->nrm, size_t(ix->n_pad) * sizeof(float4)));
+  hipLaunchKernelGGL(gather_normals_kernel, dim3((ix->n_pad + 255) / 256), dim3(256), 0, ctx->stream, dn, stride,
+                     ix->pts, ix->n, ix->n_pad, ix->nrm);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ix->has_normals = true;
+  return PCLHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+void pclhip_icp_params_default(pclhip_icp_params* p) {
+  if (!p) return;
+  p->max_iterations = 10;
+  p->max_correspondence_distance = std::sqrt(DBL_MAX);
+  p->transformation_epsilon = 0.0;
+  p->transformation_rotation_epsilon = 0.0;
+  p->euclidean_fitness_epsilon = -DBL_MAX;
+  p->min_number_correspondences = 3;
+  p->mode = PCLHIP_ICP_POINT_TO_POINT;
+  p->failure_after_max_iterations = 0;
+  p->max_iterations_similar_transforms = 0;
+  p->mse_threshold_absolute = 1e-12;
+}
+
+pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out) {
+  if (!target || !out) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = target->ctx;
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  pclhip_icp* icp = new pclhip_icp();
+  icp->ctx = ctx;
+  icp->target = target;
+  icp->prev_mse = DBL_MAX;
+  if (hipMalloc(&icp->sums_dev, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
+      hipHostMalloc(&icp->sums_host, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
+      hipEventCreate(&icp->ev0) != hipSuccess || hipEventCreate(&icp->ev1) != hipSuccess) {
+    set_error(ctx, "allocation failed in pclhip_icp_create");
+    pclhip_icp_destroy(icp);
+    return PCLHIP_ERR_HIP;
+  }
+  *out = icp;
+  return PCLHIP_OK;
+}
+
+static void icp_free_source(pclhip_icp* icp) {
+  if (icp->src_sorted0) (void)hipFree(icp->src_sorted0);
+  if (icp->src_cur) (void)hipFree(icp->src_cur);
+  if (icp->match) (void)hipFree(icp->match);
+  if (icp->match_d2) (void)hipFree(icp->match_d2);
+  if (icp->partials) (void)hipFree(icp->partials);
+  icp->src_sorted0 = icp->src_cur = nullptr;
+  icp->match = nullptr;
+  icp->match_d2 = nullptr;
+  icp->partials = nullptr;
+}
+
+void pclhip_icp_destroy(pclhip_icp* icp) {
+  if (!icp) return;
+  if (icp->ctx) {
+    (void)hipSetDevice(icp->ctx->device);
+    (void)hipStreamSynchronize(icp->ctx->stream);
+  }
+  icp_free_source(icp);
+  if (icp->sums_dev) (void)hipFree(icp->sums_dev);
+  if (icp->sums_host) (void)hipHostFree(icp->sums_host);
+  if (icp->ev0) (void)hipEventDestroy(icp->ev0);
+  if (icp->ev1) (void)hipEventDestroy(icp->ev1);
+  delete icp;
+}
+
+pclhip_status pclhip_icp_set_source(pclhip_icp* icp, const void* points, size_t stride, uint64_t n) {
+  if (!icp) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = icp->ctx;
+  PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
+  PCLHIP_REQUIRE(ctx, n < 0x7FFFFFFFull, "cloud too large for int32 indices");
+  PCLHIP_REQUIRE(ctx, n == 0 || points != nullptr, "null point buffer");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  icp_free_source(icp);
+  DeviceGuard guard;
+  const void* dp = nullptr;
+  void* owned = nullptr;
+  pclhip_status st = to_device(ctx, points, size_t(n) * stride, &dp, &owned);
+  if (st != PCLHIP_OK) return st;
+  guard.add(owned);
+  icp->n_orig = n;
+  icp->n = uint32_t(n);
+  const size_t cap = n > 0 ? n : 1;
+  icp->grid_blocks = icp_grid_blocks(ctx, icp->n);
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->src_sorted0, cap * sizeof(float4)));
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->src_cur, cap * sizeof(float4)));
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->match, cap * sizeof(uint32_t)));
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->match_d2, cap * sizeof(float)));
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->partials, size_t(icp->grid_blocks) * PCLHIP_ICP_NSUMS * sizeof(double)));
+  uint32_t nf = 0;
+  float lo[3], hi[3];
+  st = morton_order(ctx, dp, stride, n, nullptr, 0, icp->src_sorted0, uint32_t(n), &nf, lo, hi, true, nullptr);
+  if (st != PCLHIP_OK) return st;
+  return pclhip_icp_reset(icp);
+}
+
+pclhip_status pclhip_icp_set_allreduce(pclhip_icp* icp, pclhip_allreduce_fn fn, void* user) {
+  if (!icp) return PCLHIP_ERR_INVALID;
+  icp->allreduce = fn;
+  icp->allreduce_user = user;
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_icp_reset(pclhip_icp* icp) {
+  if (!icp) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = icp->ctx;
+  if (icp->n > 0)
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(icp->src_cur, icp->src_sorted0, size_t(icp->n) * sizeof(float4),
+                                         hipMemcpyDeviceToDevice, ctx->stream));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[16], double max_dist, int mode, double* sums) {
+  if (!icp || !T_prev || !sums) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = icp->ctx;
+  PCLHIP_REQUIRE(ctx, mode == PCLHIP_ICP_POINT_TO_POINT || mode == PCLHIP_ICP_POINT_TO_PLANE, "bad mode");
+  if (mode == PCLHIP_ICP_POINT_TO_PLANE && !icp->target->has_normals) {
+    set_error(ctx, "point-to-plane ICP needs target normals (pclhip_normals / pclhip_index_set_normals)");
+    return PCLHIP_ERR_STATE;
+  }
+  PCLHIP_REQUIRE(ctx, icp->src_cur != nullptr, "no source cloud set");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  // correspondence_estimation.hpp:161,176: drop if double(d2) > max_dist*max_dist
+  const double md2 = max_dist * max_dist;
+  const bool use_max = md2 < double(FLT_MAX);
+  const float fmax2 = use_max ? float_at_most(md2) : FLT_MAX;
+  pclhip_status st = launch_icp_iterate(icp, T_prev, fmax2, use_max, mode);
+  if (st != PCLHIP_OK) return st;
+  if (icp->allreduce) {
+    const int rc = icp->allreduce(icp->allreduce_user, icp->sums_dev, PCLHIP_ICP_NSUMS, ctx->stream);
+    if (rc != 0) {
+      set_error(ctx, "all-reduce hook failed");
+      return PCLHIP_ERR_STATE;
+    }
+  }
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(icp->sums_host, icp->sums_dev, PCLHIP_ICP_NSUMS * sizeof(double),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::memcpy(sums, icp->sums_host, PCLHIP_ICP_NSUMS * sizeof(double));
+  float ms = 0;
+  if (icp->n > 0 && hipEventElapsedTime(&ms, icp->ev0, icp->ev1) == hipSuccess) icp->last_kernel_ms = ms;
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_solve_transformation(const double* sums, int mode, float* T) {
+  if (!sums || !T) return PCLHIP_ERR_INVALID;
+  if (mode == PCLHIP_ICP_POINT_TO_PLANE)
+    solve_point_to_plane(sums, T);
+  else
+    solve_point_to_point(sums, T);
+  return PCLHIP_OK;
+}
+
+// IterativeClosestPoint::computeTransformation, registration/include/pcl/registration/impl/icp.hpp:113-268
+// with DefaultConvergenceCriteria::hasConverged, impl/default_convergence_criteria.hpp:49-140.
+pclhip_status pclhip_icp_align(pclhip_icp* icp, const pclhip_icp_params* params, const float* guess,
+                               pclhip_icp_result* res) {
+  if (!icp || !params || !res) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = icp->ctx;
+  static const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  std::memset(res, 0, sizeof *res);
+  pclhip_status st = pclhip_icp_reset(icp);
+  if (st != PCLHIP_OK) return st;
+  hipEvent_t t0, t1;
+  PCLHIP_CHECK_HIP(ctx, hipEventCreate(&t0));
+  PCLHIP_CHECK_HIP(ctx, hipEventCreate(&t1));
+  (void)hipEventRecord(t0, ctx->stream);
+
+  float final_T[16], Tk[16], T_apply[16];
+  std::memcpy(final_T, guess ? guess : I4, sizeof final_T);  // :123
+  std::memcpy(T_apply, guess ? guess : I4, sizeof T_apply);  // :126-131 applied by the first launch
+  std::memcpy(Tk, I4, sizeof Tk);
+  // :157-161 criteria setup (rotation threshold default 0.99999, default_convergence_criteria.h:298)
+  const int max_iterations = params->max_iterations;
+  const double mse_rel = params->euclidean_fitness_epsilon;
+  const double trans_thr = params->transformation_epsilon;
+  const double rot_thr = params->transformation_rotation_epsilon > 0 ? params->transformation_rotation_epsilon : 0.99999;
+  const double mse_abs = params->mse_threshold_absolute;
+  const int max_similar = params->max_iterations_similar_transforms;
+
+  int nr_iterations = 0;
+  bool converged = false;
+  double sums[PCLHIP_ICP_NSUMS];
+  double kernel_ms = 0;
+  enum { NOT_CONVERGED = 0, ITERATIONS, TRANSFORM, ABS_MSE, REL_MSE, NO_CORRESPONDENCES, FAILURE_AFTER_MAX_ITERATIONS };
+  do {
+    st = pclhip_icp_iterate(icp, T_apply, params->max_correspondence_distance, params->mode, sums);
+    if (st != PCLHIP_OK) break;
+    kernel_ms += icp->last_kernel_ms;
+    const double ncorr = sums[28];
+    res->num_correspondences = uint64_t(ncorr);
+    if (ncorr < double(params->min_number_correspondences)) {  // :204-213
+      icp->convergence_state = NO_CORRESPONDENCES;
+      converged = false;
+      break;
+    }
+    pclhip_solve_transformation(sums, params->mode, Tk);  // :216-217
+    std::memcpy(T_apply, Tk, sizeof T_apply);              // :220 (applied by the next launch)
+    mat4_mul_f32(Tk, final_T, final_T);                    // :223
+    ++nr_iterations;
+    const double mse = sums[27] / ncorr;  // calculateMSE, default_convergence_criteria.h:262-270
+    res->mse = mse;
+
+    // ---- hasConverged ----
+    if (icp->convergence_state != NOT_CONVERGED) {
+      icp->iterations_similar_transforms = 0;
+      icp->convergence_state = NOT_CONVERGED;
+    }
+    bool is_similar = false;
+    bool done = false;
+    if (nr_iterations >= max_iterations) {
+      if (!params->failure_after_max_iterations) {
+        icp->convergence_state = ITERATIONS;
+        converged = true;
+        done = true;
+      } else {
+        icp->convergence_state = FAILURE_AFTER_MAX_ITERATIONS;
+      }
+    }
+    if (!done) {
+      const double cos_angle = 0.5 * double(Tk[0] + Tk[5] + Tk[10] - 1);
+      const double translation_sqr = double(Tk[3] * Tk[3] + Tk[7] * Tk[7] + Tk[11] * Tk[11]);
+      if (cos_angle >= rot_thr && translation_sqr <= trans_thr) {
+        if (icp->iterations_similar_transforms >= max_similar) {
+          icp->convergence_state = TRANSFORM;
+          converged = true;
+          done = true;
+        }
+        is_similar = true;
+      }
+    }
+    if (!done) {
+      if (std::fabs(mse - icp->prev_mse) < mse_abs) {
+        if (icp->iterations_similar_transforms >= max_similar) {
+          icp->convergence_state = ABS_MSE;
+          converged = true;
+          done = true;
+        }
+        is_similar = true;
+      }
+    }
+    if (!done) {
+      if (std::fabs(mse - icp->prev_mse) / icp->prev_mse < mse_rel) {
+        if (icp->iterations_similar_transforms >= max_similar) {
+          icp->convergence_state = REL_MSE;
+          converged = true;
+          done = true;
+        }
+        is_similar = true;
+      }
+    }
+    if (!done) {
+      if (is_similar)
+        ++icp->iterations_similar_transforms;
+      else
+        icp->iterations_similar_transforms = 0;
+      icp->prev_mse = mse;
+      converged = false;
+    }
+  } while (icp->convergence_state == NOT_CONVERGED);
+  (void)hipEventRecord(t1, ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, t0, t1);
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  if (st != PCLHIP_OK) return st;
+  std::memcpy(res->final_transformation, final_T, sizeof final_T);
+  std::memcpy(res->last_transformation, Tk, sizeof Tk);
+  res->nr_iterations = nr_iterations;
+  res->converged = converged ? 1 : 0;
+  res->convergence_state = icp->convergence_state;
+  res->gpu_ms = ms;
+  res->gpu_ms_search_kernel = kernel_ms;
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_query, int32_t* index_match,
+                                               float* distance, uint64_t* out_n) {
+  if (!icp || !out_n) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = icp->ctx;
+  *out_n = 0;
+  if (icp->n == 0) return PCLHIP_OK;
+  PCLHIP_REQUIRE(ctx, index_query && index_match && distance, "null buffer");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  int32_t* dm = nullptr;
+  float* dd = nullptr;
+  DeviceGuard guard;
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&dm, size_t(icp->n) * sizeof(int32_t)));
+  guard.add(dm);
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&dd, size_t(icp->n) * sizeof(float)));
+  guard.add(dd);
+  hipLaunchKernelGGL(scatter_matches_kernel, dim3((icp->n + 255) / 256), dim3(256), 0, ctx->stream, icp->src_cur,
+                     icp->match, icp->match_d2, icp->n, dm, dd);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  std::vector<int32_t> hm(icp->n);
+  std::vector<float> hd(icp->n);
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(hm.data(), dm, size_t(icp->n) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(hd.data(), dd, size_t(icp->n) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<int32_t> q, m;
+  std::vector<float> d;
+  q.reserve(icp->n);
+  m.reserve(icp->n);
+  d.reserve(icp->n);
+  for (uint32_t i = 0; i < icp->n; ++i)
+    if (hm[i] >= 0) {
+      q.push_back(int32_t(i));
+      m.push_back(hm[i]);
+      d.push_back(hd[i]);
+    }
+  const size_t c = q.size();
+  auto put = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    if (bytes == 0) return hipSuccess;
+    if (is_device_pointer(dst)) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    std::memcpy(dst, src, bytes);
+    return hipSuccess;
+  };
+  PCLHIP_CHECK_HIP(ctx, put(index_query, q.data(), c * sizeof(int32_t)));
+  PCLHIP_CHECK_HIP(ctx, put(index_match, m.data(), c * sizeof(int32_t)));
+  PCLHIP_CHECK_HIP(ctx, put(distance, d.data(), c * sizeof(float)));
+  *out_n = c;
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_transform_cloud(pclhip_ctx* ctx, const float* T, int order, const void* in, void* out,
+                                     size_t stride, uint64_t n, size_t normals_offset_bytes) {
+  if (!ctx || !T) return PCLHIP_ERR_INVALID;
+  PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
+  PCLHIP_REQUIRE(ctx, normals_offset_bytes == 0 || normals_offset_bytes + 12 <= stride, "bad normals offset");
+  if (n == 0) return PCLHIP_OK;
+  PCLHIP_REQUIRE(ctx, in && out, "null buffer");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard;
+  const size_t bytes = size_t(n) * stride;
+  const void* din = nullptr;
+  void* owned = nullptr;
+  pclhip_status st = to_device(ctx, in, bytes, &din, &owned);
+  if (st != PCLHIP_OK) return st;
+  guard.add(owned);
+  void* dout = out;
+  const bool out_dev = is_device_pointer(out);
+  if (!out_dev) {
+    if (owned && in == out) {
+      dout = owned;  // in-place on the staged copy
+    } else {
+      PCLHIP_CHECK_HIP(ctx, hipMalloc(&dout, bytes));
+      guard.add(dout);
+      // other bytes of each record pass through unchanged
+      PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(dout, din, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  } else if (dout != din) {
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(dout, din, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  Mat44 M;
+  std::memcpy(M.m, T, sizeof M.m);
+  hipLaunchKernelGGL(transform_cloud_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, M, order, din,
+                     dout, stride, n, normals_offset_bytes);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  if (!out_dev) PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,323 @@
+// index_build.hip -- GPU construction of the Morton-ordered implicit wide BVH.
+//
+//   bbox reduce -> 63-bit Morton key (21 bits/axis, cubic cells) -> radix sort of (key, index)
+//   pairs -> gather to float4 (w = original index) -> leaf boxes (16 points) -> 64-ary box levels.
+//
+// Replaces the build half of pcl::KdTreeFLANN<PointT>::setInputCloud
+// (kdtree/include/pcl/kdtree/impl/kdtree_flann.hpp:99-136,428-498): non-finite points are
+// dropped, an optional index list selects a subset, results refer to original cloud indices.
+// The radix sort is rocprim::radix_sort_pairs (one-off per target cloud, not on the per-iteration
+// path); everything else is hand-written.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include <cfloat>
+
+#include "pclhip_internal.hpp"
+
+namespace pclhip {
+
+namespace {
+
+constexpr int BB_BLOCK = 256;
+constexpr int BB_MAX_BLOCKS = 1024;
+
+__device__ __forceinline__ const float* record(const void* base, size_t stride, uint64_t i) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + i * stride);
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// partial[b] = {lo.xyz, hi.xyz} over the finite selected records handled by block b
+__global__ __launch_bounds__(BB_BLOCK) void bbox_partial_kernel(const void* pts, size_t stride, const int32_t* sel,
+                                                                uint64_t m, float* partial) {
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < m; i += uint64_t(gridDim.x) * blockDim.x) {
+    const float* p = record(pts, stride, sel ? uint64_t(sel[i]) : i);
+    const float x = p[0], y = p[1], z = p[2];
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+      lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+      hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+    }
+  }
+  __shared__ float s[BB_BLOCK / 64][6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float a = wave_min(lo[d]), b = wave_max(hi[d]);
+    if (lane == 0) {
+      s[wave][d] = a;
+      s[wave][3 + d] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = s[0][threadIdx.x];
+    for (int w = 1; w < BB_BLOCK / 64; ++w) v = threadIdx.x < 3 ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
+    partial[blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+
+// bbox[0..5] = lo, hi ; bbox[6] = scale (cells per unit), bbox[7] unused
+__global__ void bbox_final_kernel(const float* partial, int nblocks, float* bbox) {
+  const int t = threadIdx.x;
+  if (t < 6) {
+    float v = partial[t];
+    for (int b = 1; b < nblocks; ++b) v = t < 3 ? fminf(v, partial[b * 6 + t]) : fmaxf(v, partial[b * 6 + t]);
+    bbox[t] = v;
+  }
+  __syncthreads();
+  if (t == 0) {
+    const float ex = fmaxf(fmaxf(bbox[3] - bbox[0], bbox[4] - bbox[1]), bbox[5] - bbox[2]);
+    bbox[6] = (ex > 0.0f && isfinite(ex)) ? (2097152.0f / ex) : 0.0f;  // 2^21 cells along the longest axis
+    bbox[7] = 0.0f;
+  }
+}
+
+__device__ __forceinline__ uint64_t spread3(uint32_t v) {  // 21 bits -> every third bit
+  uint64_t x = v & 0x1FFFFFu;
+  x = (x | x << 32) & 0x1F00000000FFFFull;
+  x = (x | x << 16) & 0x1F0000FF0000FFull;
+  x = (x | x << 8) & 0x100F00F00F00F00Full;
+  x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void morton_kernel(const void* pts, size_t stride, const int32_t* sel, uint64_t m,
+                                                     const float* bbox, uint64_t* keys, uint32_t* vals,
+                                                     unsigned int* n_finite) {
+  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  bool fin = false;
+  if (i < m) {
+    const uint64_t rec = sel ? uint64_t(sel[i]) : i;
+    const float* p = record(pts, stride, rec);
+    const float x = p[0], y = p[1], z = p[2];
+    uint64_t key = ~0ull;
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+      fin = true;
+      const float sc = bbox[6];
+      const float fx = (x - bbox[0]) * sc, fy = (y - bbox[1]) * sc, fz = (z - bbox[2]) * sc;
+      const uint32_t qx = uint32_t(fminf(fmaxf(fx, 0.0f), 2097151.0f));
+      const uint32_t qy = uint32_t(fminf(fmaxf(fy, 0.0f), 2097151.0f));
+      const uint32_t qz = uint32_t(fminf(fmaxf(fz, 0.0f), 2097151.0f));
+      key = spread3(qx) | (spread3(qy) << 1) | (spread3(qz) << 2);
+    }
+    keys[i] = key;
+    vals[i] = uint32_t(rec);
+  }
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(fin);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_finite, (unsigned int)__builtin_popcountll(b));
+}
+
+// sorted[j] = (xyz of record vals[j], bits(vals[j])); rank[vals[j]] = j for the finite ones
+__global__ __launch_bounds__(256) void gather_kernel(const void* pts, size_t stride, const uint32_t* vals, uint64_t m,
+                                                     const unsigned int* n_finite, float4* out, uint32_t out_cap,
+                                                     uint32_t* rank, int keep_nonfinite) {
+  const uint64_t j = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  if (j >= out_cap) return;
+  const uint32_t nf = *n_finite;
+  const uint64_t live = keep_nonfinite ? m : nf;
+  if (j < live) {
+    const uint32_t rec = vals[j];
+    const float* p = record(pts, stride, rec);
+    out[j] = make_float4(p[0], p[1], p[2], __uint_as_float(rec));
+    if (rank && j < nf) rank[rec] = uint32_t(j);
+  } else {
+    out[j] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(NO_INDEX));  // sentinel pad
+  }
+}
+
+// one 16-lane group per leaf
+__global__ __launch_bounds__(256) void leaf_box_kernel(const float4* pts, uint32_t n, uint32_t nleaf, Box* box) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t leaf = i / LEAF;
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if (i < n) {
+    const float4 p = pts[i];
+    lo[0] = hi[0] = p.x; lo[1] = hi[1] = p.y; lo[2] = hi[2] = p.z;
+  }
+#pragma unroll
+  for (int o = LEAF / 2; o > 0; o >>= 1) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
+      hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
+    }
+  }
+  if ((i % LEAF) == 0 && leaf < nleaf) {
+    Box b;
+    b.lo = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    b.hi = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    box[leaf] = b;
+  }
+}
+
+// one wavefront per parent node
+__global__ __launch_bounds__(256) void node_box_kernel(const Box* child, uint32_t nchild, Box* parent, uint32_t nparent) {
+  const uint32_t node = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const uint32_t lane = threadIdx.x & 63;
+  if (node >= nparent) return;
+  const uint32_t c = node * FANOUT + lane;
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if (c < nchild) {
+    const Box b = child[c];
+    lo[0] = b.lo.x; lo[1] = b.lo.y; lo[2] = b.lo.z;
+    hi[0] = b.hi.x; hi[1] = b.hi.y; hi[2] = b.hi.z;
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = wave_min(lo[d]);
+    hi[d] = wave_max(hi[d]);
+  }
+  if (lane == 0) {
+    Box b;
+    b.lo = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    b.hi = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    parent[node] = b;
+  }
+}
+
+}  // namespace
+
+pclhip_status morton_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
+                           const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
+                           uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
+                           uint32_t* rank_or_null) {
+  hipStream_t s = ctx->stream;
+  const uint64_t m = dev_sel ? n_sel : n_records;
+  if (m == 0) {
+    if (out_capacity) {
+      unsigned int zero = 0;
+      unsigned int* dz = nullptr;
+      PCLHIP_CHECK_HIP(ctx, hipMalloc(&dz, sizeof zero));
+      PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(dz, &zero, sizeof zero, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(gather_kernel, dim3((out_capacity + 255) / 256), dim3(256), 0, s, dev_points, stride,
+                         (const uint32_t*)nullptr, uint64_t(0), dz, out_sorted, out_capacity, (uint32_t*)nullptr, 0);
+      PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+      (void)hipFree(dz);
+    }
+    *out_n_finite = 0;
+    for (int d = 0; d < 3; ++d) lo[d] = hi[d] = 0;
+    return PCLHIP_OK;
+  }
+  // workspace: keys x2, vals x2, bbox partials, bbox, counter, rocprim temp
+  size_t temp_bytes = 0;
+  {
+    uint64_t* kn = nullptr;
+    uint32_t* vn = nullptr;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, temp_bytes, kn, kn, vn, vn, size_t(m), 0, 64, s);
+    PCLHIP_CHECK_HIP(ctx, e);
+  }
+  auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
+  const size_t off_k0 = 0;
+  const size_t off_k1 = off_k0 + align(m * sizeof(uint64_t));
+  const size_t off_v0 = off_k1 + align(m * sizeof(uint64_t));
+  const size_t off_v1 = off_v0 + align(m * sizeof(uint32_t));
+  const size_t off_pb = off_v1 + align(m * sizeof(uint32_t));
+  const size_t off_bb = off_pb + align(size_t(BB_MAX_BLOCKS) * 6 * sizeof(float));
+  const size_t off_cn = off_bb + align(8 * sizeof(float));
+  const size_t off_tmp = off_cn + align(sizeof(unsigned int));
+  const size_t total = off_tmp + align(temp_bytes);
+  pclhip_status st = ensure_scratch(ctx, total);
+  if (st != PCLHIP_OK) return st;
+  char* base = static_cast<char*>(ctx->scratch);
+  uint64_t* k0 = reinterpret_cast<uint64_t*>(base + off_k0);
+  uint64_t* k1 = reinterpret_cast<uint64_t*>(base + off_k1);
+  uint32_t* v0 = reinterpret_cast<uint32_t*>(base + off_v0);
+  uint32_t* v1 = reinterpret_cast<uint32_t*>(base + off_v1);
+  float* pb = reinterpret_cast<float*>(base + off_pb);
+  float* bb = reinterpret_cast<float*>(base + off_bb);
+  unsigned int* cn = reinterpret_cast<unsigned int*>(base + off_cn);
+  void* tmp = base + off_tmp;
+
+  int nb = int((m + BB_BLOCK * 8 - 1) / (BB_BLOCK * 8));
+  if (nb > BB_MAX_BLOCKS) nb = BB_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(BB_BLOCK), 0, s, dev_points, stride, dev_sel, m, pb);
+  hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, s, pb, nb, bb);
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(cn, 0, sizeof(unsigned int), s));
+  hipLaunchKernelGGL(morton_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride, dev_sel, m, bb,
+                     k0, v0, cn);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, temp_bytes, k0, k1, v0, v1, size_t(m), 0, 64, s));
+  if (rank_or_null) PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(rank_or_null, 0xFF, n_records * sizeof(uint32_t), s));
+  hipLaunchKernelGGL(gather_kernel, dim3((out_capacity + 255) / 256), dim3(256), 0, s, dev_points, stride, v1, m, cn,
+                     out_sorted, out_capacity, rank_or_null, keep_nonfinite_at_end ? 1 : 0);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  float hb[8];
+  unsigned int hn = 0;
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(hb, bb, sizeof hb, hipMemcpyDeviceToHost, s));
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&hn, cn, sizeof hn, hipMemcpyDeviceToHost, s));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  *out_n_finite = hn;
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = hb[d];
+    hi[d] = hb[3 + d];
+  }
+  return PCLHIP_OK;
+}
+
+pclhip_status build_boxes(pclhip_index* ix) {
+  pclhip_ctx* ctx = ix->ctx;
+  hipStream_t s = ctx->stream;
+  for (int l = 0; l < MAX_LEVELS; ++l) {
+    if (ix->box[l]) (void)hipFree(ix->box[l]);
+    ix->box[l] = nullptr;
+    ix->count[l] = 0;
+  }
+  ix->count[0] = ix->n;
+  uint32_t c = (ix->n + LEAF - 1) / LEAF;
+  if (c == 0) c = 1;  // an empty index still has one (empty) leaf so kernels stay uniform
+  int l = 1;
+  for (;;) {
+    if (l >= MAX_LEVELS) {
+      set_error(ctx, "index too large for MAX_LEVELS");
+      return PCLHIP_ERR_INVALID;
+    }
+    ix->count[l] = c;
+    PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->box[l], size_t(c) * sizeof(Box)));
+    if (l == 1) {
+      const uint32_t threads = c * LEAF;
+      hipLaunchKernelGGL(leaf_box_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c, ix->box[1]);
+    } else {
+      const uint64_t threads = uint64_t(c) * WAVE;
+      hipLaunchKernelGGL(node_box_kernel, dim3(unsigned((threads + 255) / 256)), dim3(256), 0, s, ix->box[l - 1],
+                         ix->count[l - 1], ix->box[l], c);
+    }
+    if (c <= uint32_t(FANOUT) && l >= 1) break;
+    c = (c + FANOUT - 1) / FANOUT;
+    ++l;
+  }
+  ix->top = l;
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  return PCLHIP_OK;
+}
+
+}  // namespace pclhip
+
+pclhip::IndexView pclhip_index::view() const {
+  pclhip::IndexView v;
+  v.pts = pts;
+  v.nrm = nrm;
+  for (int l = 0; l < pclhip::MAX_LEVELS; ++l) {
+    v.box[l] = box[l];
+    v.count[l] = count[l];
+  }
+  v.top = top;
+  v.n = n;
+  v.n_pad = n_pad;
+  return v;
+}

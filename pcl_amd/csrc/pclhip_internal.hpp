@@ -1,0 +1,150 @@
+// pclhip_internal.hpp -- shared host/device definitions of the MI355X ICP hot path.
+//
+// Data layout in HBM (one pclhip_index):
+//   pts   [n_pad]  float4   target points in 63-bit Morton order; .w = original index (bit cast).
+//                           n_pad = n rounded up to a whole leaf; pad slots hold +FLT_MAX
+//                           sentinels with index 0xFFFFFFFF (distance overflows to +inf).
+//   nrm   [n_pad]  float4   (nx,ny,nz,curvature) in the same order (optional).
+//   box[1][n1]     Box      tight AABB of every leaf = LEAF consecutive sorted points.
+//   box[l][n_l]    Box      AABB of FANOUT consecutive boxes of level l-1 (implicit wide BVH:
+//                           no pointers, child c of node i at level l is node i*FANOUT+c of l-1).
+//   rank  [n_orig] uint32   original index -> sorted position (0xFFFFFFFF for dropped points).
+// The top level has <= FANOUT boxes and is scanned by one wavefront (lane j <-> child j).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pclhip.h"
+
+namespace pclhip {
+
+constexpr int LEAF = 16;        // points per leaf (candidates broadcast through SGPRs)
+constexpr int FANOUT = 64;      // children per internal node = one per lane of a wavefront
+constexpr int MAX_LEVELS = 8;   // 16 * 64^7 points
+constexpr int WAVE = 64;
+constexpr uint32_t NO_INDEX = 0xFFFFFFFFu;
+
+struct Box {       // 32 B: two aligned float4 loads
+  float4 lo;       // xyz = min corner
+  float4 hi;       // xyz = max corner
+};
+
+// Device-visible view of an index (passed to kernels by value).
+struct IndexView {
+  const float4* pts;
+  const float4* nrm;
+  const Box* box[MAX_LEVELS];   // box[1] = leaves
+  uint32_t count[MAX_LEVELS];   // boxes per level
+  int top;                      // highest level (count[top] <= FANOUT)
+  uint32_t n;                   // finite points
+  uint32_t n_pad;
+};
+
+}  // namespace pclhip
+
+struct pclhip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string last_error;
+  int num_cus = 256;
+  // reusable scratch
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  void* staging = nullptr;  // device staging for host inputs
+  size_t staging_bytes = 0;
+};
+
+struct pclhip_index {
+  pclhip_ctx* ctx = nullptr;
+  uint64_t n_orig = 0;  // records in the user's cloud (index space of results)
+  uint32_t n = 0;       // finite, selected points
+  uint32_t n_pad = 0;
+  float4* pts = nullptr;
+  float4* nrm = nullptr;
+  uint32_t* rank = nullptr;
+  pclhip::Box* box[pclhip::MAX_LEVELS] = {};
+  uint32_t count[pclhip::MAX_LEVELS] = {};
+  int top = 0;
+  float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
+  double build_ms = 0;
+  bool has_normals = false;
+  pclhip::IndexView view() const;
+};
+
+struct pclhip_icp {
+  pclhip_ctx* ctx = nullptr;
+  pclhip_index* target = nullptr;
+  uint64_t n_orig = 0;       // source records
+  uint32_t n = 0;            // source points (all records; non-finite ones are flagged invalid)
+  float4* src_sorted0 = nullptr;   // Morton-ordered input (w = original index), pristine
+  float4* src_cur = nullptr;       // working copy (input_transformed)
+  uint32_t* match = nullptr;       // per sorted source slot: ORIGINAL target index or NO_INDEX
+  float* match_d2 = nullptr;
+  double* partials = nullptr;      // [blocks][NSUMS]
+  double* sums_dev = nullptr;      // [NSUMS]
+  double* sums_host = nullptr;     // pinned
+  int grid_blocks = 0;
+  pclhip_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  // DefaultConvergenceCriteria state that persists across align() calls
+  double prev_mse;
+  int iterations_similar_transforms = 0;
+  int convergence_state = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_kernel_ms = 0;
+};
+
+namespace pclhip {
+
+// ---- error plumbing -----------------------------------------------------------------------
+void set_error(pclhip_ctx* ctx, const std::string& msg);
+#define PCLHIP_CHECK_HIP(ctx, expr)                                                         \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      ::pclhip::set_error((ctx), std::string(#expr) + ": " + hipGetErrorString(e__));       \
+      return PCLHIP_ERR_HIP;                                                                \
+    }                                                                                       \
+  } while (0)
+#define PCLHIP_REQUIRE(ctx, cond, msg)                     \
+  do {                                                     \
+    if (!(cond)) {                                         \
+      ::pclhip::set_error((ctx), (msg));                   \
+      return PCLHIP_ERR_INVALID;                           \
+    }                                                      \
+  } while (0)
+
+// Resolve a user pointer: returns a device pointer valid on ctx->stream.  Host memory is staged
+// (async copy from pageable memory is synchronous w.r.t. the host, which is what we want).
+pclhip_status to_device(pclhip_ctx* ctx, const void* p, size_t bytes, const void** dev, void** owned);
+bool is_device_pointer(const void* p);
+pclhip_status ensure_scratch(pclhip_ctx* ctx, size_t bytes);
+
+// ---- build steps (index_build.hip) ----------------------------------------------------------
+// Sort `n` records (strided, device) into Morton order.  Outputs: sorted float4 (w = original
+// index), number of finite points, bbox.  `sel` optionally selects a subset (device int32).
+pclhip_status morton_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
+                           const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted,
+                           uint32_t out_capacity, uint32_t* out_n_finite, float lo[3], float hi[3],
+                           bool keep_nonfinite_at_end, uint32_t* rank_or_null);
+pclhip_status build_boxes(pclhip_index* ix);
+int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns);
+
+// ---- kernels launched from api.cpp ----------------------------------------------------------
+pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, int k,
+                         int32_t* out_idx_sorted, float* out_d2_sorted);
+pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_t* nan_count);
+pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d2, bool use_max,
+                                 int mode);
+
+// ---- host closed forms (host_math.cpp) -------------------------------------------------------
+void solve_point_to_plane(const double* sums, float* T);
+void solve_point_to_point(const double* sums, float* T);
+void mat4_mul_f32(const float* A, const float* B, float* C);
+
+}  // namespace pclhip

@@ -1,0 +1,635 @@
+// search.hip -- kernels that traverse the index: batched k-NN, fused k-NN + normal estimation, and
+// the fused ICP iteration (transform -> 1-NN -> normal-system accumulation).
+//
+// Compiled with -ffp-contract=off: every float expression that has a counterpart in the reference
+// keeps the reference's operation order and rounding (see traverse.hpp and the citations below).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "traverse.hpp"
+
+namespace pclhip {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+
+// =================================================================================================
+// batched exact k-NN
+// =================================================================================================
+// Queries are Morton-ordered float4 (w = original query index, NO_INDEX bits for non-finite
+// queries).  Results are written at the ORIGINAL query position: out[(orig*k) + c].
+template <int K>
+__global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const float4* __restrict__ q,
+                                                        uint32_t nq, int k, int32_t* __restrict__ out_idx,
+                                                        float* __restrict__ out_d2) {
+  __shared__ uint2 stack_s[WAVES_PER_BLOCK][STACK_ENTRIES];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
+  const GroupSchedule sched(ngroups);
+  for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
+    const uint32_t g = sched.global(gl);
+    if (g >= ngroups) break;
+    const uint32_t i = g * WAVE + lane;
+    float4 p = make_float4(0, 0, 0, 0);
+    bool valid = i < nq;
+    if (valid) p = q[i];
+    const uint32_t oq = __float_as_uint(p.w);
+    const bool real = valid;  // has an output row
+    valid = valid && isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+    if constexpr (K == 1) {
+      NN1 pol;
+      pol.init(KEY_NONE);
+      traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE]);
+      if (real) {
+        const uint32_t id = key_index(pol.key);
+        out_idx[size_t(oq) * k] = (id == NO_INDEX) ? -1 : int32_t(id);
+        out_d2[size_t(oq) * k] = key_dist(pol.key);
+        for (int c = 1; c < k; ++c) {  // k > n
+          out_idx[size_t(oq) * k + c] = -1;
+          out_d2[size_t(oq) * k + c] = __builtin_inff();
+        }
+      }
+    } else {
+      TopKReg<K> pol;
+      pol.init(KEY_NONE);
+      traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE]);
+      if (real) {
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+          if (c < k) {
+            const uint32_t id = key_index(pol.keys[c]);
+            out_idx[size_t(oq) * k + c] = (id == NO_INDEX) ? -1 : int32_t(id);
+            out_d2[size_t(oq) * k + c] = key_dist(pol.keys[c]);
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void knn_heap_kernel(IndexView ix, const float4* __restrict__ q,
+                                                         uint32_t nq, int k, int32_t* __restrict__ out_idx,
+                                                         float* __restrict__ out_d2, uint64_t* heap) {
+  __shared__ uint2 stack_s[WAVES_PER_BLOCK][STACK_ENTRIES];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
+  const GroupSchedule sched(ngroups);
+  for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
+    const uint32_t g = sched.global(gl);
+    if (g >= ngroups) break;
+    const uint32_t i = g * WAVE + lane;
+    float4 p = make_float4(0, 0, 0, 0);
+    bool valid = i < nq;
+    if (valid) p = q[i];
+    const uint32_t oq = __float_as_uint(p.w);
+    const bool real = valid;
+    valid = valid && isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+    TopKHeap pol;
+    pol.heap = heap + (real ? i : 0);
+    pol.stride = nq;
+    pol.k = real ? k : 0;
+    pol.init(KEY_NONE);
+    if (!valid) pol.root = 0;  // lanes without a finite query never insert (key < 0 is impossible)
+    traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE]);
+    if (real) {
+      pol.sort_ascending();
+      for (int c = 0; c < k; ++c) {
+        const uint64_t key = pol.heap[size_t(c) * nq];
+        const uint32_t id = key_index(key);
+        out_idx[size_t(oq) * k + c] = (id == NO_INDEX) ? -1 : int32_t(id);
+        out_d2[size_t(oq) * k + c] = key_dist(key);
+      }
+    }
+  }
+}
+
+static int persistent_blocks(pclhip_ctx* ctx, uint32_t ngroups, int blocks_per_cu) {
+  const int64_t want = (int64_t(ngroups) + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  int64_t cap = int64_t(ctx->num_cus) * blocks_per_cu;
+  if (cap < 8) cap = 8;
+  int64_t b = want < cap ? want : cap;
+  if (b < 1) b = 1;
+  return int(b);
+}
+
+pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, int k, int32_t* out_idx,
+                         float* out_d2) {
+  pclhip_ctx* ctx = ix->ctx;
+  if (nq == 0) return PCLHIP_OK;
+  const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
+  const IndexView v = ix->view();
+  hipStream_t s = ctx->stream;
+  if (k == 1) {
+    const int grid = persistent_blocks(ctx, ngroups, 8);
+    hipLaunchKernelGGL(knn_reg_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2);
+  } else if (k <= 8) {
+    const int grid = persistent_blocks(ctx, ngroups, 6);
+    hipLaunchKernelGGL(knn_reg_kernel<8>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2);
+  } else if (k <= 16) {
+    const int grid = persistent_blocks(ctx, ngroups, 4);
+    hipLaunchKernelGGL(knn_reg_kernel<16>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2);
+  } else if (k <= 32) {
+    const int grid = persistent_blocks(ctx, ngroups, 2);
+    hipLaunchKernelGGL(knn_reg_kernel<32>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2);
+  } else {
+    const size_t bytes = size_t(nq) * size_t(k) * sizeof(uint64_t);
+    uint64_t* heap = nullptr;
+    PCLHIP_CHECK_HIP(ctx, hipMalloc(&heap, bytes));
+    const int grid = persistent_blocks(ctx, ngroups, 4);
+    hipLaunchKernelGGL(knn_heap_kernel, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2,
+                       heap);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(heap);
+    PCLHIP_CHECK_HIP(ctx, e);
+  }
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  return PCLHIP_OK;
+}
+
+// =================================================================================================
+// fused k-NN + NormalEstimation over the indexed cloud itself
+// =================================================================================================
+// computeMeanAndCovarianceMatrix, common/include/pcl/common/impl/centroid.hpp:581-650 (float,
+// shifted by the first neighbour, neighbours in ascending distance order).
+struct Cov {
+  float a[9];
+  float K[3];
+  __device__ __forceinline__ void start(float x, float y, float z) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = 0.0f;
+    K[0] = x; K[1] = y; K[2] = z;
+  }
+  __device__ __forceinline__ void add(float px, float py, float pz) {
+    const float x = __fsub_rn(px, K[0]), y = __fsub_rn(py, K[1]), z = __fsub_rn(pz, K[2]);
+    a[0] = __fadd_rn(a[0], __fmul_rn(x, x));
+    a[1] = __fadd_rn(a[1], __fmul_rn(x, y));
+    a[2] = __fadd_rn(a[2], __fmul_rn(x, z));
+    a[3] = __fadd_rn(a[3], __fmul_rn(y, y));
+    a[4] = __fadd_rn(a[4], __fmul_rn(y, z));
+    a[5] = __fadd_rn(a[5], __fmul_rn(z, z));
+    a[6] = __fadd_rn(a[6], x);
+    a[7] = __fadd_rn(a[7], y);
+    a[8] = __fadd_rn(a[8], z);
+  }
+  // row-major symmetric 3x3
+  __device__ __forceinline__ void finish(int count, float* c) {
+    const float fc = float(count);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = __fdiv_rn(a[i], fc);
+    c[0] = __fsub_rn(a[0], __fmul_rn(a[6], a[6]));
+    c[1] = __fsub_rn(a[1], __fmul_rn(a[6], a[7]));
+    c[2] = __fsub_rn(a[2], __fmul_rn(a[6], a[8]));
+    c[4] = __fsub_rn(a[3], __fmul_rn(a[7], a[7]));
+    c[5] = __fsub_rn(a[4], __fmul_rn(a[7], a[8]));
+    c[8] = __fsub_rn(a[5], __fmul_rn(a[8], a[8]));
+    c[3] = c[1]; c[6] = c[2]; c[7] = c[5];
+  }
+};
+
+// common/include/pcl/common/impl/eigen.hpp:52-65
+__device__ __forceinline__ void compute_roots2(float b, float c, float* r) {
+  r[0] = 0.0f;
+  float d = float(double(__fmul_rn(b, b)) - 4.0 * double(c));
+  if (d < 0.0f) d = 0.0f;
+  const float sd = sqrtf(d);
+  r[2] = __fmul_rn(0.5f, __fadd_rn(b, sd));
+  r[1] = __fmul_rn(0.5f, __fsub_rn(b, sd));
+}
+
+// common/include/pcl/common/impl/eigen.hpp:68-128
+__device__ __forceinline__ void compute_roots(const float* m, float* roots) {
+#define M_(i, j) m[(i)*3 + (j)]
+  const float c0 = M_(0, 0) * M_(1, 1) * M_(2, 2) + 2.0f * M_(0, 1) * M_(0, 2) * M_(1, 2) -
+                   M_(0, 0) * M_(1, 2) * M_(1, 2) - M_(1, 1) * M_(0, 2) * M_(0, 2) -
+                   M_(2, 2) * M_(0, 1) * M_(0, 1);
+  const float c1 = M_(0, 0) * M_(1, 1) - M_(0, 1) * M_(0, 1) + M_(0, 0) * M_(2, 2) - M_(0, 2) * M_(0, 2) +
+                   M_(1, 1) * M_(2, 2) - M_(1, 2) * M_(1, 2);
+  const float c2 = M_(0, 0) + M_(1, 1) + M_(2, 2);
+#undef M_
+  if (fabsf(c0) < FLT_EPSILON) {
+    compute_roots2(c2, c1, roots);
+  } else {
+    const float s_inv3 = float(1.0 / 3.0);
+    const float s_sqrt3 = sqrtf(3.0f);
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.0f) q = 0.0f;
+    const float rho = sqrtf(-a_over_3);
+    const float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
+    const float cos_theta = cosf(theta);
+    const float sin_theta = sinf(theta);
+    roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
+    roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    float t;
+    if (roots[0] >= roots[1]) { t = roots[0]; roots[0] = roots[1]; roots[1] = t; }
+    if (roots[1] >= roots[2]) {
+      t = roots[1]; roots[1] = roots[2]; roots[2] = t;
+      if (roots[0] >= roots[1]) { t = roots[0]; roots[0] = roots[1]; roots[1] = t; }
+    }
+    if (roots[0] <= 0) compute_roots2(c2, c1, roots);
+  }
+}
+
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// common/include/pcl/common/impl/eigen.hpp:272-290
+__device__ __forceinline__ void largest_eigvec(const float* sm, float* v) {
+  float cp[3][3];
+  cross3(sm + 0, sm + 3, cp[0]);
+  cross3(sm + 0, sm + 6, cp[1]);
+  cross3(sm + 3, sm + 6, cp[2]);
+  float len = -1.0f;
+  float bx = 0, by = 0, bz = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float l = sqrtf((cp[i][0] * cp[i][0] + cp[i][1] * cp[i][1]) + cp[i][2] * cp[i][2]);
+    if (l > len) {
+      len = l;
+      bx = cp[i][0]; by = cp[i][1]; bz = cp[i][2];
+    }
+  }
+  v[0] = bx / len; v[1] = by / len; v[2] = bz / len;
+}
+
+__device__ __forceinline__ void unit_orthogonal(const float* s, float* o) {
+  const float prec = 1e-5f;
+  const bool x_small = fabsf(s[0]) <= prec * fabsf(s[2]);
+  const bool y_small = fabsf(s[1]) <= prec * fabsf(s[2]);
+  if (!x_small || !y_small) {
+    const float inv = 1.0f / sqrtf(s[0] * s[0] + s[1] * s[1]);
+    o[0] = -s[1] * inv; o[1] = s[0] * inv; o[2] = 0.0f;
+  } else {
+    const float inv = 1.0f / sqrtf(s[1] * s[1] + s[2] * s[2]);
+    o[0] = 0.0f; o[1] = -s[2] * inv; o[2] = s[1] * inv;
+  }
+}
+
+// pcl::eigen33 (common/include/pcl/common/impl/eigen.hpp:295-325) + solvePlaneParameters
+// (features/include/pcl/features/impl/feature.hpp:64-89)
+__device__ __forceinline__ void solve_plane(const float* cov, float& nx, float& ny, float& nz, float& curv) {
+  float scale = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) scale = fmaxf(scale, fabsf(cov[i]));
+  if (scale <= FLT_MIN) scale = 1.0f;
+  float sm[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) sm[i] = cov[i] / scale;
+  float ev[3], v[3];
+  compute_roots(sm, ev);
+  const float eigenvalue = ev[0] * scale;
+  if ((ev[1] - ev[0]) > FLT_EPSILON) {
+    sm[0] -= ev[0]; sm[4] -= ev[0]; sm[8] -= ev[0];
+    largest_eigvec(sm, v);
+  } else if ((ev[2] - ev[0]) > FLT_EPSILON) {
+    sm[0] -= ev[2]; sm[4] -= ev[2]; sm[8] -= ev[2];
+    float tmp[3];
+    largest_eigvec(sm, tmp);
+    unit_orthogonal(tmp, v);
+  } else {
+    v[0] = 1.0f; v[1] = 0.0f; v[2] = 0.0f;
+  }
+  nx = v[0]; ny = v[1]; nz = v[2];
+  const float eig_sum = cov[0] + cov[4] + cov[8];
+  curv = (eig_sum != 0) ? fabsf(eigenvalue / eig_sum) : 0.0f;
+}
+
+// features/include/pcl/features/normal_3d.h:169-188
+__device__ __forceinline__ void flip_to_viewpoint(float px, float py, float pz, float vx, float vy, float vz,
+                                                  float& nx, float& ny, float& nz) {
+  vx -= px; vy -= py; vz -= pz;
+  const float cos_theta = (vx * nx + vy * ny + vz * nz);
+  if (cos_theta < 0) { nx *= -1; ny *= -1; nz *= -1; }
+}
+
+template <int K>
+__global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, float vx, float vy, float vz,
+                                                        float4* __restrict__ nrm_sorted,
+                                                        unsigned long long* __restrict__ nan_count) {
+  __shared__ uint2 stack_s[WAVES_PER_BLOCK][STACK_ENTRIES];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const uint32_t ngroups = (ix.n + WAVE - 1) / WAVE;
+  const GroupSchedule sched(ngroups);
+  const float qnan = __builtin_nanf("");
+  for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
+    const uint32_t g = sched.global(gl);
+    if (g >= ngroups) break;
+    const uint32_t i = g * WAVE + lane;
+    const bool valid = i < ix.n;
+    float4 p = make_float4(0, 0, 0, 0);
+    if (valid) p = ix.pts[i];
+    TopKReg<K> pol;
+    pol.init(KEY_NONE);
+    traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE]);
+    if (valid) {
+      // normal_3d.hpp:59-66 + normal_3d.h:308-322: fewer than 3 neighbours -> NaN
+      int found = 0;
+#pragma unroll
+      for (int c = 0; c < K; ++c)
+        if (c < k && pol.pos[c] != NO_INDEX) ++found;
+      float4 out;
+      if (found < 3) {
+        out = make_float4(qnan, qnan, qnan, qnan);
+        atomicAdd(nan_count, 1ull);
+      } else {
+        Cov cv;
+        const float4 p0 = ix.pts[pol.pos[0]];
+        cv.start(p0.x, p0.y, p0.z);
+        cv.add(p0.x, p0.y, p0.z);
+#pragma unroll
+        for (int c = 1; c < K; ++c) {
+          if (c < found) {
+            const float4 pc = ix.pts[pol.pos[c]];
+            cv.add(pc.x, pc.y, pc.z);
+          }
+        }
+        float cov[9];
+        cv.finish(found, cov);
+        float nx, ny, nz, curv;
+        solve_plane(cov, nx, ny, nz, curv);
+        flip_to_viewpoint(p.x, p.y, p.z, vx, vy, vz, nx, ny, nz);
+        out = make_float4(nx, ny, nz, curv);
+      }
+      nrm_sorted[i] = out;
+    }
+  }
+}
+
+// k > 32: neighbours through the generic k-NN kernel (results by original index) then this pass.
+__global__ __launch_bounds__(BLOCK) void normals_from_knn_kernel(IndexView ix, int k, const uint32_t* __restrict__ rank,
+                                                                 const int32_t* __restrict__ knn_by_sorted, float vx,
+                                                                 float vy, float vz, float4* __restrict__ nrm_sorted,
+                                                                 unsigned long long* __restrict__ nan_count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ix.n) return;
+  const float4 p = ix.pts[i];
+  const int32_t* nb = knn_by_sorted + size_t(i) * k;
+  int found = 0;
+  for (int c = 0; c < k; ++c) found += (nb[c] >= 0);
+  const float qnan = __builtin_nanf("");
+  float4 out;
+  if (found < 3) {
+    out = make_float4(qnan, qnan, qnan, qnan);
+    atomicAdd(nan_count, 1ull);
+  } else {
+    Cov cv;
+    const float4 p0 = ix.pts[rank[nb[0]]];
+    cv.start(p0.x, p0.y, p0.z);
+    for (int c = 0; c < found; ++c) {
+      const float4 pc = ix.pts[rank[nb[c]]];
+      cv.add(pc.x, pc.y, pc.z);
+    }
+    float cov[9];
+    cv.finish(found, cov);
+    float nx, ny, nz, curv;
+    solve_plane(cov, nx, ny, nz, curv);
+    flip_to_viewpoint(p.x, p.y, p.z, vx, vy, vz, nx, ny, nz);
+    out = make_float4(nx, ny, nz, curv);
+  }
+  nrm_sorted[i] = out;
+}
+
+__global__ void iota_w_kernel(const float4* __restrict__ pts, uint32_t n, float4* __restrict__ q) {
+  // queries = the sorted points with w = SORTED position, so knn results land at row `sorted pos`
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    float4 p = pts[i];
+    p.w = __uint_as_float(i);
+    q[i] = p;
+  }
+}
+
+pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_t* nan_count) {
+  pclhip_ctx* ctx = ix->ctx;
+  hipStream_t s = ctx->stream;
+  if (!ix->nrm) PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->nrm, size_t(ix->n_pad > 0 ? ix->n_pad : 1) * sizeof(float4)));
+  unsigned long long* d_nan = nullptr;
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&d_nan, sizeof(unsigned long long)));
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_nan, 0, sizeof(unsigned long long), s));
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(ix->nrm, 0xFF, size_t(ix->n_pad) * sizeof(float4), s));  // NaN pads
+  const IndexView v = ix->view();
+  const uint32_t ngroups = (ix->n + WAVE - 1) / WAVE;
+  if (ix->n > 0) {
+    if (k <= 8) {
+      hipLaunchKernelGGL(normals_kernel<8>, dim3(persistent_blocks(ctx, ngroups, 6)), dim3(BLOCK), 0, s, v, k, vp[0],
+                         vp[1], vp[2], ix->nrm, d_nan);
+    } else if (k <= 16) {
+      hipLaunchKernelGGL(normals_kernel<16>, dim3(persistent_blocks(ctx, ngroups, 4)), dim3(BLOCK), 0, s, v, k, vp[0],
+                         vp[1], vp[2], ix->nrm, d_nan);
+    } else if (k <= 32) {
+      hipLaunchKernelGGL(normals_kernel<32>, dim3(persistent_blocks(ctx, ngroups, 2)), dim3(BLOCK), 0, s, v, k, vp[0],
+                         vp[1], vp[2], ix->nrm, d_nan);
+    } else {
+      float4* q = nullptr;
+      int32_t* nb = nullptr;
+      float* nd = nullptr;
+      PCLHIP_CHECK_HIP(ctx, hipMalloc(&q, size_t(ix->n) * sizeof(float4)));
+      PCLHIP_CHECK_HIP(ctx, hipMalloc(&nb, size_t(ix->n) * k * sizeof(int32_t)));
+      PCLHIP_CHECK_HIP(ctx, hipMalloc(&nd, size_t(ix->n) * k * sizeof(float)));
+      hipLaunchKernelGGL(iota_w_kernel, dim3((ix->n + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, q);
+      pclhip_status st = launch_knn(ix, q, ix->n, k, nb, nd);
+      if (st == PCLHIP_OK)
+        hipLaunchKernelGGL(normals_from_knn_kernel, dim3((ix->n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, v, k,
+                           ix->rank, nb, vp[0], vp[1], vp[2], ix->nrm, d_nan);
+      hipError_t e = hipStreamSynchronize(s);
+      (void)hipFree(q);
+      (void)hipFree(nb);
+      (void)hipFree(nd);
+      if (st != PCLHIP_OK) return st;
+      PCLHIP_CHECK_HIP(ctx, e);
+    }
+  }
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  unsigned long long h = 0;
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&h, d_nan, sizeof h, hipMemcpyDeviceToHost, s));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  (void)hipFree(d_nan);
+  if (nan_count) *nan_count = h;
+  ix->has_normals = true;
+  return PCLHIP_OK;
+}
+
+// =================================================================================================
+// fused ICP iteration
+// =================================================================================================
+struct Mat34 {
+  float m[12];  // rows 0..2 of the 4x4
+};
+
+// order 0: Eigen Matrix4f * Vector4f (registration/include/pcl/registration/impl/icp.hpp:49-111)
+// order 1: Transformer<float>::se3 (common/include/pcl/common/impl/transforms.hpp:117-123)
+__device__ __forceinline__ float xform_row(const float* r, float x, float y, float z, int order) {
+  if (order == 0)
+    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r[0], x), __fmul_rn(r[1], y)), __fmul_rn(r[2], z)),
+                     __fmul_rn(r[3], 1.0f));
+  return __fadd_rn(__fmul_rn(r[0], x), __fadd_rn(__fmul_rn(r[1], y), __fadd_rn(__fmul_rn(r[2], z), r[3])));
+}
+
+constexpr int NS = PCLHIP_ICP_NSUMS;
+
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void icp_iterate_kernel(IndexView ix, float4* __restrict__ cur, uint32_t ns,
+                                                            Mat34 T, int order, uint64_t key0,
+                                                            uint32_t* __restrict__ match,
+                                                            float* __restrict__ match_d2,
+                                                            double* __restrict__ partials) {
+  __shared__ uint2 stack_s[WAVES_PER_BLOCK][STACK_ENTRIES];
+  __shared__ double red_s[WAVES_PER_BLOCK][NS];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const uint32_t ngroups = (ns + WAVE - 1) / WAVE;
+  const GroupSchedule sched(ngroups);
+  constexpr int NACC = (MODE == PCLHIP_ICP_POINT_TO_PLANE) ? 27 : 15;
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  double sum_d2 = 0.0;
+  uint32_t cnt = 0, skipped = 0;
+
+  for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
+    const uint32_t g = sched.global(gl);
+    if (g >= ngroups) break;
+    const uint32_t i = g * WAVE + lane;
+    bool valid = i < ns;
+    float4 p = make_float4(0, 0, 0, 0);
+    if (valid) p = cur[i];
+    const bool in_range = valid;
+    valid = valid && isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+    if (valid) {  // cur <- T * cur (non-finite points are left untouched, icp.hpp:97-98)
+      const float x = xform_row(T.m + 0, p.x, p.y, p.z, order);
+      const float y = xform_row(T.m + 4, p.x, p.y, p.z, order);
+      const float z = xform_row(T.m + 8, p.x, p.y, p.z, order);
+      p.x = x; p.y = y; p.z = z;
+      cur[i] = p;
+    }
+    NN1 pol;
+    pol.init(key0);
+    traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[wave]);
+    const uint32_t mid = key_index(pol.key);
+    const bool found = valid && mid != NO_INDEX;
+    if (in_range) {
+      match[i] = found ? mid : NO_INDEX;
+      match_d2[i] = found ? key_dist(pol.key) : __builtin_inff();
+    }
+    if (found) {
+      ++cnt;
+      sum_d2 += double(key_dist(pol.key));
+      const float4 t = ix.pts[pol.pos];
+      if constexpr (MODE == PCLHIP_ICP_POINT_TO_PLANE) {
+        // impl/transformation_estimation_point_to_plane_lls.hpp:182-241
+        const float4 n = ix.nrm[pol.pos];
+        if (isfinite(n.x) && isfinite(n.y) && isfinite(n.z)) {
+          const float sx = p.x, sy = p.y, sz = p.z;
+          const float nx = n.x, ny = n.y, nz = n.z;
+          const double a = double(__fsub_rn(__fmul_rn(nz, sy), __fmul_rn(ny, sz)));
+          const double b = double(__fsub_rn(__fmul_rn(nx, sz), __fmul_rn(nz, sx)));
+          const double c = double(__fsub_rn(__fmul_rn(ny, sx), __fmul_rn(nx, sy)));
+          acc[0] += a * a;  acc[1] += a * b;  acc[2] += a * c;
+          acc[3] += a * double(nx); acc[4] += a * double(ny); acc[5] += a * double(nz);
+          acc[6] += b * b;  acc[7] += b * c;
+          acc[8] += b * double(nx); acc[9] += b * double(ny); acc[10] += b * double(nz);
+          acc[11] += c * c;
+          acc[12] += c * double(nx); acc[13] += c * double(ny); acc[14] += c * double(nz);
+          acc[15] += double(__fmul_rn(nx, nx)); acc[16] += double(__fmul_rn(nx, ny));
+          acc[17] += double(__fmul_rn(nx, nz)); acc[18] += double(__fmul_rn(ny, ny));
+          acc[19] += double(__fmul_rn(ny, nz)); acc[20] += double(__fmul_rn(nz, nz));
+          // :235  nx*dx + ny*dy + nz*dz - nx*sx - ny*sy - nz*sz, float, left to right
+          float df = __fmul_rn(nx, t.x);
+          df = __fadd_rn(df, __fmul_rn(ny, t.y));
+          df = __fadd_rn(df, __fmul_rn(nz, t.z));
+          df = __fsub_rn(df, __fmul_rn(nx, sx));
+          df = __fsub_rn(df, __fmul_rn(ny, sy));
+          df = __fsub_rn(df, __fmul_rn(nz, sz));
+          const double d = double(df);
+          acc[21] += a * d; acc[22] += b * d; acc[23] += c * d;
+          acc[24] += double(nx) * d; acc[25] += double(ny) * d; acc[26] += double(nz) * d;
+        } else {
+          ++skipped;
+        }
+      } else {
+        // raw sums for umeyama (common/include/pcl/common/impl/eigen.hpp:696-712)
+        const double sx = p.x, sy = p.y, sz = p.z, tx = t.x, ty = t.y, tz = t.z;
+        acc[0] += sx; acc[1] += sy; acc[2] += sz;
+        acc[3] += tx; acc[4] += ty; acc[5] += tz;
+        acc[6] += tx * sx; acc[7] += tx * sy; acc[8] += tx * sz;
+        acc[9] += ty * sx; acc[10] += ty * sy; acc[11] += ty * sz;
+        acc[12] += tz * sx; acc[13] += tz * sy; acc[14] += tz * sz;
+      }
+    }
+  }
+  // wave tree-reduce (shuffles), then fixed-order block reduce through LDS -> deterministic
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    const double s = wave_sum_d(acc[i]);
+    if (lane == 0) red_s[wave][i] = s;
+  }
+  {
+    const double s0 = wave_sum_d(sum_d2), s1 = wave_sum_d(double(cnt)), s2 = wave_sum_d(double(skipped));
+    if (lane == 0) {
+      for (int i = NACC; i < NS; ++i) red_s[wave][i] = 0.0;
+      red_s[wave][27] = s0;
+      red_s[wave][28] = s1;
+      red_s[wave][29] = s2;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES_PER_BLOCK; ++w) s += red_s[w][threadIdx.x];
+    partials[size_t(blockIdx.x) * NS + threadIdx.x] = s;
+  }
+}
+
+__global__ void icp_finalize_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ sums) {
+  const int t = threadIdx.x;
+  if (t < NS) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partials[size_t(b) * NS + t];
+    sums[t] = s;
+  }
+}
+
+pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d2, bool use_max, int mode) {
+  pclhip_ctx* ctx = icp->ctx;
+  hipStream_t s = ctx->stream;
+  const IndexView v = icp->target->view();
+  Mat34 M;
+  for (int i = 0; i < 12; ++i) M.m[i] = T[i];
+  const int order = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? 1 : 0;
+  uint32_t dbits = 0x7F800000u;
+  if (use_max) memcpy(&dbits, &max_d2, sizeof dbits);
+  const uint64_t key0 = (uint64_t(dbits) << 32) | 0xFFFFFFFFull;
+  const int grid = icp->grid_blocks;
+  if (icp->n > 0) {
+    (void)hipEventRecord(icp->ev0, s);
+    if (mode == PCLHIP_ICP_POINT_TO_PLANE)
+      hipLaunchKernelGGL(icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE>, dim3(grid), dim3(BLOCK), 0, s, v,
+                         icp->src_cur, icp->n, M, order, key0, icp->match, icp->match_d2, icp->partials);
+    else
+      hipLaunchKernelGGL(icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT>, dim3(grid), dim3(BLOCK), 0, s, v,
+                         icp->src_cur, icp->n, M, order, key0, icp->match, icp->match_d2, icp->partials);
+    (void)hipEventRecord(icp->ev1, s);
+    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(64), 0, s, icp->partials, grid, icp->sums_dev);
+  } else {
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(icp->sums_dev, 0, NS * sizeof(double), s));
+  }
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  return PCLHIP_OK;
+}
+
+int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns) {
+  return persistent_blocks(ctx, (ns + WAVE - 1) / WAVE, 4);
+}
+
+}  // namespace pclhip

@@ -1,0 +1,88 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/pclhip.h declares, and the product path fails loudly (no CPU fallback) without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from pcl_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pclhip.h")).read()
+    return sorted(set(re.findall(r"PCLHIP_API\s+[\w\s\*]+?\b(pclhip_\w+)\s*\(", text)))
+
+
+def test_header_and_binding_table_agree():
+    names = declared_symbols()
+    assert len(names) >= 20
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.pclhip_version().startswith(b"pclhip")
+
+
+def test_struct_layouts_match_header():
+    # sizes the C side was compiled with (x86-64 SysV): guards against silent field drift
+    assert C.sizeof(_lib.IcpParams) == 64
+    assert C.sizeof(_lib.IcpResult) == 176
+    p = _lib.IcpParams()
+    _lib.load().pclhip_icp_params_default(C.byref(p))
+    assert p.max_iterations == 10 and p.min_number_correspondences == 3 and p.mode == 0
+    assert p.transformation_epsilon == 0.0 and p.mse_threshold_absolute == 1e-12
+    assert p.max_correspondence_distance > 1e150 and p.euclidean_fitness_epsilon < -1e300
+
+
+def test_host_closed_forms_match_oracle():
+    # pclhip_solve_transformation is pure host code: check it against the oracle on CPU
+    import numpy as np
+    from oracle import pcl_oracle as orc
+    rng = np.random.default_rng(0)
+    src = rng.normal(0, 1, (500, 4)).astype(np.float32)
+    th = 0.03
+    G = np.eye(4, dtype=np.float32)
+    G[0, 0] = G[2, 2] = np.cos(th)
+    G[0, 2] = np.sin(th)
+    G[2, 0] = -np.sin(th)
+    G[:3, 3] = (0.02, -0.01, 0.03)
+    nrm = rng.normal(0, 1, (500, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    tgt, tn = orc.transform_cloud(G, src, order=1, normals=nrm)
+    T_ref, sums27, _ = orc.lls_point_to_plane(src, tgt, tn)
+    sums = np.zeros(32)
+    sums[:27] = sums27
+    sums[28] = 500
+    T = np.zeros(16, np.float32)
+    lib = _lib.load()
+    assert lib.pclhip_solve_transformation(sums.ctypes.data_as(C.POINTER(C.c_double)), 1,
+                                           T.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    assert np.abs(T.reshape(4, 4) - T_ref).max() < 1e-6
+    # point-to-point from raw sums
+    s, t = src[:, :3].astype(np.float64), tgt[:, :3].astype(np.float64)
+    sums = np.zeros(32)
+    sums[0:3] = s.sum(0)
+    sums[3:6] = t.sum(0)
+    sums[6:15] = (t.T @ s).reshape(9)
+    sums[28] = 500
+    assert lib.pclhip_solve_transformation(sums.ctypes.data_as(C.POINTER(C.c_double)), 0,
+                                           T.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    assert np.abs(T.reshape(4, 4) - orc.umeyama(src, tgt, acc_double=True)).max() < 1e-6
+    assert np.abs(T.reshape(4, 4) - G).max() < 1e-5
+    assert np.abs(orc.umeyama_from_sums(sums[:15], 500) - T.reshape(4, 4)).max() < 1e-6
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import pcl_amd
+    with pytest.raises(pcl_amd.PclHipError) as e:
+        pcl_amd.Context(0)
+    assert e.value.status == -3  # PCLHIP_ERR_NO_DEVICE

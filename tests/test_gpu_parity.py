@@ -1,0 +1,503 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle.
+
+Bars: bit-exact for indices and squared distances; float tolerances are written in each test.
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def xyz1(a):
+    out = np.ones((len(a), 4), np.float32)
+    out[:, :3] = a[:, :3]
+    return out
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import pcl_amd
+    return pcl_amd.Context(0)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pcl_oracle
+    return pcl_oracle
+
+
+def build_tree(gpu, cloud, indices=None):
+    import pcl_amd
+    t = pcl_amd.KdTree(gpu)
+    t.setInputCloud(cloud, indices)
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# k-NN
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [1, 3, 8, 10, 16, 20, 32, 64, 512])
+def test_knn_random_vs_bruteforce(gpu, orc, k):
+    # test/search/test_search.cpp:292-364 (k in {1,8,64,512}, 1200 random points), plus the
+    # register (k<=32) / heap (k>32) boundaries
+    rng = np.random.default_rng(100 + k)
+    pts = rng.uniform(0, 1, (1200, 3)).astype(np.float32)
+    qry = rng.uniform(-0.1, 1.1, (777, 3)).astype(np.float32)
+    gi, gd = build_tree(gpu, pts).nearestKSearch(qry, k)
+    oi, od = orc.knn_bruteforce(pts, qry, k)
+    assert np.array_equal(gi, oi)
+    assert np.array_equal(gd, od)
+    assert np.all(np.diff(gd, axis=1) >= 0)
+
+
+def test_knn_hand_points_golden(gpu, golden):
+    # test/kdtree/test_kdtree.cpp:226-289
+    g = golden["kdtree_hand"]
+    pts = np.asarray(g["points"], np.float32)
+    qry = np.asarray([g["query"]], np.float32)
+    for name, scale in (("xyz", (1, 1, 1)), ("xy", (1, 1, 0)), ("rescaled_123", (1, 2, 3))):
+        s = np.asarray(scale, np.float32)
+        idx, d2 = build_tree(gpu, pts * s).nearestKSearch(qry * s, 10)
+        assert idx[0].tolist() == g[name]["indices"], name
+        assert np.allclose(d2[0], g[name]["distances"], atol=g["dist_tol"])
+
+
+def test_knn_lattice_ties_lowest_index(gpu, orc):
+    # 11^3 lattice (test/kdtree/test_kdtree.cpp:161-208): masses of exact distance ties, the lower
+    # index must win exactly as in the oracle
+    g = np.arange(-5, 6, dtype=np.float32) * np.float32(0.1)
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(7)
+    qry = np.concatenate([pts[::17], rng.uniform(-0.6, 0.6, (200, 3)).astype(np.float32)])
+    tree = build_tree(gpu, pts)
+    for k in (1, 8, 20, 40):
+        gi, gd = tree.nearestKSearch(qry, k)
+        oi, od = orc.knn_bruteforce(pts, qry, k)
+        assert np.array_equal(gi, oi), k
+        assert np.array_equal(gd, od), k
+
+
+def test_knn_duplicates_and_nonfinite(gpu, orc):
+    rng = np.random.default_rng(3)
+    pts = rng.normal(0, 1, (5000, 3)).astype(np.float32)
+    pts[100:200] = pts[0:100]            # exact duplicates -> ties
+    pts[7] = np.nan                      # dropped (kdtree_flann.hpp:443-452)
+    pts[4999, 1] = np.inf
+    qry = rng.normal(0, 1, (1000, 3)).astype(np.float32)
+    qry[5] = np.nan                      # no neighbours
+    tree = build_tree(gpu, pts)
+    assert tree.size() == 4998
+    for k in (1, 8):
+        gi, gd = tree.nearestKSearch(qry, k)
+        oi, od = orc.knn_bruteforce(pts, qry, k)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+        assert np.all(gi[5] == -1) and np.all(np.isinf(gd[5]))
+
+
+def test_knn_k_larger_than_cloud_and_tiny_clouds(gpu, orc):
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 5, 15, 16, 17, 63, 64, 65, 1025):
+        pts = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        qry = rng.uniform(0, 1, (70, 3)).astype(np.float32)
+        for k in (1, 8, 40):
+            gi, gd = build_tree(gpu, pts).nearestKSearch(qry, k)
+            oi, od = orc.knn_bruteforce(pts, qry, k)
+            assert np.array_equal(gi, oi), (n, k)
+            assert np.array_equal(gd, od), (n, k)
+
+
+def test_knn_empty_inputs(gpu):
+    tree = build_tree(gpu, np.zeros((0, 4), np.float32))
+    assert tree.size() == 0
+    idx, d2 = tree.nearestKSearch(np.zeros((3, 4), np.float32), 2)
+    assert np.all(idx == -1) and np.all(np.isinf(d2))
+    tree = build_tree(gpu, np.random.default_rng(1).uniform(0, 1, (10, 3)).astype(np.float32))
+    idx, d2 = tree.nearestKSearch(np.zeros((0, 3), np.float32), 2)
+    assert idx.shape == (0, 2)
+
+
+def test_knn_with_indices_subset(gpu, orc):
+    # KdTreeFLANN::setInputCloud(cloud, indices): results index the ORIGINAL cloud
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(0, 1, (3000, 3)).astype(np.float32)
+    sel = np.sort(rng.choice(3000, 1000, replace=False)).astype(np.int32)
+    qry = rng.uniform(0, 1, (500, 3)).astype(np.float32)
+    gi, gd = build_tree(gpu, pts, sel).nearestKSearch(qry, 4)
+    oi, od = orc.knn_bruteforce(pts[sel], qry, 4)
+    assert np.array_equal(gi, sel[oi]) and np.array_equal(gd, od)
+
+
+def test_knn_strided_pointnormal_records(gpu, orc):
+    rng = np.random.default_rng(12)
+    rec = rng.uniform(0, 1, (2000, 12)).astype(np.float32)  # 48-byte pcl::PointNormal-like records
+    qry = rng.uniform(0, 1, (300, 12)).astype(np.float32)
+    gi, gd = build_tree(gpu, rec).nearestKSearch(qry, 8)
+    oi, od = orc.knn_bruteforce(rec[:, :3], qry[:, :3], 8)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+
+
+def test_knn_synthetic_surface_200k(gpu, orc):
+    import pcl_amd
+    tgt, src, _ = pcl_amd.synth.icp_pair(200_000)
+    tree = build_tree(gpu, tgt)
+    otree = orc.KdTree(tgt)
+    for k in (1, 8):
+        gi, gd = tree.nearestKSearch(src, k)
+        oi, od = otree.knn(src, k)
+        assert np.array_equal(gi, oi), k
+        assert np.array_equal(gd, od), k
+
+
+def test_knn_far_queries_and_clustered_target(gpu, orc):
+    # queries far outside the target's bounding box, a target with a dense cluster + outliers
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([rng.normal(0, 1e-3, (20000, 3)), rng.uniform(-50, 50, (200, 3))]).astype(np.float32)
+    qry = np.concatenate([rng.uniform(-200, 200, (500, 3)), rng.normal(0, 2e-3, (500, 3))]).astype(np.float32)
+    gi, gd = build_tree(gpu, pts).nearestKSearch(qry, 8)
+    oi, od = orc.KdTree(pts).knn(qry, 8)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+
+
+def test_knn_device_resident_torch_buffers(gpu, orc):
+    import torch
+    rng = np.random.default_rng(21)
+    pts = rng.uniform(0, 1, (50000, 4)).astype(np.float32)
+    qry = rng.uniform(0, 1, (10000, 4)).astype(np.float32)
+    tp, tq = torch.from_numpy(pts).cuda(), torch.from_numpy(qry).cuda()
+    gi, gd = build_tree(gpu, tp).nearestKSearch(tq, 8)
+    assert gi.is_cuda and gd.is_cuda
+    oi, od = orc.KdTree(pts).knn(qry, 8)
+    assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gd.cpu().numpy(), od)
+
+
+# ------------------------------------------------------------------------------------------------
+# CorrespondenceEstimation
+# ------------------------------------------------------------------------------------------------
+def test_correspondences_bunny_golden(gpu, bunny, golden):
+    # test/registration/test_registration_api.cpp:83-104 -- 397 exact pairs
+    import pcl_amd
+    ce = pcl_amd.CorrespondenceEstimation(gpu)
+    ce.setInputSource(xyz1(bunny["bun0"]))
+    ce.setInputTarget(xyz1(bunny["bun4"]))
+    q, m, d = ce.determineCorrespondences()
+    gold = np.asarray(golden["correspondences_original"], np.int32)
+    assert np.array_equal(q, gold[:, 0]) and np.array_equal(m, gold[:, 1])
+
+
+def test_correspondences_max_distance(gpu, orc, bunny):
+    import pcl_amd
+    src, tgt = xyz1(bunny["bun0"]), xyz1(bunny["bun4"])
+    src[11, 0] = np.nan  # non-finite source points are skipped (correspondence_estimation.hpp:173-174)
+    otree = orc.KdTree(tgt)
+    for md in (0.002, 0.01, 0.05):
+        ce = pcl_amd.CorrespondenceEstimation(gpu)
+        ce.setInputSource(src)
+        ce.setInputTarget(tgt)
+        q, m, d = ce.determineCorrespondences(md)
+        oq, om, od = otree.correspondences(src, md)
+        assert np.array_equal(q, oq) and np.array_equal(m, om) and np.array_equal(d, od), md
+        assert 0 < len(q) < 397
+
+
+# ------------------------------------------------------------------------------------------------
+# ICP
+# ------------------------------------------------------------------------------------------------
+def run_icp_pair(gpu, orc, tgt, src, mode, normals=None, **kw):
+    import pcl_amd
+    cls = pcl_amd.IterativeClosestPointWithNormals if mode == 1 else pcl_amd.IterativeClosestPoint
+    icp = cls(gpu)
+    icp.setInputTarget(tgt)
+    if normals is not None:
+        icp.setTargetNormals(normals)
+    icp.setInputSource(src)
+    icp.setMaximumIterations(kw["max_iterations"])
+    if "max_correspondence_distance" in kw:
+        icp.setMaxCorrespondenceDistance(kw["max_correspondence_distance"])
+    if "transformation_epsilon" in kw:
+        icp.setTransformationEpsilon(kw["transformation_epsilon"])
+    icp.align()
+    ref = orc.icp_align(orc.KdTree(tgt), tgt, src, mode=mode, tgt_normals=normals, record=True, **kw)
+    return icp, ref
+
+
+def test_icp_bunny_golden_and_oracle(gpu, orc, bunny, golden):
+    # test/registration/test_registration.cpp:236-270
+    g = golden["icp_bunny"]
+    src, tgt = xyz1(bunny["bun0"]), xyz1(bunny["bun4"])
+    icp, ref = run_icp_pair(gpu, orc, tgt, src, 0, max_iterations=g["max_iterations"],
+                            transformation_epsilon=g["transformation_epsilon"],
+                            max_correspondence_distance=g["max_correspondence_distance"])
+    T = icp.getFinalTransformation()
+    assert np.all(np.abs(T[:3] - np.asarray(g["rows"])) <= np.asarray(g["tol"])), T
+    assert T[3].tolist() == [0, 0, 0, 1]
+    assert icp.hasConverged()
+    # vs the oracle: same iteration count, final 4x4 within 1e-5 Frobenius (north_star tolerance)
+    assert icp.nr_iterations_ == ref["iterations"]
+    assert icp.getConvergenceState() == ("NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE",
+                                         "NO_CORRESPONDENCES", "FAILURE")[ref["state"]]
+    assert np.linalg.norm(T.astype(np.float64) - ref["T"]) < 1e-5
+
+
+def test_icp_per_iteration_correspondences_bit_exact(gpu, orc, bunny):
+    # drive the fused iteration by hand with the ORACLE's per-iteration transforms: every
+    # iteration's matches must equal the oracle's bit for bit (same float transform order)
+    import pcl_amd
+    src, tgt = xyz1(bunny["bun0"]), xyz1(bunny["bun4"])
+    ref = orc.icp_align(orc.KdTree(tgt), tgt, src, mode=0, max_iterations=12,
+                        max_correspondence_distance=0.05, transformation_epsilon=1e-9, record=True)
+    icp = pcl_amd.IterativeClosestPoint(gpu)
+    icp.setInputTarget(tgt)
+    icp.setInputSource(src)
+    icp.setMaxCorrespondenceDistance(0.05)
+    icp.reset()
+    T_prev = np.eye(4, dtype=np.float32)
+    for it in range(ref["iterations"]):
+        sums = icp.iterate(T_prev)
+        q, m, d = icp.fetchCorrespondences()
+        row = ref["per_iter_match"][it]
+        assert np.array_equal(q, np.nonzero(row >= 0)[0]), it
+        assert np.array_equal(m, row[row >= 0]), it
+        assert int(sums[28]) == len(q)
+        T_prev = ref["per_iter_T"][it]
+        # the host closed form agrees with the oracle's estimate for this iteration (fp64 sums vs
+        # the oracle's float sums: 1e-5)
+        assert np.abs(icp.solve(sums) - T_prev).max() < 1e-5, it
+
+
+def test_icp_translation_recovery(gpu, bunny):
+    # test/registration/test_registration.cpp:161-195
+    import pcl_amd
+    src = xyz1(bunny["bun0"])
+    tgt = src.copy()
+    tgt[:, 2] += np.float32(0.2)
+    icp = pcl_amd.IterativeClosestPoint(gpu)
+    icp.setInputTarget(tgt)
+    icp.setInputSource(src)
+    icp.setMaximumIterations(50)
+    out = icp.align(want_output=True)
+    T = icp.getFinalTransformation()
+    assert np.abs(T[:3, :3] - np.eye(3)).max() < 2e-3 and np.abs(T[:3, 3] - [0, 0, 0.2]).max() < 2e-3
+    assert np.abs(out[:, :3] - tgt[:, :3]).max() < 5e-3
+
+
+def test_icp_with_normals_bunny(gpu, orc, bunny):
+    # test/registration/test_registration.cpp:272-318: NormalEstimation(k=10) + ICPWithNormals
+    import pcl_amd
+    src, tgt = xyz1(bunny["bun0"]), xyz1(bunny["bun4"])
+    tree = build_tree(gpu, tgt)
+    ne = pcl_amd.NormalEstimation(gpu)
+    ne.setInputCloud(tgt)
+    ne.setSearchMethod(tree)
+    ne.setKSearch(10)
+    nrm = ne.compute()
+    onrm, nan = orc.KdTree(tgt).normals(tgt, 10)
+    assert ne.nan_count == nan == 0
+    assert np.abs(np.sum(nrm[:, :3] * onrm[:, :3], axis=1)).min() > 1 - 1e-5
+    icp = pcl_amd.IterativeClosestPointWithNormals(gpu)
+    icp.setSearchMethodTarget(tree)
+    icp.setInputSource(src)
+    icp.setMaximumIterations(50)
+    icp.setTransformationEpsilon(1e-8)
+    icp.align()
+    ref = orc.icp_align(orc.KdTree(tgt), tgt, src, mode=1, tgt_normals=onrm, max_iterations=50,
+                        transformation_epsilon=1e-8)
+    assert icp.hasConverged() and icp.nr_iterations_ == ref["iterations"]
+    T = icp.getFinalTransformation()
+    assert np.linalg.norm(T.astype(np.float64) - ref["T"]) < 1e-5
+    out = orc.transform_cloud(T, src, order=1)
+    _, d2 = orc.KdTree(tgt).knn(out, 1)
+    assert float(d2.mean()) < 1e-3  # fitness bar of the reference test
+
+
+def test_icp_point_to_plane_lls_sums_match_oracle(gpu, orc):
+    import pcl_amd
+    tgt, src, _ = pcl_amd.synth.icp_pair(50_000)
+    otree = orc.KdTree(tgt)
+    onrm, _ = otree.normals(tgt, 8, viewpoint=(0, 0, 10))
+    icp = pcl_amd.IterativeClosestPointWithNormals(gpu)
+    icp.setInputTarget(tgt)
+    icp.setTargetNormals(onrm)
+    icp.setInputSource(src)
+    icp.reset()
+    sums = icp.iterate(np.eye(4, dtype=np.float32), max_dist=0.1)
+    q, m, d = otree.correspondences(src, 0.1)
+    T, osums, used = orc.lls_point_to_plane(src, tgt, onrm, q, m)
+    assert int(sums[28]) == len(q) == used
+    assert np.allclose(sums[:27], osums, rtol=1e-11, atol=1e-13)   # fp64 sums, different order
+    assert abs(sums[27] - d.astype(np.float64).sum()) <= 1e-12 * len(q)
+    assert np.abs(icp.solve(sums) - T).max() < 1e-6
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_icp_synthetic_100k_vs_oracle(gpu, orc, mode):
+    # BASELINE.json configs 2/3 at a size the oracle finishes in seconds
+    import pcl_amd
+    tgt, src, T_gt = pcl_amd.synth.icp_pair(100_000)
+    otree = orc.KdTree(tgt)
+    normals = otree.normals(tgt, 8, viewpoint=(0, 0, 10))[0] if mode == 1 else None
+    kw = dict(max_iterations=20, max_correspondence_distance=0.1, transformation_epsilon=1e-10)
+    icp, ref = run_icp_pair(gpu, orc, tgt, src, mode, normals=normals, **kw)
+    T = icp.getFinalTransformation().astype(np.float64)
+    assert icp.nr_iterations_ == ref["iterations"]
+    assert np.linalg.norm(T - ref["T"]) < 1e-5, np.linalg.norm(T - ref["T"])
+    assert np.linalg.norm(T - T_gt) < 2e-3  # and it actually registers the clouds
+    # last-iteration correspondences are bit-exact too
+    q, m, d = icp.fetchCorrespondences()
+    row = ref["per_iter_match"][ref["iterations"] - 1]
+    assert np.array_equal(q, np.nonzero(row >= 0)[0]) and np.array_equal(m, row[row >= 0])
+
+
+def test_icp_guess_and_repeated_align(gpu, orc, bunny):
+    import pcl_amd
+    src, tgt = xyz1(bunny["bun0"]), xyz1(bunny["bun4"])
+    th = 0.05
+    G = np.eye(4, dtype=np.float32)
+    G[0, 0] = G[1, 1] = np.cos(th)
+    G[0, 1] = -np.sin(th)
+    G[1, 0] = np.sin(th)
+    G[:3, 3] = (0.01, -0.02, 0.005)
+    icp = pcl_amd.IterativeClosestPoint(gpu)
+    icp.setInputTarget(tgt)
+    icp.setInputSource(src)
+    icp.setMaximumIterations(30)
+    icp.setMaxCorrespondenceDistance(0.05)
+    icp.setTransformationEpsilon(1e-8)
+    conv = orc.new_convergence()
+    for rep in range(2):  # the criteria's previous-MSE memory persists across align() calls
+        icp.align(guess=G)
+        ref = orc.icp_align(orc.KdTree(tgt), tgt, src, mode=0, guess=G, conv=conv, max_iterations=30,
+                            max_correspondence_distance=0.05, transformation_epsilon=1e-8)
+        assert icp.nr_iterations_ == ref["iterations"], rep
+        assert np.linalg.norm(icp.getFinalTransformation().astype(np.float64) - ref["T"]) < 1e-5
+
+
+def test_icp_not_enough_correspondences(gpu, bunny):
+    import pcl_amd
+    src, tgt = xyz1(bunny["bun0"]), xyz1(bunny["bun4"])
+    src[:, 0] += 10.0
+    icp = pcl_amd.IterativeClosestPoint(gpu)
+    icp.setInputTarget(tgt)
+    icp.setInputSource(src)
+    icp.setMaxCorrespondenceDistance(0.01)
+    icp.align()
+    assert not icp.hasConverged() and icp.getConvergenceState() == "NO_CORRESPONDENCES"
+    assert icp.nr_iterations_ == 0
+
+
+def test_point_to_plane_requires_normals(gpu, bunny):
+    import pcl_amd
+    icp = pcl_amd.IterativeClosestPointWithNormals(gpu)
+    icp.setInputTarget(xyz1(bunny["bun4"]))
+    icp.setInputSource(xyz1(bunny["bun0"]))
+    with pytest.raises(pcl_amd.PclHipError):
+        icp.align()
+
+
+def test_transform_cloud_orders_bit_exact(gpu, orc):
+    import pcl_amd
+    rng = np.random.default_rng(9)
+    pts = rng.normal(0, 1, (10000, 4)).astype(np.float32)
+    pts[3, 1] = np.nan
+    T = pcl_amd.synth.ground_truth_transform().astype(np.float32)
+    for cls, order in ((pcl_amd.IterativeClosestPoint, 0), (pcl_amd.IterativeClosestPointWithNormals, 1)):
+        out = cls(gpu).transformCloud(pts, T)
+        ref = orc.transform_cloud(T, pts, order=order)
+        assert np.array_equal(out[:, :3], ref[:, :3], equal_nan=True), order
+
+
+# ------------------------------------------------------------------------------------------------
+# NormalEstimation
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [8, 15, 40])
+def test_normals_vs_oracle(gpu, orc, k):
+    import pcl_amd
+    tgt, _, _ = pcl_amd.synth.icp_pair(60_000)
+    tgt[17] = np.nan
+    ne = pcl_amd.NormalEstimation(gpu)
+    ne.setInputCloud(tgt)
+    ne.setKSearch(k)
+    ne.setViewPoint(0, 0, 10)
+    nrm = ne.compute()
+    onrm, nan = orc.KdTree(tgt).normals(tgt, k, viewpoint=(0, 0, 10))
+    assert ne.nan_count == nan == 1 and np.all(np.isnan(nrm[17]))
+    ok = ~np.isnan(onrm[:, 0])
+    # float eigen-solve with device atan2f/cosf/sinf vs libm: direction within 1e-5 (|dot| >= 1-1e-5
+    # after unit length), same orientation after the viewpoint flip, curvature to 1e-5 absolute
+    dots = np.sum(nrm[ok, :3] * onrm[ok, :3], axis=1)
+    assert dots.min() > 1 - 1e-5, dots.min()
+    assert np.abs(nrm[ok, 3] - onrm[ok, 3]).max() < 1e-5
+    assert np.allclose(np.linalg.norm(nrm[ok, :3], axis=1), 1, atol=1e-5)
+
+
+def test_normals_bunny_translation_invariance(gpu, bunny):
+    # test/features/test_normal_estimation.cpp:287-312
+    import pcl_amd
+    cloud = xyz1(bunny["bun0"])
+    shifted = cloud.copy()
+    shifted[:, :3] += np.array([123, -45, 98], np.float32)
+    outs = []
+    for c, vp in ((cloud, (0, 0, 0)), (shifted, (123, -45, 98))):
+        ne = pcl_amd.NormalEstimation(gpu)
+        ne.setInputCloud(c)
+        ne.setKSearch(15)
+        ne.setViewPoint(*vp)
+        outs.append(ne.compute())
+    assert np.all(np.abs(np.sum(outs[0][:, :3] * outs[1][:, :3], axis=1)) >= 1 - 1e-4)
+
+
+def test_normals_too_few_neighbours(gpu):
+    import pcl_amd
+    pts = np.random.default_rng(2).uniform(0, 1, (2, 3)).astype(np.float32)
+    ne = pcl_amd.NormalEstimation(gpu)
+    ne.setInputCloud(pts)
+    ne.setKSearch(8)
+    nrm = ne.compute()
+    assert np.all(np.isnan(nrm)) and ne.nan_count == 2
+
+
+# ------------------------------------------------------------------------------------------------
+# VoxelGrid
+# ------------------------------------------------------------------------------------------------
+def test_voxelgrid_bunny_golden(gpu, orc, bunny, golden):
+    # test/filters/test_filters.cpp:566-596
+    import pcl_amd
+    g = golden["voxelgrid_bun0"]
+    cloud = xyz1(bunny["bun0"])
+    vg = pcl_amd.VoxelGrid(gpu)
+    vg.setInputCloud(cloud)
+    vg.setLeafSize(g["leaf"])
+    out = vg.filter()
+    assert len(out) == g["count"]
+    assert np.array_equal(out, orc.voxelgrid(cloud, g["leaf"])[0])
+    vg.setFilterFieldName("z")
+    vg.setFilterLimits(g["z_min"], g["z_max"])
+    out = vg.filter()
+    assert len(out) == g["count_z"]
+    assert np.allclose(out[0, :3], g["first_z"], atol=g["tol"])
+    assert np.allclose(out[-1, :3], g["last_z"], atol=g["tol"])
+
+
+def test_voxelgrid_synthetic_bit_exact(gpu, orc):
+    import pcl_amd
+    tgt, _, _ = pcl_amd.synth.icp_pair(300_000)
+    tgt[5] = np.nan
+    for leaf, minpts in ((0.01, 0), (0.05, 0), (0.01, 6)):
+        vg = pcl_amd.VoxelGrid(gpu)
+        vg.setInputCloud(tgt)
+        vg.setLeafSize(leaf)
+        vg.setMinimumPointsNumberPerVoxel(minpts)
+        out = vg.filter()
+        ref, _ = orc.voxelgrid(tgt, leaf, min_points_per_voxel=minpts)
+        assert out.shape == ref.shape and np.array_equal(out, ref), (leaf, minpts)
+
+
+def test_voxelgrid_overflow_refused(gpu):
+    import pcl_amd
+    pts = np.random.default_rng(4).uniform(-1000, 1000, (100, 3)).astype(np.float32)
+    vg = pcl_amd.VoxelGrid(gpu)
+    vg.setInputCloud(pts)
+    vg.setLeafSize(1e-4)
+    with pytest.raises(pcl_amd.PclHipError) as e:
+        vg.filter()
+    assert e.value.status == -5
