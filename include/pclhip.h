@@ -97,6 +97,8 @@ PCLHIP_API pclhip_status pclhip_knn(pclhip_index* index, const void* queries, si
  * The normals are also retained inside the index for point-to-plane ICP.  out_nan_count optional. */
 PCLHIP_API pclhip_status pclhip_normals(pclhip_index* index, int k, const float viewpoint[3],
                                         void* out, size_t out_stride_bytes, uint64_t* out_nan_count);
+/* GPU time (ms) of the last pclhip_knn / pclhip_normals traversal kernel on this index. */
+PCLHIP_API double pclhip_index_last_kernel_ms(const pclhip_index* index);
 /* Supply target normals computed elsewhere (e.g. a pcl::PointNormal target: normals = points + 16,
  * stride 48).  One record per ORIGINAL cloud point. */
 PCLHIP_API pclhip_status pclhip_index_set_normals(pclhip_index* index, const void* normals,
@@ -168,6 +170,10 @@ PCLHIP_API pclhip_status pclhip_icp_reset(pclhip_icp* icp);
  * sums: PCLHIP_ICP_NSUMS doubles on the host. */
 PCLHIP_API pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[16], double max_dist,
                                             int mode, double sums[PCLHIP_ICP_NSUMS]);
+
+/* GPU time (ms, HIP events on the context stream) of the fused search+accumulate kernel of the
+ * last pclhip_icp_iterate call. */
+PCLHIP_API double pclhip_icp_last_kernel_ms(const pclhip_icp* icp);
 
 /* Host-side closed forms on a reduction record (exposed for the adapters and for tests):
  * 6x6 solve + constructTransformationMatrix (…point_to_plane_lls.hpp:132-163,264-268) or umeyama

@@ -70,6 +70,8 @@ SIGNATURES = {
     "pclhip_icp_reset": (C.c_int, [_vp]),
     "pclhip_icp_iterate": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_double, C.c_int,
                                      C.POINTER(C.c_double)]),
+    "pclhip_icp_last_kernel_ms": (C.c_double, [_vp]),
+    "pclhip_index_last_kernel_ms": (C.c_double, [_vp]),
     "pclhip_solve_transformation": (C.c_int, [C.POINTER(C.c_double), C.c_int,
                                               C.POINTER(C.c_float)]),
     "pclhip_icp_align": (C.c_int, [_vp, C.POINTER(IcpParams), C.POINTER(C.c_float),

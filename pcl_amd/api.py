@@ -49,12 +49,24 @@ class Context:
                                          C.byref(h)))
         self.h = h
         self.device = device
+        self._children = []  # weakrefs to objects holding handles that point into this context
+
+    def _adopt(self, obj):
+        import weakref
+        self._children.append(weakref.ref(obj))
 
     def synchronize(self):
         check(self.lib.pclhip_ctx_synchronize(self.h), self.h)
 
     def close(self):
         if getattr(self, "h", None):
+            # handles hold a raw pointer to the context: release them first, whatever order the
+            # interpreter finalises objects in
+            for ref in self._children:
+                obj = ref()
+                if obj is not None:
+                    obj._release()
+            self._children = []
             self.lib.pclhip_ctx_destroy(self.h)
             self.h = None
 
@@ -84,6 +96,10 @@ class KdTree:
         self.h = None
         self._cloud_id = None
         self.n_cloud = 0
+        self.ctx._adopt(self)
+
+    def _release(self):
+        self._free()
 
     def setInputCloud(self, cloud, indices=None):
         # registration.h:214-221 / registration.hpp:84-87: rebuilding for the same cloud is a no-op
@@ -112,6 +128,9 @@ class KdTree:
     def build_ms(self):
         return float(self.lib.pclhip_index_build_ms(self.h))
 
+    def lastKernelMs(self):
+        return float(self.lib.pclhip_index_last_kernel_ms(self.h))
+
     def nearestKSearch(self, queries, k, out=None):
         """Batch overload (search.h:216-219).  Returns (indices int32 [nq,k], sqr_distances [nq,k])."""
         ptr, stride, nq, keep = _cloud(queries)
@@ -135,8 +154,10 @@ class KdTree:
 
     def _free(self):
         if getattr(self, "h", None):
-            self.lib.pclhip_index_destroy(self.h)
+            if self.ctx.h is not None:
+                self.lib.pclhip_index_destroy(self.h)
             self.h = None
+            self._cloud_id = None
 
     def __del__(self):
         try:
@@ -256,6 +277,10 @@ class IterativeClosestPoint:
         self._src_id = None
         self.result = None
         self._allreduce = None
+        self.ctx._adopt(self)
+
+    def _release(self):
+        self._drop_icp()
 
     # --- setters named after registration.h:276-415 ---
     def setInputTarget(self, cloud):
@@ -298,8 +323,9 @@ class IterativeClosestPoint:
             check(self.lib.pclhip_icp_set_allreduce(self.h, self._allreduce, None), self.ctx.h)
 
     def _drop_icp(self):
-        if self.h:
-            self.lib.pclhip_icp_destroy(self.h)
+        if getattr(self, "h", None):
+            if self.ctx.h is not None:
+                self.lib.pclhip_icp_destroy(self.h)
             self.h = None
             self._src_id = None
 
@@ -328,6 +354,9 @@ class IterativeClosestPoint:
     def reset(self):
         self._ensure()
         check(self.lib.pclhip_icp_reset(self.h), self.ctx.h)
+
+    def lastKernelMs(self):
+        return float(self.lib.pclhip_icp_last_kernel_ms(self.h))
 
     def solve(self, sums):
         T = np.zeros(16, np.float32)

@@ -265,7 +265,7 @@ pclhip_status pclhip_index_build(pclhip_ctx* ctx, const void* points, size_t str
     return fail(PCLHIP_ERR_HIP);
   }
   uint32_t nf = 0;
-  st = morton_order(ctx, dpts, stride, n, static_cast<const int32_t*>(dsel), n_indices, ix->pts, cap, &nf, ix->bbox_lo,
+  st = spatial_order(ctx, dpts, stride, n, static_cast<const int32_t*>(dsel), n_indices, ix->pts, cap, &nf, ix->bbox_lo,
                     ix->bbox_hi, false, ix->rank);
   if (st != PCLHIP_OK) return fail(st);
   ix->n = nf;
@@ -322,7 +322,7 @@ pclhip_status pclhip_knn(pclhip_index* ix, const void* queries, size_t stride, u
   guard.add(qs);
   uint32_t nf = 0;
   float lo[3], hi[3];
-  st = morton_order(ctx, dq, stride, nq, nullptr, 0, qs, uint32_t(nq), &nf, lo, hi, true, nullptr);
+  st = spatial_order(ctx, dq, stride, nq, nullptr, 0, qs, uint32_t(nq), &nf, lo, hi, true, nullptr);
   if (st != PCLHIP_OK) return st;
   const size_t cnt = size_t(nq) * size_t(k);
   int32_t* d_idx = out_idx;
@@ -484,7 +484,7 @@ pclhip_status pclhip_icp_set_source(pclhip_icp* icp, const void* points, size_t 
   PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->partials, size_t(icp->grid_blocks) * PCLHIP_ICP_NSUMS * sizeof(double)));
   uint32_t nf = 0;
   float lo[3], hi[3];
-  st = morton_order(ctx, dp, stride, n, nullptr, 0, icp->src_sorted0, uint32_t(n), &nf, lo, hi, true, nullptr);
+  st = spatial_order(ctx, dp, stride, n, nullptr, 0, icp->src_sorted0, uint32_t(n), &nf, lo, hi, true, nullptr);
   if (st != PCLHIP_OK) return st;
   return pclhip_icp_reset(icp);
 }
@@ -537,6 +537,9 @@ pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[16], double
   if (icp->n > 0 && hipEventElapsedTime(&ms, icp->ev0, icp->ev1) == hipSuccess) icp->last_kernel_ms = ms;
   return PCLHIP_OK;
 }
+
+double pclhip_icp_last_kernel_ms(const pclhip_icp* icp) { return icp ? icp->last_kernel_ms : 0.0; }
+double pclhip_index_last_kernel_ms(const pclhip_index* ix) { return ix ? ix->last_kernel_ms : 0.0; }
 
 pclhip_status pclhip_solve_transformation(const double* sums, int mode, float* T) {
   if (!sums || !T) return PCLHIP_ERR_INVALID;

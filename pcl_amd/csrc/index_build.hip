@@ -15,6 +15,9 @@
 #include <rocprim/rocprim.hpp>
 
 #include <cfloat>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
 
 #include "pclhip_internal.hpp"
 
@@ -268,6 +271,284 @@ pclhip_status morton_order(pclhip_ctx* ctx, const void* dev_points, size_t strid
     hi[d] = hb[3 + d];
   }
   return PCLHIP_OK;
+}
+
+
+// =================================================================================================
+// kd ordering by radix-sort rounds
+// =================================================================================================
+// Z-order (Morton) runs of a 2-D surface embedded in 3-D jump: on the benchmark surface the boxes
+// of 16 consecutive Morton-sorted points overlap 4.6x and a few of them span the whole domain, so
+// one wavefront ends up scanning every leaf.  The order produced here has no jumps: R =
+// ceil(log4(#leaves)) rounds, each round sorts every aligned block of LEAF*4^(R-r+1) points along
+// the widest axis of its bounding box (one radix sort of (block id, float coordinate) keys for the
+// whole cloud), so every aligned block of LEAF*4^j points ends up as one cell of a 4-ary kd
+// partition: leaf boxes do not overlap and 64-point query groups are compact.
+namespace {
+
+constexpr int KD_CHUNK_MAX = 4096;
+
+// one wavefront per chunk of `chunk` consecutive points -> chunk box
+__global__ __launch_bounds__(256) void kd_chunk_box_kernel(const float4* __restrict__ pts, uint32_t n, uint32_t chunk,
+                                                           uint32_t nchunks, Box* __restrict__ out) {
+  const uint32_t c = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const uint32_t lane = threadIdx.x & 63;
+  if (c >= nchunks) return;
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  const uint64_t b = uint64_t(c) * chunk;
+  uint64_t e = b + chunk;
+  if (e > n) e = n;
+  for (uint64_t i = b + lane; i < e; i += WAVE) {
+    const float4 p = pts[i];
+    lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+    hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = wave_min(lo[d]);
+    hi[d] = wave_max(hi[d]);
+  }
+  if (lane == 0) {
+    Box bx;
+    bx.lo = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    bx.hi = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    out[c] = bx;
+  }
+}
+
+// one wavefront per segment: reduce its chunk boxes, pick the widest axis
+__global__ __launch_bounds__(256) void kd_axis_kernel(const Box* __restrict__ chunk_box, uint32_t nchunks,
+                                                      uint32_t chunks_per_seg, uint32_t nseg,
+                                                      uint8_t* __restrict__ axis) {
+  const uint32_t sgm = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const uint32_t lane = threadIdx.x & 63;
+  if (sgm >= nseg) return;
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  const uint64_t b = uint64_t(sgm) * chunks_per_seg;
+  uint64_t e = b + chunks_per_seg;
+  if (e > nchunks) e = nchunks;
+  for (uint64_t i = b + lane; i < e; i += WAVE) {
+    const Box bx = chunk_box[i];
+    lo[0] = fminf(lo[0], bx.lo.x); lo[1] = fminf(lo[1], bx.lo.y); lo[2] = fminf(lo[2], bx.lo.z);
+    hi[0] = fmaxf(hi[0], bx.hi.x); hi[1] = fmaxf(hi[1], bx.hi.y); hi[2] = fmaxf(hi[2], bx.hi.z);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = wave_min(lo[d]);
+    hi[d] = wave_max(hi[d]);
+  }
+  if (lane == 0) {
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    uint8_t a = 0;
+    float best = ex;
+    if (ey > best) { best = ey; a = 1; }
+    if (ez > best) { a = 2; }
+    axis[sgm] = a;
+  }
+}
+
+__device__ __forceinline__ uint32_t orderable(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void kd_key_kernel(const float4* __restrict__ pts, uint32_t n, uint64_t seg_size,
+                                                     const uint8_t* __restrict__ axis, uint64_t* __restrict__ keys,
+                                                     uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t sgm = uint32_t(uint64_t(i) / seg_size);
+  const float4 p = pts[i];
+  const uint8_t a = axis[sgm];
+  const float c = a == 0 ? p.x : (a == 1 ? p.y : p.z);
+  keys[i] = (uint64_t(sgm) << 32) | orderable(c);
+  vals[i] = i;
+}
+
+__global__ __launch_bounds__(256) void kd_permute_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ vals,
+                                                         uint32_t n, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[vals[i]];
+}
+
+// initial compaction: finite selected records first (stable), non-finite ones after them
+__global__ __launch_bounds__(256) void kd_flag_kernel(const void* pts, size_t stride, const int32_t* sel, uint64_t m,
+                                                      uint32_t* keys, uint32_t* vals, unsigned int* n_finite) {
+  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  bool fin = false;
+  if (i < m) {
+    const uint64_t rec = sel ? uint64_t(sel[i]) : i;
+    const float* p = record(pts, stride, rec);
+    fin = isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]);
+    keys[i] = fin ? 0u : 1u;
+    vals[i] = uint32_t(rec);
+  }
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(fin);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_finite, (unsigned int)__builtin_popcountll(b));
+}
+
+__global__ __launch_bounds__(256) void kd_load_kernel(const void* pts, size_t stride, const uint32_t* vals, uint64_t m,
+                                                      float4* out) {
+  const uint64_t j = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  if (j >= m) return;
+  const uint32_t rec = vals[j];
+  const float* p = record(pts, stride, rec);
+  out[j] = make_float4(p[0], p[1], p[2], __uint_as_float(rec));
+}
+
+__global__ __launch_bounds__(256) void kd_finish_kernel(const float4* __restrict__ in, uint64_t live, uint32_t nf,
+                                                        float4* __restrict__ out, uint32_t out_cap,
+                                                        uint32_t* __restrict__ rank) {
+  const uint64_t j = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  if (j >= out_cap) return;
+  if (j < live) {
+    const float4 p = in[j];
+    out[j] = p;
+    if (rank && j < nf) rank[__float_as_uint(p.w)] = uint32_t(j);
+  } else {
+    out[j] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(NO_INDEX));
+  }
+}
+
+}  // namespace
+
+pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
+                       const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
+                       uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
+                       uint32_t* rank_or_null) {
+  hipStream_t s = ctx->stream;
+  const uint64_t m = dev_sel ? n_sel : n_records;
+  for (int d = 0; d < 3; ++d) lo[d] = hi[d] = 0;
+  *out_n_finite = 0;
+  if (rank_or_null && n_records) PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(rank_or_null, 0xFF, n_records * sizeof(uint32_t), s));
+  if (m == 0) {
+    if (out_capacity)
+      hipLaunchKernelGGL(kd_finish_kernel, dim3((out_capacity + 255) / 256), dim3(256), 0, s, (const float4*)nullptr,
+                         uint64_t(0), 0u, out_sorted, out_capacity, (uint32_t*)nullptr);
+    PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+    return PCLHIP_OK;
+  }
+  size_t temp_bytes = 0, temp32 = 0;
+  {
+    uint64_t* kn = nullptr;
+    uint32_t* vn = nullptr;
+    PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, kn, kn, vn, vn, size_t(m), 0, 64, s));
+    PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp32, vn, vn, vn, vn, size_t(m), 0, 1, s));
+    if (temp32 > temp_bytes) temp_bytes = temp32;
+  }
+  auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
+  const uint32_t max_chunks = uint32_t((m + 63) / 64);
+  const size_t off_k0 = 0;
+  const size_t off_k1 = off_k0 + align(m * sizeof(uint64_t));
+  const size_t off_v0 = off_k1 + align(m * sizeof(uint64_t));
+  const size_t off_v1 = off_v0 + align(m * sizeof(uint32_t));
+  const size_t off_pa = off_v1 + align(m * sizeof(uint32_t));
+  const size_t off_pb = off_pa + align(m * sizeof(float4));
+  const size_t off_cb = off_pb + align(m * sizeof(float4));
+  const size_t off_ax = off_cb + align(size_t(max_chunks) * sizeof(Box));
+  const size_t off_cn = off_ax + align(size_t(max_chunks));
+  const size_t off_tmp = off_cn + align(sizeof(unsigned int));
+  const size_t total = off_tmp + align(temp_bytes);
+  pclhip_status st = ensure_scratch(ctx, total);
+  if (st != PCLHIP_OK) return st;
+  char* base = static_cast<char*>(ctx->scratch);
+  uint64_t* k0 = reinterpret_cast<uint64_t*>(base + off_k0);
+  uint64_t* k1 = reinterpret_cast<uint64_t*>(base + off_k1);
+  uint32_t* v0 = reinterpret_cast<uint32_t*>(base + off_v0);
+  uint32_t* v1 = reinterpret_cast<uint32_t*>(base + off_v1);
+  float4* pa = reinterpret_cast<float4*>(base + off_pa);
+  float4* pb = reinterpret_cast<float4*>(base + off_pb);
+  Box* cb = reinterpret_cast<Box*>(base + off_cb);
+  uint8_t* ax = reinterpret_cast<uint8_t*>(base + off_ax);
+  unsigned int* cn = reinterpret_cast<unsigned int*>(base + off_cn);
+  void* tmp = base + off_tmp;
+
+  // --- compaction: finite records first (stable 1-bit sort of (flag, record)) ---
+  uint32_t* f0 = reinterpret_cast<uint32_t*>(k0);
+  uint32_t* f1 = reinterpret_cast<uint32_t*>(k1);
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(cn, 0, sizeof(unsigned int), s));
+  hipLaunchKernelGGL(kd_flag_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride, dev_sel, m, f0, v0,
+                     cn);
+  PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, temp_bytes, f0, f1, v0, v1, size_t(m), 0, 1, s));
+  hipLaunchKernelGGL(kd_load_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride, v1, m, pa);
+  unsigned int hn = 0;
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&hn, cn, sizeof hn, hipMemcpyDeviceToHost, s));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  const uint32_t nf = hn;
+  *out_n_finite = nf;
+
+  // --- kd rounds over the finite prefix ---
+  float4* cur = pa;
+  float4* nxt = pb;
+  if (nf > 0) {
+    const uint64_t nleaf = (uint64_t(nf) + LEAF - 1) / LEAF;
+    int R = 0;
+    uint64_t cap = 1;
+    while (cap < nleaf) {
+      cap *= 4;
+      ++R;
+    }
+    // round 0 (no sort) only measures the bounding box of everything for the caller
+    for (int r = 0; r <= R; ++r) {
+      // segment being split this round (r = 0: one segment covering all points, bbox only)
+      uint64_t seg_size = uint64_t(LEAF);
+      for (int j = 0; j < R - r + 1; ++j) seg_size *= 4;
+      if (r == 0) seg_size = uint64_t(LEAF) * cap * 4;
+      uint32_t chunk = seg_size < uint64_t(KD_CHUNK_MAX) ? uint32_t(seg_size) : uint32_t(KD_CHUNK_MAX);
+      const uint32_t nchunks = uint32_t((uint64_t(nf) + chunk - 1) / chunk);
+      const uint32_t chunks_per_seg = uint32_t(seg_size / chunk);
+      const uint32_t nseg = uint32_t((uint64_t(nf) + seg_size - 1) / seg_size);
+      hipLaunchKernelGGL(kd_chunk_box_kernel, dim3(unsigned((uint64_t(nchunks) * WAVE + 255) / 256)), dim3(256), 0, s, cur,
+                         nf, chunk, nchunks, cb);
+      if (r == 0) {
+        // nseg == 1: reduce on the host (tiny)
+        std::vector<Box> hb(nchunks);
+        PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(hb.data(), cb, size_t(nchunks) * sizeof(Box), hipMemcpyDeviceToHost, s));
+        PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+        float l[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, h[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (const Box& b : hb) {
+          l[0] = std::fmin(l[0], b.lo.x); l[1] = std::fmin(l[1], b.lo.y); l[2] = std::fmin(l[2], b.lo.z);
+          h[0] = std::fmax(h[0], b.hi.x); h[1] = std::fmax(h[1], b.hi.y); h[2] = std::fmax(h[2], b.hi.z);
+        }
+        for (int d = 0; d < 3; ++d) {
+          lo[d] = l[d];
+          hi[d] = h[d];
+        }
+        continue;
+      }
+      hipLaunchKernelGGL(kd_axis_kernel, dim3(unsigned((uint64_t(nseg) * WAVE + 255) / 256)), dim3(256), 0, s, cb, nchunks,
+                         chunks_per_seg, nseg, ax);
+      hipLaunchKernelGGL(kd_key_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, cur, nf, seg_size, ax, k0, v0);
+      int seg_bits = 0;
+      while ((uint64_t(1) << seg_bits) < uint64_t(nseg)) ++seg_bits;
+      PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, temp_bytes, k0, k1, v0, v1, size_t(nf), 0, 32 + seg_bits, s));
+      hipLaunchKernelGGL(kd_permute_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, cur, v1, nf, nxt);
+      // the non-finite tail (if kept) rides along unchanged
+      if (keep_nonfinite_at_end && m > nf)
+        PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(nxt + nf, cur + nf, (m - nf) * sizeof(float4), hipMemcpyDeviceToDevice, s));
+      float4* t = cur;
+      cur = nxt;
+      nxt = t;
+    }
+  }
+  const uint64_t live = keep_nonfinite_at_end ? m : nf;
+  hipLaunchKernelGGL(kd_finish_kernel, dim3((out_capacity + 255) / 256), dim3(256), 0, s, cur, live, nf, out_sorted,
+                     out_capacity, rank_or_null);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  return PCLHIP_OK;
+}
+
+pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
+                            const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
+                            uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
+                            uint32_t* rank_or_null) {
+  const char* e = getenv("PCLHIP_ORDER");
+  if (e && strcmp(e, "morton") == 0)
+    return morton_order(ctx, dev_points, stride, n_records, dev_sel, n_sel, out_sorted, out_capacity, out_n_finite, lo, hi,
+                        keep_nonfinite_at_end, rank_or_null);
+  return kd_order(ctx, dev_points, stride, n_records, dev_sel, n_sel, out_sorted, out_capacity, out_n_finite, lo, hi,
+                  keep_nonfinite_at_end, rank_or_null);
 }
 
 pclhip_status build_boxes(pclhip_index* ix) {

@@ -72,6 +72,7 @@ struct pclhip_index {
   int top = 0;
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
   double build_ms = 0;
+  double last_kernel_ms = 0;
   bool has_normals = false;
   pclhip::IndexView view() const;
 };
@@ -132,6 +133,16 @@ pclhip_status morton_order(pclhip_ctx* ctx, const void* dev_points, size_t strid
                            const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted,
                            uint32_t out_capacity, uint32_t* out_n_finite, float lo[3], float hi[3],
                            bool keep_nonfinite_at_end, uint32_t* rank_or_null);
+// Same contract, kd order by radix-sort rounds (the production order; see index_build.hip).
+pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
+                       const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
+                       uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
+                       uint32_t* rank_or_null);
+// dispatches on PCLHIP_ORDER=morton|kd (default kd); morton is kept for A/B measurements only
+pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
+                            const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
+                            uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
+                            uint32_t* rank_or_null);
 pclhip_status build_boxes(pclhip_index* ix);
 int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns);
 

@@ -122,6 +122,18 @@ pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, 
   const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
   const IndexView v = ix->view();
   hipStream_t s = ctx->stream;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, s);
+  struct Timer {
+    pclhip_index* ix; hipEvent_t a, b; hipStream_t s;
+    ~Timer() {
+      (void)hipEventRecord(b, s);
+      if (hipEventSynchronize(b) == hipSuccess) { float ms = 0; if (hipEventElapsedTime(&ms, a, b) == hipSuccess) ix->last_kernel_ms = ms; }
+      (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    }
+  } timer{ix, e0, e1, s};
   if (k == 1) {
     const int grid = persistent_blocks(ctx, ngroups, 8);
     hipLaunchKernelGGL(knn_reg_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2);
@@ -419,6 +431,10 @@ pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(ix->nrm, 0xFF, size_t(ix->n_pad) * sizeof(float4), s));  // NaN pads
   const IndexView v = ix->view();
   const uint32_t ngroups = (ix->n + WAVE - 1) / WAVE;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, s);
   if (ix->n > 0) {
     if (k <= 8) {
       hipLaunchKernelGGL(normals_kernel<8>, dim3(persistent_blocks(ctx, ngroups, 6)), dim3(BLOCK), 0, s, v, k, vp[0],
@@ -449,7 +465,14 @@ pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_
       PCLHIP_CHECK_HIP(ctx, e);
     }
   }
+  (void)hipEventRecord(e1, s);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  if (hipEventSynchronize(e1) == hipSuccess) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ix->last_kernel_ms = ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   unsigned long long h = 0;
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&h, d_nan, sizeof h, hipMemcpyDeviceToHost, s));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));

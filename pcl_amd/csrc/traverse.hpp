@@ -329,7 +329,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, float qx, float qy
 struct GroupSchedule {
   uint32_t groups_per_xcd, xcd_first, slot_wave, waves_per_xcd;
   __device__ __forceinline__ GroupSchedule(uint32_t ngroups) {
-    const uint32_t nxcd = 8;
+    const uint32_t nxcd = gridDim.x < 8u ? gridDim.x : 8u;  // partitions = XCDs that own a block
     const uint32_t xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
     const uint32_t slots = (gridDim.x + nxcd - 1 - xcd) / nxcd;  // blocks on this XCD
     const uint32_t waves_per_block = blockDim.x / WAVE;

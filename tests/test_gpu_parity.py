@@ -341,11 +341,45 @@ def test_icp_synthetic_100k_vs_oracle(gpu, orc, mode):
     T = icp.getFinalTransformation().astype(np.float64)
     assert icp.nr_iterations_ == ref["iterations"]
     assert np.linalg.norm(T - ref["T"]) < 1e-5, np.linalg.norm(T - ref["T"])
-    assert np.linalg.norm(T - T_gt) < 2e-3  # and it actually registers the clouds
-    # last-iteration correspondences are bit-exact too
+    # and it actually registers the clouds (point-to-point slides slowly along the surface: after
+    # 20 iterations it is only part of the way, point-to-plane is there in a handful)
+    assert np.linalg.norm(T - T_gt) < (2e-3 if mode == 1 else 2e-2)
+    # Last-iteration correspondences: the GPU solved every iteration from fp64 tree-reduced sums,
+    # the oracle from its own (float for umeyama / serial double for LLS) sums, so the two working
+    # clouds differ in the last float bits and a few near-equidistant matches may flip.  (Bit-exact
+    # per-iteration parity under IDENTICAL transforms is test_icp_per_iteration_* / *_driven_*.)
     q, m, d = icp.fetchCorrespondences()
     row = ref["per_iter_match"][ref["iterations"] - 1]
-    assert np.array_equal(q, np.nonzero(row >= 0)[0]) and np.array_equal(m, row[row >= 0])
+    assert np.array_equal(q, np.nonzero(row >= 0)[0])
+    assert np.mean(m == row[row >= 0]) > 0.999
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_icp_synthetic_driven_by_oracle_transforms_bit_exact(gpu, orc, mode):
+    # same clouds, but every GPU iteration is fed the ORACLE's transform: all matches bit-exact
+    import pcl_amd
+    tgt, src, _ = pcl_amd.synth.icp_pair(100_000)
+    otree = orc.KdTree(tgt)
+    normals = otree.normals(tgt, 8, viewpoint=(0, 0, 10))[0] if mode == 1 else None
+    ref = orc.icp_align(otree, tgt, src, mode=mode, tgt_normals=normals, record=True, max_iterations=6,
+                        max_correspondence_distance=0.1, transformation_epsilon=1e-10)
+    cls = pcl_amd.IterativeClosestPointWithNormals if mode == 1 else pcl_amd.IterativeClosestPoint
+    icp = cls(gpu)
+    icp.setInputTarget(tgt)
+    if normals is not None:
+        icp.setTargetNormals(normals)
+    icp.setInputSource(src)
+    icp.reset()
+    T_prev = np.eye(4, dtype=np.float32)
+    for it in range(ref["iterations"]):
+        sums = icp.iterate(T_prev, max_dist=0.1)
+        q, m, d = icp.fetchCorrespondences()
+        row = ref["per_iter_match"][it]
+        assert np.array_equal(q, np.nonzero(row >= 0)[0]), it
+        assert np.array_equal(m, row[row >= 0]), it
+        # float-sum umeyama (mode 0) carries ~1e-5 noise at 1e5 points; LLS sums are double
+        assert np.abs(icp.solve(sums) - ref["per_iter_T"][it]).max() < (2e-5 if mode == 0 else 1e-6), it
+        T_prev = ref["per_iter_T"][it]
 
 
 def test_icp_guess_and_repeated_align(gpu, orc, bunny):
