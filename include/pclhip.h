@@ -58,6 +58,11 @@ PCLHIP_API void pclhip_ctx_destroy(pclhip_ctx* ctx);
 PCLHIP_API const char* pclhip_last_error(const pclhip_ctx* ctx /* may be NULL */);
 PCLHIP_API pclhip_status pclhip_ctx_synchronize(pclhip_ctx* ctx);
 PCLHIP_API const char* pclhip_version(void);
+/* Optional traversal work counters (diagnostics): enable != 0 allocates/zeroes 8 device counters
+ * that every search kernel of this context adds to; out (8 x uint64, may be NULL) receives the
+ * current values: [0] interior nodes scanned, [1] leaves past the group test, [2] leaves past the
+ * per-lane test (16-candidate all-pairs blocks), [3] stack pushes, [4] 64-query groups. */
+PCLHIP_API pclhip_status pclhip_ctx_stats(pclhip_ctx* ctx, int enable, uint64_t* out);
 
 /* ---- spatial index over the target cloud ------------------------------------------------------
  * Replaces pcl::KdTreeFLANN<PointT>::setInputCloud (kdtree/include/pcl/kdtree/impl/

@@ -55,6 +55,7 @@ SIGNATURES = {
     "pclhip_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
     "pclhip_ctx_destroy": (None, [_vp]),
     "pclhip_ctx_synchronize": (C.c_int, [_vp]),
+    "pclhip_ctx_stats": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64)]),
     "pclhip_index_build": (C.c_int, [_vp, _vp, _sz, _u64, _vp, _u64, C.POINTER(_vp)]),
     "pclhip_index_destroy": (None, [_vp]),
     "pclhip_index_size": (_u64, [_vp]),

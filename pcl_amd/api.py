@@ -58,6 +58,13 @@ class Context:
     def synchronize(self):
         check(self.lib.pclhip_ctx_synchronize(self.h), self.h)
 
+    def stats(self, enable=True):
+        """Read (then re-arm or disable) the traversal work counters."""
+        out = (C.c_uint64 * 8)()
+        check(self.lib.pclhip_ctx_stats(self.h, int(enable), out), self.h)
+        names = ("nodes", "leaves_group", "leaves_allpairs", "pushes", "groups")
+        return {n: int(out[i]) for i, n in enumerate(names)}
+
     def close(self):
         if getattr(self, "h", None):
             # handles hold a raw pointer to the context: release them first, whatever order the

@@ -212,9 +212,30 @@ void pclhip_ctx_destroy(pclhip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->stats) (void)hipFree(ctx->stats);
   if (ctx->staging) (void)hipFree(ctx->staging);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+pclhip_status pclhip_ctx_stats(pclhip_ctx* ctx, int enable, uint64_t* out) {
+  if (!ctx) return PCLHIP_ERR_INVALID;
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (out) {
+    if (ctx->stats)
+      PCLHIP_CHECK_HIP(ctx, hipMemcpy(out, ctx->stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    else
+      std::memset(out, 0, 8 * sizeof(uint64_t));
+  }
+  if (enable) {
+    if (!ctx->stats) PCLHIP_CHECK_HIP(ctx, hipMalloc(&ctx->stats, 8 * sizeof(uint64_t)));
+    PCLHIP_CHECK_HIP(ctx, hipMemset(ctx->stats, 0, 8 * sizeof(uint64_t)));
+  } else if (ctx->stats) {
+    (void)hipFree(ctx->stats);
+    ctx->stats = nullptr;
+  }
+  return PCLHIP_OK;
 }
 
 pclhip_status pclhip_ctx_synchronize(pclhip_ctx* ctx) {
@@ -291,6 +312,7 @@ void pclhip_index_destroy(pclhip_index* ix) {
     (void)hipStreamSynchronize(ix->ctx->stream);
   }
   if (ix->pts) (void)hipFree(ix->pts);
+  if (ix->soa) (void)hipFree(ix->soa);
   if (ix->nrm) (void)hipFree(ix->nrm);
   if (ix->rank) (void)hipFree(ix->rank);
   for (int l = 0; l < MAX_LEVELS; ++l)
@@ -436,10 +458,12 @@ static void icp_free_source(pclhip_icp* icp) {
   if (icp->src_sorted0) (void)hipFree(icp->src_sorted0);
   if (icp->src_cur) (void)hipFree(icp->src_cur);
   if (icp->match) (void)hipFree(icp->match);
+  if (icp->match_pos) (void)hipFree(icp->match_pos);
   if (icp->match_d2) (void)hipFree(icp->match_d2);
   if (icp->partials) (void)hipFree(icp->partials);
   icp->src_sorted0 = icp->src_cur = nullptr;
   icp->match = nullptr;
+  icp->match_pos = nullptr;
   icp->match_d2 = nullptr;
   icp->partials = nullptr;
 }
@@ -480,6 +504,7 @@ pclhip_status pclhip_icp_set_source(pclhip_icp* icp, const void* points, size_t 
   PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->src_sorted0, cap * sizeof(float4)));
   PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->src_cur, cap * sizeof(float4)));
   PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->match, cap * sizeof(uint32_t)));
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->match_pos, cap * sizeof(uint32_t)));
   PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->match_d2, cap * sizeof(float)));
   PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->partials, size_t(icp->grid_blocks) * PCLHIP_ICP_NSUMS * sizeof(double)));
   uint32_t nf = 0;
@@ -499,9 +524,12 @@ pclhip_status pclhip_icp_set_allreduce(pclhip_icp* icp, pclhip_allreduce_fn fn, 
 pclhip_status pclhip_icp_reset(pclhip_icp* icp) {
   if (!icp) return PCLHIP_ERR_INVALID;
   pclhip_ctx* ctx = icp->ctx;
-  if (icp->n > 0)
+  if (icp->n > 0) {
     PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(icp->src_cur, icp->src_sorted0, size_t(icp->n) * sizeof(float4),
                                          hipMemcpyDeviceToDevice, ctx->stream));
+    // no seeds from a previous alignment: the first iteration searches from scratch
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(icp->match_pos, 0xFF, size_t(icp->n) * sizeof(uint32_t), ctx->stream));
+  }
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PCLHIP_OK;
 }

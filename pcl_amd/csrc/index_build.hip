@@ -168,6 +168,17 @@ __global__ __launch_bounds__(256) void leaf_box_kernel(const float4* pts, uint32
   }
 }
 
+// per-leaf structure-of-arrays copy of the coordinates
+__global__ __launch_bounds__(256) void leaf_soa_kernel(const float4* pts, uint32_t n_pad, float* soa) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;
+  const float4 p = pts[i];
+  float* l = soa + size_t(i / LEAF) * (3 * LEAF) + (i % LEAF);
+  l[0] = p.x;
+  l[LEAF] = p.y;
+  l[2 * LEAF] = p.z;
+}
+
 // one wavefront per parent node
 __global__ __launch_bounds__(256) void node_box_kernel(const Box* child, uint32_t nchild, Box* parent, uint32_t nparent) {
   const uint32_t node = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
@@ -573,6 +584,10 @@ pclhip_status build_boxes(pclhip_index* ix) {
     if (l == 1) {
       const uint32_t threads = c * LEAF;
       hipLaunchKernelGGL(leaf_box_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c, ix->box[1]);
+      if (ix->soa) (void)hipFree(ix->soa);
+      ix->soa = nullptr;
+      PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->soa, size_t(c) * 3 * LEAF * sizeof(float)));
+      hipLaunchKernelGGL(leaf_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, threads, ix->soa);
     } else {
       const uint64_t threads = uint64_t(c) * WAVE;
       hipLaunchKernelGGL(node_box_kernel, dim3(unsigned((threads + 255) / 256)), dim3(256), 0, s, ix->box[l - 1],
@@ -592,6 +607,7 @@ pclhip_status build_boxes(pclhip_index* ix) {
 pclhip::IndexView pclhip_index::view() const {
   pclhip::IndexView v;
   v.pts = pts;
+  v.soa = soa;
   v.nrm = nrm;
   for (int l = 0; l < pclhip::MAX_LEVELS; ++l) {
     v.box[l] = box[l];

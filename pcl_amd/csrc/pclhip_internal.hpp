@@ -4,6 +4,8 @@
 //   pts   [n_pad]  float4   target points in 63-bit Morton order; .w = original index (bit cast).
 //                           n_pad = n rounded up to a whole leaf; pad slots hold +FLT_MAX
 //                           sentinels with index 0xFFFFFFFF (distance overflows to +inf).
+//   soa   [n1][3*LEAF] float same coordinates, per leaf x[16] y[16] z[16]: one leaf = 3 scalar
+//                           s_load_dwordx16, candidate pairs feed v_pk_* ops straight from SGPRs.
 //   nrm   [n_pad]  float4   (nx,ny,nz,curvature) in the same order (optional).
 //   box[1][n1]     Box      tight AABB of every leaf = LEAF consecutive sorted points.
 //   box[l][n_l]    Box      AABB of FANOUT consecutive boxes of level l-1 (implicit wide BVH:
@@ -36,6 +38,7 @@ struct Box {       // 32 B: two aligned float4 loads
 // Device-visible view of an index (passed to kernels by value).
 struct IndexView {
   const float4* pts;
+  const float* soa;             // per leaf: x[LEAF], y[LEAF], z[LEAF] (scalar-load friendly copy)
   const float4* nrm;
   const Box* box[MAX_LEVELS];   // box[1] = leaves
   uint32_t count[MAX_LEVELS];   // boxes per level
@@ -55,6 +58,7 @@ struct pclhip_ctx {
   // reusable scratch
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  unsigned long long* stats = nullptr;  // 8 work counters (device), non-null when enabled
   void* staging = nullptr;  // device staging for host inputs
   size_t staging_bytes = 0;
 };
@@ -65,6 +69,7 @@ struct pclhip_index {
   uint32_t n = 0;       // finite, selected points
   uint32_t n_pad = 0;
   float4* pts = nullptr;
+  float* soa = nullptr;
   float4* nrm = nullptr;
   uint32_t* rank = nullptr;
   pclhip::Box* box[pclhip::MAX_LEVELS] = {};
@@ -85,6 +90,7 @@ struct pclhip_icp {
   float4* src_sorted0 = nullptr;   // Morton-ordered input (w = original index), pristine
   float4* src_cur = nullptr;       // working copy (input_transformed)
   uint32_t* match = nullptr;       // per sorted source slot: ORIGINAL target index or NO_INDEX
+  uint32_t* match_pos = nullptr;   // ... and its sorted position (seed of the next iteration)
   float* match_d2 = nullptr;
   double* partials = nullptr;      // [blocks][NSUMS]
   double* sums_dev = nullptr;      // [NSUMS]

@@ -24,11 +24,12 @@ constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
 template <int K>
 __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const float4* __restrict__ q,
                                                         uint32_t nq, int k, int32_t* __restrict__ out_idx,
-                                                        float* __restrict__ out_d2) {
+                                                        float* __restrict__ out_d2, unsigned long long* gstats) {
   __shared__ uint2 stack_s[WAVES_PER_BLOCK][STACK_ENTRIES];
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups);
+  TraverseStats ts;
   for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
     const uint32_t g = sched.global(gl);
     if (g >= ngroups) break;
@@ -40,9 +41,18 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
     const bool real = valid;  // has an output row
     valid = valid && isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
     if constexpr (K == 1) {
+      NN1Min fast;
+      fast.init(__builtin_inff());
+      traverse(ix, p.x, p.y, p.z, valid, fast, stack_s[threadIdx.x / WAVE], ts);
       NN1 pol;
-      pol.init(KEY_NONE);
-      traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE]);
+      fast.resolve(ix, p.x, p.y, p.z, pol.key, pol.pos);
+      // exactness: cross-leaf distance ties, or nothing below +inf although the index is not empty
+      const bool redo = valid && (fast.tie || fast.bestleaf == NO_INDEX);
+      if (__builtin_amdgcn_ballot_w64(redo) != 0) {
+        NN1 ex = pol;
+        traverse(ix, p.x, p.y, p.z, redo, ex, stack_s[threadIdx.x / WAVE], ts);
+        if (redo) pol = ex;
+      }
       if (real) {
         const uint32_t id = key_index(pol.key);
         out_idx[size_t(oq) * k] = (id == NO_INDEX) ? -1 : int32_t(id);
@@ -55,7 +65,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
     } else {
       TopKReg<K> pol;
       pol.init(KEY_NONE);
-      traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE]);
+      traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE], ts);
       if (real) {
 #pragma unroll
         for (int c = 0; c < K; ++c) {
@@ -68,15 +78,17 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
       }
     }
   }
+  flush_stats(ts, gstats);
 }
 
 __global__ __launch_bounds__(BLOCK) void knn_heap_kernel(IndexView ix, const float4* __restrict__ q,
                                                          uint32_t nq, int k, int32_t* __restrict__ out_idx,
-                                                         float* __restrict__ out_d2, uint64_t* heap) {
+                                                         float* __restrict__ out_d2, uint64_t* heap, unsigned long long* gstats) {
   __shared__ uint2 stack_s[WAVES_PER_BLOCK][STACK_ENTRIES];
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups);
+  TraverseStats ts;
   for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
     const uint32_t g = sched.global(gl);
     if (g >= ngroups) break;
@@ -93,7 +105,7 @@ __global__ __launch_bounds__(BLOCK) void knn_heap_kernel(IndexView ix, const flo
     pol.k = real ? k : 0;
     pol.init(KEY_NONE);
     if (!valid) pol.root = 0;  // lanes without a finite query never insert (key < 0 is impossible)
-    traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE]);
+    traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE], ts);
     if (real) {
       pol.sort_ascending();
       for (int c = 0; c < k; ++c) {
@@ -104,6 +116,7 @@ __global__ __launch_bounds__(BLOCK) void knn_heap_kernel(IndexView ix, const flo
       }
     }
   }
+  flush_stats(ts, gstats);
 }
 
 static int persistent_blocks(pclhip_ctx* ctx, uint32_t ngroups, int blocks_per_cu) {
@@ -113,6 +126,22 @@ static int persistent_blocks(pclhip_ctx* ctx, uint32_t ngroups, int blocks_per_c
   int64_t b = want < cap ? want : cap;
   if (b < 1) b = 1;
   return int(b);
+}
+
+// Persistent grid = what is actually co-resident (occupancy query), so no block waits for a free
+// slot while the others are already through their share of the groups.
+template <class K>
+static int resident_blocks(pclhip_ctx* ctx, K kernel, uint32_t ngroups) {
+  static int per_cu = 0;  // one static per kernel instantiation
+  if (per_cu == 0) {
+    int v = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, BLOCK, 0) != hipSuccess || v < 1) {
+      (void)hipGetLastError();
+      v = 2;
+    }
+    per_cu = v;
+  }
+  return persistent_blocks(ctx, ngroups, per_cu);
 }
 
 pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, int k, int32_t* out_idx,
@@ -135,24 +164,24 @@ pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, 
     }
   } timer{ix, e0, e1, s};
   if (k == 1) {
-    const int grid = persistent_blocks(ctx, ngroups, 8);
-    hipLaunchKernelGGL(knn_reg_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2);
+    const int grid = resident_blocks(ctx, knn_reg_kernel<1>, ngroups);
+    hipLaunchKernelGGL(knn_reg_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2, ctx->stats);
   } else if (k <= 8) {
-    const int grid = persistent_blocks(ctx, ngroups, 6);
-    hipLaunchKernelGGL(knn_reg_kernel<8>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2);
+    const int grid = resident_blocks(ctx, knn_reg_kernel<8>, ngroups);
+    hipLaunchKernelGGL(knn_reg_kernel<8>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2, ctx->stats);
   } else if (k <= 16) {
-    const int grid = persistent_blocks(ctx, ngroups, 4);
-    hipLaunchKernelGGL(knn_reg_kernel<16>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2);
+    const int grid = resident_blocks(ctx, knn_reg_kernel<16>, ngroups);
+    hipLaunchKernelGGL(knn_reg_kernel<16>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2, ctx->stats);
   } else if (k <= 32) {
-    const int grid = persistent_blocks(ctx, ngroups, 2);
-    hipLaunchKernelGGL(knn_reg_kernel<32>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2);
+    const int grid = resident_blocks(ctx, knn_reg_kernel<32>, ngroups);
+    hipLaunchKernelGGL(knn_reg_kernel<32>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2, ctx->stats);
   } else {
     const size_t bytes = size_t(nq) * size_t(k) * sizeof(uint64_t);
     uint64_t* heap = nullptr;
     PCLHIP_CHECK_HIP(ctx, hipMalloc(&heap, bytes));
-    const int grid = persistent_blocks(ctx, ngroups, 4);
+    const int grid = resident_blocks(ctx, knn_heap_kernel, ngroups);
     hipLaunchKernelGGL(knn_heap_kernel, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2,
-                       heap);
+                       heap, ctx->stats);
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(heap);
     PCLHIP_CHECK_HIP(ctx, e);
@@ -327,11 +356,13 @@ __device__ __forceinline__ void flip_to_viewpoint(float px, float py, float pz, 
 template <int K>
 __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, float vx, float vy, float vz,
                                                         float4* __restrict__ nrm_sorted,
-                                                        unsigned long long* __restrict__ nan_count) {
+                                                        unsigned long long* __restrict__ nan_count,
+                                                        unsigned long long* gstats) {
   __shared__ uint2 stack_s[WAVES_PER_BLOCK][STACK_ENTRIES];
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t ngroups = (ix.n + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups);
+  TraverseStats ts;
   const float qnan = __builtin_nanf("");
   for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
     const uint32_t g = sched.global(gl);
@@ -342,7 +373,7 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
     if (valid) p = ix.pts[i];
     TopKReg<K> pol;
     pol.init(KEY_NONE);
-    traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE]);
+    traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE], ts);
     if (valid) {
       // normal_3d.hpp:59-66 + normal_3d.h:308-322: fewer than 3 neighbours -> NaN
       int found = 0;
@@ -375,6 +406,7 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
       nrm_sorted[i] = out;
     }
   }
+  flush_stats(ts, gstats);
 }
 
 // k > 32: neighbours through the generic k-NN kernel (results by original index) then this pass.
@@ -437,14 +469,14 @@ pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_
   (void)hipEventRecord(e0, s);
   if (ix->n > 0) {
     if (k <= 8) {
-      hipLaunchKernelGGL(normals_kernel<8>, dim3(persistent_blocks(ctx, ngroups, 6)), dim3(BLOCK), 0, s, v, k, vp[0],
-                         vp[1], vp[2], ix->nrm, d_nan);
+      hipLaunchKernelGGL(normals_kernel<8>, dim3(resident_blocks(ctx, normals_kernel<8>, ngroups)), dim3(BLOCK), 0, s, v, k, vp[0],
+                         vp[1], vp[2], ix->nrm, d_nan, ctx->stats);
     } else if (k <= 16) {
-      hipLaunchKernelGGL(normals_kernel<16>, dim3(persistent_blocks(ctx, ngroups, 4)), dim3(BLOCK), 0, s, v, k, vp[0],
-                         vp[1], vp[2], ix->nrm, d_nan);
+      hipLaunchKernelGGL(normals_kernel<16>, dim3(resident_blocks(ctx, normals_kernel<16>, ngroups)), dim3(BLOCK), 0, s, v, k, vp[0],
+                         vp[1], vp[2], ix->nrm, d_nan, ctx->stats);
     } else if (k <= 32) {
-      hipLaunchKernelGGL(normals_kernel<32>, dim3(persistent_blocks(ctx, ngroups, 2)), dim3(BLOCK), 0, s, v, k, vp[0],
-                         vp[1], vp[2], ix->nrm, d_nan);
+      hipLaunchKernelGGL(normals_kernel<32>, dim3(resident_blocks(ctx, normals_kernel<32>, ngroups)), dim3(BLOCK), 0, s, v, k, vp[0],
+                         vp[1], vp[2], ix->nrm, d_nan, ctx->stats);
     } else {
       float4* q = nullptr;
       int32_t* nb = nullptr;
@@ -502,16 +534,19 @@ constexpr int NS = PCLHIP_ICP_NSUMS;
 
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void icp_iterate_kernel(IndexView ix, float4* __restrict__ cur, uint32_t ns,
-                                                            Mat34 T, int order, uint64_t key0,
+                                                            Mat34 T, int order, float bound, int use_max,
+                                                            uint32_t* __restrict__ match_pos,
                                                             uint32_t* __restrict__ match,
                                                             float* __restrict__ match_d2,
-                                                            double* __restrict__ partials) {
+                                                            double* __restrict__ partials,
+                                                            unsigned long long* gstats) {
   __shared__ uint2 stack_s[WAVES_PER_BLOCK][STACK_ENTRIES];
   __shared__ double red_s[WAVES_PER_BLOCK][NS];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   const uint32_t ngroups = (ns + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups);
+  TraverseStats ts;
   constexpr int NACC = (MODE == PCLHIP_ICP_POINT_TO_PLANE) ? 27 : 15;
   double acc[NACC];
 #pragma unroll
@@ -535,13 +570,31 @@ __global__ __launch_bounds__(BLOCK) void icp_iterate_kernel(IndexView ix, float4
       p.x = x; p.y = y; p.z = z;
       cur[i] = p;
     }
+    // fast minimum-distance traversal, seeded with the previous iteration's match (a valid upper
+    // bound: the same target point, re-measured against the moved query)
+    NN1Min fast;
+    fast.init(bound);
+    const uint32_t seed_pos = in_range ? match_pos[i] : NO_INDEX;
+    if (valid && seed_pos != NO_INDEX) {
+      const float4 t0 = ix.pts[seed_pos];
+      fast.seed(l2_simple(p.x, p.y, p.z, t0.x, t0.y, t0.z), seed_pos / LEAF);
+    }
+    traverse(ix, p.x, p.y, p.z, valid, fast, stack_s[wave], ts);
     NN1 pol;
-    pol.init(key0);
-    traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[wave]);
+    fast.resolve(ix, p.x, p.y, p.z, pol.key, pol.pos);
+    {
+      const bool redo = valid && (fast.tie || (fast.bestleaf == NO_INDEX && !use_max));
+      if (__builtin_amdgcn_ballot_w64(redo) != 0) {  // exact (distance, index) policy for tie lanes
+        NN1 ex = pol;
+        traverse(ix, p.x, p.y, p.z, redo, ex, stack_s[wave], ts);
+        if (redo) pol = ex;
+      }
+    }
     const uint32_t mid = key_index(pol.key);
     const bool found = valid && mid != NO_INDEX;
     if (in_range) {
       match[i] = found ? mid : NO_INDEX;
+      match_pos[i] = found ? pol.pos : NO_INDEX;
       match_d2[i] = found ? key_dist(pol.key) : __builtin_inff();
     }
     if (found) {
@@ -590,6 +643,7 @@ __global__ __launch_bounds__(BLOCK) void icp_iterate_kernel(IndexView ix, float4
       }
     }
   }
+  flush_stats(ts, gstats);
   // wave tree-reduce (shuffles), then fixed-order block reduce through LDS -> deterministic
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
@@ -614,12 +668,21 @@ __global__ __launch_bounds__(BLOCK) void icp_iterate_kernel(IndexView ix, float4
   }
 }
 
-__global__ void icp_finalize_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ sums) {
-  const int t = threadIdx.x;
-  if (t < NS) {
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partials[size_t(b) * NS + t];
-    sums[t] = s;
+// partials[nblocks][NS] -> sums[NS]; fixed summation order (stride-32 lanes, then 32 partial sums in
+// order) so the result does not depend on scheduling
+__global__ __launch_bounds__(1024) void icp_finalize_kernel(const double* __restrict__ partials, int nblocks,
+                                                            double* __restrict__ sums) {
+  __shared__ double red[32][NS + 1];
+  const int t = threadIdx.x % NS, r = threadIdx.x / NS;  // NS == 32
+  double s = 0.0;
+  for (int b = r; b < nblocks; b += 32) s += partials[size_t(b) * NS + t];
+  red[r][t] = s;
+  __syncthreads();
+  if (r == 0) {
+    double a = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a += red[i][t];
+    sums[t] = a;
   }
 }
 
@@ -630,20 +693,25 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   Mat34 M;
   for (int i = 0; i < 12; ++i) M.m[i] = T[i];
   const int order = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? 1 : 0;
-  uint32_t dbits = 0x7F800000u;
-  if (use_max) memcpy(&dbits, &max_d2, sizeof dbits);
-  const uint64_t key0 = (uint64_t(dbits) << 32) | 0xFFFFFFFFull;
-  const int grid = icp->grid_blocks;
+  // candidates must be <= max_d2 (a float): strict bound just above it; +inf when unbounded
+  const float bound = use_max ? std::nextafterf(max_d2, __builtin_inff()) : __builtin_inff();
+  const uint32_t ngroups = (icp->n + WAVE - 1) / WAVE;
+  int grid = (mode == PCLHIP_ICP_POINT_TO_PLANE)
+                 ? resident_blocks(ctx, icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE>, ngroups)
+                 : resident_blocks(ctx, icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT>, ngroups);
+  if (grid > icp->grid_blocks) grid = icp->grid_blocks;
   if (icp->n > 0) {
     (void)hipEventRecord(icp->ev0, s);
     if (mode == PCLHIP_ICP_POINT_TO_PLANE)
       hipLaunchKernelGGL(icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE>, dim3(grid), dim3(BLOCK), 0, s, v,
-                         icp->src_cur, icp->n, M, order, key0, icp->match, icp->match_d2, icp->partials);
+                         icp->src_cur, icp->n, M, order, bound, use_max ? 1 : 0, icp->match_pos, icp->match, icp->match_d2,
+                         icp->partials, ctx->stats);
     else
       hipLaunchKernelGGL(icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT>, dim3(grid), dim3(BLOCK), 0, s, v,
-                         icp->src_cur, icp->n, M, order, key0, icp->match, icp->match_d2, icp->partials);
+                         icp->src_cur, icp->n, M, order, bound, use_max ? 1 : 0, icp->match_pos, icp->match, icp->match_d2,
+                         icp->partials, ctx->stats);
     (void)hipEventRecord(icp->ev1, s);
-    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(64), 0, s, icp->partials, grid, icp->sums_dev);
+    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, grid, icp->sums_dev);
   } else {
     PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(icp->sums_dev, 0, NS * sizeof(double), s));
   }
@@ -651,8 +719,12 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   return PCLHIP_OK;
 }
 
+// upper bound of the persistent grid (sizes the partial-sum buffer)
 int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns) {
-  return persistent_blocks(ctx, (ns + WAVE - 1) / WAVE, 4);
+  const uint32_t ngroups = (ns + WAVE - 1) / WAVE;
+  const int a = resident_blocks(ctx, icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE>, ngroups);
+  const int b = resident_blocks(ctx, icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT>, ngroups);
+  return a > b ? a : b;
 }
 
 }  // namespace pclhip

@@ -104,9 +104,8 @@ struct NN1 {
     pos = NO_INDEX;
   }
   __device__ __forceinline__ float worst() const { return key_dist(key); }
-  __device__ __forceinline__ void leaf(const float4* __restrict__ pts, uint32_t leaf_id, float qx, float qy,
-                                       float qz) {
-    const leaf_ptr_t p = leaf_pointer(pts, leaf_id);  // wave-uniform address
+  __device__ __forceinline__ void leaf(const IndexView& ix, uint32_t leaf_id, float qx, float qy, float qz) {
+    const leaf_ptr_t p = leaf_pointer(ix.pts, leaf_id);  // wave-uniform address
     const uint32_t base = leaf_id * LEAF;
 #pragma unroll
     for (int c = 0; c < LEAF; ++c) {
@@ -115,6 +114,67 @@ struct NN1 {
       const bool t = k < key;
       key = t ? k : key;
       pos = t ? base + c : pos;
+    }
+  }
+};
+
+// 1-NN fast path: the hot loop only tracks the minimum DISTANCE (packed v_pk_* math on candidate
+// pairs read as SGPR pairs from the per-leaf SoA copy, one v_min3 per pair) and remembers in which
+// leaf the minimum was first reached.  The winner's index is resolved once per query afterwards
+// (resolve()); exact cross-leaf distance ties raise `tie`, and the caller then re-runs the exact
+// (distance, index) policy NN1 for those lanes, so results stay bit-identical to the oracle.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const v2f __attribute__((address_space(4))) * soa_ptr_t;
+struct NN1Min {
+  float best;         // candidates must be strictly below this to win
+  uint32_t bestleaf;  // leaf that first reached `best`, NO_INDEX while best is only the bound
+  bool tie;
+  __device__ __forceinline__ void init(float bound_exclusive) {
+    best = bound_exclusive;
+    bestleaf = NO_INDEX;
+    tie = false;
+  }
+  __device__ __forceinline__ void seed(float d, uint32_t leaf_id) {
+    if (d < best) {
+      best = d;
+      bestleaf = leaf_id;
+    }
+  }
+  __device__ __forceinline__ float worst() const { return best; }
+  __device__ __forceinline__ void leaf(const IndexView& ix, uint32_t leaf_id, float qx, float qy, float qz) {
+    const soa_ptr_t p = (soa_ptr_t)(unsigned long long)(ix.soa + size_t(leaf_id) * (3 * LEAF));
+    const v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+    float m = __builtin_inff();
+#pragma unroll
+    for (int j = 0; j < LEAF / 2; ++j) {
+      const v2f dx = qx2 - p[j], dy = qy2 - p[LEAF / 2 + j], dz = qz2 - p[LEAF + j];
+      v2f r = dx * dx;
+      r = r + dy * dy;
+      r = r + dz * dz;
+      m = __builtin_fminf(m, __builtin_fminf(r.x, r.y));
+    }
+    const bool imp = m < best;
+    const bool eq = (m == best) && (bestleaf != NO_INDEX) && (bestleaf != leaf_id);
+    tie = imp ? false : (tie || eq);
+    bestleaf = imp ? leaf_id : bestleaf;
+    best = imp ? m : best;
+  }
+  // (distance, original index) key and sorted position of the winner; NO_INDEX if none
+  __device__ __forceinline__ void resolve(const IndexView& ix, float qx, float qy, float qz, uint64_t& key,
+                                          uint32_t& pos) const {
+    key = KEY_NONE;
+    pos = NO_INDEX;
+    if (bestleaf == NO_INDEX) return;
+    const float4* __restrict__ p = ix.pts + size_t(bestleaf) * LEAF;
+#pragma unroll 4
+    for (int c = 0; c < LEAF; ++c) {
+      const float4 v = p[c];
+      const float d = l2_simple(qx, qy, qz, v.x, v.y, v.z);
+      const uint64_t k = make_key(d, __float_as_uint(v.w));
+      if (d == best && k < key) {
+        key = k;
+        pos = bestleaf * LEAF + c;
+      }
     }
   }
 };
@@ -145,9 +205,8 @@ struct TopKReg {
     keys[0] = below ? k : keys[0];
     pos[0] = below ? p : pos[0];
   }
-  __device__ __forceinline__ void leaf(const float4* __restrict__ pts, uint32_t leaf_id, float qx, float qy,
-                                       float qz) {
-    const leaf_ptr_t p = leaf_pointer(pts, leaf_id);
+  __device__ __forceinline__ void leaf(const IndexView& ix, uint32_t leaf_id, float qx, float qy, float qz) {
+    const leaf_ptr_t p = leaf_pointer(ix.pts, leaf_id);
     const uint32_t base = leaf_id * LEAF;
 #pragma unroll
     for (int c = 0; c < LEAF; ++c) {
@@ -196,9 +255,8 @@ struct TopKHeap {
     heap[size_t(i) * stride] = key;
     root = heap[0];
   }
-  __device__ __forceinline__ void leaf(const float4* __restrict__ pts, uint32_t leaf_id, float qx, float qy,
-                                       float qz) {
-    const leaf_ptr_t p = leaf_pointer(pts, leaf_id);
+  __device__ __forceinline__ void leaf(const IndexView& ix, uint32_t leaf_id, float qx, float qy, float qz) {
+    const leaf_ptr_t p = leaf_pointer(ix.pts, leaf_id);
     for (int c = 0; c < LEAF; ++c) {
       const float d = l2_simple(qx, qy, qz, p[4 * c], p[4 * c + 1], p[4 * c + 2]);
       const uint64_t key = make_key(d, __float_as_uint(p[4 * c + 3]));
@@ -239,13 +297,21 @@ struct TopKHeap {
   }
 };
 
+// Optional work counters (wave-uniform, live in SGPRs; flushed by the kernels when the context asked
+// for statistics).  [0] interior nodes scanned, [1] leaves that passed the group test, [2] leaves
+// that passed the per-lane test (= 16-candidate all-pairs blocks), [3] stack pushes, [4] groups.
+struct TraverseStats {
+  uint32_t c[5] = {0, 0, 0, 0, 0};
+};
+
 // ---- the traversal --------------------------------------------------------------------------------
 // `stack` points at this wave's STACK_ENTRIES uint2 slots in LDS.  Must be called by all 64 lanes.
 template <class Policy>
 __device__ __forceinline__ void traverse(const IndexView& ix, float qx, float qy, float qz, bool valid,
-                                         Policy& pol, uint2* stack) {
+                                         Policy& pol, uint2* stack, TraverseStats& ts) {
   const int lane = threadIdx.x & (WAVE - 1);
   if (__builtin_amdgcn_ballot_w64(valid) == 0 || ix.n == 0) return;
+  ++ts.c[4];
   const float BIG = 3.402823466e+38f;
   const float INF = __builtin_inff();
   // bounding box of the wave's queries
@@ -270,6 +336,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, float qx, float qy
       node = ex & 0x0FFFFFFFu;
     }
     have = false;
+    ++ts.c[0];
     const uint32_t cl = level - 1u;  // level of the children
     const uint32_t first = node * FANOUT;
     const uint32_t total = ix.count[cl];
@@ -301,12 +368,14 @@ __device__ __forceinline__ void traverse(const IndexView& ix, float qx, float qy
         }
         mask &= ~(1ull << j);
         if (readlane_f(lbG, j) > T) continue;
+        ++ts.c[1];
         const float blx = readlane_f(lx, j), bly = readlane_f(ly, j), blz = readlane_f(lz, j);
         const float bhx = readlane_f(hx, j), bhy = readlane_f(hy, j), bhz = readlane_f(hz, j);
         const float lb = point_box_lb(qx, qy, qz, blx, bly, blz, bhx, bhy, bhz);
         const bool need = valid && !(lb > pol.worst());
         if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
-        pol.leaf(ix.pts, uniform_u32(first + uint32_t(j)), qx, qy, qz);
+        ++ts.c[2];
+        pol.leaf(ix, uniform_u32(first + uint32_t(j)), qx, qy, qz);
         T = wave_max_f(valid ? pol.worst() : 0.0f);
       }
     } else {
@@ -316,11 +385,19 @@ __device__ __forceinline__ void traverse(const IndexView& ix, float qx, float qy
         stack[at] = make_uint2((cl << 28) | (first + uint32_t(lane)), __float_as_uint(lbG));
       }
       sp += __builtin_popcountll(others);
+      ts.c[3] += uint32_t(__builtin_popcountll(others));
       __builtin_amdgcn_wave_barrier();
       level = cl;
       node = first + uint32_t(jn);
       have = true;
     }
+  }
+}
+
+__device__ __forceinline__ void flush_stats(const TraverseStats& ts, unsigned long long* g) {
+  if (g != nullptr && (threadIdx.x & (WAVE - 1)) == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) atomicAdd(g + i, (unsigned long long)ts.c[i]);
   }
 }
 

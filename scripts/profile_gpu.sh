@@ -1,0 +1,26 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): kernel trace + PMC passes of the bench command.
+# Usage: scripts/profile_gpu.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
+# PMC passes are separate runs with --kernel-trace only (never combined with sys/hip traces).
+set -u
+TAG=${1:-r1}; shift || true
+ARGS=${@:-"--steps 8 --warmup 2 --no-cpu-baseline"}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+run() { # name, rocprof flags...
+  local name=$1; shift
+  rm -rf /tmp/rp_$name
+  timeout 900 rocprofv3 "$@" -d /tmp/rp_$name -o $name --output-format csv -- python $REPO/bench.py $ARGS > $OUT/$name.log 2>&1
+  echo "== $name rc=$?"
+  find /tmp/rp_$name -name "*.csv" | while read f; do cp "$f" $OUT/$(basename "$f"); done
+}
+run trace --kernel-trace --stats
+run pmc_sq1 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM
+run pmc_sq2 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SMEM SQ_WAIT_INST_LDS
+run pmc_fetch --kernel-trace --pmc FETCH_SIZE
+run pmc_write --kernel-trace --pmc WRITE_SIZE
+run pmc_tcc --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum
+ls -la $OUT | head -40
