@@ -100,11 +100,8 @@ def main():
     icp.setInputSource(src)
     max_dist = 0.1
     if world > 1:
-        def allreduce(ptr, count, strm):
-            t = _wrap_device_doubles(torch, ptr, count, local_rank)
-            dist.all_reduce(t)  # RCCL over xGMI, on the current (= context) stream
-            return 0
-        icp.setAllReduce(allreduce)
+        from pcl_amd.dist import make_allreduce_hook
+        icp.setAllReduce(make_allreduce_hook(local_rank))  # RCCL all-reduce of the 32-double record
 
     state = {"T": np.eye(4, dtype=np.float32), "it": 0}
     icp.reset()
@@ -186,15 +183,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def _wrap_device_doubles(torch, ptr, count, device):
-    """torch tensor aliasing `count` doubles at device pointer `ptr` (no copy)."""
-    class _Holder:
-        pass
-    h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (int(ptr), False), "version": 3}
-    return torch.as_tensor(h, device="cuda:%d" % device)
 
 
 def cpu_baseline(args, mode):

@@ -54,17 +54,32 @@ __device__ __forceinline__ float box_box_lb(float Qlx, float Qly, float Qlz, flo
 }
 
 // ---- wavefront reductions (all 64 lanes must be active) ---------------------------------------
-// The result is returned through readfirstlane so the compiler knows it is wave-uniform (SGPR):
-// every branch on it is then a scalar branch and dependent addresses use the scalar path.
+// DPP butterflies (no LDS traffic, plain VALU latency): quad_perm swaps, row_half_mirror and
+// row_mirror leave every row of 16 lanes holding its row result; row_bcast15/31 then fold the four
+// rows into lane 63.  The result is read back with readlane so the compiler knows it is
+// wave-uniform (SGPR): every branch on it is a scalar branch.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+  v = fminf(v, dpp_f<0xB1, 0xf>(v));   // quad_perm [1,0,3,2]
+  v = fminf(v, dpp_f<0x4E, 0xf>(v));   // quad_perm [2,3,0,1]
+  v = fminf(v, dpp_f<0x141, 0xf>(v));  // row_half_mirror
+  v = fminf(v, dpp_f<0x140, 0xf>(v));  // row_mirror
+  v = fminf(v, dpp_f<0x142, 0xa>(v));  // row_bcast15 -> rows 1,3
+  v = fminf(v, dpp_f<0x143, 0xc>(v));  // row_bcast31 -> rows 2,3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+  v = fmaxf(v, dpp_f<0xB1, 0xf>(v));
+  v = fmaxf(v, dpp_f<0x4E, 0xf>(v));
+  v = fmaxf(v, dpp_f<0x141, 0xf>(v));
+  v = fmaxf(v, dpp_f<0x140, 0xf>(v));
+  v = fmaxf(v, dpp_f<0x142, 0xa>(v));
+  v = fmaxf(v, dpp_f<0x143, 0xc>(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -375,8 +390,11 @@ __device__ __forceinline__ void traverse(const IndexView& ix, float qx, float qy
         const bool need = valid && !(lb > pol.worst());
         if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
         ++ts.c[2];
+        const float before = pol.worst();
         pol.leaf(ix, uniform_u32(first + uint32_t(j)), qx, qy, qz);
-        T = wave_max_f(valid ? pol.worst() : 0.0f);
+        // the wave radius can only shrink if some lane's own bound shrank
+        if (__builtin_amdgcn_ballot_w64(valid && pol.worst() < before) != 0)
+          T = wave_max_f(valid ? pol.worst() : 0.0f);
       }
     } else {
       const uint64_t others = mask & ~(1ull << jn);

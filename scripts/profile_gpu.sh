@@ -1,9 +1,10 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): kernel trace + PMC passes of the bench command.
-# Usage: scripts/profile_gpu.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
-# PMC passes are separate runs with --kernel-trace only (never combined with sys/hip traces).
+# Usage: scripts/profile_gpu.sh <tag> "<passes>" [bench args...]   -> gpurun_out/prof_<tag>/
+# passes: any of trace sq1 sq2 fetch write tcc.  PMC passes are separate runs with --kernel-trace
+# only (never combined with sys/hip traces).
 set -u
-TAG=${1:-r1}; shift || true
+TAG=${1:-r1}; PASSES=${2:-"trace sq1 sq2 fetch write tcc"}; shift; shift
 ARGS=${@:-"--steps 8 --warmup 2 --no-cpu-baseline"}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
@@ -17,10 +18,14 @@ run() { # name, rocprof flags...
   echo "== $name rc=$?"
   find /tmp/rp_$name -name "*.csv" | while read f; do cp "$f" $OUT/$(basename "$f"); done
 }
-run trace --kernel-trace --stats
-run pmc_sq1 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM
-run pmc_sq2 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SMEM SQ_WAIT_INST_LDS
-run pmc_fetch --kernel-trace --pmc FETCH_SIZE
-run pmc_write --kernel-trace --pmc WRITE_SIZE
-run pmc_tcc --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum
-ls -la $OUT | head -40
+for p in $PASSES; do
+case $p in
+trace) run trace --kernel-trace --stats ;;
+sq1) run pmc_sq1 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM ;;
+sq2) run pmc_sq2 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SMEM SQ_WAIT_INST_LDS ;;
+fetch) run pmc_fetch --kernel-trace --pmc FETCH_SIZE ;;
+write) run pmc_write --kernel-trace --pmc WRITE_SIZE ;;
+tcc) run pmc_tcc --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum ;;
+esac
+done
+python $REPO/scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1; cat $OUT/summary.txt

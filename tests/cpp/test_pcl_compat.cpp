@@ -1,0 +1,131 @@
+// C++ host-side test of the PCL-compatible adapters (include/pclhip/pcl_compat.hpp) over the C ABI.
+// Mirrors test/registration/test_registration_api.cpp:83-104 (397 bunny correspondences),
+// test/registration/test_registration.cpp:236-270 (ICP golden 4x4 @1e-3) and
+// test/filters/test_filters.cpp:566-596 (VoxelGrid 103).  Inputs: bun0.txt bun4.txt golden_corr.txt
+// written by the pytest wrapper (tests/test_gpu_cpp_adapters.py) from tests/golden/.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "pclhip/pcl_compat.hpp"
+
+using namespace pclhip;
+
+static PointCloud<PointXYZ>::Ptr load_xyz(const char* path) {
+  auto c = std::make_shared<PointCloud<PointXYZ>>();
+  std::ifstream f(path);
+  float x, y, z;
+  while (f >> x >> y >> z) c->push_back(PointXYZ(x, y, z));
+  return c;
+}
+
+#define EXPECT(cond)                                                        \
+  do {                                                                      \
+    if (!(cond)) {                                                          \
+      std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      ++failures;                                                           \
+    }                                                                       \
+  } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  int failures = 0;
+  auto ctx = std::make_shared<Context>(0);
+  if (!ctx->ok()) {
+    std::fprintf(stderr, "no device: %s\n", ctx->getLastError().c_str());
+    return 3;
+  }
+  auto source = load_xyz(argv[1]);
+  auto target = load_xyz(argv[2]);
+  EXPECT(source->size() == 397 && target->size() == 361);
+
+  {  // CorrespondenceEstimation: 397 exact pairs
+    std::vector<int> gold;
+    std::ifstream f(argv[3]);
+    int a, b;
+    while (f >> a >> b) gold.push_back(b);
+    registration::CorrespondenceEstimation<PointXYZ, PointXYZ> ce(ctx);
+    ce.setInputSource(source);
+    ce.setInputTarget(target);
+    Correspondences corr;
+    ce.determineCorrespondences(corr);
+    EXPECT(corr.size() == 397 && gold.size() == 397);
+    for (std::size_t i = 0; i < corr.size() && i < gold.size(); ++i) {
+      EXPECT(corr[i].index_query == int(i));
+      EXPECT(corr[i].index_match == gold[i]);
+    }
+  }
+  {  // per-point nearestKSearch through the search::KdTree surface
+    auto tree = std::make_shared<search::KdTree<PointXYZ>>(ctx);
+    EXPECT(tree->setInputCloud(target));
+    Indices idx;
+    std::vector<float> d2;
+    EXPECT(tree->nearestKSearch((*source)[0], 5, idx, d2) == 5);
+    EXPECT(idx.size() == 5 && d2[0] <= d2[1] && d2[1] <= d2[4]);
+    std::vector<Indices> bi;
+    std::vector<std::vector<float>> bd;
+    tree->nearestKSearch(*source, Indices(), 5, bi, bd);
+    EXPECT(bi.size() == 397 && bi[0] == idx && bd[0] == d2);
+    EXPECT(tree->nearestKSearch((*source)[0], 1000, idx, d2) == 361);  // k clamped to the cloud size
+  }
+  {  // IterativeClosestPoint golden
+    IterativeClosestPoint<PointXYZ, PointXYZ> reg(ctx);
+    reg.setInputSource(source);
+    reg.setInputTarget(target);
+    reg.setMaximumIterations(50);
+    reg.setTransformationEpsilon(1e-8);
+    reg.setMaxCorrespondenceDistance(0.05);
+    PointCloud<PointXYZ> out;
+    reg.align(out);
+    EXPECT(out.size() == source->size());
+    const Matrix4f T = reg.getFinalTransformation();
+    const float g[3][4] = {{0.8806f, 0.036481287f, -0.4724f, 0.03453f},
+                           {-0.02354f, 0.9992f, 0.03326f, -0.001519f},
+                           {0.4732f, -0.01817f, 0.8808f, 0.04116f}};
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) EXPECT(std::fabs(T(r, c) - g[r][c]) < ((r == 0 && c == 1) ? 1e-2f : 1e-3f));
+    EXPECT(T(3, 0) == 0 && T(3, 1) == 0 && T(3, 2) == 0 && T(3, 3) == 1);
+    EXPECT(reg.hasConverged());
+  }
+  {  // NormalEstimation(k=10) + IterativeClosestPointWithNormals on PointNormal clouds
+    NormalEstimation<PointXYZ> ne(ctx);
+    ne.setInputCloud(target);
+    ne.setKSearch(10);
+    PointCloud<Normal> normals;
+    ne.compute(normals);
+    EXPECT(normals.size() == target->size() && normals.is_dense);
+    auto tgt_n = std::make_shared<PointCloud<PointNormal>>();
+    auto src_n = std::make_shared<PointCloud<PointNormal>>();
+    for (std::size_t i = 0; i < target->size(); ++i) {
+      PointNormal p;
+      p.x = (*target)[i].x; p.y = (*target)[i].y; p.z = (*target)[i].z;
+      p.normal_x = normals[i].normal_x; p.normal_y = normals[i].normal_y; p.normal_z = normals[i].normal_z;
+      tgt_n->push_back(p);
+    }
+    for (std::size_t i = 0; i < source->size(); ++i) {
+      PointNormal p;
+      p.x = (*source)[i].x; p.y = (*source)[i].y; p.z = (*source)[i].z;
+      src_n->push_back(p);
+    }
+    IterativeClosestPointWithNormals<PointNormal, PointNormal> reg(ctx);
+    reg.setInputSource(src_n);
+    reg.setInputTarget(tgt_n);
+    reg.setMaximumIterations(50);
+    reg.setTransformationEpsilon(1e-8);
+    PointCloud<PointNormal> out;
+    reg.align(out);
+    EXPECT(reg.hasConverged());
+    EXPECT(reg.getLastMSE() < 1e-3);  // fitness bar of test_registration.cpp:272-318
+  }
+  {  // VoxelGrid 103
+    VoxelGrid grid(ctx);
+    grid.setLeafSize(0.02f, 0.02f, 0.02f);
+    grid.setInputCloud(source);
+    PointCloud<PointXYZ> out;
+    grid.filter(out);
+    EXPECT(out.size() == 103 && out.width == 103 && out.height == 1 && out.is_dense);
+  }
+  std::printf(failures ? "%d FAILURES\n" : "ALL OK\n", failures);
+  return failures ? 1 : 0;
+}

@@ -1,0 +1,97 @@
+"""N>1 path on CPU (gloo, world_size 2): source slabs are disjoint and complete, the per-rank
+reduction records sum to the single-process record, and every rank solves the same transform.
+The device kernel is stood in for by the oracle's accumulation (tests may use the oracle); the
+all-reduce + host solve are the product's own code (pcl_amd.dist + pclhip_solve_transformation)."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pcl_amd import _lib, synth
+from pcl_amd.dist import reduce_record_host, shard_range
+
+
+def test_shard_ranges_cover_everything():
+    for n in (0, 1, 7, 64, 1000, 10_000_001):
+        for w in (1, 2, 3, 8):
+            got = [shard_range(n, r, w) for r in range(w)]
+            assert sum(c for _, c in got) == n
+            pos = 0
+            for s, c in got:
+                assert s == pos
+                pos += c
+            assert max(c for _, c in got) - min(c for _, c in got) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _local_record(tgt, nrm, src, mode):
+    from oracle import pcl_oracle as orc
+    tree = orc.KdTree(tgt)
+    q, m, d = tree.correspondences(src, 0.1, nthreads=2)
+    rec = np.zeros(_lib.NSUMS)
+    if mode == 1:
+        _, s27, used = orc.lls_point_to_plane(src, tgt, nrm, q, m)
+        rec[:27] = s27
+    else:
+        s, t = src[q, :3].astype(np.float64), tgt[m, :3].astype(np.float64)
+        rec[0:3] = s.sum(0)
+        rec[3:6] = t.sum(0)
+        rec[6:15] = (t.T @ s).reshape(9)
+    rec[27] = d.astype(np.float64).sum()
+    rec[28] = len(q)
+    return rec
+
+
+def _solve(rec, mode):
+    T = np.zeros(16, np.float32)
+    assert _lib.load().pclhip_solve_transformation(rec.ctypes.data_as(C.POINTER(C.c_double)), mode,
+                                                   T.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    return T.reshape(4, 4)
+
+
+def _worker(rank, world, port, n, mode, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pcl_oracle as orc
+        tgt = synth.gaussian_surface(n, synth.TARGET_SEED)
+        nrm = orc.KdTree(tgt).normals(tgt, 8, viewpoint=(0, 0, 10), nthreads=2)[0]
+        start, count = shard_range(n, rank, world)
+        src = synth.apply_rigid(np.linalg.inv(synth.ground_truth_transform()),
+                                synth.gaussian_surface(count, synth.SOURCE_SEED, start=start))
+        rec = reduce_record_host(_local_record(tgt, nrm, src, mode))
+        out[rank] = (rec, _solve(rec, mode))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_two_rank_allreduce_matches_single_process(mode):
+    n, world = 20000, 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, mode, out), nprocs=world, join=True)
+    from oracle import pcl_oracle as orc
+    tgt = synth.gaussian_surface(n, synth.TARGET_SEED)
+    nrm = orc.KdTree(tgt).normals(tgt, 8, viewpoint=(0, 0, 10), nthreads=2)[0]
+    src = synth.apply_rigid(np.linalg.inv(synth.ground_truth_transform()), synth.gaussian_surface(n, synth.SOURCE_SEED))
+    ref = _local_record(tgt, nrm, src, mode)
+    for r in range(world):
+        rec, T = out[r]
+        assert rec[28] == ref[28]
+        assert np.allclose(rec, ref, rtol=1e-11, atol=1e-12)
+        assert np.array_equal(T, out[0][1])               # every rank solves the same system
+        assert np.abs(T - _solve(ref, mode)).max() < 1e-7  # and it is the single-process answer
