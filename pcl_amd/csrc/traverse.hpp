@@ -335,6 +335,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, float qx, float qy
   const float Qhx = wave_max_f(valid ? qx : -BIG), Qhy = wave_max_f(valid ? qy : -BIG),
               Qhz = wave_max_f(valid ? qz : -BIG);
   float T = wave_max_f(valid ? pol.worst() : 0.0f);  // wave pruning radius (squared)
+  const float gdiag2 = (Qhx - Qlx) * (Qhx - Qlx) + (Qhy - Qly) * (Qhy - Qly) + (Qhz - Qlz) * (Qhz - Qlz);
 
   int sp = 0;
   uint32_t level = uint32_t(ix.top) + 1u, node = 0u;  // virtual root above the top level
@@ -367,38 +368,80 @@ __device__ __forceinline__ void traverse(const IndexView& ix, float qx, float qy
     const bool alive = has && !(lbG > T);
     uint64_t mask = __builtin_amdgcn_ballot_w64(alive);
     if (mask == 0) continue;
-    // nearest child first
-    const float m = wave_min_f(alive ? lbG : INF);
-    const uint64_t mm = __builtin_amdgcn_ballot_w64(alive && lbG == m);
-    const int jn = __builtin_ctzll(mm);
+    // Visiting order.  Cold or lukewarm bounds (wave radius not yet small against the group's own
+    // extent, e.g. the first ICP iterations): visit children in ascending order of their distance
+    // to the group box, so the bounds collapse after the first few leaves and everything farther
+    // is cut off at once.  Tight bounds (seeded steady state): the nearest child first, then plain
+    // index order -- no per-child reduction.
+    const bool ordered = T * 16.0f > gdiag2;
     if (cl == 1u) {
-      bool first_done = false;
-      while (mask) {
-        int j;
-        if (!first_done) {
-          j = jn;
-          first_done = true;
-        } else {
-          j = __builtin_ctzll(mask);
+      if (ordered) {
+        bool live = alive;
+        for (;;) {
+          if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+          const float m = wave_min_f(live ? lbG : INF);
+          if (m > T) break;  // every remaining leaf is farther than the wave radius
+          const int j = __builtin_ctzll(__builtin_amdgcn_ballot_w64(live && lbG == m));
+          if (lane == j) live = false;
+          ++ts.c[1];
+          const float blx = readlane_f(lx, j), bly = readlane_f(ly, j), blz = readlane_f(lz, j);
+          const float bhx = readlane_f(hx, j), bhy = readlane_f(hy, j), bhz = readlane_f(hz, j);
+          const float lb = point_box_lb(qx, qy, qz, blx, bly, blz, bhx, bhy, bhz);
+          const bool need = valid && !(lb > pol.worst());
+          if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
+          ++ts.c[2];
+          const float before = pol.worst();
+          pol.leaf(ix, uniform_u32(first + uint32_t(j)), qx, qy, qz);
+          if (__builtin_amdgcn_ballot_w64(valid && pol.worst() < before) != 0)
+            T = wave_max_f(valid ? pol.worst() : 0.0f);
         }
-        mask &= ~(1ull << j);
-        if (readlane_f(lbG, j) > T) continue;
-        ++ts.c[1];
-        const float blx = readlane_f(lx, j), bly = readlane_f(ly, j), blz = readlane_f(lz, j);
-        const float bhx = readlane_f(hx, j), bhy = readlane_f(hy, j), bhz = readlane_f(hz, j);
-        const float lb = point_box_lb(qx, qy, qz, blx, bly, blz, bhx, bhy, bhz);
-        const bool need = valid && !(lb > pol.worst());
-        if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
-        ++ts.c[2];
-        const float before = pol.worst();
-        pol.leaf(ix, uniform_u32(first + uint32_t(j)), qx, qy, qz);
-        // the wave radius can only shrink if some lane's own bound shrank
-        if (__builtin_amdgcn_ballot_w64(valid && pol.worst() < before) != 0)
-          T = wave_max_f(valid ? pol.worst() : 0.0f);
+      } else {
+        const float m = wave_min_f(alive ? lbG : INF);
+        const int jn = __builtin_ctzll(__builtin_amdgcn_ballot_w64(alive && lbG == m));
+        bool first_done = false;
+        while (mask) {
+          int j;
+          if (!first_done) {
+            j = jn;
+            first_done = true;
+          } else {
+            j = __builtin_ctzll(mask);
+          }
+          mask &= ~(1ull << j);
+          if (readlane_f(lbG, j) > T) continue;
+          ++ts.c[1];
+          const float blx = readlane_f(lx, j), bly = readlane_f(ly, j), blz = readlane_f(lz, j);
+          const float bhx = readlane_f(hx, j), bhy = readlane_f(hy, j), bhz = readlane_f(hz, j);
+          const float lb = point_box_lb(qx, qy, qz, blx, bly, blz, bhx, bhy, bhz);
+          const bool need = valid && !(lb > pol.worst());
+          if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
+          ++ts.c[2];
+          const float before = pol.worst();
+          pol.leaf(ix, uniform_u32(first + uint32_t(j)), qx, qy, qz);
+          // the wave radius can only shrink if some lane's own bound shrank
+          if (__builtin_amdgcn_ballot_w64(valid && pol.worst() < before) != 0)
+            T = wave_max_f(valid ? pol.worst() : 0.0f);
+        }
       }
     } else {
+      const float m = wave_min_f(alive ? lbG : INF);
+      const int jn = __builtin_ctzll(__builtin_amdgcn_ballot_w64(alive && lbG == m));
       const uint64_t others = mask & ~(1ull << jn);
-      if (alive && lane != jn) {
+      if (ordered && __builtin_popcountll(others) > 1) {
+        // push the other survivors farthest first so that pops come back nearest first
+        bool live = alive && lane != jn;
+        int at = sp;
+        for (;;) {
+          if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+          const float far = wave_max_f(live ? lbG : -1.0f);
+          const int j = __builtin_ctzll(__builtin_amdgcn_ballot_w64(live && lbG == far));
+          if (lane == j) {
+            live = false;
+            stack[at] = make_uint2((cl << 28) | (first + uint32_t(lane)), __float_as_uint(lbG));
+          }
+          ++at;
+        }
+      } else if (alive && lane != jn) {
         const int at = sp + __builtin_popcountll(others & ((1ull << lane) - 1ull));
         stack[at] = make_uint2((cl << 28) | (first + uint32_t(lane)), __float_as_uint(lbG));
       }
