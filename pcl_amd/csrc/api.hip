@@ -315,6 +315,8 @@ void pclhip_index_destroy(pclhip_index* ix) {
   if (ix->soa) (void)hipFree(ix->soa);
   if (ix->nrm) (void)hipFree(ix->nrm);
   if (ix->rank) (void)hipFree(ix->rank);
+  if (ix->lv_dev) (void)hipFree(ix->lv_dev);
+  if (ix->topcache) (void)hipFree(ix->topcache);
   for (int l = 0; l < MAX_LEVELS; ++l)
     if (ix->box[l]) (void)hipFree(ix->box[l]);
   delete ix;

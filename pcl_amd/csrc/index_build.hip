@@ -168,15 +168,16 @@ __global__ __launch_bounds__(256) void leaf_box_kernel(const float4* pts, uint32
   }
 }
 
-// per-leaf structure-of-arrays copy of the coordinates
+// per-leaf structure-of-arrays copy: x[16] y[16] z[16] w[16] (w = original index bits), 256 B
 __global__ __launch_bounds__(256) void leaf_soa_kernel(const float4* pts, uint32_t n_pad, float* soa) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pad) return;
   const float4 p = pts[i];
-  float* l = soa + size_t(i / LEAF) * (3 * LEAF) + (i % LEAF);
+  float* l = soa + size_t(i / LEAF) * (4 * LEAF) + (i % LEAF);
   l[0] = p.x;
   l[LEAF] = p.y;
   l[2 * LEAF] = p.z;
+  l[3 * LEAF] = p.w;
 }
 
 // one wavefront per parent node
@@ -586,7 +587,7 @@ pclhip_status build_boxes(pclhip_index* ix) {
       hipLaunchKernelGGL(leaf_box_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c, ix->box[1]);
       if (ix->soa) (void)hipFree(ix->soa);
       ix->soa = nullptr;
-      PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->soa, size_t(c) * 3 * LEAF * sizeof(float)));
+      PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->soa, size_t(c) * 4 * LEAF * sizeof(float)));
       hipLaunchKernelGGL(leaf_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, threads, ix->soa);
     } else {
       const uint64_t threads = uint64_t(c) * WAVE;
@@ -598,6 +599,36 @@ pclhip_status build_boxes(pclhip_index* ix) {
     ++l;
   }
   ix->top = l;
+  // contiguous copy of the top levels (as many whole levels as fit TOPCACHE_BOXES, never the leaves)
+  {
+    uint32_t total = 0;
+    int from = MAX_LEVELS;
+    for (int lv = ix->top; lv >= 2; --lv) {
+      if (total + ix->count[lv] > uint32_t(TOPCACHE_BOXES)) break;
+      total += ix->count[lv];
+      from = lv;
+    }
+    ix->cache_from = from;
+    ix->cache_count = total;
+    if (!ix->topcache) PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->topcache, size_t(TOPCACHE_BOXES) * sizeof(Box)));
+    uint32_t off = 0;
+    for (int lv = 0; lv < MAX_LEVELS; ++lv) ix->cache_off[lv] = 0;
+    for (int lv = from; lv <= ix->top && from < MAX_LEVELS; ++lv) {
+      ix->cache_off[lv] = off;
+      PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(ix->topcache + off, ix->box[lv], size_t(ix->count[lv]) * sizeof(Box),
+                                           hipMemcpyDeviceToDevice, s));
+      off += ix->count[lv];
+    }
+  }
+  LevelInfo h[MAX_LEVELS];
+  for (int i = 0; i < MAX_LEVELS; ++i) {
+    h[i].box = ix->box[i];
+    h[i].count = ix->count[i];
+    h[i].pad = 0;
+  }
+  if (!ix->lv_dev) PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->lv_dev, sizeof h));
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(ix->lv_dev, h, sizeof h, hipMemcpyHostToDevice, s));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));  // h is a stack buffer
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   return PCLHIP_OK;
 }
@@ -609,10 +640,15 @@ pclhip::IndexView pclhip_index::view() const {
   v.pts = pts;
   v.soa = soa;
   v.nrm = nrm;
+  v.lv = lv_dev;
   for (int l = 0; l < pclhip::MAX_LEVELS; ++l) {
     v.box[l] = box[l];
     v.count[l] = count[l];
+    v.cache_off[l] = cache_off[l];
   }
+  v.topcache = topcache;
+  v.cache_from = cache_from;
+  v.cache_count = cache_count;
   v.top = top;
   v.n = n;
   v.n_pad = n_pad;

@@ -4,8 +4,9 @@
 //   pts   [n_pad]  float4   target points in 63-bit Morton order; .w = original index (bit cast).
 //                           n_pad = n rounded up to a whole leaf; pad slots hold +FLT_MAX
 //                           sentinels with index 0xFFFFFFFF (distance overflows to +inf).
-//   soa   [n1][3*LEAF] float same coordinates, per leaf x[16] y[16] z[16]: one leaf = 3 scalar
-//                           s_load_dwordx16, candidate pairs feed v_pk_* ops straight from SGPRs.
+//   soa   [n1][4*LEAF] float the same points per leaf as x[16] y[16] z[16] w[16] (256 B): the block a
+//                           wavefront stages in LDS with global_load_lds_dwordx4; candidate pairs
+//                           then feed v_pk_* math from broadcast ds_read_b128.
 //   nrm   [n_pad]  float4   (nx,ny,nz,curvature) in the same order (optional).
 //   box[1][n1]     Box      tight AABB of every leaf = LEAF consecutive sorted points.
 //   box[l][n_l]    Box      AABB of FANOUT consecutive boxes of level l-1 (implicit wide BVH:
@@ -29,19 +30,31 @@ constexpr int FANOUT = 64;      // children per internal node = one per lane of 
 constexpr int MAX_LEVELS = 8;   // 16 * 64^7 points
 constexpr int WAVE = 64;
 constexpr uint32_t NO_INDEX = 0xFFFFFFFFu;
+constexpr int TOPCACHE_BOXES = 192;  // 6 KB of LDS per block
 
 struct Box {       // 32 B: two aligned float4 loads
   float4 lo;       // xyz = min corner
   float4 hi;       // xyz = max corner
 };
 
+struct LevelInfo {  // one entry per tree level, read with a wave-uniform scalar load
+  const Box* box;
+  uint32_t count;
+  uint32_t pad;
+};
+
 // Device-visible view of an index (passed to kernels by value).
 struct IndexView {
   const float4* pts;
-  const float* soa;             // per leaf: x[LEAF], y[LEAF], z[LEAF] (scalar-load friendly copy)
+  const float* soa;             // per leaf: x[LEAF], y[LEAF], z[LEAF], w[LEAF] (LDS-staging copy)
   const float4* nrm;
-  const Box* box[MAX_LEVELS];   // box[1] = leaves
-  uint32_t count[MAX_LEVELS];   // boxes per level
+  const LevelInfo* lv;          // [MAX_LEVELS] in device memory; lv[1] = leaves
+  const Box* box[MAX_LEVELS];   // the same table in kernel arguments (SGPRs): selected with a
+  uint32_t count[MAX_LEVELS];   // wave-uniform switch, no memory access on the traversal's critical path
+  const Box* topcache;          // boxes of levels >= cache_from, contiguous (<= TOPCACHE_BOXES): every
+  uint32_t cache_off[MAX_LEVELS];  // block copies them to LDS once, so scans of the upper levels never
+  int cache_from;               // leave the CU (MAX_LEVELS if nothing is cached)
+  uint32_t cache_count;
   int top;                      // highest level (count[top] <= FANOUT)
   uint32_t n;                   // finite points
   uint32_t n_pad;
@@ -73,6 +86,11 @@ struct pclhip_index {
   float4* nrm = nullptr;
   uint32_t* rank = nullptr;
   pclhip::Box* box[pclhip::MAX_LEVELS] = {};
+  pclhip::LevelInfo* lv_dev = nullptr;
+  pclhip::Box* topcache = nullptr;
+  uint32_t cache_off[pclhip::MAX_LEVELS] = {};
+  int cache_from = pclhip::MAX_LEVELS;
+  uint32_t cache_count = 0;
   uint32_t count[pclhip::MAX_LEVELS] = {};
   int top = 0;
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};

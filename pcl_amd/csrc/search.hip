@@ -7,6 +7,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "traverse.hpp"
@@ -25,7 +26,9 @@ template <int K>
 __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const float4* __restrict__ q,
                                                         uint32_t nq, int k, int32_t* __restrict__ out_idx,
                                                         float* __restrict__ out_d2, unsigned long long* gstats) {
-  __shared__ uint2 stack_s[WAVES_PER_BLOCK][STACK_ENTRIES];
+  __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
+  __shared__ Box topbox_s[TOPCACHE_BOXES];
+  load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups);
@@ -43,14 +46,14 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
     if constexpr (K == 1) {
       NN1Min fast;
       fast.init(__builtin_inff());
-      traverse(ix, p.x, p.y, p.z, valid, fast, stack_s[threadIdx.x / WAVE], ts);
+      traverse(ix, p.x, p.y, p.z, valid, fast, wl_s[threadIdx.x / WAVE], topbox_s, ts);
       NN1 pol;
-      fast.resolve(ix, p.x, p.y, p.z, pol.key, pol.pos);
+      fast.resolve(ix, pol.key, pol.pos);
       // exactness: cross-leaf distance ties, or nothing below +inf although the index is not empty
-      const bool redo = valid && (fast.tie || fast.bestleaf == NO_INDEX);
+      const bool redo = valid && (fast.tie || fast.bestpos == NO_INDEX);
       if (__builtin_amdgcn_ballot_w64(redo) != 0) {
         NN1 ex = pol;
-        traverse(ix, p.x, p.y, p.z, redo, ex, stack_s[threadIdx.x / WAVE], ts);
+        traverse(ix, p.x, p.y, p.z, redo, ex, wl_s[threadIdx.x / WAVE], topbox_s, ts);
         if (redo) pol = ex;
       }
       if (real) {
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
     } else {
       TopKReg<K> pol;
       pol.init(KEY_NONE);
-      traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE], ts);
+      traverse(ix, p.x, p.y, p.z, valid, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
       if (real) {
 #pragma unroll
         for (int c = 0; c < K; ++c) {
@@ -84,7 +87,9 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
 __global__ __launch_bounds__(BLOCK) void knn_heap_kernel(IndexView ix, const float4* __restrict__ q,
                                                          uint32_t nq, int k, int32_t* __restrict__ out_idx,
                                                          float* __restrict__ out_d2, uint64_t* heap, unsigned long long* gstats) {
-  __shared__ uint2 stack_s[WAVES_PER_BLOCK][STACK_ENTRIES];
+  __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
+  __shared__ Box topbox_s[TOPCACHE_BOXES];
+  load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups);
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(BLOCK) void knn_heap_kernel(IndexView ix, const flo
     pol.k = real ? k : 0;
     pol.init(KEY_NONE);
     if (!valid) pol.root = 0;  // lanes without a finite query never insert (key < 0 is impossible)
-    traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE], ts);
+    traverse(ix, p.x, p.y, p.z, valid, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
     if (real) {
       pol.sort_ascending();
       for (int c = 0; c < k; ++c) {
@@ -358,7 +363,9 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
                                                         float4* __restrict__ nrm_sorted,
                                                         unsigned long long* __restrict__ nan_count,
                                                         unsigned long long* gstats) {
-  __shared__ uint2 stack_s[WAVES_PER_BLOCK][STACK_ENTRIES];
+  __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
+  __shared__ Box topbox_s[TOPCACHE_BOXES];
+  load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t ngroups = (ix.n + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups);
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
     if (valid) p = ix.pts[i];
     TopKReg<K> pol;
     pol.init(KEY_NONE);
-    traverse(ix, p.x, p.y, p.z, valid, pol, stack_s[threadIdx.x / WAVE], ts);
+    traverse(ix, p.x, p.y, p.z, valid, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
     if (valid) {
       // normal_3d.hpp:59-66 + normal_3d.h:308-322: fewer than 3 neighbours -> NaN
       int found = 0;
@@ -523,24 +530,26 @@ struct Mat34 {
 
 // order 0: Eigen Matrix4f * Vector4f (registration/include/pcl/registration/impl/icp.hpp:49-111)
 // order 1: Transformer<float>::se3 (common/include/pcl/common/impl/transforms.hpp:117-123)
-__device__ __forceinline__ float xform_row(const float* r, float x, float y, float z, int order) {
+__device__ __forceinline__ float xform_row(float r0, float r1, float r2, float r3, float x, float y, float z,
+                                           int order) {
   if (order == 0)
-    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r[0], x), __fmul_rn(r[1], y)), __fmul_rn(r[2], z)),
-                     __fmul_rn(r[3], 1.0f));
-  return __fadd_rn(__fmul_rn(r[0], x), __fadd_rn(__fmul_rn(r[1], y), __fadd_rn(__fmul_rn(r[2], z), r[3])));
+    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r0, x), __fmul_rn(r1, y)), __fmul_rn(r2, z)), __fmul_rn(r3, 1.0f));
+  return __fadd_rn(__fmul_rn(r0, x), __fadd_rn(__fmul_rn(r1, y), __fadd_rn(__fmul_rn(r2, z), r3)));
 }
 
 constexpr int NS = PCLHIP_ICP_NSUMS;
 
-template <int MODE>
-__global__ __launch_bounds__(BLOCK) void icp_iterate_kernel(IndexView ix, float4* __restrict__ cur, uint32_t ns,
+template <int MODE, int MINW>
+__global__ __launch_bounds__(BLOCK, MINW) void icp_iterate_kernel(IndexView ix, float4* __restrict__ cur, uint32_t ns,
                                                             Mat34 T, int order, float bound, int use_max,
                                                             uint32_t* __restrict__ match_pos,
                                                             uint32_t* __restrict__ match,
                                                             float* __restrict__ match_d2,
                                                             double* __restrict__ partials,
                                                             unsigned long long* gstats) {
-  __shared__ uint2 stack_s[WAVES_PER_BLOCK][STACK_ENTRIES];
+  __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
+  __shared__ Box topbox_s[TOPCACHE_BOXES];
+  load_top_cache(ix, topbox_s);
   __shared__ double red_s[WAVES_PER_BLOCK][NS];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
@@ -564,9 +573,9 @@ __global__ __launch_bounds__(BLOCK) void icp_iterate_kernel(IndexView ix, float4
     const bool in_range = valid;
     valid = valid && isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
     if (valid) {  // cur <- T * cur (non-finite points are left untouched, icp.hpp:97-98)
-      const float x = xform_row(T.m + 0, p.x, p.y, p.z, order);
-      const float y = xform_row(T.m + 4, p.x, p.y, p.z, order);
-      const float z = xform_row(T.m + 8, p.x, p.y, p.z, order);
+      const float x = xform_row(T.m[0], T.m[1], T.m[2], T.m[3], p.x, p.y, p.z, order);
+      const float y = xform_row(T.m[4], T.m[5], T.m[6], T.m[7], p.x, p.y, p.z, order);
+      const float z = xform_row(T.m[8], T.m[9], T.m[10], T.m[11], p.x, p.y, p.z, order);
       p.x = x; p.y = y; p.z = z;
       cur[i] = p;
     }
@@ -577,16 +586,16 @@ __global__ __launch_bounds__(BLOCK) void icp_iterate_kernel(IndexView ix, float4
     const uint32_t seed_pos = in_range ? match_pos[i] : NO_INDEX;
     if (valid && seed_pos != NO_INDEX) {
       const float4 t0 = ix.pts[seed_pos];
-      fast.seed(l2_simple(p.x, p.y, p.z, t0.x, t0.y, t0.z), seed_pos / LEAF);
+      fast.seed(l2_simple(p.x, p.y, p.z, t0.x, t0.y, t0.z), seed_pos);
     }
-    traverse(ix, p.x, p.y, p.z, valid, fast, stack_s[wave], ts);
+    traverse(ix, p.x, p.y, p.z, valid, fast, wl_s[wave], topbox_s, ts);
     NN1 pol;
-    fast.resolve(ix, p.x, p.y, p.z, pol.key, pol.pos);
+    fast.resolve(ix, pol.key, pol.pos);
     {
-      const bool redo = valid && (fast.tie || (fast.bestleaf == NO_INDEX && !use_max));
+      const bool redo = valid && (fast.tie || (fast.bestpos == NO_INDEX && !use_max));
       if (__builtin_amdgcn_ballot_w64(redo) != 0) {  // exact (distance, index) policy for tie lanes
         NN1 ex = pol;
-        traverse(ix, p.x, p.y, p.z, redo, ex, stack_s[wave], ts);
+        traverse(ix, p.x, p.y, p.z, redo, ex, wl_s[wave], topbox_s, ts);
         if (redo) pol = ex;
       }
     }
@@ -696,20 +705,26 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   // candidates must be <= max_d2 (a float): strict bound just above it; +inf when unbounded
   const float bound = use_max ? std::nextafterf(max_d2, __builtin_inff()) : __builtin_inff();
   const uint32_t ngroups = (icp->n + WAVE - 1) / WAVE;
-  int grid = (mode == PCLHIP_ICP_POINT_TO_PLANE)
-                 ? resident_blocks(ctx, icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE>, ngroups)
-                 : resident_blocks(ctx, icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT>, ngroups);
+  // point-to-plane carries 27 fp64 accumulators per lane: 3 waves/SIMD by default; PCLHIP_ICP_WAVES=4
+  // selects the variant compiled for 4 waves/SIMD (<= 128 VGPRs) for A/B measurements
+  static const int want4 = [] {
+    const char* e = getenv("PCLHIP_ICP_WAVES");
+    return (e && atoi(e) == 4) ? 1 : 0;
+  }();
+  auto k_plane3 = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE, 3>;
+  auto k_plane4 = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE, 4>;
+  auto k_point = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT, 4>;
+  int grid;
+  if (mode == PCLHIP_ICP_POINT_TO_PLANE)
+    grid = want4 ? resident_blocks(ctx, k_plane4, ngroups) : resident_blocks(ctx, k_plane3, ngroups);
+  else
+    grid = resident_blocks(ctx, k_point, ngroups);
   if (grid > icp->grid_blocks) grid = icp->grid_blocks;
   if (icp->n > 0) {
     (void)hipEventRecord(icp->ev0, s);
-    if (mode == PCLHIP_ICP_POINT_TO_PLANE)
-      hipLaunchKernelGGL(icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE>, dim3(grid), dim3(BLOCK), 0, s, v,
-                         icp->src_cur, icp->n, M, order, bound, use_max ? 1 : 0, icp->match_pos, icp->match, icp->match_d2,
-                         icp->partials, ctx->stats);
-    else
-      hipLaunchKernelGGL(icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT>, dim3(grid), dim3(BLOCK), 0, s, v,
-                         icp->src_cur, icp->n, M, order, bound, use_max ? 1 : 0, icp->match_pos, icp->match, icp->match_d2,
-                         icp->partials, ctx->stats);
+    auto kern = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? (want4 ? k_plane4 : k_plane3) : k_point;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound,
+                       use_max ? 1 : 0, icp->match_pos, icp->match, icp->match_d2, icp->partials, ctx->stats);
     (void)hipEventRecord(icp->ev1, s);
     hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, grid, icp->sums_dev);
   } else {
@@ -722,9 +737,14 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
 // upper bound of the persistent grid (sizes the partial-sum buffer)
 int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns) {
   const uint32_t ngroups = (ns + WAVE - 1) / WAVE;
-  const int a = resident_blocks(ctx, icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE>, ngroups);
-  const int b = resident_blocks(ctx, icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT>, ngroups);
-  return a > b ? a : b;
+  auto k_plane3 = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE, 3>;
+  auto k_plane4 = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE, 4>;
+  auto k_point = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT, 4>;
+  int g = resident_blocks(ctx, k_plane3, ngroups);
+  const int g4 = resident_blocks(ctx, k_plane4, ngroups), gp = resident_blocks(ctx, k_point, ngroups);
+  if (g4 > g) g = g4;
+  if (gp > g) g = gp;
+  return g;
 }
 
 }  // namespace pclhip

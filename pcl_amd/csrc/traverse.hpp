@@ -1,14 +1,18 @@
 // traverse.hpp -- wavefront-cooperative exact nearest-neighbour traversal of the implicit wide BVH.
 //
-// One wavefront (64 lanes) owns 64 spatially coherent queries (consecutive in Morton order), one
-// per lane.  Tree nodes are visited by the WAVE, not by lanes:
+// One wavefront (64 lanes) owns 64 spatially compact queries (consecutive in kd order), one per
+// lane.  Tree nodes are visited by the WAVE, not by lanes:
 //   * interior node: lane j loads child box j (one coalesced 2 KB read), tests it against the
-//     bounding box of the wave's 64 queries and the wave's pruning radius T = max_i worst_i;
-//     survivors are pushed on a wave-uniform stack in LDS, the nearest child is entered first.
-//   * leaf (16 consecutive sorted points): every lane tests its own query against the leaf box;
-//     if any lane still needs the leaf, its 16 candidates are read through wave-uniform (scalar)
-//     loads, i.e. they sit in SGPRs and every lane evaluates all 16 distances -- coalesced /
-//     broadcast loads only, no per-lane gathers, no divergence inside the hot loop.
+//     bounding box of the wave's 64 queries and the wave's pruning radius T = max_i worst_i
+//     (DPP butterflies); survivors are pushed on a wave-uniform stack in LDS, nearest child first.
+//   * leaf-level node: the surviving leaves are ranked (by distance to the query-group box while
+//     bounds are still loose), their ids + boxes go into a small list in LDS, and their candidate
+//     blocks (x[16] y[16] z[16] w[16] = 256 B per leaf) are fetched for up to 16 leaves at a time
+//     with `global_load_lds_dwordx4` -- the vector-memory path with its deep queues, straight into
+//     LDS, no VGPRs -- WHILE the per-lane box tests run.  (The first version read each leaf through
+//     the scalar cache: one dependent scalar-load miss per visited leaf was the whole kernel's
+//     critical path.)  A leaf that some lane still needs is then evaluated by every lane against
+//     all 16 candidates: broadcast `ds_read_b128` + packed `v_pk_*` math, no gathers, no divergence.
 // All bounds are exact in float: rounding is monotone and the bound uses the same operation order
 // as the distance, so box_lb(q, box) <= l2_simple(q, c) for every c in the box, bit for bit.
 // Distances follow FLANN's L2_Simple order ((dx*dx)+dy*dy)+dz*dz with no FMA contraction
@@ -19,7 +23,16 @@
 
 namespace pclhip {
 
-constexpr int STACK_ENTRIES = 64 * MAX_LEVELS;  // worst case: every level pushes 63 siblings
+constexpr int STACK_ENTRIES = 192;     // <= 63 siblings per interior level below the root scan, <= 3 such levels
+constexpr int LEAF_BATCH = 16;         // leaves staged in LDS at a time (16 x 256 B = 4 KB)
+constexpr int LEAF_FLOATS = 4 * LEAF;  // x[16] y[16] z[16] w[16]
+
+// Per-wavefront LDS working set (7.5 KB): traversal stack, ranked leaf list, staged candidate blocks.
+struct __attribute__((aligned(16))) WaveLds {
+  uint2 stack[STACK_ENTRIES];           // 1.5 KB
+  float4 list[2 * FANOUT];              // 2 KB: per ranked leaf (lo.xyz, id) (hi.xyz, lbG)
+  float buf[LEAF_BATCH * LEAF_FLOATS];  // 4 KB
+};
 
 __device__ __forceinline__ float l2_simple(float qx, float qy, float qz, float cx, float cy, float cz) {
   const float dx = __fsub_rn(qx, cx), dy = __fsub_rn(qy, cy), dz = __fsub_rn(qz, cz);
@@ -92,14 +105,8 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
-
-// Leaf candidates are read through the CONSTANT address space: the address is wave-uniform and the
-// index is never written while a search kernel runs, so hipcc emits s_load_dwordx4 (scalar cache
-// -> SGPRs) and every lane gets the candidate as a scalar operand -- no VGPRs, no vector-memory
-// instructions and no LDS traffic in the all-pairs loop.
-typedef const float __attribute__((address_space(4))) * leaf_ptr_t;  // 4 floats per candidate
-__device__ __forceinline__ leaf_ptr_t leaf_pointer(const float4* pts, uint32_t leaf_id) {
-  return (leaf_ptr_t)(unsigned long long)(pts + size_t(leaf_id) * LEAF);
+__device__ __forceinline__ float uniform_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
 constexpr uint64_t KEY_NONE = (uint64_t(0x7F800000u) << 32) | 0xFFFFFFFFull;  // (+inf, no index)
@@ -109,8 +116,22 @@ __device__ __forceinline__ uint64_t make_key(float d, uint32_t idx) {
 __device__ __forceinline__ float key_dist(uint64_t k) { return __uint_as_float(uint32_t(k >> 32)); }
 __device__ __forceinline__ uint32_t key_index(uint64_t k) { return uint32_t(k); }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// distances of candidate pair j of a staged leaf block (LDS, x[16] y[16] z[16] w[16])
+__device__ __forceinline__ v2f pair_dist(const float* l, int j, v2f qx2, v2f qy2, v2f qz2) {
+  const v2f* p = reinterpret_cast<const v2f*>(l);
+  const v2f dx = qx2 - p[j], dy = qy2 - p[LEAF / 2 + j], dz = qz2 - p[LEAF + j];
+  v2f r = dx * dx;
+  r = r + dy * dy;
+  r = r + dz * dz;
+  return r;
+}
+
 // ---- leaf policies -------------------------------------------------------------------------------
-// 1-NN: best (distance, original index) key + sorted position of the winner.
+// All policies see a staged leaf block `l` in LDS and the leaf id; every lane runs them.
+//
+// 1-NN, exact (distance, original index) order: used for ties and as the reference policy.
 struct NN1 {
   uint64_t key;
   uint32_t pos;
@@ -119,13 +140,12 @@ struct NN1 {
     pos = NO_INDEX;
   }
   __device__ __forceinline__ float worst() const { return key_dist(key); }
-  __device__ __forceinline__ void leaf(const IndexView& ix, uint32_t leaf_id, float qx, float qy, float qz) {
-    const leaf_ptr_t p = leaf_pointer(ix.pts, leaf_id);  // wave-uniform address
+  __device__ __forceinline__ void leaf(const float* l, uint32_t leaf_id, float qx, float qy, float qz) {
     const uint32_t base = leaf_id * LEAF;
 #pragma unroll
     for (int c = 0; c < LEAF; ++c) {
-      const float d = l2_simple(qx, qy, qz, p[4 * c], p[4 * c + 1], p[4 * c + 2]);
-      const uint64_t k = make_key(d, __float_as_uint(p[4 * c + 3]));
+      const float d = l2_simple(qx, qy, qz, l[c], l[LEAF + c], l[2 * LEAF + c]);
+      const uint64_t k = make_key(d, __float_as_uint(l[3 * LEAF + c]));
       const bool t = k < key;
       key = t ? k : key;
       pos = t ? base + c : pos;
@@ -134,63 +154,65 @@ struct NN1 {
 };
 
 // 1-NN fast path: the hot loop only tracks the minimum DISTANCE (packed v_pk_* math on candidate
-// pairs read as SGPR pairs from the per-leaf SoA copy, one v_min3 per pair) and remembers in which
-// leaf the minimum was first reached.  The winner's index is resolved once per query afterwards
-// (resolve()); exact cross-leaf distance ties raise `tie`, and the caller then re-runs the exact
-// (distance, index) policy NN1 for those lanes, so results stay bit-identical to the oracle.
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef const v2f __attribute__((address_space(4))) * soa_ptr_t;
+// pairs, one v_min3 per pair).  Only when some lane's minimum improves (rare once bounds are tight:
+// seeded ICP iterations) the leaf is re-scanned to find WHICH slot produced it.  Exact distance ties
+// (two slots of a leaf, or an equal minimum in another leaf) raise `tie`; the caller then re-runs
+// the exact policy NN1 for those lanes, so results stay bit-identical to the oracle.
 struct NN1Min {
-  float best;         // candidates must be strictly below this to win
-  uint32_t bestleaf;  // leaf that first reached `best`, NO_INDEX while best is only the bound
+  float best;        // candidates must be strictly below this to win
+  uint32_t bestpos;  // sorted position of the candidate that first reached `best`; NO_INDEX while
+                     // best is only the bound
   bool tie;
   __device__ __forceinline__ void init(float bound_exclusive) {
     best = bound_exclusive;
-    bestleaf = NO_INDEX;
+    bestpos = NO_INDEX;
     tie = false;
   }
-  __device__ __forceinline__ void seed(float d, uint32_t leaf_id) {
+  __device__ __forceinline__ void seed(float d, uint32_t pos) {
     if (d < best) {
       best = d;
-      bestleaf = leaf_id;
+      bestpos = pos;
     }
   }
   __device__ __forceinline__ float worst() const { return best; }
-  __device__ __forceinline__ void leaf(const IndexView& ix, uint32_t leaf_id, float qx, float qy, float qz) {
-    const soa_ptr_t p = (soa_ptr_t)(unsigned long long)(ix.soa + size_t(leaf_id) * (3 * LEAF));
+  __device__ __forceinline__ void leaf(const float* l, uint32_t leaf_id, float qx, float qy, float qz) {
     const v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
     float m = __builtin_inff();
 #pragma unroll
     for (int j = 0; j < LEAF / 2; ++j) {
-      const v2f dx = qx2 - p[j], dy = qy2 - p[LEAF / 2 + j], dz = qz2 - p[LEAF + j];
-      v2f r = dx * dx;
-      r = r + dy * dy;
-      r = r + dz * dz;
+      const v2f r = pair_dist(l, j, qx2, qy2, qz2);
       m = __builtin_fminf(m, __builtin_fminf(r.x, r.y));
     }
     const bool imp = m < best;
-    const bool eq = (m == best) && (bestleaf != NO_INDEX) && (bestleaf != leaf_id);
-    tie = imp ? false : (tie || eq);
-    bestleaf = imp ? leaf_id : bestleaf;
-    best = imp ? m : best;
-  }
-  // (distance, original index) key and sorted position of the winner; NO_INDEX if none
-  __device__ __forceinline__ void resolve(const IndexView& ix, float qx, float qy, float qz, uint64_t& key,
-                                          uint32_t& pos) const {
-    key = KEY_NONE;
-    pos = NO_INDEX;
-    if (bestleaf == NO_INDEX) return;
-    const float4* __restrict__ p = ix.pts + size_t(bestleaf) * LEAF;
-#pragma unroll 4
-    for (int c = 0; c < LEAF; ++c) {
-      const float4 v = p[c];
-      const float d = l2_simple(qx, qy, qz, v.x, v.y, v.z);
-      const uint64_t k = make_key(d, __float_as_uint(v.w));
-      if (d == best && k < key) {
-        key = k;
-        pos = bestleaf * LEAF + c;
+    // equal minimum in a different leaf than the current winner's: possible index tie
+    const bool eq = (m == best) && (bestpos != NO_INDEX) && (bestpos / LEAF != leaf_id);
+    tie = tie || eq;
+    if (__builtin_amdgcn_ballot_w64(imp) != 0) {
+      // The re-scan recomputes the same distances.  Launder the query through an empty asm so the
+      // compiler cannot merge it with the hot loop above (it otherwise if-converts this block and
+      // executes the 16 compares + mask building for EVERY leaf: +40 % instructions per leaf).
+      float ax = qx, ay = qy, az = qz;
+      asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az));
+      const v2f rx2 = {ax, ax}, ry2 = {ay, ay}, rz2 = {az, az};
+      uint32_t hit = 0;
+#pragma unroll
+      for (int j = 0; j < LEAF / 2; ++j) {
+        const v2f r = pair_dist(l, j, rx2, ry2, rz2);
+        hit |= (r.x == m ? 1u : 0u) << (2 * j);
+        hit |= (r.y == m ? 1u : 0u) << (2 * j + 1);
+      }
+      if (imp) {
+        best = m;
+        bestpos = leaf_id * LEAF + uint32_t(__builtin_ctz(hit));
+        tie = (hit & (hit - 1u)) != 0u;  // two slots of this leaf share the minimum: index tie
       }
     }
+  }
+  // (distance, original index) key and sorted position of the winner; NO_INDEX if none
+  __device__ __forceinline__ void resolve(const IndexView& ix, uint64_t& key, uint32_t& pos) const {
+    key = KEY_NONE;
+    pos = bestpos;
+    if (bestpos != NO_INDEX) key = make_key(best, __float_as_uint(ix.pts[bestpos].w));
   }
 };
 
@@ -220,14 +242,22 @@ struct TopKReg {
     keys[0] = below ? k : keys[0];
     pos[0] = below ? p : pos[0];
   }
-  __device__ __forceinline__ void leaf(const IndexView& ix, uint32_t leaf_id, float qx, float qy, float qz) {
-    const leaf_ptr_t p = leaf_pointer(ix.pts, leaf_id);
+  // A candidate pair is looked at further only if some lane has d <= its current k-th distance; the
+  // exact (distance, index) order is decided inside insert(), so ties stay exact.
+  __device__ __forceinline__ void leaf(const float* l, uint32_t leaf_id, float qx, float qy, float qz) {
     const uint32_t base = leaf_id * LEAF;
+    const v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
 #pragma unroll
-    for (int c = 0; c < LEAF; ++c) {
-      const float d = l2_simple(qx, qy, qz, p[4 * c], p[4 * c + 1], p[4 * c + 2]);
-      const uint64_t k = make_key(d, __float_as_uint(p[4 * c + 3]));
-      if (__builtin_amdgcn_ballot_w64(k < keys[K - 1]) != 0) insert(k, base + c);  // wave-uniform branch
+    for (int j = 0; j < LEAF / 2; ++j) {
+      const v2f r = pair_dist(l, j, qx2, qy2, qz2);
+      const float wd = key_dist(keys[K - 1]);
+      const bool e0 = r.x <= wd, e1 = r.y <= wd;
+      if (__builtin_amdgcn_ballot_w64(e0 || e1) != 0) {  // wave-uniform branch
+        if (__builtin_amdgcn_ballot_w64(e0) != 0)
+          insert(make_key(r.x, __float_as_uint(l[3 * LEAF + 2 * j])), base + 2 * j);
+        if (__builtin_amdgcn_ballot_w64(r.y <= key_dist(keys[K - 1])) != 0)
+          insert(make_key(r.y, __float_as_uint(l[3 * LEAF + 2 * j + 1])), base + 2 * j + 1);
+      }
     }
   }
 };
@@ -270,11 +300,10 @@ struct TopKHeap {
     heap[size_t(i) * stride] = key;
     root = heap[0];
   }
-  __device__ __forceinline__ void leaf(const IndexView& ix, uint32_t leaf_id, float qx, float qy, float qz) {
-    const leaf_ptr_t p = leaf_pointer(ix.pts, leaf_id);
+  __device__ __forceinline__ void leaf(const float* l, uint32_t leaf_id, float qx, float qy, float qz) {
     for (int c = 0; c < LEAF; ++c) {
-      const float d = l2_simple(qx, qy, qz, p[4 * c], p[4 * c + 1], p[4 * c + 2]);
-      const uint64_t key = make_key(d, __float_as_uint(p[4 * c + 3]));
+      const float d = l2_simple(qx, qy, qz, l[c], l[LEAF + c], l[2 * LEAF + c]);
+      const uint64_t key = make_key(d, __float_as_uint(l[3 * LEAF + c]));
       if (key < root) replace_root(key);
     }
   }
@@ -284,7 +313,6 @@ struct TopKHeap {
       const uint64_t top = heap[0];
       const uint64_t last = heap[size_t(end) * stride];
       heap[size_t(end) * stride] = top;
-      // sift `last` down in heap[0..end)
       int i = 0;
       for (;;) {
         int l = 2 * i + 1, r = l + 1, big = i;
@@ -320,10 +348,16 @@ struct TraverseStats {
 };
 
 // ---- the traversal --------------------------------------------------------------------------------
-// `stack` points at this wave's STACK_ENTRIES uint2 slots in LDS.  Must be called by all 64 lanes.
+// `wl` is this wave's LDS working set.  Must be called by all 64 lanes.
+// Per-block LDS copy of the boxes of the top tree levels (IndexView::topcache): filled once per block.
+__device__ __forceinline__ void load_top_cache(const IndexView& ix, Box* topbox) {
+  for (uint32_t i = threadIdx.x; i < ix.cache_count; i += blockDim.x) topbox[i] = ix.topcache[i];
+  __syncthreads();
+}
+
 template <class Policy>
 __device__ __forceinline__ void traverse(const IndexView& ix, float qx, float qy, float qz, bool valid,
-                                         Policy& pol, uint2* stack, TraverseStats& ts) {
+                                         Policy& pol, WaveLds& wl, const Box* topbox, TraverseStats& ts) {
   const int lane = threadIdx.x & (WAVE - 1);
   if (__builtin_amdgcn_ballot_w64(valid) == 0 || ix.n == 0) return;
   ++ts.c[4];
@@ -336,6 +370,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, float qx, float qy
               Qhz = wave_max_f(valid ? qz : -BIG);
   float T = wave_max_f(valid ? pol.worst() : 0.0f);  // wave pruning radius (squared)
   const float gdiag2 = (Qhx - Qlx) * (Qhx - Qlx) + (Qhy - Qly) * (Qhy - Qly) + (Qhz - Qlz) * (Qhz - Qlz);
+  uint2* const stack = wl.stack;
 
   int sp = 0;
   uint32_t level = uint32_t(ix.top) + 1u, node = 0u;  // virtual root above the top level
@@ -355,92 +390,121 @@ __device__ __forceinline__ void traverse(const IndexView& ix, float qx, float qy
     ++ts.c[0];
     const uint32_t cl = level - 1u;  // level of the children
     const uint32_t first = node * FANOUT;
-    const uint32_t total = ix.count[cl];
+    // level table entry: a wave-uniform select over kernel arguments (SGPRs) -- no memory access on
+    // the traversal's critical path
+    const Box* level_box = ix.box[1];
+    uint32_t total = ix.count[1], coff = 0;
+#pragma unroll
+    for (int l = 2; l < MAX_LEVELS; ++l) {
+      if (cl == uint32_t(l)) {
+        level_box = ix.box[l];
+        total = ix.count[l];
+        coff = ix.cache_off[l];
+      }
+    }
     const uint32_t nchild = (total - first) < uint32_t(FANOUT) ? (total - first) : uint32_t(FANOUT);
     const bool has = uint32_t(lane) < nchild;
     float lx = 0, ly = 0, lz = 0, hx = 0, hy = 0, hz = 0;
-    if (has) {
-      const Box b = ix.box[cl][first + lane];
+    if (int(cl) >= ix.cache_from) {  // upper levels: boxes come from the block's LDS copy
+      if (has) {
+        const Box b = topbox[coff + first + lane];
+        lx = b.lo.x; ly = b.lo.y; lz = b.lo.z;
+        hx = b.hi.x; hy = b.hi.y; hz = b.hi.z;
+      }
+    } else if (has) {
+      const Box b = level_box[first + lane];
       lx = b.lo.x; ly = b.lo.y; lz = b.lo.z;
       hx = b.hi.x; hy = b.hi.y; hz = b.hi.z;
     }
     const float lbG = has ? box_box_lb(Qlx, Qly, Qlz, Qhx, Qhy, Qhz, lx, ly, lz, hx, hy, hz) : INF;
     const bool alive = has && !(lbG > T);
-    uint64_t mask = __builtin_amdgcn_ballot_w64(alive);
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(alive);
     if (mask == 0) continue;
     // Visiting order.  Cold or lukewarm bounds (wave radius not yet small against the group's own
-    // extent, e.g. the first ICP iterations): visit children in ascending order of their distance
-    // to the group box, so the bounds collapse after the first few leaves and everything farther
-    // is cut off at once.  Tight bounds (seeded steady state): the nearest child first, then plain
-    // index order -- no per-child reduction.
+    // extent, e.g. the first ICP iterations): ascending distance to the group box, so the bounds
+    // collapse after the first few leaves and everything farther is cut off at once.  Tight bounds
+    // (seeded steady state): plain index order, no ranking work.
     const bool ordered = T * 16.0f > gdiag2;
     if (cl == 1u) {
+      // ---- rank the surviving leaves and publish (box, id, lbG) in LDS --------------------------
+      uint32_t rank = uint32_t(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
       if (ordered) {
-        bool live = alive;
-        for (;;) {
-          if (__builtin_amdgcn_ballot_w64(live) == 0) break;
-          const float m = wave_min_f(live ? lbG : INF);
-          if (m > T) break;  // every remaining leaf is farther than the wave radius
-          const int j = __builtin_ctzll(__builtin_amdgcn_ballot_w64(live && lbG == m));
-          if (lane == j) live = false;
-          ++ts.c[1];
-          const float blx = readlane_f(lx, j), bly = readlane_f(ly, j), blz = readlane_f(lz, j);
-          const float bhx = readlane_f(hx, j), bhy = readlane_f(hy, j), bhz = readlane_f(hz, j);
-          const float lb = point_box_lb(qx, qy, qz, blx, bly, blz, bhx, bhy, bhz);
-          const bool need = valid && !(lb > pol.worst());
-          if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
-          ++ts.c[2];
-          const float before = pol.worst();
-          pol.leaf(ix, uniform_u32(first + uint32_t(j)), qx, qy, qz);
-          if (__builtin_amdgcn_ballot_w64(valid && pol.worst() < before) != 0)
-            T = wave_max_f(valid ? pol.worst() : 0.0f);
+        rank = 0;
+        for (uint64_t m2 = mask; m2; m2 &= m2 - 1) {
+          const int i = __builtin_ctzll(m2);
+          const float s = readlane_f(lbG, i);
+          rank += (s < lbG || (s == lbG && i < lane)) ? 1u : 0u;
         }
-      } else {
-        const float m = wave_min_f(alive ? lbG : INF);
-        const int jn = __builtin_ctzll(__builtin_amdgcn_ballot_w64(alive && lbG == m));
-        bool first_done = false;
-        while (mask) {
-          int j;
-          if (!first_done) {
-            j = jn;
-            first_done = true;
-          } else {
-            j = __builtin_ctzll(mask);
+      }
+      const uint32_t n_alive = uint32_t(__builtin_popcountll(mask));
+      if (alive) {
+        wl.list[2 * rank] = make_float4(lx, ly, lz, __uint_as_float(first + uint32_t(lane)));
+        wl.list[2 * rank + 1] = make_float4(hx, hy, hz, lbG);
+      }
+      __builtin_amdgcn_wave_barrier();
+      bool cut = false;
+      for (uint32_t b0 = 0; b0 < n_alive && !cut; b0 += LEAF_BATCH) {
+        const uint32_t nb = (n_alive - b0) < uint32_t(LEAF_BATCH) ? (n_alive - b0) : uint32_t(LEAF_BATCH);
+        // ---- stage the batch's candidate blocks: 16 x 16-byte chunks per leaf, LDS-DMA ----------
+        // (all earlier reads of wl.buf were consumed by VALU work, so nothing is still in flight)
+#pragma unroll
+        for (int t = 0; t < (LEAF_BATCH * LEAF_FLOATS * 4) / (WAVE * 16); ++t) {  // 4 instructions
+          const uint32_t slot = uint32_t(t) * (WAVE / 16) + uint32_t(lane) / 16u;
+          if (slot < nb) {
+            const uint32_t leaf_id = __float_as_uint(wl.list[2 * (b0 + slot)].w);
+            const float* src = ix.soa + size_t(leaf_id) * LEAF_FLOATS + (lane & 15) * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(wl.buf + t * (WAVE * 4)), 16, 0,
+                                             0);
           }
-          mask &= ~(1ull << j);
-          if (readlane_f(lbG, j) > T) continue;
+        }
+        bool landed = false;
+        for (uint32_t t = 0; t < nb; ++t) {
+          const float4 ea = wl.list[2 * (b0 + t)], eb = wl.list[2 * (b0 + t) + 1];  // broadcast reads
+          if (uniform_f32(eb.w) > T) {
+            if (ordered) {  // sorted: every remaining leaf is farther than the wave radius
+              cut = true;
+              break;
+            }
+            continue;
+          }
           ++ts.c[1];
-          const float blx = readlane_f(lx, j), bly = readlane_f(ly, j), blz = readlane_f(lz, j);
-          const float bhx = readlane_f(hx, j), bhy = readlane_f(hy, j), bhz = readlane_f(hz, j);
-          const float lb = point_box_lb(qx, qy, qz, blx, bly, blz, bhx, bhy, bhz);
+          const float lb = point_box_lb(qx, qy, qz, ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
           const bool need = valid && !(lb > pol.worst());
           if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
           ++ts.c[2];
+          if (!landed) {  // first use of this batch: the DMA must have landed (it ran under the tests)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            landed = true;
+          }
           const float before = pol.worst();
-          pol.leaf(ix, uniform_u32(first + uint32_t(j)), qx, qy, qz);
+          pol.leaf(wl.buf + t * LEAF_FLOATS, uniform_u32(__float_as_uint(ea.w)), qx, qy, qz);
           // the wave radius can only shrink if some lane's own bound shrank
           if (__builtin_amdgcn_ballot_w64(valid && pol.worst() < before) != 0)
             T = wave_max_f(valid ? pol.worst() : 0.0f);
         }
+        // the next batch overwrites wl.buf: make sure this batch's DMA is not still landing
+        if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     } else {
-      const float m = wave_min_f(alive ? lbG : INF);
-      const int jn = __builtin_ctzll(__builtin_amdgcn_ballot_w64(alive && lbG == m));
+      int jn;
+      if ((mask & (mask - 1)) == 0) {
+        jn = __builtin_ctzll(mask);  // the usual case above the leaf level: exactly one survivor
+      } else {
+        const float m = wave_min_f(alive ? lbG : INF);
+        jn = __builtin_ctzll(__builtin_amdgcn_ballot_w64(alive && lbG == m));
+      }
       const uint64_t others = mask & ~(1ull << jn);
       if (ordered && __builtin_popcountll(others) > 1) {
         // push the other survivors farthest first so that pops come back nearest first
-        bool live = alive && lane != jn;
-        int at = sp;
-        for (;;) {
-          if (__builtin_amdgcn_ballot_w64(live) == 0) break;
-          const float far = wave_max_f(live ? lbG : -1.0f);
-          const int j = __builtin_ctzll(__builtin_amdgcn_ballot_w64(live && lbG == far));
-          if (lane == j) {
-            live = false;
-            stack[at] = make_uint2((cl << 28) | (first + uint32_t(lane)), __float_as_uint(lbG));
-          }
-          ++at;
+        uint32_t rank = 0;
+        for (uint64_t m2 = others; m2; m2 &= m2 - 1) {
+          const int i = __builtin_ctzll(m2);
+          const float s = readlane_f(lbG, i);
+          rank += (s > lbG || (s == lbG && i < lane)) ? 1u : 0u;
         }
+        if (alive && lane != jn)
+          stack[sp + int(rank)] = make_uint2((cl << 28) | (first + uint32_t(lane)), __float_as_uint(lbG));
       } else if (alive && lane != jn) {
         const int at = sp + __builtin_popcountll(others & ((1ull << lane) - 1ull));
         stack[at] = make_uint2((cl << 28) | (first + uint32_t(lane)), __float_as_uint(lbG));
@@ -463,7 +527,7 @@ __device__ __forceinline__ void flush_stats(const TraverseStats& ts, unsigned lo
 }
 
 // XCD-aware mapping of (block, wave, iteration) -> query group: blocks that share an XCD (and its
-// L2) work on one contiguous window of Morton-ordered groups at a time.
+// L2) work on one contiguous window of kd-ordered groups at a time.
 struct GroupSchedule {
   uint32_t groups_per_xcd, xcd_first, slot_wave, waves_per_xcd;
   __device__ __forceinline__ GroupSchedule(uint32_t ngroups) {
