@@ -43,18 +43,22 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
     const uint32_t oq = __float_as_uint(p.w);
     const bool real = valid;  // has an output row
     valid = valid && isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+    const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
+    const bool vv[1] = {valid};
     if constexpr (K == 1) {
       NN1Min fast;
       fast.init(__builtin_inff());
-      traverse(ix, p.x, p.y, p.z, valid, fast, wl_s[threadIdx.x / WAVE], topbox_s, ts);
+      traverse(ix, qx, qy, qz, vv, fast, wl_s[threadIdx.x / WAVE], topbox_s, ts);
       NN1 pol;
-      fast.resolve(ix, pol.key, pol.pos);
+      pol.key = KEY_NONE;
+      pol.pos = fast.bestpos[0];
+      if (fast.bestpos[0] != NO_INDEX) pol.key = make_key(fast.best[0], __float_as_uint(ix.pts[fast.bestpos[0]].w));
       // exactness: cross-leaf distance ties, or nothing below +inf although the index is not empty
-      const bool redo = valid && (fast.tie || fast.bestpos == NO_INDEX);
-      if (__builtin_amdgcn_ballot_w64(redo) != 0) {
+      const bool redo[1] = {valid && (fast.tie[0] || fast.bestpos[0] == NO_INDEX)};
+      if (__builtin_amdgcn_ballot_w64(redo[0]) != 0) {
         NN1 ex = pol;
-        traverse(ix, p.x, p.y, p.z, redo, ex, wl_s[threadIdx.x / WAVE], topbox_s, ts);
-        if (redo) pol = ex;
+        traverse(ix, qx, qy, qz, redo, ex, wl_s[threadIdx.x / WAVE], topbox_s, ts);
+        if (redo[0]) pol = ex;
       }
       if (real) {
         const uint32_t id = key_index(pol.key);
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
     } else {
       TopKReg<K> pol;
       pol.init(KEY_NONE);
-      traverse(ix, p.x, p.y, p.z, valid, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
+      traverse(ix, qx, qy, qz, vv, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
       if (real) {
 #pragma unroll
         for (int c = 0; c < K; ++c) {
@@ -110,7 +114,9 @@ __global__ __launch_bounds__(BLOCK) void knn_heap_kernel(IndexView ix, const flo
     pol.k = real ? k : 0;
     pol.init(KEY_NONE);
     if (!valid) pol.root = 0;  // lanes without a finite query never insert (key < 0 is impossible)
-    traverse(ix, p.x, p.y, p.z, valid, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
+    const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
+    const bool vv[1] = {valid};
+    traverse(ix, qx, qy, qz, vv, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
     if (real) {
       pol.sort_ascending();
       for (int c = 0; c < k; ++c) {
@@ -380,7 +386,11 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
     if (valid) p = ix.pts[i];
     TopKReg<K> pol;
     pol.init(KEY_NONE);
-    traverse(ix, p.x, p.y, p.z, valid, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
+    {
+      const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
+      const bool vv[1] = {valid};
+      traverse(ix, qx, qy, qz, vv, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
+    }
     if (valid) {
       // normal_3d.hpp:59-66 + normal_3d.h:308-322: fewer than 3 neighbours -> NaN
       int found = 0;
@@ -586,17 +596,21 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_iterate_kernel(IndexView ix, 
     const uint32_t seed_pos = in_range ? match_pos[i] : NO_INDEX;
     if (valid && seed_pos != NO_INDEX) {
       const float4 t0 = ix.pts[seed_pos];
-      fast.seed(l2_simple(p.x, p.y, p.z, t0.x, t0.y, t0.z), seed_pos);
+      fast.seed(0, l2_simple(p.x, p.y, p.z, t0.x, t0.y, t0.z), seed_pos);
     }
-    traverse(ix, p.x, p.y, p.z, valid, fast, wl_s[wave], topbox_s, ts);
+    const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
+    const bool vv[1] = {valid};
+    traverse(ix, qx, qy, qz, vv, fast, wl_s[wave], topbox_s, ts);
     NN1 pol;
-    fast.resolve(ix, pol.key, pol.pos);
+    pol.key = KEY_NONE;
+    pol.pos = fast.bestpos[0];
+    if (fast.bestpos[0] != NO_INDEX) pol.key = make_key(fast.best[0], __float_as_uint(ix.pts[fast.bestpos[0]].w));
     {
-      const bool redo = valid && (fast.tie || (fast.bestpos == NO_INDEX && !use_max));
-      if (__builtin_amdgcn_ballot_w64(redo) != 0) {  // exact (distance, index) policy for tie lanes
+      const bool redo[1] = {valid && (fast.tie[0] || (fast.bestpos[0] == NO_INDEX && !use_max))};
+      if (__builtin_amdgcn_ballot_w64(redo[0]) != 0) {  // exact (distance, index) policy for tie lanes
         NN1 ex = pol;
-        traverse(ix, p.x, p.y, p.z, redo, ex, wl_s[wave], topbox_s, ts);
-        if (redo) pol = ex;
+        traverse(ix, qx, qy, qz, redo, ex, wl_s[wave], topbox_s, ts);
+        if (redo[0]) pol = ex;
       }
     }
     const uint32_t mid = key_index(pol.key);
@@ -677,6 +691,206 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_iterate_kernel(IndexView ix, 
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Two-kernel variant of the iteration (PCLHIP_ICP_FUSED=0): a search-only kernel without the 27 fp64
+// accumulators (fewer registers, room to software-pipeline the next group's loads) followed by a
+// streaming accumulate kernel.  Same results as the fused kernel up to fp64 summation order.
+template <int MINW, int Q>
+__global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, float4* __restrict__ cur, uint32_t ns,
+                                                                 Mat34 T, int order, float bound, int use_max,
+                                                                 uint32_t* __restrict__ match_pos,
+                                                                 uint32_t* __restrict__ match,
+                                                                 float* __restrict__ match_d2,
+                                                                 unsigned long long* gstats) {
+  __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
+  __shared__ Box topbox_s[TOPCACHE_BOXES];
+  load_top_cache(ix, topbox_s);
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  constexpr uint32_t GROUP = WAVE * Q;  // queries per wavefront: Q per lane
+  const uint32_t ngroups = (ns + GROUP - 1) / GROUP;
+  const GroupSchedule sched(ngroups);
+  TraverseStats ts;
+  // software pipeline: the next group's points, seed positions and seed target points are already
+  // in flight while the current group is searched
+  uint32_t gl = sched.first();
+  uint32_t g = (gl < sched.groups_per_xcd) ? sched.global(gl) : ngroups;
+  float4 p_n[Q], t_n[Q];
+  uint32_t sp_n[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    p_n[q] = make_float4(0, 0, 0, 0);
+    t_n[q] = make_float4(0, 0, 0, 0);
+    sp_n[q] = NO_INDEX;
+    const uint32_t i = g * GROUP + q * WAVE + lane;
+    if (g < ngroups && i < ns) {
+      p_n[q] = cur[i];
+      sp_n[q] = match_pos[i];
+      if (sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
+    }
+  }
+  while (g < ngroups) {
+    float4 p[Q], t0[Q];
+    uint32_t seed_pos[Q];
+    bool in_range[Q], valid[Q];
+    float qx[Q], qy[Q], qz[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      p[q] = p_n[q];
+      t0[q] = t_n[q];
+      seed_pos[q] = sp_n[q];
+      in_range[q] = (g * GROUP + q * WAVE + lane) < ns;
+    }
+    // next group: issue its points + seed positions now ...
+    gl += sched.step();
+    const uint32_t g2 = (gl < sched.groups_per_xcd) ? sched.global(gl) : ngroups;
+    bool next_ok[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const uint32_t i2 = g2 * GROUP + q * WAVE + lane;
+      next_ok[q] = g2 < ngroups && i2 < ns;
+      p_n[q] = make_float4(0, 0, 0, 0);
+      sp_n[q] = NO_INDEX;
+      if (next_ok[q]) {
+        p_n[q] = cur[i2];
+        sp_n[q] = match_pos[i2];
+      }
+    }
+    NN1MinT<Q> fast;
+    fast.init(bound);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      valid[q] = in_range[q] && isfinite(p[q].x) && isfinite(p[q].y) && isfinite(p[q].z);
+      if (valid[q]) {
+        const float x = xform_row(T.m[0], T.m[1], T.m[2], T.m[3], p[q].x, p[q].y, p[q].z, order);
+        const float y = xform_row(T.m[4], T.m[5], T.m[6], T.m[7], p[q].x, p[q].y, p[q].z, order);
+        const float z = xform_row(T.m[8], T.m[9], T.m[10], T.m[11], p[q].x, p[q].y, p[q].z, order);
+        p[q].x = x; p[q].y = y; p[q].z = z;
+        cur[g * GROUP + q * WAVE + lane] = p[q];
+        if (seed_pos[q] != NO_INDEX)
+          fast.seed(q, l2_simple(x, y, z, t0[q].x, t0[q].y, t0[q].z), seed_pos[q]);
+      }
+      qx[q] = p[q].x; qy[q] = p[q].y; qz[q] = p[q].z;
+    }
+    traverse(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts);
+    // ... and their seed target points as soon as the seed positions have arrived
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      t_n[q] = make_float4(0, 0, 0, 0);
+      if (next_ok[q] && sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      NN1 pol;
+      pol.key = KEY_NONE;
+      pol.pos = fast.bestpos[q];
+      if (fast.bestpos[q] != NO_INDEX) {  // winner's original index: already here when the seed won
+        const float w = (fast.bestpos[q] == seed_pos[q]) ? t0[q].w : ix.pts[fast.bestpos[q]].w;
+        pol.key = make_key(fast.best[q], __float_as_uint(w));
+      }
+      const bool redo[1] = {valid[q] && (fast.tie[q] || (fast.bestpos[q] == NO_INDEX && !use_max))};
+      if (__builtin_amdgcn_ballot_w64(redo[0]) != 0) {  // exact (distance, index) policy for tie lanes
+        NN1 ex = pol;
+        const float ex_x[1] = {qx[q]}, ex_y[1] = {qy[q]}, ex_z[1] = {qz[q]};
+        traverse(ix, ex_x, ex_y, ex_z, redo, ex, wl_s[wave], topbox_s, ts);
+        if (redo[0]) pol = ex;
+      }
+      const uint32_t mid = key_index(pol.key);
+      const bool found = valid[q] && mid != NO_INDEX;
+      if (in_range[q]) {
+        const uint32_t i = g * GROUP + q * WAVE + lane;
+        match[i] = found ? mid : NO_INDEX;
+        match_pos[i] = found ? pol.pos : NO_INDEX;
+        match_d2[i] = found ? key_dist(pol.key) : __builtin_inff();
+      }
+    }
+    g = g2;
+  }
+  flush_stats(ts, gstats);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, const float4* __restrict__ cur, uint32_t ns,
+                                                               const uint32_t* __restrict__ match_pos,
+                                                               const float* __restrict__ match_d2,
+                                                               double* __restrict__ partials) {
+  __shared__ double red_s[WAVES_PER_BLOCK][NS];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  constexpr int NACC = (MODE == PCLHIP_ICP_POINT_TO_PLANE) ? 27 : 15;
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  double sum_d2 = 0.0;
+  uint32_t cnt = 0, skipped = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    const uint32_t pos = match_pos[i];
+    if (pos == NO_INDEX) continue;
+    const float4 p = cur[i];
+    ++cnt;
+    sum_d2 += double(match_d2[i]);
+    const float4 t = ix.pts[pos];
+    if constexpr (MODE == PCLHIP_ICP_POINT_TO_PLANE) {
+      const float4 n = ix.nrm[pos];
+      if (isfinite(n.x) && isfinite(n.y) && isfinite(n.z)) {
+        const float sx = p.x, sy = p.y, sz = p.z;
+        const float nx = n.x, ny = n.y, nz = n.z;
+        const double a = double(__fsub_rn(__fmul_rn(nz, sy), __fmul_rn(ny, sz)));
+        const double b = double(__fsub_rn(__fmul_rn(nx, sz), __fmul_rn(nz, sx)));
+        const double c = double(__fsub_rn(__fmul_rn(ny, sx), __fmul_rn(nx, sy)));
+        acc[0] += a * a;  acc[1] += a * b;  acc[2] += a * c;
+        acc[3] += a * double(nx); acc[4] += a * double(ny); acc[5] += a * double(nz);
+        acc[6] += b * b;  acc[7] += b * c;
+        acc[8] += b * double(nx); acc[9] += b * double(ny); acc[10] += b * double(nz);
+        acc[11] += c * c;
+        acc[12] += c * double(nx); acc[13] += c * double(ny); acc[14] += c * double(nz);
+        acc[15] += double(__fmul_rn(nx, nx)); acc[16] += double(__fmul_rn(nx, ny));
+        acc[17] += double(__fmul_rn(nx, nz)); acc[18] += double(__fmul_rn(ny, ny));
+        acc[19] += double(__fmul_rn(ny, nz)); acc[20] += double(__fmul_rn(nz, nz));
+        float df = __fmul_rn(nx, t.x);
+        df = __fadd_rn(df, __fmul_rn(ny, t.y));
+        df = __fadd_rn(df, __fmul_rn(nz, t.z));
+        df = __fsub_rn(df, __fmul_rn(nx, sx));
+        df = __fsub_rn(df, __fmul_rn(ny, sy));
+        df = __fsub_rn(df, __fmul_rn(nz, sz));
+        const double d = double(df);
+        acc[21] += a * d; acc[22] += b * d; acc[23] += c * d;
+        acc[24] += double(nx) * d; acc[25] += double(ny) * d; acc[26] += double(nz) * d;
+      } else {
+        ++skipped;
+      }
+    } else {
+      const double sx = p.x, sy = p.y, sz = p.z, tx = t.x, ty = t.y, tz = t.z;
+      acc[0] += sx; acc[1] += sy; acc[2] += sz;
+      acc[3] += tx; acc[4] += ty; acc[5] += tz;
+      acc[6] += tx * sx; acc[7] += tx * sy; acc[8] += tx * sz;
+      acc[9] += ty * sx; acc[10] += ty * sy; acc[11] += ty * sz;
+      acc[12] += tz * sx; acc[13] += tz * sy; acc[14] += tz * sz;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    const double s = wave_sum_d(acc[i]);
+    if (lane == 0) red_s[wave][i] = s;
+  }
+  {
+    const double s0 = wave_sum_d(sum_d2), s1 = wave_sum_d(double(cnt)), s2 = wave_sum_d(double(skipped));
+    if (lane == 0) {
+      for (int i = NACC; i < NS; ++i) red_s[wave][i] = 0.0;
+      red_s[wave][27] = s0;
+      red_s[wave][28] = s1;
+      red_s[wave][29] = s2;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES_PER_BLOCK; ++w) s += red_s[w][threadIdx.x];
+    partials[size_t(blockIdx.x) * NS + threadIdx.x] = s;
+  }
+}
+
 // partials[nblocks][NS] -> sums[NS]; fixed summation order (stride-32 lanes, then 32 partial sums in
 // order) so the result does not depend on scheduling
 __global__ __launch_bounds__(1024) void icp_finalize_kernel(const double* __restrict__ partials, int nblocks,
@@ -720,7 +934,33 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   else
     grid = resident_blocks(ctx, k_point, ngroups);
   if (grid > icp->grid_blocks) grid = icp->grid_blocks;
-  if (icp->n > 0) {
+  static const int unfused = [] {
+    const char* e = getenv("PCLHIP_ICP_FUSED");
+    return (e && atoi(e) == 0) ? 1 : 0;
+  }();
+  if (icp->n > 0 && unfused) {
+    static const int qpl = [] {
+      const char* e = getenv("PCLHIP_ICP_QPL");
+      return (e && atoi(e) == 1) ? 1 : 2;
+    }();
+    auto ks = (qpl == 2) ? icp_search_kernel<4, 2> : icp_search_kernel<4, 1>;
+    const uint32_t ngroups_s = (icp->n + WAVE * qpl - 1) / (WAVE * qpl);
+    int gs = (qpl == 2) ? resident_blocks(ctx, icp_search_kernel<4, 2>, ngroups_s)
+                        : resident_blocks(ctx, icp_search_kernel<4, 1>, ngroups_s);
+    (void)hipEventRecord(icp->ev0, s);
+    hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound, use_max ? 1 : 0,
+                       icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+    int ga = ctx->num_cus * 8;
+    if (ga > icp->grid_blocks) ga = icp->grid_blocks;
+    if (mode == PCLHIP_ICP_POINT_TO_PLANE)
+      hipLaunchKernelGGL(icp_accumulate_kernel<PCLHIP_ICP_POINT_TO_PLANE>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur,
+                         icp->n, icp->match_pos, icp->match_d2, icp->partials);
+    else
+      hipLaunchKernelGGL(icp_accumulate_kernel<PCLHIP_ICP_POINT_TO_POINT>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur,
+                         icp->n, icp->match_pos, icp->match_d2, icp->partials);
+    (void)hipEventRecord(icp->ev1, s);
+    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, ga, icp->sums_dev);
+  } else if (icp->n > 0) {
     (void)hipEventRecord(icp->ev0, s);
     auto kern = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? (want4 ? k_plane4 : k_plane3) : k_point;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound,
@@ -744,6 +984,7 @@ int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns) {
   const int g4 = resident_blocks(ctx, k_plane4, ngroups), gp = resident_blocks(ctx, k_point, ngroups);
   if (g4 > g) g = g4;
   if (gp > g) g = gp;
+  if (ctx->num_cus * 8 > g) g = ctx->num_cus * 8;  // the streaming accumulate kernel of the two-kernel variant
   return g;
 }
 

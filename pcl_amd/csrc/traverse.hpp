@@ -139,12 +139,14 @@ struct NN1 {
     key = k0;
     pos = NO_INDEX;
   }
-  __device__ __forceinline__ float worst() const { return key_dist(key); }
-  __device__ __forceinline__ void leaf(const float* l, uint32_t leaf_id, float qx, float qy, float qz) {
+  static constexpr int QPL = 1;
+  __device__ __forceinline__ float worst(int) const { return key_dist(key); }
+  __device__ __forceinline__ void leaf(const float* l, uint32_t leaf_id, const float* qx, const float* qy,
+                                       const float* qz) {
     const uint32_t base = leaf_id * LEAF;
 #pragma unroll
     for (int c = 0; c < LEAF; ++c) {
-      const float d = l2_simple(qx, qy, qz, l[c], l[LEAF + c], l[2 * LEAF + c]);
+      const float d = l2_simple(qx[0], qy[0], qz[0], l[c], l[LEAF + c], l[2 * LEAF + c]);
       const uint64_t k = make_key(d, __float_as_uint(l[3 * LEAF + c]));
       const bool t = k < key;
       key = t ? k : key;
@@ -158,63 +160,78 @@ struct NN1 {
 // seeded ICP iterations) the leaf is re-scanned to find WHICH slot produced it.  Exact distance ties
 // (two slots of a leaf, or an equal minimum in another leaf) raise `tie`; the caller then re-runs
 // the exact policy NN1 for those lanes, so results stay bit-identical to the oracle.
-struct NN1Min {
-  float best;        // candidates must be strictly below this to win
-  uint32_t bestpos;  // sorted position of the candidate that first reached `best`; NO_INDEX while
-                     // best is only the bound
-  bool tie;
+template <int Q>
+struct NN1MinT {
+  static constexpr int QPL = Q;  // queries per lane: the wave owns 64*Q queries and every staged
+                                 // candidate block / node scan / leaf test is shared by all of them
+  float best[Q];         // candidates must be strictly below this to win
+  uint32_t bestpos[Q];   // sorted position of the candidate that first reached `best`; NO_INDEX while
+                         // best is only the bound
+  bool tie[Q];
   __device__ __forceinline__ void init(float bound_exclusive) {
-    best = bound_exclusive;
-    bestpos = NO_INDEX;
-    tie = false;
-  }
-  __device__ __forceinline__ void seed(float d, uint32_t pos) {
-    if (d < best) {
-      best = d;
-      bestpos = pos;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      best[q] = bound_exclusive;
+      bestpos[q] = NO_INDEX;
+      tie[q] = false;
     }
   }
-  __device__ __forceinline__ float worst() const { return best; }
-  __device__ __forceinline__ void leaf(const float* l, uint32_t leaf_id, float qx, float qy, float qz) {
-    const v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
-    float m = __builtin_inff();
+  __device__ __forceinline__ void seed(int q, float d, uint32_t pos) {
+    if (d < best[q]) {
+      best[q] = d;
+      bestpos[q] = pos;
+    }
+  }
+  __device__ __forceinline__ float worst(int q) const { return best[q]; }
+  __device__ __forceinline__ void leaf(const float* l, uint32_t leaf_id, const float* qx, const float* qy,
+                                       const float* qz) {
+    float m[Q];
+    v2f qx2[Q], qy2[Q], qz2[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      m[q] = __builtin_inff();
+      qx2[q] = v2f{qx[q], qx[q]};
+      qy2[q] = v2f{qy[q], qy[q]};
+      qz2[q] = v2f{qz[q], qz[q]};
+    }
 #pragma unroll
     for (int j = 0; j < LEAF / 2; ++j) {
-      const v2f r = pair_dist(l, j, qx2, qy2, qz2);
-      m = __builtin_fminf(m, __builtin_fminf(r.x, r.y));
-    }
-    const bool imp = m < best;
-    // equal minimum in a different leaf than the current winner's: possible index tie
-    const bool eq = (m == best) && (bestpos != NO_INDEX) && (bestpos / LEAF != leaf_id);
-    tie = tie || eq;
-    if (__builtin_amdgcn_ballot_w64(imp) != 0) {
-      // The re-scan recomputes the same distances.  Launder the query through an empty asm so the
-      // compiler cannot merge it with the hot loop above (it otherwise if-converts this block and
-      // executes the 16 compares + mask building for EVERY leaf: +40 % instructions per leaf).
-      float ax = qx, ay = qy, az = qz;
-      asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az));
-      const v2f rx2 = {ax, ax}, ry2 = {ay, ay}, rz2 = {az, az};
-      uint32_t hit = 0;
 #pragma unroll
-      for (int j = 0; j < LEAF / 2; ++j) {
-        const v2f r = pair_dist(l, j, rx2, ry2, rz2);
-        hit |= (r.x == m ? 1u : 0u) << (2 * j);
-        hit |= (r.y == m ? 1u : 0u) << (2 * j + 1);
-      }
-      if (imp) {
-        best = m;
-        bestpos = leaf_id * LEAF + uint32_t(__builtin_ctz(hit));
-        tie = (hit & (hit - 1u)) != 0u;  // two slots of this leaf share the minimum: index tie
+      for (int q = 0; q < Q; ++q) {  // one broadcast read of the pair serves all Q queries
+        const v2f r = pair_dist(l, j, qx2[q], qy2[q], qz2[q]);
+        m[q] = __builtin_fminf(m[q], __builtin_fminf(r.x, r.y));
       }
     }
-  }
-  // (distance, original index) key and sorted position of the winner; NO_INDEX if none
-  __device__ __forceinline__ void resolve(const IndexView& ix, uint64_t& key, uint32_t& pos) const {
-    key = KEY_NONE;
-    pos = bestpos;
-    if (bestpos != NO_INDEX) key = make_key(best, __float_as_uint(ix.pts[bestpos].w));
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const bool imp = m[q] < best[q];
+      // equal minimum in a different leaf than the current winner's: possible index tie
+      const bool eq = (m[q] == best[q]) && (bestpos[q] != NO_INDEX) && (bestpos[q] / LEAF != leaf_id);
+      tie[q] = tie[q] || eq;
+      if (__builtin_amdgcn_ballot_w64(imp) != 0) {
+        // The re-scan recomputes the same distances.  Launder the query through an empty asm so the
+        // compiler cannot merge it with the hot loop above (it otherwise if-converts this block and
+        // executes the 16 compares + mask building for EVERY leaf).
+        float ax = qx[q], ay = qy[q], az = qz[q];
+        asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az));
+        const v2f rx2 = {ax, ax}, ry2 = {ay, ay}, rz2 = {az, az};
+        uint32_t hit = 0;
+#pragma unroll
+        for (int j = 0; j < LEAF / 2; ++j) {
+          const v2f r = pair_dist(l, j, rx2, ry2, rz2);
+          hit |= (r.x == m[q] ? 1u : 0u) << (2 * j);
+          hit |= (r.y == m[q] ? 1u : 0u) << (2 * j + 1);
+        }
+        if (imp) {
+          best[q] = m[q];
+          bestpos[q] = leaf_id * LEAF + uint32_t(__builtin_ctz(hit));
+          tie[q] = (hit & (hit - 1u)) != 0u;  // two slots of this leaf share the minimum: index tie
+        }
+      }
+    }
   }
 };
+typedef NN1MinT<1> NN1Min;
 
 // top-K in registers: ascending (distance, original index) keys + the sorted position of each.
 template <int K>
@@ -228,7 +245,8 @@ struct TopKReg {
       pos[i] = NO_INDEX;
     }
   }
-  __device__ __forceinline__ float worst() const { return key_dist(keys[K - 1]); }
+  static constexpr int QPL = 1;
+  __device__ __forceinline__ float worst(int) const { return key_dist(keys[K - 1]); }
   __device__ __forceinline__ void insert(uint64_t k, uint32_t p) {
     // slot j receives old[j-1] if k < old[j-1], else k if k < old[j], else keeps old[j]
     bool below = k < keys[K - 1];  // k < old[j]
@@ -244,9 +262,10 @@ struct TopKReg {
   }
   // A candidate pair is looked at further only if some lane has d <= its current k-th distance; the
   // exact (distance, index) order is decided inside insert(), so ties stay exact.
-  __device__ __forceinline__ void leaf(const float* l, uint32_t leaf_id, float qx, float qy, float qz) {
+  __device__ __forceinline__ void leaf(const float* l, uint32_t leaf_id, const float* qx, const float* qy,
+                                       const float* qz) {
     const uint32_t base = leaf_id * LEAF;
-    const v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+    const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
 #pragma unroll
     for (int j = 0; j < LEAF / 2; ++j) {
       const v2f r = pair_dist(l, j, qx2, qy2, qz2);
@@ -273,7 +292,8 @@ struct TopKHeap {
     for (int i = 0; i < k; ++i) heap[size_t(i) * stride] = k0;
     root = k0;
   }
-  __device__ __forceinline__ float worst() const { return key_dist(root); }
+  static constexpr int QPL = 1;
+  __device__ __forceinline__ float worst(int) const { return key_dist(root); }
   __device__ void replace_root(uint64_t key) {
     int i = 0;
     for (;;) {
@@ -300,9 +320,10 @@ struct TopKHeap {
     heap[size_t(i) * stride] = key;
     root = heap[0];
   }
-  __device__ __forceinline__ void leaf(const float* l, uint32_t leaf_id, float qx, float qy, float qz) {
+  __device__ __forceinline__ void leaf(const float* l, uint32_t leaf_id, const float* qx, const float* qy,
+                                       const float* qz) {
     for (int c = 0; c < LEAF; ++c) {
-      const float d = l2_simple(qx, qy, qz, l[c], l[LEAF + c], l[2 * LEAF + c]);
+      const float d = l2_simple(qx[0], qy[0], qz[0], l[c], l[LEAF + c], l[2 * LEAF + c]);
       const uint64_t key = make_key(d, __float_as_uint(l[3 * LEAF + c]));
       if (key < root) replace_root(key);
     }
@@ -355,20 +376,41 @@ __device__ __forceinline__ void load_top_cache(const IndexView& ix, Box* topbox)
   __syncthreads();
 }
 
+// per-lane maximum of the policy's bounds over the lane's valid queries
 template <class Policy>
-__device__ __forceinline__ void traverse(const IndexView& ix, float qx, float qy, float qz, bool valid,
-                                         Policy& pol, WaveLds& wl, const Box* topbox, TraverseStats& ts) {
+__device__ __forceinline__ float lane_worst(const Policy& pol, const bool* valid) {
+  float w = 0.0f;
+#pragma unroll
+  for (int q = 0; q < Policy::QPL; ++q) w = fmaxf(w, valid[q] ? pol.worst(q) : 0.0f);
+  return w;
+}
+
+// qx/qy/qz/valid: Policy::QPL queries per lane (the wave owns 64*QPL spatially compact queries).
+template <class Policy>
+__device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, const float* qy, const float* qz,
+                                         const bool* valid, Policy& pol, WaveLds& wl, const Box* topbox,
+                                         TraverseStats& ts) {
+  constexpr int QPL = Policy::QPL;
   const int lane = threadIdx.x & (WAVE - 1);
-  if (__builtin_amdgcn_ballot_w64(valid) == 0 || ix.n == 0) return;
+  bool any_valid = false;
+#pragma unroll
+  for (int q = 0; q < QPL; ++q) any_valid = any_valid || valid[q];
+  if (__builtin_amdgcn_ballot_w64(any_valid) == 0 || ix.n == 0) return;
   ++ts.c[4];
   const float BIG = 3.402823466e+38f;
   const float INF = __builtin_inff();
-  // bounding box of the wave's queries
-  const float Qlx = wave_min_f(valid ? qx : BIG), Qly = wave_min_f(valid ? qy : BIG),
-              Qlz = wave_min_f(valid ? qz : BIG);
-  const float Qhx = wave_max_f(valid ? qx : -BIG), Qhy = wave_max_f(valid ? qy : -BIG),
-              Qhz = wave_max_f(valid ? qz : -BIG);
-  float T = wave_max_f(valid ? pol.worst() : 0.0f);  // wave pruning radius (squared)
+  // bounding box of the wave's queries (per-lane fold over the lane's queries, then one reduction)
+  float lx0 = BIG, ly0 = BIG, lz0 = BIG, hx0 = -BIG, hy0 = -BIG, hz0 = -BIG;
+#pragma unroll
+  for (int q = 0; q < QPL; ++q) {
+    if (valid[q]) {
+      lx0 = fminf(lx0, qx[q]); ly0 = fminf(ly0, qy[q]); lz0 = fminf(lz0, qz[q]);
+      hx0 = fmaxf(hx0, qx[q]); hy0 = fmaxf(hy0, qy[q]); hz0 = fmaxf(hz0, qz[q]);
+    }
+  }
+  const float Qlx = wave_min_f(lx0), Qly = wave_min_f(ly0), Qlz = wave_min_f(lz0);
+  const float Qhx = wave_max_f(hx0), Qhy = wave_max_f(hy0), Qhz = wave_max_f(hz0);
+  float T = wave_max_f(lane_worst(pol, valid));  // wave pruning radius (squared)
   const float gdiag2 = (Qhx - Qlx) * (Qhx - Qlx) + (Qhy - Qly) * (Qhy - Qly) + (Qhz - Qlz) * (Qhz - Qlz);
   uint2* const stack = wl.stack;
 
@@ -469,19 +511,23 @@ __device__ __forceinline__ void traverse(const IndexView& ix, float qx, float qy
             continue;
           }
           ++ts.c[1];
-          const float lb = point_box_lb(qx, qy, qz, ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
-          const bool need = valid && !(lb > pol.worst());
+          bool need = false;
+#pragma unroll
+          for (int q = 0; q < QPL; ++q) {
+            const float lb = point_box_lb(qx[q], qy[q], qz[q], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
+            need = need || (valid[q] && !(lb > pol.worst(q)));
+          }
           if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
           ++ts.c[2];
           if (!landed) {  // first use of this batch: the DMA must have landed (it ran under the tests)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             landed = true;
           }
-          const float before = pol.worst();
+          const float before = lane_worst(pol, valid);
           pol.leaf(wl.buf + t * LEAF_FLOATS, uniform_u32(__float_as_uint(ea.w)), qx, qy, qz);
           // the wave radius can only shrink if some lane's own bound shrank
-          if (__builtin_amdgcn_ballot_w64(valid && pol.worst() < before) != 0)
-            T = wave_max_f(valid ? pol.worst() : 0.0f);
+          const float after = lane_worst(pol, valid);
+          if (__builtin_amdgcn_ballot_w64(after < before) != 0) T = wave_max_f(after);
         }
         // the next batch overwrites wl.buf: make sure this batch's DMA is not still landing
         if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
