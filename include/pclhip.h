@@ -165,6 +165,28 @@ PCLHIP_API pclhip_status pclhip_icp_set_allreduce(pclhip_icp* icp, pclhip_allred
 /* Rewind the working copy of the source to the input cloud (start of computeTransformation). */
 PCLHIP_API pclhip_status pclhip_icp_reset(pclhip_icp* icp);
 
+/* Correspondence rejectors applied on the device between the search and the accumulation of every
+ * iteration (the chain of impl/icp.hpp:187-201), in the given order:
+ *   DISTANCE         registration/src/correspondence_rejection_distance.cpp:43-68      param = max distance
+ *   MEDIAN_DISTANCE  registration/src/correspondence_rejection_median_distance.cpp:43-69 param = factor
+ *   ONE_TO_ONE       registration/src/correspondence_rejection_one_to_one.cpp:43-66
+ *   TRIMMED          registration/src/correspondence_rejection_trimmed.cpp:43-60        param = overlap ratio
+ * Exact ties, whose order the reference leaves to an unstable sort, go to the lower query index. */
+enum { PCLHIP_REJ_DISTANCE = 0, PCLHIP_REJ_MEDIAN_DISTANCE = 1, PCLHIP_REJ_ONE_TO_ONE = 2, PCLHIP_REJ_TRIMMED = 3 };
+typedef struct {
+  int kind;
+  double param;
+  uint32_t min_correspondences; /* TRIMMED: nr_min_correspondences_ */
+  uint32_t reserved;
+} pclhip_rejector;
+PCLHIP_API pclhip_status pclhip_icp_set_rejectors(pclhip_icp* icp, const pclhip_rejector* list, int n);
+/* median found by the last MEDIAN_DISTANCE rejector (getMedianDistance()) */
+PCLHIP_API double pclhip_icp_last_median_distance(const pclhip_icp* icp);
+/* use_reciprocal_correspondence_ (registration.h / impl/correspondence_estimation.hpp:220-311): keep
+ * (i, m) only if the nearest source point of target[m] is i again (source index rebuilt per iteration,
+ * as the reference does). */
+PCLHIP_API pclhip_status pclhip_icp_set_reciprocal(pclhip_icp* icp, int enable);
+
 /* One fused iteration on the device-resident working source cloud:
  *   cur <- T_prev * cur   (transformCloud, impl/icp.hpp:49-111 / transforms.hpp:109-123)
  *   1-NN of every cur point in the target, drop d2 > max_dist^2
@@ -195,7 +217,9 @@ PCLHIP_API pclhip_status pclhip_icp_align(pclhip_icp* icp, const pclhip_icp_para
 
 /* Correspondences of the LAST iteration, materialised lazily as pcl::Correspondences
  * (common/include/pcl/correspondence.h:60-89): sorted by index_query, entries beyond max_dist
- * omitted.  Buffers (host or device) must hold n_source entries; *out_n receives the count. */
+ * omitted.  With rejectors the list is the chain's output in the reference's order (ONE_TO_ONE:
+ * by match index, TRIMMED: by distance).  Buffers (host or device) must hold n_source entries;
+ * *out_n receives the count. */
 PCLHIP_API pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_query,
                                                           int32_t* index_match, float* distance,
                                                           uint64_t* out_n);

@@ -1,0 +1,89 @@
+"""numpy restatement of PCL's correspondence rejectors (list -> list).  TEST INFRASTRUCTURE ONLY
+(same rules as pcl_oracle.h).  Correspondences are (index_query int32[], index_match int32[],
+distance float32[] = squared distance), citations relative to the PCL tree.
+
+Where the reference uses an unstable std::sort the order of exact ties is unspecified; the
+restatement (and the GPU) break such ties by the lower query index."""
+import numpy as np
+
+
+def reject_distance(q, m, d, max_distance):
+    # registration/src/correspondence_rejection_distance.cpp:43-68; setMaximumDistance squares the
+    # float (correspondence_rejection_distance.h:93-97), the test is `distance < max_distance_`
+    md = np.float32(max_distance) * np.float32(max_distance)
+    k = d < md
+    return q[k], m[k], d[k]
+
+
+def reject_median_distance(q, m, d, factor):
+    # registration/src/correspondence_rejection_median_distance.cpp:43-69 (doubles, nth_element at n/2)
+    dd = d.astype(np.float64)
+    median = np.sort(dd)[len(dd) // 2]
+    k = dd <= median * float(factor)
+    return q[k], m[k], d[k], float(median)
+
+
+def reject_one_to_one(q, m, d):
+    # registration/src/correspondence_rejection_one_to_one.cpp:43-66: sort by (match, distance), keep
+    # the first of every match index; output ordered by match index
+    order = np.lexsort((q, d, m))
+    q, m, d = q[order], m[order], d[order]
+    first = np.ones(len(m), bool)
+    first[1:] = m[1:] != m[:-1]
+    first &= m >= 0
+    return q[first], m[first], d[first]
+
+
+def reject_trimmed(q, m, d, overlap_ratio, nr_min_correspondences=0):
+    # registration/src/correspondence_rejection_trimmed.cpp:43-60
+    n = int(np.floor(np.float32(overlap_ratio) * np.float32(len(d))))
+    n = max(n, int(nr_min_correspondences))
+    if n < len(d):
+        order = np.lexsort((q, d))  # by distance, ties by query index
+        q, m, d = q[order][:n], m[order][:n], d[order][:n]
+    return q, m, d
+
+
+def icp_with_filters(orc, tgt, src, mode, tgt_normals=None, rejectors=(), reciprocal=False, max_iterations=10,
+                     max_correspondence_distance=None, transformation_epsilon=0.0):
+    """IterativeClosestPoint::computeTransformation (impl/icp.hpp:113-268) composed from the C oracle's
+    pieces, with the rejector chain (:187-201) and reciprocal correspondences (:176-184).
+    rejectors: list of callables (q, m, d) -> (q, m, d).  Returns dict like orc.icp_align."""
+    import numpy as _np
+    tree = orc.KdTree(tgt)
+    order = 1 if mode == 1 else 0
+    cur = _np.ascontiguousarray(src[:, :4], _np.float32).copy()
+    final_T = _np.eye(4, dtype=_np.float32)
+    conv = orc.new_convergence()
+    conv.max_iterations = max_iterations
+    conv.mse_threshold_relative = -_np.finfo(_np.float64).max
+    conv.translation_threshold = transformation_epsilon
+    md = max_correspondence_distance if max_correspondence_distance is not None else _np.sqrt(_np.finfo(_np.float64).max)
+    it = 0
+    import ctypes as C
+    L = orc.lib()
+    per_iter = []
+    while True:
+        if reciprocal:
+            q, m, d = tree.reciprocal_correspondences(orc.KdTree(cur), cur, tgt, md)
+        else:
+            q, m, d = tree.correspondences(cur, md)
+        for r in rejectors:
+            out = r(q, m, d)
+            q, m, d = out[0], out[1], out[2]
+        per_iter.append((q.copy(), m.copy()))
+        if len(q) < 3:
+            return {"T": final_T, "iterations": it, "converged": False, "state": 5, "per_iter": per_iter}
+        if mode == 1:
+            Tk, _, _ = orc.lls_point_to_plane(cur, tgt, tgt_normals, q, m)
+        else:
+            Tk = orc.umeyama(cur, tgt, q, m, acc_double=True)
+        cur = orc.transform_cloud(Tk, cur, order=order)
+        final_T = orc.mat4_mul(Tk, final_T)
+        it += 1
+        mse = float(d.astype(_np.float64).sum() / len(d))
+        Tf = _np.ascontiguousarray(Tk, _np.float32).reshape(16)
+        if L.orc_convergence_has_converged(C.byref(conv), it, Tf.ctypes.data_as(C.POINTER(C.c_float)), mse):
+            return {"T": final_T, "iterations": it, "converged": True, "state": conv.convergence_state, "per_iter": per_iter}
+        if conv.convergence_state != 0:
+            return {"T": final_T, "iterations": it, "converged": False, "state": conv.convergence_state, "per_iter": per_iter}

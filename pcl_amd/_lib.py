@@ -45,6 +45,13 @@ class IcpResult(C.Structure):
                 ("gpu_ms_search_kernel", C.c_double)]
 
 
+class Rejector(C.Structure):
+    _fields_ = [("kind", C.c_int), ("param", C.c_double), ("min_correspondences", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+REJ_DISTANCE, REJ_MEDIAN_DISTANCE, REJ_ONE_TO_ONE, REJ_TRIMMED = 0, 1, 2, 3
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 
 # every symbol include/pclhip.h declares: (restype, argtypes)
@@ -69,6 +76,9 @@ SIGNATURES = {
     "pclhip_icp_set_source": (C.c_int, [_vp, _vp, _sz, _u64]),
     "pclhip_icp_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),
     "pclhip_icp_reset": (C.c_int, [_vp]),
+    "pclhip_icp_set_rejectors": (C.c_int, [_vp, C.POINTER(Rejector), C.c_int]),
+    "pclhip_icp_last_median_distance": (C.c_double, [_vp]),
+    "pclhip_icp_set_reciprocal": (C.c_int, [_vp, C.c_int]),
     "pclhip_icp_iterate": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_double, C.c_int,
                                      C.POINTER(C.c_double)]),
     "pclhip_icp_last_kernel_ms": (C.c_double, [_vp]),

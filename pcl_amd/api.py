@@ -223,6 +223,62 @@ class NormalEstimation:
         return out
 
 
+class CorrespondenceRejectorDistance:
+    """pcl::registration::CorrespondenceRejectorDistance (correspondence_rejection_distance.h)."""
+    kind = _lib.REJ_DISTANCE
+
+    def __init__(self):
+        self.param, self.min_corr = 0.0, 0
+
+    def setMaximumDistance(self, d):
+        self.param = float(d)
+
+
+class CorrespondenceRejectorMedianDistance:
+    """pcl::registration::CorrespondenceRejectorMedianDistance."""
+    kind = _lib.REJ_MEDIAN_DISTANCE
+
+    def __init__(self):
+        self.param, self.min_corr = 1.0, 0
+        self.median_distance_ = None
+
+    def setMedianFactor(self, f):
+        self.param = float(f)
+
+    def getMedianDistance(self):
+        return self.median_distance_
+
+
+class CorrespondenceRejectorOneToOne:
+    """pcl::registration::CorrespondenceRejectorOneToOne."""
+    kind = _lib.REJ_ONE_TO_ONE
+
+    def __init__(self):
+        self.param, self.min_corr = 0.0, 0
+
+
+class CorrespondenceRejectorTrimmed:
+    """pcl::registration::CorrespondenceRejectorTrimmed."""
+    kind = _lib.REJ_TRIMMED
+
+    def __init__(self):
+        self.param, self.min_corr = 0.5, 0
+
+    def setOverlapRatio(self, r):
+        self.param = float(r)
+
+    def setMinCorrespondences(self, n):
+        self.min_corr = int(n)
+
+
+def _set_filters(lib, ctx, h, rejectors, reciprocal):
+    arr = (_lib.Rejector * max(len(rejectors), 1))()
+    for i, r in enumerate(rejectors):
+        arr[i].kind, arr[i].param, arr[i].min_correspondences = r.kind, r.param, r.min_corr
+    check(lib.pclhip_icp_set_rejectors(h, arr, len(rejectors)), ctx.h)
+    check(lib.pclhip_icp_set_reciprocal(h, int(bool(reciprocal))), ctx.h)
+
+
 class CorrespondenceEstimation:
     """pcl::registration::CorrespondenceEstimation (determineCorrespondences only)."""
 
@@ -242,13 +298,19 @@ class CorrespondenceEstimation:
     def setInputSource(self, cloud):
         self.src = cloud
 
-    def determineCorrespondences(self, max_distance=_SQRT_DBL_MAX):
-        """-> (index_query, index_match, distance) sorted by index_query."""
+    def determineReciprocalCorrespondences(self, max_distance=_SQRT_DBL_MAX):
+        """impl/correspondence_estimation.hpp:220-311."""
+        return self.determineCorrespondences(max_distance, reciprocal=True)
+
+    def determineCorrespondences(self, max_distance=_SQRT_DBL_MAX, rejectors=(), reciprocal=False):
+        """-> (index_query, index_match, distance) sorted by index_query (after `rejectors`: in the
+        order the reference's chain leaves them)."""
         ptr, stride, n, keep = _cloud(self.src)
         h = C.c_void_p()
         check(self.lib.pclhip_icp_create(self.tree.h, C.byref(h)), self.ctx.h)
         try:
             check(self.lib.pclhip_icp_set_source(h, ptr, stride, n), self.ctx.h)
+            _set_filters(self.lib, self.ctx, h, list(rejectors), reciprocal)
             I = np.eye(4, dtype=np.float32).reshape(16)
             sums = np.zeros(_lib.NSUMS, np.float64)
             check(self.lib.pclhip_icp_iterate(h, _fp(I), float(max_distance), POINT_TO_POINT,
@@ -262,6 +324,9 @@ class CorrespondenceEstimation:
                 C.byref(cnt)), self.ctx.h)
             c = int(cnt.value)
             assert c == int(sums[28])
+            for r in rejectors:
+                if r.kind == _lib.REJ_MEDIAN_DISTANCE:
+                    r.median_distance_ = float(self.lib.pclhip_icp_last_median_distance(h))
             return q[:c].copy(), m[:c].copy(), d[:c].copy()
         finally:
             self.lib.pclhip_icp_destroy(h)
@@ -284,6 +349,8 @@ class IterativeClosestPoint:
         self._src_id = None
         self.result = None
         self._allreduce = None
+        self.rejectors = []
+        self.use_reciprocal = False
         self.ctx._adopt(self)
 
     def _release(self):
@@ -316,6 +383,20 @@ class IterativeClosestPoint:
     def setEuclideanFitnessEpsilon(self, e):
         self.p.euclidean_fitness_epsilon = float(e)
 
+    def addCorrespondenceRejector(self, rejector):
+        """Registration::addCorrespondenceRejector (registration.h:430-434)."""
+        self.rejectors.append(rejector)
+        self._filters_dirty = True
+
+    def clearCorrespondenceRejectors(self):
+        self.rejectors = []
+        self._filters_dirty = True
+
+    def setUseReciprocalCorrespondences(self, on):
+        """icp.h:251-256."""
+        self.use_reciprocal = bool(on)
+        self._filters_dirty = True
+
     def setAllReduce(self, fn):
         """fn(device_ptr:int, count:int, stream:int) -> 0 ; sums the 32 doubles across ranks."""
         def tramp(user, ptr, count, stream):
@@ -335,6 +416,7 @@ class IterativeClosestPoint:
                 self.lib.pclhip_icp_destroy(self.h)
             self.h = None
             self._src_id = None
+            self._filters_dirty = True
 
     def _ensure(self):
         if self.h is None:
@@ -347,6 +429,9 @@ class IterativeClosestPoint:
             ptr, stride, n, keep = _cloud(self.src)
             check(self.lib.pclhip_icp_set_source(self.h, ptr, stride, n), self.ctx.h)
             self._src_id = id(self.src)
+        if getattr(self, "_filters_dirty", True):
+            _set_filters(self.lib, self.ctx, self.h, self.rejectors, self.use_reciprocal)
+            self._filters_dirty = False
 
     def iterate(self, T_prev=None, max_dist=None):
         """One fused device iteration; returns the 32-double reduction record."""

@@ -3,6 +3,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -152,13 +153,14 @@ __global__ void transform_cloud_kernel(Mat44 T, int order, const void* in, void*
 
 // dense per-original-source arrays of the last iteration's matches
 __global__ void scatter_matches_kernel(const float4* __restrict__ cur, const uint32_t* __restrict__ match,
-                                       const float* __restrict__ d2, uint32_t n, int32_t* __restrict__ out_m,
-                                       float* __restrict__ out_d) {
+                                       const float* __restrict__ d2, const uint8_t* __restrict__ keep, uint32_t n,
+                                       int32_t* __restrict__ out_m, float* __restrict__ out_d) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t oq = __float_as_uint(cur[i].w);
   const uint32_t m = match[i];
-  out_m[oq] = (m == NO_INDEX) ? -1 : int32_t(m);
+  const bool kept = m != NO_INDEX && (keep == nullptr || keep[i]);
+  out_m[oq] = kept ? int32_t(m) : -1;
   out_d[oq] = d2[i];
 }
 
@@ -461,6 +463,8 @@ static void icp_free_source(pclhip_icp* icp) {
   if (icp->src_cur) (void)hipFree(icp->src_cur);
   if (icp->match) (void)hipFree(icp->match);
   if (icp->match_pos) (void)hipFree(icp->match_pos);
+  if (icp->keep) (void)hipFree(icp->keep);
+  icp->keep = nullptr;
   if (icp->match_d2) (void)hipFree(icp->match_d2);
   if (icp->partials) (void)hipFree(icp->partials);
   icp->src_sorted0 = icp->src_cur = nullptr;
@@ -520,6 +524,22 @@ pclhip_status pclhip_icp_set_allreduce(pclhip_icp* icp, pclhip_allreduce_fn fn, 
   if (!icp) return PCLHIP_ERR_INVALID;
   icp->allreduce = fn;
   icp->allreduce_user = user;
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_icp_set_rejectors(pclhip_icp* icp, const pclhip_rejector* list, int n) {
+  if (!icp || n < 0 || (n > 0 && !list)) return PCLHIP_ERR_INVALID;
+  for (int i = 0; i < n; ++i)
+    PCLHIP_REQUIRE(icp->ctx, list[i].kind >= PCLHIP_REJ_DISTANCE && list[i].kind <= PCLHIP_REJ_TRIMMED, "unknown rejector kind");
+  icp->rejectors.assign(list, list + n);
+  return PCLHIP_OK;
+}
+
+double pclhip_icp_last_median_distance(const pclhip_icp* icp) { return icp ? icp->last_median : 0.0; }
+
+pclhip_status pclhip_icp_set_reciprocal(pclhip_icp* icp, int enable) {
+  if (!icp) return PCLHIP_ERR_INVALID;
+  icp->reciprocal = enable != 0;
   return PCLHIP_OK;
 }
 
@@ -719,8 +739,9 @@ pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_q
   guard.add(dm);
   PCLHIP_CHECK_HIP(ctx, hipMalloc(&dd, size_t(icp->n) * sizeof(float)));
   guard.add(dd);
+  const bool filtered = icp->reciprocal || !icp->rejectors.empty();
   hipLaunchKernelGGL(scatter_matches_kernel, dim3((icp->n + 255) / 256), dim3(256), 0, ctx->stream, icp->src_cur,
-                     icp->match, icp->match_d2, icp->n, dm, dd);
+                     icp->match, icp->match_d2, filtered ? icp->keep : nullptr, icp->n, dm, dd);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   std::vector<int32_t> hm(icp->n);
   std::vector<float> hd(icp->n);
@@ -739,6 +760,28 @@ pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_q
       d.push_back(hd[i]);
     }
   const size_t c = q.size();
+  if (filtered && icp->fetch_order != 0 && c > 1) {
+    // the reference's output order after the chain: ONE_TO_ONE sorts by (match, distance)
+    // (correspondence_rejection_one_to_one.cpp:49-51), TRIMMED by distance (..._trimmed.cpp:53-56)
+    std::vector<size_t> ord(c);
+    for (size_t i = 0; i < c; ++i) ord[i] = i;
+    if (icp->fetch_order == 1)
+      std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
+        return m[a] < m[b] || (m[a] == m[b] && d[a] < d[b]);
+      });
+    else
+      std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return d[a] < d[b]; });
+    std::vector<int32_t> q2(c), m2(c);
+    std::vector<float> d2v(c);
+    for (size_t i = 0; i < c; ++i) {
+      q2[i] = q[ord[i]];
+      m2[i] = m[ord[i]];
+      d2v[i] = d[ord[i]];
+    }
+    q.swap(q2);
+    m.swap(m2);
+    d.swap(d2v);
+  }
   auto put = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
     if (bytes == 0) return hipSuccess;
     if (is_device_pointer(dst)) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);

@@ -122,6 +122,12 @@ struct pclhip_icp {
   int convergence_state = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_kernel_ms = 0;
+  // optional stages between search and accumulation
+  std::vector<pclhip_rejector> rejectors;
+  bool reciprocal = false;
+  uint8_t* keep = nullptr;        // per sorted source slot: correspondence survives the chain
+  double last_median = 0;
+  int fetch_order = 0;            // 0 by query, 1 by (match, distance), 2 by distance
 };
 
 namespace pclhip {
@@ -161,7 +167,7 @@ pclhip_status morton_order(pclhip_ctx* ctx, const void* dev_points, size_t strid
 pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
                        const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
                        uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
-                       uint32_t* rank_or_null);
+                       uint32_t* rank_or_null, bool ids_from_w = false);
 // dispatches on PCLHIP_ORDER=morton|kd (default kd); morton is kept for A/B measurements only
 pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
                             const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
@@ -176,6 +182,10 @@ pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, 
 pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_t* nan_count);
 pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d2, bool use_max,
                                  int mode);
+// rejectors.hip: reciprocal filter + rejector chain on icp->keep (stream-ordered, may synchronise)
+pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool use_max);
+// kd order of float4 records whose .w already holds the point's id (used for the reciprocal index)
+pclhip_status build_index_from_float4(pclhip_ctx* ctx, const float4* dev_pts_with_ids, uint32_t n, pclhip_index** out);
 
 // ---- host closed forms (host_math.cpp) -------------------------------------------------------
 void solve_point_to_plane(const double* sums, float* T);

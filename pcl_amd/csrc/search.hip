@@ -813,6 +813,7 @@ template <int MODE>
 __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, const float4* __restrict__ cur, uint32_t ns,
                                                                const uint32_t* __restrict__ match_pos,
                                                                const float* __restrict__ match_d2,
+                                                               const uint8_t* __restrict__ keep,
                                                                double* __restrict__ partials) {
   __shared__ double red_s[WAVES_PER_BLOCK][NS];
   const int lane = threadIdx.x & (WAVE - 1);
@@ -826,6 +827,7 @@ __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, con
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
     const uint32_t pos = match_pos[i];
     if (pos == NO_INDEX) continue;
+    if (keep != nullptr && !keep[i]) continue;  // rejected by the reciprocal test / rejector chain
     const float4 p = cur[i];
     ++cnt;
     sum_d2 += double(match_d2[i]);
@@ -938,7 +940,8 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     const char* e = getenv("PCLHIP_ICP_FUSED");
     return (e && atoi(e) == 0) ? 1 : 0;
   }();
-  if (icp->n > 0 && unfused) {
+  const bool filters = icp->reciprocal || !icp->rejectors.empty();
+  if (icp->n > 0 && (unfused || filters)) {
     static const int qpl = [] {
       const char* e = getenv("PCLHIP_ICP_QPL");
       return (e && atoi(e) == 1) ? 1 : 2;
@@ -950,14 +953,20 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     (void)hipEventRecord(icp->ev0, s);
     hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound, use_max ? 1 : 0,
                        icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+    const uint8_t* keep = nullptr;
+    if (filters) {
+      pclhip_status st = apply_correspondence_filters(icp, max_d2, use_max);
+      if (st != PCLHIP_OK) return st;
+      keep = icp->keep;
+    }
     int ga = ctx->num_cus * 8;
     if (ga > icp->grid_blocks) ga = icp->grid_blocks;
     if (mode == PCLHIP_ICP_POINT_TO_PLANE)
       hipLaunchKernelGGL(icp_accumulate_kernel<PCLHIP_ICP_POINT_TO_PLANE>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur,
-                         icp->n, icp->match_pos, icp->match_d2, icp->partials);
+                         icp->n, icp->match_pos, icp->match_d2, keep, icp->partials);
     else
       hipLaunchKernelGGL(icp_accumulate_kernel<PCLHIP_ICP_POINT_TO_POINT>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur,
-                         icp->n, icp->match_pos, icp->match_d2, icp->partials);
+                         icp->n, icp->match_pos, icp->match_d2, keep, icp->partials);
     (void)hipEventRecord(icp->ev1, s);
     hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, ga, icp->sums_dev);
   } else if (icp->n > 0) {

@@ -535,3 +535,104 @@ def test_voxelgrid_overflow_refused(gpu):
     with pytest.raises(pcl_amd.PclHipError) as e:
         vg.filter()
     assert e.value.status == -5
+
+
+# ------------------------------------------------------------------------------------------------
+# rejectors + reciprocal correspondences
+# ------------------------------------------------------------------------------------------------
+def test_rejectors_bunny_goldens(gpu, bunny, golden):
+    # test/registration/test_registration_api.cpp:131-380 on the device chain
+    import pcl_amd
+    src, tgt = xyz1(bunny["bun0"]), xyz1(bunny["bun4"])
+
+    def run(rej):
+        ce = pcl_amd.CorrespondenceEstimation(gpu)
+        ce.setInputSource(src)
+        ce.setInputTarget(tgt)
+        q, m, d = ce.determineCorrespondences(rejectors=[rej])
+        return np.stack([q, m], 1)
+
+    r = pcl_amd.CorrespondenceRejectorDistance()
+    r.setMaximumDistance(golden["rej_dist_max_dist"])
+    assert np.array_equal(run(r), np.asarray(golden["correspondences_dist"]))
+    r = pcl_amd.CorrespondenceRejectorMedianDistance()
+    r.setMedianFactor(golden["rej_median_factor"])
+    assert np.array_equal(run(r), np.asarray(golden["correspondences_median_dist"]))
+    assert abs(r.getMedianDistance() - golden["rej_median_distance"]) < 1e-4
+    assert np.array_equal(run(pcl_amd.CorrespondenceRejectorOneToOne()), np.asarray(golden["correspondences_one_to_one"]))
+    r = pcl_amd.CorrespondenceRejectorTrimmed()
+    r.setOverlapRatio(golden["rej_trimmed_overlap"])
+    assert np.array_equal(run(r), np.asarray(golden["correspondences_trimmed"]))
+
+
+def test_reciprocal_correspondences_bunny_golden(gpu, bunny, golden):
+    # test/registration/test_registration_api.cpp:107-128 -- 53 exact pairs
+    import pcl_amd
+    ce = pcl_amd.CorrespondenceEstimation(gpu)
+    ce.setInputSource(xyz1(bunny["bun0"]))
+    ce.setInputTarget(xyz1(bunny["bun4"]))
+    q, m, d = ce.determineReciprocalCorrespondences()
+    gold = np.asarray(golden["correspondences_reciprocal"], np.int32)
+    assert np.array_equal(q, gold[:, 0]) and np.array_equal(m, gold[:, 1])
+
+
+def test_rejector_chain_and_reciprocal_vs_oracle_50k(gpu, orc):
+    import pcl_amd
+    from oracle import rejectors as rej
+    tgt, src, _ = pcl_amd.synth.icp_pair(50_000)
+    chain_gpu = [pcl_amd.CorrespondenceRejectorMedianDistance(), pcl_amd.CorrespondenceRejectorOneToOne(),
+                 pcl_amd.CorrespondenceRejectorTrimmed()]
+    chain_gpu[0].setMedianFactor(2.0)
+    chain_gpu[2].setOverlapRatio(0.8)
+    for reciprocal in (False, True):
+        ce = pcl_amd.CorrespondenceEstimation(gpu)
+        ce.setInputSource(src)
+        ce.setInputTarget(tgt)
+        q, m, d = ce.determineCorrespondences(0.1, rejectors=chain_gpu, reciprocal=reciprocal)
+        otree = orc.KdTree(tgt)
+        if reciprocal:
+            oq, om, od = otree.reciprocal_correspondences(orc.KdTree(src), src, tgt, 0.1)
+        else:
+            oq, om, od = otree.correspondences(src, 0.1)
+        oq, om, od, _ = rej.reject_median_distance(oq, om, od, 2.0)
+        oq, om, od = rej.reject_one_to_one(oq, om, od)
+        oq, om, od = rej.reject_trimmed(oq, om, od, 0.8)
+        assert np.array_equal(q, oq) and np.array_equal(m, om) and np.array_equal(d, od), reciprocal
+        assert 0 < len(q) < 50_000
+
+
+def test_icp_with_rejectors_vs_oracle(gpu, orc, bunny):
+    # test/registration/test_registration.cpp:336-382 style: ICP + median + one-to-one rejectors
+    import pcl_amd
+    from oracle import rejectors as rej
+    src, tgt = xyz1(bunny["bun0"]), xyz1(bunny["bun4"])
+    icp = pcl_amd.IterativeClosestPoint(gpu)
+    icp.setInputTarget(tgt)
+    icp.setInputSource(src)
+    icp.setMaximumIterations(30)
+    icp.setMaxCorrespondenceDistance(0.05)
+    icp.setTransformationEpsilon(1e-8)
+    r1 = pcl_amd.CorrespondenceRejectorMedianDistance()
+    r1.setMedianFactor(4.0)
+    icp.addCorrespondenceRejector(r1)
+    icp.addCorrespondenceRejector(pcl_amd.CorrespondenceRejectorOneToOne())
+    icp.align()
+    ref = rej.icp_with_filters(orc, tgt, src, 0,
+                               rejectors=[lambda q, m, d: rej.reject_median_distance(q, m, d, 4.0),
+                                          rej.reject_one_to_one],
+                               max_iterations=30, max_correspondence_distance=0.05, transformation_epsilon=1e-8)
+    assert icp.nr_iterations_ == ref["iterations"]
+    assert np.linalg.norm(icp.getFinalTransformation().astype(np.float64) - ref["T"]) < 1e-5
+    # reciprocal ICP
+    icp2 = pcl_amd.IterativeClosestPoint(gpu)
+    icp2.setInputTarget(tgt)
+    icp2.setInputSource(src)
+    icp2.setMaximumIterations(30)
+    icp2.setMaxCorrespondenceDistance(0.05)
+    icp2.setTransformationEpsilon(1e-8)
+    icp2.setUseReciprocalCorrespondences(True)
+    icp2.align()
+    ref2 = rej.icp_with_filters(orc, tgt, src, 0, reciprocal=True, max_iterations=30,
+                                max_correspondence_distance=0.05, transformation_epsilon=1e-8)
+    assert icp2.nr_iterations_ == ref2["iterations"]
+    assert np.linalg.norm(icp2.getFinalTransformation().astype(np.float64) - ref2["T"]) < 1e-5

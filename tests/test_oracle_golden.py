@@ -230,3 +230,20 @@ def test_convergence_criteria_state_machine():
     assert L.orc_convergence_has_converged(C.byref(c3), 1, bp, 0.3) == 0
     assert L.orc_convergence_has_converged(C.byref(c3), 2, bp, 0.3) == 1
     assert c3.convergence_state == 3
+
+
+def test_rejectors_bunny_goldens(bunny, golden):
+    # test/registration/test_registration_api.cpp:131-380 (Distance 97, MedianDistance 139 +
+    # median 0.000465391, OneToOne 103, Trimmed 198) on the 397 original correspondences
+    from oracle import rejectors as rej
+    src, tgt = xyz1(bunny["bun0"]), xyz1(bunny["bun4"])
+    q, m, d = orc.KdTree(tgt).correspondences(src)
+    rq, rm, _ = rej.reject_distance(q, m, d, golden["rej_dist_max_dist"])
+    assert np.array_equal(np.stack([rq, rm], 1), np.asarray(golden["correspondences_dist"]))
+    rq, rm, _, med = rej.reject_median_distance(q, m, d, golden["rej_median_factor"])
+    assert abs(med - golden["rej_median_distance"]) < 1e-4
+    assert np.array_equal(np.stack([rq, rm], 1), np.asarray(golden["correspondences_median_dist"]))
+    rq, rm, _ = rej.reject_one_to_one(q, m, d)
+    assert np.array_equal(np.stack([rq, rm], 1), np.asarray(golden["correspondences_one_to_one"]))
+    rq, rm, _ = rej.reject_trimmed(q, m, d, golden["rej_trimmed_overlap"])
+    assert np.array_equal(np.stack([rq, rm], 1), np.asarray(golden["correspondences_trimmed"]))
