@@ -90,6 +90,19 @@ PCLHIP_API double pclhip_index_build_ms(const pclhip_index* index);
 PCLHIP_API pclhip_status pclhip_knn(pclhip_index* index, const void* queries, size_t stride_bytes,
                                     uint64_t nq, int k, int32_t* out_idx, float* out_d2);
 
+/* All neighbours within `radius` of nq query points, as a CSR list.
+ * Replaces pcl::KdTreeFLANN<PointT>::radiusSearch (kdtree_flann.hpp:372-414) and the batch overload of
+ * pcl::search::Search<PointT>::radiusSearch (search/include/pcl/search/impl/search.hpp:164-190):
+ * squared distance < float(radius*radius), ascending (distance, index); max_nn > 0 keeps only the
+ * max_nn nearest of each query (max_nn = 0: all).  out_offsets: nq+1 uint64 in HOST memory (always
+ * written); *out_total = out_offsets[nq].  out_idx/out_d2 (host or device) must hold `capacity`
+ * entries; if capacity < *out_total the call returns PCLHIP_ERR_OVERFLOW after writing the offsets,
+ * so a caller sizes the buffers with a first call (capacity 0) and fetches with a second. */
+PCLHIP_API pclhip_status pclhip_radius_search(pclhip_index* index, const void* queries, size_t stride_bytes,
+                                              uint64_t nq, double radius, uint32_t max_nn, uint64_t* out_offsets,
+                                              int32_t* out_idx, float* out_d2, uint64_t capacity,
+                                              uint64_t* out_total);
+
 /* Surface normals + curvature of every indexed point from its k nearest neighbours in the index.
  * Replaces pcl::NormalEstimation<PointInT,PointOutT>::computeFeature (features/include/pcl/
  * features/impl/normal_3d.hpp:48-95) with setKSearch(k), search surface == input:

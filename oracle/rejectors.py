@@ -87,3 +87,30 @@ def icp_with_filters(orc, tgt, src, mode, tgt_normals=None, rejectors=(), recipr
             return {"T": final_T, "iterations": it, "converged": True, "state": conv.convergence_state, "per_iter": per_iter}
         if conv.convergence_state != 0:
             return {"T": final_T, "iterations": it, "converged": False, "state": conv.convergence_state, "per_iter": per_iter}
+
+
+def radius_search_bruteforce(tgt, qry, radius, max_nn=0):
+    """KdTreeFLANN::radiusSearch (kdtree/include/pcl/kdtree/impl/kdtree_flann.hpp:372-414), brute
+    force in float32: d2 = ((dx*dx)+dy*dy)+dz*dz < float32(radius*radius), ascending (d2, index),
+    optionally only the max_nn nearest.  Returns CSR (offsets, indices, d2)."""
+    t = np.ascontiguousarray(tgt[:, :3], np.float32)
+    r2 = np.float32(np.float64(radius) * np.float64(radius))
+    offsets, idx, dd = [0], [], []
+    fin = np.isfinite(t).all(1)
+    for qp in np.ascontiguousarray(qry[:, :3], np.float32):
+        if not np.isfinite(qp).all():
+            offsets.append(offsets[-1])
+            continue
+        d = t - qp
+        d = -d  # (q - c): same squares, kept explicit for clarity of the op order below
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        sel = np.nonzero(fin & (d2 < r2))[0]
+        order = np.lexsort((sel, d2[sel]))
+        sel = sel[order]
+        if max_nn and len(sel) > max_nn:
+            sel = sel[:max_nn]
+        idx.append(sel.astype(np.int32))
+        dd.append(d2[sel])
+        offsets.append(offsets[-1] + len(sel))
+    return (np.asarray(offsets, np.uint64), np.concatenate(idx) if idx else np.zeros(0, np.int32),
+            np.concatenate(dd) if dd else np.zeros(0, np.float32))

@@ -68,6 +68,8 @@ SIGNATURES = {
     "pclhip_index_size": (_u64, [_vp]),
     "pclhip_index_build_ms": (C.c_double, [_vp]),
     "pclhip_knn": (C.c_int, [_vp, _vp, _sz, _u64, C.c_int, _vp, _vp]),
+    "pclhip_radius_search": (C.c_int, [_vp, _vp, _sz, _u64, C.c_double, C.c_uint32, C.POINTER(_u64), _vp, _vp, _u64,
+                                       C.POINTER(_u64)]),
     "pclhip_normals": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), _vp, _sz, C.POINTER(_u64)]),
     "pclhip_index_set_normals": (C.c_int, [_vp, _vp, _sz]),
     "pclhip_icp_params_default": (None, [C.POINTER(IcpParams)]),

@@ -154,6 +154,27 @@ class KdTree:
                                   C.c_void_p(d2.ctypes.data)), self.ctx.h)
         return idx, d2
 
+    def radiusSearch(self, queries, radius, max_nn=0):
+        """Batch radiusSearch (search.h:271-273 / search.hpp:164-190).  Returns (offsets uint64 [nq+1],
+        indices int32 [total], sqr_distances float32 [total]) -- neighbours of query i are
+        indices[offsets[i]:offsets[i+1]], ascending by distance."""
+        ptr, stride, nq, keep = _cloud(queries)
+        offsets = np.zeros(nq + 1, np.uint64)
+        total = C.c_uint64(0)
+        optr = offsets.ctypes.data_as(C.POINTER(C.c_uint64))
+        st = self.lib.pclhip_radius_search(self.h, ptr, stride, nq, float(radius), int(max_nn), optr, None, None, 0,
+                                           C.byref(total))
+        if st not in (0, -5):
+            check(st, self.ctx.h)
+        n = int(total.value)
+        idx = np.empty(n, np.int32)
+        d2 = np.empty(n, np.float32)
+        if n:
+            check(self.lib.pclhip_radius_search(self.h, ptr, stride, nq, float(radius), int(max_nn), optr,
+                                                C.c_void_p(idx.ctypes.data), C.c_void_p(d2.ctypes.data), n,
+                                                C.byref(total)), self.ctx.h)
+        return offsets, idx, d2
+
     def setNormals(self, normals):
         ptr, stride, n, keep = _cloud(normals)
         assert n == self.n_cloud

@@ -12,7 +12,8 @@ Inputs read (data and expected values only -- no reference source code is copied
   test/kdtree/test_kdtree.cpp:228-282                            (10 hand points, k=10 orders)
   test/features/test_normal_estimation.cpp:105-124               (bun0 plane fit golden)
   test/filters/test_filters.cpp:576-596                          (VoxelGrid counts/centroids)
-Outputs: tests/golden/bunny.npz, tests/golden/golden.json
+  test/sac_plane_test.pcd + test/kdtree/kdtree_unit_test_results.xml (radiusSearch 0.02 lists)
+Outputs: tests/golden/bunny.npz, tests/golden/golden.json, tests/golden/sac_plane_radius.npz
 """
 import json
 import os
@@ -123,6 +124,24 @@ def main():
                              [-0.05, -0.02, 0.9986, 0.3], [0, 0, 0, 1]],
         "lls_tol": 1e-2,
     }
+    # test/kdtree/test_kdtree.cpp:292-330 + test/kdtree/kdtree_unit_test_results.xml: radiusSearch(0.02)
+    # neighbour lists of every point of test/sac_plane_test.pcd
+    fs, sac = read_pcd_ascii(os.path.join(REF, "test/sac_plane_test.pcd"))
+    xml = open(os.path.join(REF, "test/kdtree/kdtree_unit_test_results.xml")).read()
+    blocks = re.findall(r"<point_(\d+)>(.*?)</point_\1>", xml, re.S)
+    assert len(blocks) == len(sac)
+    offsets, flat = [0], []
+    for i, (pid, body) in enumerate(blocks):
+        assert int(pid) == i
+        size = int(re.search(r"<size>(\d+)</size>", body).group(1))
+        nn = [int(v) for v in re.findall(r"<nn_\d+>(\d+)</nn_\d+>", body)]
+        assert len(nn) == size
+        flat.extend(nn)
+        offsets.append(len(flat))
+    np.savez_compressed(os.path.join(HERE, "sac_plane_radius.npz"), cloud=sac[:, :3].astype(np.float32),
+                        offsets=np.asarray(offsets, np.int64), indices=np.asarray(flat, np.int32),
+                        radius=np.float64(0.02))
+
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(gold, f, indent=0, separators=(",", ":"))
     print("wrote bunny.npz (%d + %d pts) and golden.json" % (len(bun0), len(bun4)))

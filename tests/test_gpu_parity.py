@@ -636,3 +636,36 @@ def test_icp_with_rejectors_vs_oracle(gpu, orc, bunny):
                                 max_correspondence_distance=0.05, transformation_epsilon=1e-8)
     assert icp2.nr_iterations_ == ref2["iterations"]
     assert np.linalg.norm(icp2.getFinalTransformation().astype(np.float64) - ref2["T"]) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# radiusSearch
+# ------------------------------------------------------------------------------------------------
+def test_radius_search_sac_plane_golden(gpu):
+    # test/kdtree/test_kdtree.cpp:292-330 + kdtree_unit_test_results.xml: 3283 exact neighbour lists
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sac_plane_radius.npz"))
+    cloud = z["cloud"]
+    off, idx, d2 = build_tree(gpu, cloud).radiusSearch(cloud, float(z["radius"]))
+    assert np.array_equal(off.astype(np.int64), z["offsets"])
+    assert np.array_equal(idx, z["indices"])
+    assert np.all(d2 < np.float32(0.02 * 0.02))
+
+
+def test_radius_search_vs_bruteforce(gpu):
+    from oracle import rejectors as rej
+    rng = np.random.default_rng(31)
+    pts = rng.uniform(0, 1, (4000, 3)).astype(np.float32)
+    pts[50:60] = pts[40:50]        # duplicates -> ties
+    pts[7] = np.nan
+    qry = rng.uniform(-0.05, 1.05, (500, 3)).astype(np.float32)
+    qry[3] = np.nan
+    tree = build_tree(gpu, pts)
+    for radius, max_nn in ((0.05, 0), (0.12, 0), (0.12, 7), (1e-4, 0), (3.0, 25)):
+        off, idx, d2 = tree.radiusSearch(qry, radius, max_nn)
+        ooff, oidx, od2 = rej.radius_search_bruteforce(pts, qry, radius, max_nn)
+        assert np.array_equal(off, ooff), (radius, max_nn)
+        assert np.array_equal(idx, oidx), (radius, max_nn)
+        assert np.array_equal(d2, od2), (radius, max_nn)
+    off, idx, d2 = tree.radiusSearch(np.zeros((0, 3), np.float32), 0.1)
+    assert len(off) == 1 and len(idx) == 0

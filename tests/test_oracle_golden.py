@@ -247,3 +247,14 @@ def test_rejectors_bunny_goldens(bunny, golden):
     assert np.array_equal(np.stack([rq, rm], 1), np.asarray(golden["correspondences_one_to_one"]))
     rq, rm, _ = rej.reject_trimmed(q, m, d, golden["rej_trimmed_overlap"])
     assert np.array_equal(np.stack([rq, rm], 1), np.asarray(golden["correspondences_trimmed"]))
+
+
+def test_radius_search_sac_plane_golden():
+    # test/kdtree/test_kdtree.cpp:292-330: radiusSearch(0.02) lists of every point of sac_plane_test.pcd
+    import os
+    from oracle import rejectors as rej
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sac_plane_radius.npz"))
+    cloud = z["cloud"]
+    off, idx, d2 = rej.radius_search_bruteforce(cloud, cloud, float(z["radius"]))
+    assert np.array_equal(off.astype(np.int64), z["offsets"])
+    assert np.array_equal(idx, z["indices"])
