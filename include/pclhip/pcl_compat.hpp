@@ -172,6 +172,56 @@ class KdTree {
       k_sqr_distances[i].assign(flat_d.begin() + i * kk, flat_d.begin() + i * kk + found);
     }
   }
+  // kdtree_flann.hpp:372-414: neighbours with squared distance < radius^2, ascending; max_nn = 0: all
+  int radiusSearch(const PointT& point, double radius, Indices& k_indices, std::vector<float>& k_sqr_distances,
+                   unsigned int max_nn = 0) const {
+    k_indices.clear();
+    k_sqr_distances.clear();
+    if (!index_) return 0;
+    std::uint64_t off[2] = {0, 0}, total = 0;
+    pclhip_status st = pclhip_radius_search(index_, &point, sizeof(PointT), 1, radius, max_nn, off, nullptr, nullptr, 0, &total);
+    if ((st != PCLHIP_OK && st != PCLHIP_ERR_OVERFLOW) || total == 0) return 0;
+    k_indices.resize(total);
+    k_sqr_distances.resize(total);
+    if (pclhip_radius_search(index_, &point, sizeof(PointT), 1, radius, max_nn, off, k_indices.data(),
+                             k_sqr_distances.data(), total, &total) != PCLHIP_OK) {
+      k_indices.clear();
+      k_sqr_distances.clear();
+      return 0;
+    }
+    return int(total);
+  }
+  // batch overload (search/include/pcl/search/impl/search.hpp:164-190): one call for the whole cloud
+  void radiusSearch(const PointCloud<PointT>& cloud, const Indices& indices, double radius,
+                    std::vector<Indices>& k_indices, std::vector<std::vector<float>>& k_sqr_distances,
+                    unsigned int max_nn = 0) const {
+    k_indices.clear();
+    k_sqr_distances.clear();
+    if (!index_) return;
+    std::vector<PointT> q;
+    const PointT* qp = cloud.points.data();
+    std::size_t nq = cloud.size();
+    if (!indices.empty()) {
+      for (index_t i : indices) q.push_back(cloud[i]);
+      qp = q.data();
+      nq = q.size();
+    }
+    k_indices.assign(nq, Indices());
+    k_sqr_distances.assign(nq, std::vector<float>());
+    if (nq == 0) return;
+    std::vector<std::uint64_t> off(nq + 1, 0);
+    std::uint64_t total = 0;
+    pclhip_status st = pclhip_radius_search(index_, qp, sizeof(PointT), nq, radius, max_nn, off.data(), nullptr, nullptr, 0, &total);
+    if ((st != PCLHIP_OK && st != PCLHIP_ERR_OVERFLOW) || total == 0) return;
+    Indices flat_i(total);
+    std::vector<float> flat_d(total);
+    if (pclhip_radius_search(index_, qp, sizeof(PointT), nq, radius, max_nn, off.data(), flat_i.data(), flat_d.data(),
+                             total, &total) != PCLHIP_OK) return;
+    for (std::size_t i = 0; i < nq; ++i) {
+      k_indices[i].assign(flat_i.begin() + off[i], flat_i.begin() + off[i + 1]);
+      k_sqr_distances[i].assign(flat_d.begin() + off[i], flat_d.begin() + off[i + 1]);
+    }
+  }
   pclhip_index* handle() const { return index_; }
   Context::Ptr context() const { return ctx_; }
 
@@ -220,6 +270,30 @@ class NormalEstimation {
 
 namespace registration {
 
+// pcl::registration::CorrespondenceRejector{Distance,MedianDistance,OneToOne,Trimmed}: parameter holders;
+// the rejection itself runs on the device inside the ICP iteration (pclhip_icp_set_rejectors).
+struct CorrespondenceRejector {
+  using Ptr = std::shared_ptr<CorrespondenceRejector>;
+  pclhip_rejector desc{PCLHIP_REJ_DISTANCE, 0.0, 0, 0};
+  virtual ~CorrespondenceRejector() = default;
+};
+struct CorrespondenceRejectorDistance : CorrespondenceRejector {
+  CorrespondenceRejectorDistance() { desc.kind = PCLHIP_REJ_DISTANCE; }
+  void setMaximumDistance(float d) { desc.param = d; }  // correspondence_rejection_distance.h:93-97
+};
+struct CorrespondenceRejectorMedianDistance : CorrespondenceRejector {
+  CorrespondenceRejectorMedianDistance() { desc.kind = PCLHIP_REJ_MEDIAN_DISTANCE; desc.param = 1.0; }
+  void setMedianFactor(double f) { desc.param = f; }
+};
+struct CorrespondenceRejectorOneToOne : CorrespondenceRejector {
+  CorrespondenceRejectorOneToOne() { desc.kind = PCLHIP_REJ_ONE_TO_ONE; }
+};
+struct CorrespondenceRejectorTrimmed : CorrespondenceRejector {
+  CorrespondenceRejectorTrimmed() { desc.kind = PCLHIP_REJ_TRIMMED; desc.param = 0.5; }
+  void setOverlapRatio(float r) { desc.param = r; }
+  void setMinCorrespondences(unsigned n) { desc.min_correspondences = n; }
+};
+
 // pcl::registration::CorrespondenceEstimation::determineCorrespondences
 template <typename PointSource, typename PointTarget>
 class CorrespondenceEstimation {
@@ -228,6 +302,11 @@ class CorrespondenceEstimation {
   void setInputSource(const typename PointCloud<PointSource>::ConstPtr& c) { source_ = c; }
   void setInputTarget(const typename PointCloud<PointTarget>::ConstPtr& c) { target_ = c; }
   void setSearchMethodTarget(const typename search::KdTree<PointTarget>::Ptr& t, bool = false) { tree_ = t; }
+  void determineReciprocalCorrespondences(Correspondences& out, double max_distance = std::sqrt(DBL_MAX)) {
+    reciprocal_ = true;
+    determineCorrespondences(out, max_distance);
+    reciprocal_ = false;
+  }
   void determineCorrespondences(Correspondences& out, double max_distance = std::sqrt(DBL_MAX)) {
     out.clear();
     if (!source_ || !target_) return;
@@ -238,6 +317,7 @@ class CorrespondenceEstimation {
     const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     double sums[PCLHIP_ICP_NSUMS];
     if (pclhip_icp_set_source(icp, source_->points.data(), sizeof(PointSource), source_->size()) == PCLHIP_OK &&
+        pclhip_icp_set_reciprocal(icp, reciprocal_ ? 1 : 0) == PCLHIP_OK &&
         pclhip_icp_iterate(icp, I, max_distance, PCLHIP_ICP_POINT_TO_POINT, sums) == PCLHIP_OK) {
       const std::size_t n = source_->size();
       Indices q(n), m(n);
@@ -255,6 +335,7 @@ class CorrespondenceEstimation {
   typename PointCloud<PointSource>::ConstPtr source_;
   typename PointCloud<PointTarget>::ConstPtr target_;
   typename search::KdTree<PointTarget>::Ptr tree_;
+  bool reciprocal_ = false;
 };
 
 }  // namespace registration
@@ -281,6 +362,10 @@ class IterativeClosestPoint {
   void setTransformationEpsilon(double e) { p_.transformation_epsilon = e; }
   void setTransformationRotationEpsilon(double e) { p_.transformation_rotation_epsilon = e; }
   void setEuclideanFitnessEpsilon(double e) { p_.euclidean_fitness_epsilon = e; }
+  // Registration::addCorrespondenceRejector (registration.h:430-434), icp.h:251-256
+  void addCorrespondenceRejector(const registration::CorrespondenceRejector::Ptr& r) { rejectors_.push_back(r); filters_dirty_ = true; }
+  void clearCorrespondenceRejectors() { rejectors_.clear(); filters_dirty_ = true; }
+  void setUseReciprocalCorrespondences(bool on) { reciprocal_ = on; filters_dirty_ = true; }
   int getMaximumIterations() const { return p_.max_iterations; }
   double getMaxCorrespondenceDistance() const { return p_.max_correspondence_distance; }
 
@@ -311,7 +396,7 @@ class IterativeClosestPoint {
   // Registration::initCompute (impl/registration.hpp:73-101): (re)build the target tree only when
   // the target changed and force_no_recompute was not requested
   bool initCompute() {
-    if (!ctx_ || !ctx_->ok() || !source_ || !target_ && !tree_) return false;
+    if (!ctx_ || !ctx_->ok() || !source_ || (!target_ && !tree_)) return false;
     if (!tree_) tree_ = std::make_shared<search::KdTree<PointTarget>>(ctx_);
     if (target_dirty_) {
       if (!(force_no_recompute_ && tree_->handle())) {
@@ -330,6 +415,14 @@ class IterativeClosestPoint {
     if (source_dirty_) {
       if (pclhip_icp_set_source(icp_, source_->points.data(), sizeof(PointSource), source_->size()) != PCLHIP_OK) return false;
       source_dirty_ = false;
+      filters_dirty_ = true;
+    }
+    if (filters_dirty_) {
+      std::vector<pclhip_rejector> list;
+      for (const auto& r : rejectors_) list.push_back(r->desc);
+      if (pclhip_icp_set_rejectors(icp_, list.data(), int(list.size())) != PCLHIP_OK) return false;
+      if (pclhip_icp_set_reciprocal(icp_, reciprocal_ ? 1 : 0) != PCLHIP_OK) return false;
+      filters_dirty_ = false;
     }
     return true;
   }
@@ -339,7 +432,9 @@ class IterativeClosestPoint {
   typename PointCloudSource::ConstPtr source_;
   typename PointCloudTarget::ConstPtr target_;
   typename search::KdTree<PointTarget>::Ptr tree_;
-  bool force_no_recompute_ = false, target_dirty_ = true, source_dirty_ = true;
+  bool force_no_recompute_ = false, target_dirty_ = true, source_dirty_ = true, filters_dirty_ = true;
+  bool reciprocal_ = false;
+  std::vector<registration::CorrespondenceRejector::Ptr> rejectors_;
   Matrix4f final_;
   bool converged_ = false;
   int nr_iterations_ = 0, state_ = 0;

@@ -118,6 +118,34 @@ int main(int argc, char** argv) {
     EXPECT(reg.hasConverged());
     EXPECT(reg.getLastMSE() < 1e-3);  // fitness bar of test_registration.cpp:272-318
   }
+  {  // reciprocal correspondences (53 pairs) + radiusSearch + a rejector inside ICP
+    registration::CorrespondenceEstimation<PointXYZ, PointXYZ> ce(ctx);
+    ce.setInputSource(source);
+    ce.setInputTarget(target);
+    Correspondences corr;
+    ce.determineReciprocalCorrespondences(corr);
+    EXPECT(corr.size() == 53);
+    auto tree = std::make_shared<search::KdTree<PointXYZ>>(ctx);
+    EXPECT(tree->setInputCloud(target));
+    Indices idx;
+    std::vector<float> d2;
+    const int n = tree->radiusSearch((*target)[0], 0.01, idx, d2);
+    EXPECT(n >= 1 && idx[0] == 0 && d2[0] == 0.0f);
+    for (int i = 1; i < n; ++i) EXPECT(d2[i] >= d2[i - 1] && d2[i] < 1e-4f);
+    EXPECT(tree->radiusSearch((*target)[0], 0.01, idx, d2, 2) == (n < 2 ? n : 2));
+    IterativeClosestPoint<PointXYZ, PointXYZ> reg(ctx);
+    reg.setInputSource(source);
+    reg.setInputTarget(target);
+    reg.setMaximumIterations(30);
+    reg.setMaxCorrespondenceDistance(0.05);
+    auto rej = std::make_shared<registration::CorrespondenceRejectorMedianDistance>();
+    rej->setMedianFactor(4.0);
+    reg.addCorrespondenceRejector(rej);
+    reg.addCorrespondenceRejector(std::make_shared<registration::CorrespondenceRejectorOneToOne>());
+    PointCloud<PointXYZ> out;
+    reg.align(out);
+    EXPECT(reg.hasConverged() && reg.getNumberOfIterations() > 1);
+  }
   {  // VoxelGrid 103
     VoxelGrid grid(ctx);
     grid.setLeafSize(0.02f, 0.02f, 0.02f);
