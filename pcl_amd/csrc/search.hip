@@ -944,7 +944,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   if (icp->n > 0 && (unfused || filters)) {
     static const int qpl = [] {
       const char* e = getenv("PCLHIP_ICP_QPL");
-      return (e && atoi(e) == 1) ? 1 : 2;
+      return (e && atoi(e) == 2) ? 2 : 1;  // QPL=2 spills (measured slower); kept as an A/B switch
     }();
     auto ks = (qpl == 2) ? icp_search_kernel<4, 2> : icp_search_kernel<4, 1>;
     const uint32_t ngroups_s = (icp->n + WAVE * qpl - 1) / (WAVE * qpl);
