@@ -29,8 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-B_ALG_P2PLANE = 56.0   # bytes per correspondence: src 16 + tgt 16 + normal 16 + (idx 4 + d2 4)
-B_ALG_P2POINT = 40.0
+# algorithmic bytes per correspondence: src 16 + tgt 16 + (idx 4 + d2 4) = 40 for the
+# search; + normal 16 = 56 for a whole point-to-plane iteration
+B_ALG_SEARCH = 40.0
+B_ALG_ITER = {1: 56.0, 0: 40.0}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -119,7 +121,7 @@ def main():
             state["it"] = 0
         else:
             state["T"] = T
-        return sums[28], icp.lastKernelMs()
+        return sums[28], icp.lastKernelMs(), icp.lastSearchMs()
 
     def fence():
         torch.cuda.synchronize()
@@ -133,10 +135,12 @@ def main():
     t0 = time.perf_counter()
     ncorr = 0.0
     kernel_ms = 0.0
+    search_ms = 0.0
     for _ in range(args.steps):
-        c, kms = step()
+        c, kms, sms = step()
         ncorr += c            # already the all-reduced (global) count when world > 1
         kernel_ms += kms
+        search_ms += sms
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -144,18 +148,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel (fused search+accumulate), live HIP-event timing
-    b_alg = B_ALG_P2PLANE if mode == 1 else B_ALG_P2POINT
-    avg_kernel_s = kernel_ms / args.steps / 1e3
+    # ---- roofline of the dominant kernel (the exact 1-NN search), live HIP-event timing on the context's
+    # stream.  The iteration is two kernels: icp_search_kernel (dominant) and the streaming
+    # icp_accumulate_kernel; with PCLHIP_ICP_FUSED=1 both run as one kernel and the two times coincide.
+    fused = os.environ.get("PCLHIP_ICP_FUSED", "0") == "1"
+    b_alg = B_ALG_ITER[mode] if fused else B_ALG_SEARCH
+    avg_kernel_s = search_ms / args.steps / 1e3
     corr_per_launch_local = ncorr / args.steps / world
     achieved = b_alg * corr_per_launch_local / avg_kernel_s / 1e9
-    roofline = {"bound": "hbm", "kernel": "icp_iterate_kernel<%d>" % mode, "achieved": round(achieved, 2),
+    roofline = {"bound": "hbm", "kernel": ("icp_iterate_kernel<%d>" % mode) if fused else "icp_search_kernel",
+                "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None, "alg_bytes_per_corr": b_alg, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4)}
+                "traffic": None, "alg_bytes_per_corr": b_alg, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
+                "iteration_kernels_ms": round(kernel_ms / args.steps, 4),
+                "iteration_alg_bytes_per_corr": B_ALG_ITER[mode]}
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tp):  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
         try:
-            roofline["traffic"] = json.load(open(tp)).get("icp_iterate_bytes_per_launch_%s" % args.mode)
+            roofline["traffic"] = json.load(open(tp)).get(
+                ("icp_iterate_bytes_per_launch_%s" % args.mode) if fused else "icp_search_bytes_per_launch")
         except Exception:
             pass
 

@@ -214,6 +214,9 @@ PCLHIP_API pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[
 /* GPU time (ms, HIP events on the context stream) of the fused search+accumulate kernel of the
  * last pclhip_icp_iterate call. */
 PCLHIP_API double pclhip_icp_last_kernel_ms(const pclhip_icp* icp);
+/* Duration (ms) of the search kernel alone in the last pclhip_icp_iterate (the default iteration is
+ * two kernels: search, then the streaming accumulation of the 6x6 / umeyama sums). */
+PCLHIP_API double pclhip_icp_last_search_ms(const pclhip_icp* icp);
 
 /* Host-side closed forms on a reduction record (exposed for the adapters and for tests):
  * 6x6 solve + constructTransformationMatrix (…point_to_plane_lls.hpp:132-163,264-268) or umeyama
@@ -227,6 +230,15 @@ PCLHIP_API pclhip_status pclhip_solve_transformation(const double sums[PCLHIP_IC
  * guess: row-major 4x4 or NULL. */
 PCLHIP_API pclhip_status pclhip_icp_align(pclhip_icp* icp, const pclhip_icp_params* params,
                                           const float guess[16], pclhip_icp_result* result);
+
+/* Registration::getFitnessScore(max_range) (registration/include/pcl/registration/impl/registration.hpp:132-168):
+ * the source is transformed by T (row-major 4x4, Transformer::se3 operation order like
+ * transformPointCloud), every finite point looks up its nearest target point, and the SQUARED
+ * distances that are <= max_range (compared as given, like the reference) are averaged in double.
+ * *score = DBL_MAX when nothing qualifies; *nr (may be NULL) = number of points that counted.
+ * Does not disturb the state of the alignment (seeds, correspondences of the last iteration). */
+PCLHIP_API pclhip_status pclhip_icp_fitness_score(pclhip_icp* icp, const float T[16], double max_range,
+                                                  double* score, uint64_t* nr);
 
 /* Correspondences of the LAST iteration, materialised lazily as pcl::Correspondences
  * (common/include/pcl/correspondence.h:60-89): sorted by index_query, entries beyond max_dist

@@ -24,6 +24,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "../pclhip.h"
@@ -387,6 +388,13 @@ class IterativeClosestPoint {
   }
   Matrix4f getFinalTransformation() const { return final_; }
   bool hasConverged() const { return converged_; }
+  // Registration::getFitnessScore (registration/include/pcl/registration/impl/registration.hpp:132-168)
+  double getFitnessScore(double max_range = std::numeric_limits<double>::max()) {
+    if (!initCompute()) return std::numeric_limits<double>::max();
+    double score = std::numeric_limits<double>::max();
+    pclhip_icp_fitness_score(icp_, final_.m, max_range, &score, nullptr);
+    return score;
+  }
   int getNumberOfIterations() const { return nr_iterations_; }
   int getConvergenceState() const { return state_; }
   double getLastMSE() const { return last_mse_; }

@@ -284,6 +284,39 @@ int64_t orc_correspondences(const orc_kdtree* t, const float* src, int64_t ns, i
   return c;
 }
 
+/* Registration::getFitnessScore, registration/include/pcl/registration/impl/registration.hpp:132-168.
+ * input_transformed = transformPointCloud(input, T) (Transformer::se3 order); for every finite point
+ * the 1-NN squared distance is added (double, ascending point order) when it is <= max_range
+ * (compared as given: squared distance against max_range, :157); returns sum/nr or DBL_MAX. */
+double orc_fitness_score(const orc_kdtree* t, const float* src, int64_t ns, int ss, const float* T,
+                         double max_range, int64_t* out_nr, int nthreads) {
+  float* cur = (float*)calloc((size_t)(ns > 0 ? ns : 1) * 4, sizeof(float));
+  for (int64_t i = 0; i < ns; ++i) {
+    cur[4 * i] = src[i * ss];
+    cur[4 * i + 1] = src[i * ss + 1];
+    cur[4 * i + 2] = src[i * ss + 2];
+    cur[4 * i + 3] = 1.0f;
+  }
+  orc_transform_cloud(T, 1, cur, 4, cur, 4, NULL, 0, NULL, 0, ns);
+  int32_t* nn = (int32_t*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
+  float* dd = (float*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(float));
+  orc_kdtree_knn(t, cur, ns, 4, 1, nn, dd, nthreads);
+  double fitness = 0.0;
+  int64_t nr = 0;
+  for (int64_t i = 0; i < ns; ++i) {
+    if (nn[i] < 0) continue; /* non-finite point (:151-152) */
+    if ((double)dd[i] <= max_range) {
+      fitness += (double)dd[i];
+      ++nr;
+    }
+  }
+  free(cur);
+  free(nn);
+  free(dd);
+  if (out_nr) *out_nr = nr;
+  return nr > 0 ? fitness / (double)nr : DBL_MAX;
+}
+
 int64_t orc_reciprocal_correspondences(const orc_kdtree* tgt_tree, const orc_kdtree* src_tree,
                                        const float* src, int64_t ns, int ss, const float* tgt,
                                        int ts, double max_dist, int32_t* out_q, int32_t* out_m,

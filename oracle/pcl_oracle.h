@@ -50,6 +50,9 @@ int orc_kdtree_knn(const orc_kdtree* t, const float* qry, int64_t nq, int qs, in
 int64_t orc_correspondences(const orc_kdtree* t, const float* src, int64_t ns, int ss,
                             double max_dist, int32_t* out_q, int32_t* out_m, float* out_d2,
                             int nthreads);
+/* Registration::getFitnessScore (registration/include/pcl/registration/impl/registration.hpp:132-168) */
+double orc_fitness_score(const orc_kdtree* t, const float* src, int64_t ns, int ss, const float* T,
+                         double max_range, int64_t* out_nr, int nthreads);
 /* determineReciprocalCorrespondences (:220-311): keep (i, m) only if the 1-NN of target[m] in the
  * source tree is i again.  src_tree indexes the source cloud. */
 int64_t orc_reciprocal_correspondences(const orc_kdtree* tgt_tree, const orc_kdtree* src_tree,

@@ -70,6 +70,9 @@ def lib():
         L.orc_correspondences.restype = C.c_int64
         L.orc_correspondences.argtypes = [vp, fp, C.c_int64, C.c_int, C.c_double, ip, ip, fp,
                                           C.c_int]
+        L.orc_fitness_score.restype = C.c_double
+        L.orc_fitness_score.argtypes = [vp, fp, C.c_int64, C.c_int, fp, C.c_double,
+                                        C.POINTER(C.c_int64), C.c_int]
         L.orc_reciprocal_correspondences.restype = C.c_int64
         L.orc_reciprocal_correspondences.argtypes = [vp, vp, fp, C.c_int64, C.c_int, fp, C.c_int,
                                                      C.c_double, ip, ip, fp, C.c_int]
@@ -167,6 +170,15 @@ class KdTree:
         c = lib().orc_correspondences(self.h, _f(src), ns, ss, float(max_dist), _i(q), _i(m),
                                       _f(d2), nthreads or default_threads())
         return q[:c].copy(), m[:c].copy(), d2[:c].copy()
+
+    def fitness_score(self, src, T, max_range=float(np.finfo(np.float64).max), nthreads=None):
+        """Registration::getFitnessScore; returns (score, nr)."""
+        src, ns, ss = _cloud(src)
+        T = np.ascontiguousarray(T, np.float32).reshape(16)
+        nr = C.c_int64(0)
+        v = lib().orc_fitness_score(self.h, _f(src), ns, ss, _f(T), float(max_range), C.byref(nr),
+                                    nthreads or default_threads())
+        return float(v), int(nr.value)
 
     def reciprocal_correspondences(self, src_tree, src, tgt,
                                    max_dist=np.sqrt(np.finfo(np.float64).max), nthreads=None):

@@ -84,11 +84,14 @@ SIGNATURES = {
     "pclhip_icp_iterate": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_double, C.c_int,
                                      C.POINTER(C.c_double)]),
     "pclhip_icp_last_kernel_ms": (C.c_double, [_vp]),
+    "pclhip_icp_last_search_ms": (C.c_double, [_vp]),
     "pclhip_index_last_kernel_ms": (C.c_double, [_vp]),
     "pclhip_solve_transformation": (C.c_int, [C.POINTER(C.c_double), C.c_int,
                                               C.POINTER(C.c_float)]),
     "pclhip_icp_align": (C.c_int, [_vp, C.POINTER(IcpParams), C.POINTER(C.c_float),
                                    C.POINTER(IcpResult)]),
+    "pclhip_icp_fitness_score": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_double, C.POINTER(C.c_double),
+                                           C.POINTER(_u64)]),
     "pclhip_icp_fetch_correspondences": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_u64)]),
     "pclhip_transform_cloud": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int, _vp, _vp, _sz, _u64,
                                          _sz]),

@@ -469,7 +469,12 @@ class IterativeClosestPoint:
         check(self.lib.pclhip_icp_reset(self.h), self.ctx.h)
 
     def lastKernelMs(self):
+        """search + (filters) + accumulate kernels of the last iterate(), HIP events"""
         return float(self.lib.pclhip_icp_last_kernel_ms(self.h))
+
+    def lastSearchMs(self):
+        """the search kernel alone"""
+        return float(self.lib.pclhip_icp_last_search_ms(self.h))
 
     def solve(self, sums):
         T = np.zeros(16, np.float32)
@@ -520,6 +525,20 @@ class IterativeClosestPoint:
 
     def getFinalTransformation(self):
         return np.array(self.result.final_transformation, np.float32).reshape(4, 4)
+
+    def getFitnessScore(self, max_range=float(np.finfo(np.float64).max), transform=None):
+        """Registration::getFitnessScore (impl/registration.hpp:132-168): mean squared 1-NN distance
+        of the source moved by the final transformation (or `transform`), over the points whose
+        squared distance is <= max_range; DBL_MAX when none qualifies."""
+        self._ensure()
+        T = self.getFinalTransformation() if transform is None else transform
+        T = np.ascontiguousarray(T, np.float32).reshape(16)
+        score = C.c_double(0.0)
+        nr = C.c_uint64(0)
+        check(self.lib.pclhip_icp_fitness_score(self.h, _fp(T), C.c_double(max_range), C.byref(score),
+                                                C.byref(nr)), self.ctx.h)
+        self.fitness_points = int(nr.value)
+        return float(score.value)
 
     def getLastIncrementalTransformation(self):
         return np.array(self.result.last_transformation, np.float32).reshape(4, 4)

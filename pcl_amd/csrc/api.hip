@@ -449,7 +449,8 @@ pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out) {
   icp->prev_mse = DBL_MAX;
   if (hipMalloc(&icp->sums_dev, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
       hipHostMalloc(&icp->sums_host, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
-      hipEventCreate(&icp->ev0) != hipSuccess || hipEventCreate(&icp->ev1) != hipSuccess) {
+      hipEventCreate(&icp->ev0) != hipSuccess || hipEventCreate(&icp->ev1) != hipSuccess ||
+      hipEventCreate(&icp->ev_mid) != hipSuccess) {
     set_error(ctx, "allocation failed in pclhip_icp_create");
     pclhip_icp_destroy(icp);
     return PCLHIP_ERR_HIP;
@@ -485,6 +486,7 @@ void pclhip_icp_destroy(pclhip_icp* icp) {
   if (icp->sums_host) (void)hipHostFree(icp->sums_host);
   if (icp->ev0) (void)hipEventDestroy(icp->ev0);
   if (icp->ev1) (void)hipEventDestroy(icp->ev1);
+  if (icp->ev_mid) (void)hipEventDestroy(icp->ev_mid);
   delete icp;
 }
 
@@ -585,10 +587,14 @@ pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[16], double
   std::memcpy(sums, icp->sums_host, PCLHIP_ICP_NSUMS * sizeof(double));
   float ms = 0;
   if (icp->n > 0 && hipEventElapsedTime(&ms, icp->ev0, icp->ev1) == hipSuccess) icp->last_kernel_ms = ms;
+  icp->last_search_ms = icp->last_kernel_ms;
+  if (icp->n > 0 && icp->mid_recorded && hipEventElapsedTime(&ms, icp->ev0, icp->ev_mid) == hipSuccess)
+    icp->last_search_ms = ms;
   return PCLHIP_OK;
 }
 
 double pclhip_icp_last_kernel_ms(const pclhip_icp* icp) { return icp ? icp->last_kernel_ms : 0.0; }
+double pclhip_icp_last_search_ms(const pclhip_icp* icp) { return icp ? icp->last_search_ms : 0.0; }
 double pclhip_index_last_kernel_ms(const pclhip_index* ix) { return ix ? ix->last_kernel_ms : 0.0; }
 
 pclhip_status pclhip_solve_transformation(const double* sums, int mode, float* T) {
@@ -722,6 +728,18 @@ pclhip_status pclhip_icp_align(pclhip_icp* icp, const pclhip_icp_params* params,
   res->gpu_ms = ms;
   res->gpu_ms_search_kernel = kernel_ms;
   return PCLHIP_OK;
+}
+
+pclhip_status pclhip_icp_fitness_score(pclhip_icp* icp, const float T[16], double max_range, double* score,
+                                       uint64_t* nr) {
+  if (!icp || !T || !score) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = icp->ctx;
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  PCLHIP_REQUIRE(ctx, icp->target != nullptr, "no target index");
+  uint64_t n_used = 0;
+  pclhip_status st = launch_fitness_score(icp, T, max_range, score, &n_used);
+  if (nr) *nr = n_used;
+  return st;
 }
 
 pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_query, int32_t* index_match,

@@ -120,8 +120,10 @@ struct pclhip_icp {
   double prev_mse;
   int iterations_similar_transforms = 0;
   int convergence_state = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;  // ev_mid: end of the search kernel
+  bool mid_recorded = false;
   double last_kernel_ms = 0;
+  double last_search_ms = 0;  // the search kernel alone (two-kernel variant); = last_kernel_ms when fused
   // optional stages between search and accumulation
   std::vector<pclhip_rejector> rejectors;
   bool reciprocal = false;
@@ -175,6 +177,8 @@ pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stri
                             uint32_t* rank_or_null);
 pclhip_status build_boxes(pclhip_index* ix);
 int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns);
+pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double max_range, double* score,
+                                   uint64_t* nr);
 
 // ---- kernels launched from api.cpp ----------------------------------------------------------
 pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, int k,

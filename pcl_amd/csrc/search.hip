@@ -11,6 +11,9 @@
 #include <cstring>
 
 #include "traverse.hpp"
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 
 namespace pclhip {
 
@@ -49,6 +52,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
       NN1Min fast;
       fast.init(__builtin_inff());
       traverse(ix, qx, qy, qz, vv, fast, wl_s[threadIdx.x / WAVE], topbox_s, ts);
+      fast.resolve(ix, qx, qy, qz);
       NN1 pol;
       pol.key = KEY_NONE;
       pol.pos = fast.bestpos[0];
@@ -143,14 +147,22 @@ static int persistent_blocks(pclhip_ctx* ctx, uint32_t ngroups, int blocks_per_c
 // slot while the others are already through their share of the groups.
 template <class K>
 static int resident_blocks(pclhip_ctx* ctx, K kernel, uint32_t ngroups) {
-  static int per_cu = 0;  // one static per kernel instantiation
-  if (per_cu == 0) {
-    int v = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, BLOCK, 0) != hipSuccess || v < 1) {
-      (void)hipGetLastError();
-      v = 2;
+  // keyed by the kernel's address: instantiations with the same signature share this function
+  static std::mutex mu;
+  static std::unordered_map<const void*, int> cache;
+  int per_cu;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(reinterpret_cast<const void*>(kernel));
+    if (it == cache.end()) {
+      int v = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, BLOCK, 0) != hipSuccess || v < 1) {
+        (void)hipGetLastError();
+        v = 2;
+      }
+      it = cache.emplace(reinterpret_cast<const void*>(kernel), v).first;
     }
-    per_cu = v;
+    per_cu = it->second;
   }
   return persistent_blocks(ctx, ngroups, per_cu);
 }
@@ -600,7 +612,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_iterate_kernel(IndexView ix, 
     }
     const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
     const bool vv[1] = {valid};
-    traverse(ix, qx, qy, qz, vv, fast, wl_s[wave], topbox_s, ts);
+    traverse<NN1Min, true>(ix, qx, qy, qz, vv, fast, wl_s[wave], topbox_s, ts);
+    fast.resolve(ix, qx, qy, qz);
     NN1 pol;
     pol.key = KEY_NONE;
     pol.pos = fast.bestpos[0];
@@ -695,13 +708,15 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_iterate_kernel(IndexView ix, 
 // Two-kernel variant of the iteration (PCLHIP_ICP_FUSED=0): a search-only kernel without the 27 fp64
 // accumulators (fewer registers, room to software-pipeline the next group's loads) followed by a
 // streaming accumulate kernel.  Same results as the fused kernel up to fp64 summation order.
-template <int MINW, int Q>
+template <int MINW, int Q, bool SPARSE>
 __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, float4* __restrict__ cur, uint32_t ns,
-                                                                 Mat34 T, int order, float bound, int use_max,
+                                                                 Mat34 T, int order, float bound, int flags,
                                                                  uint32_t* __restrict__ match_pos,
                                                                  uint32_t* __restrict__ match,
                                                                  float* __restrict__ match_d2,
                                                                  unsigned long long* gstats) {
+  const int use_max = flags & 1;        // a finite max correspondence distance is set
+  const bool use_hint = (flags & 2) != 0;  // prefetch the box rows along the seeds' ancestors
   __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
   load_top_cache(ix, topbox_s);
@@ -729,7 +744,17 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
       if (sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
     }
   }
+  static_assert(LEAF == 16, "seed position -> leaf");
+  // box rows along the ancestors of one seed of the group: in flight before the traversal needs them
+  const auto hint_leaf = [&](const uint32_t* sp) -> uint32_t {
+    const uint64_t hm = __builtin_amdgcn_ballot_w64(sp[0] != NO_INDEX);
+    if (hm == 0) return NO_INDEX;
+    return uint32_t(__builtin_amdgcn_readlane(int(sp[0]), __builtin_ctzll(hm))) / LEAF;
+  };
+  RowHint hint_n;
+  hint_n.fetch(ix, use_hint ? hint_leaf(sp_n) : NO_INDEX);
   while (g < ngroups) {
+    const RowHint hint = hint_n;
     float4 p[Q], t0[Q];
     uint32_t seed_pos[Q];
     bool in_range[Q], valid[Q];
@@ -772,13 +797,15 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
       }
       qx[q] = p[q].x; qy[q] = p[q].y; qz[q] = p[q].z;
     }
-    traverse(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts);
+    traverse<NN1MinT<Q>, SPARSE>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, &hint);
+    fast.resolve(ix, qx, qy, qz);
     // ... and their seed target points as soon as the seed positions have arrived
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       t_n[q] = make_float4(0, 0, 0, 0);
       if (next_ok[q] && sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
     }
+    hint_n.fetch(ix, use_hint ? hint_leaf(sp_n) : NO_INDEX);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       NN1 pol;
@@ -921,24 +948,15 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   // candidates must be <= max_d2 (a float): strict bound just above it; +inf when unbounded
   const float bound = use_max ? std::nextafterf(max_d2, __builtin_inff()) : __builtin_inff();
   const uint32_t ngroups = (icp->n + WAVE - 1) / WAVE;
-  // point-to-plane carries 27 fp64 accumulators per lane: 3 waves/SIMD by default; PCLHIP_ICP_WAVES=4
-  // selects the variant compiled for 4 waves/SIMD (<= 128 VGPRs) for A/B measurements
-  static const int want4 = [] {
-    const char* e = getenv("PCLHIP_ICP_WAVES");
-    return (e && atoi(e) == 4) ? 1 : 0;
-  }();
-  auto k_plane3 = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE, 3>;
-  auto k_plane4 = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE, 4>;
-  auto k_point = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT, 4>;
-  int grid;
-  if (mode == PCLHIP_ICP_POINT_TO_PLANE)
-    grid = want4 ? resident_blocks(ctx, k_plane4, ngroups) : resident_blocks(ctx, k_plane3, ngroups);
-  else
-    grid = resident_blocks(ctx, k_point, ngroups);
+  // single-kernel variant (PCLHIP_ICP_FUSED=1): 27 (15) fp64 accumulators per lane -> 3 waves/SIMD
+  auto k_plane = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE, 3>;
+  auto k_point = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT, 3>;
+  int grid = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? resident_blocks(ctx, k_plane, ngroups)
+                                                 : resident_blocks(ctx, k_point, ngroups);
   if (grid > icp->grid_blocks) grid = icp->grid_blocks;
   static const int unfused = [] {
     const char* e = getenv("PCLHIP_ICP_FUSED");
-    return (e && atoi(e) == 0) ? 1 : 0;
+    return (e && atoi(e) == 1) ? 0 : 1;  // default: the two-kernel variant (measured faster)
   }();
   const bool filters = icp->reciprocal || !icp->rejectors.empty();
   if (icp->n > 0 && (unfused || filters)) {
@@ -946,13 +964,32 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
       const char* e = getenv("PCLHIP_ICP_QPL");
       return (e && atoi(e) == 2) ? 2 : 1;  // QPL=2 spills (measured slower); kept as an A/B switch
     }();
-    auto ks = (qpl == 2) ? icp_search_kernel<4, 2> : icp_search_kernel<4, 1>;
+    static const int sparse = [] {
+      const char* e = getenv("PCLHIP_ICP_SPARSE");
+      return (e && atoi(e) == 0) ? 0 : 1;
+    }();
+    static const int hint = [] {
+      const char* e = getenv("PCLHIP_ICP_HINT");
+      return (e && atoi(e) == 0) ? 0 : 2;
+    }();
+    static const bool cold_set = [] {
+      const char* e = getenv("PCLHIP_SPARSE_COLD");
+      if (e) {
+        const float f = float(atof(e));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(c_sparse_cold), &f, sizeof(float));
+      }
+      return e != nullptr;
+    }();
+    (void)cold_set;
+    auto ks = (qpl == 2) ? icp_search_kernel<4, 2, false>
+                         : (sparse ? icp_search_kernel<4, 1, true> : icp_search_kernel<4, 1, false>);
     const uint32_t ngroups_s = (icp->n + WAVE * qpl - 1) / (WAVE * qpl);
-    int gs = (qpl == 2) ? resident_blocks(ctx, icp_search_kernel<4, 2>, ngroups_s)
-                        : resident_blocks(ctx, icp_search_kernel<4, 1>, ngroups_s);
+    const int gs = resident_blocks(ctx, ks, ngroups_s);
     (void)hipEventRecord(icp->ev0, s);
-    hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound, use_max ? 1 : 0,
-                       icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+    hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound,
+                       (use_max ? 1 : 0) | hint, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+    (void)hipEventRecord(icp->ev_mid, s);
+    icp->mid_recorded = true;
     const uint8_t* keep = nullptr;
     if (filters) {
       pclhip_status st = apply_correspondence_filters(icp, max_d2, use_max);
@@ -970,8 +1007,9 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     (void)hipEventRecord(icp->ev1, s);
     hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, ga, icp->sums_dev);
   } else if (icp->n > 0) {
+    icp->mid_recorded = false;
     (void)hipEventRecord(icp->ev0, s);
-    auto kern = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? (want4 ? k_plane4 : k_plane3) : k_point;
+    auto kern = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? k_plane : k_point;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound,
                        use_max ? 1 : 0, icp->match_pos, icp->match, icp->match_d2, icp->partials, ctx->stats);
     (void)hipEventRecord(icp->ev1, s);
@@ -983,16 +1021,91 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   return PCLHIP_OK;
 }
 
+// ---- Registration::getFitnessScore (registration/include/pcl/registration/impl/registration.hpp:132-168)
+// Mean of the 1-NN squared distances that are <= max_range (the reference compares the SQUARED distance
+// with max_range as given, in double).  Per-block partial (sum, count) pairs, summed on the host in
+// block order: deterministic.
+__global__ __launch_bounds__(BLOCK) void fitness_partial_kernel(const float* __restrict__ d2, uint32_t n,
+                                                                double max_range, double* __restrict__ partials) {
+  __shared__ double red_s[WAVES_PER_BLOCK][2];
+  double s = 0.0, c = 0.0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float d = d2[i];
+    if (double(d) <= max_range) {  // +inf (no match / non-finite source point) never passes
+      s += double(d);
+      c += 1.0;
+    }
+  }
+  s = wave_sum_d(s);
+  c = wave_sum_d(c);
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+  if (lane == 0) {
+    red_s[wave][0] = s;
+    red_s[wave][1] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double a = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES_PER_BLOCK; ++w) a += red_s[w][threadIdx.x];
+    partials[size_t(blockIdx.x) * 2 + threadIdx.x] = a;
+  }
+}
+
+pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double max_range, double* score,
+                                   uint64_t* nr) {
+  pclhip_ctx* ctx = icp->ctx;
+  hipStream_t s = ctx->stream;
+  *score = DBL_MAX;
+  *nr = 0;
+  if (icp->n == 0) return PCLHIP_OK;
+  const IndexView v = icp->target->view();
+  Mat34 M;
+  for (int i = 0; i < 12; ++i) M.m[i] = T[i];
+  const uint32_t n = icp->n;
+  const int gr = ctx->num_cus * 4;
+  // scratch: transformed copy of the source, seed/match positions, match ids, distances, partials
+  const size_t o_pos = size_t(n) * sizeof(float4), o_id = o_pos + size_t(n) * 4, o_d2 = o_id + size_t(n) * 4;
+  const size_t o_part = (o_d2 + size_t(n) * 4 + 15) & ~size_t(15);
+  pclhip_status st = ensure_scratch(ctx, o_part + size_t(gr) * 2 * sizeof(double));
+  if (st != PCLHIP_OK) return st;
+  char* base = static_cast<char*>(ctx->scratch);
+  float4* cur = reinterpret_cast<float4*>(base);
+  uint32_t* pos = reinterpret_cast<uint32_t*>(base + o_pos);
+  uint32_t* id = reinterpret_cast<uint32_t*>(base + o_id);
+  float* d2 = reinterpret_cast<float*>(base + o_d2);
+  double* part = reinterpret_cast<double*>(base + o_part);
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(cur, icp->src_sorted0, size_t(n) * sizeof(float4), hipMemcpyDeviceToDevice, s));
+  // the last iteration's matches are valid upper bounds for any pose: use them as seeds
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(pos, icp->match_pos, size_t(n) * 4, hipMemcpyDeviceToDevice, s));
+  const uint32_t ngroups = (n + WAVE - 1) / WAVE;
+  const int gs = resident_blocks(ctx, icp_search_kernel<4, 1, true>, ngroups);
+  // transformPointCloud(cloud, out, Matrix4) is Transformer::se3 (transforms.hpp:109-123): order 1
+  hipLaunchKernelGGL((icp_search_kernel<4, 1, true>), dim3(gs), dim3(BLOCK), 0, s, v, cur, n, M, 1, __builtin_inff(), 2, pos,
+                     id, d2, ctx->stats);
+  hipLaunchKernelGGL(fitness_partial_kernel, dim3(gr), dim3(BLOCK), 0, s, d2, n, max_range, part);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  std::vector<double> h(size_t(gr) * 2);
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(h.data(), part, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  double sum = 0.0, cnt = 0.0;
+  for (int b = 0; b < gr; ++b) {
+    sum += h[size_t(b) * 2];
+    cnt += h[size_t(b) * 2 + 1];
+  }
+  *nr = uint64_t(cnt);
+  if (cnt > 0.0) *score = sum / cnt;
+  return PCLHIP_OK;
+}
+
 // upper bound of the persistent grid (sizes the partial-sum buffer)
 int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns) {
   const uint32_t ngroups = (ns + WAVE - 1) / WAVE;
-  auto k_plane3 = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE, 3>;
-  auto k_plane4 = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE, 4>;
-  auto k_point = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT, 4>;
-  int g = resident_blocks(ctx, k_plane3, ngroups);
-  const int g4 = resident_blocks(ctx, k_plane4, ngroups), gp = resident_blocks(ctx, k_point, ngroups);
-  if (g4 > g) g = g4;
+  int g = resident_blocks(ctx, icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE, 3>, ngroups);
+  const int gp = resident_blocks(ctx, icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT, 3>, ngroups);
+  const int gsr = resident_blocks(ctx, icp_search_kernel<4, 1, true>, ngroups);
   if (gp > g) g = gp;
+  if (gsr > g) g = gsr;
   if (ctx->num_cus * 8 > g) g = ctx->num_cus * 8;  // the streaming accumulate kernel of the two-kernel variant
   return g;
 }

@@ -23,6 +23,10 @@
 
 namespace pclhip {
 
+// tuning knob (A/B only, PCLHIP_SPARSE_COLD): a leaf-level node is walked with the "loose bounds" scheme
+// while T * c_sparse_cold > (diagonal of the query group)^2
+static __constant__ float c_sparse_cold = 16.0f;
+
 constexpr int STACK_ENTRIES = 192;     // <= 63 siblings per interior level below the root scan, <= 3 such levels
 constexpr int LEAF_BATCH = 16;         // leaves staged in LDS at a time (16 x 256 B = 4 KB)
 constexpr int LEAF_FLOATS = 4 * LEAF;  // x[16] y[16] z[16] w[16]
@@ -156,24 +160,27 @@ struct NN1 {
 };
 
 // 1-NN fast path: the hot loop only tracks the minimum DISTANCE (packed v_pk_* math on candidate
-// pairs, one v_min3 per pair).  Only when some lane's minimum improves (rare once bounds are tight:
-// seeded ICP iterations) the leaf is re-scanned to find WHICH slot produced it.  Exact distance ties
-// (two slots of a leaf, or an equal minimum in another leaf) raise `tie`; the caller then re-runs
-// the exact policy NN1 for those lanes, so results stay bit-identical to the oracle.
+// pairs, one v_min3 per pair) and the LEAF that first reached it (a wave-uniform id: one select).
+// WHICH slot of that leaf won is resolved once per query after the traversal (resolve()): the lane
+// re-reads its winning leaf and recomputes the same 16 distances.  Exact distance ties (two slots of
+// a leaf, or an equal minimum in another leaf) raise `tie`; the caller then re-runs the exact policy
+// NN1 for those lanes, so results stay bit-identical to the oracle.
 template <int Q>
 struct NN1MinT {
   static constexpr int QPL = Q;  // queries per lane: the wave owns 64*Q queries and every staged
                                  // candidate block / node scan / leaf test is shared by all of them
   float best[Q];         // candidates must be strictly below this to win
-  uint32_t bestpos[Q];   // sorted position of the candidate that first reached `best`; NO_INDEX while
-                         // best is only the bound
+  uint32_t bestpos[Q];   // sorted position of the winner; while `unres`: first slot of the winning leaf;
+                         // NO_INDEX while best is only the bound
   bool tie[Q];
+  bool unres[Q];         // the winner's slot inside leaf bestpos/LEAF is not known yet
   __device__ __forceinline__ void init(float bound_exclusive) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       best[q] = bound_exclusive;
       bestpos[q] = NO_INDEX;
       tie[q] = false;
+      unres[q] = false;
     }
   }
   __device__ __forceinline__ void seed(int q, float d, uint32_t pos) {
@@ -202,31 +209,74 @@ struct NN1MinT {
         m[q] = __builtin_fminf(m[q], __builtin_fminf(r.x, r.y));
       }
     }
+    const uint32_t first = leaf_id * LEAF;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const bool imp = m[q] < best[q];
-      // equal minimum in a different leaf than the current winner's: possible index tie
+      // equal minimum in another leaf than the current winner's: index tie, the exact policy decides
       const bool eq = (m[q] == best[q]) && (bestpos[q] != NO_INDEX) && (bestpos[q] / LEAF != leaf_id);
-      tie[q] = tie[q] || eq;
-      if (__builtin_amdgcn_ballot_w64(imp) != 0) {
-        // The re-scan recomputes the same distances.  Launder the query through an empty asm so the
-        // compiler cannot merge it with the hot loop above (it otherwise if-converts this block and
-        // executes the 16 compares + mask building for EVERY leaf).
-        float ax = qx[q], ay = qy[q], az = qz[q];
-        asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az));
-        const v2f rx2 = {ax, ax}, ry2 = {ay, ay}, rz2 = {az, az};
+      tie[q] = imp ? false : (tie[q] || eq);
+      best[q] = imp ? m[q] : best[q];
+      bestpos[q] = imp ? first : bestpos[q];
+      unres[q] = unres[q] || imp;
+    }
+  }
+  // Lane-sparse evaluation (traverse(): SPARSE): every lane gathers ITS OWN pending leaf (NO_INDEX =
+  // nothing pending) from the SoA copy and evaluates its 16 candidates -- a lane only pays for the
+  // leaves its own bound could not exclude instead of for the union over the wave's 64 queries.
+  static constexpr bool LANE_SPARSE = (Q == 1);
+  __device__ __forceinline__ void leaf_lane(const IndexView& ix, uint32_t leaf_id, const float* qx, const float* qy,
+                                            const float* qz) {
+    if (leaf_id != NO_INDEX) {
+      const float4* s = reinterpret_cast<const float4*>(ix.soa + size_t(leaf_id) * LEAF_FLOATS);
+      const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
+      float m = __builtin_inff();
+#pragma unroll
+      for (int c4 = 0; c4 < LEAF / 4; ++c4) {
+        const float4 X = s[c4], Y = s[LEAF / 4 + c4], Z = s[2 * (LEAF / 4) + c4];
+        {
+          const v2f dx = qx2 - v2f{X.x, X.y}, dy = qy2 - v2f{Y.x, Y.y}, dz = qz2 - v2f{Z.x, Z.y};
+          v2f r = dx * dx;
+          r = r + dy * dy;
+          r = r + dz * dz;
+          m = __builtin_fminf(m, __builtin_fminf(r.x, r.y));
+        }
+        {
+          const v2f dx = qx2 - v2f{X.z, X.w}, dy = qy2 - v2f{Y.z, Y.w}, dz = qz2 - v2f{Z.z, Z.w};
+          v2f r = dx * dx;
+          r = r + dy * dy;
+          r = r + dz * dz;
+          m = __builtin_fminf(m, __builtin_fminf(r.x, r.y));
+        }
+      }
+      const bool imp = m < best[0];
+      const bool eq = (m == best[0]) && (bestpos[0] != NO_INDEX) && (bestpos[0] / LEAF != leaf_id);
+      tie[0] = imp ? false : (tie[0] || eq);
+      best[0] = imp ? m : best[0];
+      bestpos[0] = imp ? leaf_id * LEAF : bestpos[0];
+      unres[0] = unres[0] || imp;
+    }
+  }
+  // after the traversal: find the winning slot inside the winning leaf (same arithmetic, same bits)
+  __device__ __forceinline__ void resolve(const IndexView& ix, const float* qx, const float* qy, const float* qz) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (__builtin_amdgcn_ballot_w64(unres[q]) == 0) continue;
+      if (unres[q]) {
+        const float4* s = reinterpret_cast<const float4*>(ix.soa + size_t(bestpos[q] / LEAF) * LEAF_FLOATS);
         uint32_t hit = 0;
 #pragma unroll
-        for (int j = 0; j < LEAF / 2; ++j) {
-          const v2f r = pair_dist(l, j, rx2, ry2, rz2);
-          hit |= (r.x == m[q] ? 1u : 0u) << (2 * j);
-          hit |= (r.y == m[q] ? 1u : 0u) << (2 * j + 1);
+        for (int c4 = 0; c4 < LEAF / 4; ++c4) {
+          const float4 X = s[c4], Y = s[LEAF / 4 + c4], Z = s[2 * (LEAF / 4) + c4];
+          hit |= (l2_simple(qx[q], qy[q], qz[q], X.x, Y.x, Z.x) == best[q] ? 1u : 0u) << (4 * c4);
+          hit |= (l2_simple(qx[q], qy[q], qz[q], X.y, Y.y, Z.y) == best[q] ? 1u : 0u) << (4 * c4 + 1);
+          hit |= (l2_simple(qx[q], qy[q], qz[q], X.z, Y.z, Z.z) == best[q] ? 1u : 0u) << (4 * c4 + 2);
+          hit |= (l2_simple(qx[q], qy[q], qz[q], X.w, Y.w, Z.w) == best[q] ? 1u : 0u) << (4 * c4 + 3);
         }
-        if (imp) {
-          best[q] = m[q];
-          bestpos[q] = leaf_id * LEAF + uint32_t(__builtin_ctz(hit));
-          tie[q] = (hit & (hit - 1u)) != 0u;  // two slots of this leaf share the minimum: index tie
-        }
+        // hit == 0 cannot happen (identical operations); if it ever did, the exact policy takes over
+        tie[q] = tie[q] || hit == 0u || (hit & (hit - 1u)) != 0u;
+        bestpos[q] = hit ? (bestpos[q] / LEAF) * LEAF + uint32_t(__builtin_ctz(hit)) : NO_INDEX;
+        unres[q] = false;
       }
     }
   }
@@ -368,6 +418,12 @@ struct TraverseStats {
   uint32_t c[5] = {0, 0, 0, 0, 0};
 };
 
+// does the policy offer the lane-sparse leaf evaluation?
+template <class P, class = void>
+struct lane_sparse_of { static constexpr bool value = false; };
+template <class P>
+struct lane_sparse_of<P, decltype(void(P::LANE_SPARSE))> { static constexpr bool value = P::LANE_SPARSE; };
+
 // ---- the traversal --------------------------------------------------------------------------------
 // `wl` is this wave's LDS working set.  Must be called by all 64 lanes.
 // Per-block LDS copy of the boxes of the top tree levels (IndexView::topcache): filled once per block.
@@ -385,11 +441,39 @@ __device__ __forceinline__ float lane_worst(const Policy& pol, const bool* valid
   return w;
 }
 
+// Child-box rows of the two lowest tree levels along the ancestors of a hint leaf (e.g. the leaf of
+// a query's previous match), fetched ahead of the traversal: when the descent reaches those nodes
+// their boxes are already in registers, so the dependent chain "level-2 row -> leaf-box row -> leaf
+// data" pays one memory latency instead of three.  Purely a latency device: a wrong hint costs nothing
+// but the two loads.
+struct RowHint {
+  uint32_t node[2];     // parent node whose children were fetched: [0] children are leaves, [1] level 2
+  float4 lo[2], hi[2];  // lane j holds child box j
+  __device__ __forceinline__ void fetch(const IndexView& ix, uint32_t leaf) {  // leaf: wave-uniform
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int cl = c + 1;
+      node[c] = NO_INDEX;
+      lo[c] = hi[c] = make_float4(0, 0, 0, 0);
+      if (leaf != NO_INDEX && cl < ix.cache_from && cl <= ix.top) {
+        const uint32_t nd = leaf >> (6 * cl);
+        node[c] = nd;
+        if (nd * FANOUT + lane < ix.count[cl]) {
+          const Box b = ix.box[cl][nd * FANOUT + lane];
+          lo[c] = b.lo;
+          hi[c] = b.hi;
+        }
+      }
+    }
+  }
+};
+
 // qx/qy/qz/valid: Policy::QPL queries per lane (the wave owns 64*QPL spatially compact queries).
-template <class Policy>
+template <class Policy, bool SPARSE = false>
 __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, const float* qy, const float* qz,
                                          const bool* valid, Policy& pol, WaveLds& wl, const Box* topbox,
-                                         TraverseStats& ts) {
+                                         TraverseStats& ts, const RowHint* hint = nullptr) {
   constexpr int QPL = Policy::QPL;
   const int lane = threadIdx.x & (WAVE - 1);
   bool any_valid = false;
@@ -453,6 +537,16 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         lx = b.lo.x; ly = b.lo.y; lz = b.lo.z;
         hx = b.hi.x; hy = b.hi.y; hz = b.hi.z;
       }
+    } else if (hint != nullptr && cl == 1u && hint->node[0] == node) {  // prefetched rows (wave-uniform tests)
+      if (has) {
+        lx = hint->lo[0].x; ly = hint->lo[0].y; lz = hint->lo[0].z;
+        hx = hint->hi[0].x; hy = hint->hi[0].y; hz = hint->hi[0].z;
+      }
+    } else if (hint != nullptr && cl == 2u && hint->node[1] == node) {
+      if (has) {
+        lx = hint->lo[1].x; ly = hint->lo[1].y; lz = hint->lo[1].z;
+        hx = hint->hi[1].x; hy = hint->hi[1].y; hz = hint->hi[1].z;
+      }
     } else if (has) {
       const Box b = level_box[first + lane];
       lx = b.lo.x; ly = b.lo.y; lz = b.lo.z;
@@ -484,6 +578,73 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         wl.list[2 * rank + 1] = make_float4(hx, hy, hz, lbG);
       }
       __builtin_amdgcn_wave_barrier();
+      if constexpr (SPARSE) {
+        static_assert(QPL == 1 && lane_sparse_of<Policy>::value, "lane-sparse evaluation: one query per lane");
+        // Lane-sparse evaluation: a lane only gathers and evaluates the leaves ITS OWN bound cannot
+        // exclude, instead of every leaf some lane of the wave needs.
+        const auto round = [&](uint32_t id) {
+          const uint64_t act = __builtin_amdgcn_ballot_w64(id != NO_INDEX);
+          if (act == 0) return;
+          ++ts.c[2];
+#ifdef PCLHIP_STATS_LANES
+          ts.c[3] += uint32_t(__builtin_popcountll(act));
+#endif
+          pol.leaf_lane(ix, id, qx, qy, qz);
+        };
+        const float before = pol.worst(0);
+        if (ordered && T * c_sparse_cold > gdiag2) {
+          // Loose bounds (first ICP iterations): walk the sorted list; every lane keeps at most one
+          // pending leaf and a round runs when some lane would need a second one, so bounds tighten as
+          // early as possible and the tail of the list is cut off by the shrinking wave radius.
+          uint32_t pend = NO_INDEX;
+          for (uint32_t t = 0; t < n_alive; ++t) {
+            const float4 ea = wl.list[2 * t], eb = wl.list[2 * t + 1];  // broadcast reads
+            if (uniform_f32(eb.w) > T) break;  // sorted: every remaining leaf is farther than the wave radius
+            ++ts.c[1];
+            const float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
+            bool need = valid[0] && !(lb > pol.worst(0));
+            if (__builtin_amdgcn_ballot_w64(need && pend != NO_INDEX) != 0) {
+              const float b0 = pol.worst(0);
+              round(pend);
+              pend = NO_INDEX;
+              const float now = pol.worst(0);
+              if (__builtin_amdgcn_ballot_w64(valid[0] && now < b0) != 0) T = wave_max_f(valid[0] ? now : 0.0f);
+              need = need && !(lb > now);
+            }
+            if (need) pend = __float_as_uint(ea.w);
+          }
+          round(pend);
+        } else {
+          // Tight bounds (seeded iterations): one branch-free scan builds a per-lane bit mask of the
+          // leaves the lane's bound cannot exclude (the box tests pipeline freely), then every lane pops
+          // its leaves in rounds.  Rounds per node ~ max over lanes of the leaves a lane really needs
+          // (1-2), not the union over the wave's 64 queries.
+          ts.c[1] += n_alive;
+          for (uint32_t c0 = 0; c0 < n_alive; c0 += 32u) {
+            const uint32_t ce = (n_alive - c0) < 32u ? (n_alive - c0) : 32u;
+            uint32_t mask = 0;
+            for (uint32_t t = 0; t < ce; ++t) {
+              const float4 ea = wl.list[2 * (c0 + t)], eb = wl.list[2 * (c0 + t) + 1];  // broadcast reads
+              const float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
+              mask |= (!(lb > pol.worst(0)) ? 1u : 0u) << t;
+            }
+            if (!valid[0]) mask = 0;
+            while (__builtin_amdgcn_ballot_w64(mask != 0) != 0) {
+              uint32_t id = NO_INDEX;
+              if (mask != 0) {
+                id = __float_as_uint(wl.list[2 * (c0 + uint32_t(__builtin_ctz(mask)))].w);
+                mask &= mask - 1u;
+              }
+              round(id);
+            }
+          }
+        }
+        {
+          const float after = pol.worst(0);
+          if (__builtin_amdgcn_ballot_w64(valid[0] && after < before) != 0) T = wave_max_f(valid[0] ? after : 0.0f);
+        }
+        continue;
+      }
       bool cut = false;
       for (uint32_t b0 = 0; b0 < n_alive && !cut; b0 += LEAF_BATCH) {
         const uint32_t nb = (n_alive - b0) < uint32_t(LEAF_BATCH) ? (n_alive - b0) : uint32_t(LEAF_BATCH);
@@ -556,7 +717,9 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         stack[at] = make_uint2((cl << 28) | (first + uint32_t(lane)), __float_as_uint(lbG));
       }
       sp += __builtin_popcountll(others);
+#ifndef PCLHIP_STATS_LANES
       ts.c[3] += uint32_t(__builtin_popcountll(others));
+#endif
       __builtin_amdgcn_wave_barrier();
       level = cl;
       node = first + uint32_t(jn);

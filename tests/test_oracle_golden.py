@@ -258,3 +258,16 @@ def test_radius_search_sac_plane_golden():
     off, idx, d2 = rej.radius_search_bruteforce(cloud, cloud, float(z["radius"]))
     assert np.array_equal(off.astype(np.int64), z["offsets"])
     assert np.array_equal(idx, z["indices"])
+
+
+def test_fitness_score_known_answer():
+    # test/registration/test_registration.cpp:198-229: (0 + 0 + 0 + 0.25) / 4 = 0.0625
+    src = np.asarray([(0, 0, 0), (0, 1, 0), (0, 0, 1), (10, 0, 0)], np.float32)
+    tgt = np.asarray([(0, 0, 0), (0, 1, 0), (0, 0, 1), (10, 0, 0.5)], np.float32)
+    tree = orc.KdTree(tgt)
+    score, nr = tree.fitness_score(src, np.eye(4, dtype=np.float32), 1.0)
+    assert abs(score - 0.0625) < 1e-4 and nr == 4
+    score, nr = tree.fitness_score(src, np.eye(4, dtype=np.float32), 0.2)
+    assert score == 0.0 and nr == 3
+    score, nr = tree.fitness_score(src, np.eye(4, dtype=np.float32), -1.0)
+    assert score == np.finfo(np.float64).max and nr == 0
