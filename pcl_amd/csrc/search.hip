@@ -622,7 +622,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_iterate_kernel(IndexView ix, 
       const bool redo[1] = {valid && (fast.tie[0] || (fast.bestpos[0] == NO_INDEX && !use_max))};
       if (__builtin_amdgcn_ballot_w64(redo[0]) != 0) {  // exact (distance, index) policy for tie lanes
         NN1 ex = pol;
-        traverse(ix, qx, qy, qz, redo, ex, wl_s[wave], topbox_s, ts);
+        traverse<NN1, true>(ix, qx, qy, qz, redo, ex, wl_s[wave], topbox_s, ts);
         if (redo[0]) pol = ex;
       }
     }
@@ -716,7 +716,6 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
                                                                  float* __restrict__ match_d2,
                                                                  unsigned long long* gstats) {
   const int use_max = flags & 1;        // a finite max correspondence distance is set
-  const bool use_hint = (flags & 2) != 0;  // prefetch the box rows along the seeds' ancestors
   __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
   load_top_cache(ix, topbox_s);
@@ -744,17 +743,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
       if (sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
     }
   }
-  static_assert(LEAF == 16, "seed position -> leaf");
-  // box rows along the ancestors of one seed of the group: in flight before the traversal needs them
-  const auto hint_leaf = [&](const uint32_t* sp) -> uint32_t {
-    const uint64_t hm = __builtin_amdgcn_ballot_w64(sp[0] != NO_INDEX);
-    if (hm == 0) return NO_INDEX;
-    return uint32_t(__builtin_amdgcn_readlane(int(sp[0]), __builtin_ctzll(hm))) / LEAF;
-  };
-  RowHint hint_n;
-  hint_n.fetch(ix, use_hint ? hint_leaf(sp_n) : NO_INDEX);
   while (g < ngroups) {
-    const RowHint hint = hint_n;
     float4 p[Q], t0[Q];
     uint32_t seed_pos[Q];
     bool in_range[Q], valid[Q];
@@ -797,7 +786,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
       }
       qx[q] = p[q].x; qy[q] = p[q].y; qz[q] = p[q].z;
     }
-    traverse<NN1MinT<Q>, SPARSE>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, &hint);
+    traverse<NN1MinT<Q>, SPARSE>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts);
     fast.resolve(ix, qx, qy, qz);
     // ... and their seed target points as soon as the seed positions have arrived
 #pragma unroll
@@ -805,7 +794,6 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
       t_n[q] = make_float4(0, 0, 0, 0);
       if (next_ok[q] && sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
     }
-    hint_n.fetch(ix, use_hint ? hint_leaf(sp_n) : NO_INDEX);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       NN1 pol;
@@ -819,7 +807,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
       if (__builtin_amdgcn_ballot_w64(redo[0]) != 0) {  // exact (distance, index) policy for tie lanes
         NN1 ex = pol;
         const float ex_x[1] = {qx[q]}, ex_y[1] = {qy[q]}, ex_z[1] = {qz[q]};
-        traverse(ix, ex_x, ex_y, ex_z, redo, ex, wl_s[wave], topbox_s, ts);
+        traverse<NN1, SPARSE>(ix, ex_x, ex_y, ex_z, redo, ex, wl_s[wave], topbox_s, ts);
         if (redo[0]) pol = ex;
       }
       const uint32_t mid = key_index(pol.key);
@@ -968,26 +956,13 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
       const char* e = getenv("PCLHIP_ICP_SPARSE");
       return (e && atoi(e) == 0) ? 0 : 1;
     }();
-    static const int hint = [] {
-      const char* e = getenv("PCLHIP_ICP_HINT");
-      return (e && atoi(e) == 0) ? 0 : 2;
-    }();
-    static const bool cold_set = [] {
-      const char* e = getenv("PCLHIP_SPARSE_COLD");
-      if (e) {
-        const float f = float(atof(e));
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(c_sparse_cold), &f, sizeof(float));
-      }
-      return e != nullptr;
-    }();
-    (void)cold_set;
     auto ks = (qpl == 2) ? icp_search_kernel<4, 2, false>
                          : (sparse ? icp_search_kernel<4, 1, true> : icp_search_kernel<4, 1, false>);
     const uint32_t ngroups_s = (icp->n + WAVE * qpl - 1) / (WAVE * qpl);
     const int gs = resident_blocks(ctx, ks, ngroups_s);
     (void)hipEventRecord(icp->ev0, s);
     hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound,
-                       (use_max ? 1 : 0) | hint, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+                       (use_max ? 1 : 0), icp->match_pos, icp->match, icp->match_d2, ctx->stats);
     (void)hipEventRecord(icp->ev_mid, s);
     icp->mid_recorded = true;
     const uint8_t* keep = nullptr;
@@ -1081,7 +1056,7 @@ pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double ma
   const uint32_t ngroups = (n + WAVE - 1) / WAVE;
   const int gs = resident_blocks(ctx, icp_search_kernel<4, 1, true>, ngroups);
   // transformPointCloud(cloud, out, Matrix4) is Transformer::se3 (transforms.hpp:109-123): order 1
-  hipLaunchKernelGGL((icp_search_kernel<4, 1, true>), dim3(gs), dim3(BLOCK), 0, s, v, cur, n, M, 1, __builtin_inff(), 2, pos,
+  hipLaunchKernelGGL((icp_search_kernel<4, 1, true>), dim3(gs), dim3(BLOCK), 0, s, v, cur, n, M, 1, __builtin_inff(), 0, pos,
                      id, d2, ctx->stats);
   hipLaunchKernelGGL(fitness_partial_kernel, dim3(gr), dim3(BLOCK), 0, s, d2, n, max_range, part);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());

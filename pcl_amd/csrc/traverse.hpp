@@ -23,10 +23,6 @@
 
 namespace pclhip {
 
-// tuning knob (A/B only, PCLHIP_SPARSE_COLD): a leaf-level node is walked with the "loose bounds" scheme
-// while T * c_sparse_cold > (diagonal of the query group)^2
-static __constant__ float c_sparse_cold = 16.0f;
-
 constexpr int STACK_ENTRIES = 192;     // <= 63 siblings per interior level below the root scan, <= 3 such levels
 constexpr int LEAF_BATCH = 16;         // leaves staged in LDS at a time (16 x 256 B = 4 KB)
 constexpr int LEAF_FLOATS = 4 * LEAF;  // x[16] y[16] z[16] w[16]
@@ -157,6 +153,30 @@ struct NN1 {
       pos = t ? base + c : pos;
     }
   }
+  // lane-sparse evaluation from the transposed LDS staging buffer (see traverse(): SPARSE)
+  static constexpr bool LANE_SPARSE = true;
+  static constexpr bool NEEDS_W = true;
+  __device__ __forceinline__ void leaf_lane(const float* buf, uint32_t slot, uint32_t leaf_id, const float* qx,
+                                            const float* qy, const float* qz) {
+    if (leaf_id != NO_INDEX) {
+      const float4* s = reinterpret_cast<const float4*>(buf) + slot;  // chunk c at s[c * 16]
+      const uint32_t base = leaf_id * LEAF;
+#pragma unroll
+      for (int c4 = 0; c4 < LEAF / 4; ++c4) {
+        const float4 X = s[c4 * 16], Y = s[(4 + c4) * 16], Z = s[(8 + c4) * 16], W = s[(12 + c4) * 16];
+        const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w},
+                    ws[4] = {W.x, W.y, W.z, W.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = l2_simple(qx[0], qy[0], qz[0], xs[j], ys[j], zs[j]);
+          const uint64_t k = make_key(d, __float_as_uint(ws[j]));
+          const bool t = k < key;
+          key = t ? k : key;
+          pos = t ? base + uint32_t(4 * c4 + j) : pos;
+        }
+      }
+    }
+  }
 };
 
 // 1-NN fast path: the hot loop only tracks the minimum DISTANCE (packed v_pk_* math on candidate
@@ -221,19 +241,20 @@ struct NN1MinT {
       unres[q] = unres[q] || imp;
     }
   }
-  // Lane-sparse evaluation (traverse(): SPARSE): every lane gathers ITS OWN pending leaf (NO_INDEX =
-  // nothing pending) from the SoA copy and evaluates its 16 candidates -- a lane only pays for the
-  // leaves its own bound could not exclude instead of for the union over the wave's 64 queries.
+  // Lane-sparse evaluation (traverse(): SPARSE): every lane evaluates ITS OWN leaf (id NO_INDEX = none),
+  // staged in batch slot `slot` of the transposed LDS buffer -- a lane only pays for the leaves its own
+  // bound could not exclude instead of for the union over the wave's 64 queries.
   static constexpr bool LANE_SPARSE = (Q == 1);
-  __device__ __forceinline__ void leaf_lane(const IndexView& ix, uint32_t leaf_id, const float* qx, const float* qy,
-                                            const float* qz) {
+  static constexpr bool NEEDS_W = false;
+  __device__ __forceinline__ void leaf_lane(const float* buf, uint32_t slot, uint32_t leaf_id, const float* qx,
+                                            const float* qy, const float* qz) {
     if (leaf_id != NO_INDEX) {
-      const float4* s = reinterpret_cast<const float4*>(ix.soa + size_t(leaf_id) * LEAF_FLOATS);
+      const float4* s = reinterpret_cast<const float4*>(buf) + slot;  // chunk c at s[c * 16]
       const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
       float m = __builtin_inff();
 #pragma unroll
       for (int c4 = 0; c4 < LEAF / 4; ++c4) {
-        const float4 X = s[c4], Y = s[LEAF / 4 + c4], Z = s[2 * (LEAF / 4) + c4];
+        const float4 X = s[c4 * 16], Y = s[(LEAF / 4 + c4) * 16], Z = s[(2 * (LEAF / 4) + c4) * 16];
         {
           const v2f dx = qx2 - v2f{X.x, X.y}, dy = qy2 - v2f{Y.x, Y.y}, dz = qz2 - v2f{Z.x, Z.y};
           v2f r = dx * dx;
@@ -441,39 +462,11 @@ __device__ __forceinline__ float lane_worst(const Policy& pol, const bool* valid
   return w;
 }
 
-// Child-box rows of the two lowest tree levels along the ancestors of a hint leaf (e.g. the leaf of
-// a query's previous match), fetched ahead of the traversal: when the descent reaches those nodes
-// their boxes are already in registers, so the dependent chain "level-2 row -> leaf-box row -> leaf
-// data" pays one memory latency instead of three.  Purely a latency device: a wrong hint costs nothing
-// but the two loads.
-struct RowHint {
-  uint32_t node[2];     // parent node whose children were fetched: [0] children are leaves, [1] level 2
-  float4 lo[2], hi[2];  // lane j holds child box j
-  __device__ __forceinline__ void fetch(const IndexView& ix, uint32_t leaf) {  // leaf: wave-uniform
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int cl = c + 1;
-      node[c] = NO_INDEX;
-      lo[c] = hi[c] = make_float4(0, 0, 0, 0);
-      if (leaf != NO_INDEX && cl < ix.cache_from && cl <= ix.top) {
-        const uint32_t nd = leaf >> (6 * cl);
-        node[c] = nd;
-        if (nd * FANOUT + lane < ix.count[cl]) {
-          const Box b = ix.box[cl][nd * FANOUT + lane];
-          lo[c] = b.lo;
-          hi[c] = b.hi;
-        }
-      }
-    }
-  }
-};
-
 // qx/qy/qz/valid: Policy::QPL queries per lane (the wave owns 64*QPL spatially compact queries).
 template <class Policy, bool SPARSE = false>
 __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, const float* qy, const float* qz,
                                          const bool* valid, Policy& pol, WaveLds& wl, const Box* topbox,
-                                         TraverseStats& ts, const RowHint* hint = nullptr) {
+                                         TraverseStats& ts) {
   constexpr int QPL = Policy::QPL;
   const int lane = threadIdx.x & (WAVE - 1);
   bool any_valid = false;
@@ -537,16 +530,6 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         lx = b.lo.x; ly = b.lo.y; lz = b.lo.z;
         hx = b.hi.x; hy = b.hi.y; hz = b.hi.z;
       }
-    } else if (hint != nullptr && cl == 1u && hint->node[0] == node) {  // prefetched rows (wave-uniform tests)
-      if (has) {
-        lx = hint->lo[0].x; ly = hint->lo[0].y; lz = hint->lo[0].z;
-        hx = hint->hi[0].x; hy = hint->hi[0].y; hz = hint->hi[0].z;
-      }
-    } else if (hint != nullptr && cl == 2u && hint->node[1] == node) {
-      if (has) {
-        lx = hint->lo[1].x; ly = hint->lo[1].y; lz = hint->lo[1].z;
-        hx = hint->hi[1].x; hy = hint->hi[1].y; hz = hint->hi[1].z;
-      }
     } else if (has) {
       const Box b = level_box[first + lane];
       lx = b.lo.x; ly = b.lo.y; lz = b.lo.z;
@@ -580,71 +563,116 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
       __builtin_amdgcn_wave_barrier();
       if constexpr (SPARSE) {
         static_assert(QPL == 1 && lane_sparse_of<Policy>::value, "lane-sparse evaluation: one query per lane");
-        // Lane-sparse evaluation: a lane only gathers and evaluates the leaves ITS OWN bound cannot
-        // exclude, instead of every leaf some lane of the wave needs.
-        const auto round = [&](uint32_t id) {
+        // Lane-sparse evaluation: a lane only evaluates the leaves ITS OWN bound cannot exclude.
+        // The listed leaves are staged in LDS 16 at a time with the LDS-DMA path, TRANSPOSED: chunk c
+        // (16 bytes) of the leaf in batch slot s lands at ((c * 16 + s) * 16) bytes, so lanes that read
+        // the same chunk of different leaves hit different banks.  The DMA runs under the box tests.
+        constexpr int NCHUNK = Policy::NEEDS_W ? 16 : 12;  // x[16] y[16] z[16] (+ w[16]) in 16-byte chunks
+        const auto round = [&](uint32_t slot, uint32_t id) {
           const uint64_t act = __builtin_amdgcn_ballot_w64(id != NO_INDEX);
           if (act == 0) return;
           ++ts.c[2];
 #ifdef PCLHIP_STATS_LANES
           ts.c[3] += uint32_t(__builtin_popcountll(act));
 #endif
-          pol.leaf_lane(ix, id, qx, qy, qz);
+          pol.leaf_lane(wl.buf, slot, id, qx, qy, qz);
         };
         const float before = pol.worst(0);
-        if (ordered && T * c_sparse_cold > gdiag2) {
-          // Loose bounds (first ICP iterations): walk the sorted list; every lane keeps at most one
-          // pending leaf and a round runs when some lane would need a second one, so bounds tighten as
-          // early as possible and the tail of the list is cut off by the shrinking wave radius.
-          uint32_t pend = NO_INDEX;
-          for (uint32_t t = 0; t < n_alive; ++t) {
-            const float4 ea = wl.list[2 * t], eb = wl.list[2 * t + 1];  // broadcast reads
-            if (uniform_f32(eb.w) > T) break;  // sorted: every remaining leaf is farther than the wave radius
-            ++ts.c[1];
-            const float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
-            bool need = valid[0] && !(lb > pol.worst(0));
-            if (__builtin_amdgcn_ballot_w64(need && pend != NO_INDEX) != 0) {
-              const float b0 = pol.worst(0);
-              round(pend);
-              pend = NO_INDEX;
-              const float now = pol.worst(0);
-              if (__builtin_amdgcn_ballot_w64(valid[0] && now < b0) != 0) T = wave_max_f(valid[0] ? now : 0.0f);
-              need = need && !(lb > now);
+        const bool loose = ordered;
+        bool cut = false;
+        for (uint32_t b0 = 0; b0 < n_alive && !cut; b0 += LEAF_BATCH) {
+          const uint32_t nb = (n_alive - b0) < uint32_t(LEAF_BATCH) ? (n_alive - b0) : uint32_t(LEAF_BATCH);
+          {
+            const uint32_t slot = uint32_t(lane) & 15u;
+            uint32_t leaf_id = 0;
+            if (slot < nb) leaf_id = __float_as_uint(wl.list[2 * (b0 + slot)].w);
+#pragma unroll
+            for (int i = 0; i < NCHUNK / 4; ++i) {
+              if (slot < nb) {
+                const float* src = ix.soa + size_t(leaf_id) * LEAF_FLOATS + (i * 4 + (lane >> 4)) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(wl.buf + i * (WAVE * 4)), 16,
+                                                 0, 0);
+              }
             }
-            if (need) pend = __float_as_uint(ea.w);
           }
-          round(pend);
-        } else {
-          // Tight bounds (seeded iterations): one branch-free scan builds a per-lane bit mask of the
-          // leaves the lane's bound cannot exclude (the box tests pipeline freely), then every lane pops
-          // its leaves in rounds.  Rounds per node ~ max over lanes of the leaves a lane really needs
-          // (1-2), not the union over the wave's 64 queries.
-          ts.c[1] += n_alive;
-          for (uint32_t c0 = 0; c0 < n_alive; c0 += 32u) {
-            const uint32_t ce = (n_alive - c0) < 32u ? (n_alive - c0) : 32u;
+          bool landed = false;
+          if (loose) {
+            // Loose bounds (first ICP iterations): walk the sorted batch; every lane keeps at most one
+            // pending leaf and a round runs when some lane would need a second one, so bounds tighten
+            // as early as possible and the tail of the list is cut off by the shrinking wave radius.
+            uint32_t pslot = 0, pid = NO_INDEX;
+            for (uint32_t t = 0; t < nb; ++t) {
+              const float4 ea = wl.list[2 * (b0 + t)], eb = wl.list[2 * (b0 + t) + 1];  // broadcast reads
+              if (uniform_f32(eb.w) > T) {  // sorted: every remaining leaf is farther than the wave radius
+                cut = true;
+                break;
+              }
+              ++ts.c[1];
+              const float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
+              bool need = valid[0] && !(lb > pol.worst(0));
+              if (__builtin_amdgcn_ballot_w64(need && pid != NO_INDEX) != 0) {
+                if (!landed) {
+                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                  landed = true;
+                }
+                const float w0 = pol.worst(0);
+                round(pslot, pid);
+                pid = NO_INDEX;
+                const float now = pol.worst(0);
+                if (__builtin_amdgcn_ballot_w64(valid[0] && now < w0) != 0) T = wave_max_f(valid[0] ? now : 0.0f);
+                need = need && !(lb > now);
+              }
+              if (need) {
+                pslot = t;
+                pid = __float_as_uint(ea.w);
+              }
+            }
+            if (__builtin_amdgcn_ballot_w64(pid != NO_INDEX) != 0) {
+              if (!landed) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                landed = true;
+              }
+              const float w0 = pol.worst(0);
+              round(pslot, pid);
+              const float now = pol.worst(0);
+              if (__builtin_amdgcn_ballot_w64(valid[0] && now < w0) != 0) T = wave_max_f(valid[0] ? now : 0.0f);
+            }
+          } else {
+            // Tight bounds (seeded iterations): one branch-free scan builds a per-lane bit mask of the
+            // batch's leaves the lane's bound cannot exclude (the box tests pipeline freely), then every
+            // lane pops its leaves in rounds.  Rounds per node ~ max over lanes of the leaves a lane
+            // really needs (1-2), not the union over the wave's 64 queries.
+            ts.c[1] += nb;
             uint32_t mask = 0;
-            for (uint32_t t = 0; t < ce; ++t) {
-              const float4 ea = wl.list[2 * (c0 + t)], eb = wl.list[2 * (c0 + t) + 1];  // broadcast reads
+            for (uint32_t t = 0; t < nb; ++t) {
+              const float4 ea = wl.list[2 * (b0 + t)], eb = wl.list[2 * (b0 + t) + 1];  // broadcast reads
               const float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
               mask |= (!(lb > pol.worst(0)) ? 1u : 0u) << t;
             }
             if (!valid[0]) mask = 0;
             while (__builtin_amdgcn_ballot_w64(mask != 0) != 0) {
-              uint32_t id = NO_INDEX;
+              if (!landed) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                landed = true;
+              }
+              uint32_t slot = 0, id = NO_INDEX;
               if (mask != 0) {
-                id = __float_as_uint(wl.list[2 * (c0 + uint32_t(__builtin_ctz(mask)))].w);
+                slot = uint32_t(__builtin_ctz(mask));
+                id = __float_as_uint(wl.list[2 * (b0 + slot)].w);
                 mask &= mask - 1u;
               }
-              round(id);
+              round(slot, id);
             }
           }
+          // the next batch overwrites wl.buf: make sure this batch's DMA is not still landing
+          if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         {
           const float after = pol.worst(0);
           if (__builtin_amdgcn_ballot_w64(valid[0] && after < before) != 0) T = wave_max_f(valid[0] ? after : 0.0f);
         }
-        continue;
-      }
+      } else {
       bool cut = false;
       for (uint32_t b0 = 0; b0 < n_alive && !cut; b0 += LEAF_BATCH) {
         const uint32_t nb = (n_alive - b0) < uint32_t(LEAF_BATCH) ? (n_alive - b0) : uint32_t(LEAF_BATCH);
@@ -693,6 +721,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         // the next batch overwrites wl.buf: make sure this batch's DMA is not still landing
         if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      }  // wave-uniform leaf evaluation
     } else {
       int jn;
       if ((mask & (mask - 1)) == 0) {
