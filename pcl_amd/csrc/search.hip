@@ -51,7 +51,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
     if constexpr (K == 1) {
       NN1Min fast;
       fast.init(__builtin_inff());
-      traverse(ix, qx, qy, qz, vv, fast, wl_s[threadIdx.x / WAVE], topbox_s, ts);
+      traverse<NN1Min, true>(ix, qx, qy, qz, vv, fast, wl_s[threadIdx.x / WAVE], topbox_s, ts);
       fast.resolve(ix, qx, qy, qz);
       NN1 pol;
       pol.key = KEY_NONE;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
       const bool redo[1] = {valid && (fast.tie[0] || fast.bestpos[0] == NO_INDEX)};
       if (__builtin_amdgcn_ballot_w64(redo[0]) != 0) {
         NN1 ex = pol;
-        traverse(ix, qx, qy, qz, redo, ex, wl_s[threadIdx.x / WAVE], topbox_s, ts);
+        traverse<NN1, true>(ix, qx, qy, qz, redo, ex, wl_s[threadIdx.x / WAVE], topbox_s, ts);
         if (redo[0]) pol = ex;
       }
       if (real) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
     } else {
       TopKReg<K> pol;
       pol.init(KEY_NONE);
-      traverse(ix, qx, qy, qz, vv, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
+      traverse<TopKReg<K>, true>(ix, qx, qy, qz, vv, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
       if (real) {
 #pragma unroll
         for (int c = 0; c < K; ++c) {
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
     {
       const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
       const bool vv[1] = {valid};
-      traverse(ix, qx, qy, qz, vv, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
+      traverse<TopKReg<K>, true>(ix, qx, qy, qz, vv, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
     }
     if (valid) {
       // normal_3d.hpp:59-66 + normal_3d.h:308-322: fewer than 3 neighbours -> NaN

@@ -71,29 +71,55 @@ __device__ __forceinline__ float box_box_lb(float Qlx, float Qly, float Qlz, flo
 // row_mirror leave every row of 16 lanes holding its row result; row_bcast15/31 then fold the four
 // rows into lane 63.  The result is read back with readlane so the compiler knows it is
 // wave-uniform (SGPR): every branch on it is a scalar branch.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __int_as_float(
-      __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
+// The DPP modifier is folded into the min/max itself (one VALU instruction per butterfly step; the
+// update_dpp builtin costs a copy, a v_mov_dpp, a canonicalising v_max and the min).  A DPP read of a
+// VGPR written by the previous VALU instruction needs two wait states: s_nop 1 in the single-value
+// chains, independent work in between in the 7-wide version.  Inputs are never NaN.
+#define PCLHIP_DPP_STEPS(OP)                                                                 \
+  "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"          \
+  "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"          \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"              \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                   \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                 \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                 \
+  "s_nop 1"
 __device__ __forceinline__ float wave_min_f(float v) {
-  v = fminf(v, dpp_f<0xB1, 0xf>(v));   // quad_perm [1,0,3,2]
-  v = fminf(v, dpp_f<0x4E, 0xf>(v));   // quad_perm [2,3,0,1]
-  v = fminf(v, dpp_f<0x141, 0xf>(v));  // row_half_mirror
-  v = fminf(v, dpp_f<0x140, 0xf>(v));  // row_mirror
-  v = fminf(v, dpp_f<0x142, 0xa>(v));  // row_bcast15 -> rows 1,3
-  v = fminf(v, dpp_f<0x143, 0xc>(v));  // row_bcast31 -> rows 2,3
+  asm volatile(PCLHIP_DPP_STEPS("v_min_f32_dpp") : "+v"(v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max_f(float v) {
-  v = fmaxf(v, dpp_f<0xB1, 0xf>(v));
-  v = fmaxf(v, dpp_f<0x4E, 0xf>(v));
-  v = fmaxf(v, dpp_f<0x141, 0xf>(v));
-  v = fmaxf(v, dpp_f<0x140, 0xf>(v));
-  v = fmaxf(v, dpp_f<0x142, 0xa>(v));
-  v = fmaxf(v, dpp_f<0x143, 0xc>(v));
+  asm volatile(PCLHIP_DPP_STEPS("v_max_f32_dpp") : "+v"(v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+#undef PCLHIP_DPP_STEPS
+// three minima and four maxima at once (the query group's box and the wave radius): the seven chains
+// interleave, so no wait states are needed
+#define PCLHIP_DPP_STEP7(CTRL)                              \
+  "v_min_f32_dpp %0, %0, %0 " CTRL "\n\t"                   \
+  "v_min_f32_dpp %1, %1, %1 " CTRL "\n\t"                   \
+  "v_min_f32_dpp %2, %2, %2 " CTRL "\n\t"                   \
+  "v_max_f32_dpp %3, %3, %3 " CTRL "\n\t"                   \
+  "v_max_f32_dpp %4, %4, %4 " CTRL "\n\t"                   \
+  "v_max_f32_dpp %5, %5, %5 " CTRL "\n\t"                   \
+  "v_max_f32_dpp %6, %6, %6 " CTRL "\n\t"
+__device__ __forceinline__ void wave_min3_max4(float& a0, float& a1, float& a2, float& b0, float& b1, float& b2,
+                                               float& b3) {
+  asm volatile("s_nop 1\n\t" PCLHIP_DPP_STEP7("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                   PCLHIP_DPP_STEP7("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                       PCLHIP_DPP_STEP7("row_half_mirror row_mask:0xf bank_mask:0xf")
+                           PCLHIP_DPP_STEP7("row_mirror row_mask:0xf bank_mask:0xf")
+                               PCLHIP_DPP_STEP7("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                                   PCLHIP_DPP_STEP7("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+  a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0), 63));
+  a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a1), 63));
+  a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a2), 63));
+  b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0), 63));
+  b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1), 63));
+  b2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b2), 63));
+  b3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b3), 63));
+}
+#undef PCLHIP_DPP_STEP7
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -350,6 +376,43 @@ struct TopKReg {
       }
     }
   }
+  // lane-sparse evaluation from the transposed LDS staging buffer (see traverse(): SPARSE): the lane's
+  // own leaf; a candidate goes through the insertion network only if some active lane still wants it
+  static constexpr bool LANE_SPARSE = true;
+  static constexpr bool NEEDS_W = true;
+  __device__ __forceinline__ void leaf_lane(const float* buf, uint32_t slot, uint32_t leaf_id, const float* qx,
+                                            const float* qy, const float* qz) {
+    if (leaf_id != NO_INDEX) {
+      const float4* s = reinterpret_cast<const float4*>(buf) + slot;  // chunk c at s[c * 16]
+      const uint32_t base = leaf_id * LEAF;
+      const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
+#pragma unroll
+      for (int c4 = 0; c4 < LEAF / 4; ++c4) {
+        const float4 X = s[c4 * 16], Y = s[(4 + c4) * 16], Z = s[(8 + c4) * 16], W = s[(12 + c4) * 16];
+        v2f r0, r1;
+        {
+          const v2f dx = qx2 - v2f{X.x, X.y}, dy = qy2 - v2f{Y.x, Y.y}, dz = qz2 - v2f{Z.x, Z.y};
+          r0 = dx * dx;
+          r0 = r0 + dy * dy;
+          r0 = r0 + dz * dz;
+        }
+        {
+          const v2f dx = qx2 - v2f{X.z, X.w}, dy = qy2 - v2f{Y.z, Y.w}, dz = qz2 - v2f{Z.z, Z.w};
+          r1 = dx * dx;
+          r1 = r1 + dy * dy;
+          r1 = r1 + dz * dz;
+        }
+        const float ds[4] = {r0.x, r0.y, r1.x, r1.y}, ws[4] = {W.x, W.y, W.z, W.w};
+        const float m = __builtin_fminf(__builtin_fminf(ds[0], ds[1]), __builtin_fminf(ds[2], ds[3]));
+        if (__builtin_amdgcn_ballot_w64(m <= key_dist(keys[K - 1])) == 0) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (__builtin_amdgcn_ballot_w64(ds[j] <= key_dist(keys[K - 1])) != 0)
+            insert(make_key(ds[j], __float_as_uint(ws[j])), base + uint32_t(4 * c4 + j));
+        }
+      }
+    }
+  }
 };
 
 // top-k for arbitrary k in a per-lane binary max-heap in global memory, layout heap[slot*nq + q]
@@ -485,9 +548,9 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
       hx0 = fmaxf(hx0, qx[q]); hy0 = fmaxf(hy0, qy[q]); hz0 = fmaxf(hz0, qz[q]);
     }
   }
-  const float Qlx = wave_min_f(lx0), Qly = wave_min_f(ly0), Qlz = wave_min_f(lz0);
-  const float Qhx = wave_max_f(hx0), Qhy = wave_max_f(hy0), Qhz = wave_max_f(hz0);
-  float T = wave_max_f(lane_worst(pol, valid));  // wave pruning radius (squared)
+  float T = lane_worst(pol, valid);  // wave pruning radius (squared)
+  wave_min3_max4(lx0, ly0, lz0, hx0, hy0, hz0, T);
+  const float Qlx = lx0, Qly = ly0, Qlz = lz0, Qhx = hx0, Qhy = hy0, Qhz = hz0;
   const float gdiag2 = (Qhx - Qlx) * (Qhx - Qlx) + (Qhy - Qly) * (Qhy - Qly) + (Qhz - Qlz) * (Qhz - Qlz);
   uint2* const stack = wl.stack;
 
