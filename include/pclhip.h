@@ -124,13 +124,18 @@ PCLHIP_API pclhip_status pclhip_index_set_normals(pclhip_index* index, const voi
 
 /* ---- ICP --------------------------------------------------------------------------------------*/
 enum { PCLHIP_ICP_POINT_TO_POINT = 0, /* TransformationEstimationSVD, icp.h:149-151 */
-       PCLHIP_ICP_POINT_TO_PLANE = 1  /* TransformationEstimationPointToPlaneLLS, icp.h:395-398 */ };
+       PCLHIP_ICP_POINT_TO_PLANE = 1, /* TransformationEstimationPointToPlaneLLS, icp.h:395-398 */
+       PCLHIP_ICP_SYMMETRIC = 2       /* TransformationEstimationSymmetricPointToPlaneLLS,
+                                         IterativeClosestPointWithNormals::setUseSymmetricObjective, icp.h:380-400;
+                                         needs source normals too (pclhip_icp_set_source_normals) */ };
 
 /* number of doubles in the per-iteration reduction record */
 #define PCLHIP_ICP_NSUMS 32
 /* layout of sums[]:
  *   point-to-plane: [0..20] upper triangle of ATA (row-major, order of impl/
  *                   transformation_estimation_point_to_plane_lls.hpp:213-233), [21..26] ATb
+ *   symmetric:      same slots, for v = [(p+q) x n ; n] and rhs v ((q-p).n)
+ *                   (impl/transformation_estimation_symmetric_point_to_plane_lls.hpp:161-190)
  *   point-to-point: [0..2] sum s, [3..5] sum t, [6..14] sum t_i*s_j (row-major), rest 0
  *   [27] sum of squared correspondence distances, [28] number of correspondences,
  *   [29] number of pairs skipped for non-finite normals, [30..31] reserved */
@@ -174,6 +179,12 @@ PCLHIP_API void pclhip_icp_destroy(pclhip_icp* icp);
 /* Registration::setInputSource (registration.h:195-196): uploads + Morton-orders the source. */
 PCLHIP_API pclhip_status pclhip_icp_set_source(pclhip_icp* icp, const void* points,
                                                size_t stride_bytes, uint64_t n);
+/* Normals of the source cloud, one record per source point in the order given to
+ * pclhip_icp_set_source (a pcl::PointNormal source: normals = points + 16, stride 48).  Required by
+ * PCLHIP_ICP_SYMMETRIC; call after pclhip_icp_set_source. */
+PCLHIP_API pclhip_status pclhip_icp_set_source_normals(pclhip_icp* icp, const void* normals, size_t stride_bytes);
+/* setEnforceSameDirectionNormals (icp.h:416-428), default 1 */
+PCLHIP_API pclhip_status pclhip_icp_set_enforce_same_direction_normals(pclhip_icp* icp, int enforce);
 PCLHIP_API pclhip_status pclhip_icp_set_allreduce(pclhip_icp* icp, pclhip_allreduce_fn fn, void* user);
 /* Rewind the working copy of the source to the input cloud (start of computeTransformation). */
 PCLHIP_API pclhip_status pclhip_icp_reset(pclhip_icp* icp);
@@ -248,6 +259,16 @@ PCLHIP_API pclhip_status pclhip_icp_fitness_score(pclhip_icp* icp, const float T
 PCLHIP_API pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_query,
                                                           int32_t* index_match, float* distance,
                                                           uint64_t* out_n);
+
+/* TransformationEstimation::estimateRigidTransformation(cloud_src, cloud_tgt, T)
+ * (registration/include/pcl/registration/transformation_estimation.h:71-115) for n explicit pairs
+ * (src[i], tgt[i]); `mode` selects TransformationEstimationSVD / PointToPlaneLLS (target normals) /
+ * SymmetricPointToPlaneLLS (both normals).  Buffers host or device; normals may be NULL when the mode
+ * does not use them.  T: row-major 4x4; sums (may be NULL): the PCLHIP_ICP_NSUMS reduction record. */
+PCLHIP_API pclhip_status pclhip_estimate_rigid_transformation(
+    pclhip_ctx* ctx, int mode, const void* src, size_t src_stride, const void* src_normals,
+    size_t src_normals_stride, const void* tgt, size_t tgt_stride, const void* tgt_normals,
+    size_t tgt_normals_stride, uint64_t n, int enforce_same_direction_normals, float T[16], double* sums);
 
 /* out = T * in for n records (x,y,z at byte 0; other bytes of the record untouched);
  * order 0: Eigen Matrix4f*Vector4f order (icp.hpp:49-111); order 1: Transformer::se3 order

@@ -367,6 +367,15 @@ class IterativeClosestPoint {
   void addCorrespondenceRejector(const registration::CorrespondenceRejector::Ptr& r) { rejectors_.push_back(r); filters_dirty_ = true; }
   void clearCorrespondenceRejectors() { rejectors_.clear(); filters_dirty_ = true; }
   void setUseReciprocalCorrespondences(bool on) { reciprocal_ = on; filters_dirty_ = true; }
+  // IterativeClosestPointWithNormals::setUseSymmetricObjective / setEnforceSameDirectionNormals
+  // (icp.h:380-428): TransformationEstimationSymmetricPointToPlaneLLS; source AND target need normals
+  void setUseSymmetricObjective(bool on) {
+    static_assert(MODE == PCLHIP_ICP_POINT_TO_PLANE, "only IterativeClosestPointWithNormals has this option");
+    p_.mode = on ? PCLHIP_ICP_SYMMETRIC : PCLHIP_ICP_POINT_TO_PLANE;
+  }
+  bool getUseSymmetricObjective() const { return p_.mode == PCLHIP_ICP_SYMMETRIC; }
+  void setEnforceSameDirectionNormals(bool on) { enforce_same_direction_ = on; filters_dirty_ = true; }
+  bool getEnforceSameDirectionNormals() const { return enforce_same_direction_; }
   int getMaximumIterations() const { return p_.max_iterations; }
   double getMaxCorrespondenceDistance() const { return p_.max_correspondence_distance; }
 
@@ -422,6 +431,10 @@ class IterativeClosestPoint {
     if (!icp_ && pclhip_icp_create(tree_->handle(), &icp_) != PCLHIP_OK) return false;
     if (source_dirty_) {
       if (pclhip_icp_set_source(icp_, source_->points.data(), sizeof(PointSource), source_->size()) != PCLHIP_OK) return false;
+      if (MODE == PCLHIP_ICP_POINT_TO_PLANE && sizeof(PointSource) >= 28) {  // pcl::PointNormal source
+        const char* base = reinterpret_cast<const char*>(source_->points.data());
+        if (pclhip_icp_set_source_normals(icp_, base + 16, sizeof(PointSource)) != PCLHIP_OK) return false;
+      }
       source_dirty_ = false;
       filters_dirty_ = true;
     }
@@ -430,6 +443,7 @@ class IterativeClosestPoint {
       for (const auto& r : rejectors_) list.push_back(r->desc);
       if (pclhip_icp_set_rejectors(icp_, list.data(), int(list.size())) != PCLHIP_OK) return false;
       if (pclhip_icp_set_reciprocal(icp_, reciprocal_ ? 1 : 0) != PCLHIP_OK) return false;
+      if (pclhip_icp_set_enforce_same_direction_normals(icp_, enforce_same_direction_ ? 1 : 0) != PCLHIP_OK) return false;
       filters_dirty_ = false;
     }
     return true;
@@ -441,7 +455,7 @@ class IterativeClosestPoint {
   typename PointCloudTarget::ConstPtr target_;
   typename search::KdTree<PointTarget>::Ptr tree_;
   bool force_no_recompute_ = false, target_dirty_ = true, source_dirty_ = true, filters_dirty_ = true;
-  bool reciprocal_ = false;
+  bool reciprocal_ = false, enforce_same_direction_ = true;
   std::vector<registration::CorrespondenceRejector::Ptr> rejectors_;
   Matrix4f final_;
   bool converged_ = false;
@@ -451,6 +465,35 @@ class IterativeClosestPoint {
 
 template <typename PointSource, typename PointTarget>
 using IterativeClosestPointWithNormals = IterativeClosestPoint<PointSource, PointTarget, PCLHIP_ICP_POINT_TO_PLANE>;
+
+namespace registration {
+// TransformationEstimationSVD / PointToPlaneLLS / SymmetricPointToPlaneLLS::estimateRigidTransformation
+// (cloud_src, cloud_tgt, T): pair i = (src[i], tgt[i]) (transformation_estimation.h:71-115).  Normals are
+// read from the PointNormal layout (+16 bytes).
+template <typename PointSource, typename PointTarget, int MODE>
+class TransformationEstimation {
+ public:
+  explicit TransformationEstimation(Context::Ptr ctx) : ctx_(std::move(ctx)) {}
+  void setEnforceSameDirectionNormals(bool on) { enforce_ = on; }
+  bool estimateRigidTransformation(const PointCloud<PointSource>& src, const PointCloud<PointTarget>& tgt,
+                                   Matrix4f& T) const {
+    if (src.size() != tgt.size()) return false;  // "Number or points in source differs than target"
+    const char* s = reinterpret_cast<const char*>(src.points.data());
+    const char* t = reinterpret_cast<const char*>(tgt.points.data());
+    const void* sn = (MODE == PCLHIP_ICP_SYMMETRIC && sizeof(PointSource) >= 28) ? s + 16 : nullptr;
+    const void* tn = (MODE != PCLHIP_ICP_POINT_TO_POINT && sizeof(PointTarget) >= 28) ? t + 16 : nullptr;
+    return pclhip_estimate_rigid_transformation(ctx_->get(), MODE, s, sizeof(PointSource), sn, sizeof(PointSource), t,
+                                                sizeof(PointTarget), tn, sizeof(PointTarget), src.size(),
+                                                enforce_ ? 1 : 0, T.m, nullptr) == PCLHIP_OK;
+  }
+ private:
+  Context::Ptr ctx_;
+  bool enforce_ = true;
+};
+template <typename S, typename T> using TransformationEstimationSVD = TransformationEstimation<S, T, PCLHIP_ICP_POINT_TO_POINT>;
+template <typename S, typename T> using TransformationEstimationPointToPlaneLLS = TransformationEstimation<S, T, PCLHIP_ICP_POINT_TO_PLANE>;
+template <typename S, typename T> using TransformationEstimationSymmetricPointToPlaneLLS = TransformationEstimation<S, T, PCLHIP_ICP_SYMMETRIC>;
+}  // namespace registration
 
 // pcl::VoxelGrid<pcl::PointXYZ>
 class VoxelGrid {

@@ -852,6 +852,131 @@ int orc_icp_align(const orc_kdtree* tgt_tree, const float* tgt, int ts, const fl
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* TransformationEstimationSymmetricPointToPlaneLLS,
+ * registration/include/pcl/registration/impl/transformation_estimation_symmetric_point_to_plane_lls.hpp:149-197.
+ * Per pair (float, Scalar = float): n = n1 + n2, or n1 - n2 when enforce_same_direction and n1.n2 < 0
+ * (:167-177); skipped unless p, q, n are finite (:179-182); v = [(p+q) x n ; n]; ATA += v v^T
+ * (rankUpdate, :186); ATb += v * ((q-p).n) (:188).  acc_double = 0: sums in float, sequential (the
+ * reference sums in float inside Eigen, order unspecified); acc_double = 1: float terms, double sums.
+ * sums27: upper triangle row-major [21] + ATb [6]. */
+void orc_symmetric_solve(const double* s, float* T);
+int64_t orc_lls_symmetric(const float* src, int ss, const float* src_nrm, int sns, const float* tgt,
+                          int ts, const float* tgt_nrm, int tns, const int32_t* q, const int32_t* m,
+                          int64_t npairs, int enforce_same_direction, int acc_double, double* sums27,
+                          float* T) {
+  double sd[27];
+  float sf[27];
+  memset(sd, 0, sizeof sd);
+  memset(sf, 0, sizeof sf);
+  int64_t used = 0;
+  for (int64_t k = 0; k < npairs; ++k) {
+    const int64_t iq = q ? q[k] : k, im = m ? m[k] : k;
+    const float* P = src + iq * ss;
+    const float* N1 = src_nrm + iq * sns;
+    const float* Q = tgt + im * ts;
+    const float* N2 = tgt_nrm + im * tns;
+    float n[3];
+    const float dot12 = (N1[0] * N2[0] + N1[1] * N2[1]) + N1[2] * N2[2];
+    if (enforce_same_direction && !(dot12 >= 0.0f)) {
+      n[0] = N1[0] - N2[0];
+      n[1] = N1[1] - N2[1];
+      n[2] = N1[2] - N2[2];
+    } else {
+      n[0] = N1[0] + N2[0];
+      n[1] = N1[1] + N2[1];
+      n[2] = N1[2] + N2[2];
+    }
+    if (!finite3(P) || !finite3(Q) || !finite3(n)) continue;
+    const float sx = P[0] + Q[0], sy = P[1] + Q[1], sz = P[2] + Q[2];
+    float v[6];
+    v[0] = sy * n[2] - sz * n[1];
+    v[1] = sz * n[0] - sx * n[2];
+    v[2] = sx * n[1] - sy * n[0];
+    v[3] = n[0];
+    v[4] = n[1];
+    v[5] = n[2];
+    const float dx = Q[0] - P[0], dy = Q[1] - P[1], dz = Q[2] - P[2];
+    const float r = (dx * n[0] + dy * n[1]) + dz * n[2];
+    int c = 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = i; j < 6; ++j) {
+        const float t = v[i] * v[j];
+        sd[c] += (double)t;
+        sf[c] += t;
+        ++c;
+      }
+    for (int i = 0; i < 6; ++i) {
+      const float t = v[i] * r;
+      sd[21 + i] += (double)t;
+      sf[21 + i] += t;
+    }
+    ++used;
+  }
+  if (!acc_double)
+    for (int i = 0; i < 27; ++i) sd[i] = (double)sf[i];
+  if (sums27) memcpy(sums27, sd, sizeof sd);
+  if (T) orc_symmetric_solve(sd, T);
+  return used;
+}
+
+/* x = ATA^-1 ATb (:193, LDLT in the reference; Gaussian elimination with partial pivoting in double
+ * here), then constructTransformationMatrix (:128-147):
+ * T = Rz Ry Rx * Translation(t) * Rz Ry Rx = [R R | R t], R = Rz(x2) Ry(x1) Rx(x0). */
+void orc_symmetric_solve(const double* s, float* T) {
+  double A[6][7];
+  int c = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) {
+      A[i][j] = s[c];
+      A[j][i] = s[c];
+      ++c;
+    }
+  for (int i = 0; i < 6; ++i) A[i][6] = s[21 + i];
+  double x[6];
+  int singular = 0;
+  for (int col = 0; col < 6; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 6; ++r)
+      if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
+    if (!(fabs(A[piv][col]) > 0.0)) {
+      singular = 1;
+      break;
+    }
+    if (piv != col)
+      for (int k = 0; k < 7; ++k) {
+        const double t = A[col][k];
+        A[col][k] = A[piv][k];
+        A[piv][k] = t;
+      }
+    for (int r = col + 1; r < 6; ++r) {
+      const double f = A[r][col] / A[col][col];
+      for (int k = col; k < 7; ++k) A[r][k] -= f * A[col][k];
+    }
+  }
+  for (int i = 5; i >= 0 && !singular; --i) {
+    double v = A[i][6];
+    for (int k = i + 1; k < 6; ++k) v -= A[i][k] * x[k];
+    x[i] = v / A[i][i];
+  }
+  if (singular)
+    for (int i = 0; i < 6; ++i) x[i] = NAN;
+  const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+  const double R[3][3] = {{cg * cb, -sg * ca + cg * sb * sa, sg * sa + cg * sb * ca},
+                          {sg * cb, cg * ca + sg * sb * sa, -cg * sa + sg * sb * ca},
+                          {-sb, cb * sa, cb * ca}};
+  memset(T, 0, 16 * sizeof(float));
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      double v = 0.0;
+      for (int k = 0; k < 3; ++k) v += R[i][k] * R[k][j];
+      T[4 * i + j] = (float)v;
+    }
+    T[4 * i + 3] = (float)(R[i][0] * x[3] + R[i][1] * x[4] + R[i][2] * x[5]);
+  }
+  T[15] = 1.0f;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 unsigned orc_mean_and_covariance(const float* cloud, int cs, const int32_t* indices, int n,
                                  float* cov, float* centroid) {
   /* centroid.hpp:587-648 (the !is_dense branch; identical to the dense one on finite data) */

@@ -72,6 +72,14 @@ int64_t orc_lls_point_to_plane(const float* src, int ss, const float* tgt, int t
                                int64_t npairs, double* sums27, float* T);
 void orc_lls_solve(const double* sums27, float* T);
 
+/* TransformationEstimationSymmetricPointToPlaneLLS
+ * (impl/transformation_estimation_symmetric_point_to_plane_lls.hpp:149-197); see the .c file. */
+int64_t orc_lls_symmetric(const float* src, int ss, const float* src_nrm, int sns, const float* tgt,
+                          int ts, const float* tgt_nrm, int tns, const int32_t* q, const int32_t* m,
+                          int64_t npairs, int enforce_same_direction, int acc_double, double* sums27,
+                          float* T);
+void orc_symmetric_solve(const double* sums27, float* T);
+
 /* TransformationEstimationSVD with use_umeyama_ = true (impl/transformation_estimation_svd.hpp
  * :127-155 -> common/include/pcl/common/impl/eigen.hpp:675-738).  acc_double = 0: all sums in
  * float, sequential (Scalar = float as in the reference; Eigen's internal summation order is not

@@ -80,6 +80,10 @@ def lib():
         L.orc_lls_point_to_plane.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_int, ip, ip,
                                              C.c_int64, dp, fp]
         L.orc_lls_solve.argtypes = [dp, fp]
+        L.orc_lls_symmetric.restype = C.c_int64
+        L.orc_lls_symmetric.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_int, fp, C.c_int, ip, ip,
+                                        C.c_int64, C.c_int, C.c_int, dp, fp]
+        L.orc_symmetric_solve.argtypes = [dp, fp]
         L.orc_umeyama.restype = C.c_int64
         L.orc_umeyama.argtypes = [fp, C.c_int, fp, C.c_int, ip, ip, C.c_int64, C.c_int, fp]
         L.orc_umeyama_from_sums.argtypes = [dp, C.c_double, fp]
@@ -215,6 +219,33 @@ def lls_point_to_plane(src, tgt, nrm, q=None, m=None):
                                         _i(qq) if qq is not None else None,
                                         _i(mm) if mm is not None else None, n, _d(sums), _f(T))
     return T.reshape(4, 4), sums, used
+
+
+def lls_symmetric(src, src_nrm, tgt, tgt_nrm, q=None, m=None, enforce_same_direction=True,
+                  acc_double=True):
+    """TransformationEstimationSymmetricPointToPlaneLLS; returns (T 4x4, sums27, used)."""
+    src, ns, ss = _cloud(src)
+    sn, _, sns = _cloud(src_nrm)
+    tgt, nt, ts = _cloud(tgt)
+    tn, _, tns = _cloud(tgt_nrm)
+    n = len(q) if q is not None else ns
+    qq = np.ascontiguousarray(q, np.int32) if q is not None else None
+    mm = np.ascontiguousarray(m, np.int32) if m is not None else None
+    sums = np.zeros(27, np.float64)
+    T = np.zeros(16, np.float32)
+    used = lib().orc_lls_symmetric(_f(src), ss, _f(sn), sns, _f(tgt), ts, _f(tn), tns,
+                                   _i(qq) if qq is not None else None,
+                                   _i(mm) if mm is not None else None, n,
+                                   1 if enforce_same_direction else 0, 1 if acc_double else 0,
+                                   _d(sums), _f(T))
+    return T.reshape(4, 4), sums, used
+
+
+def symmetric_solve(sums27):
+    s = np.ascontiguousarray(sums27, np.float64)
+    T = np.zeros(16, np.float32)
+    lib().orc_symmetric_solve(_d(s), _f(T))
+    return T.reshape(4, 4)
 
 
 def lls_solve(sums27):

@@ -45,14 +45,16 @@ def reject_trimmed(q, m, d, overlap_ratio, nr_min_correspondences=0):
 
 
 def icp_with_filters(orc, tgt, src, mode, tgt_normals=None, rejectors=(), reciprocal=False, max_iterations=10,
-                     max_correspondence_distance=None, transformation_epsilon=0.0):
+                     max_correspondence_distance=None, transformation_epsilon=0.0, src_normals=None,
+                     enforce_same_direction=True):
     """IterativeClosestPoint::computeTransformation (impl/icp.hpp:113-268) composed from the C oracle's
     pieces, with the rejector chain (:187-201) and reciprocal correspondences (:176-184).
     rejectors: list of callables (q, m, d) -> (q, m, d).  Returns dict like orc.icp_align."""
     import numpy as _np
     tree = orc.KdTree(tgt)
-    order = 1 if mode == 1 else 0
+    order = 0 if mode == 0 else 1
     cur = _np.ascontiguousarray(src[:, :4], _np.float32).copy()
+    cur_n = None if src_normals is None else _np.ascontiguousarray(src_normals, _np.float32).copy()
     final_T = _np.eye(4, dtype=_np.float32)
     conv = orc.new_convergence()
     conv.max_iterations = max_iterations
@@ -76,9 +78,14 @@ def icp_with_filters(orc, tgt, src, mode, tgt_normals=None, rejectors=(), recipr
             return {"T": final_T, "iterations": it, "converged": False, "state": 5, "per_iter": per_iter}
         if mode == 1:
             Tk, _, _ = orc.lls_point_to_plane(cur, tgt, tgt_normals, q, m)
+        elif mode == 2:  # setUseSymmetricObjective (icp.h:380-400): the source normals move with the cloud
+            Tk, _, _ = orc.lls_symmetric(cur, cur_n, tgt, tgt_normals, q, m, enforce_same_direction, acc_double=True)
         else:
             Tk = orc.umeyama(cur, tgt, q, m, acc_double=True)
-        cur = orc.transform_cloud(Tk, cur, order=order)
+        if cur_n is not None:
+            cur, cur_n = orc.transform_cloud(Tk, cur, order=order, normals=cur_n)
+        else:
+            cur = orc.transform_cloud(Tk, cur, order=order)
         final_T = orc.mat4_mul(Tk, final_T)
         it += 1
         mse = float(d.astype(_np.float64).sum() / len(d))

@@ -3,9 +3,9 @@ VoxelGrid) behind PCL's plugin surface.  Compute lives in libpclhip.so (pcl_amd/
 behind the C ABI of include/pclhip.h; this package is the ctypes host mirror used by tests and
 bench.py.  The C++ mirror of the same surface is include/pclhip/pcl_compat.hpp."""
 from . import synth  # noqa: F401
-from ._lib import (POINT_TO_PLANE, POINT_TO_POINT, PclHipError, PclHipUnavailable)  # noqa: F401
+from ._lib import (POINT_TO_PLANE, POINT_TO_POINT, SYMMETRIC, PclHipError, PclHipUnavailable)  # noqa: F401
 from .api import (Context, CorrespondenceEstimation, CorrespondenceRejectorDistance,  # noqa: F401
                   CorrespondenceRejectorMedianDistance, CorrespondenceRejectorOneToOne,
                   CorrespondenceRejectorTrimmed, IterativeClosestPoint,
                   IterativeClosestPointWithNormals, KdTree, NormalEstimation, VoxelGrid,
-                  default_context)
+                  default_context, estimateRigidTransformation)

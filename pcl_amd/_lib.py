@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpclhip.so")
 NSUMS = 32
 POINT_TO_POINT = 0
 POINT_TO_PLANE = 1
+SYMMETRIC = 2
 
 CONVERGENCE_STATES = ("NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE",
                       "NO_CORRESPONDENCES", "FAILURE_AFTER_MAX_ITERATIONS")
@@ -76,6 +77,8 @@ SIGNATURES = {
     "pclhip_icp_create": (C.c_int, [_vp, C.POINTER(_vp)]),
     "pclhip_icp_destroy": (None, [_vp]),
     "pclhip_icp_set_source": (C.c_int, [_vp, _vp, _sz, _u64]),
+    "pclhip_icp_set_source_normals": (C.c_int, [_vp, _vp, _sz]),
+    "pclhip_icp_set_enforce_same_direction_normals": (C.c_int, [_vp, C.c_int]),
     "pclhip_icp_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),
     "pclhip_icp_reset": (C.c_int, [_vp]),
     "pclhip_icp_set_rejectors": (C.c_int, [_vp, C.POINTER(Rejector), C.c_int]),
@@ -93,6 +96,8 @@ SIGNATURES = {
     "pclhip_icp_fitness_score": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_double, C.POINTER(C.c_double),
                                            C.POINTER(_u64)]),
     "pclhip_icp_fetch_correspondences": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "pclhip_estimate_rigid_transformation": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _u64,
+                                                       C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "pclhip_transform_cloud": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int, _vp, _vp, _sz, _u64,
                                          _sz]),
     "pclhip_voxelgrid": (C.c_int, [_vp, _vp, _sz, _u64, C.POINTER(C.c_float), C.c_uint32, C.c_int,

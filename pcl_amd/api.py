@@ -450,6 +450,12 @@ class IterativeClosestPoint:
             ptr, stride, n, keep = _cloud(self.src)
             check(self.lib.pclhip_icp_set_source(self.h, ptr, stride, n), self.ctx.h)
             self._src_id = id(self.src)
+            self._src_nrm_id = None
+        nrm = getattr(self, "src_normals", None)
+        if nrm is not None and getattr(self, "_src_nrm_id", None) != id(nrm):
+            nptr, nstride, nn, _keep = _cloud(nrm)
+            check(self.lib.pclhip_icp_set_source_normals(self.h, nptr, nstride), self.ctx.h)
+            self._src_nrm_id = id(nrm)
         if getattr(self, "_filters_dirty", True):
             _set_filters(self.lib, self.ctx, self.h, self.rejectors, self.use_reciprocal)
             self._filters_dirty = False
@@ -576,6 +582,52 @@ class IterativeClosestPointWithNormals(IterativeClosestPoint):
 
     def setTargetNormals(self, normals):
         self.tree.setNormals(normals)
+
+    def setInputSource(self, cloud):
+        super().setInputSource(cloud)
+        if cloud.shape[1] >= 7:  # pcl::PointNormal source: its normals feed the symmetric objective
+            self.src_normals = cloud[:, 4:7]
+
+    def setSourceNormals(self, normals):
+        self.src_normals = normals
+
+    def setUseSymmetricObjective(self, on):
+        """icp.h:380-400: TransformationEstimationSymmetricPointToPlaneLLS instead of PointToPlaneLLS."""
+        self.MODE = _lib.SYMMETRIC if on else POINT_TO_PLANE
+        self.p.mode = self.MODE
+
+    def getUseSymmetricObjective(self):
+        return self.MODE == _lib.SYMMETRIC
+
+    def setEnforceSameDirectionNormals(self, on):
+        """icp.h:416-428"""
+        self._enforce = bool(on)
+        self._ensure()
+        check(self.lib.pclhip_icp_set_enforce_same_direction_normals(self.h, 1 if on else 0), self.ctx.h)
+
+    def getEnforceSameDirectionNormals(self):
+        return getattr(self, "_enforce", True)
+
+
+def estimateRigidTransformation(ctx, mode, src, tgt, src_normals=None, tgt_normals=None,
+                                enforce_same_direction_normals=True):
+    """TransformationEstimation{SVD, PointToPlaneLLS, SymmetricPointToPlaneLLS}::estimateRigidTransformation
+    (cloud_src, cloud_tgt) for equally sized clouds (pair i = (src[i], tgt[i])).  Returns (T 4x4, sums)."""
+    sp, ss, n, _k1 = _cloud(src)
+    tp, ts, nt, _k2 = _cloud(tgt)
+    assert n == nt, "Number or points in source differs than target"
+    snp, sns = None, 0
+    tnp, tns = None, 0
+    if src_normals is not None:
+        snp, sns, _, _k3 = _cloud(src_normals)
+    if tgt_normals is not None:
+        tnp, tns, _, _k4 = _cloud(tgt_normals)
+    T = np.zeros(16, np.float32)
+    sums = np.zeros(_lib.NSUMS, np.float64)
+    check(ctx.lib.pclhip_estimate_rigid_transformation(
+        ctx.h, int(mode), sp, ss, snp, sns, tp, ts, tnp, tns, n, 1 if enforce_same_direction_normals else 0,
+        _fp(T), sums.ctypes.data_as(C.POINTER(C.c_double))), ctx.h)
+    return T.reshape(4, 4), sums
 
 
 class VoxelGrid:

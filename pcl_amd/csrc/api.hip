@@ -462,6 +462,9 @@ pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out) {
 static void icp_free_source(pclhip_icp* icp) {
   if (icp->src_sorted0) (void)hipFree(icp->src_sorted0);
   if (icp->src_cur) (void)hipFree(icp->src_cur);
+  if (icp->src_nrm_sorted0) (void)hipFree(icp->src_nrm_sorted0);
+  if (icp->src_nrm_cur) (void)hipFree(icp->src_nrm_cur);
+  icp->src_nrm_sorted0 = icp->src_nrm_cur = nullptr;
   if (icp->match) (void)hipFree(icp->match);
   if (icp->match_pos) (void)hipFree(icp->match_pos);
   if (icp->keep) (void)hipFree(icp->keep);
@@ -522,6 +525,39 @@ pclhip_status pclhip_icp_set_source(pclhip_icp* icp, const void* points, size_t 
   return pclhip_icp_reset(icp);
 }
 
+pclhip_status pclhip_icp_set_source_normals(pclhip_icp* icp, const void* normals, size_t stride) {
+  if (!icp) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = icp->ctx;
+  PCLHIP_REQUIRE(ctx, icp->src_sorted0 != nullptr, "set the source cloud first");
+  PCLHIP_REQUIRE(ctx, normals != nullptr || icp->n == 0, "null normals");
+  PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard;
+  const void* dn = nullptr;
+  void* owned = nullptr;
+  pclhip_status st = to_device(ctx, normals, size_t(icp->n_orig) * stride, &dn, &owned);
+  if (st != PCLHIP_OK) return st;
+  guard.add(owned);
+  const size_t cap = icp->n > 0 ? icp->n : 1;
+  if (!icp->src_nrm_sorted0) PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->src_nrm_sorted0, cap * sizeof(float4)));
+  if (!icp->src_nrm_cur) PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->src_nrm_cur, cap * sizeof(float4)));
+  if (icp->n > 0) {
+    hipLaunchKernelGGL(gather_normals_kernel, dim3((icp->n + 255) / 256), dim3(256), 0, ctx->stream, dn, stride,
+                       icp->src_sorted0, icp->n, icp->n, icp->src_nrm_sorted0);
+    PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(icp->src_nrm_cur, icp->src_nrm_sorted0, size_t(icp->n) * sizeof(float4),
+                                         hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_icp_set_enforce_same_direction_normals(pclhip_icp* icp, int enforce) {
+  if (!icp) return PCLHIP_ERR_INVALID;
+  icp->enforce_same_direction_normals = enforce != 0;
+  return PCLHIP_OK;
+}
+
 pclhip_status pclhip_icp_set_allreduce(pclhip_icp* icp, pclhip_allreduce_fn fn, void* user) {
   if (!icp) return PCLHIP_ERR_INVALID;
   icp->allreduce = fn;
@@ -551,6 +587,9 @@ pclhip_status pclhip_icp_reset(pclhip_icp* icp) {
   if (icp->n > 0) {
     PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(icp->src_cur, icp->src_sorted0, size_t(icp->n) * sizeof(float4),
                                          hipMemcpyDeviceToDevice, ctx->stream));
+    if (icp->src_nrm_cur)
+      PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(icp->src_nrm_cur, icp->src_nrm_sorted0, size_t(icp->n) * sizeof(float4),
+                                           hipMemcpyDeviceToDevice, ctx->stream));
     // no seeds from a previous alignment: the first iteration searches from scratch
     PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(icp->match_pos, 0xFF, size_t(icp->n) * sizeof(uint32_t), ctx->stream));
   }
@@ -561,8 +600,15 @@ pclhip_status pclhip_icp_reset(pclhip_icp* icp) {
 pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[16], double max_dist, int mode, double* sums) {
   if (!icp || !T_prev || !sums) return PCLHIP_ERR_INVALID;
   pclhip_ctx* ctx = icp->ctx;
-  PCLHIP_REQUIRE(ctx, mode == PCLHIP_ICP_POINT_TO_POINT || mode == PCLHIP_ICP_POINT_TO_PLANE, "bad mode");
-  if (mode == PCLHIP_ICP_POINT_TO_PLANE && !icp->target->has_normals) {
+  if (mode != PCLHIP_ICP_POINT_TO_POINT && mode != PCLHIP_ICP_POINT_TO_PLANE && mode != PCLHIP_ICP_SYMMETRIC) {
+    set_error(ctx, "unknown ICP mode");
+    return PCLHIP_ERR_INVALID;
+  }
+  if (mode == PCLHIP_ICP_SYMMETRIC && icp->src_nrm_cur == nullptr) {
+    set_error(ctx, "the symmetric objective needs source normals (pclhip_icp_set_source_normals)");
+    return PCLHIP_ERR_STATE;
+  }
+  if (mode != PCLHIP_ICP_POINT_TO_POINT && !icp->target->has_normals) {
     set_error(ctx, "point-to-plane ICP needs target normals (pclhip_normals / pclhip_index_set_normals)");
     return PCLHIP_ERR_STATE;
   }
@@ -601,8 +647,12 @@ pclhip_status pclhip_solve_transformation(const double* sums, int mode, float* T
   if (!sums || !T) return PCLHIP_ERR_INVALID;
   if (mode == PCLHIP_ICP_POINT_TO_PLANE)
     solve_point_to_plane(sums, T);
-  else
+  else if (mode == PCLHIP_ICP_SYMMETRIC)
+    solve_symmetric(sums, T);
+  else if (mode == PCLHIP_ICP_POINT_TO_POINT)
     solve_point_to_point(sums, T);
+  else
+    return PCLHIP_ERR_INVALID;
   return PCLHIP_OK;
 }
 
@@ -728,6 +778,58 @@ pclhip_status pclhip_icp_align(pclhip_icp* icp, const pclhip_icp_params* params,
   res->gpu_ms = ms;
   res->gpu_ms_search_kernel = kernel_ms;
   return PCLHIP_OK;
+}
+
+namespace {
+__global__ void pack_float4_kernel(const void* in, size_t stride, uint32_t n, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(in) + size_t(i) * stride);
+  out[i] = make_float4(p[0], p[1], p[2], 0.0f);
+}
+}  // namespace
+
+pclhip_status pclhip_estimate_rigid_transformation(pclhip_ctx* ctx, int mode, const void* src, size_t src_stride,
+                                                   const void* src_normals, size_t src_normals_stride, const void* tgt,
+                                                   size_t tgt_stride, const void* tgt_normals, size_t tgt_normals_stride,
+                                                   uint64_t n, int enforce, float T[16], double* sums_out) {
+  if (!ctx || !T) return PCLHIP_ERR_INVALID;
+  PCLHIP_REQUIRE(ctx, mode >= PCLHIP_ICP_POINT_TO_POINT && mode <= PCLHIP_ICP_SYMMETRIC, "unknown estimator");
+  PCLHIP_REQUIRE(ctx, n < 0x7FFFFFFFull, "too many pairs");
+  PCLHIP_REQUIRE(ctx, n == 0 || (src && tgt), "null point buffer");
+  PCLHIP_REQUIRE(ctx, mode == PCLHIP_ICP_POINT_TO_POINT || n == 0 || tgt_normals, "this estimator needs target normals");
+  PCLHIP_REQUIRE(ctx, mode != PCLHIP_ICP_SYMMETRIC || n == 0 || src_normals, "this estimator needs source normals");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  double sums[PCLHIP_ICP_NSUMS];
+  std::memset(sums, 0, sizeof sums);
+  if (n > 0) {
+    DeviceGuard guard;
+    const void* in[4] = {src, mode == PCLHIP_ICP_SYMMETRIC ? src_normals : nullptr, tgt,
+                         mode != PCLHIP_ICP_POINT_TO_POINT ? tgt_normals : nullptr};
+    const size_t strides[4] = {src_stride, src_normals_stride, tgt_stride, tgt_normals_stride};
+    float4* packed[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int a = 0; a < 4; ++a) {
+      if (!in[a]) continue;
+      PCLHIP_REQUIRE(ctx, strides[a] >= 12 && strides[a] % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
+      const void* d = nullptr;
+      void* owned = nullptr;
+      pclhip_status st = to_device(ctx, in[a], size_t(n) * strides[a], &d, &owned);
+      if (st != PCLHIP_OK) return st;
+      guard.add(owned);
+      void* buf = nullptr;
+      PCLHIP_CHECK_HIP(ctx, hipMalloc(&buf, size_t(n) * sizeof(float4)));
+      guard.add(buf);
+      packed[a] = static_cast<float4*>(buf);
+      hipLaunchKernelGGL(pack_float4_kernel, dim3((uint32_t(n) + 255) / 256), dim3(256), 0, ctx->stream, d, strides[a],
+                         uint32_t(n), packed[a]);
+    }
+    PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+    pclhip_status st = launch_estimate_pairs(ctx, mode, packed[0], packed[1], packed[2], packed[3], uint32_t(n),
+                                             enforce != 0, sums);
+    if (st != PCLHIP_OK) return st;
+  }
+  if (sums_out) std::memcpy(sums_out, sums, sizeof sums);
+  return pclhip_solve_transformation(sums, mode, T);
 }
 
 pclhip_status pclhip_icp_fitness_score(pclhip_icp* icp, const float T[16], double max_range, double* score,

@@ -184,6 +184,38 @@ void solve_point_to_plane(const double* s, float* T) {
   T[15] = 1.0f;
 }
 
+// TransformationEstimationSymmetricPointToPlaneLLS: solve + constructTransformationMatrix
+// (impl/transformation_estimation_symmetric_point_to_plane_lls.hpp:128-147,192-196):
+// T = Rz Ry Rx * Translation(t) * Rz Ry Rx = [R R | R t] with R = Rz(x2) Ry(x1) Rx(x0).
+void solve_symmetric(const double* s, float* T) {
+  double A[6][6], b[6], x[6] = {0, 0, 0, 0, 0, 0};
+  int k = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) {
+      A[i][j] = s[k];
+      A[j][i] = s[k];
+      ++k;
+    }
+  for (int i = 0; i < 6; ++i) b[i] = s[21 + i];
+  if (!lu_solve6(A, b, x))
+    for (int i = 0; i < 6; ++i) x[i] = std::nan("");
+  const double ca = std::cos(x[0]), sa = std::sin(x[0]), cb = std::cos(x[1]), sb = std::sin(x[1]), cg = std::cos(x[2]),
+               sg = std::sin(x[2]);
+  const double R[3][3] = {{cg * cb, -sg * ca + cg * sb * sa, sg * sa + cg * sb * ca},
+                          {sg * cb, cg * ca + sg * sb * sa, -cg * sa + sg * sb * ca},
+                          {-sb, cb * sa, cb * ca}};
+  std::memset(T, 0, 16 * sizeof(float));
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      double v = 0.0;
+      for (int m = 0; m < 3; ++m) v += R[i][m] * R[m][j];
+      T[4 * i + j] = float(v);
+    }
+    T[4 * i + 3] = float(R[i][0] * x[3] + R[i][1] * x[4] + R[i][2] * x[5]);
+  }
+  T[15] = 1.0f;
+}
+
 void solve_point_to_point(const double* s, float* T) {
   const double n = s[28];
   double sm[3], dm[3], sigma[3][3], R[3][3];

@@ -107,6 +107,9 @@ struct pclhip_icp {
   uint32_t n = 0;            // source points (all records; non-finite ones are flagged invalid)
   float4* src_sorted0 = nullptr;   // Morton-ordered input (w = original index), pristine
   float4* src_cur = nullptr;       // working copy (input_transformed)
+  float4* src_nrm_sorted0 = nullptr;  // source normals in the same order (symmetric objective), pristine
+  float4* src_nrm_cur = nullptr;      // ... rotated along with the working copy
+  bool enforce_same_direction_normals = true;  // icp.h:368
   uint32_t* match = nullptr;       // per sorted source slot: ORIGINAL target index or NO_INDEX
   uint32_t* match_pos = nullptr;   // ... and its sorted position (seed of the next iteration)
   float* match_d2 = nullptr;
@@ -177,6 +180,8 @@ pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stri
                             uint32_t* rank_or_null);
 pclhip_status build_boxes(pclhip_index* ix);
 int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns);
+pclhip_status launch_estimate_pairs(pclhip_ctx* ctx, int mode, const float4* src, const float4* src_nrm,
+                                    const float4* tgt, const float4* tgt_nrm, uint32_t n, bool enforce, double* sums);
 pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double max_range, double* score,
                                    uint64_t* nr);
 
@@ -194,6 +199,7 @@ pclhip_status build_index_from_float4(pclhip_ctx* ctx, const float4* dev_pts_wit
 // ---- host closed forms (host_math.cpp) -------------------------------------------------------
 void solve_point_to_plane(const double* sums, float* T);
 void solve_point_to_point(const double* sums, float* T);
+void solve_symmetric(const double* sums, float* T);
 void mat4_mul_f32(const float* A, const float* B, float* C);
 
 }  // namespace pclhip

@@ -824,31 +824,34 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
   flush_stats(ts, gstats);
 }
 
+// Per-pair terms of the three transformation estimators, accumulated per lane in fp64 and reduced in a
+// fixed order (wave shuffles, then the block's waves through LDS): deterministic for a given grid.
+//   MODE 0  raw sums for umeyama (common/include/pcl/common/impl/eigen.hpp:696-712)
+//   MODE 1  TransformationEstimationPointToPlaneLLS, impl/transformation_estimation_point_to_plane_lls.hpp:182-241
+//           (float products in the reference's order, double sums)
+//   MODE 2  TransformationEstimationSymmetricPointToPlaneLLS,
+//           impl/transformation_estimation_symmetric_point_to_plane_lls.hpp:161-190: n = n1 +- n2,
+//           v = [(p+q) x n ; n], ATA += v v^T, ATb += v ((q-p).n) -- float terms, double sums (the
+//           reference sums in float in Eigen's internal order, which is not reproducible)
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, const float4* __restrict__ cur, uint32_t ns,
-                                                               const uint32_t* __restrict__ match_pos,
-                                                               const float* __restrict__ match_d2,
-                                                               const uint8_t* __restrict__ keep,
-                                                               double* __restrict__ partials) {
-  __shared__ double red_s[WAVES_PER_BLOCK][NS];
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int wave = threadIdx.x / WAVE;
-  constexpr int NACC = (MODE == PCLHIP_ICP_POINT_TO_PLANE) ? 27 : 15;
+struct PairAcc {
+  static constexpr int NACC = (MODE == PCLHIP_ICP_POINT_TO_POINT) ? 15 : 27;
   double acc[NACC];
+  double sum_d2;
+  uint32_t cnt, skipped;
+  __device__ __forceinline__ void init() {
 #pragma unroll
-  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-  double sum_d2 = 0.0;
-  uint32_t cnt = 0, skipped = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
-    const uint32_t pos = match_pos[i];
-    if (pos == NO_INDEX) continue;
-    if (keep != nullptr && !keep[i]) continue;  // rejected by the reciprocal test / rejector chain
-    const float4 p = cur[i];
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+    sum_d2 = 0.0;
+    cnt = 0;
+    skipped = 0;
+  }
+  // p: source point (already moved), n1: its normal (MODE 2), t: matched target point, n: its normal
+  __device__ __forceinline__ void add(const float4 p, const float4 n1, const float4 t, const float4 n, float d2,
+                                      bool enforce_same_direction) {
     ++cnt;
-    sum_d2 += double(match_d2[i]);
-    const float4 t = ix.pts[pos];
+    sum_d2 += double(d2);
     if constexpr (MODE == PCLHIP_ICP_POINT_TO_PLANE) {
-      const float4 n = ix.nrm[pos];
       if (isfinite(n.x) && isfinite(n.y) && isfinite(n.z)) {
         const float sx = p.x, sy = p.y, sz = p.z;
         const float nx = n.x, ny = n.y, nz = n.z;
@@ -864,6 +867,7 @@ __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, con
         acc[15] += double(__fmul_rn(nx, nx)); acc[16] += double(__fmul_rn(nx, ny));
         acc[17] += double(__fmul_rn(nx, nz)); acc[18] += double(__fmul_rn(ny, ny));
         acc[19] += double(__fmul_rn(ny, nz)); acc[20] += double(__fmul_rn(nz, nz));
+        // :235  nx*dx + ny*dy + nz*dz - nx*sx - ny*sy - nz*sz, float, left to right
         float df = __fmul_rn(nx, t.x);
         df = __fadd_rn(df, __fmul_rn(ny, t.y));
         df = __fadd_rn(df, __fmul_rn(nz, t.z));
@@ -876,6 +880,36 @@ __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, con
       } else {
         ++skipped;
       }
+    } else if constexpr (MODE == PCLHIP_ICP_SYMMETRIC) {
+      float nx, ny, nz;
+      const float dot12 = __fadd_rn(__fadd_rn(__fmul_rn(n1.x, n.x), __fmul_rn(n1.y, n.y)), __fmul_rn(n1.z, n.z));
+      if (enforce_same_direction && !(dot12 >= 0.0f)) {  // :169-174
+        nx = __fsub_rn(n1.x, n.x); ny = __fsub_rn(n1.y, n.y); nz = __fsub_rn(n1.z, n.z);
+      } else {
+        nx = __fadd_rn(n1.x, n.x); ny = __fadd_rn(n1.y, n.y); nz = __fadd_rn(n1.z, n.z);
+      }
+      const bool ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(t.x) && isfinite(t.y) &&
+                      isfinite(t.z) && isfinite(nx) && isfinite(ny) && isfinite(nz);  // :180-183
+      if (ok) {
+        const float sx = __fadd_rn(p.x, t.x), sy = __fadd_rn(p.y, t.y), sz = __fadd_rn(p.z, t.z);
+        float v[6];
+        v[0] = __fsub_rn(__fmul_rn(sy, nz), __fmul_rn(sz, ny));  // (p+q) x n
+        v[1] = __fsub_rn(__fmul_rn(sz, nx), __fmul_rn(sx, nz));
+        v[2] = __fsub_rn(__fmul_rn(sx, ny), __fmul_rn(sy, nx));
+        v[3] = nx; v[4] = ny; v[5] = nz;
+        const float dx = __fsub_rn(t.x, p.x), dy = __fsub_rn(t.y, p.y), dz = __fsub_rn(t.z, p.z);
+        const float r = __fadd_rn(__fadd_rn(__fmul_rn(dx, nx), __fmul_rn(dy, ny)), __fmul_rn(dz, nz));
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+          for (int j = i; j < 6; ++j) acc[k++] += double(__fmul_rn(v[i], v[j]));  // upper triangle, row-major
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[21 + i] += double(__fmul_rn(v[i], r));
+      } else {
+        ++skipped;
+      }
     } else {
       const double sx = p.x, sy = p.y, sz = p.z, tx = t.x, ty = t.y, tz = t.z;
       acc[0] += sx; acc[1] += sy; acc[2] += sz;
@@ -885,12 +919,15 @@ __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, con
       acc[12] += tz * sx; acc[13] += tz * sy; acc[14] += tz * sz;
     }
   }
+  // block partial -> partials[blockIdx.x][NS]; red_s: [WAVES_PER_BLOCK][NS] doubles of LDS
+  __device__ __forceinline__ void store_block(double (*red_s)[NS], double* __restrict__ partials) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = threadIdx.x / WAVE;
 #pragma unroll
-  for (int i = 0; i < NACC; ++i) {
-    const double s = wave_sum_d(acc[i]);
-    if (lane == 0) red_s[wave][i] = s;
-  }
-  {
+    for (int i = 0; i < NACC; ++i) {
+      const double s = wave_sum_d(acc[i]);
+      if (lane == 0) red_s[wave][i] = s;
+    }
     const double s0 = wave_sum_d(sum_d2), s1 = wave_sum_d(double(cnt)), s2 = wave_sum_d(double(skipped));
     if (lane == 0) {
       for (int i = NACC; i < NS; ++i) red_s[wave][i] = 0.0;
@@ -898,14 +935,75 @@ __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, con
       red_s[wave][28] = s1;
       red_s[wave][29] = s2;
     }
-  }
-  __syncthreads();
-  if (threadIdx.x < NS) {
-    double s = 0.0;
+    __syncthreads();
+    if (threadIdx.x < NS) {
+      double s = 0.0;
 #pragma unroll
-    for (int w = 0; w < WAVES_PER_BLOCK; ++w) s += red_s[w][threadIdx.x];
-    partials[size_t(blockIdx.x) * NS + threadIdx.x] = s;
+      for (int w = 0; w < WAVES_PER_BLOCK; ++w) s += red_s[w][threadIdx.x];
+      partials[size_t(blockIdx.x) * NS + threadIdx.x] = s;
+    }
   }
+};
+
+// so3 part of Transformer (common/include/pcl/common/impl/transforms.hpp:83-96): r0*a + (r1*b + r2*c)
+__device__ __forceinline__ float rotate_row(float r0, float r1, float r2, float a, float b, float c) {
+  return __fadd_rn(__fmul_rn(r0, a), __fadd_rn(__fmul_rn(r1, b), __fmul_rn(r2, c)));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, const float4* __restrict__ cur, uint32_t ns,
+                                                               const uint32_t* __restrict__ match_pos,
+                                                               const float* __restrict__ match_d2,
+                                                               const uint8_t* __restrict__ keep, Mat34 T,
+                                                               float4* __restrict__ src_nrm, int enforce,
+                                                               double* __restrict__ partials) {
+  __shared__ double red_s[WAVES_PER_BLOCK][NS];
+  PairAcc<MODE> pa;
+  pa.init();
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    float4 n1 = make_float4(0, 0, 0, 0);
+    if constexpr (MODE == PCLHIP_ICP_SYMMETRIC) {
+      // the source normals move with the cloud (transformPointCloudWithNormals, icp.hpp:49-111 override
+      // of IterativeClosestPointWithNormals): rotate by this iteration's incremental transform
+      const float4 m = src_nrm[i];
+      n1.x = rotate_row(T.m[0], T.m[1], T.m[2], m.x, m.y, m.z);
+      n1.y = rotate_row(T.m[4], T.m[5], T.m[6], m.x, m.y, m.z);
+      n1.z = rotate_row(T.m[8], T.m[9], T.m[10], m.x, m.y, m.z);
+      n1.w = m.w;
+      src_nrm[i] = n1;
+    }
+    const uint32_t pos = match_pos[i];
+    if (pos == NO_INDEX) continue;
+    if (keep != nullptr && !keep[i]) continue;  // rejected by the reciprocal test / rejector chain
+    const float4 p = cur[i];
+    const float4 t = ix.pts[pos];
+    float4 n = make_float4(0, 0, 0, 0);
+    if constexpr (MODE != PCLHIP_ICP_POINT_TO_POINT) n = ix.nrm[pos];
+    pa.add(p, n1, t, n, match_d2[i], enforce != 0);
+  }
+  pa.store_block(red_s, partials);
+}
+
+// TransformationEstimation::estimateRigidTransformation(cloud_src, cloud_tgt) for n given pairs
+// (registration/include/pcl/registration/transformation_estimation.h:71-115): pair i = (src[i], tgt[i]).
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void estimate_pairs_kernel(const float4* __restrict__ src,
+                                                               const float4* __restrict__ src_nrm,
+                                                               const float4* __restrict__ tgt,
+                                                               const float4* __restrict__ tgt_nrm, uint32_t n,
+                                                               int enforce, double* __restrict__ partials) {
+  __shared__ double red_s[WAVES_PER_BLOCK][NS];
+  PairAcc<MODE> pa;
+  pa.init();
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 p = src[i], t = tgt[i];
+    float4 n1 = make_float4(0, 0, 0, 0), n2 = make_float4(0, 0, 0, 0);
+    if constexpr (MODE == PCLHIP_ICP_SYMMETRIC) n1 = src_nrm[i];
+    if constexpr (MODE != PCLHIP_ICP_POINT_TO_POINT) n2 = tgt_nrm[i];
+    const float dx = __fsub_rn(p.x, t.x), dy = __fsub_rn(p.y, t.y), dz = __fsub_rn(p.z, t.z);
+    pa.add(p, n1, t, n2, __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)), enforce != 0);
+  }
+  pa.store_block(red_s, partials);
 }
 
 // partials[nblocks][NS] -> sums[NS]; fixed summation order (stride-32 lanes, then 32 partial sums in
@@ -932,7 +1030,9 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   const IndexView v = icp->target->view();
   Mat34 M;
   for (int i = 0; i < 12; ++i) M.m[i] = T[i];
-  const int order = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? 1 : 0;
+  // clouds with normals move through transformPointCloudWithNormals (Transformer order), plain clouds
+  // through Matrix4f * Vector4f (impl/icp.hpp:49-111)
+  const int order = (mode == PCLHIP_ICP_POINT_TO_POINT) ? 0 : 1;
   // candidates must be <= max_d2 (a float): strict bound just above it; +inf when unbounded
   const float bound = use_max ? std::nextafterf(max_d2, __builtin_inff()) : __builtin_inff();
   const uint32_t ngroups = (icp->n + WAVE - 1) / WAVE;
@@ -947,7 +1047,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     return (e && atoi(e) == 1) ? 0 : 1;  // default: the two-kernel variant (measured faster)
   }();
   const bool filters = icp->reciprocal || !icp->rejectors.empty();
-  if (icp->n > 0 && (unfused || filters)) {
+  if (icp->n > 0 && (unfused || filters || mode == PCLHIP_ICP_SYMMETRIC)) {
     static const int qpl = [] {
       const char* e = getenv("PCLHIP_ICP_QPL");
       return (e && atoi(e) == 2) ? 2 : 1;  // QPL=2 spills (measured slower); kept as an A/B switch
@@ -973,12 +1073,16 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     }
     int ga = ctx->num_cus * 8;
     if (ga > icp->grid_blocks) ga = icp->grid_blocks;
+    const int enforce = icp->enforce_same_direction_normals ? 1 : 0;
     if (mode == PCLHIP_ICP_POINT_TO_PLANE)
       hipLaunchKernelGGL(icp_accumulate_kernel<PCLHIP_ICP_POINT_TO_PLANE>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur,
-                         icp->n, icp->match_pos, icp->match_d2, keep, icp->partials);
+                         icp->n, icp->match_pos, icp->match_d2, keep, M, icp->src_nrm_cur, enforce, icp->partials);
+    else if (mode == PCLHIP_ICP_SYMMETRIC)
+      hipLaunchKernelGGL(icp_accumulate_kernel<PCLHIP_ICP_SYMMETRIC>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur,
+                         icp->n, icp->match_pos, icp->match_d2, keep, M, icp->src_nrm_cur, enforce, icp->partials);
     else
       hipLaunchKernelGGL(icp_accumulate_kernel<PCLHIP_ICP_POINT_TO_POINT>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur,
-                         icp->n, icp->match_pos, icp->match_d2, keep, icp->partials);
+                         icp->n, icp->match_pos, icp->match_d2, keep, M, icp->src_nrm_cur, enforce, icp->partials);
     (void)hipEventRecord(icp->ev1, s);
     hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, ga, icp->sums_dev);
   } else if (icp->n > 0) {
@@ -1070,6 +1174,31 @@ pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double ma
   }
   *nr = uint64_t(cnt);
   if (cnt > 0.0) *score = sum / cnt;
+  return PCLHIP_OK;
+}
+
+// sums[NS] (host) of the estimator `mode` over n explicit pairs (dense float4 device arrays)
+pclhip_status launch_estimate_pairs(pclhip_ctx* ctx, int mode, const float4* src, const float4* src_nrm,
+                                    const float4* tgt, const float4* tgt_nrm, uint32_t n, bool enforce, double* sums) {
+  hipStream_t s = ctx->stream;
+  const int grid = ctx->num_cus * 4;
+  double* dev = nullptr;  // partials [grid][NS] + sums [NS]
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&dev, (size_t(grid) + 1) * NS * sizeof(double)));
+  if (mode == PCLHIP_ICP_POINT_TO_PLANE)
+    hipLaunchKernelGGL(estimate_pairs_kernel<PCLHIP_ICP_POINT_TO_PLANE>, dim3(grid), dim3(BLOCK), 0, s, src, src_nrm, tgt,
+                       tgt_nrm, n, enforce ? 1 : 0, dev);
+  else if (mode == PCLHIP_ICP_SYMMETRIC)
+    hipLaunchKernelGGL(estimate_pairs_kernel<PCLHIP_ICP_SYMMETRIC>, dim3(grid), dim3(BLOCK), 0, s, src, src_nrm, tgt,
+                       tgt_nrm, n, enforce ? 1 : 0, dev);
+  else
+    hipLaunchKernelGGL(estimate_pairs_kernel<PCLHIP_ICP_POINT_TO_POINT>, dim3(grid), dim3(BLOCK), 0, s, src, src_nrm, tgt,
+                       tgt_nrm, n, enforce ? 1 : 0, dev);
+  hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, dev, grid, dev + size_t(grid) * NS);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(sums, dev + size_t(grid) * NS, NS * sizeof(double), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(dev);
+  PCLHIP_CHECK_HIP(ctx, e);
   return PCLHIP_OK;
 }
 

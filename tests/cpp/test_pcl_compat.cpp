@@ -154,6 +154,52 @@ int main(int argc, char** argv) {
     grid.filter(out);
     EXPECT(out.size() == 103 && out.width == 103 && out.height == 1 && out.is_dense);
   }
+  {  // estimators on explicit pairs: test/registration/test_registration_api.cpp:469-518, :663-712 (1e-2)
+    PointCloud<PointNormal> src, tgt;
+    const float G[16] = {0.9938f, 0.0988f, 0.0517f, 0.1000f, -0.0997f, 0.9949f, 0.0149f, -0.2000f,
+                         -0.0500f, -0.0200f, 0.9986f, 0.3000f, 0, 0, 0, 1};
+    for (float x = -5.0f; x <= 5.0f; x += 0.5f)
+      for (float y = -5.0f; y <= 5.0f; y += 0.5f) {
+        PointNormal p;
+        p.x = x; p.y = y; p.z = 0.1f * x * x + 0.2f * x * y - 0.3f * y + 1.0f;
+        float nx = -0.2f * x - 0.2f, ny = 0.6f * y - 0.2f, nz = 1.0f;
+        const float m = std::sqrt(nx * nx + ny * ny + nz * nz);
+        p.normal_x = nx / m; p.normal_y = ny / m; p.normal_z = nz / m;
+        src.push_back(p);
+      }
+    tgt = src;
+    pclhip_transform_cloud(ctx->get(), G, 1, src.points.data(), tgt.points.data(), sizeof(PointNormal), src.size(), 16);
+    Matrix4f T;
+    registration::TransformationEstimationSymmetricPointToPlaneLLS<PointNormal, PointNormal> sym(ctx);
+    EXPECT(sym.estimateRigidTransformation(src, tgt, T));
+    for (int i = 0; i < 16; ++i) EXPECT(std::fabs(T.m[i] - G[i]) < 1e-2f);
+    registration::TransformationEstimationPointToPlaneLLS<PointNormal, PointNormal> lls(ctx);
+    EXPECT(lls.estimateRigidTransformation(src, tgt, T));
+    for (int i = 0; i < 16; ++i) EXPECT(std::fabs(T.m[i] - G[i]) < 1e-2f);
+    registration::TransformationEstimationSVD<PointNormal, PointNormal> svd(ctx);
+    EXPECT(svd.estimateRigidTransformation(src, tgt, T));
+    for (int i = 0; i < 16; ++i) EXPECT(std::fabs(T.m[i] - G[i]) < 1e-4f);
+    // IterativeClosestPointWithNormals + setUseSymmetricObjective on PointNormal clouds: a motion small
+    // against the 0.5 grid spacing, so nearest neighbours are the true pairs and the motion is recovered
+    const float c = std::cos(0.02f), sn = std::sin(0.02f);
+    const float G2[16] = {c, -sn, 0, 0.03f, sn, c, 0, -0.02f, 0, 0, 1, 0.04f, 0, 0, 0, 1};
+    PointCloud<PointNormal> tgt_small = src;
+    pclhip_transform_cloud(ctx->get(), G2, 1, src.points.data(), tgt_small.points.data(), sizeof(PointNormal), src.size(), 16);
+    auto s2 = std::make_shared<PointCloud<PointNormal>>(src);
+    auto t2 = std::make_shared<PointCloud<PointNormal>>(tgt_small);
+    IterativeClosestPointWithNormals<PointNormal, PointNormal> reg(ctx);
+    reg.setUseSymmetricObjective(true);
+    EXPECT(reg.getUseSymmetricObjective());
+    reg.setInputSource(s2);
+    reg.setInputTarget(t2);
+    reg.setMaximumIterations(50);
+    PointCloud<PointNormal> out;
+    reg.align(out);
+    EXPECT(reg.hasConverged());
+    const Matrix4f F = reg.getFinalTransformation();
+    for (int i = 0; i < 16; ++i) EXPECT(std::fabs(F.m[i] - G2[i]) < 1e-3f);
+    EXPECT(reg.getFitnessScore() < 1e-6);
+  }
   std::printf(failures ? "%d FAILURES\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
 }

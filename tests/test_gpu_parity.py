@@ -734,3 +734,86 @@ def test_fitness_score_vs_oracle(gpu, orc):
     s1 = icp.iterate(np.eye(4, dtype=np.float32), max_dist=0.1)
     q1 = icp.fetchCorrespondences()
     assert np.array_equal(s0, s1) and all(np.array_equal(a, b) for a, b in zip(q0, q1))
+
+
+# ------------------------------------------------------------------------------------------------
+# transformation estimators on explicit pairs + the symmetric objective
+# ------------------------------------------------------------------------------------------------
+def _quadric_with_normals():
+    # the test surface of test/registration/test_registration_api.cpp:469-518 and :663-712
+    xs = np.arange(-5.0, 5.0001, 0.5, dtype=np.float32)
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    x, y = X.ravel(), Y.ravel()
+    z = np.float32(0.1) * x ** 2 + np.float32(0.2) * x * y - np.float32(0.3) * y + np.float32(1.0)
+    n = np.stack([-0.2 * x - 0.2, 0.6 * y - 0.2, np.ones_like(x)], 1).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    return np.stack([x, y, z, np.ones_like(x)], 1).astype(np.float32), n
+
+
+def test_estimators_known_answers_and_oracle(gpu, orc, golden):
+    # test/registration/test_registration_api.cpp:383-424 (SVD), :469-518 (LLS), :663-712 (symmetric LLS)
+    import pcl_amd
+    src, sn = _quadric_with_normals()
+    G = np.asarray(golden["lls_ground_truth"], np.float32)
+    tgt, tn = orc.transform_cloud(G, src, order=1, normals=sn)
+    # point-to-plane LLS
+    T, sums = pcl_amd.estimateRigidTransformation(gpu, pcl_amd.POINT_TO_PLANE, src, tgt, tgt_normals=tn)
+    To, so, used = orc.lls_point_to_plane(src, tgt, tn)
+    assert np.abs(T - G).max() < golden["lls_tol"]
+    assert sums[28] == used == 441
+    assert np.allclose(sums[:27], so, rtol=1e-11, atol=1e-13)   # fp64 sums, different summation order
+    assert np.abs(T - To).max() < 1e-6
+    # symmetric LLS (tolerance of the reference test: 1e-2)
+    for flip, enforce in ((1.0, True), (-1.0, True)):
+        T, sums = pcl_amd.estimateRigidTransformation(gpu, pcl_amd.SYMMETRIC, src, tgt, src_normals=sn,
+                                                      tgt_normals=np.float32(flip) * tn,
+                                                      enforce_same_direction_normals=enforce)
+        To, so, used = orc.lls_symmetric(src, sn, tgt, np.float32(flip) * tn, enforce_same_direction=enforce)
+        assert np.abs(T - G).max() < 1e-2
+        assert sums[28] == used
+        assert np.allclose(sums[:27], so, rtol=1e-11, atol=1e-13)
+        assert np.abs(T - To).max() < 1e-6
+    # SVD / umeyama: exact recovery of a rigid motion to 2e-6 (the reference tests 1e-6 on quaternion + t)
+    T, sums = pcl_amd.estimateRigidTransformation(gpu, pcl_amd.POINT_TO_POINT, src, tgt)
+    assert np.abs(T - orc.umeyama(src, tgt, acc_double=True)).max() < 2e-6
+    # size mismatch is refused like the reference (transformation_estimation_svd.hpp:53-60)
+    with pytest.raises(AssertionError):
+        pcl_amd.estimateRigidTransformation(gpu, pcl_amd.POINT_TO_POINT, src, tgt[:-1])
+
+
+def test_icp_symmetric_objective_vs_oracle(gpu, orc, bunny):
+    # test/registration/test_registration.cpp:305-318 (setUseSymmetricObjective) on the bunny pair
+    import pcl_amd
+    from oracle import rejectors as rej
+    src, tgt = xyz1(bunny["bun0"]), xyz1(bunny["bun4"])
+    # normals of both clouds from the oracle so that both sides start from identical inputs
+    tn, _ = orc.KdTree(tgt).normals(tgt, 15, viewpoint=(0, 0, 10))
+    sn, _ = orc.KdTree(src).normals(src, 15, viewpoint=(0, 0, 10))
+    tn = np.ascontiguousarray(tn[:, :3], np.float32)
+    sn = np.ascontiguousarray(sn[:, :3], np.float32)
+    for enforce in (True, False):
+        icp = pcl_amd.IterativeClosestPointWithNormals(gpu)
+        icp.setInputTarget(tgt)
+        icp.setTargetNormals(tn)
+        icp.setInputSource(src)
+        icp.setSourceNormals(sn)
+        icp.setUseSymmetricObjective(True)
+        assert icp.getUseSymmetricObjective()
+        icp.setEnforceSameDirectionNormals(enforce)
+        icp.setMaximumIterations(30)
+        icp.setMaxCorrespondenceDistance(0.05)
+        icp.setTransformationEpsilon(1e-8)
+        icp.align()
+        ref = rej.icp_with_filters(orc, tgt, src, 2, tgt_normals=tn, src_normals=sn, enforce_same_direction=enforce,
+                                   max_iterations=30, max_correspondence_distance=0.05, transformation_epsilon=1e-8)
+        assert icp.nr_iterations_ == ref["iterations"]
+        assert np.linalg.norm(icp.getFinalTransformation().astype(np.float64) - ref["T"]) < 1e-5
+        assert icp.hasConverged() == ref["converged"]
+    # without source normals the symmetric objective is refused
+    icp = pcl_amd.IterativeClosestPointWithNormals(gpu)
+    icp.setInputTarget(tgt)
+    icp.setTargetNormals(tn)
+    icp.setInputSource(src)
+    icp.setUseSymmetricObjective(True)
+    with pytest.raises(pcl_amd.PclHipError):
+        icp.align()

@@ -271,3 +271,31 @@ def test_fitness_score_known_answer():
     assert score == 0.0 and nr == 3
     score, nr = tree.fitness_score(src, np.eye(4, dtype=np.float32), -1.0)
     assert score == np.finfo(np.float64).max and nr == 0
+
+
+def _quadric_with_normals():
+    # the test surface of test/registration/test_registration_api.cpp:469-518 and :663-712
+    xs = np.arange(-5.0, 5.0001, 0.5, dtype=np.float32)
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    x, y = X.ravel(), Y.ravel()
+    z = np.float32(0.1) * x ** 2 + np.float32(0.2) * x * y - np.float32(0.3) * y + np.float32(1.0)
+    n = np.stack([-0.2 * x - 0.2, 0.6 * y - 0.2, np.ones_like(x)], 1).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    return np.stack([x, y, z, np.ones_like(x)], 1).astype(np.float32), n
+
+
+def test_symmetric_lls_known_answer(golden):
+    # test/registration/test_registration_api.cpp:663-712 (tolerance 1e-2, same ground truth as the LLS test)
+    src, sn = _quadric_with_normals()
+    G = np.asarray(golden["lls_ground_truth"], np.float32)
+    tgt, tn = orc.transform_cloud(G, src, order=1, normals=sn)
+    for acc in (False, True):
+        T, sums, used = orc.lls_symmetric(src, sn, tgt, tn, acc_double=acc)
+        assert used == 441
+        assert np.abs(T - G).max() < 1e-2, (acc, np.abs(T - G).max())
+        assert np.array_equal(orc.symmetric_solve(sums), T)
+    # flipped target normals: enforce_same_direction recovers the same answer, without it the system changes
+    T1, _, _ = orc.lls_symmetric(src, sn, tgt, -tn, enforce_same_direction=True)
+    assert np.abs(T1 - G).max() < 1e-2
+    T2, _, _ = orc.lls_symmetric(src, sn, tgt, -tn, enforce_same_direction=False)
+    assert not np.abs(T2 - G).max() < 1e-2
