@@ -288,6 +288,39 @@ PCLHIP_API pclhip_status pclhip_voxelgrid(pclhip_ctx* ctx, const void* points, s
                                           int has_z_limits, double z_min, double z_max,
                                           void* out_xyzw, uint64_t* out_n);
 
+/* ---- PCD files (io/src/pcd_io.cpp: PCDReader :115-675, PCDWriter :848-1500) ----------------------
+ * The on-disk format either side of the path.  ascii, binary and binary_compressed (LZF, fields stored
+ * as struct of arrays) are read straight into the strided records the calls above consume.  Errors are
+ * reported through pclhip_last_error(NULL). */
+typedef struct {
+  uint64_t points;       /* POINTS */
+  uint32_t width, height;
+  int data_type;         /* 0 ascii, 1 binary, 2 binary_compressed */
+  int version;           /* 7 when a VIEWPOINT line is present, else 6 */
+  uint32_t point_step;   /* bytes per point in the file */
+  uint32_t num_fields;
+  int has_xyz, has_normals, has_curvature, has_intensity, has_rgb;
+  float viewpoint[7];    /* tx ty tz qw qx qy qz */
+  uint64_t data_offset;  /* byte offset of the body */
+} pclhip_pcd_info;
+
+/* PCDReader::readHeader */
+PCLHIP_API pclhip_status pclhip_pcd_read_header(const char* path, pclhip_pcd_info* info);
+/* pcl::io::loadPCDFile into records of stride_bytes: x,y,z at +0 (and 1.0f at +12 when the record has
+ * room, like PointXYZ); if normals_offset != 0 and the file has normal_x/y/z they go to +normals_offset
+ * (3 floats, then 0.0f, then curvature at +normals_offset+16 when the file has it and the record has
+ * room -- the PointNormal layout with normals_offset = 16, stride 48).  float64 / integer fields are
+ * converted.  points: host or device memory holding `capacity` records; *n_out = POINTS (also when the
+ * buffer is too small: PCLHIP_ERR_OVERFLOW); *is_dense as the reference computes it. */
+PCLHIP_API pclhip_status pclhip_pcd_read(const char* path, void* points, size_t stride_bytes,
+                                         size_t normals_offset, uint64_t capacity, uint64_t* n_out,
+                                         int* is_dense);
+/* pcl::io::savePCDFile{ASCII,Binary,BinaryCompressed}: unorganized cloud of n records (x y z, plus
+ * normal_x normal_y normal_z [curvature] when normals_offset != 0); precision: significant digits of the
+ * ascii writer (<= 0: the reference's default 8). */
+PCLHIP_API pclhip_status pclhip_pcd_write(const char* path, const void* points, size_t stride_bytes,
+                                          size_t normals_offset, uint64_t n, int data_type, int precision);
+
 #ifdef __cplusplus
 }
 #endif

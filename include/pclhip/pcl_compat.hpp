@@ -495,6 +495,35 @@ template <typename S, typename T> using TransformationEstimationPointToPlaneLLS 
 template <typename S, typename T> using TransformationEstimationSymmetricPointToPlaneLLS = TransformationEstimation<S, T, PCLHIP_ICP_SYMMETRIC>;
 }  // namespace registration
 
+// pcl::io::loadPCDFile / savePCDFile{ASCII,Binary,BinaryCompressed} (io/include/pcl/io/pcd_io.h:685-800)
+// for the point types of this header: records of sizeof(PointT) bytes, normals at +16 when the type has them.
+namespace io {
+template <typename PointT>
+int loadPCDFile(const std::string& file_name, PointCloud<PointT>& cloud) {
+  pclhip_pcd_info info;
+  if (pclhip_pcd_read_header(file_name.c_str(), &info) != PCLHIP_OK) return -1;
+  cloud.points.assign(info.points, PointT());
+  uint64_t n = 0;
+  int dense = 1;
+  const std::size_t nrm_off = sizeof(PointT) >= 28 ? 16 : 0;
+  if (pclhip_pcd_read(file_name.c_str(), cloud.points.data(), sizeof(PointT), nrm_off, info.points, &n, &dense) != PCLHIP_OK)
+    return -1;
+  cloud.width = info.width;
+  cloud.height = info.height;
+  cloud.is_dense = dense != 0;
+  return 0;
+}
+template <typename PointT>
+int savePCDFile(const std::string& file_name, const PointCloud<PointT>& cloud, int data_type, int precision = 8) {
+  const std::size_t nrm_off = sizeof(PointT) >= 28 ? 16 : 0;
+  return pclhip_pcd_write(file_name.c_str(), cloud.points.data(), sizeof(PointT), nrm_off, cloud.size(), data_type,
+                          precision) == PCLHIP_OK ? 0 : -1;
+}
+template <typename PointT> int savePCDFileASCII(const std::string& f, const PointCloud<PointT>& c) { return savePCDFile(f, c, 0); }
+template <typename PointT> int savePCDFileBinary(const std::string& f, const PointCloud<PointT>& c) { return savePCDFile(f, c, 1); }
+template <typename PointT> int savePCDFileBinaryCompressed(const std::string& f, const PointCloud<PointT>& c) { return savePCDFile(f, c, 2); }
+}  // namespace io
+
 // pcl::VoxelGrid<pcl::PointXYZ>
 class VoxelGrid {
  public:

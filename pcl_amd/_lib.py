@@ -51,6 +51,16 @@ class Rejector(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+class PcdInfo(C.Structure):
+    _fields_ = [("points", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32), ("data_type", C.c_int),
+                ("version", C.c_int), ("point_step", C.c_uint32), ("num_fields", C.c_uint32),
+                ("has_xyz", C.c_int), ("has_normals", C.c_int), ("has_curvature", C.c_int),
+                ("has_intensity", C.c_int), ("has_rgb", C.c_int), ("viewpoint", C.c_float * 7),
+                ("data_offset", C.c_uint64)]
+
+
+PCD_ASCII, PCD_BINARY, PCD_BINARY_COMPRESSED = 0, 1, 2
+
 REJ_DISTANCE, REJ_MEDIAN_DISTANCE, REJ_ONE_TO_ONE, REJ_TRIMMED = 0, 1, 2, 3
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
@@ -100,6 +110,9 @@ SIGNATURES = {
                                                        C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "pclhip_transform_cloud": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int, _vp, _vp, _sz, _u64,
                                          _sz]),
+    "pclhip_pcd_read_header": (C.c_int, [C.c_char_p, C.POINTER(PcdInfo)]),
+    "pclhip_pcd_read": (C.c_int, [C.c_char_p, _vp, _sz, _sz, _u64, C.POINTER(_u64), C.POINTER(C.c_int)]),
+    "pclhip_pcd_write": (C.c_int, [C.c_char_p, _vp, _sz, _sz, _u64, C.c_int, C.c_int]),
     "pclhip_voxelgrid": (C.c_int, [_vp, _vp, _sz, _u64, C.POINTER(C.c_float), C.c_uint32, C.c_int,
                                    C.c_double, C.c_double, _vp, C.POINTER(_u64)]),
 }

@@ -10,6 +10,7 @@ Clouds are (n, c>=3) float32 arrays: numpy (host) or torch CUDA tensors (device-
 pointer crosses the boundary).  All compute happens in libpclhip.so; there is no CPU fallback.
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -628,6 +629,45 @@ def estimateRigidTransformation(ctx, mode, src, tgt, src_normals=None, tgt_norma
         ctx.h, int(mode), sp, ss, snp, sns, tp, ts, tnp, tns, n, 1 if enforce_same_direction_normals else 0,
         _fp(T), sums.ctypes.data_as(C.POINTER(C.c_double))), ctx.h)
     return T.reshape(4, 4), sums
+
+
+def getPCDHeader(path):
+    """PCDReader::readHeader (io/src/pcd_io.cpp:115-392) -> _lib.PcdInfo"""
+    info = _lib.PcdInfo()
+    check(_lib.load().pclhip_pcd_read_header(os.fsencode(path), C.byref(info)))
+    return info
+
+
+def loadPCDFile(path, with_normals=False, device=None):
+    """pcl::io::loadPCDFile into PointXYZ records [n,4] (x,y,z,1) or PointNormal records [n,12]
+    (x,y,z,1, nx,ny,nz,0, curvature,0,0,0).  device=None -> numpy array, else a torch tensor on that
+    device (the library writes straight into its memory).  Returns (cloud, is_dense)."""
+    lib = _lib.load()
+    info = getPCDHeader(path)
+    n = int(info.points)
+    cols = 12 if with_normals else 4
+    dense = C.c_int(1)
+    cnt = C.c_uint64(0)
+    if device is None:
+        out = np.zeros((n, cols), np.float32)
+        ptr = C.c_void_p(out.ctypes.data)
+    else:
+        import torch
+        out = torch.zeros((n, cols), dtype=torch.float32, device=device)
+        ptr = C.c_void_p(out.data_ptr())
+    check(lib.pclhip_pcd_read(os.fsencode(path), ptr, cols * 4, 16 if with_normals else 0, n, C.byref(cnt),
+                              C.byref(dense)))
+    return out, bool(dense.value)
+
+
+def savePCDFile(path, cloud, mode="binary", precision=8):
+    """pcl::io::savePCDFile{ASCII,Binary,BinaryCompressed}; clouds with >= 7 columns (PointNormal layout:
+    normals at floats 4..6, curvature at float 8 when present) are written with their normals."""
+    data_type = {"ascii": 0, "binary": 1, "binary_compressed": 2}[mode]
+    ptr, stride, n, keep = _cloud(cloud)
+    ncol = stride // 4
+    check(_lib.load().pclhip_pcd_write(os.fsencode(path), ptr, stride, 16 if ncol >= 7 else 0, n, data_type,
+                                       int(precision)))
 
 
 class VoxelGrid:

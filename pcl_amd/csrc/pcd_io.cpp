@@ -1,0 +1,663 @@
+// pcd_io.cpp -- PCD reader / writer for the clouds either side of the ICP path (SURVEY.md section 8(f)
+// rank 4): ascii, binary and binary_compressed (LZF) files straight into the strided point records the
+// rest of the C ABI consumes (PointXYZ 16 B, PointNormal 48 B, ...; host, pinned or device memory).
+//
+// Format and semantics follow io/src/pcd_io.cpp of the reference:
+//   header      PCDReader::readHeader            :115-392  (FIELDS/SIZE/TYPE/COUNT/WIDTH/HEIGHT/VIEWPOINT/POINTS/DATA)
+//   ascii body  PCDReader::readBodyASCII         :456-559  (one point per line, "nan" allowed)
+//   binary      PCDReader::readBodyBinary        :561-675  (array of structs; compressed: u32 compressed size,
+//                                                            u32 uncompressed size, LZF stream holding the fields as
+//                                                            struct of arrays: all x, all y, ...)
+//   writer      PCDWriter::generateHeader*, writeASCII / writeBinary / writeBinaryCompressed :848-1500
+// LZF is liblzf's format (Marc Lehmann), which the reference vendors as io/src/lzf.cpp: a control byte
+// c < 32 starts a literal run of c + 1 bytes; otherwise a back reference of length (c >> 5) + 2 (a
+// length field of 7 is extended by the next byte) at distance (((c & 31) << 8) | next byte) + 1.
+#include <hip/hip_runtime.h>
+
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "pclhip_internal.hpp"
+
+using namespace pclhip;
+
+namespace {
+
+struct Field {
+  std::string name;
+  int size = 4;      // bytes per element
+  char type = 'F';   // F float, I signed, U unsigned
+  int count = 1;
+  size_t offset = 0;  // byte offset inside one point (array-of-structs layout)
+};
+
+struct Header {
+  std::vector<Field> fields;
+  uint64_t points = 0;
+  uint32_t width = 0, height = 0;
+  int data_type = 0, version = 6;
+  size_t point_step = 0;
+  float viewpoint[7] = {0, 0, 0, 1, 0, 0, 0};
+  uint64_t data_offset = 0;
+};
+
+std::vector<std::string> split_ws(const std::string& line) {
+  std::vector<std::string> out;
+  size_t i = 0;
+  while (i < line.size()) {
+    while (i < line.size() && (line[i] == ' ' || line[i] == '\t' || line[i] == '\r')) ++i;
+    size_t j = i;
+    while (j < line.size() && line[j] != ' ' && line[j] != '\t' && line[j] != '\r') ++j;
+    if (j > i) out.push_back(line.substr(i, j - i));
+    i = j;
+  }
+  return out;
+}
+
+bool starts_with(const std::string& s, const char* p) { return s.compare(0, std::strlen(p), p) == 0; }
+
+// PCDReader::readHeader, io/src/pcd_io.cpp:115-392.  `err` receives the reference's message on failure.
+bool parse_header(const std::string& bytes, Header& h, std::string& err) {
+  size_t pos = 0;
+  bool width_read = false, height_read = false, points_read = false, data_seen = false;
+  std::vector<int> sizes;
+  std::vector<char> types;
+  while (pos < bytes.size()) {
+    size_t eol = bytes.find('\n', pos);
+    if (eol == std::string::npos) eol = bytes.size();
+    const std::string line = bytes.substr(pos, eol - pos);
+    pos = eol + 1;
+    const std::vector<std::string> st = split_ws(line);
+    if (st.empty()) continue;
+    const std::string& key = st[0];
+    if (key[0] == '#') continue;
+    if (starts_with(key, "VERSION")) continue;
+    if (starts_with(key, "FIELDS") || starts_with(key, "COLUMNS")) {
+      h.fields.assign(st.size() - 1, Field());
+      size_t off = 0;
+      for (size_t i = 0; i + 1 < st.size(); ++i) {  // older files: everything float32 unless SIZE/TYPE say otherwise
+        h.fields[i].name = st[i + 1];
+        h.fields[i].offset = off;
+        off += 4;
+      }
+      h.point_step = off;
+      continue;
+    }
+    if (starts_with(key, "SIZE")) {
+      if (st.size() - 1 != h.fields.size()) {
+        err = "The number of elements in <SIZE> differs than the number of elements in <FIELDS>!";
+        return false;
+      }
+      sizes.resize(h.fields.size());
+      size_t off = 0;
+      for (size_t i = 0; i < h.fields.size(); ++i) {
+        sizes[i] = std::atoi(st[i + 1].c_str());
+        h.fields[i].size = sizes[i];
+        h.fields[i].offset = off;
+        off += size_t(sizes[i]);
+      }
+      h.point_step = off;
+      continue;
+    }
+    if (starts_with(key, "TYPE")) {
+      if (sizes.empty()) {
+        err = "TYPE of FIELDS specified before SIZE in header!";
+        return false;
+      }
+      if (st.size() - 1 != h.fields.size()) {
+        err = "The number of elements in <TYPE> differs than the number of elements in <FIELDS>!";
+        return false;
+      }
+      types.resize(h.fields.size());
+      for (size_t i = 0; i < h.fields.size(); ++i) {
+        types[i] = st[i + 1][0];
+        h.fields[i].type = types[i];
+      }
+      continue;
+    }
+    if (starts_with(key, "COUNT")) {
+      if (sizes.empty() || types.empty()) {
+        err = "COUNT of FIELDS specified before SIZE or TYPE in header!";
+        return false;
+      }
+      if (st.size() - 1 != h.fields.size()) {
+        err = "The number of elements in <COUNT> differs than the number of elements in <FIELDS>!";
+        return false;
+      }
+      size_t off = 0;
+      for (size_t i = 0; i < h.fields.size(); ++i) {
+        h.fields[i].offset = off;
+        h.fields[i].count = std::atoi(st[i + 1].c_str());
+        off += size_t(h.fields[i].count > 0 ? h.fields[i].count : 0) * size_t(sizes[i]);
+      }
+      h.point_step = off;
+      continue;
+    }
+    if (starts_with(key, "WIDTH")) {
+      if (st.size() < 2) {
+        err = "Invalid WIDTH value specified.";
+        return false;
+      }
+      h.width = uint32_t(std::strtoul(st[1].c_str(), nullptr, 10));
+      width_read = true;
+      continue;
+    }
+    if (starts_with(key, "HEIGHT")) {
+      if (st.size() < 2) {
+        err = "Invalid HEIGHT value specified.";
+        return false;
+      }
+      h.height = uint32_t(std::strtoul(st[1].c_str(), nullptr, 10));
+      height_read = true;
+      continue;
+    }
+    if (starts_with(key, "VIEWPOINT")) {
+      h.version = 7;
+      if (st.size() < 8) {
+        err = "Not enough number of elements in <VIEWPOINT>! Need 7 values (tx ty tz qw qx qy qz).";
+        return false;
+      }
+      for (int i = 0; i < 7; ++i) h.viewpoint[i] = std::strtof(st[size_t(i) + 1].c_str(), nullptr);
+      continue;
+    }
+    if (starts_with(key, "POINTS")) {
+      if (h.point_step == 0) {
+        err = "Number of POINTS specified before COUNT in header!";
+        return false;
+      }
+      h.points = st.size() > 1 ? std::strtoull(st[1].c_str(), nullptr, 10) : 0;
+      points_read = true;
+      continue;
+    }
+    if (starts_with(key, "DATA")) {
+      if (st.size() < 2) continue;
+      if (starts_with(st[1], "binary_compressed"))
+        h.data_type = 2;
+      else if (starts_with(st[1], "binary"))
+        h.data_type = 1;
+      else if (starts_with(st[1], "ascii"))
+        h.data_type = 0;
+      else
+        continue;  // unknown DATA format: the reference warns and reads on
+      h.data_offset = pos;
+      data_seen = true;
+    }
+    break;  // DATA is the last header entry (also: any unknown line ends the header, as in the reference)
+  }
+  (void)points_read;
+  (void)data_seen;
+  // fields with COUNT < 1 are dropped (:339-341)
+  {
+    std::vector<Field> kept;
+    for (const Field& f : h.fields)
+      if (f.count >= 1) kept.push_back(f);
+    h.fields.swap(kept);
+  }
+  if (!width_read && !height_read) {
+    h.width = uint32_t(h.points);
+    h.height = 1;
+  }
+  if (!height_read) {
+    h.height = 1;
+    if (h.width == 0) h.width = uint32_t(h.points);
+  } else if (h.width == 0 && h.points != 0) {
+    err = "HEIGHT given but no WIDTH!";
+    return false;
+  }
+  if (uint64_t(h.width) * uint64_t(h.height) != h.points) {
+    err = "HEIGHT x WIDTH != number of points";
+    return false;
+  }
+  return true;
+}
+
+// liblzf decompression (the reference's pcl::lzfDecompress, io/src/lzf.cpp): returns the number of
+// bytes produced, 0 on malformed input or if the output would not fit
+size_t lzf_decompress(const unsigned char* ip, size_t in_len, unsigned char* op, size_t out_len) {
+  const unsigned char* const in_end = ip + in_len;
+  unsigned char* const out_begin = op;
+  unsigned char* const out_end = op + out_len;
+  while (ip < in_end) {
+    unsigned ctrl = *ip++;
+    if (ctrl < 32) {  // literal run
+      ++ctrl;
+      if (op + ctrl > out_end || ip + ctrl > in_end) return 0;
+      std::memcpy(op, ip, ctrl);
+      op += ctrl;
+      ip += ctrl;
+    } else {  // back reference
+      size_t len = ctrl >> 5;
+      if (ip >= in_end) return 0;
+      if (len == 7) {
+        len += *ip++;
+        if (ip >= in_end) return 0;
+      }
+      const size_t dist = (size_t(ctrl & 0x1f) << 8) + size_t(*ip++) + 1;
+      len += 2;
+      if (size_t(op - out_begin) < dist || op + len > out_end) return 0;
+      const unsigned char* ref = op - dist;
+      for (size_t i = 0; i < len; ++i) op[i] = ref[i];  // may overlap: byte by byte
+      op += len;
+    }
+  }
+  return size_t(op - out_begin);
+}
+
+// liblzf-format compressor: greedy matcher over a hash of 3-byte sequences.  Any stream this produces
+// is decoded by the reference's lzfDecompress; it is not byte-identical to the reference's compressor
+// (nothing depends on that).  Returns 0 if the result would not fit into out_len.
+size_t lzf_compress(const unsigned char* in, size_t in_len, unsigned char* out, size_t out_len) {
+  constexpr int HLOG = 16;
+  constexpr size_t MAX_LIT = 32, MAX_OFF = 1u << 13, MAX_REF = (1u << 8) + (1u << 3);
+  std::vector<uint32_t> htab(size_t(1) << HLOG, 0xFFFFFFFFu);
+  size_t ip = 0, op = 0, lit_start = 0;
+  auto flush_literals = [&](size_t end) -> bool {
+    while (lit_start < end) {
+      const size_t run = (end - lit_start) < MAX_LIT ? (end - lit_start) : MAX_LIT;
+      if (op + 1 + run > out_len) return false;
+      out[op++] = (unsigned char)(run - 1);
+      std::memcpy(out + op, in + lit_start, run);
+      op += run;
+      lit_start += run;
+    }
+    return true;
+  };
+  while (ip + 2 < in_len) {
+    const uint32_t v = (uint32_t(in[ip]) << 16) | (uint32_t(in[ip + 1]) << 8) | in[ip + 2];
+    const uint32_t hs = ((v * 2654435761u) >> (32 - HLOG));
+    const uint32_t ref = htab[hs];
+    htab[hs] = uint32_t(ip);
+    if (ref != 0xFFFFFFFFu && ip - ref <= MAX_OFF && ip > ref && in[ref] == in[ip] && in[ref + 1] == in[ip + 1] &&
+        in[ref + 2] == in[ip + 2]) {
+      size_t len = 3;
+      const size_t max_len = (in_len - ip) < MAX_REF ? (in_len - ip) : MAX_REF;
+      while (len < max_len && in[ref + len] == in[ip + len]) ++len;
+      if (!flush_literals(ip)) return 0;
+      const size_t off = ip - ref - 1, l = len - 2;
+      if (op + 3 > out_len) return 0;
+      if (l < 7) {
+        out[op++] = (unsigned char)((off >> 8) + (l << 5));
+      } else {
+        out[op++] = (unsigned char)((off >> 8) + (7u << 5));
+        out[op++] = (unsigned char)(l - 7);
+      }
+      out[op++] = (unsigned char)(off & 0xff);
+      ip += len;
+      lit_start = ip;
+    } else {
+      ++ip;
+    }
+  }
+  if (!flush_literals(in_len)) return 0;
+  return op;
+}
+
+bool read_file(const char* path, std::string& bytes, std::string& err) {
+  std::FILE* f = std::fopen(path, "rb");
+  if (!f) {
+    err = std::string("cannot open ") + path + ": " + std::strerror(errno);
+    return false;
+  }
+  std::fseek(f, 0, SEEK_END);
+  const long sz = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  bytes.resize(sz > 0 ? size_t(sz) : 0);
+  const size_t got = bytes.empty() ? 0 : std::fread(&bytes[0], 1, bytes.size(), f);
+  std::fclose(f);
+  if (got != bytes.size()) {
+    err = std::string("short read on ") + path;
+    return false;
+  }
+  return true;
+}
+
+int find_field(const Header& h, const char* name) {
+  for (size_t i = 0; i < h.fields.size(); ++i)
+    if (h.fields[i].name == name) return int(i);
+  return -1;
+}
+
+// element `c` of field f of a point stored array-of-structs at p, as double
+double load_value(const unsigned char* p, const Field& f, int c) {
+  const unsigned char* q = p + f.offset + size_t(c) * size_t(f.size);
+  switch (f.type) {
+    case 'F':
+      if (f.size == 4) { float v; std::memcpy(&v, q, 4); return v; }
+      if (f.size == 8) { double v; std::memcpy(&v, q, 8); return v; }
+      break;
+    case 'I':
+      if (f.size == 1) { int8_t v; std::memcpy(&v, q, 1); return v; }
+      if (f.size == 2) { int16_t v; std::memcpy(&v, q, 2); return v; }
+      if (f.size == 4) { int32_t v; std::memcpy(&v, q, 4); return v; }
+      if (f.size == 8) { int64_t v; std::memcpy(&v, q, 8); return double(v); }
+      break;
+    default:
+      if (f.size == 1) { uint8_t v; std::memcpy(&v, q, 1); return v; }
+      if (f.size == 2) { uint16_t v; std::memcpy(&v, q, 2); return v; }
+      if (f.size == 4) { uint32_t v; std::memcpy(&v, q, 4); return v; }
+      if (f.size == 8) { uint64_t v; std::memcpy(&v, q, 8); return double(v); }
+  }
+  return 0.0;
+}
+
+void store_ascii_value(unsigned char* p, const Field& f, int c, const std::string& tok, bool& dense) {
+  unsigned char* q = p + f.offset + size_t(c) * size_t(f.size);
+  if (f.type == 'F') {
+    // copyStringValue (pcd_io.h): "nan" -> quiet NaN and the cloud is not dense
+    double v;
+    if (tok == "nan" || tok == "-nan" || tok == "NaN") {
+      v = std::nan("");
+      dense = false;
+    } else {
+      v = std::strtod(tok.c_str(), nullptr);
+      if (!std::isfinite(v)) dense = false;
+    }
+    if (f.size == 4) { const float x = float(v); std::memcpy(q, &x, 4); }
+    else if (f.size == 8) std::memcpy(q, &v, 8);
+  } else if (f.type == 'I') {
+    const long long v = std::strtoll(tok.c_str(), nullptr, 10);
+    if (f.size == 1) { const int8_t x = int8_t(v); std::memcpy(q, &x, 1); }
+    else if (f.size == 2) { const int16_t x = int16_t(v); std::memcpy(q, &x, 2); }
+    else if (f.size == 4) { const int32_t x = int32_t(v); std::memcpy(q, &x, 4); }
+    else if (f.size == 8) { const int64_t x = int64_t(v); std::memcpy(q, &x, 8); }
+  } else {
+    const unsigned long long v = std::strtoull(tok.c_str(), nullptr, 10);
+    if (f.size == 1) { const uint8_t x = uint8_t(v); std::memcpy(q, &x, 1); }
+    else if (f.size == 2) { const uint16_t x = uint16_t(v); std::memcpy(q, &x, 2); }
+    else if (f.size == 4) { const uint32_t x = uint32_t(v); std::memcpy(q, &x, 4); }
+    else if (f.size == 8) { const uint64_t x = uint64_t(v); std::memcpy(q, &x, 8); }
+  }
+}
+
+// the file's points as an array of structs (h.point_step bytes each); sets `dense` like the reference
+bool decode_body(const std::string& bytes, const Header& h, std::vector<unsigned char>& aos, bool& dense,
+                 std::string& err) {
+  dense = true;
+  aos.assign(size_t(h.points) * h.point_step, 0);
+  if (h.points == 0) return true;
+  if (h.data_type == 0) {  // readBodyASCII :456-559
+    size_t elems = 0;
+    for (const Field& f : h.fields) elems += size_t(f.count);
+    size_t pos = size_t(h.data_offset);
+    uint64_t idx = 0;
+    while (idx < h.points && pos < bytes.size()) {
+      size_t eol = bytes.find('\n', pos);
+      if (eol == std::string::npos) eol = bytes.size();
+      const std::string line = bytes.substr(pos, eol - pos);
+      pos = eol + 1;
+      if (line.empty()) continue;
+      const std::vector<std::string> st = split_ws(line);
+      if (st.empty()) continue;
+      if (st.size() != elems) {  // malformed line: the point is skipped but counted (:489-495)
+        ++idx;
+        continue;
+      }
+      size_t total = 0;
+      for (const Field& f : h.fields) {
+        if (f.name != "_")
+          for (int c = 0; c < f.count; ++c) store_ascii_value(&aos[size_t(idx) * h.point_step], f, c, st[total + size_t(c)], dense);
+        total += size_t(f.count);
+      }
+      ++idx;
+    }
+    if (idx != h.points) {
+      err = "Number of points read is different than expected";
+      return false;
+    }
+    return true;
+  }
+  if (h.data_type == 1) {  // binary: array of structs as is
+    if (h.data_offset + aos.size() > bytes.size()) {
+      err = "file is shorter than WIDTH x HEIGHT x point size";
+      return false;
+    }
+    std::memcpy(aos.data(), bytes.data() + h.data_offset, aos.size());
+  } else {  // binary_compressed :568-629
+    if (h.data_offset + 8 > bytes.size()) {
+      err = "truncated binary_compressed header";
+      return false;
+    }
+    uint32_t csize = 0, usize = 0;
+    std::memcpy(&csize, bytes.data() + h.data_offset, 4);
+    std::memcpy(&usize, bytes.data() + h.data_offset + 4, 4);
+    if (h.data_offset + 8 + csize > bytes.size()) {
+      err = "truncated binary_compressed body";
+      return false;
+    }
+    std::vector<unsigned char> soa(usize);
+    const size_t got = usize ? lzf_decompress(reinterpret_cast<const unsigned char*>(bytes.data()) + h.data_offset + 8,
+                                              csize, soa.data(), usize)
+                             : 0;
+    if (got != usize) {
+      err = "Size of decompressed lzf data does not match value stored in PCD header";
+      return false;
+    }
+    if (usize != aos.size()) aos.assign(usize, 0);  // the reference trusts the stored size (:579-583)
+    // struct of arrays -> array of structs ("unpack the xxyyzz to xyz", :605-623); "_" padding fields are
+    // not stored in the compressed stream
+    size_t fsize = 0;
+    for (const Field& f : h.fields)
+      if (f.name != "_") fsize += size_t(f.count) * size_t(f.size);
+    const uint64_t n = h.points;
+    if (fsize * n > usize) {
+      err = "compressed stream smaller than the fields it should hold";
+      return false;
+    }
+    size_t toff = 0;
+    for (const Field& f : h.fields) {
+      if (f.name == "_") continue;
+      const size_t fs = size_t(f.count) * size_t(f.size);
+      for (uint64_t i = 0; i < n; ++i) std::memcpy(&aos[size_t(i) * fsize + f.offset], &soa[toff + size_t(i) * fs], fs);
+      toff += fs * size_t(n);
+    }
+  }
+  // is_dense: any non-finite value of any floating field (:634-672)
+  const size_t step = aos.size() / size_t(h.points);
+  for (uint64_t i = 0; i < h.points && dense; ++i)
+    for (const Field& f : h.fields)
+      if (f.type == 'F' && f.name != "_")
+        for (int c = 0; c < f.count; ++c)
+          if (!std::isfinite(load_value(&aos[size_t(i) * step], f, c))) dense = false;
+  return true;
+}
+
+void fill_info(const Header& h, pclhip_pcd_info* info) {
+  std::memset(info, 0, sizeof *info);
+  info->points = h.points;
+  info->width = h.width;
+  info->height = h.height;
+  info->data_type = h.data_type;
+  info->version = h.version;
+  info->point_step = uint32_t(h.point_step);
+  info->num_fields = uint32_t(h.fields.size());
+  info->has_xyz = find_field(h, "x") >= 0 && find_field(h, "y") >= 0 && find_field(h, "z") >= 0;
+  info->has_normals = find_field(h, "normal_x") >= 0 && find_field(h, "normal_y") >= 0 && find_field(h, "normal_z") >= 0;
+  info->has_curvature = find_field(h, "curvature") >= 0;
+  info->has_intensity = find_field(h, "intensity") >= 0;
+  info->has_rgb = find_field(h, "rgb") >= 0 || find_field(h, "rgba") >= 0;
+  std::memcpy(info->viewpoint, h.viewpoint, sizeof h.viewpoint);
+  info->data_offset = h.data_offset;
+}
+
+pclhip_status fail(const std::string& msg) {
+  set_error(nullptr, msg);
+  return PCLHIP_ERR_INVALID;
+}
+
+}  // namespace
+
+extern "C" {
+
+pclhip_status pclhip_pcd_read_header(const char* path, pclhip_pcd_info* info) {
+  if (!path || !info) return PCLHIP_ERR_INVALID;
+  std::string bytes, err;
+  if (!read_file(path, bytes, err)) return fail(err);
+  Header h;
+  if (!parse_header(bytes, h, err)) return fail("[pcl::PCDReader::readHeader] " + err);
+  fill_info(h, info);
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_pcd_read(const char* path, void* points, size_t stride, size_t normals_offset, uint64_t capacity,
+                              uint64_t* n_out, int* is_dense) {
+  if (!path || !n_out) return PCLHIP_ERR_INVALID;
+  std::string bytes, err;
+  if (!read_file(path, bytes, err)) return fail(err);
+  Header h;
+  if (!parse_header(bytes, h, err)) return fail("[pcl::PCDReader::readHeader] " + err);
+  *n_out = h.points;
+  const int ix = find_field(h, "x"), iy = find_field(h, "y"), iz = find_field(h, "z");
+  if (ix < 0 || iy < 0 || iz < 0) return fail("the file has no x/y/z fields");
+  if (h.points == 0) {
+    if (is_dense) *is_dense = 1;
+    return PCLHIP_OK;
+  }
+  if (!points) return PCLHIP_ERR_INVALID;
+  if (capacity < h.points) {
+    set_error(nullptr, "output buffer too small for the cloud (see *n_out)");
+    return PCLHIP_ERR_OVERFLOW;
+  }
+  if (stride < 12 || stride % 4 != 0) return fail("stride must be a multiple of 4 and >= 12 bytes");
+  const int inx = find_field(h, "normal_x"), iny = find_field(h, "normal_y"), inz = find_field(h, "normal_z");
+  const int icv = find_field(h, "curvature");
+  const bool want_n = normals_offset != 0 && inx >= 0 && iny >= 0 && inz >= 0;
+  if (normals_offset != 0 && (normals_offset % 4 != 0 || normals_offset + 12 > stride))
+    return fail("normals_offset must be a multiple of 4 with room for 3 floats inside the record");
+  std::vector<unsigned char> aos;
+  bool dense = true;
+  if (!decode_body(bytes, h, aos, dense, err)) return fail("[pcl::PCDReader::read] " + err);
+  if (is_dense) *is_dense = dense ? 1 : 0;
+  const size_t step = h.points ? aos.size() / size_t(h.points) : 0;
+  // assemble the records on the host (a staging buffer when the destination is device memory)
+  const bool dev = is_device_pointer(points);
+  std::vector<unsigned char> staging;
+  unsigned char* dst = static_cast<unsigned char*>(points);
+  if (dev) {
+    staging.assign(size_t(h.points) * stride, 0);
+    dst = staging.data();
+  }
+  for (uint64_t i = 0; i < h.points; ++i) {
+    const unsigned char* p = &aos[size_t(i) * step];
+    float* o = reinterpret_cast<float*>(dst + size_t(i) * stride);
+    o[0] = float(load_value(p, h.fields[size_t(ix)], 0));
+    o[1] = float(load_value(p, h.fields[size_t(iy)], 0));
+    o[2] = float(load_value(p, h.fields[size_t(iz)], 0));
+    if (stride >= 16 && !(normals_offset != 0 && normals_offset < 16)) o[3] = 1.0f;  // PointXYZ padding (data[3] = 1)
+    if (want_n) {
+      float* nn = reinterpret_cast<float*>(dst + size_t(i) * stride + normals_offset);
+      nn[0] = float(load_value(p, h.fields[size_t(inx)], 0));
+      nn[1] = float(load_value(p, h.fields[size_t(iny)], 0));
+      nn[2] = float(load_value(p, h.fields[size_t(inz)], 0));
+      if (normals_offset + 16 <= stride) nn[3] = 0.0f;
+      if (icv >= 0 && normals_offset + 20 <= stride) nn[4] = float(load_value(p, h.fields[size_t(icv)], 0));
+    }
+  }
+  if (dev) {
+    if (hipMemcpy(points, staging.data(), staging.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      set_error(nullptr, "hipMemcpy to the device buffer failed");
+      return PCLHIP_ERR_HIP;
+    }
+  }
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_pcd_write(const char* path, const void* points, size_t stride, size_t normals_offset, uint64_t n,
+                               int data_type, int precision) {
+  if (!path || (n > 0 && !points)) return PCLHIP_ERR_INVALID;
+  if (stride < 12 || stride % 4 != 0) return fail("stride must be a multiple of 4 and >= 12 bytes");
+  if (data_type < 0 || data_type > 2) return fail("data_type: 0 ascii, 1 binary, 2 binary_compressed");
+  const bool with_n = normals_offset != 0;
+  if (with_n && (normals_offset % 4 != 0 || normals_offset + 12 > stride)) return fail("bad normals_offset");
+  const bool with_curv = with_n && normals_offset + 20 <= stride;
+  if (n > 0xFFFFFFFFull) return fail("too many points for a PCD header");
+  // gather the records on the host
+  std::vector<unsigned char> host;
+  const unsigned char* src = static_cast<const unsigned char*>(points);
+  if (n > 0 && is_device_pointer(points)) {
+    host.resize(size_t(n) * stride);
+    if (hipMemcpy(host.data(), points, host.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+      set_error(nullptr, "hipMemcpy from the device buffer failed");
+      return PCLHIP_ERR_HIP;
+    }
+    src = host.data();
+  }
+  const int nf = 3 + (with_n ? 3 : 0) + (with_curv ? 1 : 0);
+  const size_t fsize = size_t(nf) * 4;
+  // generateHeaderBinary / ASCII (io/src/pcd_io.cpp:848-1043): v0.7 header, unorganized cloud
+  std::ostringstream hd;
+  hd << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z";
+  if (with_n) hd << " normal_x normal_y normal_z";
+  if (with_curv) hd << " curvature";
+  hd << "\nSIZE";
+  for (int i = 0; i < nf; ++i) hd << " 4";
+  hd << "\nTYPE";
+  for (int i = 0; i < nf; ++i) hd << " F";
+  hd << "\nCOUNT";
+  for (int i = 0; i < nf; ++i) hd << " 1";
+  hd << "\nWIDTH " << n << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA "
+     << (data_type == 0 ? "ascii" : (data_type == 1 ? "binary" : "binary_compressed")) << "\n";
+  const std::string header = hd.str();
+  auto value = [&](uint64_t i, int f) -> float {
+    const float* o = reinterpret_cast<const float*>(src + size_t(i) * stride);
+    if (f < 3) return o[f];
+    const float* nn = reinterpret_cast<const float*>(src + size_t(i) * stride + normals_offset);
+    return f < 6 ? nn[f - 3] : nn[4];
+  };
+  std::FILE* f = std::fopen(path, "wb");
+  if (!f) return fail(std::string("cannot create ") + path + ": " + std::strerror(errno));
+  bool ok = std::fwrite(header.data(), 1, header.size(), f) == header.size();
+  if (data_type == 0) {  // writeASCII: values separated by one blank, `precision` significant digits, "nan"
+    std::ostringstream os;
+    os.imbue(std::locale::classic());
+    os.precision(precision > 0 ? precision : 8);
+    for (uint64_t i = 0; i < n; ++i) {
+      for (int k = 0; k < nf; ++k) {
+        const float v = value(i, k);
+        if (k) os << ' ';
+        if (std::isnan(v))
+          os << "nan";
+        else
+          os << v;
+      }
+      os << '\n';
+    }
+    const std::string body = os.str();
+    ok = ok && std::fwrite(body.data(), 1, body.size(), f) == body.size();
+  } else if (data_type == 1) {  // writeBinary: packed array of structs
+    std::vector<float> body(size_t(n) * size_t(nf));
+    for (uint64_t i = 0; i < n; ++i)
+      for (int k = 0; k < nf; ++k) body[size_t(i) * size_t(nf) + size_t(k)] = value(i, k);
+    ok = ok && (body.empty() || std::fwrite(body.data(), 4, body.size(), f) == body.size());
+  } else {  // writeBinaryCompressed: struct of arrays, LZF, sizes in front
+    std::vector<float> soa(size_t(n) * size_t(nf));
+    for (int k = 0; k < nf; ++k)
+      for (uint64_t i = 0; i < n; ++i) soa[size_t(k) * size_t(n) + size_t(i)] = value(i, k);
+    const size_t usize = soa.size() * 4;
+    if (usize > 0xFFFFFFFFull) {
+      std::fclose(f);
+      return fail("cloud too large for binary_compressed (32-bit sizes)");
+    }
+    std::vector<unsigned char> comp(usize + usize / 16 + 64);
+    const size_t csize = usize ? lzf_compress(reinterpret_cast<const unsigned char*>(soa.data()), usize, comp.data(), comp.size()) : 0;
+    if (usize && csize == 0) {
+      std::fclose(f);
+      return fail("LZF compression failed");
+    }
+    const uint32_t c32 = uint32_t(csize), u32 = uint32_t(usize);
+    ok = ok && std::fwrite(&c32, 4, 1, f) == 1 && std::fwrite(&u32, 4, 1, f) == 1;
+    ok = ok && (csize == 0 || std::fwrite(comp.data(), 1, csize, f) == csize);
+  }
+  (void)fsize;
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok) return fail(std::string("write failed on ") + path);
+  return PCLHIP_OK;
+}
+
+}  // extern "C"

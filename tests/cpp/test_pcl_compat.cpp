@@ -200,6 +200,30 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 16; ++i) EXPECT(std::fabs(F.m[i] - G2[i]) < 1e-3f);
     EXPECT(reg.getFitnessScore() < 1e-6);
   }
+  {  // PCD round trip through pcl::io-style calls (binary_compressed, PointNormal and PointXYZ)
+    const std::string dir = std::string(argv[1]).substr(0, std::string(argv[1]).find_last_of('/') + 1);
+    PointCloud<PointNormal> pn;
+    for (int i = 0; i < 500; ++i) {
+      PointNormal p;
+      p.x = 0.01f * float(i); p.y = float(i % 7); p.z = -1.5f;
+      p.normal_x = 0; p.normal_y = 0.6f; p.normal_z = 0.8f; p.curvature = 0.001f * float(i);
+      pn.push_back(p);
+    }
+    EXPECT(io::savePCDFileBinaryCompressed(dir + "pn.pcd", pn) == 0);
+    PointCloud<PointNormal> back;
+    EXPECT(io::loadPCDFile(dir + "pn.pcd", back) == 0);
+    EXPECT(back.size() == 500 && back.width == 500 && back.height == 1 && back.is_dense);
+    for (std::size_t i = 0; i < back.size() && i < pn.size(); ++i)
+      EXPECT(back[i].x == pn[i].x && back[i].y == pn[i].y && back[i].z == pn[i].z && back[i].normal_y == 0.6f &&
+             back[i].normal_z == 0.8f && back[i].curvature == pn[i].curvature);
+    EXPECT(io::savePCDFileASCII(dir + "xyz.pcd", *source) == 0);
+    PointCloud<PointXYZ> sb;
+    EXPECT(io::loadPCDFile(dir + "xyz.pcd", sb) == 0);
+    EXPECT(sb.size() == source->size());
+    for (std::size_t i = 0; i < sb.size() && i < source->size(); ++i)
+      EXPECT(std::fabs(sb[i].x - (*source)[i].x) <= 1e-7f * std::fabs((*source)[i].x) && sb[i].w == 1.0f);
+    EXPECT(io::loadPCDFile(dir + "does_not_exist.pcd", sb) == -1);
+  }
   std::printf(failures ? "%d FAILURES\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
 }

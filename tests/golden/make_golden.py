@@ -142,6 +142,30 @@ def main():
                         offsets=np.asarray(offsets, np.int64), indices=np.asarray(flat, np.int32),
                         radius=np.float64(0.02))
 
+    # PCD fixtures: files the reference ships for its own tests (test/*.pcd), one per on-disk flavour, plus
+    # the facts about them that pin the reader: POINTS, field list, extents of x/y/z after decoding with
+    # oracle/pcd.py (whose LZF decoder must reproduce the stored uncompressed size exactly)
+    import shutil
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle import pcd as opcd
+    os.makedirs(os.path.join(HERE, "pcd"), exist_ok=True)
+    facts = {}
+    for name in ("curve_close.pcd",            # binary, x y z
+                 "colored_cloud.pcd",          # binary, x y z rgb normal_x normal_y normal_z curvature
+                 "ism_test.pcd",               # binary_compressed, x y z
+                 "noisy_slice_displaced.pcd",  # binary_compressed, x y z
+                 "bun0.pcd"):                  # ascii, x y z normal_x normal_y normal_z curvature
+        src_path = os.path.join(REF, "test", name)
+        shutil.copyfile(src_path, os.path.join(HERE, "pcd", name))
+        h, fld, dense = opcd.read(src_path)
+        facts[name] = {"data": h["data"], "points": h["points"], "width": h["width"], "height": h["height"],
+                       "fields": [fl[0] for fl in h["fields"]], "is_dense": bool(dense),
+                       "min": [float(fld[a].min()) for a in "xyz"], "max": [float(fld[a].max()) for a in "xyz"],
+                       "bytes": os.path.getsize(src_path)}
+    gold["pcd_files"] = facts
+    # the ascii decoder agrees with the independent parser used for bunny.npz above
+    assert np.array_equal(opcd.xyz(os.path.join(REF, "test/bun0.pcd"))[0][:, :3], bun0[:, :3].astype(np.float32))
+
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(gold, f, indent=0, separators=(",", ":"))
     print("wrote bunny.npz (%d + %d pts) and golden.json" % (len(bun0), len(bun4)))

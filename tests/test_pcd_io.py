@@ -1,0 +1,135 @@
+"""PCD reader / writer (host code of libpclhip.so, no GPU needed) against the oracle (oracle/pcd.py) and
+the reference's own binary / binary_compressed / ascii test files (tests/golden/pcd/)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PCD = os.path.join(HERE, "golden", "pcd")
+
+
+@pytest.fixture(scope="module")
+def facts():
+    return json.load(open(os.path.join(HERE, "golden", "golden.json")))["pcd_files"]
+
+
+@pytest.fixture(scope="module")
+def api():
+    import pcl_amd
+    return pcl_amd
+
+
+def test_oracle_pinned_on_reference_files(facts):
+    # the oracle's decoders reproduce the recorded facts (and, for binary_compressed, the stored
+    # uncompressed size exactly -- asserted inside oracle.pcd.read)
+    from oracle import pcd as opcd
+    bunny = np.load(os.path.join(HERE, "golden", "bunny.npz"))
+    for name, f in facts.items():
+        h, fld, dense = opcd.read(os.path.join(PCD, name))
+        assert os.path.getsize(os.path.join(PCD, name)) == f["bytes"]
+        assert (h["data"], h["points"], h["width"], h["height"]) == (f["data"], f["points"], f["width"], f["height"])
+        assert [x[0] for x in h["fields"]] == f["fields"] and dense == f["is_dense"]
+        assert [float(fld[a].min()) for a in "xyz"] == f["min"] and [float(fld[a].max()) for a in "xyz"] == f["max"]
+    # ascii: same numbers as the independent parser behind bunny.npz
+    assert np.array_equal(opcd.xyz(os.path.join(PCD, "bun0.pcd"))[0][:, :3], bunny["bun0"][:, :3].astype(np.float32))
+
+
+@pytest.mark.parametrize("name", ["curve_close.pcd", "colored_cloud.pcd", "ism_test.pcd", "noisy_slice_displaced.pcd",
+                                  "bun0.pcd"])
+def test_reader_matches_oracle_bit_exact(api, facts, name):
+    from oracle import pcd as opcd
+    path = os.path.join(PCD, name)
+    info = api.getPCDHeader(path)
+    f = facts[name]
+    assert (info.points, info.width, info.height) == (f["points"], f["width"], f["height"])
+    assert info.data_type == {"ascii": 0, "binary": 1, "binary_compressed": 2}[f["data"]]
+    assert info.num_fields == len(f["fields"]) and info.has_xyz == 1
+    assert info.has_normals == int("normal_x" in f["fields"]) and info.has_curvature == int("curvature" in f["fields"])
+    assert info.has_rgb == int("rgb" in f["fields"] or "rgba" in f["fields"])
+    assert info.version == 7 and list(info.viewpoint) == [0, 0, 0, 1, 0, 0, 0]
+    for with_normals in (False, True):
+        got, dense = api.loadPCDFile(path, with_normals=with_normals)
+        want, wdense = opcd.xyz(path, with_normals=with_normals)
+        assert dense == wdense == f["is_dense"]
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("mode", ["ascii", "binary", "binary_compressed"])
+@pytest.mark.parametrize("with_normals", [False, True])
+def test_write_read_round_trip(api, tmp_path, mode, with_normals):
+    # test/io/test_io.cpp (PCDReaderWriter family): what is written is read back; binary modes bit-exact,
+    # ascii to the 8 significant digits the reference writes by default
+    from oracle import pcd as opcd
+    rng = np.random.default_rng(5)
+    n = 3000
+    cloud = np.zeros((n, 12 if with_normals else 4), np.float32)
+    cloud[:, :3] = rng.normal(0, 10, (n, 3))
+    cloud[::7, :3] = np.round(cloud[::7, :3])   # runs of equal bytes for the compressor
+    cloud[:, 3] = 1
+    if with_normals:
+        v = rng.normal(0, 1, (n, 3))
+        cloud[:, 4:7] = v / np.linalg.norm(v, axis=1, keepdims=True)
+        cloud[:, 8] = rng.uniform(0, 0.3, n)
+    cloud[5, 0] = np.nan                         # "nan" in ascii, is_dense = false
+    path = str(tmp_path / ("t_%s_%d.pcd" % (mode, with_normals)))
+    api.savePCDFile(path, cloud, mode)
+    info = api.getPCDHeader(path)
+    assert (info.points, info.width, info.height, info.version) == (n, n, 1, 7)
+    assert info.data_type == {"ascii": 0, "binary": 1, "binary_compressed": 2}[mode]
+    assert info.has_normals == int(with_normals) and info.has_curvature == int(with_normals)
+    back, dense = api.loadPCDFile(path, with_normals=with_normals)
+    oback, odense = opcd.xyz(path, with_normals=with_normals)       # the oracle reads our files too
+    assert not dense and not odense
+    assert np.array_equal(back.view(np.uint32), oback.view(np.uint32))
+    if mode == "ascii":
+        assert np.allclose(back, cloud, rtol=1e-7, atol=0, equal_nan=True)
+    else:
+        assert np.array_equal(back.view(np.uint32), cloud.view(np.uint32))
+    if mode == "binary_compressed":
+        # random mantissas barely compress: LZF's worst case is one control byte per 32 literals
+        assert os.path.getsize(path) < n * (28 if with_normals else 12) * 33 // 32 + 400
+
+
+def test_lzf_edge_cases(api, tmp_path):
+    # highly repetitive data (long back references, length extension byte) and incompressible data
+    from oracle import pcd as opcd
+    for k, cloud in enumerate((np.zeros((70000, 4), np.float32),
+                               np.random.default_rng(1).integers(0, 2 ** 32, (5000, 4), dtype=np.uint32).view(np.float32),
+                               np.ones((1, 4), np.float32), np.zeros((0, 4), np.float32))):
+        cloud = np.ascontiguousarray(cloud)
+        cloud = np.where(np.isfinite(cloud), cloud, np.float32(1.5)).astype(np.float32)
+        path = str(tmp_path / ("e%d.pcd" % k))
+        api.savePCDFile(path, cloud, "binary_compressed")
+        back, _ = api.loadPCDFile(path)
+        want = cloud.copy()
+        want[:, 3] = 1
+        assert np.array_equal(back.view(np.uint32), want.view(np.uint32))
+        if len(cloud):
+            assert np.array_equal(opcd.xyz(path)[0].view(np.uint32), want.view(np.uint32))
+
+
+def test_reader_errors(api, tmp_path):
+    p = tmp_path / "bad.pcd"
+    p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA ascii\n0 0 0\n")
+    with pytest.raises(api.PclHipError, match="SIZE"):
+        api.getPCDHeader(str(p))
+    p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 2\nHEIGHT 2\nPOINTS 3\nDATA ascii\n")
+    with pytest.raises(api.PclHipError, match="number of points"):
+        api.getPCDHeader(str(p))
+    p.write_text("VERSION 0.7\nFIELDS a b\nSIZE 4 4\nTYPE F F\nCOUNT 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA ascii\n1 2\n")
+    with pytest.raises(api.PclHipError, match="x/y/z"):
+        api.loadPCDFile(str(p))
+    with pytest.raises(api.PclHipError, match="cannot open"):
+        api.getPCDHeader(str(tmp_path / "missing.pcd"))
+    # older header without SIZE/TYPE/COUNT: everything float32 (pcd_io.cpp:181-189); float64 fields convert
+    p.write_text("FIELDS x y z\nWIDTH 2\nHEIGHT 1\nPOINTS 2\nDATA ascii\n1 2 3\n4 5 nan\n")
+    c, dense = api.loadPCDFile(str(p))
+    assert not dense and c[0].tolist() == [1, 2, 3, 1] and np.isnan(c[1, 2])
+    assert api.getPCDHeader(str(p)).version == 6
+    p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 8 8 8\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nVIEWPOINT 1 2 3 1 0 0 0\n"
+                 "POINTS 1\nDATA ascii\n0.1 0.2 0.3\n")
+    c, dense = api.loadPCDFile(str(p))
+    assert dense and c[0].tolist() == [np.float32(0.1), np.float32(0.2), np.float32(0.3), 1.0]
+    assert list(api.getPCDHeader(str(p)).viewpoint) == [1, 2, 3, 1, 0, 0, 0]
