@@ -115,6 +115,11 @@ PCLHIP_API pclhip_status pclhip_radius_search(pclhip_index* index, const void* q
  * The normals are also retained inside the index for point-to-plane ICP.  out_nan_count optional. */
 PCLHIP_API pclhip_status pclhip_normals(pclhip_index* index, int k, const float viewpoint[3],
                                         void* out, size_t out_stride_bytes, uint64_t* out_nan_count);
+/* Same with setRadiusSearch(radius) (Feature::compute, features/include/pcl/features/impl/feature.hpp:140-155):
+ * the plane is fitted to ALL indexed points with squared distance < float(radius^2), taken in the
+ * order radiusSearch returns them (ascending distance); fewer than 3 neighbours -> NaN. */
+PCLHIP_API pclhip_status pclhip_normals_radius(pclhip_index* index, double radius, const float viewpoint[3],
+                                               void* out, size_t out_stride_bytes, uint64_t* out_nan_count);
 /* GPU time (ms) of the last pclhip_knn / pclhip_normals traversal kernel on this index. */
 PCLHIP_API double pclhip_index_last_kernel_ms(const pclhip_index* index);
 /* Supply target normals computed elsewhere (e.g. a pcl::PointNormal target: normals = points + 16,

@@ -243,17 +243,21 @@ class NormalEstimation {
   void setInputCloud(const typename PointCloud<PointInT>::ConstPtr& cloud) { input_ = cloud; }
   void setSearchMethod(const typename search::KdTree<PointInT>::Ptr& tree) { tree_ = tree; }
   void setKSearch(int k) { k_ = k; }
+  void setRadiusSearch(double radius) { radius_ = radius; }
   void setViewPoint(float x, float y, float z) { vp_[0] = x; vp_[1] = y; vp_[2] = z; }
-  // Feature::compute (features/include/pcl/features/impl/feature.hpp:195-229)
+  // Feature::compute (features/include/pcl/features/impl/feature.hpp:195-229); initCompute refuses
+  // "both radius and K defined" and "neither defined" (:131-174)
   void compute(PointCloud<Normal>& output) {
     output.points.clear();
-    if (!input_ || k_ < 1) return;
+    if (!input_ || (k_ < 1) == !(radius_ > 0.0)) return;
     if (!tree_) tree_ = std::make_shared<search::KdTree<PointInT>>(ctx_);
     if (!tree_->setInputCloud(input_)) return;
     output.resize(input_->size());
     std::uint64_t nan = 0;
     std::vector<float> tmp(input_->size() * 4);
-    if (pclhip_normals(tree_->handle(), k_, vp_, tmp.data(), 16, &nan) != PCLHIP_OK) { output.points.clear(); return; }
+    const pclhip_status st = (k_ >= 1) ? pclhip_normals(tree_->handle(), k_, vp_, tmp.data(), 16, &nan)
+                                       : pclhip_normals_radius(tree_->handle(), radius_, vp_, tmp.data(), 16, &nan);
+    if (st != PCLHIP_OK) { output.points.clear(); return; }
     for (std::size_t i = 0; i < output.size(); ++i) {
       output[i].normal_x = tmp[4 * i]; output[i].normal_y = tmp[4 * i + 1]; output[i].normal_z = tmp[4 * i + 2];
       output[i].curvature = tmp[4 * i + 3];
@@ -266,6 +270,7 @@ class NormalEstimation {
   typename PointCloud<PointInT>::ConstPtr input_;
   typename search::KdTree<PointInT>::Ptr tree_;
   int k_ = 0;
+  double radius_ = 0.0;
   float vp_[3] = {0, 0, 0};
 };
 

@@ -121,3 +121,32 @@ def radius_search_bruteforce(tgt, qry, radius, max_nn=0):
         offsets.append(offsets[-1] + len(sel))
     return (np.asarray(offsets, np.uint64), np.concatenate(idx) if idx else np.zeros(0, np.int32),
             np.concatenate(dd) if dd else np.zeros(0, np.float32))
+
+
+def normals_radius(orc, cloud, radius, viewpoint=(0.0, 0.0, 0.0)):
+    """NormalEstimation with setRadiusSearch (Feature::compute, features/include/pcl/features/impl/feature.hpp
+    :140-155 -> normal_3d.hpp:48-95): plane fit over all neighbours within the radius in the order
+    radiusSearch returns them (ascending distance, ties by index); fewer than 3 -> NaN (normal_3d.h:308-322).
+    Small clouds only (brute-force search, Python loop).  Returns ((n,4) float32, nan_count)."""
+    cloud = np.ascontiguousarray(cloud, np.float32)
+    n = len(cloud)
+    off, idx, _ = radius_search_bruteforce(cloud, cloud, radius)
+    out = np.full((n, 4), np.nan, np.float32)
+    nan = 0
+    vp = np.asarray(viewpoint, np.float32)
+    for i in range(n):
+        nb = idx[int(off[i]):int(off[i + 1])]
+        if not np.isfinite(cloud[i, :3]).all() or len(nb) < 3:
+            nan += 1
+            continue
+        cov, cen, cnt = orc.mean_and_covariance(cloud, nb)
+        if cnt == 0:
+            nan += 1
+            continue
+        nx, ny, nz, curv = orc.solve_plane_parameters(cov)
+        v = vp - cloud[i, :3]                       # flipNormalTowardsViewpoint, normal_3d.h:169-188
+        cos_theta = np.float32(v[0] * np.float32(nx) + v[1] * np.float32(ny)) + v[2] * np.float32(nz)
+        if cos_theta < 0:
+            nx, ny, nz = -nx, -ny, -nz
+        out[i] = (nx, ny, nz, curv)
+    return out, nan

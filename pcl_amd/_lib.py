@@ -82,6 +82,7 @@ SIGNATURES = {
     "pclhip_radius_search": (C.c_int, [_vp, _vp, _sz, _u64, C.c_double, C.c_uint32, C.POINTER(_u64), _vp, _vp, _u64,
                                        C.POINTER(_u64)]),
     "pclhip_normals": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), _vp, _sz, C.POINTER(_u64)]),
+    "pclhip_normals_radius": (C.c_int, [_vp, C.c_double, C.POINTER(C.c_float), _vp, _sz, C.POINTER(_u64)]),
     "pclhip_index_set_normals": (C.c_int, [_vp, _vp, _sz]),
     "pclhip_icp_params_default": (None, [C.POINTER(IcpParams)]),
     "pclhip_icp_create": (C.c_int, [_vp, C.POINTER(_vp)]),

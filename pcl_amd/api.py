@@ -196,13 +196,14 @@ class KdTree:
 
 
 class NormalEstimation:
-    """pcl::NormalEstimation<PointInT, pcl::Normal> with setKSearch (k-NN mode)."""
+    """pcl::NormalEstimation<PointInT, pcl::Normal> with setKSearch (k-NN mode) or setRadiusSearch."""
 
     def __init__(self, ctx=None):
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
         self.tree = None
         self.k = 0
+        self.radius = 0.0
         self.vp = np.zeros(3, np.float32)  # sensor_origin_ default (normal_3d.h:328-351)
         self.cloud = None
         self.nan_count = 0
@@ -216,19 +217,28 @@ class NormalEstimation:
     def setKSearch(self, k):
         self.k = int(k)
 
+    def setRadiusSearch(self, radius):
+        self.radius = float(radius)
+
     def setViewPoint(self, x, y, z):
         self.vp = np.asarray([x, y, z], np.float32)
 
     def compute(self, want_output=True):
         """-> (n,4) float32 [nx,ny,nz,curvature]; also retains the normals inside the tree."""
-        assert self.k > 0, "only k-NN mode (setKSearch) is on the accelerated path"
+        # Feature::initCompute (impl/feature.hpp:131-155): exactly one of k and radius must be set
+        if self.radius != 0.0 and self.k != 0:
+            raise ValueError("Both radius (%f) and K (%d) defined! Set one of them to zero first" % (self.radius, self.k))
+        if self.radius == 0.0 and self.k == 0:
+            raise ValueError("Neither radius nor K defined! Set one of them to a positive number first")
         if self.tree is None:
             self.tree = KdTree(self.ctx)
         self.tree.setInputCloud(self.cloud)  # feature.hpp:125-130
         n = self.tree.n_cloud
         nan = C.c_uint64(0)
         out = None
+        optr, stride = None, 0
         if want_output:
+            stride = 16
             if _is_torch(self.cloud):
                 import torch
                 out = torch.empty((n, 4), dtype=torch.float32, device=self.cloud.device)
@@ -236,10 +246,10 @@ class NormalEstimation:
             else:
                 out = np.empty((n, 4), np.float32)
                 optr = C.c_void_p(out.ctypes.data)
-            check(self.lib.pclhip_normals(self.tree.h, self.k, _fp(self.vp), optr, 16, C.byref(nan)),
-                  self.ctx.h)
+        if self.k > 0:
+            check(self.lib.pclhip_normals(self.tree.h, self.k, _fp(self.vp), optr, stride, C.byref(nan)), self.ctx.h)
         else:
-            check(self.lib.pclhip_normals(self.tree.h, self.k, _fp(self.vp), None, 0, C.byref(nan)),
+            check(self.lib.pclhip_normals_radius(self.tree.h, self.radius, _fp(self.vp), optr, stride, C.byref(nan)),
                   self.ctx.h)
         self.nan_count = int(nan.value)
         return out

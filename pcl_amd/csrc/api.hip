@@ -375,17 +375,17 @@ pclhip_status pclhip_knn(pclhip_index* ix, const void* queries, size_t stride, u
   return PCLHIP_OK;
 }
 
-pclhip_status pclhip_normals(pclhip_index* ix, int k, const float viewpoint[3], void* out, size_t out_stride,
-                             uint64_t* out_nan_count) {
+static pclhip_status normals_common(pclhip_index* ix, int k, double radius, const float viewpoint[3], void* out,
+                                     size_t out_stride, uint64_t* out_nan_count) {
   if (!ix) return PCLHIP_ERR_INVALID;
   pclhip_ctx* ctx = ix->ctx;
-  PCLHIP_REQUIRE(ctx, k >= 1, "k must be >= 1");
+  PCLHIP_REQUIRE(ctx, (k >= 1) != (radius > 0.0), "set either k >= 1 or a positive radius");
   PCLHIP_REQUIRE(ctx, !out || (out_stride >= 16 && out_stride % 4 == 0), "out stride must be >= 16 bytes");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   const float zero[3] = {0, 0, 0};
   const float* vp = viewpoint ? viewpoint : zero;
   uint64_t nan = 0;
-  pclhip_status st = launch_normals(ix, k, vp, &nan);
+  pclhip_status st = (k >= 1) ? launch_normals(ix, k, vp, &nan) : launch_normals_radius(ix, radius, vp, &nan);
   if (st != PCLHIP_OK) return st;
   // points that were dropped from the index have NaN normals as well
   if (out_nan_count) *out_nan_count = nan + (ix->n_orig - ix->n);
@@ -401,6 +401,24 @@ pclhip_status pclhip_normals(pclhip_index* ix, int k, const float viewpoint[3], 
     if (st != PCLHIP_OK) return st;
   }
   return PCLHIP_OK;
+}
+
+pclhip_status pclhip_normals(pclhip_index* ix, int k, const float viewpoint[3], void* out, size_t out_stride,
+                             uint64_t* out_nan_count) {
+  if (ix && k < 1) {
+    set_error(ix->ctx, "k must be >= 1");
+    return PCLHIP_ERR_INVALID;
+  }
+  return normals_common(ix, k, 0.0, viewpoint, out, out_stride, out_nan_count);
+}
+
+pclhip_status pclhip_normals_radius(pclhip_index* ix, double radius, const float viewpoint[3], void* out,
+                                    size_t out_stride, uint64_t* out_nan_count) {
+  if (ix && !(radius > 0.0)) {
+    set_error(ix->ctx, "radius must be > 0");
+    return PCLHIP_ERR_INVALID;
+  }
+  return normals_common(ix, 0, radius, viewpoint, out, out_stride, out_nan_count);
 }
 
 pclhip_status pclhip_index_set_normals(pclhip_index* ix, const void* normals, size_t stride) {

@@ -14,6 +14,7 @@
 #include <cmath>
 
 #include "traverse.hpp"
+#include "normals_math.hpp"
 
 namespace pclhip {
 namespace {
@@ -54,26 +55,30 @@ struct RadiusFill {
   }
 };
 
-template <bool FILL>
+// BYPOS: counts / offsets are indexed by the query's position in `q` (self-queries of the index in kd
+// order) instead of by the original index stored in q[i].w; [q_begin, q_end) restricts the launch to a
+// chunk of queries whose segments start at offsets[i] - base.
+template <bool FILL, bool BYPOS = false>
 __global__ __launch_bounds__(BLOCK) void radius_kernel(IndexView ix, const float4* __restrict__ q, uint32_t nq, float r2,
                                                        uint32_t* __restrict__ counts,
                                                        const unsigned long long* __restrict__ offsets,
-                                                       uint64_t* __restrict__ keys) {
+                                                       uint64_t* __restrict__ keys, uint32_t q_begin = 0,
+                                                       unsigned long long base = 0) {
   __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
   load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
-  const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
+  const uint32_t ngroups = (nq - q_begin + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups);
   TraverseStats ts;
   for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
     const uint32_t g = sched.global(gl);
     if (g >= ngroups) break;
-    const uint32_t i = g * WAVE + lane;
+    const uint32_t i = q_begin + g * WAVE + lane;
     float4 p = make_float4(0, 0, 0, 0);
     const bool real = i < nq;
     if (real) p = q[i];
-    const uint32_t oq = __float_as_uint(p.w);
+    const uint32_t oq = BYPOS ? i : __float_as_uint(p.w);
     const bool vv[1] = {real && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)};
     const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
     if constexpr (!FILL) {
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(IndexView ix, const float
       pol.r2 = r2;
       pol.cnt = 0;
       pol.active = vv[0];
-      pol.out = keys + (real ? offsets[oq] : 0ull);
+      pol.out = keys + (real ? offsets[oq] - base : 0ull);
       traverse(ix, qx, qy, qz, vv, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
     }
   }
@@ -115,6 +120,49 @@ __global__ void radius_emit_kernel(const uint64_t* __restrict__ keys, const unsi
     out_d2[dst + t] = __uint_as_float(uint32_t(k >> 32));
   }
 }
+
+// NormalEstimation with setRadiusSearch (features/include/pcl/features/impl/normal_3d.hpp:48-95 through
+// Feature::compute, impl/feature.hpp:140-155): plane fit over ALL neighbours within the radius, in the
+// order radiusSearch returns them (ascending distance, ties by index).  One thread per query walks its
+// sorted segment; fewer than 3 neighbours -> NaN (normal_3d.h:308-322).
+__global__ __launch_bounds__(BLOCK) void normals_from_radius_kernel(IndexView ix, const uint32_t* __restrict__ rank,
+                                                                    const uint64_t* __restrict__ keys,
+                                                                    const unsigned long long* __restrict__ offsets,
+                                                                    unsigned long long base, uint32_t q_begin,
+                                                                    uint32_t q_end, float vx, float vy, float vz,
+                                                                    float4* __restrict__ nrm_sorted,
+                                                                    unsigned long long* __restrict__ nan_count) {
+  const uint32_t i = q_begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= q_end) return;
+  const float4 p = ix.pts[i];
+  const unsigned long long b = offsets[i] - base, cnt = offsets[i + 1] - offsets[i];
+  const float qnan = __builtin_nanf("");
+  float4 out;
+  if (cnt < 3) {
+    out = make_float4(qnan, qnan, qnan, qnan);
+    atomicAdd(nan_count, 1ull);
+  } else {
+    Cov cv;
+    const float4 p0 = ix.pts[rank[uint32_t(keys[b])]];
+    cv.start(p0.x, p0.y, p0.z);
+    for (unsigned long long c = 0; c < cnt; ++c) {
+      const float4 pc = ix.pts[rank[uint32_t(keys[b + c])]];
+      cv.add(pc.x, pc.y, pc.z);
+    }
+    float cov[9];
+    cv.finish(int(cnt), cov);
+    float nx, ny, nz, curv;
+    solve_plane(cov, nx, ny, nz, curv);
+    flip_to_viewpoint(p.x, p.y, p.z, vx, vy, vz, nx, ny, nz);
+    out = make_float4(nx, ny, nz, curv);
+  }
+  nrm_sorted[i] = out;
+}
+
+struct SubBase {  // segment offsets relative to a chunk's first key
+  unsigned long long base;
+  __host__ __device__ unsigned long long operator()(unsigned long long x) const { return x - base; }
+};
 
 struct Guard {
   std::vector<void*> p;
@@ -217,5 +265,103 @@ extern "C" pclhip_status pclhip_radius_search(pclhip_index* ix, const void* quer
   if (!idx_dev) PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out_idx, d_idx, size_t(total) * 4, hipMemcpyDeviceToHost, s));
   if (!d2_dev) PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out_d2, d_d2, size_t(total) * 4, hipMemcpyDeviceToHost, s));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  return PCLHIP_OK;
+}
+
+// NormalEstimation::setRadiusSearch path.  Neighbour lists are materialised chunk by chunk (at most
+// ~2^27 (distance, index) keys = 2 GB of sort buffers at a time), never for the whole cloud at once.
+pclhip_status pclhip::launch_normals_radius(pclhip_index* ix, double radius, const float vp[3], uint64_t* nan_count) {
+  pclhip_ctx* ctx = ix->ctx;
+  hipStream_t s = ctx->stream;
+  Guard g;
+  if (!ix->nrm) PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->nrm, size_t(ix->n_pad > 0 ? ix->n_pad : 1) * sizeof(float4)));
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(ix->nrm, 0xFF, size_t(ix->n_pad) * sizeof(float4), s));  // NaN pads
+  if (nan_count) *nan_count = 0;
+  const uint32_t n = ix->n;
+  if (n == 0) {
+    ix->has_normals = true;
+    return PCLHIP_OK;
+  }
+  const float r2 = float(radius * radius);  // kdtree_flann.hpp:398
+  const IndexView v = ix->view();
+  auto grid_for = [&](uint32_t nq) {
+    const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
+    int grid = int((ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    const int cap = ctx->num_cus * 4;
+    if (grid > cap) grid = cap;
+    return grid < 1 ? 1 : grid;
+  };
+  uint32_t* counts = nullptr;
+  unsigned long long *wide = nullptr, *off = nullptr, *d_nan = nullptr;
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&counts, size_t(n) * 4));
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&wide, size_t(n + 1) * 8));
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&off, size_t(n + 1) * 8));
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&d_nan, 8));
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_nan, 0, 8, s));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, s);
+  hipLaunchKernelGGL((radius_kernel<false, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, v, ix->pts, n, r2, counts,
+                     (const unsigned long long*)nullptr, (uint64_t*)nullptr, 0u, 0ull);
+  size_t tb = 0;
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(wide + n, 0, 8, s));
+  PCLHIP_CHECK_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, wide, off, 0ull, size_t(n + 1), rocprim::plus<unsigned long long>(), s));
+  void* tmp = nullptr;
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&tmp, tb));
+  hipLaunchKernelGGL(widen_counts_kernel, dim3((n + 255) / 256), dim3(256), 0, s, counts, n, wide);
+  PCLHIP_CHECK_HIP(ctx, rocprim::exclusive_scan(tmp, tb, wide, off, 0ull, size_t(n + 1), rocprim::plus<unsigned long long>(), s));
+  std::vector<unsigned long long> h_off(size_t(n) + 1);
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(h_off.data(), off, h_off.size() * 8, hipMemcpyDeviceToHost, s));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  // chunks of whole queries with at most KEY_BUDGET keys (a single query larger than that gets its own chunk)
+  const unsigned long long KEY_BUDGET = 1ull << 27;
+  unsigned long long max_keys = 0;
+  std::vector<uint32_t> cuts{0};
+  for (uint32_t a = 0; a < n;) {
+    uint32_t b = a + 1;
+    while (b < n && h_off[b + 1] - h_off[a] <= KEY_BUDGET) ++b;
+    if (h_off[b] - h_off[a] > max_keys) max_keys = h_off[b] - h_off[a];
+    cuts.push_back(b);
+    a = b;
+  }
+  uint64_t *k0 = nullptr, *k1 = nullptr;
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&k0, size_t(max_keys) * 8));
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&k1, size_t(max_keys) * 8));
+  void* stmp = nullptr;
+  size_t stmp_bytes = 0;
+  for (size_t c = 0; c + 1 < cuts.size(); ++c) {
+    const uint32_t a = cuts[c], b = cuts[c + 1];
+    const unsigned long long base = h_off[a], nkeys = h_off[b] - h_off[a];
+    if (nkeys > 0) {
+      hipLaunchKernelGGL((radius_kernel<true, true>), dim3(grid_for(b - a)), dim3(BLOCK), 0, s, v, ix->pts, b, r2, counts, off,
+                         k0, a, base);
+      // segment offsets of this chunk, relative to its first key: sort with begin/end iterators shifted by base
+      const SubBase sub{base};
+      auto begin_it = rocprim::make_transform_iterator(off + a, sub);
+      auto end_it = rocprim::make_transform_iterator(off + a + 1, sub);
+      size_t sb = 0;
+      PCLHIP_CHECK_HIP(ctx, rocprim::segmented_radix_sort_keys(nullptr, sb, k0, k1, size_t(nkeys), b - a, begin_it, end_it, 0, 64, s));
+      if (sb > stmp_bytes) {
+        PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+        PCLHIP_CHECK_HIP(ctx, g.alloc(&stmp, sb));
+        stmp_bytes = sb;
+      }
+      PCLHIP_CHECK_HIP(ctx, rocprim::segmented_radix_sort_keys(stmp, sb, k0, k1, size_t(nkeys), b - a, begin_it, end_it, 0, 64, s));
+    }
+    hipLaunchKernelGGL(normals_from_radius_kernel, dim3((b - a + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, v, ix->rank, k1, off,
+                       base, a, b, vp[0], vp[1], vp[2], ix->nrm, d_nan);
+  }
+  (void)hipEventRecord(e1, s);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  unsigned long long h = 0;
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&h, d_nan, 8, hipMemcpyDeviceToHost, s));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ix->last_kernel_ms = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (nan_count) *nan_count = h;
+  ix->has_normals = true;
   return PCLHIP_OK;
 }
