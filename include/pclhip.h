@@ -275,6 +275,14 @@ PCLHIP_API pclhip_status pclhip_estimate_rigid_transformation(
     size_t src_normals_stride, const void* tgt, size_t tgt_stride, const void* tgt_normals,
     size_t tgt_normals_stride, uint64_t n, int enforce_same_direction_normals, float T[16], double* sums);
 
+/* TransformationEstimationPointToPlaneLLSWeighted::estimateRigidTransformation
+ * (impl/transformation_estimation_point_to_plane_lls_weighted.hpp:195-290): the point-to-plane system
+ * with every target normal scaled by its pair's weight (n floats, host or device). */
+PCLHIP_API pclhip_status pclhip_estimate_rigid_transformation_weighted(
+    pclhip_ctx* ctx, const void* src, size_t src_stride, const void* tgt, size_t tgt_stride,
+    const void* tgt_normals, size_t tgt_normals_stride, const float* weights, uint64_t n, float T[16],
+    double* sums);
+
 /* out = T * in for n records (x,y,z at byte 0; other bytes of the record untouched);
  * order 0: Eigen Matrix4f*Vector4f order (icp.hpp:49-111); order 1: Transformer::se3 order
  * (transforms.hpp:117-123).  If normals_offset_bytes != 0 the 3 floats there are rotated too. */

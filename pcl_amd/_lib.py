@@ -109,6 +109,8 @@ SIGNATURES = {
     "pclhip_icp_fetch_correspondences": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_u64)]),
     "pclhip_estimate_rigid_transformation": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _u64,
                                                        C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
+    "pclhip_estimate_rigid_transformation_weighted": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _u64,
+                                                                C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "pclhip_transform_cloud": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int, _vp, _vp, _sz, _u64,
                                          _sz]),
     "pclhip_pcd_read_header": (C.c_int, [C.c_char_p, C.POINTER(PcdInfo)]),

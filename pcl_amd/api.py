@@ -621,7 +621,7 @@ class IterativeClosestPointWithNormals(IterativeClosestPoint):
 
 
 def estimateRigidTransformation(ctx, mode, src, tgt, src_normals=None, tgt_normals=None,
-                                enforce_same_direction_normals=True):
+                                enforce_same_direction_normals=True, weights=None):
     """TransformationEstimation{SVD, PointToPlaneLLS, SymmetricPointToPlaneLLS}::estimateRigidTransformation
     (cloud_src, cloud_tgt) for equally sized clouds (pair i = (src[i], tgt[i])).  Returns (T 4x4, sums)."""
     sp, ss, n, _k1 = _cloud(src)
@@ -635,6 +635,14 @@ def estimateRigidTransformation(ctx, mode, src, tgt, src_normals=None, tgt_norma
         tnp, tns, _, _k4 = _cloud(tgt_normals)
     T = np.zeros(16, np.float32)
     sums = np.zeros(_lib.NSUMS, np.float64)
+    if weights is not None:  # TransformationEstimationPointToPlaneLLSWeighted::setWeights
+        assert int(mode) == POINT_TO_PLANE, "weights belong to the point-to-plane estimator"
+        w = np.ascontiguousarray(weights, np.float32)
+        assert w.shape == (n,), "Number or weights from the number of correspondences"
+        check(ctx.lib.pclhip_estimate_rigid_transformation_weighted(
+            ctx.h, sp, ss, tp, ts, tnp, tns, C.c_void_p(w.ctypes.data), n, _fp(T),
+            sums.ctypes.data_as(C.POINTER(C.c_double))), ctx.h)
+        return T.reshape(4, 4), sums
     check(ctx.lib.pclhip_estimate_rigid_transformation(
         ctx.h, int(mode), sp, ss, snp, sns, tp, ts, tnp, tns, n, 1 if enforce_same_direction_normals else 0,
         _fp(T), sums.ctypes.data_as(C.POINTER(C.c_double))), ctx.h)

@@ -807,10 +807,10 @@ __global__ void pack_float4_kernel(const void* in, size_t stride, uint32_t n, fl
 }
 }  // namespace
 
-pclhip_status pclhip_estimate_rigid_transformation(pclhip_ctx* ctx, int mode, const void* src, size_t src_stride,
-                                                   const void* src_normals, size_t src_normals_stride, const void* tgt,
-                                                   size_t tgt_stride, const void* tgt_normals, size_t tgt_normals_stride,
-                                                   uint64_t n, int enforce, float T[16], double* sums_out) {
+static pclhip_status estimate_pairs_common(pclhip_ctx* ctx, int mode, const void* src, size_t src_stride,
+                                           const void* src_normals, size_t src_normals_stride, const void* tgt,
+                                           size_t tgt_stride, const void* tgt_normals, size_t tgt_normals_stride,
+                                           const float* weights, uint64_t n, int enforce, float T[16], double* sums_out) {
   if (!ctx || !T) return PCLHIP_ERR_INVALID;
   PCLHIP_REQUIRE(ctx, mode >= PCLHIP_ICP_POINT_TO_POINT && mode <= PCLHIP_ICP_SYMMETRIC, "unknown estimator");
   PCLHIP_REQUIRE(ctx, n < 0x7FFFFFFFull, "too many pairs");
@@ -841,13 +841,40 @@ pclhip_status pclhip_estimate_rigid_transformation(pclhip_ctx* ctx, int mode, co
       hipLaunchKernelGGL(pack_float4_kernel, dim3((uint32_t(n) + 255) / 256), dim3(256), 0, ctx->stream, d, strides[a],
                          uint32_t(n), packed[a]);
     }
+    const float* dw = nullptr;
+    if (weights) {
+      const void* d = nullptr;
+      void* owned = nullptr;
+      pclhip_status stw = to_device(ctx, weights, size_t(n) * sizeof(float), &d, &owned);
+      if (stw != PCLHIP_OK) return stw;
+      guard.add(owned);
+      dw = static_cast<const float*>(d);
+    }
     PCLHIP_CHECK_HIP(ctx, hipGetLastError());
-    pclhip_status st = launch_estimate_pairs(ctx, mode, packed[0], packed[1], packed[2], packed[3], uint32_t(n),
+    pclhip_status st = launch_estimate_pairs(ctx, mode, packed[0], packed[1], packed[2], packed[3], dw, uint32_t(n),
                                              enforce != 0, sums);
     if (st != PCLHIP_OK) return st;
   }
   if (sums_out) std::memcpy(sums_out, sums, sizeof sums);
   return pclhip_solve_transformation(sums, mode, T);
+}
+
+pclhip_status pclhip_estimate_rigid_transformation(pclhip_ctx* ctx, int mode, const void* src, size_t src_stride,
+                                                   const void* src_normals, size_t src_normals_stride, const void* tgt,
+                                                   size_t tgt_stride, const void* tgt_normals, size_t tgt_normals_stride,
+                                                   uint64_t n, int enforce, float T[16], double* sums_out) {
+  return estimate_pairs_common(ctx, mode, src, src_stride, src_normals, src_normals_stride, tgt, tgt_stride, tgt_normals,
+                               tgt_normals_stride, nullptr, n, enforce, T, sums_out);
+}
+
+pclhip_status pclhip_estimate_rigid_transformation_weighted(pclhip_ctx* ctx, const void* src, size_t src_stride,
+                                                            const void* tgt, size_t tgt_stride, const void* tgt_normals,
+                                                            size_t tgt_normals_stride, const float* weights, uint64_t n,
+                                                            float T[16], double* sums_out) {
+  if (!ctx) return PCLHIP_ERR_INVALID;
+  PCLHIP_REQUIRE(ctx, n == 0 || weights != nullptr, "null weights");
+  return estimate_pairs_common(ctx, PCLHIP_ICP_POINT_TO_PLANE, src, src_stride, nullptr, 0, tgt, tgt_stride, tgt_normals,
+                               tgt_normals_stride, weights, n, 1, T, sums_out);
 }
 
 pclhip_status pclhip_icp_fitness_score(pclhip_icp* icp, const float T[16], double max_range, double* score,

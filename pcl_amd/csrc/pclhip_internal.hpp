@@ -181,7 +181,8 @@ pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stri
 pclhip_status build_boxes(pclhip_index* ix);
 int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns);
 pclhip_status launch_estimate_pairs(pclhip_ctx* ctx, int mode, const float4* src, const float4* src_nrm,
-                                    const float4* tgt, const float4* tgt_nrm, uint32_t n, bool enforce, double* sums);
+                                    const float4* tgt, const float4* tgt_nrm, const float* weights, uint32_t n, bool enforce,
+                                    double* sums);
 pclhip_status launch_normals_radius(pclhip_index* ix, double radius, const float vp[3], uint64_t* nan_count);
 pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double max_range, double* score,
                                    uint64_t* nr);

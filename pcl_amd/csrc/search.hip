@@ -832,7 +832,8 @@ template <int MODE>
 __global__ __launch_bounds__(BLOCK) void estimate_pairs_kernel(const float4* __restrict__ src,
                                                                const float4* __restrict__ src_nrm,
                                                                const float4* __restrict__ tgt,
-                                                               const float4* __restrict__ tgt_nrm, uint32_t n,
+                                                               const float4* __restrict__ tgt_nrm,
+                                                               const float* __restrict__ weights, uint32_t n,
                                                                int enforce, double* __restrict__ partials) {
   __shared__ double red_s[WAVES_PER_BLOCK][NS];
   PairAcc<MODE> pa;
@@ -842,6 +843,14 @@ __global__ __launch_bounds__(BLOCK) void estimate_pairs_kernel(const float4* __r
     float4 n1 = make_float4(0, 0, 0, 0), n2 = make_float4(0, 0, 0, 0);
     if constexpr (MODE == PCLHIP_ICP_SYMMETRIC) n1 = src_nrm[i];
     if constexpr (MODE != PCLHIP_ICP_POINT_TO_POINT) n2 = tgt_nrm[i];
+    if constexpr (MODE == PCLHIP_ICP_POINT_TO_PLANE) {
+      // TransformationEstimationPointToPlaneLLSWeighted (impl/transformation_estimation_point_to_plane_lls_weighted.hpp
+      // :227-229): the same sums with the target normal scaled by the pair's weight (float)
+      if (weights != nullptr) {
+        const float w = weights[i];
+        n2.x = __fmul_rn(n2.x, w); n2.y = __fmul_rn(n2.y, w); n2.z = __fmul_rn(n2.z, w);
+      }
+    }
     const float dx = __fsub_rn(p.x, t.x), dy = __fsub_rn(p.y, t.y), dz = __fsub_rn(p.z, t.z);
     pa.add(p, n1, t, n2, __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)), enforce != 0);
   }
@@ -1021,20 +1030,21 @@ pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double ma
 
 // sums[NS] (host) of the estimator `mode` over n explicit pairs (dense float4 device arrays)
 pclhip_status launch_estimate_pairs(pclhip_ctx* ctx, int mode, const float4* src, const float4* src_nrm,
-                                    const float4* tgt, const float4* tgt_nrm, uint32_t n, bool enforce, double* sums) {
+                                    const float4* tgt, const float4* tgt_nrm, const float* weights, uint32_t n,
+                                    bool enforce, double* sums) {
   hipStream_t s = ctx->stream;
   const int grid = ctx->num_cus * 4;
   double* dev = nullptr;  // partials [grid][NS] + sums [NS]
   PCLHIP_CHECK_HIP(ctx, hipMalloc(&dev, (size_t(grid) + 1) * NS * sizeof(double)));
   if (mode == PCLHIP_ICP_POINT_TO_PLANE)
     hipLaunchKernelGGL(estimate_pairs_kernel<PCLHIP_ICP_POINT_TO_PLANE>, dim3(grid), dim3(BLOCK), 0, s, src, src_nrm, tgt,
-                       tgt_nrm, n, enforce ? 1 : 0, dev);
+                       tgt_nrm, weights, n, enforce ? 1 : 0, dev);
   else if (mode == PCLHIP_ICP_SYMMETRIC)
     hipLaunchKernelGGL(estimate_pairs_kernel<PCLHIP_ICP_SYMMETRIC>, dim3(grid), dim3(BLOCK), 0, s, src, src_nrm, tgt,
-                       tgt_nrm, n, enforce ? 1 : 0, dev);
+                       tgt_nrm, weights, n, enforce ? 1 : 0, dev);
   else
     hipLaunchKernelGGL(estimate_pairs_kernel<PCLHIP_ICP_POINT_TO_POINT>, dim3(grid), dim3(BLOCK), 0, s, src, src_nrm, tgt,
-                       tgt_nrm, n, enforce ? 1 : 0, dev);
+                       tgt_nrm, weights, n, enforce ? 1 : 0, dev);
   hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, dev, grid, dev + size_t(grid) * NS);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(sums, dev + size_t(grid) * NS, NS * sizeof(double), hipMemcpyDeviceToHost, s);

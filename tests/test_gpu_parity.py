@@ -885,3 +885,25 @@ def test_normals_radius_chunked_large(gpu, orc):
     nx, ny, nz, curv = orc.solve_plane_parameters(cov)
     assert abs(abs(nx * nr[sub[0], 0] + ny * nr[sub[0], 1] + nz * nr[sub[0], 2]) - 1) < 1e-5
     assert abs(curv - nr[sub[0], 3]) < 1e-5
+
+
+def test_weighted_point_to_plane_lls_vs_oracle(gpu, orc, golden):
+    # TransformationEstimationPointToPlaneLLSWeighted (impl/transformation_estimation_point_to_plane_lls_weighted.hpp
+    # :195-290): the LLS system with the target normal scaled by the pair's weight (float product, :227-229)
+    import pcl_amd
+    src, sn = _quadric_with_normals()
+    G = np.asarray(golden["lls_ground_truth"], np.float32)
+    tgt, tn = orc.transform_cloud(G, src, order=1, normals=sn)
+    rng = np.random.default_rng(3)
+    w = rng.uniform(0.1, 2.0, len(src)).astype(np.float32)
+    T, sums = pcl_amd.estimateRigidTransformation(gpu, pcl_amd.POINT_TO_PLANE, src, tgt, tgt_normals=tn, weights=w)
+    To, so, used = orc.lls_point_to_plane(src, tgt, (tn * w[:, None]).astype(np.float32))
+    assert used == sums[28] == 441
+    assert np.allclose(sums[:27], so, rtol=1e-11, atol=1e-13)
+    assert np.abs(T - To).max() < 1e-6
+    assert np.abs(T - G).max() < golden["lls_tol"]      # exact pairs: any positive weights recover the motion
+    # unit weights are the unweighted estimator, bit for bit
+    T1, s1 = pcl_amd.estimateRigidTransformation(gpu, pcl_amd.POINT_TO_PLANE, src, tgt, tgt_normals=tn,
+                                                 weights=np.ones(len(src), np.float32))
+    T0, s0 = pcl_amd.estimateRigidTransformation(gpu, pcl_amd.POINT_TO_PLANE, src, tgt, tgt_normals=tn)
+    assert np.array_equal(s1, s0) and np.array_equal(T1, T0)
