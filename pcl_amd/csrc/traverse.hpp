@@ -23,13 +23,15 @@
 
 namespace pclhip {
 
-constexpr int STACK_ENTRIES = 192;     // <= 63 siblings per interior level below the root scan, <= 3 such levels
+// worst case for n < 2^31 points (int32 indices): 134M leaves -> levels of 2.1M, 32768, 512 and 8 boxes;
+// the virtual root's scan pushes <= 7, every interior node below it <= 63 siblings: 7 + 3 * 63 = 196
+constexpr int STACK_ENTRIES = 208;
 constexpr int LEAF_BATCH = 16;         // leaves staged in LDS at a time (16 x 256 B = 4 KB)
 constexpr int LEAF_FLOATS = 4 * LEAF;  // x[16] y[16] z[16] w[16]
 
 // Per-wavefront LDS working set (7.5 KB): traversal stack, ranked leaf list, staged candidate blocks.
 struct __attribute__((aligned(16))) WaveLds {
-  uint2 stack[STACK_ENTRIES];           // 1.5 KB
+  uint2 stack[STACK_ENTRIES];           // 1.6 KB
   float4 list[2 * FANOUT];              // 2 KB: per ranked leaf (lo.xyz, id) (hi.xyz, lbG)
   float buf[LEAF_BATCH * LEAF_FLOATS];  // 4 KB
 };
