@@ -11,7 +11,7 @@ the realistic mix of far-from-aligned and nearly-aligned iterations.  Target ind
 built before the timed region (reported separately) and stay resident in HBM.
 
 Multi-GPU (weak scaling): every rank holds the full target index (it fits HBM many times over;
-north_star shards the target only when it does not) and its own Morton slab of the source
+north_star shards the target only when it does not) and its own slab of the source
 (n_points source points per rank, disjoint counter ranges of the same surface); the only exchange
 per iteration is the all-reduce of the 32-double reduction record over RCCL.
 
@@ -184,7 +184,7 @@ def main():
                                    "%s ICP, 1-NN correspondences, max_dist 0.1" %
                                    (n // 1_000_000, args.knn, "point-to-plane" if mode == 1 else "point-to-point"),
                        "points_per_gpu": n, "target_points": n, "mode": args.mode,
-                       "parallelism": "source Morton-slab sharded x%d, target replicated" % world},
+                       "parallelism": "source slab sharded x%d (kd-ordered per rank), target replicated" % world},
             "roofline": roofline, "cpu_baseline": cpu,
             "setup": {"index_build_ms": round(build_ms, 3),
                       "normals_kernel_ms": None if normals_ms is None else round(normals_ms, 3),

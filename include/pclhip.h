@@ -78,7 +78,7 @@ PCLHIP_API pclhip_status pclhip_index_build(pclhip_ctx* ctx, const void* points,
 PCLHIP_API void pclhip_index_destroy(pclhip_index* index);
 /* number of finite points indexed */
 PCLHIP_API uint64_t pclhip_index_size(const pclhip_index* index);
-/* milliseconds of GPU time spent in the last build (bbox + Morton + radix sort + gather + boxes) */
+/* milliseconds of GPU time spent in the last build (bbox + kd ordering by radix-sort rounds + gather + boxes) */
 PCLHIP_API double pclhip_index_build_ms(const pclhip_index* index);
 
 /* Exact k nearest neighbours of nq query points.
@@ -181,7 +181,7 @@ PCLHIP_API void pclhip_icp_params_default(pclhip_icp_params* p);
  * pcl::IterativeClosestPoint (registration/include/pcl/registration/icp.h:98-347). */
 PCLHIP_API pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out);
 PCLHIP_API void pclhip_icp_destroy(pclhip_icp* icp);
-/* Registration::setInputSource (registration.h:195-196): uploads + Morton-orders the source. */
+/* Registration::setInputSource (registration.h:195-196): uploads + kd-orders the source. */
 PCLHIP_API pclhip_status pclhip_icp_set_source(pclhip_icp* icp, const void* points,
                                                size_t stride_bytes, uint64_t n);
 /* Normals of the source cloud, one record per source point in the order given to

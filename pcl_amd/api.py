@@ -96,7 +96,7 @@ def default_context():
 
 
 class KdTree:
-    """pcl::search::KdTree<PointT> backed by the GPU Morton BVH (pclhip_index)."""
+    """pcl::search::KdTree<PointT> backed by the GPU kd-ordered wide BVH (pclhip_index)."""
 
     def __init__(self, ctx=None, sorted_results=True):
         self.ctx = ctx or default_context()
