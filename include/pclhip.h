@@ -120,6 +120,11 @@ PCLHIP_API pclhip_status pclhip_normals(pclhip_index* index, int k, const float 
  * order radiusSearch returns them (ascending distance); fewer than 3 neighbours -> NaN. */
 PCLHIP_API pclhip_status pclhip_normals_radius(pclhip_index* index, double radius, const float viewpoint[3],
                                                void* out, size_t out_stride_bytes, uint64_t* out_nan_count);
+/* GeneralizedIterativeClosestPoint::computeCovariances (registration/include/pcl/registration/impl/gicp.hpp
+ * :70-147): for every indexed point the covariance of its k nearest neighbours (k_correspondences_, default
+ * 20, <= 32 here), regularised to singular values (1, 1, epsilon) (gicp_epsilon_, default 0.001).
+ * out (host or device): 9 doubles (row-major 3x3) per ORIGINAL cloud point; NaN for dropped points. */
+PCLHIP_API pclhip_status pclhip_gicp_covariances(pclhip_index* index, int k, double epsilon, double* out);
 /* GPU time (ms) of the last pclhip_knn / pclhip_normals traversal kernel on this index. */
 PCLHIP_API double pclhip_index_last_kernel_ms(const pclhip_index* index);
 /* Supply target normals computed elsewhere (e.g. a pcl::PointNormal target: normals = points + 16,

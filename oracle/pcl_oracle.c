@@ -977,6 +977,96 @@ void orc_symmetric_solve(const double* s, float* T) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* GeneralizedIterativeClosestPoint::computeCovariances, registration/include/pcl/registration/impl/gicp.hpp
+ * :70-147.  Per point: k nearest neighbours (:101), float differences to the query accumulated in
+ * double (:104-120), mean and covariance (:122-129), JacobiSVD of the symmetric 3x3 (:132; restated as a
+ * cyclic Jacobi eigen-iteration: singular values = |eigenvalues|, U = eigenvectors), singular values
+ * replaced by (1, 1, epsilon) (:134-143) => cov = I - (1 - eps) u3 u3^T.  out: 9 doubles per point.
+ * Parity note: the reference's tests hold no golden vector for these matrices; this function is pinned
+ * by its properties (tests/test_oracle_golden.py: eigenvalues {1, 1, eps}, u3 = known plane normal). */
+static void orc_jacobi3(double A[3][3], double V[3][3]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (A[p][q] == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq;
+          A[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk;
+          A[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+}
+
+int orc_gicp_covariances(const orc_kdtree* t, const float* cloud, int64_t n, int cs, int k, double eps,
+                         double* out, int nthreads) {
+  if (k < 1 || (int64_t)k > orc_kdtree_size(t)) return -1; /* :77-83 */
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+  {
+    int32_t* idx = (int32_t*)malloc((size_t)k * sizeof(int32_t));
+    float* d2 = (float*)malloc((size_t)k * sizeof(float));
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t i = 0; i < n; ++i) {
+      const float* p = cloud + i * cs;
+      double* o = out + 9 * i;
+      if (!finite3(p)) {
+        for (int c = 0; c < 9; ++c) o[c] = NAN;
+        continue;
+      }
+      orc_kdtree_knn(t, p, 1, cs, k, idx, d2, 1);
+      double mean[3] = {0, 0, 0}, cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      for (int j = 0; j < k; ++j) {
+        const float* q = cloud + (int64_t)idx[j] * cs;
+        const double ptx = (double)(q[0] - p[0]), pty = (double)(q[1] - p[1]), ptz = (double)(q[2] - p[2]);
+        mean[0] += ptx;
+        mean[1] += pty;
+        mean[2] += ptz;
+        cov[0][0] += ptx * ptx;
+        cov[1][0] += pty * ptx;
+        cov[1][1] += pty * pty;
+        cov[2][0] += ptz * ptx;
+        cov[2][1] += ptz * pty;
+        cov[2][2] += ptz * ptz;
+      }
+      for (int a = 0; a < 3; ++a) mean[a] /= (double)k;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b <= a; ++b) {
+          cov[a][b] /= (double)k;
+          cov[a][b] -= mean[a] * mean[b];
+          cov[b][a] = cov[a][b];
+        }
+      double V[3][3];
+      orc_jacobi3(cov, V);
+      const double w0 = fabs(cov[0][0]), w1 = fabs(cov[1][1]), w2 = fabs(cov[2][2]);
+      const int m = (w0 <= w1 && w0 <= w2) ? 0 : ((w1 <= w2) ? 1 : 2);
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) o[3 * a + b] = (a == b ? 1.0 : 0.0) - (1.0 - eps) * V[a][m] * V[b][m];
+    }
+    free(idx);
+    free(d2);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 unsigned orc_mean_and_covariance(const float* cloud, int cs, const int32_t* indices, int n,
                                  float* cov, float* centroid) {
   /* centroid.hpp:587-648 (the !is_dense branch; identical to the dense one on finite data) */

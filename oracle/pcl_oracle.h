@@ -162,6 +162,11 @@ int orc_icp_align(const orc_kdtree* tgt_tree, const float* tgt, int ts, const fl
                   const orc_icp_params* p, orc_convergence* conv, orc_icp_result* r,
                   float* per_iter_T, int32_t* per_iter_match);
 
+/* GeneralizedIterativeClosestPoint::computeCovariances (impl/gicp.hpp:70-147); out: 9 doubles per point.
+ * Returns -1 when the cloud has fewer than k points. */
+int orc_gicp_covariances(const orc_kdtree* t, const float* cloud, int64_t n, int cs, int k, double eps,
+                         double* out, int nthreads);
+
 /* ---- NormalEstimation ---------------------------------------------------------------------- */
 /* computeMeanAndCovarianceMatrix (common/include/pcl/common/impl/centroid.hpp:581-650), float. */
 unsigned orc_mean_and_covariance(const float* cloud, int cs, const int32_t* indices, int n,

@@ -70,6 +70,8 @@ def lib():
         L.orc_correspondences.restype = C.c_int64
         L.orc_correspondences.argtypes = [vp, fp, C.c_int64, C.c_int, C.c_double, ip, ip, fp,
                                           C.c_int]
+        L.orc_gicp_covariances.restype = C.c_int
+        L.orc_gicp_covariances.argtypes = [vp, fp, C.c_int64, C.c_int, C.c_int, C.c_double, dp, C.c_int]
         L.orc_fitness_score.restype = C.c_double
         L.orc_fitness_score.argtypes = [vp, fp, C.c_int64, C.c_int, fp, C.c_double,
                                         C.POINTER(C.c_int64), C.c_int]
@@ -174,6 +176,16 @@ class KdTree:
         c = lib().orc_correspondences(self.h, _f(src), ns, ss, float(max_dist), _i(q), _i(m),
                                       _f(d2), nthreads or default_threads())
         return q[:c].copy(), m[:c].copy(), d2[:c].copy()
+
+    def gicp_covariances(self, cloud, k=20, epsilon=0.001, nthreads=None):
+        """GeneralizedIterativeClosestPoint::computeCovariances -> (n, 3, 3) float64"""
+        cloud, n, cs = _cloud(cloud)
+        out = np.empty((n, 9), np.float64)
+        rc = lib().orc_gicp_covariances(self.h, _f(cloud), n, cs, int(k), float(epsilon), _d(out),
+                                        nthreads or default_threads())
+        if rc != 0:
+            raise ValueError("Number or points in cloud is less than k_correspondences_")
+        return out.reshape(n, 3, 3)
 
     def fitness_score(self, src, T, max_range=float(np.finfo(np.float64).max), nthreads=None):
         """Registration::getFitnessScore; returns (score, nr)."""

@@ -155,6 +155,13 @@ class KdTree:
                                   C.c_void_p(d2.ctypes.data)), self.ctx.h)
         return idx, d2
 
+    def gicpCovariances(self, k=20, epsilon=0.001):
+        """GeneralizedIterativeClosestPoint::computeCovariances (impl/gicp.hpp:70-147) for the indexed cloud:
+        (n, 3, 3) float64, NaN for points that are not in the index."""
+        out = np.empty((self.n_cloud, 9), np.float64)
+        check(self.lib.pclhip_gicp_covariances(self.h, int(k), float(epsilon), C.c_void_p(out.ctypes.data)), self.ctx.h)
+        return out.reshape(self.n_cloud, 3, 3)
+
     def radiusSearch(self, queries, radius, max_nn=0):
         """Batch radiusSearch (search.h:271-273 / search.hpp:164-190).  Returns (offsets uint64 [nq+1],
         indices int32 [total], sqr_distances float32 [total]) -- neighbours of query i are

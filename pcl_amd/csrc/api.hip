@@ -421,6 +421,45 @@ pclhip_status pclhip_normals_radius(pclhip_index* ix, double radius, const float
   return normals_common(ix, 0, radius, viewpoint, out, out_stride, out_nan_count);
 }
 
+namespace {
+__global__ void scatter_cov_kernel(const double* __restrict__ cov_sorted, const uint32_t* __restrict__ rank, uint64_t n_orig,
+                                   double* __restrict__ dense) {
+  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  if (i >= n_orig) return;
+  const uint32_t pos = rank[i];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) dense[i * 9 + c] = (pos == NO_INDEX) ? __builtin_nan("") : cov_sorted[size_t(pos) * 9 + c];
+}
+}  // namespace
+
+pclhip_status pclhip_gicp_covariances(pclhip_index* ix, int k, double epsilon, double* out) {
+  if (!ix || !out) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = ix->ctx;
+  PCLHIP_REQUIRE(ctx, k >= 1 && k <= 32, "k_correspondences must be in 1..32 on this path (reference default 20)");
+  // gicp.hpp:77-83: "Number or points in cloud is less than k_correspondences_"
+  PCLHIP_REQUIRE(ctx, uint64_t(k) <= ix->n, "number of points in cloud is less than k_correspondences");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard;
+  double* cov_sorted = nullptr;
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&cov_sorted, size_t(ix->n) * 9 * sizeof(double)));
+  guard.add(cov_sorted);
+  pclhip_status st = launch_gicp_covariances(ix, k, epsilon, cov_sorted);
+  if (st != PCLHIP_OK) return st;
+  const bool dev = is_device_pointer(out);
+  double* dense = out;
+  if (!dev) {
+    PCLHIP_CHECK_HIP(ctx, hipMalloc(&dense, size_t(ix->n_orig) * 9 * sizeof(double)));
+    guard.add(dense);
+  }
+  hipLaunchKernelGGL(scatter_cov_kernel, dim3(unsigned((ix->n_orig + 255) / 256)), dim3(256), 0, ctx->stream, cov_sorted,
+                     ix->rank, ix->n_orig, dense);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  if (!dev)
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, dense, size_t(ix->n_orig) * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLHIP_OK;
+}
+
 pclhip_status pclhip_index_set_normals(pclhip_index* ix, const void* normals, size_t stride) {
   if (!ix) return PCLHIP_ERR_INVALID;
   pclhip_ctx* ctx = ix->ctx;

@@ -386,6 +386,125 @@ pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_
 }
 
 // =================================================================================================
+// GeneralizedIterativeClosestPoint::computeCovariances (registration/include/pcl/registration/impl/gicp.hpp
+// :70-147): per point the k nearest neighbours (k <= 32), their covariance in double about the query
+// point (float differences, double sums), and the covariance "regularised" to singular values
+// (1, 1, epsilon): U diag(1,1,eps) U^T = I - (1 - eps) n n^T with n the singular vector of the smallest
+// singular value.  One 3x3 row-major double matrix per sorted point.
+// =================================================================================================
+__device__ __forceinline__ void smallest_eigenvector3(double A[3][3], double n[3]) {
+  // cyclic Jacobi on the symmetric 3x3; V accumulates the rotations
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+    if (off < 1e-300) break;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int q = p + 1; q < 3; ++q) {
+        if (A[p][q] == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - sn * akq;
+          A[k][q] = sn * akp + c * akq;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - sn * aqk;
+          A[q][k] = sn * apk + c * aqk;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - sn * vkq;
+          V[k][q] = sn * vkp + c * vkq;
+        }
+      }
+    }
+  }
+  // singular values of a symmetric matrix are |eigenvalues|
+  const double w0 = fabs(A[0][0]), w1 = fabs(A[1][1]), w2 = fabs(A[2][2]);
+  const int m = (w0 <= w1 && w0 <= w2) ? 0 : ((w1 <= w2) ? 1 : 2);
+  n[0] = V[0][m];
+  n[1] = V[1][m];
+  n[2] = V[2][m];
+}
+
+__global__ __launch_bounds__(BLOCK) void gicp_cov_kernel(IndexView ix, int k, double eps, double* __restrict__ cov_sorted,
+                                                         unsigned long long* gstats) {
+  __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
+  __shared__ Box topbox_s[TOPCACHE_BOXES];
+  load_top_cache(ix, topbox_s);
+  const int lane = threadIdx.x & (WAVE - 1);
+  const uint32_t ngroups = (ix.n + WAVE - 1) / WAVE;
+  const GroupSchedule sched(ngroups);
+  TraverseStats ts;
+  for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
+    const uint32_t g = sched.global(gl);
+    if (g >= ngroups) break;
+    const uint32_t i = g * WAVE + lane;
+    const bool valid = i < ix.n;
+    float4 p = make_float4(0, 0, 0, 0);
+    if (valid) p = ix.pts[i];
+    TopKReg<32> pol;
+    pol.init(KEY_NONE);
+    {
+      const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
+      const bool vv[1] = {valid};
+      traverse<TopKReg<32>, true>(ix, qx, qy, qz, vv, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
+    }
+    if (valid) {
+      double mean[3] = {0, 0, 0}, c00 = 0, c10 = 0, c11 = 0, c20 = 0, c21 = 0, c22 = 0;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        if (c < k) {  // the index holds >= k points (checked by the caller): all k slots are filled
+          const float4 q = ix.pts[pol.pos[c]];
+          const double ptx = double(__fsub_rn(q.x, p.x)), pty = double(__fsub_rn(q.y, p.y)), ptz = double(__fsub_rn(q.z, p.z));
+          mean[0] += ptx; mean[1] += pty; mean[2] += ptz;
+          c00 += ptx * ptx;
+          c10 += pty * ptx; c11 += pty * pty;
+          c20 += ptz * ptx; c21 += ptz * pty; c22 += ptz * ptz;
+        }
+      }
+      const double kk = double(k);
+      mean[0] /= kk; mean[1] /= kk; mean[2] /= kk;
+      double A[3][3];
+      A[0][0] = c00 / kk - mean[0] * mean[0];
+      A[1][0] = A[0][1] = c10 / kk - mean[1] * mean[0];
+      A[1][1] = c11 / kk - mean[1] * mean[1];
+      A[2][0] = A[0][2] = c20 / kk - mean[2] * mean[0];
+      A[2][1] = A[1][2] = c21 / kk - mean[2] * mean[1];
+      A[2][2] = c22 / kk - mean[2] * mean[2];
+      double n[3];
+      smallest_eigenvector3(A, n);
+      double* o = cov_sorted + size_t(i) * 9;
+      const double f = 1.0 - eps;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[3 * r + c] = (r == c ? 1.0 : 0.0) - f * n[r] * n[c];
+    }
+  }
+  flush_stats(ts, gstats);
+}
+
+pclhip_status launch_gicp_covariances(pclhip_index* ix, int k, double eps, double* cov_sorted) {
+  pclhip_ctx* ctx = ix->ctx;
+  if (ix->n == 0) return PCLHIP_OK;
+  const IndexView v = ix->view();
+  const uint32_t ngroups = (ix->n + WAVE - 1) / WAVE;
+  hipLaunchKernelGGL(gicp_cov_kernel, dim3(resident_blocks(ctx, gicp_cov_kernel, ngroups)), dim3(BLOCK), 0, ctx->stream, v, k,
+                     eps, cov_sorted, ctx->stats);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  return PCLHIP_OK;
+}
+
+// =================================================================================================
 // fused ICP iteration
 // =================================================================================================
 struct Mat34 {

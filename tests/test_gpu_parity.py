@@ -907,3 +907,31 @@ def test_weighted_point_to_plane_lls_vs_oracle(gpu, orc, golden):
                                                  weights=np.ones(len(src), np.float32))
     T0, s0 = pcl_amd.estimateRigidTransformation(gpu, pcl_amd.POINT_TO_PLANE, src, tgt, tgt_normals=tn)
     assert np.array_equal(s1, s0) and np.array_equal(T1, T0)
+
+
+# ------------------------------------------------------------------------------------------------
+# GICP covariances
+# ------------------------------------------------------------------------------------------------
+def test_gicp_covariances_vs_oracle(gpu, orc, bunny):
+    # GeneralizedIterativeClosestPoint::computeCovariances, impl/gicp.hpp:70-147
+    import pcl_amd
+    from pcl_amd import synth
+    for cloud, k in ((xyz1(bunny["bun0"]), 20), (synth.gaussian_surface(50_000, synth.TARGET_SEED), 20),
+                     (synth.gaussian_surface(20_000, synth.SOURCE_SEED), 7)):
+        cloud = cloud.copy()
+        cloud[3, 2] = np.nan     # dropped from the index: NaN matrix
+        tree = build_tree(gpu, cloud)
+        got = tree.gicpCovariances(k, 0.001)
+        want = orc.KdTree(cloud).gicp_covariances(cloud, k, 0.001)
+        assert np.isnan(got[3]).all() and np.isnan(want[3]).all()
+        ok = np.ones(len(cloud), bool)
+        ok[3] = False
+        # the matrix is I - (1 - eps) n n^T: both sides iterate a double Jacobi solve; the smallest direction of
+        # a 20-point neighbourhood is well separated on these surfaces
+        assert np.abs(got[ok] - want[ok]).max() < 1e-9
+        w = np.linalg.eigvalsh(got[ok])
+        assert np.allclose(w, [0.001, 1.0, 1.0], atol=1e-12)
+    with pytest.raises(pcl_amd.PclHipError):
+        build_tree(gpu, xyz1(bunny["bun0"])[:10]).gicpCovariances(20)
+    with pytest.raises(pcl_amd.PclHipError):
+        tree.gicpCovariances(33)

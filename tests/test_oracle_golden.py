@@ -299,3 +299,25 @@ def test_symmetric_lls_known_answer(golden):
     assert np.abs(T1 - G).max() < 1e-2
     T2, _, _ = orc.lls_symmetric(src, sn, tgt, -tn, enforce_same_direction=False)
     assert not np.abs(T2 - G).max() < 1e-2
+
+
+def test_gicp_covariances_properties():
+    # impl/gicp.hpp:70-147 -- no golden vector in the reference's tests; pinned by construction:
+    # cov = U diag(1, 1, eps) U^T, u3 = normal of the neighbourhood
+    rng = np.random.default_rng(9)
+    n = 4000
+    normal = np.array([0.3, -0.5, 0.81])
+    normal /= np.linalg.norm(normal)
+    a = np.cross(normal, [1, 0, 0])
+    a /= np.linalg.norm(a)
+    b = np.cross(normal, a)
+    uv = rng.uniform(-1, 1, (n, 2))
+    pts = (uv[:, :1] * a + uv[:, 1:] * b + 1e-5 * rng.normal(size=(n, 1)) * normal).astype(np.float32)
+    tree = orc.KdTree(pts)
+    cov = tree.gicp_covariances(pts, k=20, epsilon=0.001)
+    w, v = np.linalg.eigh(cov)
+    assert np.allclose(w, [0.001, 1.0, 1.0], atol=1e-12)
+    assert np.abs(np.abs(v[:, :, 0] @ normal) - 1).max() < 1e-3          # smallest direction = plane normal
+    assert np.allclose(cov, np.transpose(cov, (0, 2, 1)))
+    with pytest.raises(ValueError):
+        orc.KdTree(pts[:5]).gicp_covariances(pts[:5], k=20)
