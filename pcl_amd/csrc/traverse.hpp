@@ -261,12 +261,16 @@ struct NN1MinT {
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const bool imp = m[q] < best[q];
-      // equal minimum in another leaf than the current winner's: index tie, the exact policy decides
-      const bool eq = (m[q] == best[q]) && (bestpos[q] != NO_INDEX) && (bestpos[q] / LEAF != leaf_id);
-      tie[q] = imp ? false : (tie[q] || eq);
+      // equal minimum in another leaf than the current winner's: index tie, the exact policy decides;
+      // equal minimum in the winner's own leaf (a seed re-found -- or another slot at exactly the seed's
+      // distance): resolve() looks at the slots
+      const bool eq = (m[q] == best[q]) && (bestpos[q] != NO_INDEX);
+      const bool same = bestpos[q] / LEAF == leaf_id;
+      tie[q] = imp ? false : (tie[q] || (eq && !same));
+      const bool look = imp || (eq && same);
       best[q] = imp ? m[q] : best[q];
-      bestpos[q] = imp ? first : bestpos[q];
-      unres[q] = unres[q] || imp;
+      bestpos[q] = look ? first : bestpos[q];
+      unres[q] = unres[q] || look;
     }
   }
   // Lane-sparse evaluation (traverse(): SPARSE): every lane evaluates ITS OWN leaf (id NO_INDEX = none),
@@ -299,11 +303,13 @@ struct NN1MinT {
         }
       }
       const bool imp = m < best[0];
-      const bool eq = (m == best[0]) && (bestpos[0] != NO_INDEX) && (bestpos[0] / LEAF != leaf_id);
-      tie[0] = imp ? false : (tie[0] || eq);
+      const bool eq = (m == best[0]) && (bestpos[0] != NO_INDEX);  // see leaf()
+      const bool same = bestpos[0] / LEAF == leaf_id;
+      tie[0] = imp ? false : (tie[0] || (eq && !same));
+      const bool look = imp || (eq && same);
       best[0] = imp ? m : best[0];
-      bestpos[0] = imp ? leaf_id * LEAF : bestpos[0];
-      unres[0] = unres[0] || imp;
+      bestpos[0] = look ? leaf_id * LEAF : bestpos[0];
+      unres[0] = unres[0] || look;
     }
   }
   // after the traversal: find the winning slot inside the winning leaf (same arithmetic, same bits)

@@ -935,3 +935,95 @@ def test_gicp_covariances_vs_oracle(gpu, orc, bunny):
         build_tree(gpu, xyz1(bunny["bun0"])[:10]).gicpCovariances(20)
     with pytest.raises(pcl_amd.PclHipError):
         tree.gicpCovariances(33)
+
+
+# ------------------------------------------------------------------------------------------------
+# ties under seeding, and size-independent properties at the benchmark size
+# ------------------------------------------------------------------------------------------------
+def test_icp_lattice_ties_with_seeds_bit_exact(gpu, orc):
+    # lattice target, source points exactly half-way between lattice points: every query has 2 or 4
+    # equidistant targets; translations by exact binary fractions keep producing ties in later (seeded)
+    # iterations.  Every iteration must pick the lowest index, like the oracle.
+    import pcl_amd
+    g = np.arange(48, dtype=np.float32)
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    tgt = np.stack([X.ravel(), Y.ravel(), np.zeros(X.size, np.float32), np.ones(X.size, np.float32)], 1)
+    rng = np.random.default_rng(2)
+    perm = rng.permutation(len(tgt))          # original index order unrelated to position
+    tgt = np.ascontiguousarray(tgt[perm])
+    src = tgt.copy()
+    src[:, 0] += np.float32(0.5)              # ties between (x, y) and (x+1, y)
+    otree = orc.KdTree(tgt)
+    icp = pcl_amd.IterativeClosestPoint(gpu)
+    icp.setInputTarget(tgt)
+    icp.setInputSource(src)
+    icp.reset()
+    cur = src.copy()
+    steps = [np.eye(4, dtype=np.float32)]
+    for dx, dy in ((0.0, 0.5), (0.25, 0.0), (0.25, -0.5), (-1.0, 0.0), (0.0, 0.0), (0.5, 0.5)):
+        T = np.eye(4, dtype=np.float32)
+        T[0, 3], T[1, 3] = dx, dy
+        steps.append(T)
+    for it, T in enumerate(steps):
+        icp.iterate(T, max_dist=10.0)
+        q, m, d = icp.fetchCorrespondences()
+        cur = orc.transform_cloud(T, cur, order=0)
+        oq, om, od = otree.correspondences(cur, 10.0)
+        bi, bd = orc.knn_bruteforce(tgt, cur, 1)      # the lowest-index rule, by brute force
+        assert np.array_equal(om, bi[:, 0]), it
+        assert np.array_equal(q, oq) and np.array_equal(m, om) and np.array_equal(d, od), it
+
+
+def test_full_size_properties_10m(gpu):
+    # BASELINE.json's size (10M points): properties that do not need the oracle.
+    import torch
+    import pcl_amd
+    from pcl_amd import synth
+    n = 10_000_000
+    tgt_h = synth.gaussian_surface(n, synth.TARGET_SEED)
+    tgt = torch.from_numpy(tgt_h).cuda()
+    tree = pcl_amd.KdTree(gpu)
+    tree.setInputCloud(tgt)
+    # (1) self-queries: every point finds itself at distance 0 (ties between duplicates -> lower index)
+    idx, d2 = tree.nearestKSearch(tgt, 1)
+    assert int((d2 != 0).sum()) == 0
+    ar = torch.arange(n, device="cuda", dtype=torch.int32)
+    moved = idx[:, 0] != ar
+    assert bool((idx[:, 0][moved] < ar[moved]).all())            # only duplicates, resolved downwards
+    assert bool((tgt[idx[:, 0][moved].long(), :3] == tgt[moved, :3]).all())
+    # (2) k = 8: ascending distances, first neighbour is the point itself, no index repeats in a row
+    idx8, d8 = tree.nearestKSearch(tgt[:2_000_000], 8)
+    assert bool((d8[:, 1:] >= d8[:, :-1]).all()) and int((d8[:, 0] != 0).sum()) == 0
+    s = torch.sort(idx8, dim=1).values
+    assert int((s[:, 1:] == s[:, :-1]).sum()) == 0
+    # (3) a rigidly moved copy of the target: after undoing the motion every source point matches its own
+    #     original (or an exact duplicate) within float rounding, all 10M correspondences are kept
+    T = synth.ground_truth_transform().astype(np.float32)
+    icp = pcl_amd.IterativeClosestPoint(gpu)
+    icp.setSearchMethodTarget(tree)
+    src = torch.from_numpy(synth.apply_rigid(T, tgt_h)).cuda()
+    icp.setInputSource(src)
+    icp.reset()
+    sums = icp.iterate(np.linalg.inv(T.astype(np.float64)).astype(np.float32), max_dist=0.1)
+    assert sums[28] == n and sums[27] / n < 1e-12                 # mean squared distance ~ rounding^2
+    # (4) idempotence: a second iteration with the identity reproduces the same record bit for bit
+    again = icp.iterate(np.eye(4, dtype=np.float32), max_dist=0.1)
+    assert np.array_equal(again[27:29], sums[27:29]) and np.array_equal(again[:15], sums[:15])
+    # (5) the alignment from the benchmark start pose converges to the ground truth
+    src2 = torch.from_numpy(synth.apply_rigid(np.linalg.inv(synth.ground_truth_transform()),
+                                              synth.gaussian_surface(n, synth.SOURCE_SEED))).cuda()
+    ne = pcl_amd.NormalEstimation(gpu)
+    ne.setInputCloud(tgt)
+    ne.setSearchMethod(tree)
+    ne.setKSearch(8)
+    ne.setViewPoint(0, 0, 10)
+    ne.compute(want_output=False)
+    icp2 = pcl_amd.IterativeClosestPointWithNormals(gpu)
+    icp2.setSearchMethodTarget(tree)
+    icp2.setInputSource(src2)
+    icp2.setMaximumIterations(20)
+    icp2.setMaxCorrespondenceDistance(0.1)
+    icp2.setTransformationEpsilon(1e-10)
+    icp2.align()
+    assert icp2.hasConverged()
+    assert np.abs(icp2.getFinalTransformation() - synth.ground_truth_transform()).max() < 1e-4
