@@ -190,6 +190,13 @@ def main():
                       "normals_kernel_ms": None if normals_ms is None else round(normals_ms, 3),
                       "synth_gen_s": round(gen_s, 1)},
         }
+        # RCCL (NCCL_DEBUG=VERSION on this image) writes its banner through C stdio, which would otherwise be
+        # flushed after this line at exit: push it out first so the JSON line is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
