@@ -506,8 +506,11 @@ pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out) {
   icp->prev_mse = DBL_MAX;
   if (hipMalloc(&icp->sums_dev, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
       hipHostMalloc(&icp->sums_host, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
-      hipEventCreate(&icp->ev0) != hipSuccess || hipEventCreate(&icp->ev1) != hipSuccess ||
-      hipEventCreate(&icp->ev_mid) != hipSuccess) {
+      // timing markers between kernels of one stream: device-scope release is enough (a system-scope
+      // release would write the iteration's dirty lines back to memory at every marker)
+      hipEventCreateWithFlags(&icp->ev0, hipEventReleaseToDevice) != hipSuccess ||
+      hipEventCreateWithFlags(&icp->ev1, hipEventReleaseToDevice) != hipSuccess ||
+      hipEventCreateWithFlags(&icp->ev_mid, hipEventReleaseToDevice) != hipSuccess) {
     set_error(ctx, "allocation failed in pclhip_icp_create");
     pclhip_icp_destroy(icp);
     return PCLHIP_ERR_HIP;
