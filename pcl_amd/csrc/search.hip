@@ -1018,17 +1018,8 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   }();
   const bool filters = icp->reciprocal || !icp->rejectors.empty();
   if (icp->n > 0 && (unfused || filters || mode == PCLHIP_ICP_SYMMETRIC)) {
-    static const int qpl = [] {
-      const char* e = getenv("PCLHIP_ICP_QPL");
-      return (e && atoi(e) == 2) ? 2 : 1;  // QPL=2 spills (measured slower); kept as an A/B switch
-    }();
-    static const int sparse = [] {
-      const char* e = getenv("PCLHIP_ICP_SPARSE");
-      return (e && atoi(e) == 0) ? 0 : 1;
-    }();
-    auto ks = (qpl == 2) ? icp_search_kernel<4, 2, false>
-                         : (sparse ? icp_search_kernel<4, 1, true> : icp_search_kernel<4, 1, false>);
-    const uint32_t ngroups_s = (icp->n + WAVE * qpl - 1) / (WAVE * qpl);
+    auto ks = icp_search_kernel<4, 1, true>;
+    const uint32_t ngroups_s = (icp->n + WAVE - 1) / WAVE;
     const int gs = resident_blocks(ctx, ks, ngroups_s);
     (void)hipEventRecord(icp->ev0, s);
     hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound,
