@@ -1068,3 +1068,75 @@ np.savez(sys.argv[1], **out)
             assert np.allclose(a, b, rtol=1e-9, atol=1e-12), key   # fp64 sums, different partial-sum grouping
         else:
             assert np.array_equal(a, b), key
+
+
+# ------------------------------------------------------------------------------------------------
+# mirrors of the reference's own end-to-end registration tests (property checks, no oracle)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_reference_run_icp_with_normals(gpu, bunny, symmetric):
+    # test/registration/test_registration.cpp:272-318 (runICPWithNormals, both objectives)
+    import pcl_amd
+    src, tgt = xyz1(bunny["bun0"]), xyz1(bunny["bun4"])
+    normals = {}
+    for name, cloud in (("src", src), ("tgt", tgt)):
+        ne = pcl_amd.NormalEstimation(gpu)
+        ne.setInputCloud(cloud)
+        ne.setKSearch(10)
+        normals[name] = np.ascontiguousarray(ne.compute()[:, :3])
+        assert ne.nan_count == 0
+    reg = pcl_amd.IterativeClosestPointWithNormals(gpu)
+    reg.setInputSource(src)
+    reg.setSourceNormals(normals["src"])
+    reg.setInputTarget(tgt)
+    reg.setTargetNormals(normals["tgt"])
+    reg.setUseSymmetricObjective(symmetric)
+    reg.setMaximumIterations(50)
+    reg.setTransformationEpsilon(1e-8)
+    reg.setMaxCorrespondenceDistance(0.05)
+    out = reg.align(want_output=True)
+    assert len(out) == len(src)
+    assert reg.hasConverged()
+    assert reg.getFitnessScore() < 0.001
+
+
+def _random_transform(rng, max_angle, max_trans):
+    # sampleRandomTransform, test/registration/test_registration.cpp:321-333
+    axis = rng.uniform(0, 1, 3)
+    axis /= np.linalg.norm(axis)
+    angle = rng.uniform(0, 1) * max_angle
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = rng.uniform(0, 1, 3) * max_trans
+    return T
+
+
+def test_reference_icp_with_rejectors_random_global_transforms(gpu, bunny):
+    # test/registration/test_registration.cpp:336-382 (median-distance rejector; the SaC rejector of that test is
+    # outside the path): a fixed offset between the pair under random global poses is recovered to 1 cm / 0.1
+    import pcl_amd
+    from pcl_amd import synth
+    rng = np.random.default_rng(0)
+    source = xyz1(bunny["bun0"])
+    for t in range(10):
+        delta = _random_transform(rng, 0.0, 0.05)
+        net = _random_transform(rng, 2 * np.pi, 10.0)
+        src = synth.apply_rigid(np.linalg.inv(delta) @ net, source)
+        tgt = synth.apply_rigid(net, source)
+        reg = pcl_amd.IterativeClosestPoint(gpu)
+        reg.setMaximumIterations(50)
+        reg.setTransformationEpsilon(1e-8)
+        reg.setMaxCorrespondenceDistance(0.15)
+        rej = pcl_amd.CorrespondenceRejectorMedianDistance()
+        rej.setMedianFactor(4.0)
+        reg.addCorrespondenceRejector(rej)
+        reg.setInputSource(src)
+        reg.setInputTarget(tgt)
+        reg.align()
+        T = reg.getFinalTransformation()
+        # src = delta^-1 (net p), tgt = net p  =>  the registration is delta itself (:372-379)
+        assert np.abs(T[:3, 3] - delta[:3, 3]).max() < 1e-2, t        # "translation should be within 1cm"
+        assert np.abs(T[:3, :3] - delta[:3, :3]).max() < 1e-1, t      # "rotation within .1"
+        assert reg.hasConverged(), t
