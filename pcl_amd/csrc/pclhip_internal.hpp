@@ -30,7 +30,7 @@ constexpr int FANOUT = 64;      // children per internal node = one per lane of 
 constexpr int MAX_LEVELS = 8;   // 16 * 64^7 points
 constexpr int WAVE = 64;
 constexpr uint32_t NO_INDEX = 0xFFFFFFFFu;
-constexpr int TOPCACHE_BOXES = 192;  // 6 KB of LDS per block
+constexpr int TOPCACHE_BOXES = 176;  // 5.5 KB of LDS per block
 
 struct Box {       // 32 B: two aligned float4 loads
   float4 lo;       // xyz = min corner

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
       traverse<NN1Min, true>(ix, qx, qy, qz, vv, fast, wl_s[threadIdx.x / WAVE], topbox_s, ts);
       fast.resolve(ix, qx, qy, qz);
       NN1 pol;
+      pol.soa = ix.soa;
       pol.key = KEY_NONE;
       pol.pos = fast.bestpos[0];
       if (fast.bestpos[0] != NO_INDEX) pol.key = make_key(fast.best[0], __float_as_uint(ix.pts[fast.bestpos[0]].w));
@@ -576,6 +577,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_iterate_kernel(IndexView ix, 
     traverse<NN1Min, true>(ix, qx, qy, qz, vv, fast, wl_s[wave], topbox_s, ts);
     fast.resolve(ix, qx, qy, qz);
     NN1 pol;
+    pol.soa = ix.soa;
     pol.key = KEY_NONE;
     pol.pos = fast.bestpos[0];
     if (fast.bestpos[0] != NO_INDEX) pol.key = make_key(fast.best[0], __float_as_uint(ix.pts[fast.bestpos[0]].w));
@@ -677,7 +679,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
                                                                  float* __restrict__ match_d2,
                                                                  unsigned long long* gstats) {
   const int use_max = flags & 1;        // a finite max correspondence distance is set
-  __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
+  // no policy of this kernel stages the w chunks: 3 KB of staging per wave (see WaveLdsT)
+  __shared__ WaveLdsT<3072> wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
   load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
@@ -758,6 +761,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       NN1 pol;
+      pol.soa = ix.soa;
       pol.key = KEY_NONE;
       pol.pos = fast.bestpos[q];
       if (fast.bestpos[q] != NO_INDEX) {  // winner's original index: already here when the seed won

@@ -29,12 +29,17 @@ constexpr int STACK_ENTRIES = 208;
 constexpr int LEAF_BATCH = 16;         // leaves staged in LDS at a time (16 x 256 B = 4 KB)
 constexpr int LEAF_FLOATS = 4 * LEAF;  // x[16] y[16] z[16] w[16]
 
-// Per-wavefront LDS working set (7.5 KB): traversal stack, ranked leaf list, staged candidate blocks.
-struct __attribute__((aligned(16))) WaveLds {
-  uint2 stack[STACK_ENTRIES];           // 1.6 KB
-  float4 list[2 * FANOUT];              // 2 KB: per ranked leaf (lo.xyz, id) (hi.xyz, lbG)
-  float buf[LEAF_BATCH * LEAF_FLOATS];  // 4 KB
+// Per-wavefront LDS working set: traversal stack (1.6 KB), ranked leaf list (2 KB), staged candidate
+// blocks.  WaveLdsT<3072> (no room for the w[16] chunks) is for kernels whose policies never stage the
+// original indices: 6.6 KB per wave, which lets a 4-wave block fit five times into a CU's 160 KB.
+template <int BUF_BYTES>
+struct __attribute__((aligned(16))) WaveLdsT {
+  static constexpr int BUF_FLOATS = BUF_BYTES / 4;
+  uint2 stack[STACK_ENTRIES];
+  float4 list[2 * FANOUT];  // per ranked leaf (lo.xyz, id) (hi.xyz, lbG)
+  float buf[BUF_FLOATS];
 };
+typedef WaveLdsT<LEAF_BATCH * LEAF_FLOATS * 4> WaveLds;  // 4 KB of staging: x y z w chunks of 16 leaves
 
 __device__ __forceinline__ float l2_simple(float qx, float qy, float qz, float cx, float cy, float cz) {
   const float dx = __fsub_rn(qx, cx), dy = __fsub_rn(qy, cy), dz = __fsub_rn(qz, cz);
@@ -181,17 +186,21 @@ struct NN1 {
       pos = t ? base + c : pos;
     }
   }
-  // lane-sparse evaluation from the transposed LDS staging buffer (see traverse(): SPARSE)
+  // lane-sparse evaluation from the transposed LDS staging buffer (see traverse(): SPARSE); this policy
+  // only runs for the rare tie lanes, so the original indices come straight from the SoA copy (`soa`)
+  // instead of occupying staging space
   static constexpr bool LANE_SPARSE = true;
-  static constexpr bool NEEDS_W = true;
+  static constexpr bool NEEDS_W = false;
+  const float* soa = nullptr;  // IndexView::soa
   __device__ __forceinline__ void leaf_lane(const float* buf, uint32_t slot, uint32_t leaf_id, const float* qx,
                                             const float* qy, const float* qz) {
     if (leaf_id != NO_INDEX) {
       const float4* s = reinterpret_cast<const float4*>(buf) + slot;  // chunk c at s[c * 16]
+      const float4* wsrc = reinterpret_cast<const float4*>(soa + size_t(leaf_id) * LEAF_FLOATS + 3 * LEAF);
       const uint32_t base = leaf_id * LEAF;
 #pragma unroll
       for (int c4 = 0; c4 < LEAF / 4; ++c4) {
-        const float4 X = s[c4 * 16], Y = s[(4 + c4) * 16], Z = s[(8 + c4) * 16], W = s[(12 + c4) * 16];
+        const float4 X = s[c4 * 16], Y = s[(4 + c4) * 16], Z = s[(8 + c4) * 16], W = wsrc[c4];
         const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w},
                     ws[4] = {W.x, W.y, W.z, W.w};
 #pragma unroll
@@ -534,9 +543,9 @@ __device__ __forceinline__ float lane_worst(const Policy& pol, const bool* valid
 }
 
 // qx/qy/qz/valid: Policy::QPL queries per lane (the wave owns 64*QPL spatially compact queries).
-template <class Policy, bool SPARSE = false>
+template <class Policy, bool SPARSE = false, class WL = WaveLds>
 __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, const float* qy, const float* qz,
-                                         const bool* valid, Policy& pol, WaveLds& wl, const Box* topbox,
+                                         const bool* valid, Policy& pol, WL& wl, const Box* topbox,
                                          TraverseStats& ts) {
   constexpr int QPL = Policy::QPL;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -639,6 +648,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         // (16 bytes) of the leaf in batch slot s lands at ((c * 16 + s) * 16) bytes, so lanes that read
         // the same chunk of different leaves hit different banks.  The DMA runs under the box tests.
         constexpr int NCHUNK = Policy::NEEDS_W ? 16 : 12;  // x[16] y[16] z[16] (+ w[16]) in 16-byte chunks
+        static_assert(NCHUNK * LEAF_BATCH * 4 <= WL::BUF_FLOATS, "staging buffer too small for this policy");
         const auto round = [&](uint32_t slot, uint32_t id) {
           const uint64_t act = __builtin_amdgcn_ballot_w64(id != NO_INDEX);
           if (act == 0) return;
@@ -744,6 +754,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
           if (__builtin_amdgcn_ballot_w64(valid[0] && after < before) != 0) T = wave_max_f(valid[0] ? after : 0.0f);
         }
       } else {
+      static_assert(SPARSE || LEAF_BATCH * LEAF_FLOATS <= WL::BUF_FLOATS, "wave-uniform evaluation stages whole leaves");
       bool cut = false;
       for (uint32_t b0 = 0; b0 < n_alive && !cut; b0 += LEAF_BATCH) {
         const uint32_t nb = (n_alive - b0) < uint32_t(LEAF_BATCH) ? (n_alive - b0) : uint32_t(LEAF_BATCH);
