@@ -268,12 +268,16 @@ pclhip_status pclhip_index_build(pclhip_ctx* ctx, const void* points, size_t str
     guard.add(owned);
   }
   const uint64_t m = indices ? n_indices : n;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  PCLHIP_CHECK_HIP(ctx, hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) {
+    (void)hipEventDestroy(e0);
+    set_error(ctx, "hipEventCreate failed");
+    return PCLHIP_ERR_HIP;
+  }
   pclhip_index* ix = new pclhip_index();
   ix->ctx = ctx;
   ix->n_orig = n;
-  hipEvent_t e0, e1;
-  PCLHIP_CHECK_HIP(ctx, hipEventCreate(&e0));
-  PCLHIP_CHECK_HIP(ctx, hipEventCreate(&e1));
   (void)hipEventRecord(e0, ctx->stream);
   const uint32_t cap = uint32_t(((m + LEAF - 1) / LEAF) * LEAF) + LEAF;
   auto fail = [&](pclhip_status s) {
@@ -297,7 +301,10 @@ pclhip_status pclhip_index_build(pclhip_ctx* ctx, const void* points, size_t str
   st = build_boxes(ix);
   if (st != PCLHIP_OK) return fail(st);
   (void)hipEventRecord(e1, ctx->stream);
-  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    set_error(ctx, "index build failed on the device");
+    return fail(PCLHIP_ERR_HIP);
+  }
   float ms = 0;
   (void)hipEventElapsedTime(&ms, e0, e1);
   ix->build_ms = ms;

@@ -138,6 +138,31 @@ struct pclhip_icp {
 namespace pclhip {
 
 // ---- error plumbing -----------------------------------------------------------------------
+// Frees device allocations and destroys events on scope exit (every early error return included).
+struct DeviceScope {
+  std::vector<void*> mem;
+  std::vector<hipEvent_t> events;
+  ~DeviceScope() {
+    for (void* p : mem)
+      if (p) (void)hipFree(p);
+    for (hipEvent_t e : events)
+      if (e) (void)hipEventDestroy(e);
+  }
+  template <class T>
+  hipError_t alloc(T** ptr, size_t bytes) {
+    *ptr = nullptr;
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(ptr), bytes ? bytes : 16);
+    if (e == hipSuccess) mem.push_back(*ptr);
+    return e;
+  }
+  hipError_t event(hipEvent_t* ev) {
+    *ev = nullptr;
+    const hipError_t e = hipEventCreate(ev);
+    if (e == hipSuccess) events.push_back(*ev);
+    return e;
+  }
+};
+
 void set_error(pclhip_ctx* ctx, const std::string& msg);
 #define PCLHIP_CHECK_HIP(ctx, expr)                                                         \
   do {                                                                                      \

@@ -328,16 +328,17 @@ __global__ void iota_w_kernel(const float4* __restrict__ pts, uint32_t n, float4
 pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_t* nan_count) {
   pclhip_ctx* ctx = ix->ctx;
   hipStream_t s = ctx->stream;
+  DeviceScope scope;
   if (!ix->nrm) PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->nrm, size_t(ix->n_pad > 0 ? ix->n_pad : 1) * sizeof(float4)));
   unsigned long long* d_nan = nullptr;
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&d_nan, sizeof(unsigned long long)));
+  PCLHIP_CHECK_HIP(ctx, scope.alloc(&d_nan, sizeof(unsigned long long)));
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_nan, 0, sizeof(unsigned long long), s));
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(ix->nrm, 0xFF, size_t(ix->n_pad) * sizeof(float4), s));  // NaN pads
   const IndexView v = ix->view();
   const uint32_t ngroups = (ix->n + WAVE - 1) / WAVE;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
+  PCLHIP_CHECK_HIP(ctx, scope.event(&e0));
+  PCLHIP_CHECK_HIP(ctx, scope.event(&e1));
   (void)hipEventRecord(e0, s);
   if (ix->n > 0) {
     if (k <= 8) {
@@ -349,38 +350,32 @@ pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_
     } else if (k <= 32) {
       hipLaunchKernelGGL(normals_kernel<32>, dim3(resident_blocks(ctx, normals_kernel<32>, ngroups)), dim3(BLOCK), 0, s, v, k, vp[0],
                          vp[1], vp[2], ix->nrm, d_nan, ctx->stats);
-    } else {
+    } else {  // k > 32: materialise the k-NN lists (heap kernel), then fit the planes
       float4* q = nullptr;
       int32_t* nb = nullptr;
       float* nd = nullptr;
-      PCLHIP_CHECK_HIP(ctx, hipMalloc(&q, size_t(ix->n) * sizeof(float4)));
-      PCLHIP_CHECK_HIP(ctx, hipMalloc(&nb, size_t(ix->n) * k * sizeof(int32_t)));
-      PCLHIP_CHECK_HIP(ctx, hipMalloc(&nd, size_t(ix->n) * k * sizeof(float)));
+      PCLHIP_CHECK_HIP(ctx, scope.alloc(&q, size_t(ix->n) * sizeof(float4)));
+      PCLHIP_CHECK_HIP(ctx, scope.alloc(&nb, size_t(ix->n) * k * sizeof(int32_t)));
+      PCLHIP_CHECK_HIP(ctx, scope.alloc(&nd, size_t(ix->n) * k * sizeof(float)));
       hipLaunchKernelGGL(iota_w_kernel, dim3((ix->n + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, q);
-      pclhip_status st = launch_knn(ix, q, ix->n, k, nb, nd);
-      if (st == PCLHIP_OK)
-        hipLaunchKernelGGL(normals_from_knn_kernel, dim3((ix->n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, v, k,
-                           ix->rank, nb, vp[0], vp[1], vp[2], ix->nrm, d_nan);
-      hipError_t e = hipStreamSynchronize(s);
-      (void)hipFree(q);
-      (void)hipFree(nb);
-      (void)hipFree(nd);
-      if (st != PCLHIP_OK) return st;
-      PCLHIP_CHECK_HIP(ctx, e);
+      const pclhip_status st = launch_knn(ix, q, ix->n, k, nb, nd);
+      if (st != PCLHIP_OK) {
+        (void)hipStreamSynchronize(s);  // nothing may still use the scope's buffers when they are freed
+        return st;
+      }
+      hipLaunchKernelGGL(normals_from_knn_kernel, dim3((ix->n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, v, k, ix->rank, nb,
+                         vp[0], vp[1], vp[2], ix->nrm, d_nan);
     }
   }
   (void)hipEventRecord(e1, s);
-  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
-  if (hipEventSynchronize(e1) == hipSuccess) {
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ix->last_kernel_ms = ms;
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   unsigned long long h = 0;
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&h, d_nan, sizeof h, hipMemcpyDeviceToHost, s));
-  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-  (void)hipFree(d_nan);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, d_nan, sizeof h, hipMemcpyDeviceToHost, s);
+  const hipError_t es = hipStreamSynchronize(s);  // always drain the stream before the scope frees its buffers
+  PCLHIP_CHECK_HIP(ctx, e);
+  PCLHIP_CHECK_HIP(ctx, es);
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ix->last_kernel_ms = ms;
   if (nan_count) *nan_count = h;
   ix->has_normals = true;
   return PCLHIP_OK;
