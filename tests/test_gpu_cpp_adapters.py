@@ -35,3 +35,44 @@ def test_cpp_adapters_bunny_goldens(tmp_path, bunny, golden):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ALL OK" in r.stdout
+
+
+def build_c_example(tmp_path):
+    exe = str(tmp_path / "icp_pcd")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "icp_pcd.c"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "pcl_amd"), "-lpclhip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "pcl_amd"), "-lm"])
+    return exe
+
+
+def test_c_example_compiles_as_plain_c(tmp_path):
+    # CPU-only: include/pclhip.h is a C header; the example uses nothing but the C ABI
+    exe = build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_registers_the_bunny_pair(tmp_path, bunny, golden):
+    # PCD in -> index, normals, point-to-plane ICP, fitness -> PCD out, all through the C ABI from plain C
+    import pcl_amd
+    exe = build_c_example(tmp_path)
+    src_path = os.path.join(ROOT, "tests", "golden", "pcd", "bun0.pcd")          # ascii, with normals (ignored)
+    tgt_path = str(tmp_path / "bun4.pcd")
+    tgt = np.ones((len(bunny["bun4"]), 4), np.float32)
+    tgt[:, :3] = bunny["bun4"][:, :3]
+    pcl_amd.savePCDFile(tgt_path, tgt, "binary_compressed")
+    out_path = str(tmp_path / "aligned.pcd")
+    r = subprocess.run([exe, src_path, tgt_path, out_path, "0.05", "50"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "converged 1" in r.stdout
+    fitness = float(r.stdout.split("fitness ")[1].split(",")[0])
+    assert fitness < 0.001                         # test/registration/test_registration.cpp:301-302
+    aligned, dense = pcl_amd.loadPCDFile(out_path)
+    assert dense and aligned.shape == (397, 4)
+    # the written cloud is the source moved by the printed transformation
+    rows = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("  ") and len(ln.split()) == 4]
+    T = np.asarray(rows[-4:], np.float64)
+    want = bunny["bun0"][:, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    assert np.abs(aligned[:, :3] - want).max() < 1e-5
