@@ -86,3 +86,43 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(pcl_amd.PclHipError) as e:
         pcl_amd.Context(0)
     assert e.value.status == -3  # PCLHIP_ERR_NO_DEVICE
+
+
+def test_host_solvers_match_the_oracle_on_cpu():
+    """pclhip_solve_transformation is host code (6x6 solve / umeyama): checkable without a GPU for all three
+    estimators, from reduction records produced by the oracle."""
+    import ctypes as C
+
+    import numpy as np
+
+    from oracle import pcl_oracle as orc
+    from pcl_amd import _lib
+    lib = _lib.load()
+    xs = np.arange(-5.0, 5.0001, 0.5, dtype=np.float32)
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    x, y = X.ravel(), Y.ravel()
+    z = np.float32(0.1) * x ** 2 + np.float32(0.2) * x * y - np.float32(0.3) * y + np.float32(1.0)
+    n = np.stack([-0.2 * x - 0.2, 0.6 * y - 0.2, np.ones_like(x)], 1).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    src = np.stack([x, y, z, np.ones_like(x)], 1).astype(np.float32)
+    G = np.array([[0.9938, 0.0988, 0.0517, 0.1], [-0.0997, 0.9949, 0.0149, -0.2], [-0.05, -0.02, 0.9986, 0.3],
+                  [0, 0, 0, 1]], np.float32)
+    tgt, tn = orc.transform_cloud(G, src, order=1, normals=n)
+
+    def solve(rec, mode):
+        T = np.zeros(16, np.float32)
+        r = np.zeros(_lib.NSUMS, np.float64)
+        r[:len(rec)] = rec
+        r[28] = len(src)
+        assert lib.pclhip_solve_transformation(r.ctypes.data_as(C.POINTER(C.c_double)), mode,
+                                               T.ctypes.data_as(C.POINTER(C.c_float))) == 0
+        return T.reshape(4, 4)
+    To, s27, _ = orc.lls_point_to_plane(src, tgt, tn)
+    assert np.abs(solve(s27, _lib.POINT_TO_PLANE) - To).max() < 1e-6
+    To, s27, _ = orc.lls_symmetric(src, n, tgt, tn)
+    assert np.abs(solve(s27, _lib.SYMMETRIC) - To).max() < 1e-6
+    s, t = src[:, :3].astype(np.float64), tgt[:, :3].astype(np.float64)
+    rec = np.concatenate([s.sum(0), t.sum(0), (t.T @ s).reshape(9)])
+    assert np.abs(solve(rec, _lib.POINT_TO_POINT) - orc.umeyama(src, tgt, acc_double=True)).max() < 2e-6
+    assert lib.pclhip_solve_transformation(np.zeros(32).ctypes.data_as(C.POINTER(C.c_double)), 7,
+                                           np.zeros(16, np.float32).ctypes.data_as(C.POINTER(C.c_float))) != 0
