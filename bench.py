@@ -2,7 +2,7 @@
 """bench.py -- headline metric of BASELINE.json: ICP correspondences/s (+ ms/iteration) on the
 10M-point synthetic Gaussian-surface cloud, k=8 normals + point-to-plane ICP, on N MI355X GPUs.
 
-A "step" is ONE fused ICP iteration over the whole (rank-local) source cloud: transform ->
+A "step" is ONE ICP iteration over the whole (rank-local) source cloud: transform ->
 exact 1-NN in the target -> 6x6 normal-system accumulation -> (all-reduce) -> host solve.
 Iterations are drawn from repeated IterativeClosestPointWithNormals::align() runs on the config's
 clouds (point-to-plane converges in ~3-4 iterations): when an alignment

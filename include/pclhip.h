@@ -172,7 +172,7 @@ typedef struct {
   uint64_t num_correspondences;     /* of the last iteration */
   double mse;                       /* mean squared correspondence distance, last iteration */
   double gpu_ms;                    /* GPU time of all iterate launches (events on ctx stream) */
-  double gpu_ms_search_kernel;      /* ... of which the fused search+accumulate kernel */
+  double gpu_ms_search_kernel;      /* ... of which the search + accumulate kernels of the iterations */
 } pclhip_icp_result;
 
 /* Optional hook run on the 32-double DEVICE record of every iteration before the host reads it:
@@ -221,7 +221,8 @@ PCLHIP_API double pclhip_icp_last_median_distance(const pclhip_icp* icp);
  * as the reference does). */
 PCLHIP_API pclhip_status pclhip_icp_set_reciprocal(pclhip_icp* icp, int enable);
 
-/* One fused iteration on the device-resident working source cloud:
+/* One iteration on the device-resident working source cloud (a search kernel and a streaming
+ * accumulation kernel; PCLHIP_ICP_FUSED=1 selects the single-kernel form):
  *   cur <- T_prev * cur   (transformCloud, impl/icp.hpp:49-111 / transforms.hpp:109-123)
  *   1-NN of every cur point in the target, drop d2 > max_dist^2
  *        (CorrespondenceEstimation::determineCorrespondences, impl/correspondence_estimation.hpp:145-218)
@@ -232,7 +233,7 @@ PCLHIP_API pclhip_status pclhip_icp_set_reciprocal(pclhip_icp* icp, int enable);
 PCLHIP_API pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[16], double max_dist,
                                             int mode, double sums[PCLHIP_ICP_NSUMS]);
 
-/* GPU time (ms, HIP events on the context stream) of the fused search+accumulate kernel of the
+/* GPU time (ms, HIP events on the context stream) of the search + accumulate kernels of the
  * last pclhip_icp_iterate call. */
 PCLHIP_API double pclhip_icp_last_kernel_ms(const pclhip_icp* icp);
 /* Duration (ms) of the search kernel alone in the last pclhip_icp_iterate (the default iteration is

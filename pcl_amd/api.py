@@ -479,7 +479,7 @@ class IterativeClosestPoint:
             self._filters_dirty = False
 
     def iterate(self, T_prev=None, max_dist=None):
-        """One fused device iteration; returns the 32-double reduction record."""
+        """One device iteration (search + accumulate kernels); returns the 32-double reduction record."""
         self._ensure()
         T = np.eye(4, dtype=np.float32) if T_prev is None else np.ascontiguousarray(T_prev, np.float32)
         sums = np.zeros(_lib.NSUMS, np.float64)
