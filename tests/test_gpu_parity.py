@@ -1140,3 +1140,27 @@ def test_reference_icp_with_rejectors_random_global_transforms(gpu, bunny):
         assert np.abs(T[:3, 3] - delta[:3, 3]).max() < 1e-2, t        # "translation should be within 1cm"
         assert np.abs(T[:3, :3] - delta[:3, :3]).max() < 1e-1, t      # "rotation within .1"
         assert reg.hasConverged(), t
+
+
+def test_reference_correspondences_with_cached_search_tree(gpu):
+    # test/registration/test_correspondence_estimation.cpp:138-176: a search tree handed over with
+    # force_no_recompute gives the same correspondences as the estimator's own tree
+    import pcl_amd
+    rng = np.random.default_rng(11)
+    cloud1 = rng.uniform(-1, 1, (50, 3)).astype(np.float32)
+    cloud2 = rng.uniform(-1, 1, (50, 3)).astype(np.float32)
+    ce = pcl_amd.CorrespondenceEstimation(gpu)
+    ce.setInputSource(cloud1)
+    ce.setInputTarget(cloud2)
+    q0, m0, d0 = ce.determineCorrespondences()
+    tree2 = build_tree(gpu, cloud2)
+    ce.setSearchMethodTarget(tree2, True)
+    q1, m1, d1 = ce.determineCorrespondences()
+    assert len(q0) == 50 and np.array_equal(q0, q1) and np.array_equal(m0, m1) and np.array_equal(d0, d1)
+    # the same tree object serves several consumers (ICP + normals + another estimator) without a rebuild
+    h = tree2.h.value
+    ce2 = pcl_amd.CorrespondenceEstimation(gpu)
+    ce2.setSearchMethodTarget(tree2, True)
+    ce2.setInputSource(cloud1)
+    q2, m2, d2 = ce2.determineCorrespondences()
+    assert tree2.h.value == h and np.array_equal(m2, m0)
