@@ -21,7 +21,16 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <string>
+#include <string_view>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "pclhip_internal.hpp"
@@ -64,7 +73,7 @@ std::vector<std::string> split_ws(const std::string& line) {
 bool starts_with(const std::string& s, const char* p) { return s.compare(0, std::strlen(p), p) == 0; }
 
 // PCDReader::readHeader, io/src/pcd_io.cpp:115-392.  `err` receives the reference's message on failure.
-bool parse_header(const std::string& bytes, Header& h, std::string& err) {
+bool parse_header(std::string_view bytes, Header& h, std::string& err) {
   size_t pos = 0;
   bool width_read = false, height_read = false, points_read = false, data_seen = false;
   std::vector<int> sizes;
@@ -72,7 +81,7 @@ bool parse_header(const std::string& bytes, Header& h, std::string& err) {
   while (pos < bytes.size()) {
     size_t eol = bytes.find('\n', pos);
     if (eol == std::string::npos) eol = bytes.size();
-    const std::string line = bytes.substr(pos, eol - pos);
+    const std::string line(bytes.substr(pos, eol - pos));
     pos = eol + 1;
     const std::vector<std::string> st = split_ws(line);
     if (st.empty()) continue;
@@ -299,22 +308,39 @@ size_t lzf_compress(const unsigned char* in, size_t in_len, unsigned char* out, 
   return op;
 }
 
-bool read_file(const char* path, std::string& bytes, std::string& err) {
-  std::FILE* f = std::fopen(path, "rb");
-  if (!f) {
+// The file mapped read-only: binary bodies are used in place (no copy of the file image), and a header
+// query touches only the first pages.
+struct MappedFile {
+  const char* data = nullptr;
+  size_t size = 0;
+  int fd = -1;
+  ~MappedFile() {
+    if (data && size) ::munmap(const_cast<char*>(data), size);
+    if (fd >= 0) ::close(fd);
+  }
+  std::string_view view() const { return std::string_view(data ? data : "", size); }
+};
+
+bool read_file(const char* path, MappedFile& mf, std::string& err) {
+  mf.fd = ::open(path, O_RDONLY);
+  if (mf.fd < 0) {
     err = std::string("cannot open ") + path + ": " + std::strerror(errno);
     return false;
   }
-  std::fseek(f, 0, SEEK_END);
-  const long sz = std::ftell(f);
-  std::fseek(f, 0, SEEK_SET);
-  bytes.resize(sz > 0 ? size_t(sz) : 0);
-  const size_t got = bytes.empty() ? 0 : std::fread(&bytes[0], 1, bytes.size(), f);
-  std::fclose(f);
-  if (got != bytes.size()) {
-    err = std::string("short read on ") + path;
+  struct stat st;
+  if (::fstat(mf.fd, &st) != 0) {
+    err = std::string("cannot stat ") + path + ": " + std::strerror(errno);
     return false;
   }
+  mf.size = size_t(st.st_size);
+  if (mf.size == 0) return true;
+  void* p = ::mmap(nullptr, mf.size, PROT_READ, MAP_PRIVATE, mf.fd, 0);
+  if (p == MAP_FAILED) {
+    err = std::string("cannot map ") + path + ": " + std::strerror(errno);
+    mf.size = 0;
+    return false;
+  }
+  mf.data = static_cast<const char*>(p);
   return true;
 }
 
@@ -324,147 +350,214 @@ int find_field(const Header& h, const char* name) {
   return -1;
 }
 
-// element `c` of field f of a point stored array-of-structs at p, as double
-double load_value(const unsigned char* p, const Field& f, int c) {
-  const unsigned char* q = p + f.offset + size_t(c) * size_t(f.size);
-  switch (f.type) {
+// ---- small thread pool for the body loops (no OpenMP runtime dependency in the shipped library) ------
+template <class F>
+void parallel_for(uint64_t n, uint64_t grain, F&& body) {  // body(begin, end)
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 4;
+  uint64_t nt = (n + grain - 1) / (grain ? grain : 1);
+  if (nt > hw) nt = hw;
+  if (nt > 8) nt = 8;  // first-touch page faults of a fresh destination buffer stop scaling beyond this
+  if (nt <= 1) {
+    body(uint64_t(0), n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const uint64_t chunk = (n + nt - 1) / nt;
+  for (uint64_t t = 0; t < nt; ++t) {
+    const uint64_t lo = t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    if (lo >= hi) break;
+    th.emplace_back([&body, lo, hi] { body(lo, hi); });
+  }
+  for (auto& x : th) x.join();
+}
+
+// element `c` of a field stored at q, as double
+inline double load_scalar(const unsigned char* q, int size, char type) {
+  switch (type) {
     case 'F':
-      if (f.size == 4) { float v; std::memcpy(&v, q, 4); return v; }
-      if (f.size == 8) { double v; std::memcpy(&v, q, 8); return v; }
+      if (size == 4) { float v; std::memcpy(&v, q, 4); return v; }
+      if (size == 8) { double v; std::memcpy(&v, q, 8); return v; }
       break;
     case 'I':
-      if (f.size == 1) { int8_t v; std::memcpy(&v, q, 1); return v; }
-      if (f.size == 2) { int16_t v; std::memcpy(&v, q, 2); return v; }
-      if (f.size == 4) { int32_t v; std::memcpy(&v, q, 4); return v; }
-      if (f.size == 8) { int64_t v; std::memcpy(&v, q, 8); return double(v); }
+      if (size == 1) { int8_t v; std::memcpy(&v, q, 1); return v; }
+      if (size == 2) { int16_t v; std::memcpy(&v, q, 2); return v; }
+      if (size == 4) { int32_t v; std::memcpy(&v, q, 4); return v; }
+      if (size == 8) { int64_t v; std::memcpy(&v, q, 8); return double(v); }
       break;
     default:
-      if (f.size == 1) { uint8_t v; std::memcpy(&v, q, 1); return v; }
-      if (f.size == 2) { uint16_t v; std::memcpy(&v, q, 2); return v; }
-      if (f.size == 4) { uint32_t v; std::memcpy(&v, q, 4); return v; }
-      if (f.size == 8) { uint64_t v; std::memcpy(&v, q, 8); return double(v); }
+      if (size == 1) { uint8_t v; std::memcpy(&v, q, 1); return v; }
+      if (size == 2) { uint16_t v; std::memcpy(&v, q, 2); return v; }
+      if (size == 4) { uint32_t v; std::memcpy(&v, q, 4); return v; }
+      if (size == 8) { uint64_t v; std::memcpy(&v, q, 8); return double(v); }
   }
   return 0.0;
 }
 
-void store_ascii_value(unsigned char* p, const Field& f, int c, const std::string& tok, bool& dense) {
-  unsigned char* q = p + f.offset + size_t(c) * size_t(f.size);
-  if (f.type == 'F') {
-    // copyStringValue (pcd_io.h): "nan" -> quiet NaN and the cloud is not dense
+// copyStringValue (io/include/pcl/io/pcd_io.h): "nan" -> quiet NaN and the cloud is not dense
+inline void store_ascii_value(unsigned char* q, int size, char type, const char* tok, bool& dense) {
+  if (type == 'F') {
     double v;
-    if (tok == "nan" || tok == "-nan" || tok == "NaN") {
+    if (!std::strcmp(tok, "nan") || !std::strcmp(tok, "-nan") || !std::strcmp(tok, "NaN")) {
       v = std::nan("");
       dense = false;
     } else {
-      v = std::strtod(tok.c_str(), nullptr);
+      v = std::strtod(tok, nullptr);
       if (!std::isfinite(v)) dense = false;
     }
-    if (f.size == 4) { const float x = float(v); std::memcpy(q, &x, 4); }
-    else if (f.size == 8) std::memcpy(q, &v, 8);
-  } else if (f.type == 'I') {
-    const long long v = std::strtoll(tok.c_str(), nullptr, 10);
-    if (f.size == 1) { const int8_t x = int8_t(v); std::memcpy(q, &x, 1); }
-    else if (f.size == 2) { const int16_t x = int16_t(v); std::memcpy(q, &x, 2); }
-    else if (f.size == 4) { const int32_t x = int32_t(v); std::memcpy(q, &x, 4); }
-    else if (f.size == 8) { const int64_t x = int64_t(v); std::memcpy(q, &x, 8); }
+    if (size == 4) { const float x = float(v); std::memcpy(q, &x, 4); }
+    else if (size == 8) std::memcpy(q, &v, 8);
+  } else if (type == 'I') {
+    const long long v = std::strtoll(tok, nullptr, 10);
+    if (size == 1) { const int8_t x = int8_t(v); std::memcpy(q, &x, 1); }
+    else if (size == 2) { const int16_t x = int16_t(v); std::memcpy(q, &x, 2); }
+    else if (size == 4) { const int32_t x = int32_t(v); std::memcpy(q, &x, 4); }
+    else if (size == 8) { const int64_t x = int64_t(v); std::memcpy(q, &x, 8); }
   } else {
-    const unsigned long long v = std::strtoull(tok.c_str(), nullptr, 10);
-    if (f.size == 1) { const uint8_t x = uint8_t(v); std::memcpy(q, &x, 1); }
-    else if (f.size == 2) { const uint16_t x = uint16_t(v); std::memcpy(q, &x, 2); }
-    else if (f.size == 4) { const uint32_t x = uint32_t(v); std::memcpy(q, &x, 4); }
-    else if (f.size == 8) { const uint64_t x = uint64_t(v); std::memcpy(q, &x, 8); }
+    const unsigned long long v = std::strtoull(tok, nullptr, 10);
+    if (size == 1) { const uint8_t x = uint8_t(v); std::memcpy(q, &x, 1); }
+    else if (size == 2) { const uint16_t x = uint16_t(v); std::memcpy(q, &x, 2); }
+    else if (size == 4) { const uint32_t x = uint32_t(v); std::memcpy(q, &x, 4); }
+    else if (size == 8) { const uint64_t x = uint64_t(v); std::memcpy(q, &x, 8); }
   }
 }
 
-// the file's points as an array of structs (h.point_step bytes each); sets `dense` like the reference
-bool decode_body(const std::string& bytes, const Header& h, std::vector<unsigned char>& aos, bool& dense,
-                 std::string& err) {
-  dense = true;
-  aos.assign(size_t(h.points) * h.point_step, 0);
-  if (h.points == 0) return true;
+// The decoded body as per-field views: element c of field f of point i is at
+// base[f] + i * stride[f] + c * size.  binary: straight into the file image (array of structs);
+// binary_compressed: into the LZF-decoded struct of arrays; ascii: into a parsed array of structs.
+struct Body {
+  std::vector<const unsigned char*> base;
+  std::vector<size_t> stride;
+  std::vector<unsigned char> storage;
+  bool dense = true;
+};
+
+bool decode_body(std::string_view bytes, const Header& h, Body& body, std::string& err) {
+  const size_t nf = h.fields.size();
+  body.base.assign(nf, nullptr);
+  body.stride.assign(nf, 0);
+  body.dense = true;
+  const uint64_t n = h.points;
+  if (n == 0) return true;
+  const unsigned char* file = reinterpret_cast<const unsigned char*>(bytes.data());
   if (h.data_type == 0) {  // readBodyASCII :456-559
     size_t elems = 0;
     for (const Field& f : h.fields) elems += size_t(f.count);
+    body.storage.assign(size_t(n) * h.point_step, 0);
+    // the i-th non-empty line is point i (a malformed line still consumes its point, :489-495)
+    std::vector<std::pair<size_t, size_t>> lines;  // [begin, end)
+    lines.reserve(size_t(n));
     size_t pos = size_t(h.data_offset);
-    uint64_t idx = 0;
-    while (idx < h.points && pos < bytes.size()) {
-      size_t eol = bytes.find('\n', pos);
-      if (eol == std::string::npos) eol = bytes.size();
-      const std::string line = bytes.substr(pos, eol - pos);
+    while (lines.size() < n && pos < bytes.size()) {
+      const void* nl = std::memchr(bytes.data() + pos, '\n', bytes.size() - pos);
+      const size_t eol = nl ? size_t(static_cast<const char*>(nl) - bytes.data()) : bytes.size();
+      if (eol > pos) lines.emplace_back(pos, eol);
       pos = eol + 1;
-      if (line.empty()) continue;
-      const std::vector<std::string> st = split_ws(line);
-      if (st.empty()) continue;
-      if (st.size() != elems) {  // malformed line: the point is skipped but counted (:489-495)
-        ++idx;
-        continue;
-      }
-      size_t total = 0;
-      for (const Field& f : h.fields) {
-        if (f.name != "_")
-          for (int c = 0; c < f.count; ++c) store_ascii_value(&aos[size_t(idx) * h.point_step], f, c, st[total + size_t(c)], dense);
-        total += size_t(f.count);
-      }
-      ++idx;
     }
-    if (idx != h.points) {
+    if (lines.size() != n) {
       err = "Number of points read is different than expected";
       return false;
     }
-    return true;
+    std::vector<char> dense_flags(64, 1);
+    std::atomic<unsigned> slot{0};
+    parallel_for(n, 1 << 14, [&](uint64_t lo, uint64_t hi) {
+      bool dense = true;
+      std::vector<std::pair<const char*, size_t>> tok;
+      tok.reserve(elems + 1);
+      char buf[128];
+      for (uint64_t i = lo; i < hi; ++i) {
+        tok.clear();
+        const char* p = bytes.data() + lines[size_t(i)].first;
+        const char* const e = bytes.data() + lines[size_t(i)].second;
+        while (p < e) {
+          while (p < e && (*p == ' ' || *p == '\t' || *p == '\r')) ++p;
+          const char* q = p;
+          while (q < e && *q != ' ' && *q != '\t' && *q != '\r') ++q;
+          if (q > p) tok.emplace_back(p, size_t(q - p));
+          p = q;
+        }
+        if (tok.size() != elems) continue;  // malformed: the point keeps its zeros
+        unsigned char* rec = &body.storage[size_t(i) * h.point_step];
+        size_t total = 0;
+        for (const Field& f : h.fields) {
+          if (f.name != "_")
+            for (int c = 0; c < f.count; ++c) {
+              const auto& t = tok[total + size_t(c)];
+              const size_t len = t.second < sizeof(buf) - 1 ? t.second : sizeof(buf) - 1;
+              std::memcpy(buf, t.first, len);
+              buf[len] = 0;
+              store_ascii_value(rec + f.offset + size_t(c) * size_t(f.size), f.size, f.type, buf, dense);
+            }
+          total += size_t(f.count);
+        }
+      }
+      if (!dense) dense_flags[slot.fetch_add(1) % dense_flags.size()] = 0;
+    });
+    for (char d : dense_flags)
+      if (!d) body.dense = false;
+    for (size_t f = 0; f < nf; ++f) {
+      body.base[f] = body.storage.data() + h.fields[f].offset;
+      body.stride[f] = h.point_step;
+    }
+    return true;  // is_dense of ascii files comes from the parse (copyStringValue), not from a second scan
   }
-  if (h.data_type == 1) {  // binary: array of structs as is
-    if (h.data_offset + aos.size() > bytes.size()) {
+  if (h.data_type == 1) {  // binary: array of structs, used in place
+    if (h.data_offset + size_t(n) * h.point_step > bytes.size()) {
       err = "file is shorter than WIDTH x HEIGHT x point size";
       return false;
     }
-    std::memcpy(aos.data(), bytes.data() + h.data_offset, aos.size());
+    for (size_t f = 0; f < nf; ++f) {
+      body.base[f] = file + h.data_offset + h.fields[f].offset;
+      body.stride[f] = h.point_step;
+    }
   } else {  // binary_compressed :568-629
     if (h.data_offset + 8 > bytes.size()) {
       err = "truncated binary_compressed header";
       return false;
     }
     uint32_t csize = 0, usize = 0;
-    std::memcpy(&csize, bytes.data() + h.data_offset, 4);
-    std::memcpy(&usize, bytes.data() + h.data_offset + 4, 4);
+    std::memcpy(&csize, file + h.data_offset, 4);
+    std::memcpy(&usize, file + h.data_offset + 4, 4);
     if (h.data_offset + 8 + csize > bytes.size()) {
       err = "truncated binary_compressed body";
       return false;
     }
-    std::vector<unsigned char> soa(usize);
-    const size_t got = usize ? lzf_decompress(reinterpret_cast<const unsigned char*>(bytes.data()) + h.data_offset + 8,
-                                              csize, soa.data(), usize)
-                             : 0;
+    body.storage.resize(usize);
+    const size_t got = usize ? lzf_decompress(file + h.data_offset + 8, csize, body.storage.data(), usize) : 0;
     if (got != usize) {
       err = "Size of decompressed lzf data does not match value stored in PCD header";
       return false;
     }
-    if (usize != aos.size()) aos.assign(usize, 0);  // the reference trusts the stored size (:579-583)
-    // struct of arrays -> array of structs ("unpack the xxyyzz to xyz", :605-623); "_" padding fields are
-    // not stored in the compressed stream
-    size_t fsize = 0;
-    for (const Field& f : h.fields)
-      if (f.name != "_") fsize += size_t(f.count) * size_t(f.size);
-    const uint64_t n = h.points;
-    if (fsize * n > usize) {
+    // struct of arrays: all elements of field 0, then field 1, ... ("_" padding fields are not stored, :590-600)
+    size_t toff = 0;
+    for (size_t f = 0; f < nf; ++f) {
+      const Field& fd = h.fields[f];
+      if (fd.name == "_") continue;
+      const size_t fs = size_t(fd.count) * size_t(fd.size);
+      body.base[f] = body.storage.data() + toff;
+      body.stride[f] = fs;
+      toff += fs * size_t(n);
+    }
+    if (toff > usize) {
       err = "compressed stream smaller than the fields it should hold";
       return false;
     }
-    size_t toff = 0;
-    for (const Field& f : h.fields) {
-      if (f.name == "_") continue;
-      const size_t fs = size_t(f.count) * size_t(f.size);
-      for (uint64_t i = 0; i < n; ++i) std::memcpy(&aos[size_t(i) * fsize + f.offset], &soa[toff + size_t(i) * fs], fs);
-      toff += fs * size_t(n);
-    }
   }
   // is_dense: any non-finite value of any floating field (:634-672)
-  const size_t step = aos.size() / size_t(h.points);
-  for (uint64_t i = 0; i < h.points && dense; ++i)
-    for (const Field& f : h.fields)
-      if (f.type == 'F' && f.name != "_")
-        for (int c = 0; c < f.count; ++c)
-          if (!std::isfinite(load_value(&aos[size_t(i) * step], f, c))) dense = false;
+  std::atomic<int> nonfinite{0};
+  for (size_t f = 0; f < nf && !nonfinite.load(); ++f) {
+    const Field& fd = h.fields[f];
+    if (fd.type != 'F' || fd.name == "_" || !body.base[f]) continue;
+    parallel_for(n, 1 << 18, [&](uint64_t lo, uint64_t hi) {
+      bool bad = false;
+      for (uint64_t i = lo; i < hi && !bad; ++i)
+        for (int c = 0; c < fd.count; ++c)
+          if (!std::isfinite(load_scalar(body.base[f] + size_t(i) * body.stride[f] + size_t(c) * size_t(fd.size), fd.size, fd.type)))
+            bad = true;
+      if (bad) nonfinite.store(1);
+    });
+  }
+  body.dense = nonfinite.load() == 0;
   return true;
 }
 
@@ -497,8 +590,10 @@ extern "C" {
 
 pclhip_status pclhip_pcd_read_header(const char* path, pclhip_pcd_info* info) {
   if (!path || !info) return PCLHIP_ERR_INVALID;
-  std::string bytes, err;
-  if (!read_file(path, bytes, err)) return fail(err);
+  MappedFile mapped;
+  std::string err;
+  if (!read_file(path, mapped, err)) return fail(err);
+  const std::string_view bytes = mapped.view();
   Header h;
   if (!parse_header(bytes, h, err)) return fail("[pcl::PCDReader::readHeader] " + err);
   fill_info(h, info);
@@ -508,8 +603,10 @@ pclhip_status pclhip_pcd_read_header(const char* path, pclhip_pcd_info* info) {
 pclhip_status pclhip_pcd_read(const char* path, void* points, size_t stride, size_t normals_offset, uint64_t capacity,
                               uint64_t* n_out, int* is_dense) {
   if (!path || !n_out) return PCLHIP_ERR_INVALID;
-  std::string bytes, err;
-  if (!read_file(path, bytes, err)) return fail(err);
+  MappedFile mapped;
+  std::string err;
+  if (!read_file(path, mapped, err)) return fail(err);
+  const std::string_view bytes = mapped.view();
   Header h;
   if (!parse_header(bytes, h, err)) return fail("[pcl::PCDReader::readHeader] " + err);
   *n_out = h.points;
@@ -530,11 +627,9 @@ pclhip_status pclhip_pcd_read(const char* path, void* points, size_t stride, siz
   const bool want_n = normals_offset != 0 && inx >= 0 && iny >= 0 && inz >= 0;
   if (normals_offset != 0 && (normals_offset % 4 != 0 || normals_offset + 12 > stride))
     return fail("normals_offset must be a multiple of 4 with room for 3 floats inside the record");
-  std::vector<unsigned char> aos;
-  bool dense = true;
-  if (!decode_body(bytes, h, aos, dense, err)) return fail("[pcl::PCDReader::read] " + err);
-  if (is_dense) *is_dense = dense ? 1 : 0;
-  const size_t step = h.points ? aos.size() / size_t(h.points) : 0;
+  Body body;
+  if (!decode_body(bytes, h, body, err)) return fail("[pcl::PCDReader::read] " + err);
+  if (is_dense) *is_dense = body.dense ? 1 : 0;
   // assemble the records on the host (a staging buffer when the destination is device memory)
   const bool dev = is_device_pointer(points);
   std::vector<unsigned char> staging;
@@ -543,22 +638,53 @@ pclhip_status pclhip_pcd_read(const char* path, void* points, size_t stride, siz
     staging.assign(size_t(h.points) * stride, 0);
     dst = staging.data();
   }
-  for (uint64_t i = 0; i < h.points; ++i) {
-    const unsigned char* p = &aos[size_t(i) * step];
-    float* o = reinterpret_cast<float*>(dst + size_t(i) * stride);
-    o[0] = float(load_value(p, h.fields[size_t(ix)], 0));
-    o[1] = float(load_value(p, h.fields[size_t(iy)], 0));
-    o[2] = float(load_value(p, h.fields[size_t(iz)], 0));
-    if (stride >= 16 && !(normals_offset != 0 && normals_offset < 16)) o[3] = 1.0f;  // PointXYZ padding (data[3] = 1)
-    if (want_n) {
-      float* nn = reinterpret_cast<float*>(dst + size_t(i) * stride + normals_offset);
-      nn[0] = float(load_value(p, h.fields[size_t(inx)], 0));
-      nn[1] = float(load_value(p, h.fields[size_t(iny)], 0));
-      nn[2] = float(load_value(p, h.fields[size_t(inz)], 0));
-      if (normals_offset + 16 <= stride) nn[3] = 0.0f;
-      if (icv >= 0 && normals_offset + 20 <= stride) nn[4] = float(load_value(p, h.fields[size_t(icv)], 0));
+  struct Src {
+    const unsigned char* base = nullptr;
+    size_t stride = 0;
+    int size = 4;
+    char type = 'F';
+  };
+  auto src_of = [&](int fi) {
+    Src r;
+    if (fi >= 0) {
+      r.base = body.base[size_t(fi)];
+      r.stride = body.stride[size_t(fi)];
+      r.size = h.fields[size_t(fi)].size;
+      r.type = h.fields[size_t(fi)].type;
     }
-  }
+    return r;
+  };
+  const Src sx = src_of(ix), sy = src_of(iy), sz = src_of(iz);
+  const Src snx = src_of(want_n ? inx : -1), sny = src_of(want_n ? iny : -1), snz = src_of(want_n ? inz : -1);
+  const Src scv = src_of((want_n && icv >= 0 && normals_offset + 20 <= stride) ? icv : -1);
+  const bool pad_w = stride >= 16 && !(normals_offset != 0 && normals_offset < 16);  // PointXYZ padding (data[3] = 1)
+  const bool pad_n = want_n && normals_offset + 16 <= stride;
+  auto get = [](const Src& s, uint64_t i) -> float {
+    const unsigned char* q = s.base + size_t(i) * s.stride;
+    if (s.type == 'F' && s.size == 4) {  // the common case: a plain copy
+      float v;
+      std::memcpy(&v, q, 4);
+      return v;
+    }
+    return float(load_scalar(q, s.size, s.type));
+  };
+  parallel_for(h.points, 1 << 16, [&](uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; ++i) {
+      float* o = reinterpret_cast<float*>(dst + size_t(i) * stride);
+      o[0] = get(sx, i);
+      o[1] = get(sy, i);
+      o[2] = get(sz, i);
+      if (pad_w) o[3] = 1.0f;
+      if (want_n) {
+        float* nn = reinterpret_cast<float*>(dst + size_t(i) * stride + normals_offset);
+        nn[0] = get(snx, i);
+        nn[1] = get(sny, i);
+        nn[2] = get(snz, i);
+        if (pad_n) nn[3] = 0.0f;
+        if (scv.base) nn[4] = get(scv, i);
+      }
+    }
+  });
   if (dev) {
     if (hipMemcpy(points, staging.data(), staging.size(), hipMemcpyHostToDevice) != hipSuccess) {
       set_error(nullptr, "hipMemcpy to the device buffer failed");
@@ -614,31 +740,46 @@ pclhip_status pclhip_pcd_write(const char* path, const void* points, size_t stri
   if (!f) return fail(std::string("cannot create ") + path + ": " + std::strerror(errno));
   bool ok = std::fwrite(header.data(), 1, header.size(), f) == header.size();
   if (data_type == 0) {  // writeASCII: values separated by one blank, `precision` significant digits, "nan"
-    std::ostringstream os;
-    os.imbue(std::locale::classic());
-    os.precision(precision > 0 ? precision : 8);
-    for (uint64_t i = 0; i < n; ++i) {
-      for (int k = 0; k < nf; ++k) {
-        const float v = value(i, k);
-        if (k) os << ' ';
-        if (std::isnan(v))
-          os << "nan";
-        else
-          os << v;
+    // (the stream inserter of the reference formats like printf("%.{precision}g") in the classic locale)
+    const int prec = precision > 0 ? precision : 8;
+    const uint64_t nchunk = n ? (n + (1u << 15) - 1) >> 15 : 0;
+    std::vector<std::string> parts;
+    parts.resize(static_cast<size_t>(nchunk));
+    parallel_for(nchunk, 1, [&](uint64_t clo, uint64_t chi) {
+      char buf[64];
+      for (uint64_t c = clo; c < chi; ++c) {
+        std::string& out = parts[size_t(c)];
+        const uint64_t lo = c << 15, hi = (lo + (1u << 15) < n) ? lo + (1u << 15) : n;
+        out.reserve(size_t(hi - lo) * size_t(nf) * 12);
+        for (uint64_t i = lo; i < hi; ++i) {
+          for (int k = 0; k < nf; ++k) {
+            const float v = value(i, k);
+            if (k) out.push_back(' ');
+            if (std::isnan(v)) {
+              out.append("nan");
+            } else {
+              const int len = std::snprintf(buf, sizeof buf, "%.*g", prec, double(v));
+              out.append(buf, size_t(len > 0 ? len : 0));
+            }
+          }
+          out.push_back('\n');
+        }
       }
-      os << '\n';
-    }
-    const std::string body = os.str();
-    ok = ok && std::fwrite(body.data(), 1, body.size(), f) == body.size();
+    });
+    for (const std::string& part : parts) ok = ok && std::fwrite(part.data(), 1, part.size(), f) == part.size();
   } else if (data_type == 1) {  // writeBinary: packed array of structs
     std::vector<float> body(size_t(n) * size_t(nf));
-    for (uint64_t i = 0; i < n; ++i)
-      for (int k = 0; k < nf; ++k) body[size_t(i) * size_t(nf) + size_t(k)] = value(i, k);
+    parallel_for(n, 1 << 16, [&](uint64_t lo, uint64_t hi) {
+      for (uint64_t i = lo; i < hi; ++i)
+        for (int k = 0; k < nf; ++k) body[size_t(i) * size_t(nf) + size_t(k)] = value(i, k);
+    });
     ok = ok && (body.empty() || std::fwrite(body.data(), 4, body.size(), f) == body.size());
   } else {  // writeBinaryCompressed: struct of arrays, LZF, sizes in front
     std::vector<float> soa(size_t(n) * size_t(nf));
-    for (int k = 0; k < nf; ++k)
-      for (uint64_t i = 0; i < n; ++i) soa[size_t(k) * size_t(n) + size_t(i)] = value(i, k);
+    parallel_for(n, 1 << 16, [&](uint64_t lo, uint64_t hi) {
+      for (int k = 0; k < nf; ++k)
+        for (uint64_t i = lo; i < hi; ++i) soa[size_t(k) * size_t(n) + size_t(i)] = value(i, k);
+    });
     const size_t usize = soa.size() * 4;
     if (usize > 0xFFFFFFFFull) {
       std::fclose(f);
