@@ -745,7 +745,14 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
       }
       qx[q] = p[q].x; qy[q] = p[q].y; qz[q] = p[q].z;
     }
-    traverse<NN1MinT<Q>, SPARSE>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts);
+    // hint for the descent: the leaf of one lane's seed (any lane: the containment test inside traverse()
+    // decides whether the shortcut is valid for the whole wave)
+    uint32_t start_leaf = NO_INDEX;
+    if (flags & 2) {
+      const uint64_t hm = __builtin_amdgcn_ballot_w64(valid[0] && seed_pos[0] != NO_INDEX);
+      if (hm != 0) start_leaf = uint32_t(__builtin_amdgcn_readlane(int(seed_pos[0]), __builtin_ctzll(hm))) / LEAF;
+    }
+    traverse<NN1MinT<Q>, SPARSE>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, start_leaf);
     fast.resolve(ix, qx, qy, qz);
     // ... and their seed target points as soon as the seed positions have arrived
 #pragma unroll
@@ -1021,8 +1028,14 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     const uint32_t ngroups_s = (icp->n + WAVE - 1) / WAVE;
     const int gs = resident_blocks(ctx, ks, ngroups_s);
     (void)hipEventRecord(icp->ev0, s);
+    static const int skip = [] {  // A/B: PCLHIP_ICP_SKIP=0 always descends from the root
+      const char* e = getenv("PCLHIP_ICP_SKIP");
+      const char* o = getenv("PCLHIP_ORDER");  // the shortcut relies on the kd order (disjoint cells)
+      if (o && !strcmp(o, "morton")) return 0;
+      return (e && atoi(e) == 0) ? 0 : 2;
+    }();
     hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound,
-                       (use_max ? 1 : 0), icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+                       (use_max ? 1 : 0) | skip, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
     (void)hipEventRecord(icp->ev_mid, s);
     icp->mid_recorded = true;
     const uint8_t* keep = nullptr;

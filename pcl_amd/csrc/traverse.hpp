@@ -546,7 +546,7 @@ __device__ __forceinline__ float lane_worst(const Policy& pol, const bool* valid
 template <class Policy, bool SPARSE = false, class WL = WaveLds>
 __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, const float* qy, const float* qz,
                                          const bool* valid, Policy& pol, WL& wl, const Box* topbox,
-                                         TraverseStats& ts) {
+                                         TraverseStats& ts, uint32_t start_leaf = NO_INDEX) {
   constexpr int QPL = Policy::QPL;
   const int lane = threadIdx.x & (WAVE - 1);
   bool any_valid = false;
@@ -573,6 +573,30 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
 
   int sp = 0;
   uint32_t level = uint32_t(ix.top) + 1u, node = 0u;  // virtual root above the top level
+  // Seeded searches need not start at the root.  The leaves are the cells of a kd partition (every aligned
+  // block of 16 * 4^j points is one cell, index_build.hip), so cells of different nodes have disjoint
+  // interiors and a node's box lies inside its cell.  If the box of the wave's queries, grown by the wave
+  // radius, lies STRICTLY inside the box of the level-2 (64 leaves) or level-3 (4096 leaves) node that holds
+  // the hint leaf, every point within any lane's bound (equal distances included) belongs to that node:
+  // the descent starts there.  The margin covers the rounding of the differences and of the squares.
+  if (start_leaf != NO_INDEX && T < INF) {
+    const auto inside = [&](const Box& b) {
+      const float d = fminf(fminf(fminf(Qlx - b.lo.x, b.hi.x - Qhx), fminf(Qly - b.lo.y, b.hi.y - Qhy)),
+                            fminf(Qlz - b.lo.z, b.hi.z - Qhz));
+      return d > 0.0f && d * d * 0.999999f > T;
+    };
+    const bool has2 = ix.top >= 2, has3 = ix.top >= 3;
+    Box b2 = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)}, b3 = b2;
+    if (has2) b2 = ix.box[2][start_leaf >> 6];   // wave-uniform addresses: both loads are in flight together
+    if (has3) b3 = ix.box[3][start_leaf >> 12];
+    if (has2 && inside(b2)) {
+      level = 2u;
+      node = start_leaf >> 6;
+    } else if (has3 && inside(b3)) {
+      level = 3u;
+      node = start_leaf >> 12;
+    }
+  }
   bool have = true;
   for (;;) {
     if (!have) {
