@@ -7,12 +7,15 @@
 //     (DPP butterflies); survivors are pushed on a wave-uniform stack in LDS, nearest child first.
 //   * leaf-level node: the surviving leaves are ranked (by distance to the query-group box while
 //     bounds are still loose), their ids + boxes go into a small list in LDS, and their candidate
-//     blocks (x[16] y[16] z[16] w[16] = 256 B per leaf) are fetched for up to 16 leaves at a time
-//     with `global_load_lds_dwordx4` -- the vector-memory path with its deep queues, straight into
-//     LDS, no VGPRs -- WHILE the per-lane box tests run.  (The first version read each leaf through
-//     the scalar cache: one dependent scalar-load miss per visited leaf was the whole kernel's
-//     critical path.)  A leaf that some lane still needs is then evaluated by every lane against
-//     all 16 candidates: broadcast `ds_read_b128` + packed `v_pk_*` math, no gathers, no divergence.
+//     blocks (x[16] y[16] z[16] [w[16]]) are fetched for up to 16 leaves at a time with
+//     `global_load_lds_dwordx4` -- the vector-memory path with its deep queues, straight into LDS, no
+//     VGPRs -- WHILE the per-lane box tests run.  (The first version read each leaf through the scalar
+//     cache: one dependent scalar-load miss per visited leaf was the whole kernel's critical path.)
+//   * evaluation, two forms.  SPARSE (1-NN, top-K in registers): the batch is staged transposed and
+//     every lane evaluates only the leaves its own bound cannot exclude, popping them in rounds
+//     (`ds_read_b128` of its own slot + packed `v_pk_*` math).  Wave-uniform (heap / radius policies): a
+//     leaf that some lane still needs is evaluated by every lane from broadcast reads.
+//   * a seeded search may start below the root (see `start_leaf`).
 // All bounds are exact in float: rounding is monotone and the bound uses the same operation order
 // as the distance, so box_lb(q, box) <= l2_simple(q, c) for every c in the box, bit for bit.
 // Distances follow FLANN's L2_Simple order ((dx*dx)+dy*dy)+dz*dz with no FMA contraction
