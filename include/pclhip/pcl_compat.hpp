@@ -57,6 +57,10 @@ struct PointCloud {
   std::vector<PointT> points;
   std::uint32_t width = 0, height = 1;
   bool is_dense = true;
+  // acquisition pose (common/include/pcl/point_cloud.h:406-408): origin x y z 0, orientation w x y z;
+  // filled from a PCD file's VIEWPOINT line and used as NormalEstimation's default viewpoint
+  float sensor_origin_[4] = {0, 0, 0, 0};
+  float sensor_orientation_[4] = {1, 0, 0, 0};
   std::size_t size() const { return points.size(); }
   bool empty() const { return points.empty(); }
   void resize(std::size_t n) { points.resize(n); width = std::uint32_t(n); height = 1; }
@@ -244,7 +248,9 @@ class NormalEstimation {
   void setSearchMethod(const typename search::KdTree<PointInT>::Ptr& tree) { tree_ = tree; }
   void setKSearch(int k) { k_ = k; }
   void setRadiusSearch(double radius) { radius_ = radius; }
-  void setViewPoint(float x, float y, float z) { vp_[0] = x; vp_[1] = y; vp_[2] = z; }
+  // normal_3d.h:255-262 / :328-351: the cloud's sensor origin is the viewpoint until setViewPoint is called
+  void setViewPoint(float x, float y, float z) { vp_[0] = x; vp_[1] = y; vp_[2] = z; use_sensor_origin_ = false; }
+  void useSensorOriginAsViewPoint() { use_sensor_origin_ = true; }
   // Feature::compute (features/include/pcl/features/impl/feature.hpp:195-229); initCompute refuses
   // "both radius and K defined" and "neither defined" (:131-174)
   void compute(PointCloud<Normal>& output) {
@@ -252,6 +258,9 @@ class NormalEstimation {
     if (!input_ || (k_ < 1) == !(radius_ > 0.0)) return;
     if (!tree_) tree_ = std::make_shared<search::KdTree<PointInT>>(ctx_);
     if (!tree_->setInputCloud(input_)) return;
+    if (use_sensor_origin_) {
+      vp_[0] = input_->sensor_origin_[0]; vp_[1] = input_->sensor_origin_[1]; vp_[2] = input_->sensor_origin_[2];
+    }
     output.resize(input_->size());
     std::uint64_t nan = 0;
     std::vector<float> tmp(input_->size() * 4);
@@ -272,6 +281,7 @@ class NormalEstimation {
   int k_ = 0;
   double radius_ = 0.0;
   float vp_[3] = {0, 0, 0};
+  bool use_sensor_origin_ = true;
 };
 
 namespace registration {
@@ -516,6 +526,9 @@ int loadPCDFile(const std::string& file_name, PointCloud<PointT>& cloud) {
   cloud.width = info.width;
   cloud.height = info.height;
   cloud.is_dense = dense != 0;
+  for (int i = 0; i < 3; ++i) cloud.sensor_origin_[i] = info.viewpoint[i];   // VIEWPOINT tx ty tz qw qx qy qz
+  cloud.sensor_origin_[3] = 0.0f;
+  for (int i = 0; i < 4; ++i) cloud.sensor_orientation_[i] = info.viewpoint[3 + i];
   return 0;
 }
 template <typename PointT>
