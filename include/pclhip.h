@@ -339,6 +339,16 @@ PCLHIP_API pclhip_status pclhip_pcd_read(const char* path, void* points, size_t 
  * ascii writer (<= 0: the reference's default 8). */
 PCLHIP_API pclhip_status pclhip_pcd_write(const char* path, const void* points, size_t stride_bytes,
                                           size_t normals_offset, uint64_t n, int data_type, int precision);
+/* The same for an organized cloud (width x height records, row-major) with an acquisition pose
+ * (VIEWPOINT tx ty tz qw qx qy qz; NULL = 0 0 0 1 0 0 0). */
+PCLHIP_API pclhip_status pclhip_pcd_write_organized(const char* path, const void* points, size_t stride_bytes,
+                                                    size_t normals_offset, uint32_t width, uint32_t height,
+                                                    const float viewpoint[7], int data_type, int precision);
+/* One component of any field of the file (e.g. "intensity", "curvature", "normal_x") as float32, one value
+ * per point, into HOST memory.  float64 / integer fields are converted; 4-byte "rgb" / "rgba" keep their
+ * 32 bits (PCL packs colours into a float). */
+PCLHIP_API pclhip_status pclhip_pcd_read_field(const char* path, const char* field, uint32_t component,
+                                               float* out, uint64_t capacity, uint64_t* n_out);
 
 #ifdef __cplusplus
 }

@@ -534,8 +534,14 @@ int loadPCDFile(const std::string& file_name, PointCloud<PointT>& cloud) {
 template <typename PointT>
 int savePCDFile(const std::string& file_name, const PointCloud<PointT>& cloud, int data_type, int precision = 8) {
   const std::size_t nrm_off = sizeof(PointT) >= 28 ? 16 : 0;
-  return pclhip_pcd_write(file_name.c_str(), cloud.points.data(), sizeof(PointT), nrm_off, cloud.size(), data_type,
-                          precision) == PCLHIP_OK ? 0 : -1;
+  // width, height and the acquisition pose travel with the cloud (PCDWriter::generateHeader, pcd_io.cpp:848-1043)
+  const float vp[7] = {cloud.sensor_origin_[0], cloud.sensor_origin_[1], cloud.sensor_origin_[2],
+                       cloud.sensor_orientation_[0], cloud.sensor_orientation_[1], cloud.sensor_orientation_[2],
+                       cloud.sensor_orientation_[3]};
+  const bool organized = std::uint64_t(cloud.width) * cloud.height == cloud.size();
+  const std::uint32_t w = organized ? cloud.width : std::uint32_t(cloud.size()), h = organized ? cloud.height : 1;
+  return pclhip_pcd_write_organized(file_name.c_str(), cloud.points.data(), sizeof(PointT), nrm_off, w, h, vp, data_type,
+                                    precision) == PCLHIP_OK ? 0 : -1;
 }
 template <typename PointT> int savePCDFileASCII(const std::string& f, const PointCloud<PointT>& c) { return savePCDFile(f, c, 0); }
 template <typename PointT> int savePCDFileBinary(const std::string& f, const PointCloud<PointT>& c) { return savePCDFile(f, c, 1); }

@@ -8,4 +8,4 @@ from .api import (Context, CorrespondenceEstimation, CorrespondenceRejectorDista
                   CorrespondenceRejectorMedianDistance, CorrespondenceRejectorOneToOne,
                   CorrespondenceRejectorTrimmed, IterativeClosestPoint,
                   IterativeClosestPointWithNormals, KdTree, NormalEstimation, VoxelGrid,
-                  default_context, estimateRigidTransformation, getPCDHeader, loadPCDFile, savePCDFile)
+                  default_context, estimateRigidTransformation, getPCDHeader, loadPCDField, loadPCDFile, savePCDFile)

@@ -685,14 +685,35 @@ def loadPCDFile(path, with_normals=False, device=None):
     return out, bool(dense.value)
 
 
-def savePCDFile(path, cloud, mode="binary", precision=8):
+def loadPCDField(path, field, component=0):
+    """One component of any field of a PCD file as float32 [n] (packed rgb/rgba: view the result as uint32)."""
+    info = getPCDHeader(path)
+    out = np.zeros(int(info.points), np.float32)
+    cnt = C.c_uint64(0)
+    check(_lib.load().pclhip_pcd_read_field(os.fsencode(path), field.encode(), int(component),
+                                            C.c_void_p(out.ctypes.data), len(out), C.byref(cnt)))
+    return out
+
+
+def savePCDFile(path, cloud, mode="binary", precision=8, width=None, height=None, viewpoint=None):
     """pcl::io::savePCDFile{ASCII,Binary,BinaryCompressed}; clouds with >= 7 columns (PointNormal layout:
     normals at floats 4..6, curvature at float 8 when present) are written with their normals."""
     data_type = {"ascii": 0, "binary": 1, "binary_compressed": 2}[mode]
     ptr, stride, n, keep = _cloud(cloud)
     ncol = stride // 4
-    check(_lib.load().pclhip_pcd_write(os.fsencode(path), ptr, stride, 16 if ncol >= 7 else 0, n, data_type,
-                                       int(precision)))
+    if width is None and height is None and viewpoint is None:
+        check(_lib.load().pclhip_pcd_write(os.fsencode(path), ptr, stride, 16 if ncol >= 7 else 0, n, data_type,
+                                           int(precision)))
+        return
+    width = n if width is None else int(width)
+    height = 1 if height is None else int(height)
+    assert width * height == n, "width x height must equal the number of points"
+    vp = None
+    if viewpoint is not None:
+        vp = np.ascontiguousarray(viewpoint, np.float32)
+        assert vp.shape == (7,)
+    check(_lib.load().pclhip_pcd_write_organized(os.fsencode(path), ptr, stride, 16 if ncol >= 7 else 0, width, height,
+                                                 _fp(vp) if vp is not None else None, data_type, int(precision)))
 
 
 class VoxelGrid:

@@ -694,8 +694,9 @@ pclhip_status pclhip_pcd_read(const char* path, void* points, size_t stride, siz
   return PCLHIP_OK;
 }
 
-pclhip_status pclhip_pcd_write(const char* path, const void* points, size_t stride, size_t normals_offset, uint64_t n,
-                               int data_type, int precision) {
+static pclhip_status pcd_write_impl(const char* path, const void* points, size_t stride, size_t normals_offset,
+                                    uint64_t n, uint32_t width, uint32_t height, const float* viewpoint, int data_type,
+                                    int precision) {
   if (!path || (n > 0 && !points)) return PCLHIP_ERR_INVALID;
   if (stride < 12 || stride % 4 != 0) return fail("stride must be a multiple of 4 and >= 12 bytes");
   if (data_type < 0 || data_type > 2) return fail("data_type: 0 ascii, 1 binary, 2 binary_compressed");
@@ -727,7 +728,11 @@ pclhip_status pclhip_pcd_write(const char* path, const void* points, size_t stri
   for (int i = 0; i < nf; ++i) hd << " F";
   hd << "\nCOUNT";
   for (int i = 0; i < nf; ++i) hd << " 1";
-  hd << "\nWIDTH " << n << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA "
+  hd << "\nWIDTH " << width << "\nHEIGHT " << height << "\nVIEWPOINT";
+  static const float identity_pose[7] = {0, 0, 0, 1, 0, 0, 0};
+  const float* vp = viewpoint ? viewpoint : identity_pose;
+  for (int i = 0; i < 7; ++i) hd << ' ' << vp[i];
+  hd << "\nPOINTS " << n << "\nDATA "
      << (data_type == 0 ? "ascii" : (data_type == 1 ? "binary" : "binary_compressed")) << "\n";
   const std::string header = hd.str();
   auto value = [&](uint64_t i, int f) -> float {
@@ -798,6 +803,57 @@ pclhip_status pclhip_pcd_write(const char* path, const void* points, size_t stri
   (void)fsize;
   ok = (std::fclose(f) == 0) && ok;
   if (!ok) return fail(std::string("write failed on ") + path);
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_pcd_write(const char* path, const void* points, size_t stride, size_t normals_offset, uint64_t n,
+                               int data_type, int precision) {
+  if (n > 0xFFFFFFFFull) return fail("too many points for a PCD header");
+  return pcd_write_impl(path, points, stride, normals_offset, n, uint32_t(n), 1, nullptr, data_type, precision);
+}
+
+pclhip_status pclhip_pcd_write_organized(const char* path, const void* points, size_t stride, size_t normals_offset,
+                                         uint32_t width, uint32_t height, const float viewpoint[7], int data_type,
+                                         int precision) {
+  return pcd_write_impl(path, points, stride, normals_offset, uint64_t(width) * uint64_t(height), width, height, viewpoint,
+                        data_type, precision);
+}
+
+pclhip_status pclhip_pcd_read_field(const char* path, const char* field, uint32_t component, float* out, uint64_t capacity,
+                                    uint64_t* n_out) {
+  if (!path || !field || !n_out) return PCLHIP_ERR_INVALID;
+  MappedFile mapped;
+  std::string err;
+  if (!read_file(path, mapped, err)) return fail(err);
+  const std::string_view bytes = mapped.view();
+  Header h;
+  if (!parse_header(bytes, h, err)) return fail("[pcl::PCDReader::readHeader] " + err);
+  *n_out = h.points;
+  const int fi = find_field(h, field);
+  if (fi < 0) return fail(std::string("the file has no field named ") + field);
+  const Field& fd = h.fields[size_t(fi)];
+  if (component >= uint32_t(fd.count)) return fail("component index beyond the field's COUNT");
+  if (h.points == 0) return PCLHIP_OK;
+  if (!out) return PCLHIP_ERR_INVALID;
+  if (capacity < h.points) {
+    set_error(nullptr, "output buffer too small for the cloud (see *n_out)");
+    return PCLHIP_ERR_OVERFLOW;
+  }
+  if (is_device_pointer(out)) return fail("pclhip_pcd_read_field writes host memory");
+  Body body;
+  if (!decode_body(bytes, h, body, err)) return fail("[pcl::PCDReader::read] " + err);
+  const unsigned char* base = body.base[size_t(fi)] + size_t(component) * size_t(fd.size);
+  const size_t st = body.stride[size_t(fi)];
+  const bool raw32 = fd.size == 4 && (fd.type == 'F' || fd.name == "rgb" || fd.name == "rgba");
+  parallel_for(h.points, 1 << 16, [&](uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; ++i) {
+      const unsigned char* q = base + size_t(i) * st;
+      if (raw32)
+        std::memcpy(&out[i], q, 4);  // float32 as is; packed rgb / rgba keep their 32 bits
+      else
+        out[i] = float(load_scalar(q, fd.size, fd.type));
+    }
+  });
   return PCLHIP_OK;
 }
 

@@ -133,3 +133,49 @@ def test_reader_errors(api, tmp_path):
     c, dense = api.loadPCDFile(str(p))
     assert dense and c[0].tolist() == [np.float32(0.1), np.float32(0.2), np.float32(0.3), 1.0]
     assert list(api.getPCDHeader(str(p)).viewpoint) == [1, 2, 3, 1, 0, 0, 0]
+
+
+def test_organized_write_viewpoint_and_field_reader(api, tmp_path):
+    from oracle import pcd as opcd
+    rng = np.random.default_rng(8)
+    w, hgt = 64, 48
+    cloud = np.zeros((w * hgt, 12), np.float32)
+    cloud[:, :3] = rng.normal(0, 2, (w * hgt, 3))
+    cloud[:, 3] = 1
+    cloud[:, 4:7] = rng.normal(0, 1, (w * hgt, 3))
+    cloud[:, 8] = rng.uniform(0, 1, w * hgt)
+    vp = [0.5, -1.0, 2.0, 0.5, 0.5, -0.5, 0.5]
+    for mode in ("ascii", "binary", "binary_compressed"):
+        path = str(tmp_path / ("org_%s.pcd" % mode))
+        api.savePCDFile(path, cloud, mode, width=w, height=hgt, viewpoint=vp)
+        info = api.getPCDHeader(path)
+        assert (info.width, info.height, info.points, info.version) == (w, hgt, w * hgt, 7)
+        assert list(info.viewpoint) == vp
+        oh, of, _ = opcd.read(path)
+        assert (oh["width"], oh["height"]) == (w, hgt) and oh["viewpoint"] == vp
+        back, dense = api.loadPCDFile(path, with_normals=True)
+        assert dense
+        if mode == "ascii":
+            assert np.allclose(back, cloud, rtol=1e-7, atol=0)
+        else:
+            assert np.array_equal(back, cloud)
+        for name, col in (("x", 0), ("z", 2), ("normal_y", 5), ("curvature", 8)):
+            got = api.loadPCDField(path, name)
+            assert np.array_equal(got, back[:, col])
+            assert np.array_equal(got, of[name][:, 0].astype(np.float32))
+    with pytest.raises(AssertionError):
+        api.savePCDFile(str(tmp_path / "bad.pcd"), cloud, "binary", width=10, height=10)
+    with pytest.raises(api.PclHipError, match="no field named"):
+        api.loadPCDField(path, "intensity")
+    # packed colours of a reference file keep their 32 bits; float64 fields convert
+    ref = os.path.join(PCD, "colored_cloud.pcd")
+    rgb = api.loadPCDField(ref, "rgb")
+    oh, of, _ = opcd.read(ref)
+    assert np.array_equal(rgb.view(np.uint32), of["rgb"][:, 0].view(np.uint32))
+    assert np.array_equal(api.loadPCDField(ref, "curvature"), of["curvature"][:, 0])
+    p = tmp_path / "f64.pcd"
+    p.write_text("VERSION 0.7\nFIELDS x y z t\nSIZE 4 4 4 8\nTYPE F F F F\nCOUNT 1 1 1 2\nWIDTH 2\nHEIGHT 1\nPOINTS 2\n"
+                 "DATA ascii\n0 0 0 1.5 2.5\n1 1 1 3.25 4.75\n")
+    assert api.loadPCDField(str(p), "t", 1).tolist() == [2.5, 4.75]
+    with pytest.raises(api.PclHipError, match="COUNT"):
+        api.loadPCDField(str(p), "t", 2)
