@@ -173,7 +173,7 @@ def main():
     out = None
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N=1 figure (it would stall the other ranks)
             cpu = cpu_baseline(args, mode)
         out = {
             "metric": "ICP correspondences/sec", "value": round(ncorr / elapsed, 1), "unit": "correspondences/s",
