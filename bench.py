@@ -183,6 +183,9 @@ def main():
             "config": {"workload": "%dM-point synthetic Gaussian-surface cloud per GPU, k=%d NormalEstimation + "
                                    "%s ICP, 1-NN correspondences, max_dist 0.1" %
                                    (n // 1_000_000, args.knn, "point-to-plane" if mode == 1 else "point-to-point"),
+                       "baseline_metric": "ICP correspondences/sec/GPU + ms/iteration, 10M-pt cloud; HBM GB/s vs roofline "
+                                          "(BASELINE.json; `value` is the whole-job aggregate, ms/iteration = ms_per_step, "
+                                          "HBM GB/s = roofline.achieved)",
                        "points_per_gpu": n, "target_points": n, "mode": args.mode,
                        "parallelism": "source slab sharded x%d (kd-ordered per rank), target replicated" % world},
             "roofline": roofline, "cpu_baseline": cpu,
