@@ -44,6 +44,10 @@ def _local_record(tgt, nrm, src, mode):
     if mode == 1:
         _, s27, used = orc.lls_point_to_plane(src, tgt, nrm, q, m)
         rec[:27] = s27
+    elif mode == 2:  # symmetric objective: the source carries normals too (here: the normal of its match, rotated back)
+        src_nrm = np.ascontiguousarray(nrm[np.clip(orc.KdTree(tgt).knn(src, 1)[0][:, 0], 0, len(tgt) - 1), :3], np.float32)
+        _, s27, used = orc.lls_symmetric(src, src_nrm, tgt, nrm, q, m)
+        rec[:27] = s27
     else:
         s, t = src[q, :3].astype(np.float64), tgt[m, :3].astype(np.float64)
         rec[0:3] = s.sum(0)
@@ -78,7 +82,7 @@ def _worker(rank, world, port, n, mode, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_two_rank_allreduce_matches_single_process(mode):
     n, world = 20000, 2
     mgr = mp.Manager()
