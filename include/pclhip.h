@@ -54,6 +54,12 @@ typedef struct pclhip_icp pclhip_icp;
  * stream: a hipStream_t to issue work on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
  * to let the context create its own non-blocking stream. */
 PCLHIP_API pclhip_status pclhip_ctx_create(int device, void* stream, pclhip_ctx** out);
+/* Same, but `stream` is adopted as given -- including NULL, which then means the device's legacy default
+ * stream (what torch.cuda.current_stream().cuda_stream is when torch runs on its default stream), not
+ * "create one".  Use this whenever the caller orders its own work (collectives, copies) on that stream. */
+PCLHIP_API pclhip_status pclhip_ctx_create_on_stream(int device, void* stream, pclhip_ctx** out);
+/* the hipStream_t the context issues its work on */
+PCLHIP_API void* pclhip_ctx_stream(const pclhip_ctx* ctx);
 PCLHIP_API void pclhip_ctx_destroy(pclhip_ctx* ctx);
 PCLHIP_API const char* pclhip_last_error(const pclhip_ctx* ctx /* may be NULL */);
 PCLHIP_API pclhip_status pclhip_ctx_synchronize(pclhip_ctx* ctx);

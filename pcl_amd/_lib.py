@@ -71,6 +71,8 @@ SIGNATURES = {
     "pclhip_version": (C.c_char_p, []),
     "pclhip_last_error": (C.c_char_p, [_vp]),
     "pclhip_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "pclhip_ctx_create_on_stream": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "pclhip_ctx_stream": (_vp, [_vp]),
     "pclhip_ctx_destroy": (None, [_vp]),
     "pclhip_ctx_synchronize": (C.c_int, [_vp]),
     "pclhip_ctx_stats": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64)]),

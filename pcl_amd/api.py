@@ -44,12 +44,18 @@ class Context:
     """One device + one HIP stream (pclhip_ctx)."""
 
     def __init__(self, device=0, stream=None):
+        """stream=None: the context creates its own non-blocking stream.  Any integer -- including 0,
+        the legacy default stream torch reports as current_stream().cuda_stream -- is ADOPTED as given,
+        so work the caller orders on that stream (collectives, copies) stays ordered with the kernels."""
         self.lib = _lib.load()
         h = C.c_void_p()
-        check(self.lib.pclhip_ctx_create(int(device), C.c_void_p(stream) if stream else None,
-                                         C.byref(h)))
+        if stream is None:
+            check(self.lib.pclhip_ctx_create(int(device), None, C.byref(h)))
+        else:
+            check(self.lib.pclhip_ctx_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(h)))
         self.h = h
         self.device = device
+        self.stream = int(self.lib.pclhip_ctx_stream(h) or 0)
         self._children = []  # weakrefs to objects holding handles that point into this context
 
     def _adopt(self, obj):
@@ -110,10 +116,10 @@ class KdTree:
         self._free()
 
     def setInputCloud(self, cloud, indices=None):
-        # registration.h:214-221 / registration.hpp:84-87: rebuilding for the same cloud is a no-op
+        # search/include/pcl/search/impl/kdtree.hpp:87-97 -> kdtree_flann.hpp:99-136: ALWAYS rebuilds, like
+        # the reference (the array may have been modified in place since the last call).  Callers that know
+        # the cloud is unchanged keep the tree and pass it with setSearchMethodTarget(tree, True).
         key = (id(cloud), None if indices is None else id(indices))
-        if self.h is not None and key == self._cloud_id:
-            return True
         self._free()
         ptr, stride, n, keep = _cloud(cloud)
         h = C.c_void_p()
@@ -239,7 +245,11 @@ class NormalEstimation:
             raise ValueError("Neither radius nor K defined! Set one of them to a positive number first")
         if self.tree is None:
             self.tree = KdTree(self.ctx)
-        self.tree.setInputCloud(self.cloud)  # feature.hpp:125-130
+        # feature.hpp:125-130 sets the search surface on the tree.  A tree the caller has already built
+        # on this very cloud object is reused (setSearchMethod(tree) after tree.setInputCloud(cloud), the
+        # common PCL idiom, would otherwise build twice).
+        if self.tree.h is None or self.tree._cloud_id != (id(self.cloud), None):
+            self.tree.setInputCloud(self.cloud)
         n = self.tree.n_cloud
         nan = C.c_uint64(0)
         out = None
@@ -385,7 +395,12 @@ class IterativeClosestPoint:
         self.tree = KdTree(self.ctx)
         self.h = None
         self.src = None
-        self._src_id = None
+        self.src_normals = None
+        self.target = None
+        self._target_updated = False
+        self._force_no_recompute = False
+        self._src_dirty = True
+        self._src_nrm_dirty = True
         self.result = None
         self._allreduce = None
         self.rejectors = []
@@ -397,15 +412,28 @@ class IterativeClosestPoint:
 
     # --- setters named after registration.h:276-415 ---
     def setInputTarget(self, cloud):
-        self.tree.setInputCloud(cloud)
+        """Registration::setInputTarget (impl/registration.hpp:53-66): remembers the cloud and flags it as
+        updated; the tree is (re)built by the next align()/iterate() -- always, even for the same array
+        object (it may have been modified in place), unless setSearchMethodTarget(tree, True) said not to."""
+        self.target = cloud
+        self._target_updated = True
         self._drop_icp()
 
     def setSearchMethodTarget(self, tree, force_no_recompute=False):
+        """registration.h:214-221: with force_no_recompute the caller vouches that `tree` already indexes the
+        target, and it is never rebuilt here."""
         self.tree = tree
+        self._force_no_recompute = bool(force_no_recompute)
+        if force_no_recompute:
+            self._target_updated = False
         self._drop_icp()
 
     def setInputSource(self, cloud):
+        """Registration::setInputSource (registration.h:195-196): every call marks the source as new (the
+        device copy is refreshed by the next align()/iterate())."""
         self.src = cloud
+        self._src_dirty = True
+        self.src_normals = None   # a cloud without normals must not inherit the previous cloud's
 
     def setMaximumIterations(self, n):
         self.p.max_iterations = int(n)
@@ -454,29 +482,50 @@ class IterativeClosestPoint:
             if self.ctx.h is not None:
                 self.lib.pclhip_icp_destroy(self.h)
             self.h = None
-            self._src_id = None
-            self._filters_dirty = True
+        self._src_dirty = True
+        self._src_nrm_dirty = True
+        self._filters_dirty = True
+
+    def _init_target(self):
+        # Registration::initCompute (impl/registration.hpp:84-87)
+        if self._target_updated and not self._force_no_recompute:
+            self.tree.setInputCloud(self.target)
+            self._after_target_build()
+            self._target_updated = False
+            self._drop_icp()
+        if self.tree.h is None:
+            raise ValueError("No input target dataset was given!")
+
+    def _after_target_build(self):
+        pass
 
     def _ensure(self):
+        self._init_target()
+        if self.src is None:
+            raise ValueError("No input source dataset was given!")
         if self.h is None:
             h = C.c_void_p()
             check(self.lib.pclhip_icp_create(self.tree.h, C.byref(h)), self.ctx.h)
             self.h = h
             if self._allreduce is not None:
                 check(self.lib.pclhip_icp_set_allreduce(self.h, self._allreduce, None), self.ctx.h)
-        if self._src_id != id(self.src):
+        if self._src_dirty:
             ptr, stride, n, keep = _cloud(self.src)
             check(self.lib.pclhip_icp_set_source(self.h, ptr, stride, n), self.ctx.h)
-            self._src_id = id(self.src)
-            self._src_nrm_id = None
-        nrm = getattr(self, "src_normals", None)
-        if nrm is not None and getattr(self, "_src_nrm_id", None) != id(nrm):
-            nptr, nstride, nn, _keep = _cloud(nrm)
+            self._src_dirty = False
+            self._src_nrm_dirty = True
+        if self.src_normals is not None and self._src_nrm_dirty:
+            nptr, nstride, nn, _keep = _cloud(self.src_normals)
+            assert nn == _cloud(self.src)[2], "one normal per source point"
             check(self.lib.pclhip_icp_set_source_normals(self.h, nptr, nstride), self.ctx.h)
-            self._src_nrm_id = id(nrm)
+        self._src_nrm_dirty = False
+        self._apply_options()
         if getattr(self, "_filters_dirty", True):
             _set_filters(self.lib, self.ctx, self.h, self.rejectors, self.use_reciprocal)
             self._filters_dirty = False
+
+    def _apply_options(self):
+        pass
 
     def iterate(self, T_prev=None, max_dist=None):
         """One device iteration (search + accumulate kernels); returns the 32-double reduction record."""
@@ -594,20 +643,30 @@ class IterativeClosestPointWithNormals(IterativeClosestPoint):
 
     def setInputTarget(self, cloud):
         super().setInputTarget(cloud)
-        ncol = cloud.shape[1]
-        if ncol >= 7:  # pcl::PointNormal layout: normal at floats 4..6 (point_types.hpp:843-853)
-            self.tree.setNormals(cloud[:, 4:7])
+        self._target_normals = None
+
+    def _after_target_build(self):
+        # pcl::PointNormal layout: normal at floats 4..6 (point_types.hpp:843-853)
+        if self.target is not None and self.target.shape[1] >= 7:
+            self.tree.setNormals(self.target[:, 4:7])
+        if getattr(self, "_target_normals", None) is not None:
+            self.tree.setNormals(self._target_normals)
 
     def setTargetNormals(self, normals):
-        self.tree.setNormals(normals)
+        """Normals for the target given separately (one row per target point)."""
+        self._target_normals = normals
+        if self.tree.h is not None and not self._target_updated:
+            self.tree.setNormals(normals)
 
     def setInputSource(self, cloud):
         super().setInputSource(cloud)
         if cloud.shape[1] >= 7:  # pcl::PointNormal source: its normals feed the symmetric objective
             self.src_normals = cloud[:, 4:7]
+            self._src_nrm_dirty = True
 
     def setSourceNormals(self, normals):
         self.src_normals = normals
+        self._src_nrm_dirty = True
 
     def setUseSymmetricObjective(self, on):
         """icp.h:380-400: TransformationEstimationSymmetricPointToPlaneLLS instead of PointToPlaneLLS."""
@@ -618,10 +677,13 @@ class IterativeClosestPointWithNormals(IterativeClosestPoint):
         return self.MODE == _lib.SYMMETRIC
 
     def setEnforceSameDirectionNormals(self, on):
-        """icp.h:416-428"""
+        """icp.h:416-428.  Only stored here (this is usually called before the clouds are set); applied
+        whenever the device-side registration object is (re)created."""
         self._enforce = bool(on)
-        self._ensure()
-        check(self.lib.pclhip_icp_set_enforce_same_direction_normals(self.h, 1 if on else 0), self.ctx.h)
+
+    def _apply_options(self):
+        check(self.lib.pclhip_icp_set_enforce_same_direction_normals(
+            self.h, 1 if getattr(self, "_enforce", True) else 0), self.ctx.h)
 
     def getEnforceSameDirectionNormals(self):
         return getattr(self, "_enforce", True)

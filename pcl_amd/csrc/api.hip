@@ -114,6 +114,15 @@ struct Mat44 {
   float m[16];
 };
 
+// *bad = 1 if any sel[i] is outside [0, n)
+__global__ void check_indices_kernel(const int32_t* __restrict__ sel, uint64_t m, uint64_t n, int* __restrict__ bad) {
+  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  if (i < m) {
+    const int32_t v = sel[i];
+    if (v < 0 || uint64_t(v) >= n) *bad = 1;
+  }
+}
+
 __global__ void transform_cloud_kernel(Mat44 T, int order, const void* in, void* out, size_t stride, uint64_t n,
                                        size_t nrm_off) {
   const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
@@ -180,7 +189,19 @@ const char* pclhip_version(void) { return "pclhip 0.1 (gfx950)"; }
 
 const char* pclhip_last_error(const pclhip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
 
+static pclhip_status ctx_create_impl(int device, void* stream, bool adopt, pclhip_ctx** out);
+
 pclhip_status pclhip_ctx_create(int device, void* stream, pclhip_ctx** out) {
+  return ctx_create_impl(device, stream, stream != nullptr, out);
+}
+
+pclhip_status pclhip_ctx_create_on_stream(int device, void* stream, pclhip_ctx** out) {
+  return ctx_create_impl(device, stream, true, out);
+}
+
+void* pclhip_ctx_stream(const pclhip_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+static pclhip_status ctx_create_impl(int device, void* stream, bool adopt, pclhip_ctx** out) {
   if (!out) return PCLHIP_ERR_INVALID;
   *out = nullptr;
   int count = 0;
@@ -199,8 +220,8 @@ pclhip_status pclhip_ctx_create(int device, void* stream, pclhip_ctx** out) {
   hipDeviceProp_t prop;
   PCLHIP_CHECK_HIP(ctx, hipGetDeviceProperties(&prop, device));
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (stream) {
-    ctx->stream = static_cast<hipStream_t>(stream);
+  if (adopt) {
+    ctx->stream = static_cast<hipStream_t>(stream);  // may be the null (legacy default) stream
   } else {
     PCLHIP_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->own_stream = true;
@@ -268,6 +289,19 @@ pclhip_status pclhip_index_build(pclhip_ctx* ctx, const void* points, size_t str
     guard.add(owned);
   }
   const uint64_t m = indices ? n_indices : n;
+  if (indices && n_indices > 0) {  // untrusted: an index outside the cloud would be a wild device read
+    PCLHIP_REQUIRE(ctx, n_indices < 0x7FFFFFFFull, "too many indices");
+    int* bad = nullptr;
+    PCLHIP_CHECK_HIP(ctx, hipMalloc(&bad, sizeof(int)));
+    guard.add(bad);
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(check_indices_kernel, dim3(unsigned((n_indices + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<const int32_t*>(dsel), n_indices, n, bad);
+    int hbad = 0;
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PCLHIP_REQUIRE(ctx, hbad == 0, "indices must lie in [0, n)");
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   PCLHIP_CHECK_HIP(ctx, hipEventCreate(&e0));
   if (hipEventCreate(&e1) != hipSuccess) {
@@ -680,6 +714,18 @@ pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[16], double
     return PCLHIP_ERR_STATE;
   }
   PCLHIP_REQUIRE(ctx, icp->src_cur != nullptr, "no source cloud set");
+  if (icp->allreduce) {
+    // With the source sharded over ranks, MedianDistance / Trimmed thresholds, OneToOne conflicts and the
+    // reciprocal test would be evaluated per slab, which is not what a single-GPU (or the reference's) run
+    // computes.  Only per-pair filters (Distance) commute with the sharding.
+    bool global_filter = icp->reciprocal;
+    for (const pclhip_rejector& r : icp->rejectors) global_filter = global_filter || r.kind != PCLHIP_REJ_DISTANCE;
+    if (global_filter) {
+      set_error(ctx, "multi-GPU (all-reduce) iterations support only the Distance rejector: MedianDistance, Trimmed, "
+                     "OneToOne and reciprocal correspondences need cloud-global decisions");
+      return PCLHIP_ERR_STATE;
+    }
+  }
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   // correspondence_estimation.hpp:161,176: drop if double(d2) > max_dist*max_dist
   const double md2 = max_dist * max_dist;

@@ -90,6 +90,8 @@ bool parse_header(std::string_view bytes, Header& h, std::string& err) {
     if (starts_with(key, "VERSION")) continue;
     if (starts_with(key, "FIELDS") || starts_with(key, "COLUMNS")) {
       h.fields.assign(st.size() - 1, Field());
+      sizes.clear();  // a repeated FIELDS line starts over: SIZE / TYPE / COUNT must follow it again
+      types.clear();
       size_t off = 0;
       for (size_t i = 0; i + 1 < st.size(); ++i) {  // older files: everything float32 unless SIZE/TYPE say otherwise
         h.fields[i].name = st[i + 1];
@@ -108,6 +110,10 @@ bool parse_header(std::string_view bytes, Header& h, std::string& err) {
       size_t off = 0;
       for (size_t i = 0; i < h.fields.size(); ++i) {
         sizes[i] = std::atoi(st[i + 1].c_str());
+        if (sizes[i] != 1 && sizes[i] != 2 && sizes[i] != 4 && sizes[i] != 8) {
+          err = "Invalid SIZE value (must be 1, 2, 4 or 8): " + st[i + 1];
+          return false;
+        }
         h.fields[i].size = sizes[i];
         h.fields[i].offset = off;
         off += size_t(sizes[i]);
@@ -127,12 +133,20 @@ bool parse_header(std::string_view bytes, Header& h, std::string& err) {
       types.resize(h.fields.size());
       for (size_t i = 0; i < h.fields.size(); ++i) {
         types[i] = st[i + 1][0];
+        if (types[i] != 'I' && types[i] != 'U' && types[i] != 'F') {
+          err = "Invalid TYPE value (must be I, U or F): " + st[i + 1];
+          return false;
+        }
+        if (types[i] == 'F' && sizes[i] != 4 && sizes[i] != 8) {
+          err = "TYPE F needs SIZE 4 or 8";
+          return false;
+        }
         h.fields[i].type = types[i];
       }
       continue;
     }
     if (starts_with(key, "COUNT")) {
-      if (sizes.empty() || types.empty()) {
+      if (sizes.size() != h.fields.size() || types.size() != h.fields.size()) {
         err = "COUNT of FIELDS specified before SIZE or TYPE in header!";
         return false;
       }
@@ -144,7 +158,11 @@ bool parse_header(std::string_view bytes, Header& h, std::string& err) {
       for (size_t i = 0; i < h.fields.size(); ++i) {
         h.fields[i].offset = off;
         h.fields[i].count = std::atoi(st[i + 1].c_str());
-        off += size_t(h.fields[i].count > 0 ? h.fields[i].count : 0) * size_t(sizes[i]);
+        if (h.fields[i].count < 0 || h.fields[i].count > (1 << 20)) {
+          err = "Invalid COUNT value: " + st[i + 1];
+          return false;
+        }
+        off += size_t(h.fields[i].count) * size_t(sizes[i]);
       }
       h.point_step = off;
       continue;
@@ -202,6 +220,23 @@ bool parse_header(std::string_view bytes, Header& h, std::string& err) {
   }
   (void)points_read;
   (void)data_seen;
+  // untrusted input: every field must lie inside the record, sizes must be consistent, and
+  // points * point_step must not overflow
+  if (!h.fields.empty() && !sizes.empty() && sizes.size() != h.fields.size()) {
+    err = "SIZE does not match the last FIELDS line";
+    return false;
+  }
+  for (const Field& f : h.fields) {
+    const size_t cnt = f.count > 0 ? size_t(f.count) : 0;
+    if (f.size <= 0 || f.offset + cnt * size_t(f.size) > h.point_step) {
+      err = "field '" + f.name + "' does not fit the record described by SIZE/COUNT";
+      return false;
+    }
+  }
+  if (h.point_step > (1u << 24) || (h.point_step != 0 && h.points > (uint64_t(1) << 62) / h.point_step)) {
+    err = "POINTS x point size overflows";
+    return false;
+  }
   // fields with COUNT < 1 are dropped (:339-341)
   {
     std::vector<Field> kept;
@@ -443,6 +478,11 @@ bool decode_body(std::string_view bytes, const Header& h, Body& body, std::strin
   if (h.data_type == 0) {  // readBodyASCII :456-559
     size_t elems = 0;
     for (const Field& f : h.fields) elems += size_t(f.count);
+    // every ascii point takes at least one byte per element plus a line break
+    if (n > bytes.size() || n * (elems > 0 ? elems : 1) > 2 * bytes.size()) {
+      err = "file is shorter than the POINTS it announces";
+      return false;
+    }
     body.storage.assign(size_t(n) * h.point_step, 0);
     // the i-th non-empty line is point i (a malformed line still consumes its point, :489-495)
     std::vector<std::pair<size_t, size_t>> lines;  // [begin, end)

@@ -43,13 +43,22 @@ def device_doubles(ptr, count, device_index):
 
 
 def make_allreduce_hook(device_index, group=None):
-    """Hook for IterativeClosestPoint.setAllReduce: sums the DEVICE record in place over RCCL.  The
-    context must have been created on torch's current stream so the collective is ordered after
-    the kernel that produced the record and before the host read."""
+    """Hook for IterativeClosestPoint.setAllReduce: sums the DEVICE record in place over RCCL, ON THE
+    STREAM THE C SIDE PASSES (the context's stream, where the record was just produced and from which the
+    host copy is issued afterwards).  The collective is enqueued under torch.cuda.ExternalStream(stream),
+    so it is ordered after the finalize kernel and before the read-back whatever stream torch itself
+    considers current -- a context on a private stream and one on torch's default stream both work."""
+    import torch
     import torch.distributed as dist
 
     def hook(ptr, count, stream):
         assert count == NSUMS
-        dist.all_reduce(device_doubles(ptr, count, device_index), op=dist.ReduceOp.SUM, group=group)
+        rec = device_doubles(ptr, count, device_index)
+        s = int(stream or 0)
+        if s == int(torch.cuda.current_stream(device_index).cuda_stream):
+            dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=group)
+        else:
+            with torch.cuda.stream(torch.cuda.ExternalStream(s, device=torch.device("cuda", device_index))):
+                dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=group)
         return 0
     return hook

@@ -135,6 +135,39 @@ def test_reader_errors(api, tmp_path):
     assert list(api.getPCDHeader(str(p)).viewpoint) == [1, 2, 3, 1, 0, 0, 0]
 
 
+def test_reader_rejects_hostile_headers(api, tmp_path):
+    # untrusted files: negative / odd SIZE, bad TYPE, a second FIELDS line with more fields than SIZE/TYPE,
+    # field extents beyond the record, POINTS that the file cannot hold -- errors, never wild reads
+    p = tmp_path / "evil.pcd"
+    head = "VERSION 0.7\nFIELDS x y z w\nSIZE %s\nTYPE %s\nCOUNT 1 1 1 1\nWIDTH 4\nHEIGHT 1\nPOINTS 4\nDATA binary\n"
+    p.write_bytes((head % ("4 4 4 -8", "F F F F")).encode() + b"\0" * 64)
+    with pytest.raises(api.PclHipError, match="SIZE"):
+        api.loadPCDFile(str(p))
+    p.write_bytes((head % ("4 4 4 3", "F F F F")).encode() + b"\0" * 64)
+    with pytest.raises(api.PclHipError, match="SIZE"):
+        api.getPCDHeader(str(p))
+    p.write_bytes((head % ("4 4 4 4", "F F F Q")).encode() + b"\0" * 64)
+    with pytest.raises(api.PclHipError, match="TYPE"):
+        api.getPCDHeader(str(p))
+    p.write_bytes((head % ("4 4 4 2", "F F F F")).encode() + b"\0" * 64)
+    with pytest.raises(api.PclHipError, match="TYPE F"):
+        api.getPCDHeader(str(p))
+    p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nFIELDS x y z a b c d e f g\nCOUNT 1 1 1 1 1 1 1 1 1 1\n"
+                 "WIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA ascii\n0 0 0 0 0 0 0 0 0 0\n")
+    with pytest.raises(api.PclHipError, match="COUNT"):
+        api.getPCDHeader(str(p))
+    p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 -5\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA ascii\n0 0 0\n")
+    with pytest.raises(api.PclHipError, match="COUNT"):
+        api.getPCDHeader(str(p))
+    big = 2 ** 62
+    p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH %d\nHEIGHT 1\nPOINTS %d\nDATA binary\n" % (1, big))
+    with pytest.raises(api.PclHipError):
+        api.loadPCDFile(str(p))
+    p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 300000000\nHEIGHT 1\nPOINTS 300000000\nDATA ascii\n0 0 0\n")
+    with pytest.raises(api.PclHipError, match="shorter"):
+        api.loadPCDFile(str(p))
+
+
 def test_organized_write_viewpoint_and_field_reader(api, tmp_path):
     from oracle import pcd as opcd
     rng = np.random.default_rng(8)
