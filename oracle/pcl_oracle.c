@@ -1260,22 +1260,27 @@ void orc_solve_plane_parameters(const float* cov, float* nx, float* ny, float* n
     *curvature = 0;
 }
 
-int64_t orc_normals_knn(const orc_kdtree* t, const float* cloud, int64_t n, int cs, int k,
-                        const float* vp, float* out, int32_t* out_knn, int nthreads) {
+/* computeFeature loops over indices_ (features/include/pcl/features/impl/normal_3d.hpp:59,74): with
+ * `indices` == NULL every point of the cloud is a query, else only cloud[indices[j]], output row j. */
+int64_t orc_normals_knn_indices(const orc_kdtree* t, const float* cloud, int64_t n, int cs, int k,
+                                const float* vp, const int32_t* indices, int64_t n_indices, float* out,
+                                int32_t* out_knn, int nthreads) {
   int64_t nan_count = 0;
   if (nthreads < 1) nthreads = 1;
+  const int64_t nq = indices ? n_indices : n;
 #pragma omp parallel num_threads(nthreads) reduction(+ : nan_count)
   {
     int32_t* idx = (int32_t*)malloc((size_t)k * sizeof(int32_t));
     float* d2 = (float*)malloc((size_t)k * sizeof(float));
 #pragma omp for schedule(dynamic, 256)
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t j = 0; j < nq; ++j) {
+      const int64_t i = indices ? (int64_t)indices[j] : j;
       const float* p = cloud + i * cs;
-      float* o = out + 4 * i;
+      float* o = out + 4 * j;
       int found = 0;
       if (finite3(p)) found = orc_kdtree_knn(t, p, 1, cs, k, idx, d2, 1);
       if (out_knn)
-        for (int c = 0; c < k; ++c) out_knn[i * k + c] = (finite3(p) && c < found) ? idx[c] : -1;
+        for (int c = 0; c < k; ++c) out_knn[j * k + c] = (finite3(p) && c < found) ? idx[c] : -1;
       float cov[9], cen[4];
       /* normal_3d.hpp:79-87, normal_3d.h:308-322 */
       if (!finite3(p) || found == 0 || found < 3 ||
@@ -1298,6 +1303,11 @@ int64_t orc_normals_knn(const orc_kdtree* t, const float* cloud, int64_t n, int 
     free(d2);
   }
   return nan_count;
+}
+
+int64_t orc_normals_knn(const orc_kdtree* t, const float* cloud, int64_t n, int cs, int k,
+                        const float* vp, float* out, int32_t* out_knn, int nthreads) {
+  return orc_normals_knn_indices(t, cloud, n, cs, k, vp, NULL, 0, out, out_knn, nthreads);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -182,6 +182,12 @@ void orc_solve_plane_parameters(const float* cov9, float* nx, float* ny, float* 
 int64_t orc_normals_knn(const orc_kdtree* t, const float* cloud, int64_t n, int cs, int k,
                         const float* viewpoint3, float* out, int32_t* out_knn, int nthreads);
 
+/* The same for the points listed in `indices` only (Feature::setIndices; output row j = cloud[indices[j]]);
+ * the neighbours still come from the whole cloud (the search surface). */
+int64_t orc_normals_knn_indices(const orc_kdtree* t, const float* cloud, int64_t n, int cs, int k,
+                                const float* viewpoint3, const int32_t* indices, int64_t n_indices,
+                                float* out, int32_t* out_knn, int nthreads);
+
 /* ---- VoxelGrid ----------------------------------------------------------------------------- */
 /* VoxelGrid::applyFilter (filters/include/pcl/filters/impl/voxel_grid.hpp:597-814), PointXYZ,
  * downsample_all_data (centroid = float sum / n, common/include/pcl/common/impl/accumulators.hpp

@@ -105,6 +105,8 @@ def lib():
         L.orc_solve_plane_parameters.argtypes = [fp, fp, fp, fp, fp]
         L.orc_normals_knn.restype = C.c_int64
         L.orc_normals_knn.argtypes = [vp, fp, C.c_int64, C.c_int, C.c_int, fp, fp, ip, C.c_int]
+        L.orc_normals_knn_indices.restype = C.c_int64
+        L.orc_normals_knn_indices.argtypes = [vp, fp, C.c_int64, C.c_int, C.c_int, fp, ip, C.c_int64, fp, ip, C.c_int]
         L.orc_voxelgrid.restype = C.c_int64
         L.orc_voxelgrid.argtypes = [fp, C.c_int64, C.c_int, fp, C.c_uint, C.c_int, C.c_double,
                                     C.c_double, fp, ip]
@@ -208,13 +210,19 @@ class KdTree:
                                                  nthreads or default_threads())
         return q[:c].copy(), m[:c].copy(), d2[:c].copy()
 
-    def normals(self, cloud, k, viewpoint=(0.0, 0.0, 0.0), want_knn=False, nthreads=None):
+    def normals(self, cloud, k, viewpoint=(0.0, 0.0, 0.0), want_knn=False, nthreads=None, indices=None):
+        """`cloud` must be the cloud the tree was built on (search surface == input); `indices` (Feature::
+        setIndices) restricts the queries to cloud[indices], one output row per index."""
         cloud, n, cs = _cloud(cloud)
-        out = np.empty((n, 4), np.float32)
-        knn = np.empty((n, k), np.int32) if want_knn else None
+        assert n == self.n, "normals(): pass the tree's own cloud (use indices= for a subset)"
+        ind = None if indices is None else np.ascontiguousarray(indices, np.int32)
+        nq = n if ind is None else len(ind)
+        out = np.empty((nq, 4), np.float32)
+        knn = np.empty((nq, k), np.int32) if want_knn else None
         vp = np.asarray(viewpoint, np.float32)
-        nan = lib().orc_normals_knn(self.h, _f(cloud), n, cs, k, _f(vp), _f(out),
-                                    _i(knn) if want_knn else None, nthreads or default_threads())
+        nan = lib().orc_normals_knn_indices(self.h, _f(cloud), n, cs, k, _f(vp),
+                                            _i(ind) if ind is not None else None, nq, _f(out),
+                                            _i(knn) if want_knn else None, nthreads or default_threads())
         return (out, knn, nan) if want_knn else (out, nan)
 
 

@@ -974,61 +974,6 @@ def test_icp_lattice_ties_with_seeds_bit_exact(gpu, orc):
         assert np.array_equal(q, oq) and np.array_equal(m, om) and np.array_equal(d, od), it
 
 
-def test_full_size_properties_10m(gpu):
-    # BASELINE.json's size (10M points): properties that do not need the oracle.
-    import torch
-    import pcl_amd
-    from pcl_amd import synth
-    n = 10_000_000
-    tgt_h = synth.gaussian_surface(n, synth.TARGET_SEED)
-    tgt = torch.from_numpy(tgt_h).cuda()
-    tree = pcl_amd.KdTree(gpu)
-    tree.setInputCloud(tgt)
-    # (1) self-queries: every point finds itself at distance 0 (ties between duplicates -> lower index)
-    idx, d2 = tree.nearestKSearch(tgt, 1)
-    assert int((d2 != 0).sum()) == 0
-    ar = torch.arange(n, device="cuda", dtype=torch.int32)
-    moved = idx[:, 0] != ar
-    assert bool((idx[:, 0][moved] < ar[moved]).all())            # only duplicates, resolved downwards
-    assert bool((tgt[idx[:, 0][moved].long(), :3] == tgt[moved, :3]).all())
-    # (2) k = 8: ascending distances, first neighbour is the point itself, no index repeats in a row
-    idx8, d8 = tree.nearestKSearch(tgt[:2_000_000], 8)
-    assert bool((d8[:, 1:] >= d8[:, :-1]).all()) and int((d8[:, 0] != 0).sum()) == 0
-    s = torch.sort(idx8, dim=1).values
-    assert int((s[:, 1:] == s[:, :-1]).sum()) == 0
-    # (3) a rigidly moved copy of the target: after undoing the motion every source point matches its own
-    #     original (or an exact duplicate) within float rounding, all 10M correspondences are kept
-    T = synth.ground_truth_transform().astype(np.float32)
-    icp = pcl_amd.IterativeClosestPoint(gpu)
-    icp.setSearchMethodTarget(tree)
-    src = torch.from_numpy(synth.apply_rigid(T, tgt_h)).cuda()
-    icp.setInputSource(src)
-    icp.reset()
-    sums = icp.iterate(np.linalg.inv(T.astype(np.float64)).astype(np.float32), max_dist=0.1)
-    assert sums[28] == n and sums[27] / n < 1e-12                 # mean squared distance ~ rounding^2
-    # (4) idempotence: a second iteration with the identity reproduces the same record bit for bit
-    again = icp.iterate(np.eye(4, dtype=np.float32), max_dist=0.1)
-    assert np.array_equal(again[27:29], sums[27:29]) and np.array_equal(again[:15], sums[:15])
-    # (5) the alignment from the benchmark start pose converges to the ground truth
-    src2 = torch.from_numpy(synth.apply_rigid(np.linalg.inv(synth.ground_truth_transform()),
-                                              synth.gaussian_surface(n, synth.SOURCE_SEED))).cuda()
-    ne = pcl_amd.NormalEstimation(gpu)
-    ne.setInputCloud(tgt)
-    ne.setSearchMethod(tree)
-    ne.setKSearch(8)
-    ne.setViewPoint(0, 0, 10)
-    ne.compute(want_output=False)
-    icp2 = pcl_amd.IterativeClosestPointWithNormals(gpu)
-    icp2.setSearchMethodTarget(tree)
-    icp2.setInputSource(src2)
-    icp2.setMaximumIterations(20)
-    icp2.setMaxCorrespondenceDistance(0.1)
-    icp2.setTransformationEpsilon(1e-10)
-    icp2.align()
-    assert icp2.hasConverged()
-    assert np.abs(icp2.getFinalTransformation() - synth.ground_truth_transform()).max() < 1e-4
-
-
 def test_fused_single_kernel_variant_matches_default(gpu, tmp_path):
     # PCLHIP_ICP_FUSED=1 selects the single-kernel iteration (search + accumulation in one launch); it must
     # produce the same correspondences and, up to fp64 summation order, the same records.  The switch is read
