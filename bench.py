@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- headline metric of BASELINE.json: ICP correspondences/s (+ ms/iteration) on the
-10M-point synthetic Gaussian-surface cloud, k=8 normals + point-to-plane ICP, on N MI355X GPUs.
+"""bench.py -- the metric of BASELINE.json ("ICP correspondences/sec/GPU + ms/iteration, 10M-pt cloud; HBM
+GB/s vs roofline") on N MI355X GPUs of one node.
 
-A "step" is ONE ICP iteration over the whole (rank-local) source cloud: transform ->
-exact 1-NN in the target -> 6x6 normal-system accumulation -> (all-reduce) -> host solve.
-Iterations are drawn from repeated IterativeClosestPointWithNormals::align() runs on the config's
-clouds (point-to-plane converges in ~3-4 iterations): when an alignment
-converges the working cloud is rewound and the next alignment starts, so the K timed steps contain
-the realistic mix of far-from-aligned and nearly-aligned iterations.  Target index + normals are
-built before the timed region (reported separately) and stay resident in HBM.
+  --config 3 (default)  10M-point synthetic Gaussian-surface clouds, k = 8 NormalEstimation + point-to-plane ICP
+  --config 2            2^20-point clouds, k = 1, point-to-point ICP (TransformationEstimationSVD)
+  --config 4            config 3's clouds through VoxelGrid(0.01) first; a step is the whole pipeline
+                        (filter both clouds + target index + normals + the alignment), as SURVEY.md 8(d) says
+  --config 5            100M-point target cut into kd slabs + halo over the ranks (needs --gpus > 1; the
+                        replicated-target variant of the same problem is --config 5 --replicated)
 
-Multi-GPU (weak scaling): every rank holds the full target index (it fits HBM many times over;
-north_star shards the target only when it does not) and its own slab of the source
-(n_points source points per rank, disjoint counter ranges of the same surface); the only exchange
-per iteration is the all-reduce of the 32-double reduction record over RCCL.
+Configs 2/3/5: a "step" is ONE ICP iteration over the whole (rank-local) source cloud: transform -> exact 1-NN
+in the target -> normal-system accumulation -> (all-reduce) -> solve + convergence test.  The K timed steps are
+queued back to back by pclhip_icp_run_steps -- the iteration is closed on the device, nothing returns to the
+host in between -- and come from repeated IterativeClosestPoint::align() runs on the config's clouds (when an
+alignment converges the next one starts from the input cloud), so they contain the realistic mix of
+far-from-aligned and nearly-aligned iterations; the per-step list in the output says which was which.
+Target index + normals are built before the timed region (reported under "setup") and stay resident in HBM.
+
+Multi-GPU (weak scaling, configs 2/3): every rank holds the full target index and its own slab of the source;
+the only exchange per iteration is the all-reduce of the 32-double record (ncclAllReduce from C, RCCL/xGMI).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,24 +35,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# algorithmic bytes per correspondence: src 16 + tgt 16 + (idx 4 + d2 4) = 40 for the
-# search; + normal 16 = 56 for a whole point-to-plane iteration
-B_ALG_SEARCH = 40.0
-B_ALG_ITER = {1: 56.0, 0: 40.0}
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# algorithmic bytes per unit; DESIGN.md section 4 repeats the derivations
+B_ALG_SEARCH = 40.0                     # src 16 + matched tgt 16 + (idx 4 + d2 4)
+B_ALG_ITER = {1: 56.0, 0: 40.0}         # + target normal 16 for point-to-plane
+B_ALG_VOXEL = 32.0                      # per input point
+B_ALG_NORMALS = 160.0                   # per target point, k = 8
+B_ALG_BUILD = 64.0                      # per indexed point
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--points", type=int, default=10_000_000, help="source points per GPU (= target points)")
-    ap.add_argument("--mode", choices=["p2plane", "p2point"], default="p2plane")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5])
+    ap.add_argument("--points", type=int, default=0, help="override the config's points per cloud (per GPU)")
     ap.add_argument("--knn", type=int, default=8, help="k of NormalEstimation")
+    ap.add_argument("--replicated", action="store_true", help="config 5: replicate the target instead of sharding it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points of the CPU-baseline sample")
     return ap.parse_args()
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL,
+                                       text=True).strip()
+    except Exception:
+        return None
 
 
 def main():
@@ -68,10 +84,31 @@ def main():
     import pcl_amd
     from pcl_amd import synth
 
-    mode = 1 if args.mode == "p2plane" else 0
-    n = args.points
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = pcl_amd.Context(local_rank, stream=stream)
+    cfg = args.config
+    mode = 0 if cfg == 2 else 1
+    n = args.points or {2: 1 << 20, 3: 10_000_000, 4: 10_000_000, 5: 100_000_000}[cfg]
+    ctx = pcl_amd.Context(local_rank)      # its own stream; collectives are issued on it from C
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    comm = None
+    if world > 1:  # native RCCL communicator: rank 0's id travels over the torch process group once
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(pcl_amd.Communicator.unique_id()), dtype=torch.uint8).cuda()
+        dist.broadcast(uid, 0)
+        comm = pcl_amd.Communicator(ctx, rank, world, bytes(uid.cpu().numpy().tobytes()))
+
+    if cfg == 5:
+        from bench_sharded import run_config5     # target slab + halo sharding (pcl_amd/dist.py)
+        out = run_config5(args, ctx, comm, rank, local_rank, world, fence)
+        finish(out, rank, world)
+        return
 
     # ---- synthetic clouds; target identical on every rank, source = this rank's slab
     t0 = time.perf_counter()
@@ -81,6 +118,11 @@ def main():
     gen_s = time.perf_counter() - t0
     tgt = torch.from_numpy(tgt_h).cuda()
     src = torch.from_numpy(src_h).cuda()
+
+    if cfg == 4:
+        out = run_pipeline(args, ctx, comm, tgt, src, n, rank, world, fence, gen_s)
+        finish(out, rank, world)
+        return
 
     # ---- target index + normals (one-off, outside the timed region)
     tree = pcl_amd.KdTree(ctx)
@@ -98,49 +140,20 @@ def main():
 
     cls = pcl_amd.IterativeClosestPointWithNormals if mode == 1 else pcl_amd.IterativeClosestPoint
     icp = cls(ctx)
-    icp.setSearchMethodTarget(tree)
+    icp.setSearchMethodTarget(tree, True)
     icp.setInputSource(src)
-    max_dist = 0.1
-    if world > 1:
-        from pcl_amd.dist import make_allreduce_hook
-        icp.setAllReduce(make_allreduce_hook(local_rank))  # RCCL all-reduce of the 32-double record
+    icp.setMaximumIterations(20)
+    icp.setMaxCorrespondenceDistance(0.1)
+    icp.setTransformationEpsilon(1e-10)
+    if comm is not None:
+        icp.setCommunicator(comm)
+    source_order_ms = icp.sourceOrderMs()
 
-    state = {"T": np.eye(4, dtype=np.float32), "it": 0}
-    icp.reset()
-
-    def step():
-        sums = icp.iterate(state["T"], max_dist=max_dist)
-        T = icp.solve(sums)
-        state["it"] += 1
-        # DefaultConvergenceCriteria TRANSFORM test with transformation_epsilon 1e-10 (+ iteration cap 20)
-        cos_angle = 0.5 * (float(T[0, 0]) + float(T[1, 1]) + float(T[2, 2]) - 1.0)
-        tr2 = float(T[0, 3]) ** 2 + float(T[1, 3]) ** 2 + float(T[2, 3]) ** 2
-        if (cos_angle >= 0.99999 and tr2 <= 1e-10) or state["it"] >= 20 or sums[28] < 3:
-            icp.reset()                      # next alignment starts from the input cloud
-            state["T"] = np.eye(4, dtype=np.float32)
-            state["it"] = 0
-        else:
-            state["T"] = T
-        return sums[28], icp.lastKernelMs(), icp.lastSearchMs()
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
+    if args.warmup > 0:
+        icp.runSteps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    ncorr = 0.0
-    kernel_ms = 0.0
-    search_ms = 0.0
-    for _ in range(args.steps):
-        c, kms, sms = step()
-        ncorr += c            # already the all-reduced (global) count when world > 1
-        kernel_ms += kms
-        search_ms += sms
+    steps = icp.runSteps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -148,51 +161,214 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    ncorr = float(sum(s["num_correspondences"] for s in steps))   # already the all-reduced (global) count
+    search_ms = sum(s["search_ms"] for s in steps)
+    kernel_ms = sum(s["kernels_ms"] for s in steps)
     # ---- roofline of the dominant kernel (the exact 1-NN search), live HIP-event timing on the context's
-    # stream.  The iteration is two kernels: icp_search_kernel (dominant) and the streaming
-    # icp_accumulate_kernel; with PCLHIP_ICP_FUSED=1 both run as one kernel and the two times coincide.
-    fused = os.environ.get("PCLHIP_ICP_FUSED", "0") == "1"
-    b_alg = B_ALG_ITER[mode] if fused else B_ALG_SEARCH
-    avg_kernel_s = search_ms / args.steps / 1e3
-    corr_per_launch_local = ncorr / args.steps / world
-    achieved = b_alg * corr_per_launch_local / avg_kernel_s / 1e9
-    roofline = {"bound": "hbm", "kernel": ("icp_iterate_kernel<%d>" % mode) if fused else "icp_search_kernel",
-                "achieved": round(achieved, 2),
+    # stream: achieved = algorithmic bytes per launch / average launch duration
+    avg_kernel_s = search_ms / max(args.steps, 1) / 1e3
+    corr_per_launch_local = ncorr / max(args.steps, 1) / world
+    achieved = B_ALG_SEARCH * corr_per_launch_local / avg_kernel_s / 1e9
+    roofline = {"bound": "hbm", "kernel": "icp_search_kernel", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None, "alg_bytes_per_corr": b_alg, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
-                "iteration_kernels_ms": round(kernel_ms / args.steps, 4),
+                "traffic": None, "alg_bytes_per_corr": B_ALG_SEARCH, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
+                "iteration_kernels_ms": round(kernel_ms / max(args.steps, 1), 4),
                 "iteration_alg_bytes_per_corr": B_ALG_ITER[mode]}
-    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tp):  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
+    traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if cfg == 3 and os.path.exists(traffic_file):
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes of this very command
+        # (scripts/profile_gpu.sh regenerates the file and stamps the commit it measured)
         try:
-            roofline["traffic"] = json.load(open(tp)).get(
-                ("icp_iterate_bytes_per_launch_%s" % args.mode) if fused else "icp_search_bytes_per_launch")
+            tj = json.load(open(traffic_file))
+            roofline["traffic"] = tj.get("icp_search_bytes_per_launch")
+            roofline["traffic_source"] = {"file": "profiles/pmc_traffic.json", "commit": tj.get("commit"),
+                                          "date": tj.get("date")}
         except Exception:
             pass
 
     out = None
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N=1 figure (it would stall the other ranks)
-            cpu = cpu_baseline(args, mode)
+        if not args.no_cpu_baseline and world == 1:  # an N=1 figure (it would stall the other ranks)
+            cpu = cpu_baseline(args, mode, n, tgt_h, src_h)
+        name = {2: "config 2: 2^20-point clouds, k=1 NN + point-to-point ICP (SVD)",
+                3: "config 3: 10M-point clouds, k=%d NormalEstimation + point-to-plane ICP" % args.knn}[cfg]
         out = {
             "metric": "ICP correspondences/sec", "value": round(ncorr / elapsed, 1), "unit": "correspondences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 search / f64 accumulate", "data": "synthetic",
-            "config": {"workload": "%dM-point synthetic Gaussian-surface cloud per GPU, k=%d NormalEstimation + "
-                                   "%s ICP, 1-NN correspondences, max_dist 0.1" %
-                                   (n // 1_000_000, args.knn, "point-to-plane" if mode == 1 else "point-to-point"),
+            "config": {"workload": "%s; %d-point synthetic Gaussian-surface source per GPU vs %d-point target, 1-NN "
+                                   "correspondences, max_dist 0.1" % (name, n, n),
                        "baseline_metric": "ICP correspondences/sec/GPU + ms/iteration, 10M-pt cloud; HBM GB/s vs roofline "
                                           "(BASELINE.json; `value` is the whole-job aggregate, ms/iteration = ms_per_step, "
                                           "HBM GB/s = roofline.achieved)",
-                       "points_per_gpu": n, "target_points": n, "mode": args.mode,
-                       "parallelism": "source slab sharded x%d (kd-ordered per rank), target replicated" % world},
+                       "points_per_gpu": n, "target_points": n, "mode": "p2plane" if mode == 1 else "p2point",
+                       "loop": "device-driven (pclhip_icp_run_steps): search, accumulate, reduce, solve + convergence "
+                               "kernels queued back to back",
+                       "parallelism": "source slab sharded x%d, target replicated%s" %
+                                      (world, ", ncclAllReduce of the 32-double record per iteration" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu,
+            "per_step": [{"iteration": s["iteration"], "search_ms": round(s["search_ms"], 4),
+                          "step_ms": round(s["step_ms"], 4), "ended": s["alignment_ended"]} for s in steps],
             "setup": {"index_build_ms": round(build_ms, 3),
+                      "index_build_GBps_alg": round(B_ALG_BUILD * n / (build_ms * 1e-3) / 1e9, 1),
                       "normals_kernel_ms": None if normals_ms is None else round(normals_ms, 3),
-                      "synth_gen_s": round(gen_s, 1)},
+                      "normals_GBps_alg": None if normals_ms is None else
+                      round(B_ALG_NORMALS * n / (normals_ms * 1e-3) / 1e9, 1),
+                      "source_order_ms": round(source_order_ms, 3),
+                      "synth_gen_s": round(gen_s, 1), "commit": git_head()},
         }
+    finish(out, rank, world)
+
+
+def run_pipeline(args, ctx, comm, tgt, src, n, rank, world, fence, gen_s):
+    """config 4: VoxelGrid(0.01) on both clouds -> target index -> NormalEstimation(k) -> alignment.  One step =
+    the whole pipeline on the resident 10M-point clouds."""
+    import torch
+    import torch.distributed as dist
+    import pcl_amd
+
+    stage_ms = {"voxelgrid": [], "index_build": [], "normals": [], "icp": [], "source_order": []}
+    info = {}
+
+    def step():
+        t0 = time.perf_counter()
+        filt = []
+        for cloud in (tgt, src):
+            vg = pcl_amd.VoxelGrid(ctx)
+            vg.setInputCloud(cloud)
+            vg.setLeafSize(0.01, 0.01, 0.01)
+            filt.append(vg.filter())
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        tree = pcl_amd.KdTree(ctx)
+        tree.setInputCloud(filt[0])
+        ne = pcl_amd.NormalEstimation(ctx)
+        ne.setInputCloud(filt[0])
+        ne.setSearchMethod(tree)
+        ne.setKSearch(args.knn)
+        ne.setViewPoint(0, 0, 10)
+        ne.compute(want_output=False)
+        icp = pcl_amd.IterativeClosestPointWithNormals(ctx)
+        icp.setSearchMethodTarget(tree, True)
+        icp.setInputSource(filt[1])
+        icp.setMaximumIterations(20)
+        icp.setMaxCorrespondenceDistance(0.1)
+        icp.setTransformationEpsilon(1e-10)
+        if comm is not None:
+            icp.setCommunicator(comm)
+        icp.align()
+        t2 = time.perf_counter()
+        stage_ms["voxelgrid"].append((t1 - t0) * 1e3)
+        stage_ms["index_build"].append(tree.build_ms())
+        stage_ms["normals"].append(tree.lastKernelMs())
+        stage_ms["icp"].append(float(icp.result.gpu_ms))
+        stage_ms["source_order"].append(icp.sourceOrderMs())
+        info.update(filtered=(int(filt[0].shape[0]), int(filt[1].shape[0])), iterations=icp.nr_iterations_,
+                    T=icp.getFinalTransformation(), wall_rest_ms=(t2 - t1) * 1e3)
+
+    for _ in range(args.warmup):
+        step()
+    for v in stage_ms.values():
+        v.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    from pcl_amd import synth
+    vg_ms = float(np.mean(stage_ms["voxelgrid"]))
+    achieved = B_ALG_VOXEL * 2 * n / (vg_ms * 1e-3) / 1e9
+    return {
+        "metric": "VoxelGrid(0.01) + NormalEstimation + point-to-plane ICP pipeline, input points/sec",
+        "value": round(2.0 * n * args.steps * world / elapsed, 1), "unit": "input points/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 / f64 accumulate",
+        "data": "synthetic",
+        "config": {"workload": "config 4: two %d-point clouds -> VoxelGrid(0.01) -> %d / %d points -> k=%d normals -> "
+                               "point-to-plane ICP (%d iterations), everything on the device" %
+                               (n, info["filtered"][0], info["filtered"][1], args.knn, info["iterations"]),
+                   "points_per_gpu": n, "parallelism": "replicas x%d" % world},
+        "roofline": {"bound": "hbm", "kernel": "vg_* (VoxelGrid of both clouds, wall time of the two filter() calls)",
+                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_input_point": B_ALG_VOXEL},
+        "cpu_baseline": None if args.no_cpu_baseline or world > 1 else cpu_pipeline(args, tgt, src),
+        "stages_ms": {k: round(float(np.mean(v)), 3) for k, v in stage_ms.items()},
+        "result": {"T_minus_T_gt_frobenius": float(np.linalg.norm(info["T"] - synth.ground_truth_transform()))},
+        "setup": {"synth_gen_s": round(gen_s, 1), "commit": git_head()},
+    }
+
+
+def cpu_pipeline(args, tgt, src):
+    """config 4 on the host cores: the oracle's VoxelGrid (single thread, as in PCL) + kd-tree + normals + ICP."""
+    from oracle import pcl_oracle as orc
+    cores = orc.default_threads()
+    tgt_h, src_h = tgt.cpu().numpy(), src.cpu().numpy()
+    t0 = time.perf_counter()
+    ft = orc.voxelgrid(tgt_h, 0.01)[0]
+    fs = orc.voxelgrid(src_h, 0.01)[0]
+    t1 = time.perf_counter()
+    tree = orc.KdTree(ft)
+    nrm, _ = tree.normals(ft, args.knn, viewpoint=(0, 0, 10), nthreads=cores)
+    r = orc.icp_align(tree, ft, fs, mode=1, tgt_normals=nrm, max_iterations=20, nthreads=cores,
+                      max_correspondence_distance=0.1, transformation_epsilon=1e-10)
+    t2 = time.perf_counter()
+    return {"value": round(2.0 * len(tgt_h) / (t2 - t0), 1), "unit": "input points/s", "cores": cores, "kind": "port",
+            "sample": "the same two %d-point clouds, whole pipeline once: VoxelGrid %.2f s (1 thread, as in PCL), "
+                      "kd-tree + k=%d normals + %d ICP iterations %.2f s (search on %d threads)" %
+                      (len(tgt_h), t1 - t0, args.knn, r["iterations"], t2 - t1, cores)}
+
+
+def cpu_baseline(args, mode, n, tgt, src):
+    """The oracle (restated PCL KdTree + ICP, OpenMP over source points as in correspondence_estimation.hpp
+    :163-191, estimation serial as in PCL) on the SAME clouds as the GPU line, timed on this box's host cores:
+    T = all cores for 3 iterations, and T = 1 for one iteration on a bounded slice of the source (the
+    per-query cost is what matters; the full cloud single-threaded would take ~15 s per iteration)."""
+    from oracle import pcl_oracle as orc
+    cores = orc.default_threads()
+    t0 = time.perf_counter()
+    tree = orc.KdTree(tgt)
+    build_s = time.perf_counter() - t0
+    nrm = None
+    normals_s = None
+    if mode == 1:
+        t0 = time.perf_counter()
+        nrm, _ = tree.normals(tgt, args.knn, viewpoint=(0, 0, 10), nthreads=cores)
+        normals_s = time.perf_counter() - t0
+    kw = dict(mode=mode, tgt_normals=nrm, max_correspondence_distance=0.1, transformation_epsilon=0.0)
+    r = orc.icp_align(tree, tgt, src, max_iterations=3, nthreads=cores, **kw)
+    it = max(r["iterations"], 1)
+    per_iter = r["seconds_total"] / it
+    m1 = min(n, 1_000_000)
+    r1 = orc.icp_align(tree, tgt, src[:m1], max_iterations=1, nthreads=1, **kw)
+    per_iter1 = r1["seconds_total"] / max(r1["iterations"], 1)
+    return {"value": round(r["num_correspondences"] / per_iter, 1), "unit": "correspondences/s", "cores": cores,
+            "kind": "port",
+            "sample": "the bench's own %d-point target and %d-point source, %d ICP iterations on %d threads "
+                      "(search %.3f s + serial estimate/transform %.3f s per iteration); 1 thread: one iteration over "
+                      "the first %d source points against the full target; kd-tree build %.2f s single-thread (as in "
+                      "FLANN)%s" %
+                      (n, n, it, cores, r["seconds_search"] / it, (r["seconds_total"] - r["seconds_search"]) / it, m1,
+                       build_s, "" if normals_s is None else ", k=%d normals %.2f s on %d threads" % (args.knn, normals_s, cores)),
+            "ms_per_iteration": round(per_iter * 1e3, 2),
+            "search_ms_per_iteration": round(r["seconds_search"] / it * 1e3, 2),
+            "serial_ms_per_iteration": round((r["seconds_total"] - r["seconds_search"]) / it * 1e3, 2),
+            "single_thread": {"value": round(r1["num_correspondences"] / per_iter1, 1), "unit": "correspondences/s",
+                              "cores": 1, "us_per_query": round(r1["seconds_search"] / m1 * 1e6, 3),
+                              "sample_points": m1}}
+
+
+def finish(out, rank, world):
+    import torch.distributed as dist
+    if rank == 0 and out is not None:
         # RCCL (NCCL_DEBUG=VERSION on this image) writes its banner through C stdio, which would otherwise be
         # flushed after this line at exit: push it out first so the JSON line is the last thing on stdout
         try:
@@ -204,37 +380,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def cpu_baseline(args, mode):
-    """The oracle (restated PCL KdTree+ICP, OpenMP over source points as in correspondence_estimation.hpp
-    :163-191) on a bounded sample of the same workload, timed on this box's host cores."""
-    from oracle import pcl_oracle as orc
-    from pcl_amd import synth
-    m = min(args.cpu_sample, args.points)
-    tgt = synth.gaussian_surface(m, synth.TARGET_SEED)
-    src = synth.apply_rigid(np.linalg.inv(synth.ground_truth_transform()), synth.gaussian_surface(m, synth.SOURCE_SEED))
-    cores = orc.default_threads()
-    t0 = time.perf_counter()
-    tree = orc.KdTree(tgt)
-    build_s = time.perf_counter() - t0
-    nrm = None
-    normals_s = None
-    if mode == 1:
-        t0 = time.perf_counter()
-        nrm, _ = tree.normals(tgt, args.knn, viewpoint=(0, 0, 10), nthreads=cores)
-        normals_s = time.perf_counter() - t0
-    iters = 3
-    r = orc.icp_align(tree, tgt, src, mode=mode, tgt_normals=nrm, max_iterations=iters, nthreads=cores,
-                      max_correspondence_distance=0.1, transformation_epsilon=0.0)
-    per_iter = r["seconds_total"] / max(r["iterations"], 1)
-    return {"value": round(r["num_correspondences"] / per_iter, 1), "unit": "correspondences/s", "cores": cores,
-            "kind": "port",
-            "sample": "%d-point target + %d-point source of the same surface, %d ICP iterations (search OpenMP over "
-                      "%d threads, estimation serial as in PCL); kd-tree build %.2f s single-thread%s" %
-                      (m, m, r["iterations"], cores, build_s,
-                       "" if normals_s is None else ", k=%d normals %.2f s" % (args.knn, normals_s)),
-            "ms_per_iteration": round(per_iter * 1e3, 2)}
 
 
 if __name__ == "__main__":

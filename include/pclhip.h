@@ -242,6 +242,9 @@ PCLHIP_API pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[
 /* GPU time (ms, HIP events on the context stream) of the search + accumulate kernels of the
  * last pclhip_icp_iterate call. */
 PCLHIP_API double pclhip_icp_last_kernel_ms(const pclhip_icp* icp);
+/* GPU time (ms) the last pclhip_icp_set_source spent ordering the source spatially (the same ordering the
+ * index build applies to the target; paid once per source cloud, not per iteration). */
+PCLHIP_API double pclhip_icp_source_order_ms(const pclhip_icp* icp);
 /* Duration (ms) of the search kernel alone in the last pclhip_icp_iterate (the default iteration is
  * two kernels: search, then the streaming accumulation of the 6x6 / umeyama sums). */
 PCLHIP_API double pclhip_icp_last_search_ms(const pclhip_icp* icp);
@@ -258,6 +261,47 @@ PCLHIP_API pclhip_status pclhip_solve_transformation(const double sums[PCLHIP_IC
  * guess: row-major 4x4 or NULL. */
 PCLHIP_API pclhip_status pclhip_icp_align(pclhip_icp* icp, const pclhip_icp_params* params,
                                           const float guess[16], pclhip_icp_result* result);
+
+/* The same loop as a stream of exactly n_steps iterations for measurements and for back-to-back registration
+ * of the same clouds: Registration::align() called again and again -- when an alignment ends (converged or
+ * not) the next step starts the next one from the input cloud and `guess`, on the device, without host
+ * involvement.  All steps are queued on the context's stream before the first result is read; the solve,
+ * final = T * final and the convergence test of every iteration run in a device kernel.  out_steps[i]
+ * describes step i.  No rejectors / reciprocal correspondences (they need host decisions). */
+typedef struct {
+  int iteration;              /* nr_iterations_ of the running alignment after this step (0: no correspondences) */
+  int convergence_state;      /* DefaultConvergenceCriteria state after this step */
+  int converged;              /* the alignment ended here with converged_ = true */
+  int alignment_ended;        /* this step was the last of its alignment */
+  uint64_t num_correspondences;
+  double mse;
+  float search_ms;            /* HIP events on the context's stream: the search kernel ... */
+  float kernels_ms;           /* ... search + accumulation ... */
+  float step_ms;              /* ... the whole step incl. reduction, (all-reduce,) solve */
+  float final_transformation[16];
+} pclhip_icp_step;
+PCLHIP_API pclhip_status pclhip_icp_run_steps(pclhip_icp* icp, const pclhip_icp_params* params,
+                                              const float guess[16], int n_steps, pclhip_icp_step* out_steps);
+
+/* ---- multi-GPU: one process per GPU, the 32-double record summed over the ranks per iteration --------
+ * PCL has no multi-GPU path (gpu/containers/src/initialization.cpp:109 picks one device); the contract is
+ * SURVEY.md 8(e).  A communicator wraps an RCCL (ncclComm_t) group over xGMI: rank 0 obtains an id, the
+ * application distributes its 128 bytes to the other ranks by whatever means it has (MPI, a file, a socket,
+ * torch.distributed's store), every rank calls pclhip_comm_create.  With a communicator attached the
+ * all-reduce is issued from C on the context's stream between the reduction and the solve kernel of every
+ * iteration; RCCL is bound with dlopen at first use (no link-time dependency). */
+#define PCLHIP_COMM_ID_BYTES 128
+typedef struct pclhip_comm pclhip_comm;
+PCLHIP_API pclhip_status pclhip_comm_get_unique_id(unsigned char id[PCLHIP_COMM_ID_BYTES]);
+PCLHIP_API pclhip_status pclhip_comm_create(pclhip_ctx* ctx, int rank, int nranks,
+                                            const unsigned char id[PCLHIP_COMM_ID_BYTES], pclhip_comm** out);
+PCLHIP_API void pclhip_comm_destroy(pclhip_comm* comm);
+PCLHIP_API int pclhip_comm_rank(const pclhip_comm* comm);
+PCLHIP_API int pclhip_comm_size(const pclhip_comm* comm);
+/* in-place sum of `count` doubles in device memory over the ranks, on the context's stream (asynchronous) */
+PCLHIP_API pclhip_status pclhip_comm_allreduce_sum_f64(pclhip_comm* comm, double* device_buf, int count);
+/* attach (or detach with NULL) a communicator; replaces the pclhip_icp_set_allreduce hook when both are set */
+PCLHIP_API pclhip_status pclhip_icp_set_comm(pclhip_icp* icp, pclhip_comm* comm);
 
 /* Registration::getFitnessScore(max_range) (registration/include/pcl/registration/impl/registration.hpp:132-168):
  * the source is transformed by T (row-major 4x4, Transformer::se3 operation order like

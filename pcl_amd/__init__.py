@@ -4,7 +4,7 @@ behind the C ABI of include/pclhip.h; this package is the ctypes host mirror use
 bench.py.  The C++ mirror of the same surface is include/pclhip/pcl_compat.hpp."""
 from . import synth  # noqa: F401
 from ._lib import (POINT_TO_PLANE, POINT_TO_POINT, SYMMETRIC, PclHipError, PclHipUnavailable)  # noqa: F401
-from .api import (Context, CorrespondenceEstimation, CorrespondenceRejectorDistance,  # noqa: F401
+from .api import (Communicator, Context, CorrespondenceEstimation, CorrespondenceRejectorDistance,  # noqa: F401
                   CorrespondenceRejectorMedianDistance, CorrespondenceRejectorOneToOne,
                   CorrespondenceRejectorTrimmed, IterativeClosestPoint,
                   IterativeClosestPointWithNormals, KdTree, NormalEstimation, VoxelGrid,

@@ -46,6 +46,16 @@ class IcpResult(C.Structure):
                 ("gpu_ms_search_kernel", C.c_double)]
 
 
+class IcpStep(C.Structure):
+    _fields_ = [("iteration", C.c_int), ("convergence_state", C.c_int), ("converged", C.c_int),
+                ("alignment_ended", C.c_int), ("num_correspondences", C.c_uint64), ("mse", C.c_double),
+                ("search_ms", C.c_float), ("kernels_ms", C.c_float), ("step_ms", C.c_float),
+                ("final_transformation", C.c_float * 16)]
+
+
+COMM_ID_BYTES = 128
+
+
 class Rejector(C.Structure):
     _fields_ = [("kind", C.c_int), ("param", C.c_double), ("min_correspondences", C.c_uint32),
                 ("reserved", C.c_uint32)]
@@ -102,11 +112,20 @@ SIGNATURES = {
                                      C.POINTER(C.c_double)]),
     "pclhip_icp_last_kernel_ms": (C.c_double, [_vp]),
     "pclhip_icp_last_search_ms": (C.c_double, [_vp]),
+    "pclhip_icp_source_order_ms": (C.c_double, [_vp]),
     "pclhip_index_last_kernel_ms": (C.c_double, [_vp]),
     "pclhip_solve_transformation": (C.c_int, [C.POINTER(C.c_double), C.c_int,
                                               C.POINTER(C.c_float)]),
     "pclhip_icp_align": (C.c_int, [_vp, C.POINTER(IcpParams), C.POINTER(C.c_float),
                                    C.POINTER(IcpResult)]),
+    "pclhip_icp_run_steps": (C.c_int, [_vp, C.POINTER(IcpParams), C.POINTER(C.c_float), C.c_int, C.POINTER(IcpStep)]),
+    "pclhip_comm_get_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
+    "pclhip_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(_vp)]),
+    "pclhip_comm_destroy": (None, [_vp]),
+    "pclhip_comm_rank": (C.c_int, [_vp]),
+    "pclhip_comm_size": (C.c_int, [_vp]),
+    "pclhip_comm_allreduce_sum_f64": (C.c_int, [_vp, _vp, C.c_int]),
+    "pclhip_icp_set_comm": (C.c_int, [_vp, _vp]),
     "pclhip_icp_fitness_score": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_double, C.POINTER(C.c_double),
                                            C.POINTER(_u64)]),
     "pclhip_icp_fetch_correspondences": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_u64)]),

@@ -91,6 +91,44 @@ class Context:
             pass
 
 
+class Communicator:
+    """pclhip_comm: an RCCL group (one rank per GPU/process) for the per-iteration all-reduce of the record.
+    `unique_id()` on rank 0, distribute the 128 bytes (e.g. torch.distributed.broadcast_object_list over gloo,
+    MPI, a file), then Communicator(ctx, rank, nranks, id) on every rank."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+        check(_lib.load().pclhip_comm_get_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, ctx, rank, nranks, uid):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        assert len(uid) == _lib.COMM_ID_BYTES
+        buf = (C.c_ubyte * _lib.COMM_ID_BYTES).from_buffer_copy(uid)
+        h = C.c_void_p()
+        check(self.lib.pclhip_comm_create(ctx.h, int(rank), int(nranks), buf, C.byref(h)), ctx.h)
+        self.h = h
+        self.rank, self.size = int(rank), int(nranks)
+        ctx._adopt(self)
+
+    def allreduce_sum_f64(self, device_ptr, count):
+        check(self.lib.pclhip_comm_allreduce_sum_f64(self.h, C.c_void_p(int(device_ptr)), int(count)), self.ctx.h)
+
+    def _release(self):
+        if getattr(self, "h", None):
+            if self.ctx.h is not None:
+                self.lib.pclhip_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+
 _default_ctx = None
 
 
@@ -477,6 +515,32 @@ class IterativeClosestPoint:
         if self.h:
             check(self.lib.pclhip_icp_set_allreduce(self.h, self._allreduce, None), self.ctx.h)
 
+    def setCommunicator(self, comm):
+        """Multi-GPU: sum the per-iteration record over the ranks of `comm` (a Communicator: RCCL over xGMI,
+        issued from C on the context's stream).  None detaches."""
+        self._comm = comm
+        if self.h:
+            check(self.lib.pclhip_icp_set_comm(self.h, comm.h if comm is not None else None), self.ctx.h)
+
+    def runSteps(self, n_steps, guess=None):
+        """pclhip_icp_run_steps: exactly n_steps iterations queued back to back on the device, alignments
+        restarting on convergence.  Returns the list of per-step dicts."""
+        self._ensure()
+        arr = (_lib.IcpStep * max(int(n_steps), 1))()
+        g = None if guess is None else np.ascontiguousarray(guess, np.float32).reshape(16)
+        check(self.lib.pclhip_icp_run_steps(self.h, C.byref(self.p), _fp(g) if g is not None else None, int(n_steps),
+                                            arr), self.ctx.h)
+        out = []
+        for i in range(int(n_steps)):
+            s = arr[i]
+            out.append({"iteration": s.iteration, "state": _lib.CONVERGENCE_STATES[s.convergence_state],
+                        "converged": bool(s.converged), "alignment_ended": bool(s.alignment_ended),
+                        "num_correspondences": int(s.num_correspondences), "mse": float(s.mse),
+                        "search_ms": float(s.search_ms), "kernels_ms": float(s.kernels_ms),
+                        "step_ms": float(s.step_ms),
+                        "final_transformation": np.array(s.final_transformation, np.float32).reshape(4, 4)})
+        return out
+
     def _drop_icp(self):
         if getattr(self, "h", None):
             if self.ctx.h is not None:
@@ -509,6 +573,8 @@ class IterativeClosestPoint:
             self.h = h
             if self._allreduce is not None:
                 check(self.lib.pclhip_icp_set_allreduce(self.h, self._allreduce, None), self.ctx.h)
+            if getattr(self, "_comm", None) is not None:
+                check(self.lib.pclhip_icp_set_comm(self.h, self._comm.h), self.ctx.h)
         if self._src_dirty:
             ptr, stride, n, keep = _cloud(self.src)
             check(self.lib.pclhip_icp_set_source(self.h, ptr, stride, n), self.ctx.h)
@@ -544,6 +610,11 @@ class IterativeClosestPoint:
     def lastKernelMs(self):
         """search + (filters) + accumulate kernels of the last iterate(), HIP events"""
         return float(self.lib.pclhip_icp_last_kernel_ms(self.h))
+
+    def sourceOrderMs(self):
+        """GPU time the last source upload spent on the spatial ordering (once per source cloud)"""
+        self._ensure()
+        return float(self.lib.pclhip_icp_source_order_ms(self.h))
 
     def lastSearchMs(self):
         """the search kernel alone"""

@@ -4,6 +4,7 @@
 #include <cfloat>
 #include <cmath>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -588,6 +589,11 @@ void pclhip_icp_destroy(pclhip_icp* icp) {
   icp_free_source(icp);
   if (icp->sums_dev) (void)hipFree(icp->sums_dev);
   if (icp->sums_host) (void)hipHostFree(icp->sums_host);
+  if (icp->ctl) (void)hipFree(icp->ctl);
+  if (icp->ctl_host) (void)hipHostFree(icp->ctl_host);
+  if (icp->steps) (void)hipHostFree(icp->steps);
+  for (hipEvent_t e : icp->step_events)
+    if (e) (void)hipEventDestroy(e);
   if (icp->ev0) (void)hipEventDestroy(icp->ev0);
   if (icp->ev1) (void)hipEventDestroy(icp->ev1);
   if (icp->ev_mid) (void)hipEventDestroy(icp->ev_mid);
@@ -621,9 +627,18 @@ pclhip_status pclhip_icp_set_source(pclhip_icp* icp, const void* points, size_t 
   PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->partials, size_t(icp->grid_blocks) * PCLHIP_ICP_NSUMS * sizeof(double)));
   uint32_t nf = 0;
   float lo[3], hi[3];
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  DeviceScope timing;
+  PCLHIP_CHECK_HIP(ctx, timing.event(&e0));
+  PCLHIP_CHECK_HIP(ctx, timing.event(&e1));
+  (void)hipEventRecord(e0, ctx->stream);
   st = spatial_order(ctx, dp, stride, n, nullptr, 0, icp->src_sorted0, uint32_t(n), &nf, lo, hi, true, nullptr);
   if (st != PCLHIP_OK) return st;
-  return pclhip_icp_reset(icp);
+  (void)hipEventRecord(e1, ctx->stream);
+  st = pclhip_icp_reset(icp);
+  float ms = 0;
+  if (st == PCLHIP_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) icp->source_order_ms = ms;
+  return st;
 }
 
 pclhip_status pclhip_icp_set_source_normals(pclhip_icp* icp, const void* normals, size_t stride) {
@@ -714,7 +729,7 @@ pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[16], double
     return PCLHIP_ERR_STATE;
   }
   PCLHIP_REQUIRE(ctx, icp->src_cur != nullptr, "no source cloud set");
-  if (icp->allreduce) {
+  if (icp_is_sharded(icp)) {
     // With the source sharded over ranks, MedianDistance / Trimmed thresholds, OneToOne conflicts and the
     // reciprocal test would be evaluated per slab, which is not what a single-GPU (or the reference's) run
     // computes.  Only per-pair filters (Distance) commute with the sharding.
@@ -731,15 +746,8 @@ pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[16], double
   const double md2 = max_dist * max_dist;
   const bool use_max = md2 < double(FLT_MAX);
   const float fmax2 = use_max ? float_at_most(md2) : FLT_MAX;
-  pclhip_status st = launch_icp_iterate(icp, T_prev, fmax2, use_max, mode);
+  pclhip_status st = launch_icp_iterate(icp, T_prev, fmax2, use_max, mode);  // incl. the all-reduce of the record
   if (st != PCLHIP_OK) return st;
-  if (icp->allreduce) {
-    const int rc = icp->allreduce(icp->allreduce_user, icp->sums_dev, PCLHIP_ICP_NSUMS, ctx->stream);
-    if (rc != 0) {
-      set_error(ctx, "all-reduce hook failed");
-      return PCLHIP_ERR_STATE;
-    }
-  }
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(icp->sums_host, icp->sums_dev, PCLHIP_ICP_NSUMS * sizeof(double),
                                        hipMemcpyDeviceToHost, ctx->stream));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -753,6 +761,7 @@ pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[16], double
 }
 
 double pclhip_icp_last_kernel_ms(const pclhip_icp* icp) { return icp ? icp->last_kernel_ms : 0.0; }
+double pclhip_icp_source_order_ms(const pclhip_icp* icp) { return icp ? icp->source_order_ms : 0.0; }
 double pclhip_icp_last_search_ms(const pclhip_icp* icp) { return icp ? icp->last_search_ms : 0.0; }
 double pclhip_index_last_kernel_ms(const pclhip_index* ix) { return ix ? ix->last_kernel_ms : 0.0; }
 
@@ -777,6 +786,31 @@ pclhip_status pclhip_icp_align(pclhip_icp* icp, const pclhip_icp_params* params,
   pclhip_ctx* ctx = icp->ctx;
   static const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   std::memset(res, 0, sizeof *res);
+  // The plain loop runs on the device (icp_loop.hip): no read-back, host solve or reset copy between
+  // iterations.  Rejectors and reciprocal correspondences need host decisions per iteration and use the
+  // host-driven loop below (also selectable with PCLHIP_ICP_HOST_LOOP=1 for A/B and for the twin test).
+  static const bool host_loop = [] {
+    const char* e = getenv("PCLHIP_ICP_HOST_LOOP");
+    return e && atoi(e) == 1;
+  }();
+  if (!host_loop && !icp->reciprocal && icp->rejectors.empty()) {
+    if (params->mode != PCLHIP_ICP_POINT_TO_POINT && params->mode != PCLHIP_ICP_POINT_TO_PLANE &&
+        params->mode != PCLHIP_ICP_SYMMETRIC) {
+      set_error(ctx, "unknown ICP mode");
+      return PCLHIP_ERR_INVALID;
+    }
+    if (params->mode == PCLHIP_ICP_SYMMETRIC && icp->src_nrm_cur == nullptr) {
+      set_error(ctx, "the symmetric objective needs source normals (pclhip_icp_set_source_normals)");
+      return PCLHIP_ERR_STATE;
+    }
+    if (params->mode != PCLHIP_ICP_POINT_TO_POINT && !icp->target->has_normals) {
+      set_error(ctx, "point-to-plane ICP needs target normals (pclhip_normals / pclhip_index_set_normals)");
+      return PCLHIP_ERR_STATE;
+    }
+    PCLHIP_REQUIRE(ctx, icp->src_cur != nullptr, "no source cloud set");
+    PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    return icp_align_device(icp, params, guess, res);
+  }
   pclhip_status st = pclhip_icp_reset(icp);
   if (st != PCLHIP_OK) return st;
   hipEvent_t t0, t1;

@@ -1,254 +1,13 @@
-// host_math.cpp -- host-side closed forms of the ICP loop (tiny, latency-bound, fp64):
-//   * 6x6 normal-system solve + constructTransformationMatrix
-//     (registration/include/pcl/registration/impl/transformation_estimation_point_to_plane_lls.hpp:132-163,247-268)
-//   * umeyama from raw sums (common/include/pcl/common/impl/eigen.hpp:675-738)
-//   * float 4x4 product for final_transformation_ (registration/include/pcl/registration/impl/icp.hpp:223)
-#include <cmath>
-#include <cstring>
-#include <utility>
-
+// host_math.cpp -- host instantiation of the closed forms in closed_forms.hpp (the device twin is
+// icp_solve_kernel in icp_loop.hip).  Tiny, latency-bound, fp64.
+#include "closed_forms.hpp"
 #include "pclhip_internal.hpp"
 
 namespace pclhip {
 
-namespace {
-
-// Doolittle LU with partial pivoting on a 6x6, then forward/back substitution.
-bool lu_solve6(double A[6][6], double b[6], double x[6]) {
-  int perm[6];
-  for (int i = 0; i < 6; ++i) perm[i] = i;
-  for (int c = 0; c < 6; ++c) {
-    int p = c;
-    double best = std::fabs(A[c][c]);
-    for (int r = c + 1; r < 6; ++r)
-      if (std::fabs(A[r][c]) > best) {
-        best = std::fabs(A[r][c]);
-        p = r;
-      }
-    if (best == 0.0) return false;
-    if (p != c) {
-      for (int j = 0; j < 6; ++j) std::swap(A[c][j], A[p][j]);
-      std::swap(b[c], b[p]);
-      std::swap(perm[c], perm[p]);
-    }
-    for (int r = c + 1; r < 6; ++r) {
-      const double f = A[r][c] / A[c][c];
-      A[r][c] = f;
-      for (int j = c + 1; j < 6; ++j) A[r][j] -= f * A[c][j];
-      b[r] -= f * b[c];
-    }
-  }
-  for (int i = 5; i >= 0; --i) {
-    double s = b[i];
-    for (int j = i + 1; j < 6; ++j) s -= A[i][j] * x[j];
-    x[i] = s / A[i][i];
-  }
-  return true;
-}
-
-// cyclic Jacobi eigen-decomposition of a symmetric 3x3: A = V diag(w) V^T
-void jacobi_eig3(double A[3][3], double V[3][3], double w[3]) {
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 64; ++sweep) {
-    const double off = std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]);
-    if (off < 1e-300) break;
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        if (A[p][q] == 0.0) continue;
-        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 3; ++k) {  // A <- A * J
-          const double akp = A[k][p], akq = A[k][q];
-          A[k][p] = c * akp - s * akq;
-          A[k][q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < 3; ++k) {  // A <- J^T * A
-          const double apk = A[p][k], aqk = A[q][k];
-          A[p][k] = c * apk - s * aqk;
-          A[q][k] = s * apk + c * aqk;
-        }
-        for (int k = 0; k < 3; ++k) {
-          const double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - s * vkq;
-          V[k][q] = s * vkp + c * vkq;
-        }
-      }
-  }
-  for (int i = 0; i < 3; ++i) w[i] = A[i][i];
-}
-
-double det3(const double M[3][3]) {
-  return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
-         M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
-}
-
-void cross(const double a[3], const double b[3], double c[3]) {
-  c[0] = a[1] * b[2] - a[2] * b[1];
-  c[1] = a[2] * b[0] - a[0] * b[2];
-  c[2] = a[0] * b[1] - a[1] * b[0];
-}
-
-// R = U S V^T of sigma via the eigen-decomposition of sigma^T sigma (V, singular values) and
-// U = sigma V / s, with the umeyama reflection fix on the smallest singular direction.
-void rotation_from_sigma(const double sigma[3][3], double R[3][3]) {
-  double AtA[3][3];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      double s = 0;
-      for (int k = 0; k < 3; ++k) s += sigma[k][i] * sigma[k][j];
-      AtA[i][j] = s;
-    }
-  double V[3][3], w[3];
-  jacobi_eig3(AtA, V, w);
-  int ord[3] = {0, 1, 2};  // descending eigenvalues
-  for (int i = 0; i < 2; ++i)
-    for (int j = i + 1; j < 3; ++j)
-      if (w[ord[j]] > w[ord[i]]) std::swap(ord[i], ord[j]);
-  double Vs[3][3], sv[3];
-  for (int c = 0; c < 3; ++c) {
-    sv[c] = std::sqrt(w[ord[c]] > 0 ? w[ord[c]] : 0.0);
-    for (int r = 0; r < 3; ++r) Vs[r][c] = V[r][ord[c]];
-  }
-  if (det3(Vs) < 0)  // keep V a proper rotation; the sign moves into U, U S V^T is unchanged
-    for (int r = 0; r < 3; ++r) Vs[r][2] = -Vs[r][2];
-  double U[3][3];
-  const double tol = 1e-13 * (sv[0] > 0 ? sv[0] : 1.0);
-  for (int c = 0; c < 3; ++c) {
-    double u[3];
-    for (int r = 0; r < 3; ++r) u[r] = sigma[r][0] * Vs[0][c] + sigma[r][1] * Vs[1][c] + sigma[r][2] * Vs[2][c];
-    const double n = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-    for (int r = 0; r < 3; ++r) U[r][c] = (sv[c] > tol && n > 0) ? u[r] / n : 0.0;
-  }
-  // complete rank-deficient cases with cross products (right-handed completion)
-  auto col = [&](int c, double o[3]) { o[0] = U[0][c]; o[1] = U[1][c]; o[2] = U[2][c]; };
-  auto setcol = [&](int c, const double o[3]) { U[0][c] = o[0]; U[1][c] = o[1]; U[2][c] = o[2]; };
-  if (!(sv[0] > tol)) {
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) U[i][j] = (i == j) ? 1.0 : 0.0;
-  } else {
-    double u0[3], u1[3], u2[3];
-    col(0, u0);
-    if (!(sv[1] > tol)) {
-      int mi = 0;
-      for (int d = 1; d < 3; ++d)
-        if (std::fabs(u0[d]) < std::fabs(u0[mi])) mi = d;
-      double e[3] = {0, 0, 0};
-      e[mi] = 1.0;
-      cross(u0, e, u1);
-      const double n = std::sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
-      for (int d = 0; d < 3; ++d) u1[d] /= n;
-      setcol(1, u1);
-    }
-    col(1, u1);
-    if (!(sv[2] > tol)) {
-      cross(u0, u1, u2);
-      setcol(2, u2);
-    }
-  }
-  // eigen.hpp:716-724: S = diag(1,1,-1) if det(U) det(V) < 0
-  const double sgn = (det3(U) * det3(Vs) < 0) ? -1.0 : 1.0;
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) R[i][j] = U[i][0] * Vs[j][0] + U[i][1] * Vs[j][1] + sgn * U[i][2] * Vs[j][2];
-}
-
-}  // namespace
-
-void solve_point_to_plane(const double* s, float* T) {
-  double A[6][6], b[6], x[6] = {0, 0, 0, 0, 0, 0};
-  int k = 0;
-  for (int i = 0; i < 6; ++i)
-    for (int j = i; j < 6; ++j) {
-      A[i][j] = s[k];
-      A[j][i] = s[k];
-      ++k;
-    }
-  for (int i = 0; i < 6; ++i) b[i] = s[21 + i];
-  if (!lu_solve6(A, b, x))
-    for (int i = 0; i < 6; ++i) x[i] = std::nan("");  // singular system: Eigen's inverse() yields non-finite too
-  const double al = x[0], be = x[1], ga = x[2];
-  std::memset(T, 0, 16 * sizeof(float));
-  T[0] = float(std::cos(ga) * std::cos(be));
-  T[1] = float(-std::sin(ga) * std::cos(al) + std::cos(ga) * std::sin(be) * std::sin(al));
-  T[2] = float(std::sin(ga) * std::sin(al) + std::cos(ga) * std::sin(be) * std::cos(al));
-  T[4] = float(std::sin(ga) * std::cos(be));
-  T[5] = float(std::cos(ga) * std::cos(al) + std::sin(ga) * std::sin(be) * std::sin(al));
-  T[6] = float(-std::cos(ga) * std::sin(al) + std::sin(ga) * std::sin(be) * std::cos(al));
-  T[8] = float(-std::sin(be));
-  T[9] = float(std::cos(be) * std::sin(al));
-  T[10] = float(std::cos(be) * std::cos(al));
-  T[3] = float(x[3]);
-  T[7] = float(x[4]);
-  T[11] = float(x[5]);
-  T[15] = 1.0f;
-}
-
-// TransformationEstimationSymmetricPointToPlaneLLS: solve + constructTransformationMatrix
-// (impl/transformation_estimation_symmetric_point_to_plane_lls.hpp:128-147,192-196):
-// T = Rz Ry Rx * Translation(t) * Rz Ry Rx = [R R | R t] with R = Rz(x2) Ry(x1) Rx(x0).
-void solve_symmetric(const double* s, float* T) {
-  double A[6][6], b[6], x[6] = {0, 0, 0, 0, 0, 0};
-  int k = 0;
-  for (int i = 0; i < 6; ++i)
-    for (int j = i; j < 6; ++j) {
-      A[i][j] = s[k];
-      A[j][i] = s[k];
-      ++k;
-    }
-  for (int i = 0; i < 6; ++i) b[i] = s[21 + i];
-  if (!lu_solve6(A, b, x))
-    for (int i = 0; i < 6; ++i) x[i] = std::nan("");
-  const double ca = std::cos(x[0]), sa = std::sin(x[0]), cb = std::cos(x[1]), sb = std::sin(x[1]), cg = std::cos(x[2]),
-               sg = std::sin(x[2]);
-  const double R[3][3] = {{cg * cb, -sg * ca + cg * sb * sa, sg * sa + cg * sb * ca},
-                          {sg * cb, cg * ca + sg * sb * sa, -cg * sa + sg * sb * ca},
-                          {-sb, cb * sa, cb * ca}};
-  std::memset(T, 0, 16 * sizeof(float));
-  for (int i = 0; i < 3; ++i) {
-    for (int j = 0; j < 3; ++j) {
-      double v = 0.0;
-      for (int m = 0; m < 3; ++m) v += R[i][m] * R[m][j];
-      T[4 * i + j] = float(v);
-    }
-    T[4 * i + 3] = float(R[i][0] * x[3] + R[i][1] * x[4] + R[i][2] * x[5]);
-  }
-  T[15] = 1.0f;
-}
-
-void solve_point_to_point(const double* s, float* T) {
-  const double n = s[28];
-  double sm[3], dm[3], sigma[3][3], R[3][3];
-  for (int d = 0; d < 3; ++d) {
-    sm[d] = s[d] / n;
-    dm[d] = s[3 + d] / n;
-  }
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) sigma[i][j] = s[6 + 3 * i + j] / n - dm[i] * sm[j];
-  rotation_from_sigma(sigma, R);
-  std::memset(T, 0, 16 * sizeof(float));
-  for (int i = 0; i < 3; ++i) {
-    for (int j = 0; j < 3; ++j) T[4 * i + j] = float(R[i][j]);
-    T[4 * i + 3] = float(dm[i] - (R[i][0] * sm[0] + R[i][1] * sm[1] + R[i][2] * sm[2]));
-  }
-  T[15] = 1.0f;
-}
-
-void mat4_mul_f32(const float* A, const float* B, float* C) {
-  float R[16];
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) {
-      // Eigen coefficient-based product order ((a0*b0 + a1*b1) + a2*b2) + a3*b3, no contraction
-      volatile float t0 = A[4 * i + 0] * B[0 * 4 + j];
-      volatile float t1 = A[4 * i + 1] * B[1 * 4 + j];
-      volatile float t2 = A[4 * i + 2] * B[2 * 4 + j];
-      volatile float t3 = A[4 * i + 3] * B[3 * 4 + j];
-      volatile float r = t0 + t1;
-      r = r + t2;
-      r = r + t3;
-      R[4 * i + j] = r;
-    }
-  std::memcpy(C, R, sizeof R);
-}
+void solve_point_to_plane(const double* s, float* T) { cf::solve_point_to_plane(s, T); }
+void solve_symmetric(const double* s, float* T) { cf::solve_symmetric(s, T); }
+void solve_point_to_point(const double* s, float* T) { cf::solve_point_to_point(s, T); }
+void mat4_mul_f32(const float* A, const float* B, float* C) { cf::mat4_mul_f32(A, B, C); }
 
 }  // namespace pclhip

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/pclhip.h"
+#include "closed_forms.hpp"
 
 namespace pclhip {
 
@@ -60,7 +61,51 @@ struct IndexView {
   uint32_t n_pad;
 };
 
+// Axis-aligned region [lo, hi) of the rank that owns a query (target sharding, dist.hip): a source point
+// takes part in an iteration only while its CURRENT position lies inside.  Unbounded sides are +-inf.
+struct RegionBox {
+  float lo[3], hi[3];
+  int on;
+};
+
+// Device-resident state of the ICP loop (icp_loop.hip): the iteration is closed on the GPU
+// (icp_solve_kernel), so consecutive iterations are queued back to back and the host only observes.
+struct IcpControl {
+  float T_apply[12];   // rows 0..2 of the transform the next search launch applies to the working cloud
+  int restart;         // the next search launch starts an alignment: pristine source, no seeds
+  int stop;            // the alignment is over: launches already queued behind it fall through
+  int mode;            // PCLHIP_ICP_*
+  int auto_restart;    // measurement loop: a finished alignment is followed by the next one, never stop
+  int nr_iterations;   // of the running alignment
+  int step;            // iterations completed since the loop was armed (index of the next step record)
+  int log_capacity;
+  int pad0;
+  float guess[16];
+  float final_T[16];
+  float Tk[16];
+  cf::Criteria crit;
+  cf::CriteriaState st;
+};
+
+// One record per completed iteration, written by icp_solve_kernel into pinned host memory.
+struct IcpStepRecord {
+  int step;               // running index
+  int iteration;          // nr_iterations_ after this iteration (0: it failed for lack of correspondences)
+  int convergence_state;  // DefaultConvergenceCriteria state after hasConverged
+  int converged;          // the alignment ended with converged_ = true
+  int ended;              // the alignment ended with this iteration (either way)
+  int similar;            // iterations_similar_transforms_
+  double num_correspondences;
+  double mse;
+  double prev_mse;        // criteria memory after this iteration
+  float Tk[16];           // transformation_ of this iteration
+  float final_T[16];      // final_transformation_ after it
+  double sums[PCLHIP_ICP_NSUMS];
+};
+
 }  // namespace pclhip
+
+struct pclhip_comm;
 
 struct pclhip_ctx {
   int device = 0;
@@ -127,12 +172,21 @@ struct pclhip_icp {
   bool mid_recorded = false;
   double last_kernel_ms = 0;
   double last_search_ms = 0;  // the search kernel alone (two-kernel variant); = last_kernel_ms when fused
+  double source_order_ms = 0; // GPU time of the spatial ordering in the last pclhip_icp_set_source
   // optional stages between search and accumulation
   std::vector<pclhip_rejector> rejectors;
   bool reciprocal = false;
   uint8_t* keep = nullptr;        // per sorted source slot: correspondence survives the chain
   double last_median = 0;
   int fetch_order = 0;            // 0 by query, 1 by (match, distance), 2 by distance
+  // device-driven loop (icp_loop.hip)
+  pclhip::IcpControl* ctl = nullptr;        // device
+  pclhip::IcpControl* ctl_host = nullptr;   // pinned staging copy used to arm the loop
+  pclhip::IcpStepRecord* steps = nullptr;   // pinned ring written by icp_solve_kernel
+  int steps_capacity = 0;
+  std::vector<hipEvent_t> step_events;      // 4 per ring slot: start, after search, after accumulate, after solve
+  pclhip_comm* comm = nullptr;              // native RCCL all-reduce of the record (dist.hip); not owned
+  pclhip::RegionBox region = {{0, 0, 0}, {0, 0, 0}, 0};  // target sharding: the source points this rank serves
 };
 
 namespace pclhip {
@@ -212,13 +266,20 @@ pclhip_status launch_normals_radius(pclhip_index* ix, double radius, const float
 pclhip_status launch_gicp_covariances(pclhip_index* ix, int k, double eps, double* cov_sorted);
 pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double max_range, double* score,
                                    uint64_t* nr);
+// icp_loop.hip
+pclhip_status icp_align_device(pclhip_icp* icp, const pclhip_icp_params* params, const float* guess,
+                               pclhip_icp_result* res);
+bool icp_is_sharded(const pclhip_icp* icp);
 
 // ---- kernels launched from api.cpp ----------------------------------------------------------
 pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, int k,
                          int32_t* out_idx_sorted, float* out_d2_sorted);
 pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_t* nan_count);
 pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d2, bool use_max,
-                                 int mode);
+                                 int mode, hipEvent_t* step_events = nullptr);
+// sums icp->sums_dev over the ranks on the context's stream (native RCCL communicator or the hook); no-op
+// for a single-GPU registration
+pclhip_status allreduce_record(pclhip_icp* icp);
 // rejectors.hip: reciprocal filter + rejector chain on icp->keep (stream-ordered, may synchronise)
 pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool use_max);
 // kd order of float4 records whose .w already holds the point's id (used for the reciprocal index)

@@ -666,13 +666,31 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_iterate_kernel(IndexView ix, 
 // Two-kernel variant of the iteration (PCLHIP_ICP_FUSED=0): a search-only kernel without the 27 fp64
 // accumulators (fewer registers, room to software-pipeline the next group's loads) followed by a
 // streaming accumulate kernel.  Same results as the fused kernel up to fp64 summation order.
+// With `ctl` (device-driven loop, icp_loop.hip) the transform, the "alignment starts here" flag and the stop
+// flag come from device memory, written by the icp_solve_kernel of the previous iteration: iterations are
+// queued back to back and the host never sits between them.  A starting alignment reads the pristine
+// source `src0` instead of the working copy and has no seeds, so no reset copy is needed either.
+__device__ __forceinline__ bool in_region(const RegionBox& r, float x, float y, float z) {
+  return x >= r.lo[0] && x < r.hi[0] && y >= r.lo[1] && y < r.hi[1] && z >= r.lo[2] && z < r.hi[2];
+}
+
 template <int MINW, int Q, bool SPARSE>
-__global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, float4* __restrict__ cur, uint32_t ns,
-                                                                 Mat34 T, int order, float bound, int flags,
+__global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, float4* __restrict__ cur,
+                                                                 const float4* __restrict__ src0, uint32_t ns,
+                                                                 Mat34 T, const IcpControl* __restrict__ ctl,
+                                                                 RegionBox region, int order, float bound, int flags,
                                                                  uint32_t* __restrict__ match_pos,
                                                                  uint32_t* __restrict__ match,
                                                                  float* __restrict__ match_d2,
                                                                  unsigned long long* gstats) {
+  bool restart = false;
+  if (ctl != nullptr) {
+    if (ctl->stop != 0) return;  // the alignment ended before this (speculatively queued) launch
+    restart = ctl->restart != 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T.m[i] = ctl->T_apply[i];
+  }
+  const float4* in = restart ? src0 : cur;  // may alias cur (written below, other groups only)
   const int use_max = flags & 1;        // a finite max correspondence distance is set
   // no policy of this kernel stages the w chunks: 3 KB of staging per wave (see WaveLdsT)
   __shared__ WaveLdsT<3072> wl_s[WAVES_PER_BLOCK];
@@ -697,8 +715,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
     sp_n[q] = NO_INDEX;
     const uint32_t i = g * GROUP + q * WAVE + lane;
     if (g < ngroups && i < ns) {
-      p_n[q] = cur[i];
-      sp_n[q] = match_pos[i];
+      p_n[q] = in[i];
+      sp_n[q] = restart ? NO_INDEX : match_pos[i];
       if (sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
     }
   }
@@ -725,8 +743,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
       p_n[q] = make_float4(0, 0, 0, 0);
       sp_n[q] = NO_INDEX;
       if (next_ok[q]) {
-        p_n[q] = cur[i2];
-        sp_n[q] = match_pos[i2];
+        p_n[q] = in[i2];
+        sp_n[q] = restart ? NO_INDEX : match_pos[i2];
       }
     }
     NN1MinT<Q> fast;
@@ -740,8 +758,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
         const float z = xform_row(T.m[8], T.m[9], T.m[10], T.m[11], p[q].x, p[q].y, p[q].z, order);
         p[q].x = x; p[q].y = y; p[q].z = z;
         cur[g * GROUP + q * WAVE + lane] = p[q];
-        if (seed_pos[q] != NO_INDEX)
+        // target sharding: every rank moves the whole source, but serves only the points inside its region
+        if (region.on) valid[q] = in_region(region, x, y, z);
+        if (valid[q] && seed_pos[q] != NO_INDEX)
           fast.seed(q, l2_simple(x, y, z, t0[q].x, t0[q].y, t0[q].z), seed_pos[q]);
+      } else if (in_range[q] && restart) {
+        cur[g * GROUP + q * WAVE + lane] = p[q];  // non-finite points travel unchanged (icp.hpp:97-98)
       }
       qx[q] = p[q].x; qy[q] = p[q].y; qz[q] = p[q].z;
     }
@@ -922,9 +944,18 @@ __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, con
                                                                const uint32_t* __restrict__ match_pos,
                                                                const float* __restrict__ match_d2,
                                                                const uint8_t* __restrict__ keep, Mat34 T,
-                                                               float4* __restrict__ src_nrm, int enforce,
+                                                               const IcpControl* __restrict__ ctl,
+                                                               float4* __restrict__ src_nrm,
+                                                               const float4* __restrict__ src_nrm0, int enforce,
                                                                double* __restrict__ partials) {
   __shared__ double red_s[WAVES_PER_BLOCK][NS];
+  bool restart = false;
+  if (ctl != nullptr) {
+    if (ctl->stop != 0) return;
+    restart = ctl->restart != 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T.m[i] = ctl->T_apply[i];
+  }
   PairAcc<MODE> pa;
   pa.init();
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
@@ -932,7 +963,7 @@ __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, con
     if constexpr (MODE == PCLHIP_ICP_SYMMETRIC) {
       // the source normals move with the cloud (transformPointCloudWithNormals, icp.hpp:49-111 override
       // of IterativeClosestPointWithNormals): rotate by this iteration's incremental transform
-      const float4 m = src_nrm[i];
+      const float4 m = restart ? src_nrm0[i] : src_nrm[i];
       n1.x = rotate_row(T.m[0], T.m[1], T.m[2], m.x, m.y, m.z);
       n1.y = rotate_row(T.m[4], T.m[5], T.m[6], m.x, m.y, m.z);
       n1.z = rotate_row(T.m[8], T.m[9], T.m[10], m.x, m.y, m.z);
@@ -985,7 +1016,9 @@ __global__ __launch_bounds__(BLOCK) void estimate_pairs_kernel(const float4* __r
 // partials[nblocks][NS] -> sums[NS]; fixed summation order (stride-32 lanes, then 32 partial sums in
 // order) so the result does not depend on scheduling
 __global__ __launch_bounds__(1024) void icp_finalize_kernel(const double* __restrict__ partials, int nblocks,
-                                                            double* __restrict__ sums) {
+                                                            double* __restrict__ sums,
+                                                            const IcpControl* __restrict__ ctl = nullptr) {
+  if (ctl != nullptr && ctl->stop != 0) return;
   __shared__ double red[32][NS + 1];
   const int t = threadIdx.x % NS, r = threadIdx.x / NS;  // NS == 32
   double s = 0.0;
@@ -1000,12 +1033,97 @@ __global__ __launch_bounds__(1024) void icp_finalize_kernel(const double* __rest
   }
 }
 
-pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d2, bool use_max, int mode) {
+// Closes an iteration on the device: closed form of the estimator on the (all-reduced) record, final = Tk *
+// final, DefaultConvergenceCriteria, and the control words of the next launch (impl/icp.hpp:204-238).
+// One thread: ~2k double operations, a few microseconds -- the point is that nothing leaves the GPU.
+__global__ void icp_solve_kernel(IcpControl* __restrict__ ctl, const double* __restrict__ sums,
+                                 IcpStepRecord* __restrict__ log) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (ctl->stop != 0) return;
+  IcpControl c = *ctl;
+  IcpStepRecord r;
+  r.step = c.step;
+  const double ncorr = sums[28];
+  r.num_correspondences = ncorr;
+  r.mse = 0.0;
+  bool converged = false;
+  if (ncorr < double(c.crit.min_number_correspondences)) {  // icp.hpp:204-213
+    c.st.convergence_state = cf::NO_CORRESPONDENCES;
+  } else {
+    cf::solve(sums, c.mode, c.Tk);                     // :216-217
+    cf::mat4_mul_f32(c.Tk, c.final_T, c.final_T);      // :223
+    ++c.nr_iterations;
+    const double mse = sums[27] / ncorr;               // calculateMSE, default_convergence_criteria.h:262-270
+    r.mse = mse;
+    converged = cf::has_converged(c.crit, c.st, c.nr_iterations, c.Tk, mse);
+  }
+  const bool ended = c.st.convergence_state != cf::NOT_CONVERGED;
+  r.iteration = c.nr_iterations;
+  r.convergence_state = c.st.convergence_state;
+  r.converged = converged ? 1 : 0;
+  r.ended = ended ? 1 : 0;
+  r.similar = c.st.iterations_similar_transforms;
+  r.prev_mse = c.st.prev_mse;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    r.Tk[i] = c.Tk[i];
+    r.final_T[i] = c.final_T[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) r.sums[i] = sums[i];
+  if (ended) {
+    if (c.auto_restart) {  // the next launch starts the next alignment from the input cloud and the guess
+      c.restart = 1;
+      c.nr_iterations = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) c.final_T[i] = c.guess[i];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) c.T_apply[i] = c.guess[i];
+    } else {
+      c.stop = 1;
+    }
+  } else {
+    c.restart = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) c.T_apply[i] = c.Tk[i];  // :220, applied by the next search launch
+  }
+  ++c.step;
+  *ctl = c;
+  log[r.step % c.log_capacity] = r;
+  __threadfence_system();
+}
+
+static int search_skip_flag() {
+  static const int skip = [] {  // A/B: PCLHIP_ICP_SKIP=0 always descends from the root
+    const char* e = getenv("PCLHIP_ICP_SKIP");
+    const char* o = getenv("PCLHIP_ORDER");  // the shortcut relies on the kd order (disjoint cells)
+    if (o && !strcmp(o, "morton")) return 0;
+    return (e && atoi(e) == 0) ? 0 : 2;
+  }();
+  return skip;
+}
+
+template <int MODE>
+static void launch_accumulate(pclhip_icp* icp, const IndexView& v, int ga, const uint8_t* keep, const Mat34& M,
+                              const IcpControl* ctl, hipStream_t s) {
+  hipLaunchKernelGGL(icp_accumulate_kernel<MODE>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, icp->match_pos,
+                     icp->match_d2, keep, M, ctl, icp->src_nrm_cur, icp->src_nrm_sorted0,
+                     icp->enforce_same_direction_normals ? 1 : 0, icp->partials);
+}
+
+// One iteration.  ev == nullptr: the host-driven form (T by value, the caller reads the record back);
+// ev != nullptr: the device-driven form -- transform / restart / stop come from icp->ctl, the iteration is
+// closed by icp_solve_kernel, and ev[0..3] are recorded before the search, after it, after the accumulation
+// and after the solve.
+pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d2, bool use_max, int mode,
+                                 hipEvent_t* ev) {
   pclhip_ctx* ctx = icp->ctx;
   hipStream_t s = ctx->stream;
   const IndexView v = icp->target->view();
+  const bool device_loop = ev != nullptr;
+  const IcpControl* ctl = device_loop ? icp->ctl : nullptr;
   Mat34 M;
-  for (int i = 0; i < 12; ++i) M.m[i] = T[i];
+  for (int i = 0; i < 12; ++i) M.m[i] = T ? T[i] : 0.0f;
   // clouds with normals move through transformPointCloudWithNormals (Transformer order), plain clouds
   // through Matrix4f * Vector4f (impl/icp.hpp:49-111)
   const int order = (mode == PCLHIP_ICP_POINT_TO_POINT) ? 0 : 1;
@@ -1015,28 +1133,19 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   // single-kernel variant (PCLHIP_ICP_FUSED=1): 27 (15) fp64 accumulators per lane -> 3 waves/SIMD
   auto k_plane = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE, 3>;
   auto k_point = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT, 3>;
-  int grid = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? resident_blocks(ctx, k_plane, ngroups)
-                                                 : resident_blocks(ctx, k_point, ngroups);
-  if (grid > icp->grid_blocks) grid = icp->grid_blocks;
   static const int unfused = [] {
     const char* e = getenv("PCLHIP_ICP_FUSED");
     return (e && atoi(e) == 1) ? 0 : 1;  // default: the two-kernel variant (measured faster)
   }();
   const bool filters = icp->reciprocal || !icp->rejectors.empty();
-  if (icp->n > 0 && (unfused || filters || mode == PCLHIP_ICP_SYMMETRIC)) {
+  if (icp->n > 0 && (device_loop || unfused || filters || mode == PCLHIP_ICP_SYMMETRIC || icp->region.on)) {
     auto ks = icp_search_kernel<4, 1, true>;
-    const uint32_t ngroups_s = (icp->n + WAVE - 1) / WAVE;
-    const int gs = resident_blocks(ctx, ks, ngroups_s);
-    (void)hipEventRecord(icp->ev0, s);
-    static const int skip = [] {  // A/B: PCLHIP_ICP_SKIP=0 always descends from the root
-      const char* e = getenv("PCLHIP_ICP_SKIP");
-      const char* o = getenv("PCLHIP_ORDER");  // the shortcut relies on the kd order (disjoint cells)
-      if (o && !strcmp(o, "morton")) return 0;
-      return (e && atoi(e) == 0) ? 0 : 2;
-    }();
-    hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound,
-                       (use_max ? 1 : 0) | skip, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
-    (void)hipEventRecord(icp->ev_mid, s);
+    const int gs = resident_blocks(ctx, ks, ngroups);
+    (void)hipEventRecord(device_loop ? ev[0] : icp->ev0, s);
+    hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl, icp->region,
+                       order, bound, (use_max ? 1 : 0) | search_skip_flag(), icp->match_pos, icp->match, icp->match_d2,
+                       ctx->stats);
+    (void)hipEventRecord(device_loop ? ev[1] : icp->ev_mid, s);
     icp->mid_recorded = true;
     const uint8_t* keep = nullptr;
     if (filters) {
@@ -1046,30 +1155,43 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     }
     int ga = ctx->num_cus * 8;
     if (ga > icp->grid_blocks) ga = icp->grid_blocks;
-    const int enforce = icp->enforce_same_direction_normals ? 1 : 0;
     if (mode == PCLHIP_ICP_POINT_TO_PLANE)
-      hipLaunchKernelGGL(icp_accumulate_kernel<PCLHIP_ICP_POINT_TO_PLANE>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur,
-                         icp->n, icp->match_pos, icp->match_d2, keep, M, icp->src_nrm_cur, enforce, icp->partials);
+      launch_accumulate<PCLHIP_ICP_POINT_TO_PLANE>(icp, v, ga, keep, M, ctl, s);
     else if (mode == PCLHIP_ICP_SYMMETRIC)
-      hipLaunchKernelGGL(icp_accumulate_kernel<PCLHIP_ICP_SYMMETRIC>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur,
-                         icp->n, icp->match_pos, icp->match_d2, keep, M, icp->src_nrm_cur, enforce, icp->partials);
+      launch_accumulate<PCLHIP_ICP_SYMMETRIC>(icp, v, ga, keep, M, ctl, s);
     else
-      hipLaunchKernelGGL(icp_accumulate_kernel<PCLHIP_ICP_POINT_TO_POINT>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur,
-                         icp->n, icp->match_pos, icp->match_d2, keep, M, icp->src_nrm_cur, enforce, icp->partials);
-    (void)hipEventRecord(icp->ev1, s);
-    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, ga, icp->sums_dev);
+      launch_accumulate<PCLHIP_ICP_POINT_TO_POINT>(icp, v, ga, keep, M, ctl, s);
+    (void)hipEventRecord(device_loop ? ev[2] : icp->ev1, s);
+    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, ga, icp->sums_dev, ctl);
   } else if (icp->n > 0) {
+    int grid = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? resident_blocks(ctx, k_plane, ngroups)
+                                                   : resident_blocks(ctx, k_point, ngroups);
+    if (grid > icp->grid_blocks) grid = icp->grid_blocks;
     icp->mid_recorded = false;
     (void)hipEventRecord(icp->ev0, s);
     auto kern = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? k_plane : k_point;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound,
                        use_max ? 1 : 0, icp->match_pos, icp->match, icp->match_d2, icp->partials, ctx->stats);
     (void)hipEventRecord(icp->ev1, s);
-    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, grid, icp->sums_dev);
+    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, grid, icp->sums_dev,
+                       static_cast<const IcpControl*>(nullptr));
   } else {
+    if (device_loop) {
+      (void)hipEventRecord(ev[0], s);
+      (void)hipEventRecord(ev[1], s);
+    }
     PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(icp->sums_dev, 0, NS * sizeof(double), s));
+    if (device_loop) (void)hipEventRecord(ev[2], s);
   }
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  // multi-GPU: the record is summed over the ranks on this stream, between the reduction and the solve
+  pclhip_status st = allreduce_record(icp);
+  if (st != PCLHIP_OK) return st;
+  if (device_loop) {
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, s, icp->ctl, icp->sums_dev, icp->steps);
+    (void)hipEventRecord(ev[3], s);
+    PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  }
   return PCLHIP_OK;
 }
 
@@ -1133,8 +1255,10 @@ pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double ma
   const uint32_t ngroups = (n + WAVE - 1) / WAVE;
   const int gs = resident_blocks(ctx, icp_search_kernel<4, 1, true>, ngroups);
   // transformPointCloud(cloud, out, Matrix4) is Transformer::se3 (transforms.hpp:109-123): order 1
-  hipLaunchKernelGGL((icp_search_kernel<4, 1, true>), dim3(gs), dim3(BLOCK), 0, s, v, cur, n, M, 1, __builtin_inff(), 0, pos,
-                     id, d2, ctx->stats);
+  RegionBox all;
+  all.on = 0;
+  hipLaunchKernelGGL((icp_search_kernel<4, 1, true>), dim3(gs), dim3(BLOCK), 0, s, v, cur, static_cast<const float4*>(cur), n,
+                     M, static_cast<const IcpControl*>(nullptr), all, 1, __builtin_inff(), 0, pos, id, d2, ctx->stats);
   hipLaunchKernelGGL(fitness_partial_kernel, dim3(gr), dim3(BLOCK), 0, s, d2, n, max_range, part);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   std::vector<double> h(size_t(gr) * 2);

@@ -1,0 +1,168 @@
+"""The device-driven ICP loop (pcl_amd/csrc/icp_loop.hip): iterations closed on the GPU by icp_solve_kernel
+(solve + final = T * final + DefaultConvergenceCriteria, impl/icp.hpp:204-238,
+impl/default_convergence_criteria.hpp:49-140) against its host twin and against the oracle."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import pcl_amd
+    return pcl_amd.Context(0)
+
+
+def _make_icp(gpu, tgt, src, mode, normals=None):
+    import pcl_amd
+    cls = pcl_amd.IterativeClosestPointWithNormals if mode == 1 else pcl_amd.IterativeClosestPoint
+    icp = cls(gpu)
+    icp.setInputTarget(tgt)
+    if normals is not None:
+        icp.setTargetNormals(normals)
+    icp.setInputSource(src)
+    icp.setMaximumIterations(20)
+    icp.setMaxCorrespondenceDistance(0.1)
+    icp.setTransformationEpsilon(1e-10)
+    return icp
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_run_steps_is_align_repeated(gpu, mode):
+    import pcl_amd
+    from oracle import pcl_oracle as orc
+    tgt, src, T_gt = pcl_amd.synth.icp_pair(100_000)
+    normals = orc.KdTree(tgt).normals(tgt, 8, viewpoint=(0, 0, 10))[0] if mode == 1 else None
+    icp = _make_icp(gpu, tgt, src, mode, normals)
+    icp.align()
+    k = icp.nr_iterations_
+    T = icp.getFinalTransformation()
+    state = icp.getConvergenceState()
+    assert k >= 3
+    # the criteria keep their memory across align() calls (as in the reference), so the second alignment
+    # is the steady reference for the stream of steps
+    icp.align()
+    k2, T2, state2 = icp.nr_iterations_, icp.getFinalTransformation(), icp.getConvergenceState()
+    steps = icp.runSteps(2 * k2 + 2)
+    assert len(steps) == 2 * k2 + 2
+    assert [s["iteration"] for s in steps[:k2]] == list(range(1, k2 + 1))
+    assert [s["alignment_ended"] for s in steps[:k2]] == [False] * (k2 - 1) + [True]
+    assert steps[k2 - 1]["state"] == state2 and steps[k2 - 1]["converged"]
+    assert np.array_equal(steps[k2 - 1]["final_transformation"], T2)       # same kernels, same bits
+    assert steps[k2]["iteration"] == 1 and not steps[k2]["alignment_ended"]   # the next alignment started
+    assert np.array_equal(steps[2 * k2 - 1]["final_transformation"], T2)
+    assert all(s["num_correspondences"] == len(src) for s in steps)
+    assert all(s["search_ms"] > 0 and s["step_ms"] >= s["kernels_ms"] >= s["search_ms"] for s in steps)
+    assert np.abs(T - T2).max() < 1e-5 and state != "NOT_CONVERGED" and abs(k2 - k) <= 1
+
+
+def test_device_loop_matches_host_loop_twin(gpu, tmp_path):
+    # PCLHIP_ICP_HOST_LOOP=1 runs the same iterations with the read-back + host solve + host criteria of
+    # round 1 (still the path of rejectors / reciprocal correspondences).  The switch is read once per
+    # process, so the host twin runs in a subprocess.  Device and host libm may differ in the last ulp of a
+    # double sin/cos: the 4x4 agree to float rounding, iteration counts and states exactly.
+    import pcl_amd
+    script = tmp_path / "twin.py"
+    script.write_text('''
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+import pcl_amd
+from oracle import pcl_oracle as orc
+ctx = pcl_amd.Context(0)
+out = {}
+z = np.load(%r)
+def xyz1(a):
+    o = np.ones((len(a), 4), np.float32); o[:, :3] = a[:, :3]; return o
+cases = {"bunny": (xyz1(z["bun4"]), xyz1(z["bun0"]), 0, None, 0.05)}
+tgt, src, _ = pcl_amd.synth.icp_pair(60_000)
+cases["p2plane"] = (tgt, src, 1, orc.KdTree(tgt).normals(tgt, 8, viewpoint=(0, 0, 10))[0], 0.1)
+cases["p2point"] = (tgt, src, 0, None, 0.1)
+for name, (tgt, src, mode, nrm, md) in cases.items():
+    cls = pcl_amd.IterativeClosestPointWithNormals if mode == 1 else pcl_amd.IterativeClosestPoint
+    icp = cls(ctx)
+    icp.setInputTarget(tgt)
+    if nrm is not None:
+        icp.setTargetNormals(nrm)
+    icp.setInputSource(src)
+    icp.setMaximumIterations(25)
+    icp.setMaxCorrespondenceDistance(md)
+    icp.setTransformationEpsilon(1e-9)
+    res = []
+    for rep in range(2):   # twice: the criteria's MSE memory persists across align() calls
+        icp.align()
+        res.append({"T": icp.getFinalTransformation().tolist(), "it": icp.nr_iterations_, "state": icp.getConvergenceState(),
+                    "conv": icp.hasConverged(), "last": icp.getLastIncrementalTransformation().tolist()})
+    out[name] = res
+print("RESULT" + json.dumps(out))
+''' % (ROOT, os.path.join(ROOT, "tests", "golden", "bunny.npz")))
+    runs = {}
+    for host in ("0", "1"):
+        env = dict(os.environ, PCLHIP_ICP_HOST_LOOP=host)
+        p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1]
+        runs[host] = json.loads(line[len("RESULT"):])
+    for name in runs["0"]:
+        for a, b in zip(runs["0"][name], runs["1"][name]):
+            assert a["it"] == b["it"] and a["state"] == b["state"] and a["conv"] == b["conv"], (name, a, b)
+            assert np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max() < 2e-6, name
+            assert np.abs(np.asarray(a["last"]) - np.asarray(b["last"])).max() < 2e-6, name
+
+
+def test_run_steps_refuses_rejectors_and_reports_no_correspondences(gpu):
+    import pcl_amd
+    tgt, src, _ = pcl_amd.synth.icp_pair(5_000)
+    icp = _make_icp(gpu, tgt, src, 0)
+    rej = pcl_amd.CorrespondenceRejectorMedianDistance()
+    rej.setMedianFactor(2.0)
+    icp.addCorrespondenceRejector(rej)
+    with pytest.raises(pcl_amd.PclHipError, match="rejectors"):
+        icp.runSteps(3)
+    # nothing within reach: every step is an alignment that ends at once with NO_CORRESPONDENCES
+    far = src.copy()
+    far[:, 0] += 100.0
+    icp2 = _make_icp(gpu, tgt, far, 0)
+    steps = icp2.runSteps(3)
+    assert [s["state"] for s in steps] == ["NO_CORRESPONDENCES"] * 3
+    assert all(s["alignment_ended"] and not s["converged"] and s["iteration"] == 0 for s in steps)
+    icp2.align()
+    assert not icp2.hasConverged() and icp2.getConvergenceState() == "NO_CORRESPONDENCES" and icp2.nr_iterations_ == 0
+    assert np.array_equal(icp2.getFinalTransformation(), np.eye(4, dtype=np.float32))
+
+
+def test_native_communicator_single_rank(gpu):
+    # the C-side RCCL path on a 1-rank group: ncclAllReduce from libpclhip.so on the context's stream;
+    # a 1-rank sum is the identity, so results are bit-identical with and without the communicator
+    import torch
+    import pcl_amd
+    from oracle import pcl_oracle as orc
+    uid = pcl_amd.Communicator.unique_id()
+    assert len(uid) == 128
+    comm = pcl_amd.Communicator(gpu, 0, 1, uid)
+    buf = torch.arange(32, dtype=torch.float64, device="cuda")
+    comm.allreduce_sum_f64(buf.data_ptr(), 32)
+    gpu.synchronize()
+    assert torch.equal(buf.cpu(), torch.arange(32, dtype=torch.float64))
+    tgt, src, _ = pcl_amd.synth.icp_pair(50_000)
+    nrm = orc.KdTree(tgt).normals(tgt, 8, viewpoint=(0, 0, 10))[0]
+    res = []
+    for use in (False, True):
+        icp = _make_icp(gpu, tgt, src, 1, nrm)
+        if use:
+            icp.setCommunicator(comm)
+        icp.align()
+        res.append((icp.getFinalTransformation().copy(), icp.nr_iterations_))
+        if use:  # cloud-global rejectors are refused under sharding (they would be evaluated per slab)
+            rej = pcl_amd.CorrespondenceRejectorTrimmed()
+            icp.addCorrespondenceRejector(rej)
+            with pytest.raises(pcl_amd.PclHipError, match="Distance rejector"):
+                icp.align()
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
