@@ -16,7 +16,9 @@
 #include <dlfcn.h>
 
 #include <cfloat>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -276,10 +278,19 @@ pclhip_status run_loop(pclhip_icp* icp, const pclhip_icp_params* p, int window, 
   long enq = 0, done = 0;
   bool feed = true;
   pclhip_status st = PCLHIP_OK;
+  static const bool debug = getenv("PCLHIP_LOOP_DEBUG") != nullptr;
+  double t_enq = 0, t_wait = 0;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  struct Report {
+    const bool on; const double& a; const double& b; const long& n;
+    ~Report() { if (on) fprintf(stderr, "[pclhip loop] %ld steps: enqueue %.3f ms, waiting %.3f ms (host)\n", n, a, b); }
+  } report{debug, t_enq, t_wait, done};
   while (done < enq || (feed && (max_steps < 0 || enq < max_steps))) {
     while (feed && (max_steps < 0 || enq < max_steps) && enq - done < window) {
       hipEvent_t* ev = &icp->step_events[size_t(enq % icp->steps_capacity) * 4];
+      const double t0 = debug ? now() : 0;
       st = launch_icp_iterate(icp, nullptr, fmax2, use_max, p->mode, ev);
+      if (debug) t_enq += now() - t0;
       if (st != PCLHIP_OK) {
         (void)hipStreamSynchronize(ctx->stream);
         return st;
@@ -288,7 +299,9 @@ pclhip_status run_loop(pclhip_icp* icp, const pclhip_icp_params* p, int window, 
     }
     if (done == enq) break;
     hipEvent_t* ev = &icp->step_events[size_t(done % icp->steps_capacity) * 4];
+    const double tw = debug ? now() : 0;
     PCLHIP_CHECK_HIP(ctx, hipEventSynchronize(ev[3]));
+    if (debug) t_wait += now() - tw;
     const IcpStepRecord rec = icp->steps[done % icp->steps_capacity];
     StepTimes t;
     if (feed) {  // launches queued behind a finished alignment fell through: no record, no times

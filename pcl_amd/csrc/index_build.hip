@@ -186,6 +186,66 @@ __global__ __launch_bounds__(256) void leaf_soa_kernel(const float4* pts, uint32
   l[3 * LEAF] = p.w;
 }
 
+// One thread per leaf: the oriented slab dmin <= n.p <= dmax of its points (traverse.hpp: point_slab_lb).
+// n = direction of least variance of the leaf's points (double covariance, cyclic Jacobi), shrunk so that
+// the stored float vector has |n| <= 1; dmin / dmax are taken with THAT float vector in double and rounded
+// outwards, so the slab contains every point of the leaf whatever the quality of the fit.  Leaves that hold
+// padding sentinels (or yield anything non-finite) get the empty direction n = 0, which bounds nothing.
+__global__ __launch_bounds__(256) void leaf_slab_kernel(const float4* __restrict__ pts, uint32_t n, uint32_t nleaf,
+                                                        float4* __restrict__ slab, Box* __restrict__ box) {
+  const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (leaf >= nleaf) return;
+  const uint32_t b = leaf * LEAF;
+  float4 out = make_float4(0, 0, 0, 0);
+  float dmax_f = 0.0f;
+  if (b + LEAF <= n) {
+    double m[3] = {0, 0, 0};
+    float4 p[LEAF];
+#pragma unroll
+    for (int i = 0; i < LEAF; ++i) {
+      p[i] = pts[b + i];
+      m[0] += p[i].x; m[1] += p[i].y; m[2] += p[i].z;
+    }
+    m[0] /= LEAF; m[1] /= LEAF; m[2] /= LEAF;
+    double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int i = 0; i < LEAF; ++i) {
+      const double d[3] = {p[i].x - m[0], p[i].y - m[1], p[i].z - m[2]};
+      for (int r = 0; r < 3; ++r)
+        for (int c = r; c < 3; ++c) A[r][c] += d[r] * d[c];
+    }
+    A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
+    double V[3][3], w[3];
+    cf::jacobi_eig3(A, V, w);
+    const int k = (w[0] <= w[1] && w[0] <= w[2]) ? 0 : ((w[1] <= w[2]) ? 1 : 2);
+    double nd[3] = {V[0][k], V[1][k], V[2][k]};
+    const double len = sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
+    if (len > 0.5 && len < 2.0) {
+      float nf[3];
+      for (int d = 0; d < 3; ++d) nf[d] = float(nd[d] / len * (1.0 - 4e-7));
+      const double nn = double(nf[0]) * nf[0] + double(nf[1]) * nf[1] + double(nf[2]) * nf[2];
+      if (nn <= 1.0) {
+        double lo = 1e300, hi = -1e300;
+#pragma unroll
+        for (int i = 0; i < LEAF; ++i) {
+          const double s = double(nf[0]) * p[i].x + double(nf[1]) * p[i].y + double(nf[2]) * p[i].z;
+          lo = fmin(lo, s);
+          hi = fmax(hi, s);
+        }
+        float lo_f = float(lo), hi_f = float(hi);
+        if (double(lo_f) > lo) lo_f = nextafterf(lo_f, -INFINITY);
+        if (double(hi_f) < hi) hi_f = nextafterf(hi_f, INFINITY);
+        if (isfinite(lo_f) && isfinite(hi_f)) {
+          out = make_float4(nf[0], nf[1], nf[2], lo_f);
+          dmax_f = hi_f;
+        }
+      }
+    }
+  }
+  slab[leaf] = out;
+  box[leaf].hi.w = dmax_f;
+}
+
 // one wavefront per parent node
 __global__ __launch_bounds__(256) void node_box_kernel(const Box* child, uint32_t nchild, Box* parent, uint32_t nparent) {
   const uint32_t node = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
@@ -630,6 +690,10 @@ pclhip_status build_boxes(pclhip_index* ix) {
       ix->soa = nullptr;
       PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->soa, size_t(c) * 4 * LEAF * sizeof(float)));
       hipLaunchKernelGGL(leaf_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, threads, ix->soa);
+      if (ix->slab) (void)hipFree(ix->slab);
+      ix->slab = nullptr;
+      PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->slab, size_t(c) * sizeof(float4)));
+      hipLaunchKernelGGL(leaf_slab_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c, ix->slab, ix->box[1]);
     } else {
       const uint64_t threads = uint64_t(c) * WAVE;
       hipLaunchKernelGGL(node_box_kernel, dim3(unsigned((threads + 255) / 256)), dim3(256), 0, s, ix->box[l - 1],
@@ -681,6 +745,11 @@ pclhip::IndexView pclhip_index::view() const {
   v.pts = pts;
   v.soa = soa;
   v.nrm = nrm;
+  static const bool use_slabs = [] {  // A/B: PCLHIP_SLAB=0 searches with the axis-aligned boxes only
+    const char* e = getenv("PCLHIP_SLAB");
+    return !(e && atoi(e) == 0);
+  }();
+  v.slab = use_slabs ? slab : nullptr;
   v.lv = lv_dev;
   for (int l = 0; l < pclhip::MAX_LEVELS; ++l) {
     v.box[l] = box[l];

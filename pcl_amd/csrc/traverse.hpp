@@ -32,14 +32,15 @@ constexpr int STACK_ENTRIES = 208;
 constexpr int LEAF_BATCH = 16;         // leaves staged in LDS at a time (16 x 256 B = 4 KB)
 constexpr int LEAF_FLOATS = 4 * LEAF;  // x[16] y[16] z[16] w[16]
 
-// Per-wavefront LDS working set: traversal stack (1.6 KB), ranked leaf list (2 KB), staged candidate
+// Per-wavefront LDS working set: traversal stack (1.6 KB), ranked leaf list (3.25 KB), staged candidate
 // blocks.  WaveLdsT<3072> (no room for the w[16] chunks) is for kernels whose policies never stage the
 // original indices: 6.6 KB per wave, which lets a 4-wave block fit five times into a CU's 160 KB.
 template <int BUF_BYTES>
 struct __attribute__((aligned(16))) WaveLdsT {
   static constexpr int BUF_FLOATS = BUF_BYTES / 4;
   uint2 stack[STACK_ENTRIES];
-  float4 list[2 * FANOUT];  // per ranked leaf (lo.xyz, id) (hi.xyz, lbG)
+  float4 list[3 * FANOUT];  // per ranked leaf (lo.xyz, id) (hi.xyz, lbG) (slab normal.xyz, dmin)
+  float dmax[FANOUT];       // ... and the slab's dmax
   float buf[BUF_FLOATS];
 };
 typedef WaveLdsT<LEAF_BATCH * LEAF_FLOATS * 4> WaveLds;  // 4 KB of staging: x y z w chunks of 16 leaves
@@ -74,6 +75,34 @@ __device__ __forceinline__ float box_box_lb(float Qlx, float Qly, float Qlz, flo
   r = __fadd_rn(r, __fmul_rn(gy, gy));
   r = __fadd_rn(r, __fmul_rn(gz, gz));
   return r;
+}
+
+// ---- oriented slab bounds ---------------------------------------------------------------------------
+// Every leaf also carries a slab {p : dmin <= n.p <= dmax} with |n| <= 1 that contains its points
+// (index_build.hip: leaf_slab_kernel).  |q - p| >= |n.q - n.p| for every p of the leaf, so
+// gap = max(n.q - dmax, dmin - n.q, 0) bounds the distance from below.  Unlike the AABB bound this one
+// is not bit-monotone; it is made safe instead: `eq` covers the rounding of the float dot product
+// (|n_i| <= 1: 4 ulp of |q|_1), the factor below the rounding of the differences, of the square and of the
+// l2_simple distance it is compared with.  On a sloped sheet the AABB of 16 points is ~10x thicker than the
+// slab, which is what decides how many leaves a query standing off the surface must evaluate.
+constexpr float SLAB_SHRINK = 0.999996f;
+__device__ __forceinline__ float slab_eps(float ax, float ay, float az) {  // |q| components, or box magnitudes
+  return 2.4e-7f * (ax + ay + az);
+}
+__device__ __forceinline__ float point_slab_lb(float qx, float qy, float qz, float eq, float nx, float ny, float nz,
+                                               float dmin, float dmax) {
+  const float s = __fmaf_rn(nz, qz, __fmaf_rn(ny, qy, __fmul_rn(nx, qx)));
+  const float g = fmaxf(fmaxf(s - dmax, dmin - s), eq) - eq;  // max(s - dmax - eq, dmin - s - eq, 0)
+  return g * g * SLAB_SHRINK;
+}
+// the same for every q of the box [Ql, Qh]: the dot product ranges over [smin, smax]
+__device__ __forceinline__ float box_slab_lb(float Qlx, float Qly, float Qlz, float Qhx, float Qhy, float Qhz, float eQ,
+                                             float nx, float ny, float nz, float dmin, float dmax) {
+  const float ax = nx * Qlx, bx = nx * Qhx, ay = ny * Qly, by = ny * Qhy, az = nz * Qlz, bz = nz * Qhz;
+  const float smin = (fminf(ax, bx) + fminf(ay, by)) + fminf(az, bz);
+  const float smax = (fmaxf(ax, bx) + fmaxf(ay, by)) + fmaxf(az, bz);
+  const float g = fmaxf(fmaxf(smin - dmax, dmin - smax), eQ) - eQ;
+  return g * g * SLAB_SHRINK;
 }
 
 // ---- wavefront reductions (all 64 lanes must be active) ---------------------------------------
@@ -572,6 +601,10 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
   wave_min3_max4(lx0, ly0, lz0, hx0, hy0, hz0, T);
   const float Qlx = lx0, Qly = ly0, Qlz = lz0, Qhx = hx0, Qhy = hy0, Qhz = hz0;
   const float gdiag2 = (Qhx - Qlx) * (Qhx - Qlx) + (Qhy - Qly) * (Qhy - Qly) + (Qhz - Qlz) * (Qhz - Qlz);
+  // rounding allowances of the slab bounds (see point_slab_lb): for the group's box and for the lane's query
+  const float eQ = slab_eps(fmaxf(fabsf(Qlx), fabsf(Qhx)), fmaxf(fabsf(Qly), fabsf(Qhy)), fmaxf(fabsf(Qlz), fabsf(Qhz)));
+  const float eq = slab_eps(fabsf(qx[0]), fabsf(qy[0]), fabsf(qz[0]));
+  const bool have_slab = ix.slab != nullptr;
   uint2* const stack = wl.stack;
 
   int sp = 0;
@@ -630,7 +663,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
     }
     const uint32_t nchild = (total - first) < uint32_t(FANOUT) ? (total - first) : uint32_t(FANOUT);
     const bool has = uint32_t(lane) < nchild;
-    float lx = 0, ly = 0, lz = 0, hx = 0, hy = 0, hz = 0;
+    float lx = 0, ly = 0, lz = 0, hx = 0, hy = 0, hz = 0, hw = 0;
     if (int(cl) >= ix.cache_from) {  // upper levels: boxes come from the block's LDS copy
       if (has) {
         const Box b = topbox[coff + first + lane];
@@ -641,16 +674,25 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
       const Box b = level_box[first + lane];
       lx = b.lo.x; ly = b.lo.y; lz = b.lo.z;
       hx = b.hi.x; hy = b.hi.y; hz = b.hi.z;
+      hw = b.hi.w;  // leaves: the slab's dmax
     }
-    const float lbG = has ? box_box_lb(Qlx, Qly, Qlz, Qhx, Qhy, Qhz, lx, ly, lz, hx, hy, hz) : INF;
-    const bool alive = has && !(lbG > T);
-    const uint64_t mask = __builtin_amdgcn_ballot_w64(alive);
-    if (mask == 0) continue;
+    float lbG = has ? box_box_lb(Qlx, Qly, Qlz, Qhx, Qhy, Qhz, lx, ly, lz, hx, hy, hz) : INF;
     // Visiting order.  Cold or lukewarm bounds (wave radius not yet small against the group's own
     // extent, e.g. the first ICP iterations): ascending distance to the group box, so the bounds
     // collapse after the first few leaves and everything farther is cut off at once.  Tight bounds
     // (seeded steady state): plain index order, no ranking work.
     const bool ordered = T * 16.0f > gdiag2;
+    // Leaves of a loose search are also bounded by their oriented slab: a query standing off a sloped sheet
+    // is much farther from the sheet's slab than from the axis-aligned boxes of its 16-point patches.
+    const bool use_slab = have_slab && ordered && cl == 1u;
+    float4 sl = make_float4(0, 0, 0, 0);
+    if (use_slab && has) {
+      sl = ix.slab[first + lane];
+      lbG = fmaxf(lbG, box_slab_lb(Qlx, Qly, Qlz, Qhx, Qhy, Qhz, eQ, sl.x, sl.y, sl.z, sl.w, hw));
+    }
+    const bool alive = has && !(lbG > T);
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(alive);
+    if (mask == 0) continue;
     if (cl == 1u) {
       // ---- rank the surviving leaves and publish (box, id, lbG) in LDS --------------------------
       uint32_t rank = uint32_t(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
@@ -664,8 +706,12 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
       }
       const uint32_t n_alive = uint32_t(__builtin_popcountll(mask));
       if (alive) {
-        wl.list[2 * rank] = make_float4(lx, ly, lz, __uint_as_float(first + uint32_t(lane)));
-        wl.list[2 * rank + 1] = make_float4(hx, hy, hz, lbG);
+        wl.list[3 * rank] = make_float4(lx, ly, lz, __uint_as_float(first + uint32_t(lane)));
+        wl.list[3 * rank + 1] = make_float4(hx, hy, hz, lbG);
+        if (use_slab) {
+          wl.list[3 * rank + 2] = sl;
+          wl.dmax[rank] = hw;
+        }
       }
       __builtin_amdgcn_wave_barrier();
       if constexpr (SPARSE) {
@@ -693,7 +739,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
           {
             const uint32_t slot = uint32_t(lane) & 15u;
             uint32_t leaf_id = 0;
-            if (slot < nb) leaf_id = __float_as_uint(wl.list[2 * (b0 + slot)].w);
+            if (slot < nb) leaf_id = __float_as_uint(wl.list[3 * (b0 + slot)].w);
 #pragma unroll
             for (int i = 0; i < NCHUNK / 4; ++i) {
               if (slot < nb) {
@@ -711,13 +757,17 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
             // as early as possible and the tail of the list is cut off by the shrinking wave radius.
             uint32_t pslot = 0, pid = NO_INDEX;
             for (uint32_t t = 0; t < nb; ++t) {
-              const float4 ea = wl.list[2 * (b0 + t)], eb = wl.list[2 * (b0 + t) + 1];  // broadcast reads
+              const float4 ea = wl.list[3 * (b0 + t)], eb = wl.list[3 * (b0 + t) + 1];  // broadcast reads
               if (uniform_f32(eb.w) > T) {  // sorted: every remaining leaf is farther than the wave radius
                 cut = true;
                 break;
               }
               ++ts.c[1];
-              const float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
+              float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
+              if (use_slab) {
+                const float4 es = wl.list[3 * (b0 + t) + 2];
+                lb = fmaxf(lb, point_slab_lb(qx[0], qy[0], qz[0], eq, es.x, es.y, es.z, es.w, wl.dmax[b0 + t]));
+              }
               bool need = valid[0] && !(lb > pol.worst(0));
               if (__builtin_amdgcn_ballot_w64(need && pid != NO_INDEX) != 0) {
                 if (!landed) {
@@ -754,7 +804,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
             ts.c[1] += nb;
             uint32_t mask = 0;
             for (uint32_t t = 0; t < nb; ++t) {
-              const float4 ea = wl.list[2 * (b0 + t)], eb = wl.list[2 * (b0 + t) + 1];  // broadcast reads
+              const float4 ea = wl.list[3 * (b0 + t)], eb = wl.list[3 * (b0 + t) + 1];  // broadcast reads
               const float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
               mask |= (!(lb > pol.worst(0)) ? 1u : 0u) << t;
             }
@@ -767,7 +817,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
               uint32_t slot = 0, id = NO_INDEX;
               if (mask != 0) {
                 slot = uint32_t(__builtin_ctz(mask));
-                id = __float_as_uint(wl.list[2 * (b0 + slot)].w);
+                id = __float_as_uint(wl.list[3 * (b0 + slot)].w);
                 mask &= mask - 1u;
               }
               round(slot, id);
@@ -791,7 +841,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         for (int t = 0; t < (LEAF_BATCH * LEAF_FLOATS * 4) / (WAVE * 16); ++t) {  // 4 instructions
           const uint32_t slot = uint32_t(t) * (WAVE / 16) + uint32_t(lane) / 16u;
           if (slot < nb) {
-            const uint32_t leaf_id = __float_as_uint(wl.list[2 * (b0 + slot)].w);
+            const uint32_t leaf_id = __float_as_uint(wl.list[3 * (b0 + slot)].w);
             const float* src = ix.soa + size_t(leaf_id) * LEAF_FLOATS + (lane & 15) * 4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(wl.buf + t * (WAVE * 4)), 16, 0,
@@ -800,7 +850,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         }
         bool landed = false;
         for (uint32_t t = 0; t < nb; ++t) {
-          const float4 ea = wl.list[2 * (b0 + t)], eb = wl.list[2 * (b0 + t) + 1];  // broadcast reads
+          const float4 ea = wl.list[3 * (b0 + t)], eb = wl.list[3 * (b0 + t) + 1];  // broadcast reads
           if (uniform_f32(eb.w) > T) {
             if (ordered) {  // sorted: every remaining leaf is farther than the wave radius
               cut = true;
@@ -812,7 +862,12 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
           bool need = false;
 #pragma unroll
           for (int q = 0; q < QPL; ++q) {
-            const float lb = point_box_lb(qx[q], qy[q], qz[q], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
+            float lb = point_box_lb(qx[q], qy[q], qz[q], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
+            if (use_slab) {
+              const float4 es = wl.list[3 * (b0 + t) + 2];
+              lb = fmaxf(lb, point_slab_lb(qx[q], qy[q], qz[q], slab_eps(fabsf(qx[q]), fabsf(qy[q]), fabsf(qz[q])), es.x,
+                                           es.y, es.z, es.w, wl.dmax[b0 + t]));
+            }
             need = need || (valid[q] && !(lb > pol.worst(q)));
           }
           if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
