@@ -262,6 +262,21 @@ PCLHIP_API pclhip_status pclhip_solve_transformation(const double sums[PCLHIP_IC
 PCLHIP_API pclhip_status pclhip_icp_align(pclhip_icp* icp, const pclhip_icp_params* params,
                                           const float guess[16], pclhip_icp_result* result);
 
+/* DefaultConvergenceCriteria::hasConverged (impl/default_convergence_criteria.hpp:49-140) as a host function, for
+ * callers that run the loop themselves (a Registration with a foreign CorrespondenceEstimation /
+ * TransformationEstimation plugged in): the same code the device loop runs.  `params` supplies the thresholds as
+ * ICP sets them (impl/icp.hpp:157-161); `st` is the criteria's memory, which persists across alignments.
+ * Returns 1 when the alignment ends with converged_ = true; the loop also ends whenever
+ * st->convergence_state != 0 (NOT_CONVERGED). */
+typedef struct {
+  double prev_mse;                    /* correspondences_prev_mse_, DBL_MAX initially */
+  int iterations_similar_transforms;
+  int convergence_state;              /* ConvergenceState values of default_convergence_criteria.h:71-80 */
+} pclhip_convergence_state;
+PCLHIP_API void pclhip_convergence_init(pclhip_convergence_state* st);
+PCLHIP_API int pclhip_convergence_has_converged(const pclhip_icp_params* params, pclhip_convergence_state* st,
+                                                int nr_iterations, const float T[16], double mse);
+
 /* The same loop as a stream of exactly n_steps iterations for measurements and for back-to-back registration
  * of the same clouds: Registration::align() called again and again -- when an alignment ends (converged or
  * not) the next step starts the next one from the input cloud and `guess`, on the device, without host

@@ -53,6 +53,10 @@ class IcpStep(C.Structure):
                 ("final_transformation", C.c_float * 16)]
 
 
+class ConvergenceState(C.Structure):
+    _fields_ = [("prev_mse", C.c_double), ("iterations_similar_transforms", C.c_int), ("convergence_state", C.c_int)]
+
+
 COMM_ID_BYTES = 128
 
 
@@ -118,6 +122,9 @@ SIGNATURES = {
                                               C.POINTER(C.c_float)]),
     "pclhip_icp_align": (C.c_int, [_vp, C.POINTER(IcpParams), C.POINTER(C.c_float),
                                    C.POINTER(IcpResult)]),
+    "pclhip_convergence_init": (None, [C.POINTER(ConvergenceState)]),
+    "pclhip_convergence_has_converged": (C.c_int, [C.POINTER(IcpParams), C.POINTER(ConvergenceState), C.c_int,
+                                                   C.POINTER(C.c_float), C.c_double]),
     "pclhip_icp_run_steps": (C.c_int, [_vp, C.POINTER(IcpParams), C.POINTER(C.c_float), C.c_int, C.POINTER(IcpStep)]),
     "pclhip_comm_get_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "pclhip_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(_vp)]),

@@ -358,7 +358,7 @@ void pclhip_index_destroy(pclhip_index* ix) {
   if (ix->pts) (void)hipFree(ix->pts);
   if (ix->soa) (void)hipFree(ix->soa);
   if (ix->nrm) (void)hipFree(ix->nrm);
-  if (ix->slab) (void)hipFree(ix->slab);
+  if (ix->disc) (void)hipFree(ix->disc);
   if (ix->rank) (void)hipFree(ix->rank);
   if (ix->lv_dev) (void)hipFree(ix->lv_dev);
   if (ix->topcache) (void)hipFree(ix->topcache);

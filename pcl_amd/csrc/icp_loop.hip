@@ -370,6 +370,29 @@ pclhip_status icp_align_device(pclhip_icp* icp, const pclhip_icp_params* params,
 
 }  // namespace pclhip
 
+extern "C" void pclhip_convergence_init(pclhip_convergence_state* st) {
+  if (!st) return;
+  st->prev_mse = DBL_MAX;  // default_convergence_criteria.h: correspondences_prev_mse_
+  st->iterations_similar_transforms = 0;
+  st->convergence_state = cf::NOT_CONVERGED;
+}
+
+extern "C" int pclhip_convergence_has_converged(const pclhip_icp_params* params, pclhip_convergence_state* st,
+                                                int nr_iterations, const float T[16], double mse) {
+  if (!params || !st || !T) return 0;
+  cf::Criteria c;
+  fill_criteria(params, c);
+  cf::CriteriaState s;
+  s.prev_mse = st->prev_mse;
+  s.iterations_similar_transforms = st->iterations_similar_transforms;
+  s.convergence_state = st->convergence_state;
+  const bool r = cf::has_converged(c, s, nr_iterations, T, mse);
+  st->prev_mse = s.prev_mse;
+  st->iterations_similar_transforms = s.iterations_similar_transforms;
+  st->convergence_state = s.convergence_state;
+  return r ? 1 : 0;
+}
+
 extern "C" pclhip_status pclhip_icp_run_steps(pclhip_icp* icp, const pclhip_icp_params* params, const float* guess,
                                               int n_steps, pclhip_icp_step* out_steps) {
   if (!icp || !params || n_steps < 0 || (n_steps > 0 && !out_steps)) return PCLHIP_ERR_INVALID;

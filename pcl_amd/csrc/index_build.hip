@@ -186,64 +186,73 @@ __global__ __launch_bounds__(256) void leaf_soa_kernel(const float4* pts, uint32
   l[3 * LEAF] = p.w;
 }
 
-// One thread per leaf: the oriented slab dmin <= n.p <= dmax of its points (traverse.hpp: point_slab_lb).
-// n = direction of least variance of the leaf's points (double covariance, cyclic Jacobi), shrunk so that
-// the stored float vector has |n| <= 1; dmin / dmax are taken with THAT float vector in double and rounded
-// outwards, so the slab contains every point of the leaf whatever the quality of the fit.  Leaves that hold
-// padding sentinels (or yield anything non-finite) get the empty direction n = 0, which bounds nothing.
-__global__ __launch_bounds__(256) void leaf_slab_kernel(const float4* __restrict__ pts, uint32_t n, uint32_t nleaf,
-                                                        float4* __restrict__ slab, Box* __restrict__ box) {
+// One thread per leaf: the bounded cylinder ("disc") of its points (traverse.hpp: point_disc_lb) -- centre c
+// (their mean, as a float), radius R >= |p - c|, direction n of least variance (double covariance, cyclic
+// Jacobi) shrunk so that the stored float vector has |n|^2 >= 1 - 1e-6 and |n| <= 1, half thickness
+// hn >= |n.(p - c)|.  R and hn are taken in double with the STORED float c and n and rounded upwards, so the
+// disc holds every point of the leaf whatever the quality of the fit.  Anything non-finite -> the disc that
+// bounds nothing (R = hn = FLT_MAX).
+__global__ __launch_bounds__(256) void leaf_disc_kernel(const float4* __restrict__ pts, uint32_t n, uint32_t nleaf,
+                                                        float4* __restrict__ disc) {
   const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
   if (leaf >= nleaf) return;
   const uint32_t b = leaf * LEAF;
-  float4 out = make_float4(0, 0, 0, 0);
-  float dmax_f = 0.0f;
-  if (b + LEAF <= n) {
-    double m[3] = {0, 0, 0};
+  const int m = int(b < n ? (n - b < uint32_t(LEAF) ? n - b : uint32_t(LEAF)) : 0u);  // real points (the rest is padding)
+  float4 cR = make_float4(0, 0, 0, FLT_MAX), nh = make_float4(0, 0, 0, FLT_MAX);
+  if (m > 0) {
+    double mean[3] = {0, 0, 0};
     float4 p[LEAF];
 #pragma unroll
     for (int i = 0; i < LEAF; ++i) {
-      p[i] = pts[b + i];
-      m[0] += p[i].x; m[1] += p[i].y; m[2] += p[i].z;
+      p[i] = pts[b + (i < m ? i : 0)];
+      if (i < m) { mean[0] += p[i].x; mean[1] += p[i].y; mean[2] += p[i].z; }
     }
-    m[0] /= LEAF; m[1] /= LEAF; m[2] /= LEAF;
+    const float c[3] = {float(mean[0] / m), float(mean[1] / m), float(mean[2] / m)};
     double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    double r2max = 0.0;
 #pragma unroll
     for (int i = 0; i < LEAF; ++i) {
-      const double d[3] = {p[i].x - m[0], p[i].y - m[1], p[i].z - m[2]};
-      for (int r = 0; r < 3; ++r)
-        for (int c = r; c < 3; ++c) A[r][c] += d[r] * d[c];
+      if (i < m) {
+        const double d[3] = {double(p[i].x) - c[0], double(p[i].y) - c[1], double(p[i].z) - c[2]};
+        for (int r = 0; r < 3; ++r)
+          for (int cc = r; cc < 3; ++cc) A[r][cc] += d[r] * d[cc];
+        r2max = fmax(r2max, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      }
     }
     A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
     double V[3][3], w[3];
     cf::jacobi_eig3(A, V, w);
     const int k = (w[0] <= w[1] && w[0] <= w[2]) ? 0 : ((w[1] <= w[2]) ? 1 : 2);
-    double nd[3] = {V[0][k], V[1][k], V[2][k]};
+    const double nd[3] = {V[0][k], V[1][k], V[2][k]};
     const double len = sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
-    if (len > 0.5 && len < 2.0) {
-      float nf[3];
+    float nf[3] = {0, 0, 0};
+    bool ok = len > 0.5 && len < 2.0;
+    if (ok) {
       for (int d = 0; d < 3; ++d) nf[d] = float(nd[d] / len * (1.0 - 4e-7));
       const double nn = double(nf[0]) * nf[0] + double(nf[1]) * nf[1] + double(nf[2]) * nf[2];
-      if (nn <= 1.0) {
-        double lo = 1e300, hi = -1e300;
+      ok = nn <= 1.0 && nn >= 1.0 - 1e-6;
+    }
+    if (ok) {
+      double hmax = 0.0;
 #pragma unroll
-        for (int i = 0; i < LEAF; ++i) {
-          const double s = double(nf[0]) * p[i].x + double(nf[1]) * p[i].y + double(nf[2]) * p[i].z;
-          lo = fmin(lo, s);
-          hi = fmax(hi, s);
+      for (int i = 0; i < LEAF; ++i) {
+        if (i < m) {
+          const double s = double(nf[0]) * (double(p[i].x) - c[0]) + double(nf[1]) * (double(p[i].y) - c[1]) +
+                           double(nf[2]) * (double(p[i].z) - c[2]);
+          hmax = fmax(hmax, fabs(s));
         }
-        float lo_f = float(lo), hi_f = float(hi);
-        if (double(lo_f) > lo) lo_f = nextafterf(lo_f, -INFINITY);
-        if (double(hi_f) < hi) hi_f = nextafterf(hi_f, INFINITY);
-        if (isfinite(lo_f) && isfinite(hi_f)) {
-          out = make_float4(nf[0], nf[1], nf[2], lo_f);
-          dmax_f = hi_f;
-        }
+      }
+      float R = float(sqrt(r2max) * (1.0 + 1e-6)), hn = float(hmax * (1.0 + 1e-6));
+      R = nextafterf(R, INFINITY);
+      hn = nextafterf(hn, INFINITY);
+      if (isfinite(R) && isfinite(hn) && isfinite(c[0]) && isfinite(c[1]) && isfinite(c[2])) {
+        cR = make_float4(c[0], c[1], c[2], R);
+        nh = make_float4(nf[0], nf[1], nf[2], hn);
       }
     }
   }
-  slab[leaf] = out;
-  box[leaf].hi.w = dmax_f;
+  disc[2 * leaf] = cR;
+  disc[2 * leaf + 1] = nh;
 }
 
 // one wavefront per parent node
@@ -449,6 +458,63 @@ __global__ __launch_bounds__(256) void kd_permute_kernel(const float4* __restric
   if (i < n) out[i] = in[vals[i]];
 }
 
+// ---- last kd round in a wavefront -----------------------------------------------------------------
+// The rounds above cut every segment into four slabs along its widest axis.  Done once more at the bottom
+// that would leave 16-point leaves shaped 8 x 2 point spacings on a surface; two binary cuts (widest axis of
+// the 64-point cell, then the widest axis of each half) give 4 x 4 patches instead: smaller boxes, smaller
+// discs, and no radix sort of the whole cloud for this round -- one wavefront orders one cell with a bitonic
+// network over its lanes.  Cells stay cells of a kd partition (disjoint interiors), which is all the search needs.
+template <int N>
+__device__ __forceinline__ float4 wave_sort_widest(float4 p, bool valid, uint32_t lane) {
+  float lo[3] = {valid ? p.x : FLT_MAX, valid ? p.y : FLT_MAX, valid ? p.z : FLT_MAX};
+  float hi[3] = {valid ? p.x : -FLT_MAX, valid ? p.y : -FLT_MAX, valid ? p.z : -FLT_MAX};
+#pragma unroll
+  for (int o = N / 2; o > 0; o >>= 1) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
+      hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
+    }
+  }
+  const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+  int a = 0;
+  float best = ex;
+  if (ey > best) { best = ey; a = 1; }
+  if (ez > best) { a = 2; }
+  const float c = a == 0 ? p.x : (a == 1 ? p.y : p.z);
+  // (coordinate, lane) keys: equal coordinates keep their order; lanes without a point sort last
+  unsigned long long key = valid ? ((static_cast<unsigned long long>(orderable(c)) << 8) | lane) : ~0ull;
+  const uint32_t il = lane & (N - 1);
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const unsigned long long other = __shfl_xor(key, j);
+      const bool up = (il & k) == 0, lower = (il & j) == 0;
+      const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
+      key = (lower == up) ? mn : mx;
+    }
+  }
+  const int src = int(key & 63ull);
+  float4 r;
+  r.x = __shfl(p.x, src); r.y = __shfl(p.y, src); r.z = __shfl(p.z, src); r.w = __shfl(p.w, src);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void kd_cell_split_kernel(const float4* __restrict__ in, uint32_t n,
+                                                            float4* __restrict__ out) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t base = wave * WAVE;
+  if (base >= n) return;
+  const uint32_t m = (n - base) < uint32_t(WAVE) ? (n - base) : uint32_t(WAVE);
+  float4 p = make_float4(0, 0, 0, 0);
+  if (lane < m) p = in[base + lane];
+  p = wave_sort_widest<64>(p, lane < m, lane);   // the cell's points come out first, ordered along its widest axis
+  p = wave_sort_widest<32>(p, lane < m, lane);   // each half along ITS widest axis
+  if (lane < m) out[base + lane] = p;
+}
+
 // initial compaction: finite selected records first (stable), non-finite ones after them
 __global__ __launch_bounds__(256) void kd_flag_kernel(const void* pts, size_t stride, const int32_t* sel, uint64_t m,
                                                       uint32_t* keys, uint32_t* vals, unsigned int* n_finite) {
@@ -583,6 +649,19 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
       const uint32_t nchunks = uint32_t((uint64_t(nf) + chunk - 1) / chunk);
       const uint32_t chunks_per_seg = uint32_t(seg_size / chunk);
       const uint32_t nseg = uint32_t((uint64_t(nf) + seg_size - 1) / seg_size);
+      static const bool square_leaves = [] {  // A/B: PCLHIP_KD_LEAF=strip keeps the four-slab cut at the bottom too
+        const char* e = getenv("PCLHIP_KD_LEAF");
+        return !(e && strcmp(e, "strip") == 0);
+      }();
+      if (r == R && r > 0 && square_leaves) {  // 64-point cells: two binary cuts inside one wavefront each
+        hipLaunchKernelGGL(kd_cell_split_kernel, dim3(unsigned((uint64_t(nf) + 255) / 256)), dim3(256), 0, s, cur, nf, nxt);
+        if (keep_nonfinite_at_end && m > nf)
+          PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(nxt + nf, cur + nf, (m - nf) * sizeof(float4), hipMemcpyDeviceToDevice, s));
+        float4* t = cur;
+        cur = nxt;
+        nxt = t;
+        continue;
+      }
       hipLaunchKernelGGL(kd_chunk_box_kernel, dim3(unsigned((uint64_t(nchunks) * WAVE + 255) / 256)), dim3(256), 0, s, cur,
                          nf, chunk, nchunks, cb);
       if (r == 0) {
@@ -690,10 +769,10 @@ pclhip_status build_boxes(pclhip_index* ix) {
       ix->soa = nullptr;
       PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->soa, size_t(c) * 4 * LEAF * sizeof(float)));
       hipLaunchKernelGGL(leaf_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, threads, ix->soa);
-      if (ix->slab) (void)hipFree(ix->slab);
-      ix->slab = nullptr;
-      PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->slab, size_t(c) * sizeof(float4)));
-      hipLaunchKernelGGL(leaf_slab_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c, ix->slab, ix->box[1]);
+      if (ix->disc) (void)hipFree(ix->disc);
+      ix->disc = nullptr;
+      PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->disc, size_t(c) * 2 * sizeof(float4)));
+      hipLaunchKernelGGL(leaf_disc_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c, ix->disc);
     } else {
       const uint64_t threads = uint64_t(c) * WAVE;
       hipLaunchKernelGGL(node_box_kernel, dim3(unsigned((threads + 255) / 256)), dim3(256), 0, s, ix->box[l - 1],
@@ -745,11 +824,11 @@ pclhip::IndexView pclhip_index::view() const {
   v.pts = pts;
   v.soa = soa;
   v.nrm = nrm;
-  static const bool use_slabs = [] {  // A/B: PCLHIP_SLAB=0 searches with the axis-aligned boxes only
-    const char* e = getenv("PCLHIP_SLAB");
+  static const bool use_discs = [] {  // A/B: PCLHIP_DISC=0 searches with the axis-aligned boxes only
+    const char* e = getenv("PCLHIP_DISC");
     return !(e && atoi(e) == 0);
   }();
-  v.slab = use_slabs ? slab : nullptr;
+  v.disc = use_discs ? disc : nullptr;
   v.lv = lv_dev;
   for (int l = 0; l < pclhip::MAX_LEVELS; ++l) {
     v.box[l] = box[l];

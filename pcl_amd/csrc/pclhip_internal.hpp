@@ -49,8 +49,8 @@ struct IndexView {
   const float4* pts;
   const float* soa;             // per leaf: x[LEAF], y[LEAF], z[LEAF], w[LEAF] (LDS-staging copy)
   const float4* nrm;
-  const float4* slab;           // per leaf: unit-ish normal (|n| <= 1) and dmin of the slab dmin <= n.p <= dmax that
-                                // holds the leaf's points; dmax rides in box[1][leaf].hi.w.  nullptr: no slabs.
+  const float4* disc;           // per leaf two float4: (centre.xyz, R) (n.xyz, hn) of the bounded cylinder that holds
+                                // the leaf's points (traverse.hpp: point_disc_lb).  nullptr: search with boxes only.
   const LevelInfo* lv;          // [MAX_LEVELS] in device memory; lv[1] = leaves
   const Box* box[MAX_LEVELS];   // the same table in kernel arguments (SGPRs): selected with a
   uint32_t count[MAX_LEVELS];   // wave-uniform switch, no memory access on the traversal's critical path
@@ -131,7 +131,7 @@ struct pclhip_index {
   float4* pts = nullptr;
   float* soa = nullptr;
   float4* nrm = nullptr;
-  float4* slab = nullptr;
+  float4* disc = nullptr;
   uint32_t* rank = nullptr;
   pclhip::Box* box[pclhip::MAX_LEVELS] = {};
   pclhip::LevelInfo* lv_dev = nullptr;

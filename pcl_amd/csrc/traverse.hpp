@@ -39,8 +39,9 @@ template <int BUF_BYTES>
 struct __attribute__((aligned(16))) WaveLdsT {
   static constexpr int BUF_FLOATS = BUF_BYTES / 4;
   uint2 stack[STACK_ENTRIES];
-  float4 list[3 * FANOUT];  // per ranked leaf (lo.xyz, id) (hi.xyz, lbG) (slab normal.xyz, dmin)
-  float dmax[FANOUT];       // ... and the slab's dmax
+  float4 list[3 * FANOUT];  // per ranked leaf: seeded searches (lo.xyz, id) (hi.xyz, lbG) (-);
+                            // loose searches (disc centre.xyz, id) (-, -, -, lbG) (disc normal.xyz, hn), R in rad[]
+  float rad[FANOUT];
   float buf[BUF_FLOATS];
 };
 typedef WaveLdsT<LEAF_BATCH * LEAF_FLOATS * 4> WaveLds;  // 4 KB of staging: x y z w chunks of 16 leaves
@@ -77,32 +78,36 @@ __device__ __forceinline__ float box_box_lb(float Qlx, float Qly, float Qlz, flo
   return r;
 }
 
-// ---- oriented slab bounds ---------------------------------------------------------------------------
-// Every leaf also carries a slab {p : dmin <= n.p <= dmax} with |n| <= 1 that contains its points
-// (index_build.hip: leaf_slab_kernel).  |q - p| >= |n.q - n.p| for every p of the leaf, so
-// gap = max(n.q - dmax, dmin - n.q, 0) bounds the distance from below.  Unlike the AABB bound this one
-// is not bit-monotone; it is made safe instead: `eq` covers the rounding of the float dot product
-// (|n_i| <= 1: 4 ulp of |q|_1), the factor below the rounding of the differences, of the square and of the
-// l2_simple distance it is compared with.  On a sloped sheet the AABB of 16 points is ~10x thicker than the
-// slab, which is what decides how many leaves a query standing off the surface must evaluate.
-constexpr float SLAB_SHRINK = 0.999996f;
-__device__ __forceinline__ float slab_eps(float ax, float ay, float az) {  // |q| components, or box magnitudes
-  return 2.4e-7f * (ax + ay + az);
+// ---- disc bounds -------------------------------------------------------------------------------------
+// Every leaf also carries a bounded cylinder ("disc") that holds its points: centre c, radius R >= |p - c|,
+// direction n with |n| <= 1 (least variance of the leaf's points) and half thickness hn >= |n.(p - c)|
+// (index_build.hip: leaf_disc_kernel).  Splitting q - p into its parts along and across n,
+//     |q - p|^2 >= max(|n.q'| - hn, 0)^2 + max(|q'_perp| - R, 0)^2,     q' = q - c,
+// which couples the stand-off of a query from a sloped sheet with its offset along the sheet -- the axis-aligned
+// box of a 16-point patch is ~10x thicker than the patch and cannot: a query 0.015 off the surface has to
+// evaluate every leaf whose box it sees within sqrt(2 * 0.015 * thickness).  Unlike the AABB bound this one
+// is not bit-monotone; it is made safe instead: every rounding below is covered by an explicit allowance
+// (1e-6 relative, ~16 ulp, against 1-4 ulp of actual error), and the result is shrunk once more before it is
+// compared with a float l2_simple distance.  Used for loose searches only; seeded ones keep the exact boxes.
+constexpr float DISC_SHRINK = 0.999996f;
+__device__ __forceinline__ float point_disc_lb(float qx, float qy, float qz, const float4 cR, const float4 nh) {
+  const float dx = qx - cR.x, dy = qy - cR.y, dz = qz - cR.z;
+  const float r2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+  const float a = fabsf(__fmaf_rn(nh.z, dz, __fmaf_rn(nh.y, dy, __fmul_rn(nh.x, dx))));
+  const float e = 1e-6f * ((fabsf(dx) + fabsf(dy)) + fabsf(dz));  // rounding of the dot product
+  const float a_hi = a + e;                                        // >= |n.q'|
+  // across n: |q'|^2 - (n.q' / |n|)^2 with |n|^2 >= 1 - 1e-6 (the build shrinks n by 4e-7)
+  const float b2 = fmaxf(__fmaf_rn(r2, 0.999999f, -(a_hi * a_hi) * 1.000003f), 0.0f);
+  const float gt = fmaxf(__fmaf_rn(__fsqrt_rn(b2), 0.999999f, -cR.w), 0.0f);
+  const float gn = fmaxf((a - e) - nh.w, 0.0f);
+  return __fmaf_rn(gt, gt, gn * gn) * DISC_SHRINK;
 }
-__device__ __forceinline__ float point_slab_lb(float qx, float qy, float qz, float eq, float nx, float ny, float nz,
-                                               float dmin, float dmax) {
-  const float s = __fmaf_rn(nz, qz, __fmaf_rn(ny, qy, __fmul_rn(nx, qx)));
-  const float g = fmaxf(fmaxf(s - dmax, dmin - s), eq) - eq;  // max(s - dmax - eq, dmin - s - eq, 0)
-  return g * g * SLAB_SHRINK;
-}
-// the same for every q of the box [Ql, Qh]: the dot product ranges over [smin, smax]
-__device__ __forceinline__ float box_slab_lb(float Qlx, float Qly, float Qlz, float Qhx, float Qhy, float Qhz, float eQ,
-                                             float nx, float ny, float nz, float dmin, float dmax) {
-  const float ax = nx * Qlx, bx = nx * Qhx, ay = ny * Qly, by = ny * Qhy, az = nz * Qlz, bz = nz * Qhz;
-  const float smin = (fminf(ax, bx) + fminf(ay, by)) + fminf(az, bz);
-  const float smax = (fmaxf(ax, bx) + fmaxf(ay, by)) + fmaxf(az, bz);
-  const float g = fmaxf(fmaxf(smin - dmax, dmin - smax), eQ) - eQ;
-  return g * g * SLAB_SHRINK;
+// the same for every query of a group, through the group's bounding sphere (centre Qc, radius rQ rounded up):
+// |q - p| >= |Qc - p| - rQ
+__device__ __forceinline__ float group_disc_lb(float Qcx, float Qcy, float Qcz, float rQ, const float4 cR, const float4 nh) {
+  const float d = __fsqrt_rn(point_disc_lb(Qcx, Qcy, Qcz, cR, nh)) * 0.999999f - rQ;
+  const float g = fmaxf(d, 0.0f);
+  return g * g * DISC_SHRINK;
 }
 
 // ---- wavefront reductions (all 64 lanes must be active) ---------------------------------------
@@ -601,10 +606,10 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
   wave_min3_max4(lx0, ly0, lz0, hx0, hy0, hz0, T);
   const float Qlx = lx0, Qly = ly0, Qlz = lz0, Qhx = hx0, Qhy = hy0, Qhz = hz0;
   const float gdiag2 = (Qhx - Qlx) * (Qhx - Qlx) + (Qhy - Qly) * (Qhy - Qly) + (Qhz - Qlz) * (Qhz - Qlz);
-  // rounding allowances of the slab bounds (see point_slab_lb): for the group's box and for the lane's query
-  const float eQ = slab_eps(fmaxf(fabsf(Qlx), fabsf(Qhx)), fmaxf(fabsf(Qly), fabsf(Qhy)), fmaxf(fabsf(Qlz), fabsf(Qhz)));
-  const float eq = slab_eps(fabsf(qx[0]), fabsf(qy[0]), fabsf(qz[0]));
-  const bool have_slab = ix.slab != nullptr;
+  // bounding sphere of the group (for the disc bounds of loose searches), radius rounded up
+  const float Qcx = 0.5f * (Qlx + Qhx), Qcy = 0.5f * (Qly + Qhy), Qcz = 0.5f * (Qlz + Qhz);
+  const float rQ = __fsqrt_rn(gdiag2) * 0.5000005f + 1e-6f * ((fabsf(Qcx) + fabsf(Qcy)) + fabsf(Qcz));
+  const bool have_disc = ix.disc != nullptr;
   uint2* const stack = wl.stack;
 
   int sp = 0;
@@ -663,7 +668,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
     }
     const uint32_t nchild = (total - first) < uint32_t(FANOUT) ? (total - first) : uint32_t(FANOUT);
     const bool has = uint32_t(lane) < nchild;
-    float lx = 0, ly = 0, lz = 0, hx = 0, hy = 0, hz = 0, hw = 0;
+    float lx = 0, ly = 0, lz = 0, hx = 0, hy = 0, hz = 0;
     if (int(cl) >= ix.cache_from) {  // upper levels: boxes come from the block's LDS copy
       if (has) {
         const Box b = topbox[coff + first + lane];
@@ -674,7 +679,6 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
       const Box b = level_box[first + lane];
       lx = b.lo.x; ly = b.lo.y; lz = b.lo.z;
       hx = b.hi.x; hy = b.hi.y; hz = b.hi.z;
-      hw = b.hi.w;  // leaves: the slab's dmax
     }
     float lbG = has ? box_box_lb(Qlx, Qly, Qlz, Qhx, Qhy, Qhz, lx, ly, lz, hx, hy, hz) : INF;
     // Visiting order.  Cold or lukewarm bounds (wave radius not yet small against the group's own
@@ -682,13 +686,13 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
     // collapse after the first few leaves and everything farther is cut off at once.  Tight bounds
     // (seeded steady state): plain index order, no ranking work.
     const bool ordered = T * 16.0f > gdiag2;
-    // Leaves of a loose search are also bounded by their oriented slab: a query standing off a sloped sheet
-    // is much farther from the sheet's slab than from the axis-aligned boxes of its 16-point patches.
-    const bool use_slab = have_slab && ordered && cl == 1u;
-    float4 sl = make_float4(0, 0, 0, 0);
-    if (use_slab && has) {
-      sl = ix.slab[first + lane];
-      lbG = fmaxf(lbG, box_slab_lb(Qlx, Qly, Qlz, Qhx, Qhy, Qhz, eQ, sl.x, sl.y, sl.z, sl.w, hw));
+    // Leaves of a loose search are bounded by their discs (see point_disc_lb)
+    const bool use_disc = have_disc && ordered && cl == 1u;
+    float4 dcR = make_float4(0, 0, 0, 0), dnh = make_float4(0, 0, 0, 0);
+    if (use_disc && has) {
+      dcR = ix.disc[2 * (first + lane)];
+      dnh = ix.disc[2 * (first + lane) + 1];
+      lbG = fmaxf(lbG, group_disc_lb(Qcx, Qcy, Qcz, rQ, dcR, dnh));
     }
     const bool alive = has && !(lbG > T);
     const uint64_t mask = __builtin_amdgcn_ballot_w64(alive);
@@ -706,11 +710,14 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
       }
       const uint32_t n_alive = uint32_t(__builtin_popcountll(mask));
       if (alive) {
-        wl.list[3 * rank] = make_float4(lx, ly, lz, __uint_as_float(first + uint32_t(lane)));
-        wl.list[3 * rank + 1] = make_float4(hx, hy, hz, lbG);
-        if (use_slab) {
-          wl.list[3 * rank + 2] = sl;
-          wl.dmax[rank] = hw;
+        if (use_disc) {
+          wl.list[3 * rank] = make_float4(dcR.x, dcR.y, dcR.z, __uint_as_float(first + uint32_t(lane)));
+          wl.list[3 * rank + 1] = make_float4(0.0f, 0.0f, 0.0f, lbG);
+          wl.list[3 * rank + 2] = dnh;
+          wl.rad[rank] = dcR.w;
+        } else {
+          wl.list[3 * rank] = make_float4(lx, ly, lz, __uint_as_float(first + uint32_t(lane)));
+          wl.list[3 * rank + 1] = make_float4(hx, hy, hz, lbG);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -763,10 +770,12 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
                 break;
               }
               ++ts.c[1];
-              float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
-              if (use_slab) {
+              float lb;
+              if (use_disc) {
                 const float4 es = wl.list[3 * (b0 + t) + 2];
-                lb = fmaxf(lb, point_slab_lb(qx[0], qy[0], qz[0], eq, es.x, es.y, es.z, es.w, wl.dmax[b0 + t]));
+                lb = point_disc_lb(qx[0], qy[0], qz[0], make_float4(ea.x, ea.y, ea.z, wl.rad[b0 + t]), es);
+              } else {
+                lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
               }
               bool need = valid[0] && !(lb > pol.worst(0));
               if (__builtin_amdgcn_ballot_w64(need && pid != NO_INDEX) != 0) {
@@ -862,11 +871,12 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
           bool need = false;
 #pragma unroll
           for (int q = 0; q < QPL; ++q) {
-            float lb = point_box_lb(qx[q], qy[q], qz[q], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
-            if (use_slab) {
+            float lb;
+            if (use_disc) {
               const float4 es = wl.list[3 * (b0 + t) + 2];
-              lb = fmaxf(lb, point_slab_lb(qx[q], qy[q], qz[q], slab_eps(fabsf(qx[q]), fabsf(qy[q]), fabsf(qz[q])), es.x,
-                                           es.y, es.z, es.w, wl.dmax[b0 + t]));
+              lb = point_disc_lb(qx[q], qy[q], qz[q], make_float4(ea.x, ea.y, ea.z, wl.rad[b0 + t]), es);
+            } else {
+              lb = point_box_lb(qx[q], qy[q], qz[q], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
             }
             need = need || (valid[q] && !(lb > pol.worst(q)));
           }

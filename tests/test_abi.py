@@ -126,3 +126,54 @@ def test_host_solvers_match_the_oracle_on_cpu():
     assert np.abs(solve(rec, _lib.POINT_TO_POINT) - orc.umeyama(src, tgt, acc_double=True)).max() < 2e-6
     assert lib.pclhip_solve_transformation(np.zeros(32).ctypes.data_as(C.POINTER(C.c_double)), 7,
                                            np.zeros(16, np.float32).ctypes.data_as(C.POINTER(C.c_float))) != 0
+
+
+def test_convergence_criteria_twin_matches_the_oracle():
+    """pclhip_convergence_has_converged (the host instantiation of the code icp_solve_kernel runs on the device,
+    pcl_amd/csrc/closed_forms.hpp) against the oracle's restatement of
+    impl/default_convergence_criteria.hpp:49-140 on random iteration histories, for every option."""
+    import numpy as np
+
+    from oracle import pcl_oracle as orc
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for trial in range(300):
+        p = _lib.IcpParams()
+        lib.pclhip_icp_params_default(C.byref(p))
+        p.max_iterations = int(rng.integers(2, 12))
+        p.failure_after_max_iterations = int(rng.integers(0, 2))
+        p.max_iterations_similar_transforms = int(rng.integers(0, 3))
+        p.transformation_epsilon = float(rng.choice([0.0, 1e-8, 1e-4]))
+        p.transformation_rotation_epsilon = float(rng.choice([0.0, 0.9999]))
+        p.euclidean_fitness_epsilon = float(rng.choice([-1e300, 1e-3, 0.5]))
+        p.mse_threshold_absolute = float(rng.choice([1e-12, 1e-5]))
+        st = _lib.ConvergenceState()
+        lib.pclhip_convergence_init(C.byref(st))
+        oc = orc.new_convergence()
+        oc.max_iterations = p.max_iterations
+        oc.failure_after_max_iter = p.failure_after_max_iterations
+        oc.max_iterations_similar_transforms = p.max_iterations_similar_transforms
+        oc.rotation_threshold = p.transformation_rotation_epsilon if p.transformation_rotation_epsilon > 0 else 0.99999
+        oc.translation_threshold = p.transformation_epsilon
+        oc.mse_threshold_relative = p.euclidean_fitness_epsilon
+        oc.mse_threshold_absolute = p.mse_threshold_absolute
+        mse = float(rng.uniform(1e-3, 1e-2))
+        for align in range(2):          # the memory persists across alignments
+            for it in range(1, 40):
+                ang = float(rng.choice([0.0, 1e-6, 1e-3, 3e-2])) * float(rng.uniform(0.5, 1.0))
+                T = np.eye(4, dtype=np.float32)
+                T[0, 0] = T[1, 1] = np.cos(ang)
+                T[0, 1], T[1, 0] = -np.sin(ang), np.sin(ang)
+                T[:3, 3] = rng.uniform(-1, 1, 3) * float(rng.choice([0.0, 1e-6, 1e-2]))
+                mse *= float(rng.choice([1.0, 1.0 - 1e-7, 0.9, 0.5]))
+                Tf = np.ascontiguousarray(T.reshape(16))
+                a = lib.pclhip_convergence_has_converged(C.byref(p), C.byref(st), it,
+                                                         Tf.ctypes.data_as(C.POINTER(C.c_float)), mse)
+                b = orc.lib().orc_convergence_has_converged(C.byref(oc), it, Tf.ctypes.data_as(C.POINTER(C.c_float)),
+                                                            C.c_double(mse))
+                assert bool(a) == bool(b), (trial, align, it)
+                assert st.convergence_state == oc.convergence_state, (trial, align, it)
+                assert st.iterations_similar_transforms == oc.iterations_similar_transforms
+                assert st.prev_mse == oc.correspondences_prev_mse
+                if st.convergence_state != 0:
+                    break
