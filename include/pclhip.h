@@ -81,6 +81,16 @@ PCLHIP_API pclhip_status pclhip_ctx_stats(pclhip_ctx* ctx, int enable, uint64_t*
 PCLHIP_API pclhip_status pclhip_index_build(pclhip_ctx* ctx, const void* points, size_t stride_bytes,
                                             uint64_t n, const int32_t* indices, uint64_t n_indices,
                                             pclhip_index** out);
+/* The same through a pcl::PointRepresentation that maps a point to (x, y, z) times per-axis rescale values
+ * (pcl::search::KdTree::setPointRepresentation, search/include/pcl/search/kdtree.h:110; KdTreeFLANN vectorises
+ * every point with it, kdtree_flann.hpp:463-498; CustomPointRepresentation / setRescaleValues,
+ * common/include/pcl/point_representation.h:150-190,546-579): the index holds coordinate * scale[axis], queries of
+ * pclhip_knn / pclhip_radius_search are mapped the same way, distances are those of the rescaled space.  A
+ * scale of 0 removes the axis (e.g. {1, 1, 0}: the x-y representation; that coordinate need not be finite).
+ * scale == NULL: the default representation.  Registration (pclhip_icp_create) needs the default one. */
+PCLHIP_API pclhip_status pclhip_index_build_scaled(pclhip_ctx* ctx, const void* points, size_t stride_bytes,
+                                                   uint64_t n, const int32_t* indices, uint64_t n_indices,
+                                                   const float scale[3], pclhip_index** out);
 PCLHIP_API void pclhip_index_destroy(pclhip_index* index);
 /* number of finite points indexed */
 PCLHIP_API uint64_t pclhip_index_size(const pclhip_index* index);
@@ -195,6 +205,13 @@ PCLHIP_API void pclhip_icp_destroy(pclhip_icp* icp);
 /* Registration::setInputSource (registration.h:195-196): uploads + kd-orders the source. */
 PCLHIP_API pclhip_status pclhip_icp_set_source(pclhip_icp* icp, const void* points,
                                                size_t stride_bytes, uint64_t n);
+/* The same with PCLBase::setIndices (common/include/pcl/pcl_base.h:102-125) / CorrespondenceEstimationBase::
+ * setIndicesSource (registration/include/pcl/registration/correspondence_estimation.h:194): only
+ * points[indices[j]] take part in the correspondence search and the estimation; correspondences still carry
+ * index_query into the ORIGINAL cloud.  indices == NULL: every point.  (The registered output of align() is
+ * the whole input cloud moved by the final transformation either way, impl/icp.hpp:264-267.) */
+PCLHIP_API pclhip_status pclhip_icp_set_source_indexed(pclhip_icp* icp, const void* points, size_t stride_bytes,
+                                                       uint64_t n, const int32_t* indices, uint64_t n_indices);
 /* Normals of the source cloud, one record per source point in the order given to
  * pclhip_icp_set_source (a pcl::PointNormal source: normals = points + 16, stride 48).  Required by
  * PCLHIP_ICP_SYMMETRIC; call after pclhip_icp_set_source. */

@@ -1,0 +1,440 @@
+// pcl_plugin.hpp -- the binding that plugs libpclhip.so INTO real PCL objects: subclasses of PCL's own virtual
+// plugin points, written against PCL's public headers only.  A PCL application switches by constructing these
+// instead of the stock classes; everything else (setters, getters, align(), the containers) is PCL's own code.
+//
+//   pclhip::plugin::KdTreeHIP<PointT>                    : pcl::search::KdTree<PointT>
+//        search/include/pcl/search/kdtree.h:61-168 -- what Registration::setSearchMethodTarget,
+//        CorrespondenceEstimationBase::setSearchMethodTarget and Feature::setSearchMethod accept
+//   pclhip::plugin::CorrespondenceEstimationHIP<S,T>     : pcl::registration::CorrespondenceEstimationBase<S,T,float>
+//        registration/include/pcl/registration/correspondence_estimation.h:62-330 -- the BATCH entry
+//        (Registration::setCorrespondenceEstimation, registration.h:173-177)
+//   pclhip::plugin::IterativeClosestPointHIP<S,T>        : pcl::IterativeClosestPoint<S,T,float>
+//   pclhip::plugin::IterativeClosestPointWithNormalsHIP  : pcl::IterativeClosestPointWithNormals<S,T,float>
+//        override the protected computeTransformation (registration.h:678-679, icp.h:292-293): the whole loop
+//        of impl/icp.hpp:113-268 runs on the device
+//
+// Compiled and run here against tests/cpp/pcl_mock (a stand-in for the PCL base classes with the same
+// signatures; PCL itself needs Eigen/Boost/FLANN, which this image lacks): tests/cpp/test_pcl_plugin.cpp.
+// Matrices cross the boundary through operator()(row, col) only, so Eigen's storage order does not matter.
+#pragma once
+
+#include <pcl/registration/correspondence_estimation.h>
+#include <pcl/registration/icp.h>
+#include <pcl/search/kdtree.h>
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../pclhip.h"
+
+namespace pclhip {
+namespace plugin {
+
+// One device context shared by the objects of an application (pclhip_ctx).
+class Device {
+ public:
+  using Ptr = std::shared_ptr<Device>;
+  explicit Device(int device = 0, void* hip_stream = nullptr) {
+    if (pclhip_ctx_create(device, hip_stream, &ctx_) != PCLHIP_OK) ctx_ = nullptr;
+  }
+  ~Device() { if (ctx_) pclhip_ctx_destroy(ctx_); }
+  Device(const Device&) = delete;
+  Device& operator=(const Device&) = delete;
+  pclhip_ctx* get() const { return ctx_; }
+  bool ok() const { return ctx_ != nullptr; }
+  static Ptr instance() {  // the default device of the process
+    static Ptr d = std::make_shared<Device>(0);
+    return d;
+  }
+ private:
+  pclhip_ctx* ctx_ = nullptr;
+};
+
+template <typename PointT> constexpr bool has_normal_fields() { return sizeof(PointT) >= 48; }  // PointNormal layout
+
+// ---- search backend ---------------------------------------------------------------------------------
+template <typename PointT>
+class KdTreeHIP : public pcl::search::KdTree<PointT> {
+  using Base = pcl::search::KdTree<PointT>;
+ public:
+  using Ptr = std::shared_ptr<KdTreeHIP<PointT>>;
+  using PointCloudConstPtr = typename Base::PointCloudConstPtr;
+  using IndicesConstPtr = pcl::IndicesConstPtr;
+  using PointRepresentationConstPtr = typename Base::PointRepresentationConstPtr;
+
+  // the protected constructor leaves the FLANN tree_ unset (kdtree.h:165-167), as KdTreeNanoflann does
+  explicit KdTreeHIP(Device::Ptr dev = Device::instance(), bool sorted = true) : Base("KdTreeHIP", sorted), dev_(std::move(dev)) {}
+  ~KdTreeHIP() override { if (index_) pclhip_index_destroy(index_); }
+  KdTreeHIP(const KdTreeHIP&) = delete;
+  KdTreeHIP& operator=(const KdTreeHIP&) = delete;
+
+  // search/include/pcl/search/impl/kdtree.hpp:87-97: always rebuilds, like the reference
+  bool setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) override {
+    if (index_) { pclhip_index_destroy(index_); index_ = nullptr; }
+    this->input_ = cloud;
+    this->indices_ = indices;
+    if (!dev_ || !dev_->ok() || !cloud) return false;
+    const bool use_idx = indices && !indices->empty();
+    return pclhip_index_build_scaled(dev_->get(), cloud->points.data(), sizeof(PointT), cloud->size(),
+                                     use_idx ? indices->data() : nullptr, use_idx ? indices->size() : 0,
+                                     scaled_ ? scale_ : nullptr, &index_) == PCLHIP_OK;
+  }
+  // The index is three-dimensional: a representation is honoured when it is x, y, z (or a prefix of them)
+  // with per-axis rescale factors (kdtree.h:110 -> KdTreeFLANN::setPointRepresentation); anything else is
+  // refused loudly -- searches would silently mean something different.
+  void setPointRepresentation(const PointRepresentationConstPtr& rep) override {
+    rep_ = rep;
+    scaled_ = false;
+    if (!rep) return;
+    const int d = rep->getNumberOfDimensions();
+    float probe[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    bool ok = d >= 1 && d <= 3;
+    for (int a = 0; a < 3 && ok; ++a) {
+      PointT p;
+      p.x = a == 0 ? 1.0f : 0.0f; p.y = a == 1 ? 1.0f : 0.0f; p.z = a == 2 ? 1.0f : 0.0f;
+      std::vector<float> out(size_t(d), 0.0f);
+      rep->vectorize(p, out);
+      for (int j = 0; j < d; ++j) probe[a][j] = out[size_t(j)];
+    }
+    for (int a = 0; a < 3 && ok; ++a)
+      for (int j = 0; j < 3; ++j)
+        if (j != a && probe[a][j] != 0.0f) ok = false;  // not a diagonal map of (x, y, z)
+    if (!ok) {
+      unsupported_ = true;
+      return;
+    }
+    unsupported_ = false;
+    for (int a = 0; a < 3; ++a) scale_[a] = a < d ? probe[a][a] : 0.0f;
+    scaled_ = !(scale_[0] == 1.0f && scale_[1] == 1.0f && scale_[2] == 1.0f);
+    if (this->input_) setInputCloud(this->input_, this->indices_);
+  }
+  PointRepresentationConstPtr getPointRepresentation() const override { return rep_; }
+  bool representationSupported() const { return !unsupported_; }
+  void setEpsilon(float eps) override { eps_ = eps; }  // the search is exact: an error bound is trivially met
+  float getEpsilon() const override { return eps_; }
+
+  // kdtree/include/pcl/kdtree/impl/kdtree_flann.hpp:234-274 (one launch per call: API parity, not the fast path)
+  int nearestKSearch(const PointT& p, int k, pcl::Indices& k_indices, std::vector<float>& k_sqr_distances) const override {
+    k_indices.clear();
+    k_sqr_distances.clear();
+    if (!index_ || unsupported_ || k < 1) return 0;
+    const std::uint64_t n = pclhip_index_size(index_);
+    if (std::uint64_t(k) > n) k = int(n);
+    if (k == 0) return 0;
+    k_indices.resize(size_t(k));
+    k_sqr_distances.resize(size_t(k));
+    if (pclhip_knn(index_, &p, sizeof(PointT), 1, k, k_indices.data(), k_sqr_distances.data()) != PCLHIP_OK) return 0;
+    int found = 0;
+    while (found < k && k_indices[size_t(found)] >= 0) ++found;
+    k_indices.resize(size_t(found));
+    k_sqr_distances.resize(size_t(found));
+    return found;
+  }
+  // the batch overload (search.h:216-219): ONE launch for the whole cloud
+  void nearestKSearch(const pcl::PointCloud<PointT>& cloud, const pcl::Indices& indices, int k,
+                      std::vector<pcl::Indices>& k_indices, std::vector<std::vector<float>>& k_sqr_distances) const override {
+    k_indices.clear();
+    k_sqr_distances.clear();
+    if (!index_ || unsupported_ || k < 1) return;
+    std::vector<PointT> gathered;
+    const PointT* q = cloud.points.data();
+    std::size_t nq = cloud.size();
+    if (!indices.empty()) {
+      gathered.reserve(indices.size());
+      for (pcl::index_t i : indices) gathered.push_back(cloud[size_t(i)]);
+      q = gathered.data();
+      nq = gathered.size();
+    }
+    const std::uint64_t n = pclhip_index_size(index_);
+    const int kk = std::uint64_t(k) > n ? int(n) : k;
+    k_indices.assign(nq, pcl::Indices());
+    k_sqr_distances.assign(nq, std::vector<float>());
+    if (kk == 0 || nq == 0) return;
+    pcl::Indices flat_i(nq * size_t(kk));
+    std::vector<float> flat_d(nq * size_t(kk));
+    if (pclhip_knn(index_, q, sizeof(PointT), nq, kk, flat_i.data(), flat_d.data()) != PCLHIP_OK) return;
+    for (std::size_t i = 0; i < nq; ++i) {
+      int found = 0;
+      while (found < kk && flat_i[i * size_t(kk) + size_t(found)] >= 0) ++found;
+      k_indices[i].assign(flat_i.begin() + long(i * size_t(kk)), flat_i.begin() + long(i * size_t(kk)) + found);
+      k_sqr_distances[i].assign(flat_d.begin() + long(i * size_t(kk)), flat_d.begin() + long(i * size_t(kk)) + found);
+    }
+  }
+  // kdtree_flann.hpp:372-414: squared distance < radius^2, ascending; max_nn == 0: unlimited
+  int radiusSearch(const PointT& p, double radius, pcl::Indices& k_indices, std::vector<float>& k_sqr_distances,
+                   unsigned int max_nn = 0) const override {
+    k_indices.clear();
+    k_sqr_distances.clear();
+    if (!index_ || unsupported_) return 0;
+    std::uint64_t off[2] = {0, 0}, total = 0;
+    const pclhip_status st = pclhip_radius_search(index_, &p, sizeof(PointT), 1, radius, max_nn, off, nullptr, nullptr, 0, &total);
+    if ((st != PCLHIP_OK && st != PCLHIP_ERR_OVERFLOW) || total == 0) return 0;
+    k_indices.resize(size_t(total));
+    k_sqr_distances.resize(size_t(total));
+    if (pclhip_radius_search(index_, &p, sizeof(PointT), 1, radius, max_nn, off, k_indices.data(), k_sqr_distances.data(),
+                             total, &total) != PCLHIP_OK) {
+      k_indices.clear();
+      k_sqr_distances.clear();
+      return 0;
+    }
+    return int(total);
+  }
+  pclhip_index* handle() const { return index_; }
+  const Device::Ptr& device() const { return dev_; }
+
+ private:
+  Device::Ptr dev_;
+  pclhip_index* index_ = nullptr;
+  PointRepresentationConstPtr rep_;
+  float scale_[3] = {1, 1, 1};
+  bool scaled_ = false, unsupported_ = false;
+  float eps_ = 0.0f;
+};
+
+// ---- the batch correspondence entry -------------------------------------------------------------------
+template <typename PointSource, typename PointTarget, typename Scalar = float>
+class CorrespondenceEstimationHIP : public pcl::registration::CorrespondenceEstimationBase<PointSource, PointTarget, Scalar> {
+  using Base = pcl::registration::CorrespondenceEstimationBase<PointSource, PointTarget, Scalar>;
+ public:
+  using Ptr = std::shared_ptr<CorrespondenceEstimationHIP<PointSource, PointTarget, Scalar>>;
+  CorrespondenceEstimationHIP() { this->corr_name_ = "CorrespondenceEstimationHIP"; }
+  ~CorrespondenceEstimationHIP() override { if (icp_) pclhip_icp_destroy(icp_); }
+  CorrespondenceEstimationHIP(const CorrespondenceEstimationHIP& o) : Base(o) { this->corr_name_ = "CorrespondenceEstimationHIP"; }
+
+  // impl/correspondence_estimation.hpp:145-218 for the whole cloud in one launch
+  void determineCorrespondences(pcl::Correspondences& correspondences,
+                                double max_distance = std::numeric_limits<double>::max()) override {
+    run(correspondences, max_distance, false);
+  }
+  // :220-311
+  void determineReciprocalCorrespondences(pcl::Correspondences& correspondences,
+                                          double max_distance = std::numeric_limits<double>::max()) override {
+    run(correspondences, max_distance, true);
+  }
+  typename Base::Ptr clone() const override {
+    return typename Base::Ptr(new CorrespondenceEstimationHIP<PointSource, PointTarget, Scalar>(*this));
+  }
+
+ private:
+  void run(pcl::Correspondences& out, double max_distance, bool reciprocal) {
+    out.clear();
+    if (!this->initCompute()) return;  // PCL's own bookkeeping: (re)builds the target tree when it changed
+    auto* tree = dynamic_cast<KdTreeHIP<PointTarget>*>(this->tree_.get());
+    if (tree == nullptr || tree->handle() == nullptr) { this->deinitCompute(); return; }  // needs the HIP search backend
+    if (icp_ && icp_target_ != tree->handle()) { pclhip_icp_destroy(icp_); icp_ = nullptr; }
+    if (!icp_) {
+      if (pclhip_icp_create(tree->handle(), &icp_) != PCLHIP_OK) { this->deinitCompute(); return; }
+      icp_target_ = tree->handle();
+    }
+    const bool subset = this->indices_ && this->indices_->size() != this->input_->size();
+    static const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double sums[PCLHIP_ICP_NSUMS];
+    // the squared distances of ALL pairs up to max_distance are wanted: pass the distance itself
+    const double md = max_distance < 1e150 ? max_distance : 1e150;
+    if (pclhip_icp_set_source_indexed(icp_, this->input_->points.data(), sizeof(PointSource), this->input_->size(),
+                                      subset ? this->indices_->data() : nullptr, subset ? this->indices_->size() : 0) == PCLHIP_OK &&
+        pclhip_icp_set_reciprocal(icp_, reciprocal ? 1 : 0) == PCLHIP_OK &&
+        pclhip_icp_iterate(icp_, I, md, PCLHIP_ICP_POINT_TO_POINT, sums) == PCLHIP_OK) {
+      const std::size_t n = this->input_->size();
+      pcl::Indices q(n), m(n);
+      std::vector<float> d(n);
+      std::uint64_t cnt = 0;
+      if (pclhip_icp_fetch_correspondences(icp_, q.data(), m.data(), d.data(), &cnt) == PCLHIP_OK) {
+        out.reserve(size_t(cnt));
+        for (std::uint64_t i = 0; i < cnt; ++i) out.emplace_back(q[size_t(i)], m[size_t(i)], d[size_t(i)]);
+      }
+    }
+    this->deinitCompute();
+  }
+  pclhip_icp* icp_ = nullptr;
+  pclhip_index* icp_target_ = nullptr;
+};
+
+// ---- the whole loop on the device ------------------------------------------------------------------------
+// Shared body of the two ICP subclasses.  `Base` is pcl::IterativeClosestPoint<S,T,float> or
+// pcl::IterativeClosestPointWithNormals<S,T,float>.
+template <typename Base, typename PointSource, typename PointTarget>
+class RegistrationHIP : public Base {
+ public:
+  using PointCloudSource = pcl::PointCloud<PointSource>;
+  using Matrix4 = typename Base::Matrix4;
+  ~RegistrationHIP() override { if (icp_) pclhip_icp_destroy(icp_); }
+  // Why the last align() ran where it ran: "" = device; otherwise the reason it deferred to PCL's CPU loop.
+  const std::string& deferredReason() const { return deferred_; }
+  // Registration::getFitnessScore (impl/registration.hpp:132-168) on the device (after an align())
+  double getFitnessScore(double max_range = std::numeric_limits<double>::max()) override {
+    if (!icp_) return Base::getFitnessScore(max_range);
+    float T[16];
+    to_rows(this->final_transformation_, T);
+    double score = std::numeric_limits<double>::max();
+    pclhip_icp_fitness_score(icp_, T, max_range, &score, nullptr);
+    return score;
+  }
+
+ protected:
+  enum Kind { SVD = PCLHIP_ICP_POINT_TO_POINT, LLS = PCLHIP_ICP_POINT_TO_PLANE, SYM = PCLHIP_ICP_SYMMETRIC, FOREIGN = -1 };
+  virtual bool enforceSameDirectionNormals() const { return true; }
+
+  static void to_rows(const Matrix4& M, float* T) {
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) T[4 * r + c] = M(r, c);
+  }
+  static void from_rows(const float* T, Matrix4& M) {
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) M(r, c) = T[4 * r + c];
+  }
+  Kind estimatorKind() const {
+    using namespace pcl::registration;
+    const auto* te = this->transformation_estimation_.get();
+    if (dynamic_cast<const TransformationEstimationSymmetricPointToPlaneLLS<PointSource, PointTarget, float>*>(te)) return SYM;
+    if (dynamic_cast<const TransformationEstimationPointToPlaneLLS<PointSource, PointTarget, float>*>(te)) return LLS;
+    if (dynamic_cast<const TransformationEstimationSVD<PointSource, PointTarget, float>*>(te)) return SVD;
+    return FOREIGN;
+  }
+  // the rejectors the device chain knows, recognised by class name (registration.h:518-547)
+  bool mapRejectors(std::vector<pclhip_rejector>& out) const {
+    using namespace pcl::registration;
+    for (const auto& r : this->correspondence_rejectors_) {
+      pclhip_rejector d{PCLHIP_REJ_DISTANCE, 0.0, 0, 0};
+      const std::string& name = r->getClassName();
+      if (name == "CorrespondenceRejectorDistance") {
+        d.kind = PCLHIP_REJ_DISTANCE;
+        d.param = static_cast<const CorrespondenceRejectorDistance*>(r.get())->getMaximumDistance();
+      } else if (name == "CorrespondenceRejectorMedianDistance") {
+        d.kind = PCLHIP_REJ_MEDIAN_DISTANCE;
+        d.param = static_cast<const CorrespondenceRejectorMedianDistance*>(r.get())->getMedianFactor();
+      } else if (name == "CorrespondenceRejectorOneToOne") {
+        d.kind = PCLHIP_REJ_ONE_TO_ONE;
+      } else if (name == "CorrespondenceRejectorTrimmed") {
+        const auto* t = static_cast<const CorrespondenceRejectorTrimmed*>(r.get());
+        d.kind = PCLHIP_REJ_TRIMMED;
+        d.param = t->getOverlapRatio();
+        d.min_correspondences = t->getMinCorrespondences();
+      } else {
+        return false;
+      }
+      out.push_back(d);
+    }
+    return true;
+  }
+
+  // impl/icp.hpp:113-268 on the device.  Anything this path cannot express exactly -- a foreign search
+  // backend, estimator, correspondence estimator or rejector -- defers to PCL's own loop, so behaviour
+  // never changes silently.
+  void computeTransformation(PointCloudSource& output, const Matrix4& guess) override {
+    using namespace pcl::registration;
+    deferred_.clear();
+    auto* tree = dynamic_cast<KdTreeHIP<PointTarget>*>(this->tree_.get());
+    const Kind kind = estimatorKind();
+    std::vector<pclhip_rejector> rej;
+    const auto* ce = this->correspondence_estimation_.get();
+    const bool own_ce = ce == nullptr || dynamic_cast<const CorrespondenceEstimationHIP<PointSource, PointTarget, float>*>(ce) ||
+                        dynamic_cast<const CorrespondenceEstimation<PointSource, PointTarget, float>*>(ce);
+    if (tree == nullptr || tree->handle() == nullptr) deferred_ = "the target search method is not a KdTreeHIP";
+    else if (!tree->representationSupported()) deferred_ = "the point representation is not a rescaled (x, y, z)";
+    else if (kind == FOREIGN) deferred_ = "foreign TransformationEstimation";
+    else if (!own_ce) deferred_ = "foreign CorrespondenceEstimation";
+    else if (!mapRejectors(rej)) deferred_ = "foreign CorrespondenceRejector";
+    else if (kind != SVD && !has_normal_fields<PointTarget>()) deferred_ = "point-to-plane needs a target type with normals";
+    else if (kind == SYM && !has_normal_fields<PointSource>()) deferred_ = "the symmetric objective needs a source type with normals";
+    if (!deferred_.empty()) {
+      Base::computeTransformation(output, guess);
+      return;
+    }
+    if (icp_ && icp_target_ != tree->handle()) { pclhip_icp_destroy(icp_); icp_ = nullptr; }
+    if (!icp_) {
+      if (pclhip_icp_create(tree->handle(), &icp_) != PCLHIP_OK) return;
+      icp_target_ = tree->handle();
+      source_uploaded_ = nullptr;
+      target_normals_of_ = nullptr;
+    }
+    if (kind != SVD && target_normals_of_ != this->target_.get()) {  // pcl::PointNormal: normals at +16
+      const char* base = reinterpret_cast<const char*>(this->target_->points.data());
+      if (pclhip_index_set_normals(tree->handle(), base + 16, sizeof(PointTarget)) != PCLHIP_OK) return;
+      target_normals_of_ = this->target_.get();
+    }
+    const bool subset = this->indices_ && this->indices_->size() != this->input_->size();
+    if (source_uploaded_ != this->input_.get() || this->source_cloud_updated_ || subset != source_subset_) {
+      if (pclhip_icp_set_source_indexed(icp_, this->input_->points.data(), sizeof(PointSource), this->input_->size(),
+                                        subset ? this->indices_->data() : nullptr, subset ? this->indices_->size() : 0) != PCLHIP_OK)
+        return;
+      if (kind == SYM) {
+        const char* base = reinterpret_cast<const char*>(this->input_->points.data());
+        if (pclhip_icp_set_source_normals(icp_, base + 16, sizeof(PointSource)) != PCLHIP_OK) return;
+      }
+      source_uploaded_ = this->input_.get();
+      source_subset_ = subset;
+      this->source_cloud_updated_ = false;
+    }
+    if (pclhip_icp_set_rejectors(icp_, rej.data(), int(rej.size())) != PCLHIP_OK) return;
+    if (pclhip_icp_set_reciprocal(icp_, this->use_reciprocal_correspondence_ ? 1 : 0) != PCLHIP_OK) return;
+    if (pclhip_icp_set_enforce_same_direction_normals(icp_, enforceSameDirectionNormals() ? 1 : 0) != PCLHIP_OK) return;
+
+    pclhip_icp_params p;
+    pclhip_icp_params_default(&p);
+    p.mode = int(kind);
+    p.max_iterations = this->max_iterations_;
+    p.max_correspondence_distance = this->corr_dist_threshold_;
+    p.transformation_epsilon = this->transformation_epsilon_;
+    p.transformation_rotation_epsilon = this->transformation_rotation_epsilon_;
+    p.euclidean_fitness_epsilon = this->euclidean_fitness_epsilon_;
+    p.min_number_correspondences = int(this->min_number_correspondences_);
+    p.failure_after_max_iterations = this->convergence_criteria_->getFailureAfterMaximumIterations() ? 1 : 0;
+    p.max_iterations_similar_transforms = this->convergence_criteria_->getMaximumIterationsSimilarTransforms();
+    p.mse_threshold_absolute = this->convergence_criteria_->getAbsoluteMSE();
+    float g[16];
+    to_rows(guess, g);
+    pclhip_icp_result r;
+    if (pclhip_icp_align(icp_, &p, g, &r) != PCLHIP_OK) return;
+    from_rows(r.final_transformation, this->final_transformation_);
+    from_rows(r.last_transformation, this->transformation_);
+    this->nr_iterations_ = r.nr_iterations;
+    this->converged_ = r.converged != 0;
+    using Criteria = DefaultConvergenceCriteria<float>;
+    this->convergence_criteria_->setConvergenceState(static_cast<typename Criteria::ConvergenceState>(r.convergence_state));
+    output = *this->input_;  // impl/icp.hpp:264-267: the whole input cloud, moved by the final transformation
+    pclhip_transform_cloud(tree->device()->get(), r.final_transformation, kind == SVD ? 0 : 1, this->input_->points.data(),
+                           output.points.data(), sizeof(PointSource), output.size(),
+                           (kind != SVD && has_normal_fields<PointSource>()) ? 16 : 0);
+  }
+
+ private:
+  pclhip_icp* icp_ = nullptr;
+  pclhip_index* icp_target_ = nullptr;
+  const void* source_uploaded_ = nullptr;
+  const void* target_normals_of_ = nullptr;
+  bool source_subset_ = false;
+  std::string deferred_;
+};
+
+template <typename PointSource, typename PointTarget>
+class IterativeClosestPointHIP
+    : public RegistrationHIP<pcl::IterativeClosestPoint<PointSource, PointTarget, float>, PointSource, PointTarget> {
+ public:
+  using Ptr = std::shared_ptr<IterativeClosestPointHIP<PointSource, PointTarget>>;
+  explicit IterativeClosestPointHIP(Device::Ptr dev = Device::instance()) {
+    this->reg_name_ = "IterativeClosestPointHIP";
+    this->setSearchMethodTarget(std::make_shared<KdTreeHIP<PointTarget>>(dev));
+    this->setCorrespondenceEstimation(std::make_shared<CorrespondenceEstimationHIP<PointSource, PointTarget, float>>());
+  }
+};
+
+template <typename PointSource, typename PointTarget>
+class IterativeClosestPointWithNormalsHIP
+    : public RegistrationHIP<pcl::IterativeClosestPointWithNormals<PointSource, PointTarget, float>, PointSource, PointTarget> {
+ public:
+  using Ptr = std::shared_ptr<IterativeClosestPointWithNormalsHIP<PointSource, PointTarget>>;
+  explicit IterativeClosestPointWithNormalsHIP(Device::Ptr dev = Device::instance()) {
+    this->reg_name_ = "IterativeClosestPointWithNormalsHIP";
+    this->setSearchMethodTarget(std::make_shared<KdTreeHIP<PointTarget>>(dev));
+    this->setCorrespondenceEstimation(std::make_shared<CorrespondenceEstimationHIP<PointSource, PointTarget, float>>());
+  }
+ protected:
+  bool enforceSameDirectionNormals() const override { return this->getEnforceSameDirectionNormals(); }
+};
+
+}  // namespace plugin
+}  // namespace pclhip

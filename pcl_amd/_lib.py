@@ -91,6 +91,7 @@ SIGNATURES = {
     "pclhip_ctx_synchronize": (C.c_int, [_vp]),
     "pclhip_ctx_stats": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64)]),
     "pclhip_index_build": (C.c_int, [_vp, _vp, _sz, _u64, _vp, _u64, C.POINTER(_vp)]),
+    "pclhip_index_build_scaled": (C.c_int, [_vp, _vp, _sz, _u64, _vp, _u64, C.POINTER(C.c_float), C.POINTER(_vp)]),
     "pclhip_index_destroy": (None, [_vp]),
     "pclhip_index_size": (_u64, [_vp]),
     "pclhip_index_build_ms": (C.c_double, [_vp]),
@@ -105,6 +106,7 @@ SIGNATURES = {
     "pclhip_icp_create": (C.c_int, [_vp, C.POINTER(_vp)]),
     "pclhip_icp_destroy": (None, [_vp]),
     "pclhip_icp_set_source": (C.c_int, [_vp, _vp, _sz, _u64]),
+    "pclhip_icp_set_source_indexed": (C.c_int, [_vp, _vp, _sz, _u64, _vp, _u64]),
     "pclhip_icp_set_source_normals": (C.c_int, [_vp, _vp, _sz]),
     "pclhip_icp_set_enforce_same_direction_normals": (C.c_int, [_vp, C.c_int]),
     "pclhip_icp_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),

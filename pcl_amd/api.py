@@ -161,18 +161,32 @@ class KdTree:
         self._free()
         ptr, stride, n, keep = _cloud(cloud)
         h = C.c_void_p()
-        if indices is not None:
-            ind = np.ascontiguousarray(indices, np.int32)
-            check(self.lib.pclhip_index_build(self.ctx.h, ptr, stride, n, C.c_void_p(ind.ctypes.data),
-                                              len(ind), C.byref(h)), self.ctx.h)
-        else:
-            check(self.lib.pclhip_index_build(self.ctx.h, ptr, stride, n, None, 0, C.byref(h)),
-                  self.ctx.h)
+        ind = None if indices is None else np.ascontiguousarray(indices, np.int32)
+        scale = getattr(self, "_scale", None)
+        check(self.lib.pclhip_index_build_scaled(self.ctx.h, ptr, stride, n,
+                                                 None if ind is None else C.c_void_p(ind.ctypes.data),
+                                                 0 if ind is None else len(ind),
+                                                 None if scale is None else _fp(scale), C.byref(h)), self.ctx.h)
         self.h = h
         self._cloud_id = key
         self._keep = (cloud, indices)
         self.n_cloud = n
         return True
+
+    def setPointRepresentation(self, rescale_values=None, dimensions=3):
+        """pcl::search::KdTree::setPointRepresentation (search/include/pcl/search/kdtree.h:110) for the
+        representations the 3-D index can honour: the first `dimensions` of (x, y, z), each times its rescale
+        value (CustomPointRepresentation(dimensions) + setRescaleValues, common/include/pcl/point_representation.h
+        :150-190,546-579).  None / 3 = the default representation.  Takes effect at the next setInputCloud."""
+        if rescale_values is None and dimensions == 3:
+            self._scale = None
+            return
+        assert 1 <= dimensions <= 3, "the index is three-dimensional: only prefixes of (x, y, z)"
+        sc = np.zeros(3, np.float32)
+        rv = np.ones(dimensions, np.float32) if rescale_values is None else np.asarray(rescale_values, np.float32)
+        assert rv.shape == (dimensions,)
+        sc[:dimensions] = rv
+        self._scale = sc
 
     def size(self):
         return int(self.lib.pclhip_index_size(self.h))
@@ -377,13 +391,25 @@ class CorrespondenceEstimation:
         self.src = None
 
     def setInputTarget(self, cloud):
-        self.tree.setInputCloud(cloud)
+        self._target = cloud
+        self.tree.setInputCloud(cloud, getattr(self, "_tgt_indices", None))
 
     def setSearchMethodTarget(self, tree, force_no_recompute=False):
         self.tree = tree
 
     def setInputSource(self, cloud):
         self.src = cloud
+
+    def setIndicesSource(self, indices):
+        """correspondence_estimation.h:194: the source points to find correspondences for"""
+        self._src_indices = None if indices is None else np.ascontiguousarray(indices, np.int32)
+
+    def setIndicesTarget(self, indices):
+        """correspondence_estimation.h:210: the target points correspondences may go to (the tree is rebuilt on
+        them, impl/correspondence_estimation.hpp:82-91)"""
+        self._tgt_indices = None if indices is None else np.ascontiguousarray(indices, np.int32)
+        if getattr(self, "_target", None) is not None:
+            self.tree.setInputCloud(self._target, self._tgt_indices)
 
     def determineReciprocalCorrespondences(self, max_distance=_SQRT_DBL_MAX):
         """impl/correspondence_estimation.hpp:220-311."""
@@ -396,7 +422,12 @@ class CorrespondenceEstimation:
         h = C.c_void_p()
         check(self.lib.pclhip_icp_create(self.tree.h, C.byref(h)), self.ctx.h)
         try:
-            check(self.lib.pclhip_icp_set_source(h, ptr, stride, n), self.ctx.h)
+            ind = getattr(self, "_src_indices", None)
+            if ind is None:
+                check(self.lib.pclhip_icp_set_source(h, ptr, stride, n), self.ctx.h)
+            else:
+                check(self.lib.pclhip_icp_set_source_indexed(h, ptr, stride, n, C.c_void_p(ind.ctypes.data), len(ind)),
+                      self.ctx.h)
             _set_filters(self.lib, self.ctx, h, list(rejectors), reciprocal)
             I = np.eye(4, dtype=np.float32).reshape(16)
             sums = np.zeros(_lib.NSUMS, np.float64)
@@ -472,6 +503,12 @@ class IterativeClosestPoint:
         self.src = cloud
         self._src_dirty = True
         self.src_normals = None   # a cloud without normals must not inherit the previous cloud's
+
+    def setIndices(self, indices):
+        """PCLBase::setIndices (common/include/pcl/pcl_base.h:102-125): only these source points take part in
+        the correspondence search and the estimation; None = all points."""
+        self._src_indices = None if indices is None else np.ascontiguousarray(indices, np.int32)
+        self._src_dirty = True
 
     def setMaximumIterations(self, n):
         self.p.max_iterations = int(n)
@@ -577,7 +614,12 @@ class IterativeClosestPoint:
                 check(self.lib.pclhip_icp_set_comm(self.h, self._comm.h), self.ctx.h)
         if self._src_dirty:
             ptr, stride, n, keep = _cloud(self.src)
-            check(self.lib.pclhip_icp_set_source(self.h, ptr, stride, n), self.ctx.h)
+            ind = getattr(self, "_src_indices", None)
+            if ind is None:
+                check(self.lib.pclhip_icp_set_source(self.h, ptr, stride, n), self.ctx.h)
+            else:
+                check(self.lib.pclhip_icp_set_source_indexed(self.h, ptr, stride, n, C.c_void_p(ind.ctypes.data), len(ind)),
+                      self.ctx.h)
             self._src_dirty = False
             self._src_nrm_dirty = True
         if self.src_normals is not None and self._src_nrm_dirty:

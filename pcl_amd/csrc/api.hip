@@ -271,7 +271,14 @@ pclhip_status pclhip_ctx_synchronize(pclhip_ctx* ctx) {
 // ------------------------------------------------------------------------------------------------
 pclhip_status pclhip_index_build(pclhip_ctx* ctx, const void* points, size_t stride, uint64_t n,
                                  const int32_t* indices, uint64_t n_indices, pclhip_index** out) {
+  return pclhip_index_build_scaled(ctx, points, stride, n, indices, n_indices, nullptr, out);
+}
+
+pclhip_status pclhip_index_build_scaled(pclhip_ctx* ctx, const void* points, size_t stride, uint64_t n,
+                                        const int32_t* indices, uint64_t n_indices, const float* scale,
+                                        pclhip_index** out) {
   if (!ctx || !out) return PCLHIP_ERR_INVALID;
+  if (scale) PCLHIP_REQUIRE(ctx, std::isfinite(scale[0]) && std::isfinite(scale[1]) && std::isfinite(scale[2]), "non-finite rescale value");
   *out = nullptr;
   PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
   PCLHIP_REQUIRE(ctx, n < 0x7FFFFFFFull, "cloud too large for int32 indices");
@@ -313,6 +320,10 @@ pclhip_status pclhip_index_build(pclhip_ctx* ctx, const void* points, size_t str
   pclhip_index* ix = new pclhip_index();
   ix->ctx = ctx;
   ix->n_orig = n;
+  if (scale) {
+    ix->scaled = true;
+    for (int d = 0; d < 3; ++d) ix->scale[d] = scale[d];
+  }
   (void)hipEventRecord(e0, ctx->stream);
   const uint32_t cap = uint32_t(((m + LEAF - 1) / LEAF) * LEAF) + LEAF;
   auto fail = [&](pclhip_status s) {
@@ -328,7 +339,7 @@ pclhip_status pclhip_index_build(pclhip_ctx* ctx, const void* points, size_t str
   }
   uint32_t nf = 0;
   st = spatial_order(ctx, dpts, stride, n, static_cast<const int32_t*>(dsel), n_indices, ix->pts, cap, &nf, ix->bbox_lo,
-                    ix->bbox_hi, false, ix->rank);
+                    ix->bbox_hi, false, ix->rank, scale);
   if (st != PCLHIP_OK) return fail(st);
   ix->n = nf;
   ix->n_pad = ((nf + LEAF - 1) / LEAF) * LEAF;
@@ -391,7 +402,8 @@ pclhip_status pclhip_knn(pclhip_index* ix, const void* queries, size_t stride, u
   guard.add(qs);
   uint32_t nf = 0;
   float lo[3], hi[3];
-  st = spatial_order(ctx, dq, stride, nq, nullptr, 0, qs, uint32_t(nq), &nf, lo, hi, true, nullptr);
+  st = spatial_order(ctx, dq, stride, nq, nullptr, 0, qs, uint32_t(nq), &nf, lo, hi, true, nullptr,
+                     ix->scaled ? ix->scale : nullptr);  // queries live in the index's (rescaled) space
   if (st != PCLHIP_OK) return st;
   const size_t cnt = size_t(nq) * size_t(k);
   int32_t* d_idx = out_idx;
@@ -543,11 +555,16 @@ pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out) {
   if (!target || !out) return PCLHIP_ERR_INVALID;
   pclhip_ctx* ctx = target->ctx;
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  // The ICP kernels measure distances in the index's coordinates and accumulate the estimator in the cloud's:
+  // they coincide only without a rescaling point representation.
+  PCLHIP_REQUIRE(ctx, !target->scaled, "registration against an index built with rescale values is not supported");
   pclhip_icp* icp = new pclhip_icp();
   icp->ctx = ctx;
   icp->target = target;
   icp->prev_mse = DBL_MAX;
   if (hipMalloc(&icp->sums_dev, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
+      hipMalloc(&icp->blocks_done, sizeof(unsigned int)) != hipSuccess ||
+      hipMemset(icp->blocks_done, 0, sizeof(unsigned int)) != hipSuccess ||
       hipHostMalloc(&icp->sums_host, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
       // timing markers between kernels of one stream: device-scope release is enough (a system-scope
       // release would write the iteration's dirty lines back to memory at every marker)
@@ -589,6 +606,7 @@ void pclhip_icp_destroy(pclhip_icp* icp) {
   }
   icp_free_source(icp);
   if (icp->sums_dev) (void)hipFree(icp->sums_dev);
+  if (icp->blocks_done) (void)hipFree(icp->blocks_done);
   if (icp->sums_host) (void)hipHostFree(icp->sums_host);
   if (icp->ctl) (void)hipFree(icp->ctl);
   if (icp->ctl_host) (void)hipHostFree(icp->ctl_host);
@@ -602,8 +620,14 @@ void pclhip_icp_destroy(pclhip_icp* icp) {
 }
 
 pclhip_status pclhip_icp_set_source(pclhip_icp* icp, const void* points, size_t stride, uint64_t n) {
+  return pclhip_icp_set_source_indexed(icp, points, stride, n, nullptr, 0);
+}
+
+pclhip_status pclhip_icp_set_source_indexed(pclhip_icp* icp, const void* points, size_t stride, uint64_t n,
+                                            const int32_t* indices, uint64_t n_indices) {
   if (!icp) return PCLHIP_ERR_INVALID;
   pclhip_ctx* ctx = icp->ctx;
+  PCLHIP_REQUIRE(ctx, indices != nullptr || n_indices == 0, "null index buffer");
   PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
   PCLHIP_REQUIRE(ctx, n < 0x7FFFFFFFull, "cloud too large for int32 indices");
   PCLHIP_REQUIRE(ctx, n == 0 || points != nullptr, "null point buffer");
@@ -616,9 +640,29 @@ pclhip_status pclhip_icp_set_source(pclhip_icp* icp, const void* points, size_t 
   pclhip_status st = to_device(ctx, points, size_t(n) * stride, &dp, &owned);
   if (st != PCLHIP_OK) return st;
   guard.add(owned);
+  const void* dsel = nullptr;
+  if (indices) {  // PCLBase::setIndices / setIndicesSource: only these points take part
+    PCLHIP_REQUIRE(ctx, n_indices < 0x7FFFFFFFull, "too many indices");
+    st = to_device(ctx, indices, size_t(n_indices) * sizeof(int32_t), &dsel, &owned);
+    if (st != PCLHIP_OK) return st;
+    guard.add(owned);
+    if (n_indices > 0) {
+      int* bad = nullptr;
+      PCLHIP_CHECK_HIP(ctx, hipMalloc(&bad, sizeof(int)));
+      guard.add(bad);
+      PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+      hipLaunchKernelGGL(check_indices_kernel, dim3(unsigned((n_indices + 255) / 256)), dim3(256), 0, ctx->stream,
+                         static_cast<const int32_t*>(dsel), n_indices, n, bad);
+      int hbad = 0;
+      PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      PCLHIP_REQUIRE(ctx, hbad == 0, "indices must lie in [0, n)");
+    }
+  }
+  const uint64_t m = indices ? n_indices : n;
   icp->n_orig = n;
-  icp->n = uint32_t(n);
-  const size_t cap = n > 0 ? n : 1;
+  icp->n = uint32_t(m);
+  const size_t cap = m > 0 ? m : 1;
   icp->grid_blocks = icp_grid_blocks(ctx, icp->n);
   PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->src_sorted0, cap * sizeof(float4)));
   PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->src_cur, cap * sizeof(float4)));
@@ -633,7 +677,8 @@ pclhip_status pclhip_icp_set_source(pclhip_icp* icp, const void* points, size_t 
   PCLHIP_CHECK_HIP(ctx, timing.event(&e0));
   PCLHIP_CHECK_HIP(ctx, timing.event(&e1));
   (void)hipEventRecord(e0, ctx->stream);
-  st = spatial_order(ctx, dp, stride, n, nullptr, 0, icp->src_sorted0, uint32_t(n), &nf, lo, hi, true, nullptr);
+  st = spatial_order(ctx, dp, stride, n, static_cast<const int32_t*>(dsel), n_indices, icp->src_sorted0, uint32_t(m), &nf, lo,
+                     hi, true, nullptr, nullptr);
   if (st != PCLHIP_OK) return st;
   (void)hipEventRecord(e1, ctx->stream);
   st = pclhip_icp_reset(icp);
@@ -1030,25 +1075,27 @@ pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_q
   int32_t* dm = nullptr;
   float* dd = nullptr;
   DeviceGuard guard;
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&dm, size_t(icp->n) * sizeof(int32_t)));
+  const size_t no = size_t(icp->n_orig);  // dense arrays over the ORIGINAL source records (a subset leaves gaps)
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&dm, no * sizeof(int32_t)));
   guard.add(dm);
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&dd, size_t(icp->n) * sizeof(float)));
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&dd, no * sizeof(float)));
   guard.add(dd);
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(dm, 0xFF, no * sizeof(int32_t), ctx->stream));
   const bool filtered = icp->reciprocal || !icp->rejectors.empty();
   hipLaunchKernelGGL(scatter_matches_kernel, dim3((icp->n + 255) / 256), dim3(256), 0, ctx->stream, icp->src_cur,
                      icp->match, icp->match_d2, filtered ? icp->keep : nullptr, icp->n, dm, dd);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
-  std::vector<int32_t> hm(icp->n);
-  std::vector<float> hd(icp->n);
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(hm.data(), dm, size_t(icp->n) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(hd.data(), dd, size_t(icp->n) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<int32_t> hm(no);
+  std::vector<float> hd(no);
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(hm.data(), dm, no * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(hd.data(), dd, no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   std::vector<int32_t> q, m;
   std::vector<float> d;
   q.reserve(icp->n);
   m.reserve(icp->n);
   d.reserve(icp->n);
-  for (uint32_t i = 0; i < icp->n; ++i)
+  for (size_t i = 0; i < no; ++i)
     if (hm[i] >= 0) {
       q.push_back(int32_t(i));
       m.push_back(hm[i]);

@@ -516,14 +516,19 @@ __global__ __launch_bounds__(256) void kd_cell_split_kernel(const float4* __rest
 }
 
 // initial compaction: finite selected records first (stable), non-finite ones after them
+// `sc`: per-axis rescale factors of a point representation (1,1,1 normally); an axis with factor 0 does not
+// exist in the representation: its coordinate reads as 0 and need not be finite
+struct Scale3 {
+  float x, y, z;
+};
 __global__ __launch_bounds__(256) void kd_flag_kernel(const void* pts, size_t stride, const int32_t* sel, uint64_t m,
-                                                      uint32_t* keys, uint32_t* vals, unsigned int* n_finite) {
+                                                      uint32_t* keys, uint32_t* vals, unsigned int* n_finite, Scale3 sc) {
   const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
   bool fin = false;
   if (i < m) {
     const uint64_t rec = sel ? uint64_t(sel[i]) : i;
     const float* p = record(pts, stride, rec);
-    fin = isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]);
+    fin = (sc.x == 0.0f || isfinite(p[0])) && (sc.y == 0.0f || isfinite(p[1])) && (sc.z == 0.0f || isfinite(p[2]));
     keys[i] = fin ? 0u : 1u;
     vals[i] = uint32_t(rec);
   }
@@ -538,13 +543,19 @@ __global__ __launch_bounds__(256) void kd_flag_kernel(const void* pts, size_t st
 }
 
 __global__ __launch_bounds__(256) void kd_load_kernel(const void* pts, size_t stride, const uint32_t* vals, uint64_t m,
-                                                      float4* out, int ids_from_w) {
+                                                      float4* out, int ids_from_w, Scale3 sc, int scaled) {
   const uint64_t j = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
   if (j >= m) return;
   const uint32_t rec = vals[j];
   const float* p = record(pts, stride, rec);
+  float x = p[0], y = p[1], z = p[2];
+  if (scaled) {  // PointRepresentation::vectorize: coordinate * alpha (common/include/pcl/point_representation.h:150-170)
+    x = sc.x == 0.0f ? 0.0f : __fmul_rn(x, sc.x);
+    y = sc.y == 0.0f ? 0.0f : __fmul_rn(y, sc.y);
+    z = sc.z == 0.0f ? 0.0f : __fmul_rn(z, sc.z);
+  }
   // ids_from_w: the records are float4 that already carry the point's id in .w
-  out[j] = make_float4(p[0], p[1], p[2], ids_from_w ? p[3] : __uint_as_float(rec));
+  out[j] = make_float4(x, y, z, ids_from_w ? p[3] : __uint_as_float(rec));
 }
 
 __global__ __launch_bounds__(256) void kd_finish_kernel(const float4* __restrict__ in, uint64_t live, uint32_t nf,
@@ -566,8 +577,10 @@ __global__ __launch_bounds__(256) void kd_finish_kernel(const float4* __restrict
 pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
                        const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
                        uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
-                       uint32_t* rank_or_null, bool ids_from_w) {
+                       uint32_t* rank_or_null, bool ids_from_w, const float* scale) {
   hipStream_t s = ctx->stream;
+  const Scale3 sc = {scale ? scale[0] : 1.0f, scale ? scale[1] : 1.0f, scale ? scale[2] : 1.0f};
+  const int scaled = scale != nullptr ? 1 : 0;
   const uint64_t m = dev_sel ? n_sel : n_records;
   for (int d = 0; d < 3; ++d) lo[d] = hi[d] = 0;
   *out_n_finite = 0;
@@ -619,9 +632,10 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
   uint32_t* f1 = reinterpret_cast<uint32_t*>(k1);
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(cn, 0, sizeof(unsigned int), s));
   hipLaunchKernelGGL(kd_flag_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride, dev_sel, m, f0, v0,
-                     cn);
+                     cn, sc);
   PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, temp_bytes, f0, f1, v0, v1, size_t(m), 0, 1, s));
-  hipLaunchKernelGGL(kd_load_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride, v1, m, pa, ids_from_w ? 1 : 0);
+  hipLaunchKernelGGL(kd_load_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride, v1, m, pa,
+                     ids_from_w ? 1 : 0, sc, scaled);
   unsigned int hn = 0;
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&hn, cn, sizeof hn, hipMemcpyDeviceToHost, s));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
@@ -706,13 +720,13 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
 pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
                             const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
                             uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
-                            uint32_t* rank_or_null) {
+                            uint32_t* rank_or_null, const float* scale) {
   const char* e = getenv("PCLHIP_ORDER");
-  if (e && strcmp(e, "morton") == 0)
+  if (e && strcmp(e, "morton") == 0 && scale == nullptr)
     return morton_order(ctx, dev_points, stride, n_records, dev_sel, n_sel, out_sorted, out_capacity, out_n_finite, lo, hi,
                         keep_nonfinite_at_end, rank_or_null);
   return kd_order(ctx, dev_points, stride, n_records, dev_sel, n_sel, out_sorted, out_capacity, out_n_finite, lo, hi,
-                  keep_nonfinite_at_end, rank_or_null, false);
+                  keep_nonfinite_at_end, rank_or_null, false, scale);
 }
 
 pclhip_status build_index_from_float4(pclhip_ctx* ctx, const float4* dev_pts_with_ids, uint32_t n, pclhip_index** out) {
@@ -728,7 +742,7 @@ pclhip_status build_index_from_float4(pclhip_ctx* ctx, const float4* dev_pts_wit
   }
   uint32_t nf = 0;
   pclhip_status st = kd_order(ctx, dev_pts_with_ids, sizeof(float4), n, nullptr, 0, ix->pts, cap, &nf, ix->bbox_lo,
-                              ix->bbox_hi, false, nullptr, true);
+                              ix->bbox_hi, false, nullptr, true, nullptr);
   if (st == PCLHIP_OK) {
     ix->n = nf;
     ix->n_pad = ((nf + LEAF - 1) / LEAF) * LEAF;
@@ -829,6 +843,11 @@ pclhip::IndexView pclhip_index::view() const {
     return !(e && atoi(e) == 0);
   }();
   v.disc = use_discs ? disc : nullptr;
+  static const float factor = [] {  // stand-off (squared, in leaf diagonals squared) from which discs replace boxes
+    const char* e = getenv("PCLHIP_DISC_FACTOR");
+    return e ? float(atof(e)) : 4.0f;
+  }();
+  v.disc_factor = factor;
   v.lv = lv_dev;
   for (int l = 0; l < pclhip::MAX_LEVELS; ++l) {
     v.box[l] = box[l];

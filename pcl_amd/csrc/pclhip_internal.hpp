@@ -51,6 +51,7 @@ struct IndexView {
   const float4* nrm;
   const float4* disc;           // per leaf two float4: (centre.xyz, R) (n.xyz, hn) of the bounded cylinder that holds
                                 // the leaf's points (traverse.hpp: point_disc_lb).  nullptr: search with boxes only.
+  float disc_factor;            // discs are used where wave radius^2 > disc_factor * (leaf diagonal)^2
   const LevelInfo* lv;          // [MAX_LEVELS] in device memory; lv[1] = leaves
   const Box* box[MAX_LEVELS];   // the same table in kernel arguments (SGPRs): selected with a
   uint32_t count[MAX_LEVELS];   // wave-uniform switch, no memory access on the traversal's critical path
@@ -145,6 +146,8 @@ struct pclhip_index {
   double build_ms = 0;
   double last_kernel_ms = 0;
   bool has_normals = false;
+  bool scaled = false;              // built through a rescaling point representation: coordinates * scale
+  float scale[3] = {1, 1, 1};
   pclhip::IndexView view() const;
 };
 
@@ -163,6 +166,7 @@ struct pclhip_icp {
   float* match_d2 = nullptr;
   double* partials = nullptr;      // [blocks][NSUMS]
   double* sums_dev = nullptr;      // [NSUMS]
+  unsigned int* blocks_done = nullptr;  // accumulate kernel: blocks finished (the last one folds the partials)
   double* sums_host = nullptr;     // pinned
   int grid_blocks = 0;
   pclhip_allreduce_fn allreduce = nullptr;
@@ -254,12 +258,12 @@ pclhip_status morton_order(pclhip_ctx* ctx, const void* dev_points, size_t strid
 pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
                        const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
                        uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
-                       uint32_t* rank_or_null, bool ids_from_w = false);
+                       uint32_t* rank_or_null, bool ids_from_w = false, const float* scale = nullptr);
 // dispatches on PCLHIP_ORDER=morton|kd (default kd); morton is kept for A/B measurements only
 pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
                             const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
                             uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
-                            uint32_t* rank_or_null);
+                            uint32_t* rank_or_null, const float* scale = nullptr);
 pclhip_status build_boxes(pclhip_index* ix);
 int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns);
 pclhip_status launch_estimate_pairs(pclhip_ctx* ctx, int mode, const float4* src, const float4* src_nrm,

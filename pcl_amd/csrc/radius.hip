@@ -207,7 +207,8 @@ extern "C" pclhip_status pclhip_radius_search(pclhip_index* ix, const void* quer
   PCLHIP_CHECK_HIP(ctx, g.alloc(&qs, size_t(nq) * sizeof(float4)));
   uint32_t nf = 0;
   float lo[3], hi[3];
-  st = spatial_order(ctx, dq, stride, nq, nullptr, 0, qs, uint32_t(nq), &nf, lo, hi, true, nullptr);
+  st = spatial_order(ctx, dq, stride, nq, nullptr, 0, qs, uint32_t(nq), &nf, lo, hi, true, nullptr,
+                     ix->scaled ? ix->scale : nullptr);
   if (st != PCLHIP_OK) return st;
   const float r2 = float(radius * radius);  // kdtree_flann.hpp:398
   const IndexView v = ix->view();

@@ -947,7 +947,8 @@ __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, con
                                                                const IcpControl* __restrict__ ctl,
                                                                float4* __restrict__ src_nrm,
                                                                const float4* __restrict__ src_nrm0, int enforce,
-                                                               double* __restrict__ partials) {
+                                                               double* __restrict__ partials, unsigned int* __restrict__ done,
+                                                               double* __restrict__ sums) {
   __shared__ double red_s[WAVES_PER_BLOCK][NS];
   bool restart = false;
   if (ctl != nullptr) {
@@ -980,6 +981,31 @@ __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, con
     pa.add(p, n1, t, n, match_d2[i], enforce != 0);
   }
   pa.store_block(red_s, partials);
+  // The block that finishes last folds the per-block partials in a fixed order (deterministic for a given
+  // grid): no separate reduction launch.  (Closing the iteration here as well -- icp_solve_step inlined --
+  // would cost this streaming kernel 1 KB of scratch per lane and half its registers.)
+  __shared__ bool last_s;
+  __shared__ double fold_s[BLOCK / NS][NS];
+  __threadfence();
+  if (threadIdx.x == 0) last_s = atomicAdd(done, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last_s) return;
+  __threadfence();
+  {
+    const int t = threadIdx.x % NS, r = threadIdx.x / NS;  // NS == 32: 8 rows of 32 sums
+    double a = 0.0;
+    for (uint32_t b = r; b < gridDim.x; b += BLOCK / NS)
+      a += __hip_atomic_load(&partials[size_t(b) * NS + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fold_s[r][t] = a;
+    __syncthreads();
+    if (r == 0) {
+      double v = 0.0;
+#pragma unroll
+      for (int i = 0; i < BLOCK / NS; ++i) v += fold_s[i][t];
+      sums[t] = v;
+    }
+  }
+  if (threadIdx.x == 0) *done = 0;  // ready for the next launch
 }
 
 // TransformationEstimation::estimateRigidTransformation(cloud_src, cloud_tgt) for n given pairs
@@ -1036,9 +1062,8 @@ __global__ __launch_bounds__(1024) void icp_finalize_kernel(const double* __rest
 // Closes an iteration on the device: closed form of the estimator on the (all-reduced) record, final = Tk *
 // final, DefaultConvergenceCriteria, and the control words of the next launch (impl/icp.hpp:204-238).
 // One thread: ~2k double operations, a few microseconds -- the point is that nothing leaves the GPU.
-__global__ void icp_solve_kernel(IcpControl* __restrict__ ctl, const double* __restrict__ sums,
-                                 IcpStepRecord* __restrict__ log) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void icp_solve_step(IcpControl* __restrict__ ctl, const double* __restrict__ sums,
+                               IcpStepRecord* __restrict__ log) {
   if (ctl->stop != 0) return;
   IcpControl c = *ctl;
   IcpStepRecord r;
@@ -1093,6 +1118,11 @@ __global__ void icp_solve_kernel(IcpControl* __restrict__ ctl, const double* __r
   __threadfence_system();
 }
 
+__global__ void icp_solve_kernel(IcpControl* __restrict__ ctl, const double* __restrict__ sums,
+                                 IcpStepRecord* __restrict__ log) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) icp_solve_step(ctl, sums, log);
+}
+
 static int search_skip_flag() {
   static const int skip = [] {  // A/B: PCLHIP_ICP_SKIP=0 always descends from the root
     const char* e = getenv("PCLHIP_ICP_SKIP");
@@ -1108,7 +1138,7 @@ static void launch_accumulate(pclhip_icp* icp, const IndexView& v, int ga, const
                               const IcpControl* ctl, hipStream_t s) {
   hipLaunchKernelGGL(icp_accumulate_kernel<MODE>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, icp->match_pos,
                      icp->match_d2, keep, M, ctl, icp->src_nrm_cur, icp->src_nrm_sorted0,
-                     icp->enforce_same_direction_normals ? 1 : 0, icp->partials);
+                     icp->enforce_same_direction_normals ? 1 : 0, icp->partials, icp->blocks_done, icp->sums_dev);
 }
 
 // One iteration.  ev == nullptr: the host-driven form (T by value, the caller reads the record back);
@@ -1162,7 +1192,6 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     else
       launch_accumulate<PCLHIP_ICP_POINT_TO_POINT>(icp, v, ga, keep, M, ctl, s);
     (void)hipEventRecord(device_loop ? ev[2] : icp->ev1, s);
-    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, ga, icp->sums_dev, ctl);
   } else if (icp->n > 0) {
     int grid = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? resident_blocks(ctx, k_plane, ngroups)
                                                    : resident_blocks(ctx, k_point, ngroups);

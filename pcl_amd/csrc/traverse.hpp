@@ -102,12 +102,23 @@ __device__ __forceinline__ float point_disc_lb(float qx, float qy, float qz, con
   const float gn = fmaxf((a - e) - nh.w, 0.0f);
   return __fmaf_rn(gt, gt, gn * gn) * DISC_SHRINK;
 }
-// the same for every query of a group, through the group's bounding sphere (centre Qc, radius rQ rounded up):
-// |q - p| >= |Qc - p| - rQ
-__device__ __forceinline__ float group_disc_lb(float Qcx, float Qcy, float Qcz, float rQ, const float4 cR, const float4 nh) {
-  const float d = __fsqrt_rn(point_disc_lb(Qcx, Qcy, Qcz, cR, nh)) * 0.999999f - rQ;
-  const float g = fmaxf(d, 0.0f);
-  return g * g * DISC_SHRINK;
+// The same for every query q of a group with bounding box [Ql, Qh] (centre Qc, half diagonal rQ, rounded up)
+// against every point p of the disc: along n the gap between the interval n.(q - c) takes over the box and
+// [-hn, hn]; across n the distance of the centres less both radii.  Both hold for the same pair (q, p).
+__device__ __forceinline__ float group_disc_lb(float Qlx, float Qly, float Qlz, float Qhx, float Qhy, float Qhz, float Qcx,
+                                               float Qcy, float Qcz, float rQ, const float4 cR, const float4 nh) {
+  const float lx = Qlx - cR.x, ly = Qly - cR.y, lz = Qlz - cR.z, hx = Qhx - cR.x, hy = Qhy - cR.y, hz = Qhz - cR.z;
+  const float ax = nh.x * lx, bx = nh.x * hx, ay = nh.y * ly, by = nh.y * hy, az = nh.z * lz, bz = nh.z * hz;
+  const float smin = (fminf(ax, bx) + fminf(ay, by)) + fminf(az, bz);
+  const float smax = (fmaxf(ax, bx) + fmaxf(ay, by)) + fmaxf(az, bz);
+  const float eb = 1e-6f * ((fmaxf(fabsf(lx), fabsf(hx)) + fmaxf(fabsf(ly), fabsf(hy))) + fmaxf(fabsf(lz), fabsf(hz)));
+  const float gn = fmaxf(fmaxf(smin, -smax) - nh.w - eb, 0.0f);
+  const float dx = Qcx - cR.x, dy = Qcy - cR.y, dz = Qcz - cR.z;
+  const float r2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+  const float a_hi = fabsf(__fmaf_rn(nh.z, dz, __fmaf_rn(nh.y, dy, __fmul_rn(nh.x, dx)))) + 1e-6f * ((fabsf(dx) + fabsf(dy)) + fabsf(dz));
+  const float b2 = fmaxf(__fmaf_rn(r2, 0.999999f, -(a_hi * a_hi) * 1.000003f), 0.0f);
+  const float gt = fmaxf(__fmaf_rn(__fsqrt_rn(b2), 0.999999f, -(rQ + cR.w)), 0.0f);
+  return __fmaf_rn(gt, gt, gn * gn) * DISC_SHRINK;
 }
 
 // ---- wavefront reductions (all 64 lanes must be active) ---------------------------------------
@@ -686,13 +697,19 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
     // collapse after the first few leaves and everything farther is cut off at once.  Tight bounds
     // (seeded steady state): plain index order, no ranking work.
     const bool ordered = T * 16.0f > gdiag2;
-    // Leaves of a loose search are bounded by their discs (see point_disc_lb)
-    const bool use_disc = have_disc && ordered && cl == 1u;
+    // Leaves of a loose search are bounded by their discs (see point_disc_lb) once the queries stand off
+    // farther than a few leaf sizes: closer in, a disc excludes nothing a box does not and costs twice the test.
+    bool use_disc = false;
     float4 dcR = make_float4(0, 0, 0, 0), dnh = make_float4(0, 0, 0, 0);
-    if (use_disc && has) {
-      dcR = ix.disc[2 * (first + lane)];
-      dnh = ix.disc[2 * (first + lane) + 1];
-      lbG = fmaxf(lbG, group_disc_lb(Qcx, Qcy, Qcz, rQ, dcR, dnh));
+    if (have_disc && ordered && cl == 1u) {
+      const float ex = hx - lx, ey = hy - ly, ez = hz - lz;
+      const float leaf2 = wave_max_f(has ? __fmaf_rn(ez, ez, __fmaf_rn(ey, ey, ex * ex)) : 0.0f);
+      use_disc = T > ix.disc_factor * leaf2;
+      if (use_disc && has) {
+        dcR = ix.disc[2 * (first + lane)];
+        dnh = ix.disc[2 * (first + lane) + 1];
+        lbG = fmaxf(lbG, group_disc_lb(Qlx, Qly, Qlz, Qhx, Qhy, Qhz, Qcx, Qcy, Qcz, rQ, dcR, dnh));
+      }
     }
     const bool alive = has && !(lbG > T);
     const uint64_t mask = __builtin_amdgcn_ballot_w64(alive);

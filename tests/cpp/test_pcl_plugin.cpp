@@ -1,0 +1,252 @@
+// The real-PCL binding (include/pclhip/pcl_plugin.hpp) compiled against the PCL mock (tests/cpp/pcl_mock: the
+// PCL base classes with their real signatures, no Eigen) and driven THROUGH THE BASE-CLASS INTERFACES, the way
+// a PCL application and PCL's own algorithms reach a plugin:
+//   pcl::search::Search<PointT>*                 -> KdTreeHIP            (search.h:144-273 virtuals)
+//   pcl::registration::CorrespondenceEstimationBase*  -> CorrespondenceEstimationHIP (correspondence_estimation.h:277-293)
+//   pcl::Registration<...>* / pcl::IterativeClosestPoint* -> IterativeClosestPoint[WithNormals]HIP
+//        (registration.h:678-679 computeTransformation, reached from PCL's own align())
+// Goldens: test/registration/test_registration_api.cpp:83-104 (397 bunny correspondences),
+// test/registration/test_registration.cpp:236-270 (ICP 4x4 @1e-3), test/kdtree/test_kdtree.cpp:226-289.
+// Inputs are written by tests/test_gpu_cpp_adapters.py from tests/golden/.
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <memory>
+
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+
+#include "pclhip/pcl_plugin.hpp"
+
+using namespace pclhip::plugin;
+
+static int failures = 0;
+#define EXPECT(cond)                                                        \
+  do {                                                                      \
+    if (!(cond)) {                                                          \
+      std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      ++failures;                                                           \
+    }                                                                       \
+  } while (0)
+
+template <typename PointT>
+static typename pcl::PointCloud<PointT>::Ptr load_xyz(const char* path) {
+  typename pcl::PointCloud<PointT>::Ptr c(new pcl::PointCloud<PointT>);
+  std::ifstream f(path);
+  float x, y, z;
+  while (f >> x >> y >> z) {
+    PointT p;
+    p.x = x; p.y = y; p.z = z;
+    c->push_back(p);
+  }
+  return c;
+}
+
+// a TransformationEstimation the binding has never heard of: the subclass must hand over to PCL's own loop
+template <typename S, typename T>
+struct ForeignEstimation : pcl::registration::TransformationEstimation<S, T, float> {
+  using Matrix4 = typename pcl::registration::TransformationEstimation<S, T, float>::Matrix4;
+  void estimateRigidTransformation(const pcl::PointCloud<S>&, const pcl::PointCloud<T>&, Matrix4&) const override {}
+  void estimateRigidTransformation(const pcl::PointCloud<S>&, const pcl::Indices&, const pcl::PointCloud<T>&, Matrix4&) const override {}
+  void estimateRigidTransformation(const pcl::PointCloud<S>&, const pcl::Indices&, const pcl::PointCloud<T>&,
+                                   const pcl::Indices&, Matrix4&) const override {}
+  void estimateRigidTransformation(const pcl::PointCloud<S>&, const pcl::PointCloud<T>&, const pcl::Correspondences&,
+                                   Matrix4&) const override {}
+};
+
+int main(int argc, char** argv) {
+  if (argc < 5) return 2;
+  auto dev = std::make_shared<Device>(0);
+  if (!dev->ok()) {
+    std::fprintf(stderr, "no device: %s\n", pclhip_last_error(nullptr));
+    return 3;
+  }
+  auto source = load_xyz<pcl::PointXYZ>(argv[1]);
+  auto target = load_xyz<pcl::PointXYZ>(argv[2]);
+  EXPECT(source->size() == 397 && target->size() == 361);
+  std::vector<int> gold;
+  {
+    std::ifstream f(argv[3]);
+    int a, b;
+    while (f >> a >> b) gold.push_back(b);
+  }
+  EXPECT(gold.size() == 397);
+
+  {  // 1. the search backend through pcl::search::Search<PointT>
+    pcl::search::Search<pcl::PointXYZ>::Ptr search(new KdTreeHIP<pcl::PointXYZ>(dev));
+    EXPECT(search->getName() == "KdTreeHIP");
+    EXPECT(search->setInputCloud(target));
+    EXPECT(search->getInputCloud() == target);
+    pcl::Indices idx;
+    std::vector<float> d2;
+    EXPECT(search->nearestKSearch((*source)[0], 5, idx, d2) == 5);
+    EXPECT(idx.size() == 5 && idx[0] == gold[0] && d2[0] <= d2[1] && d2[1] <= d2[4]);
+    EXPECT(search->nearestKSearch(*source, 0, 5, idx, d2) == 5 && idx[0] == gold[0]);  // (cloud, index) overload of the base
+    EXPECT(search->nearestKSearch((*source)[0], 1000, idx, d2) == 361);                 // k clamped (kdtree_flann.hpp:241-242)
+    std::vector<pcl::Indices> bi;
+    std::vector<std::vector<float>> bd;
+    search->nearestKSearch(*source, pcl::Indices(), 1, bi, bd);                         // the batch virtual: one launch
+    EXPECT(bi.size() == 397);
+    for (std::size_t i = 0; i < bi.size() && i < gold.size(); ++i) EXPECT(bi[i].size() == 1 && bi[i][0] == gold[i]);
+    pcl::Indices ridx;
+    std::vector<float> rd2;
+    const int nr = search->radiusSearch((*source)[0], 0.02, ridx, rd2);
+    EXPECT(nr > 0 && int(ridx.size()) == nr && ridx[0] == gold[0]);
+    for (int i = 1; i < nr; ++i) EXPECT(rd2[std::size_t(i) - 1] <= rd2[std::size_t(i)] && rd2[std::size_t(i)] < 0.02f * 0.02f);
+    EXPECT(search->radiusSearch((*source)[0], 0.02, ridx, rd2, 3) == (nr < 3 ? nr : 3));
+    // indices: results refer to the original cloud
+    pcl::IndicesPtr sub(new pcl::Indices);
+    for (int i = 0; i < 361; i += 2) sub->push_back(i);
+    EXPECT(search->setInputCloud(target, sub));
+    EXPECT(search->nearestKSearch((*source)[0], 3, idx, d2) == 3);
+    for (int v : idx) EXPECT(v % 2 == 0);
+  }
+
+  {  // 2. point representations (test/kdtree/test_kdtree.cpp:252-282 uses these two)
+    auto tree = std::make_shared<KdTreeHIP<pcl::PointXYZ>>(dev);
+    pcl::search::KdTree<pcl::PointXYZ>& base = *tree;
+    std::shared_ptr<pcl::CustomPointRepresentation<pcl::PointXYZ>> xy(new pcl::CustomPointRepresentation<pcl::PointXYZ>(2, 0));
+    base.setPointRepresentation(xy);
+    EXPECT(tree->representationSupported());
+    EXPECT(base.setInputCloud(target));
+    pcl::Indices idx;
+    std::vector<float> d2;
+    pcl::PointXYZ q = (*target)[17];
+    q.z += 5.0f;  // z is not part of the representation: the point still finds itself at distance 0
+    EXPECT(base.nearestKSearch(q, 1, idx, d2) == 1 && idx[0] == 17 && d2[0] == 0.0f);
+    std::shared_ptr<pcl::DefaultPointRepresentation<pcl::PointXYZ>> scaled(new pcl::DefaultPointRepresentation<pcl::PointXYZ>);
+    const float alpha[3] = {1.0f, 2.0f, 3.0f};
+    scaled->setRescaleValues(alpha);
+    base.setPointRepresentation(scaled);
+    pcl::PointXYZ r = (*target)[17];
+    r.y += 0.001f;
+    EXPECT(base.nearestKSearch(r, 1, idx, d2) == 1 && idx[0] == 17);
+    EXPECT(std::fabs(d2[0] - 4.0f * 0.001f * 0.001f) < 1e-8f);  // distances live in the rescaled space
+  }
+
+  {  // 3. the batch correspondence entry through CorrespondenceEstimationBase*
+    pcl::registration::CorrespondenceEstimationBase<pcl::PointXYZ, pcl::PointXYZ, float>::Ptr ce(
+        new CorrespondenceEstimationHIP<pcl::PointXYZ, pcl::PointXYZ, float>);
+    ce->setSearchMethodTarget(std::make_shared<KdTreeHIP<pcl::PointXYZ>>(dev));
+    ce->setInputSource(source);
+    ce->setInputTarget(target);
+    pcl::Correspondences corr;
+    ce->determineCorrespondences(corr);
+    EXPECT(corr.size() == 397);
+    for (std::size_t i = 0; i < corr.size() && i < gold.size(); ++i)
+      EXPECT(corr[i].index_query == int(i) && corr[i].index_match == gold[i]);
+    pcl::Correspondences rec;
+    ce->determineReciprocalCorrespondences(rec);
+    EXPECT(rec.size() == 53);  // test_registration_api_data.h:404-459
+    auto copy = ce->clone();   // clone(): Registration copies the estimator for worker threads
+    pcl::Correspondences corr2;
+    copy->determineCorrespondences(corr2, 0.01);
+    EXPECT(!corr2.empty() && corr2.size() < 397);
+    for (const auto& c : corr2) EXPECT(c.distance <= 0.01f * 0.01f && c.index_match == gold[std::size_t(c.index_query)]);
+    // PCL's own per-point estimator over the same backend (one launch per point): identical pairs
+    pcl::registration::CorrespondenceEstimation<pcl::PointXYZ, pcl::PointXYZ, float> stock;
+    stock.setSearchMethodTarget(std::make_shared<KdTreeHIP<pcl::PointXYZ>>(dev));
+    stock.setInputSource(source);
+    stock.setInputTarget(target);
+    pcl::Correspondences slow;
+    stock.determineCorrespondences(slow);
+    EXPECT(slow.size() == corr.size());
+    for (std::size_t i = 0; i < slow.size() && i < corr.size(); ++i)
+      EXPECT(slow[i].index_match == corr[i].index_match && slow[i].distance == corr[i].distance);
+    // setIndicesSource: only those source points
+    pcl::IndicesPtr some(new pcl::Indices{3, 10, 200, 396});
+    ce->setIndicesSource(some);
+    ce->determineCorrespondences(corr);
+    EXPECT(corr.size() == 4 && corr[0].index_query == 3 && corr[3].index_query == 396 && corr[2].index_match == gold[200]);
+  }
+
+  const double G[16] = {0.9999, 0.0088, -0.0115, 0.0001, -0.0087, 0.9999, 0.0057, 0.0233,  // test_registration.cpp:251-269
+                        0.0116, -0.0056, 0.9999, 0.0023, 0, 0, 0, 1};
+  float T_point[16];
+  {  // 4. IterativeClosestPoint through pcl::Registration*: PCL's align() calls the overridden computeTransformation
+    pcl::Registration<pcl::PointXYZ, pcl::PointXYZ, float>::Ptr reg(new IterativeClosestPointHIP<pcl::PointXYZ, pcl::PointXYZ>(dev));
+    reg->setInputSource(source);
+    reg->setInputTarget(target);
+    reg->setMaximumIterations(50);
+    reg->setTransformationEpsilon(1e-8);
+    reg->setMaxCorrespondenceDistance(0.05);
+    pcl::PointCloud<pcl::PointXYZ> out;
+    reg->align(out);
+    auto* hip = dynamic_cast<IterativeClosestPointHIP<pcl::PointXYZ, pcl::PointXYZ>*>(reg.get());
+    EXPECT(hip != nullptr && hip->deferredReason().empty());
+    EXPECT(reg->hasConverged() && out.size() == source->size());
+    const auto T = reg->getFinalTransformation();
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) {
+        EXPECT(std::fabs(T(r, c) - G[4 * r + c]) < 1e-3);
+        T_point[4 * r + c] = T(r, c);
+      }
+    // the output is the input moved by the final transformation
+    const auto& p = (*source)[5];
+    const float x = T(0, 0) * p.x + T(0, 1) * p.y + T(0, 2) * p.z + T(0, 3);
+    EXPECT(std::fabs(out[5].x - x) < 1e-5f);
+    EXPECT(reg->getFitnessScore() < 0.001);  // test_registration.cpp:301-302
+    auto* icp = dynamic_cast<pcl::IterativeClosestPoint<pcl::PointXYZ, pcl::PointXYZ, float>*>(reg.get());
+    EXPECT(icp->getConvergeCriteria()->getConvergenceState() !=
+           pcl::registration::DefaultConvergenceCriteria<float>::CONVERGENCE_CRITERIA_NOT_CONVERGED);
+    // rejectors and reciprocal correspondences map onto the device chain
+    std::shared_ptr<pcl::registration::CorrespondenceRejectorMedianDistance> med(
+        new pcl::registration::CorrespondenceRejectorMedianDistance);
+    med->setMedianFactor(4.0);
+    reg->addCorrespondenceRejector(med);
+    icp->setUseReciprocalCorrespondences(true);
+    reg->align(out);
+    EXPECT(hip->deferredReason().empty() && reg->hasConverged());
+    const auto T2 = reg->getFinalTransformation();
+    for (int r = 0; r < 3; ++r) EXPECT(std::fabs(T2(r, 3) - G[4 * r + 3]) < 2e-3);
+    // a source subset through PCLBase::setIndices
+    reg->clearCorrespondenceRejectors();
+    icp->setUseReciprocalCorrespondences(false);
+    pcl::IndicesPtr half(new pcl::Indices);
+    for (int i = 0; i < 397; i += 2) half->push_back(i);
+    reg->setIndices(half);
+    reg->align(out);
+    EXPECT(hip->deferredReason().empty() && reg->hasConverged() && out.size() == source->size());
+    const auto T3 = reg->getFinalTransformation();
+    for (int r = 0; r < 3; ++r) EXPECT(std::fabs(T3(r, 3) - G[4 * r + 3]) < 3e-3);
+  }
+
+  {  // 5. what the binding cannot express is handed to PCL's own loop -- never silently replaced.  (The mock has
+     //    no CPU loop: it aborts there, so only the decision is checked, through a subclass that records it.)
+    struct Probe : IterativeClosestPointHIP<pcl::PointXYZ, pcl::PointXYZ> {
+      using IterativeClosestPointHIP<pcl::PointXYZ, pcl::PointXYZ>::IterativeClosestPointHIP;
+      bool foreign() const { return this->estimatorKind() == this->FOREIGN; }
+    } probe(dev);
+    EXPECT(!probe.foreign());
+    probe.setTransformationEstimation(std::make_shared<ForeignEstimation<pcl::PointXYZ, pcl::PointXYZ>>());
+    EXPECT(probe.foreign());
+  }
+
+  {  // 6. IterativeClosestPointWithNormals on PointNormal clouds (normals read from the records, +16 bytes)
+    auto tn = load_xyz<pcl::PointNormal>(argv[2]);
+    auto sn = load_xyz<pcl::PointNormal>(argv[1]);
+    std::ifstream fn(argv[4]);  // target normals (nx ny nz per line), computed by the Python side
+    for (auto& p : tn->points) fn >> p.normal_x >> p.normal_y >> p.normal_z;
+    std::shared_ptr<pcl::IterativeClosestPointWithNormals<pcl::PointNormal, pcl::PointNormal, float>> reg(
+        new IterativeClosestPointWithNormalsHIP<pcl::PointNormal, pcl::PointNormal>(dev));
+    reg->setInputSource(sn);
+    reg->setInputTarget(tn);
+    reg->setMaximumIterations(50);
+    reg->setTransformationEpsilon(1e-8);
+    reg->setMaxCorrespondenceDistance(0.05);
+    pcl::PointCloud<pcl::PointNormal> out;
+    reg->align(out);
+    auto* hip = dynamic_cast<IterativeClosestPointWithNormalsHIP<pcl::PointNormal, pcl::PointNormal>*>(reg.get());
+    EXPECT(hip != nullptr && hip->deferredReason().empty());
+    EXPECT(reg->hasConverged());
+    const auto T = reg->getFinalTransformation();
+    for (int r = 0; r < 3; ++r) {
+      EXPECT(std::fabs(T(r, 3) - T_point[4 * r + 3]) < 5e-3);   // the same registration as point-to-point
+      for (int c = 0; c < 3; ++c) EXPECT(std::fabs(T(r, c) - T_point[4 * r + c]) < 2e-2);
+    }
+    EXPECT(!reg->getUseSymmetricObjective());
+  }
+
+  if (failures == 0) std::printf("ALL OK\n");
+  return failures == 0 ? 0 : 1;
+}

@@ -52,15 +52,77 @@ def test_knn_random_vs_bruteforce(gpu, orc, k):
 
 
 def test_knn_hand_points_golden(gpu, golden):
-    # test/kdtree/test_kdtree.cpp:226-289
+    # test/kdtree/test_kdtree.cpp:226-289: the default representation, CustomPointRepresentation(2) (x-y only)
+    # and rescale values (1, 2, 3) -- through setPointRepresentation, the points are handed over unscaled
+    import pcl_amd
     g = golden["kdtree_hand"]
     pts = np.asarray(g["points"], np.float32)
     qry = np.asarray([g["query"]], np.float32)
-    for name, scale in (("xyz", (1, 1, 1)), ("xy", (1, 1, 0)), ("rescaled_123", (1, 2, 3))):
-        s = np.asarray(scale, np.float32)
-        idx, d2 = build_tree(gpu, pts * s).nearestKSearch(qry * s, 10)
+    for name, rep in (("xyz", {}), ("xy", {"dimensions": 2}), ("rescaled_123", {"rescale_values": (1, 2, 3)})):
+        tree = pcl_amd.KdTree(gpu)
+        tree.setPointRepresentation(**rep)
+        tree.setInputCloud(pts)
+        idx, d2 = tree.nearestKSearch(qry, 10)
         assert idx[0].tolist() == g[name]["indices"], name
         assert np.allclose(d2[0], g[name]["distances"], atol=g["dist_tol"])
+    # an axis the representation does not contain need not be finite (point_representation.h:103-135)
+    pts2 = pts.copy()
+    pts2[3, 2] = np.nan
+    tree = pcl_amd.KdTree(gpu)
+    tree.setPointRepresentation(dimensions=2)
+    tree.setInputCloud(pts2)
+    assert tree.size() == len(pts2)
+    idx2, _ = tree.nearestKSearch(qry, 10)
+    assert idx2[0].tolist() == g["xy"]["indices"]
+    # registration needs the default representation: refused loudly
+    icp = pcl_amd.IterativeClosestPoint(gpu)
+    icp.setSearchMethodTarget(tree, True)
+    icp.setInputSource(pts)
+    with pytest.raises(pcl_amd.PclHipError, match="rescale"):
+        icp.align()
+
+
+def test_source_and_target_index_subsets(gpu, orc, bunny):
+    # PCLBase::setIndices on the registration (common/include/pcl/pcl_base.h:102-125) and
+    # CorrespondenceEstimationBase::setIndicesSource / setIndicesTarget (correspondence_estimation.h:194,210):
+    # only the listed points take part; indices in the results refer to the original clouds
+    import pcl_amd
+    src, tgt = xyz1(bunny["bun0"]), xyz1(bunny["bun4"])
+    rng = np.random.default_rng(4)
+    si = np.sort(rng.choice(len(src), 150, replace=False)).astype(np.int32)
+    ti = np.sort(rng.choice(len(tgt), 200, replace=False)).astype(np.int32)
+    ce = pcl_amd.CorrespondenceEstimation(gpu)
+    ce.setInputSource(src)
+    ce.setIndicesSource(si)
+    ce.setIndicesTarget(ti)
+    ce.setInputTarget(tgt)
+    q, m, d = ce.determineCorrespondences(0.05)
+    oq, om, od = orc.KdTree(tgt[ti]).correspondences(src[si], 0.05)
+    assert np.array_equal(q, si[oq]) and np.array_equal(m, ti[om]) and np.array_equal(d, od)
+    # the whole loop on a source subset == the loop on the extracted sub-cloud
+    icp = pcl_amd.IterativeClosestPoint(gpu)
+    icp.setInputTarget(tgt)
+    icp.setInputSource(src)
+    icp.setIndices(si)
+    icp.setMaximumIterations(30)
+    icp.setMaxCorrespondenceDistance(0.05)
+    icp.align()
+    ref = pcl_amd.IterativeClosestPoint(gpu)
+    ref.setInputTarget(tgt)
+    ref.setInputSource(np.ascontiguousarray(src[si]))
+    ref.setMaximumIterations(30)
+    ref.setMaxCorrespondenceDistance(0.05)
+    ref.align()
+    assert icp.nr_iterations_ == ref.nr_iterations_
+    assert np.abs(icp.getFinalTransformation() - ref.getFinalTransformation()).max() < 1e-6
+    qq, mm, dd = icp.fetchCorrespondences()
+    assert set(qq.tolist()) <= set(si.tolist()) and len(qq) > 100
+    with pytest.raises(pcl_amd.PclHipError, match="indices"):
+        bad = pcl_amd.IterativeClosestPoint(gpu)
+        bad.setInputTarget(tgt)
+        bad.setInputSource(src)
+        bad.setIndices(np.asarray([0, len(src)], np.int32))
+        bad.align()
 
 
 def test_knn_lattice_ties_lowest_index(gpu, orc):
