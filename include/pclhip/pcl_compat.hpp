@@ -1,30 +1,40 @@
-// pcl_compat.hpp -- header-only C++ mirror of the PCL plugin surface for the ICP hot path, written
-// against the C ABI of pclhip.h (no Eigen, no Boost, no FLANN).  Names, argument meaning and error
-// behaviour follow the reference classes so user code (and PCL's own tests) port by changing the
-// namespace:
+// pcl_compat.hpp -- header-only C++ mirror of the PCL plugin surface for the ICP hot path, written against the
+// C ABI of pclhip.h (no Eigen, no Boost, no FLANN) for applications that do not have PCL at all.  Same names,
+// the same VIRTUAL structure, argument meaning and error behaviour as the reference classes, so user code
+// (and PCL's own tests) port by changing the namespace -- including code that plugs its own search method,
+// correspondence estimation or transformation estimation into a Registration:
 //
-//   pclhip::PointXYZ / PointNormal / Normal      common/include/pcl/impl/point_types.hpp:315-321,843-853,787-794
-//   pclhip::PointCloud<PointT>                   common/include/pcl/point_cloud.h:173,393-409
-//   pclhip::Correspondence(s)                    common/include/pcl/correspondence.h:60-91
-//   pclhip::search::KdTree<PointT>               search/include/pcl/search/kdtree.h:61-168
-//   pclhip::registration::CorrespondenceEstimation  registration/include/pcl/registration/correspondence_estimation.h
-//   pclhip::IterativeClosestPoint(+WithNormals)  registration/include/pcl/registration/icp.h:98-347,360-440
-//   pclhip::NormalEstimation                     features/include/pcl/features/normal_3d.h:243-420
-//   pclhip::VoxelGrid                            filters/include/pcl/filters/voxel_grid.h:221-533
+//   pclhip::PointXYZ / PointNormal / Normal         common/include/pcl/impl/point_types.hpp:315-321,843-853,787-794
+//   pclhip::PointCloud<PointT>                      common/include/pcl/point_cloud.h:173,393-409
+//   pclhip::PCLBase<PointT>                         common/include/pcl/pcl_base.h:65-175 (setIndices)
+//   pclhip::PointRepresentation<PointT> (+Default, Custom)   common/include/pcl/point_representation.h
+//   pclhip::Correspondence(s)                       common/include/pcl/correspondence.h:60-91
+//   pclhip::search::Search<PointT> (abstract)       search/include/pcl/search/search.h:60-420
+//   pclhip::search::KdTree<PointT>                  search/include/pcl/search/kdtree.h:61-168
+//   pclhip::registration::CorrespondenceEstimationBase (abstract) / CorrespondenceEstimation
+//                                                   registration/include/pcl/registration/correspondence_estimation.h
+//   pclhip::registration::TransformationEstimation (abstract, four overloads) / ...SVD / ...PointToPlaneLLS /
+//   ...SymmetricPointToPlaneLLS                     registration/include/pcl/registration/transformation_estimation*.h
+//   pclhip::registration::CorrespondenceRejector{Distance,MedianDistance,OneToOne,Trimmed}
+//   pclhip::Registration<S,T> (abstract) / IterativeClosestPoint / IterativeClosestPointWithNormals
+//                                                   registration/include/pcl/registration/registration.h, icp.h
+//   pclhip::NormalEstimation, pclhip::VoxelGrid, pclhip::io::loadPCDFile / savePCDFile*
 //
-// With real PCL available, the same calls sit inside subclasses of the real pcl:: bases; that binding
-// is shown in INTEGRATION.md (it cannot be compiled in this image: PCL needs Eigen/Boost/FLANN).
-// Errors follow PCL's convention: no exceptions on the hot path, `false`/0 results + a message
-// (getLastError()), see SURVEY.md 8(b).
+// With the stock device-backed parts plugged in (the default), align() runs the whole loop on the GPU
+// (pclhip_icp_align); a foreign CorrespondenceEstimation or TransformationEstimation makes it run the generic
+// loop of impl/icp.hpp:113-268 through the virtual calls.  With real PCL available the same C ABI sits inside
+// subclasses of the real pcl:: bases: include/pclhip/pcl_plugin.hpp.
+// Errors follow PCL's convention: no exceptions on the hot path, `false`/0 results + a message (getLastError()).
 #pragma once
 
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <string>
-#include <limits>
+#include <typeinfo>
 #include <vector>
 
 #include "../pclhip.h"
@@ -33,6 +43,8 @@ namespace pclhip {
 
 using index_t = std::int32_t;           // common/include/pcl/types.h:110-133
 using Indices = std::vector<index_t>;
+using IndicesPtr = std::shared_ptr<Indices>;
+using IndicesConstPtr = std::shared_ptr<const Indices>;
 
 struct alignas(16) PointXYZ {
   float x = 0, y = 0, z = 0, w = 1.0f;  // data[4], data[3] = 1 (point_types.hpp:205-213)
@@ -49,6 +61,7 @@ struct alignas(16) PointNormal {
   float curvature = 0, pad1[3] = {0, 0, 0};
 };
 static_assert(sizeof(PointXYZ) == 16 && sizeof(Normal) == 32 && sizeof(PointNormal) == 48, "PCL record sizes");
+template <typename PointT> constexpr bool has_normal_fields() { return sizeof(PointT) >= 48; }
 
 template <typename PointT>
 struct PointCloud {
@@ -73,19 +86,35 @@ struct PointCloud {
 struct Correspondence {
   index_t index_query = 0, index_match = -1;
   float distance = FLT_MAX;  // squared (correspondence.h:66-71)
+  Correspondence() = default;
+  Correspondence(index_t q, index_t m, float d) : index_query(q), index_match(m), distance(d) {}
 };
 using Correspondences = std::vector<Correspondence>;
+using CorrespondencesPtr = std::shared_ptr<Correspondences>;
 
-struct Matrix4f {  // row-major 4x4 (PCL hands out Eigen::Matrix4f; coefficient access is (row, col))
+struct Matrix4f {  // row-major 4x4 with Eigen's coefficient access (row, col); PCL hands out Eigen::Matrix4f
   float m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   float& operator()(int r, int c) { return m[4 * r + c]; }
   float operator()(int r, int c) const { return m[4 * r + c]; }
   static Matrix4f Identity() { return Matrix4f(); }
+  void setIdentity() { *this = Matrix4f(); }
+  Matrix4f operator*(const Matrix4f& o) const {  // Eigen's coefficient order ((a0 b0 + a1 b1) + a2 b2) + a3 b3
+    Matrix4f r;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        float s = m[4 * i] * o.m[j] + m[4 * i + 1] * o.m[4 + j];
+        s = s + m[4 * i + 2] * o.m[8 + j];
+        s = s + m[4 * i + 3] * o.m[12 + j];
+        r.m[4 * i + j] = s;
+      }
+    return r;
+  }
 };
 
 // One context per device, shared by the objects below (like PCL objects share nothing but the clouds).
 class Context {
  public:
+  using Ptr = std::shared_ptr<Context>;
   explicit Context(int device = 0, void* hip_stream = nullptr) {
     if (pclhip_ctx_create(device, hip_stream, &ctx_) != PCLHIP_OK) {
       error_ = pclhip_last_error(nullptr);
@@ -98,58 +127,207 @@ class Context {
   bool ok() const { return ctx_ != nullptr; }
   pclhip_ctx* get() const { return ctx_; }
   std::string getLastError() const { return ctx_ ? pclhip_last_error(ctx_) : error_; }
-  using Ptr = std::shared_ptr<Context>;
+  // the context objects use when none is given: PCL classes are default-constructible, so are these
+  static Ptr defaultContext() {
+    static Ptr c = std::make_shared<Context>(0);
+    return c;
+  }
  private:
   pclhip_ctx* ctx_ = nullptr;
   std::string error_;
 };
 
+// common/include/pcl/pcl_base.h:65-175
+template <typename PointT>
+class PCLBase {
+ public:
+  using PointCloudConstPtr = typename PointCloud<PointT>::ConstPtr;
+  virtual ~PCLBase() = default;
+  virtual void setInputCloud(const PointCloudConstPtr& cloud) { input_ = cloud; }
+  PointCloudConstPtr getInputCloud() const { return input_; }
+  virtual void setIndices(const IndicesPtr& indices) { indices_ = indices; fake_indices_ = false; }
+  virtual void setIndices(const IndicesConstPtr& indices) { indices_ = std::make_shared<Indices>(*indices); fake_indices_ = false; }
+  IndicesPtr getIndices() { return indices_; }
+ protected:
+  PointCloudConstPtr input_;
+  IndicesPtr indices_;
+  bool fake_indices_ = false;
+  bool initCompute() {  // impl/pcl_base.hpp:138-174: no indices given -> all points
+    if (!input_) return false;
+    if (!indices_) { fake_indices_ = true; indices_ = std::make_shared<Indices>(); }
+    if (fake_indices_ && indices_->size() != input_->size()) {
+      indices_->resize(input_->size());
+      for (std::size_t i = 0; i < indices_->size(); ++i) (*indices_)[i] = index_t(i);
+    }
+    return true;
+  }
+  bool usesAllPoints() const { return !indices_ || fake_indices_ || indices_->size() == input_->size(); }
+};
+
+// common/include/pcl/point_representation.h:59-190, 256-279, 546-579
+template <typename PointT>
+class PointRepresentation {
+ public:
+  using Ptr = std::shared_ptr<PointRepresentation<PointT>>;
+  using ConstPtr = std::shared_ptr<const PointRepresentation<PointT>>;
+  virtual ~PointRepresentation() = default;
+  virtual void copyToFloatArray(const PointT& p, float* out) const = 0;
+  template <typename OutputType> void vectorize(const PointT& p, OutputType& out) const {
+    float t[16] = {0};
+    copyToFloatArray(p, t);
+    for (int i = 0; i < nr_dimensions_; ++i) out[i] = alpha_.empty() ? t[i] : t[i] * alpha_[std::size_t(i)];
+  }
+  void setRescaleValues(const float* rescale_array) { alpha_.assign(rescale_array, rescale_array + nr_dimensions_); }
+  int getNumberOfDimensions() const { return nr_dimensions_; }
+ protected:
+  int nr_dimensions_ = 0;
+  std::vector<float> alpha_;
+};
+template <typename PointT>
+class DefaultPointRepresentation : public PointRepresentation<PointT> {
+ public:
+  DefaultPointRepresentation() { this->nr_dimensions_ = 3; }
+  void copyToFloatArray(const PointT& p, float* out) const override { out[0] = p.x; out[1] = p.y; out[2] = p.z; }
+};
+template <typename PointT>
+class CustomPointRepresentation : public PointRepresentation<PointT> {
+ public:
+  explicit CustomPointRepresentation(int max_dim = 3, int start_dim = 0) : start_dim_(start_dim) {
+    this->nr_dimensions_ = max_dim < 16 ? max_dim : 16;
+  }
+  void copyToFloatArray(const PointT& p, float* out) const override {
+    const float* f = reinterpret_cast<const float*>(&p) + start_dim_;
+    for (int i = 0; i < this->nr_dimensions_; ++i) out[i] = f[i];
+  }
+ private:
+  int start_dim_;
+};
+
 namespace search {
 
-// pcl::search::KdTree<PointT>: setInputCloud / nearestKSearch (single + batch overloads).
+// pcl::search::Search<PointT>: what Feature::setSearchMethod and the registration classes talk to.  The batch
+// overloads have the reference's default (a loop over the per-point virtual, search.hpp:113-136,164-190).
 template <typename PointT>
-class KdTree {
+class Search {
+ public:
+  using Ptr = std::shared_ptr<Search<PointT>>;
+  using ConstPtr = std::shared_ptr<const Search<PointT>>;
+  using PointCloudConstPtr = typename PointCloud<PointT>::ConstPtr;
+  explicit Search(const std::string& name = "", bool sorted = false) : sorted_results_(sorted), name_(name) {}
+  virtual ~Search() = default;
+  virtual const std::string& getName() const { return name_; }
+  virtual void setSortedResults(bool sorted) { sorted_results_ = sorted; }
+  virtual bool getSortedResults() { return sorted_results_; }
+  virtual bool setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) = 0;
+  virtual PointCloudConstPtr getInputCloud() const { return input_; }
+  virtual IndicesConstPtr getIndices() const { return indices_; }
+  virtual int nearestKSearch(const PointT& point, int k, Indices& k_indices, std::vector<float>& k_sqr_distances) const = 0;
+  virtual int nearestKSearch(const PointCloud<PointT>& cloud, index_t index, int k, Indices& k_indices,
+                             std::vector<float>& k_sqr_distances) const {
+    return nearestKSearch(cloud[std::size_t(index)], k, k_indices, k_sqr_distances);
+  }
+  virtual void nearestKSearch(const PointCloud<PointT>& cloud, const Indices& indices, int k, std::vector<Indices>& k_indices,
+                              std::vector<std::vector<float>>& k_sqr_distances) const {
+    const std::size_t n = indices.empty() ? cloud.size() : indices.size();
+    k_indices.assign(n, Indices());
+    k_sqr_distances.assign(n, std::vector<float>());
+    for (std::size_t i = 0; i < n; ++i)
+      nearestKSearch(cloud, indices.empty() ? index_t(i) : indices[i], k, k_indices[i], k_sqr_distances[i]);
+  }
+  virtual int radiusSearch(const PointT& point, double radius, Indices& k_indices, std::vector<float>& k_sqr_distances,
+                           unsigned int max_nn = 0) const = 0;
+  virtual void radiusSearch(const PointCloud<PointT>& cloud, const Indices& indices, double radius,
+                            std::vector<Indices>& k_indices, std::vector<std::vector<float>>& k_sqr_distances,
+                            unsigned int max_nn = 0) const {
+    const std::size_t n = indices.empty() ? cloud.size() : indices.size();
+    k_indices.assign(n, Indices());
+    k_sqr_distances.assign(n, std::vector<float>());
+    for (std::size_t i = 0; i < n; ++i)
+      radiusSearch(cloud[std::size_t(indices.empty() ? index_t(i) : indices[i])], radius, k_indices[i], k_sqr_distances[i], max_nn);
+  }
+ protected:
+  PointCloudConstPtr input_;
+  IndicesConstPtr indices_;
+  bool sorted_results_;
+  std::string name_;
+};
+
+// pcl::search::KdTree<PointT> on the device index: setInputCloud / nearestKSearch / radiusSearch (single +
+// batch overloads; the batch ones are ONE launch).
+template <typename PointT>
+class KdTree : public Search<PointT> {
  public:
   using Ptr = std::shared_ptr<KdTree<PointT>>;
   using PointCloudConstPtr = typename PointCloud<PointT>::ConstPtr;
-  explicit KdTree(Context::Ptr ctx, bool sorted = true) : ctx_(std::move(ctx)) { (void)sorted; }
-  ~KdTree() { if (index_) pclhip_index_destroy(index_); }
+  using PointRepresentationConstPtr = typename PointRepresentation<PointT>::ConstPtr;
+  using Search<PointT>::nearestKSearch;
+  using Search<PointT>::radiusSearch;
+  explicit KdTree(bool sorted = true) : KdTree(Context::defaultContext(), sorted) {}
+  explicit KdTree(Context::Ptr ctx, bool sorted = true) : Search<PointT>("KdTree", sorted), ctx_(std::move(ctx)) {}
+  ~KdTree() override { if (index_) pclhip_index_destroy(index_); }
   KdTree(const KdTree&) = delete;
   KdTree& operator=(const KdTree&) = delete;
 
-  // search/include/pcl/search/impl/kdtree.hpp:87-97; a repeated call with the same cloud object is
-  // a no-op (the reference rebuilds twice on a cold align())
-  bool setInputCloud(const PointCloudConstPtr& cloud, const std::shared_ptr<const Indices>& indices = nullptr) {
-    if (!ctx_ || !ctx_->ok() || !cloud) return false;
-    if (index_ && cloud == input_ && indices == indices_) return true;
+  // search/include/pcl/search/impl/kdtree.hpp:87-97 -> kdtree_flann.hpp:99-136: always (re)builds, like the
+  // reference -- the cloud behind an unchanged pointer may have been modified in place.  Who knows it has not
+  // keeps the tree and passes it with setSearchMethodTarget(tree, /*force_no_recompute=*/true).
+  bool setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) override {
     if (index_) { pclhip_index_destroy(index_); index_ = nullptr; }
-    input_ = cloud;
-    indices_ = indices;
-    const pclhip_status st = pclhip_index_build(ctx_->get(), cloud->points.data(), sizeof(PointT), cloud->size(),
-                                                indices ? indices->data() : nullptr, indices ? indices->size() : 0,
-                                                &index_);
-    return st == PCLHIP_OK;
+    this->input_ = cloud;
+    this->indices_ = indices;
+    if (!ctx_ || !ctx_->ok() || !cloud || unsupported_) return false;
+    const bool sub = indices && !indices->empty();
+    return pclhip_index_build_scaled(ctx_->get(), cloud->points.data(), sizeof(PointT), cloud->size(),
+                                     sub ? indices->data() : nullptr, sub ? indices->size() : 0,
+                                     scaled_ ? scale_ : nullptr, &index_) == PCLHIP_OK;
   }
-  PointCloudConstPtr getInputCloud() const { return input_; }
+  // kdtree.h:110: honoured for (x, y, z) prefixes with rescale values (the index is three-dimensional);
+  // any other representation makes setInputCloud fail instead of searching something else
+  void setPointRepresentation(const PointRepresentationConstPtr& rep) {
+    rep_ = rep;
+    scaled_ = unsupported_ = false;
+    if (!rep) return;
+    const int d = rep->getNumberOfDimensions();
+    float probe[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    bool ok = d >= 1 && d <= 3;
+    for (int a = 0; a < 3 && ok; ++a) {
+      PointT p;
+      p.x = a == 0 ? 1.0f : 0.0f; p.y = a == 1 ? 1.0f : 0.0f; p.z = a == 2 ? 1.0f : 0.0f;
+      float out[16] = {0};
+      rep->vectorize(p, out);
+      for (int j = 0; j < d; ++j) probe[a][j] = out[j];
+    }
+    for (int a = 0; a < 3 && ok; ++a)
+      for (int j = 0; j < 3; ++j)
+        if (j != a && probe[a][j] != 0.0f) ok = false;
+    if (!ok) { unsupported_ = true; return; }
+    for (int a = 0; a < 3; ++a) scale_[a] = a < d ? probe[a][a] : 0.0f;
+    scaled_ = !(scale_[0] == 1.0f && scale_[1] == 1.0f && scale_[2] == 1.0f);
+    if (this->input_) setInputCloud(this->input_, this->indices_);
+  }
+  PointRepresentationConstPtr getPointRepresentation() const { return rep_; }
+  bool hasDefaultRepresentation() const { return !scaled_ && !unsupported_; }
 
   // kdtree_flann.hpp:234-274: returns the number of neighbours found, resizes the outputs
-  int nearestKSearch(const PointT& point, int k, Indices& k_indices, std::vector<float>& k_sqr_distances) const {
+  int nearestKSearch(const PointT& point, int k, Indices& k_indices, std::vector<float>& k_sqr_distances) const override {
+    k_indices.clear();
+    k_sqr_distances.clear();
     if (!index_ || k < 1) return 0;
     const std::uint64_t n = pclhip_index_size(index_);
     if (std::uint64_t(k) > n) k = int(n);  // :241-242
-    k_indices.resize(k);
-    k_sqr_distances.resize(k);
     if (k == 0) return 0;
+    k_indices.resize(std::size_t(k));
+    k_sqr_distances.resize(std::size_t(k));
     if (pclhip_knn(index_, &point, sizeof(PointT), 1, k, k_indices.data(), k_sqr_distances.data()) != PCLHIP_OK) return 0;
     int found = 0;
-    while (found < k && k_indices[found] >= 0) ++found;
-    k_indices.resize(found);
-    k_sqr_distances.resize(found);
+    while (found < k && k_indices[std::size_t(found)] >= 0) ++found;
+    k_indices.resize(std::size_t(found));
+    k_sqr_distances.resize(std::size_t(found));
     return found;
   }
   // batch overload, search/include/pcl/search/search.h:216-219 -- the efficient entry: one launch
   void nearestKSearch(const PointCloud<PointT>& cloud, const Indices& indices, int k, std::vector<Indices>& k_indices,
-                      std::vector<std::vector<float>>& k_sqr_distances) const {
+                      std::vector<std::vector<float>>& k_sqr_distances) const override {
     k_indices.clear();
     k_sqr_distances.clear();
     if (!index_ || k < 1) return;
@@ -158,7 +336,7 @@ class KdTree {
     std::size_t nq = cloud.size();
     if (!indices.empty()) {
       q.reserve(indices.size());
-      for (index_t i : indices) q.push_back(cloud[i]);
+      for (index_t i : indices) q.push_back(cloud[std::size_t(i)]);
       qp = q.data();
       nq = q.size();
     }
@@ -167,27 +345,27 @@ class KdTree {
     k_indices.assign(nq, Indices());
     k_sqr_distances.assign(nq, std::vector<float>());
     if (kk == 0 || nq == 0) return;
-    Indices flat_i(nq * kk);
-    std::vector<float> flat_d(nq * kk);
+    Indices flat_i(nq * std::size_t(kk));
+    std::vector<float> flat_d(nq * std::size_t(kk));
     if (pclhip_knn(index_, qp, sizeof(PointT), nq, kk, flat_i.data(), flat_d.data()) != PCLHIP_OK) return;
     for (std::size_t i = 0; i < nq; ++i) {
       int found = 0;
-      while (found < kk && flat_i[i * kk + found] >= 0) ++found;
-      k_indices[i].assign(flat_i.begin() + i * kk, flat_i.begin() + i * kk + found);
-      k_sqr_distances[i].assign(flat_d.begin() + i * kk, flat_d.begin() + i * kk + found);
+      while (found < kk && flat_i[i * std::size_t(kk) + std::size_t(found)] >= 0) ++found;
+      k_indices[i].assign(flat_i.begin() + long(i * std::size_t(kk)), flat_i.begin() + long(i * std::size_t(kk)) + found);
+      k_sqr_distances[i].assign(flat_d.begin() + long(i * std::size_t(kk)), flat_d.begin() + long(i * std::size_t(kk)) + found);
     }
   }
   // kdtree_flann.hpp:372-414: neighbours with squared distance < radius^2, ascending; max_nn = 0: all
   int radiusSearch(const PointT& point, double radius, Indices& k_indices, std::vector<float>& k_sqr_distances,
-                   unsigned int max_nn = 0) const {
+                   unsigned int max_nn = 0) const override {
     k_indices.clear();
     k_sqr_distances.clear();
     if (!index_) return 0;
     std::uint64_t off[2] = {0, 0}, total = 0;
     pclhip_status st = pclhip_radius_search(index_, &point, sizeof(PointT), 1, radius, max_nn, off, nullptr, nullptr, 0, &total);
     if ((st != PCLHIP_OK && st != PCLHIP_ERR_OVERFLOW) || total == 0) return 0;
-    k_indices.resize(total);
-    k_sqr_distances.resize(total);
+    k_indices.resize(std::size_t(total));
+    k_sqr_distances.resize(std::size_t(total));
     if (pclhip_radius_search(index_, &point, sizeof(PointT), 1, radius, max_nn, off, k_indices.data(),
                              k_sqr_distances.data(), total, &total) != PCLHIP_OK) {
       k_indices.clear();
@@ -199,7 +377,7 @@ class KdTree {
   // batch overload (search/include/pcl/search/impl/search.hpp:164-190): one call for the whole cloud
   void radiusSearch(const PointCloud<PointT>& cloud, const Indices& indices, double radius,
                     std::vector<Indices>& k_indices, std::vector<std::vector<float>>& k_sqr_distances,
-                    unsigned int max_nn = 0) const {
+                    unsigned int max_nn = 0) const override {
     k_indices.clear();
     k_sqr_distances.clear();
     if (!index_) return;
@@ -207,7 +385,7 @@ class KdTree {
     const PointT* qp = cloud.points.data();
     std::size_t nq = cloud.size();
     if (!indices.empty()) {
-      for (index_t i : indices) q.push_back(cloud[i]);
+      for (index_t i : indices) q.push_back(cloud[std::size_t(i)]);
       qp = q.data();
       nq = q.size();
     }
@@ -218,13 +396,13 @@ class KdTree {
     std::uint64_t total = 0;
     pclhip_status st = pclhip_radius_search(index_, qp, sizeof(PointT), nq, radius, max_nn, off.data(), nullptr, nullptr, 0, &total);
     if ((st != PCLHIP_OK && st != PCLHIP_ERR_OVERFLOW) || total == 0) return;
-    Indices flat_i(total);
-    std::vector<float> flat_d(total);
+    Indices flat_i(static_cast<std::size_t>(total), 0);
+    std::vector<float> flat_d(static_cast<std::size_t>(total), 0.0f);
     if (pclhip_radius_search(index_, qp, sizeof(PointT), nq, radius, max_nn, off.data(), flat_i.data(), flat_d.data(),
                              total, &total) != PCLHIP_OK) return;
     for (std::size_t i = 0; i < nq; ++i) {
-      k_indices[i].assign(flat_i.begin() + off[i], flat_i.begin() + off[i + 1]);
-      k_sqr_distances[i].assign(flat_d.begin() + off[i], flat_d.begin() + off[i + 1]);
+      k_indices[i].assign(flat_i.begin() + long(off[i]), flat_i.begin() + long(off[i + 1]));
+      k_sqr_distances[i].assign(flat_d.begin() + long(off[i]), flat_d.begin() + long(off[i + 1]));
     }
   }
   pclhip_index* handle() const { return index_; }
@@ -233,39 +411,48 @@ class KdTree {
  private:
   Context::Ptr ctx_;
   pclhip_index* index_ = nullptr;
-  PointCloudConstPtr input_;
-  std::shared_ptr<const Indices> indices_;
+  PointRepresentationConstPtr rep_;
+  float scale_[3] = {1, 1, 1};
+  bool scaled_ = false, unsupported_ = false;
 };
 
 }  // namespace search
 
-// pcl::NormalEstimation<PointInT, pcl::Normal> in k-NN mode (setKSearch).
+// pcl::NormalEstimation<PointInT, pcl::Normal> (setKSearch or setRadiusSearch).
 template <typename PointInT>
-class NormalEstimation {
+class NormalEstimation : public PCLBase<PointInT> {
  public:
+  using SearchPtr = typename search::Search<PointInT>::Ptr;  // Feature::KdTreePtr is a search::Search (feature.h:119-120)
+  NormalEstimation() : NormalEstimation(Context::defaultContext()) {}
   explicit NormalEstimation(Context::Ptr ctx) : ctx_(std::move(ctx)) {}
-  void setInputCloud(const typename PointCloud<PointInT>::ConstPtr& cloud) { input_ = cloud; }
-  void setSearchMethod(const typename search::KdTree<PointInT>::Ptr& tree) { tree_ = tree; }
+  void setSearchMethod(const SearchPtr& tree) { tree_ = tree; }
+  SearchPtr getSearchMethod() const { return tree_; }
   void setKSearch(int k) { k_ = k; }
   void setRadiusSearch(double radius) { radius_ = radius; }
   // normal_3d.h:255-262 / :328-351: the cloud's sensor origin is the viewpoint until setViewPoint is called
   void setViewPoint(float x, float y, float z) { vp_[0] = x; vp_[1] = y; vp_[2] = z; use_sensor_origin_ = false; }
   void useSensorOriginAsViewPoint() { use_sensor_origin_ = true; }
   // Feature::compute (features/include/pcl/features/impl/feature.hpp:195-229); initCompute refuses
-  // "both radius and K defined" and "neither defined" (:131-174)
+  // "both radius and K defined" and "neither defined" (:131-174).  The fused device kernel needs the device
+  // search method (a foreign Search object has no neighbours-for-all-points entry this class could batch).
   void compute(PointCloud<Normal>& output) {
     output.points.clear();
-    if (!input_ || (k_ < 1) == !(radius_ > 0.0)) return;
+    const auto& input = this->input_;
+    if (!input || (k_ < 1) == !(radius_ > 0.0)) return;
     if (!tree_) tree_ = std::make_shared<search::KdTree<PointInT>>(ctx_);
-    if (!tree_->setInputCloud(input_)) return;
-    if (use_sensor_origin_) {
-      vp_[0] = input_->sensor_origin_[0]; vp_[1] = input_->sensor_origin_[1]; vp_[2] = input_->sensor_origin_[2];
+    auto* dev = dynamic_cast<search::KdTree<PointInT>*>(tree_.get());
+    if (dev == nullptr) return;
+    if (dev->getInputCloud() != input || dev->handle() == nullptr) {  // feature.hpp:125-130
+      if (!dev->setInputCloud(input)) return;
     }
-    output.resize(input_->size());
+    if (use_sensor_origin_) {
+      vp_[0] = input->sensor_origin_[0]; vp_[1] = input->sensor_origin_[1]; vp_[2] = input->sensor_origin_[2];
+    }
+    output.resize(input->size());
     std::uint64_t nan = 0;
-    std::vector<float> tmp(input_->size() * 4);
-    const pclhip_status st = (k_ >= 1) ? pclhip_normals(tree_->handle(), k_, vp_, tmp.data(), 16, &nan)
-                                       : pclhip_normals_radius(tree_->handle(), radius_, vp_, tmp.data(), 16, &nan);
+    std::vector<float> tmp(input->size() * 4);
+    const pclhip_status st = (k_ >= 1) ? pclhip_normals(dev->handle(), k_, vp_, tmp.data(), 16, &nan)
+                                       : pclhip_normals_radius(dev->handle(), radius_, vp_, tmp.data(), 16, &nan);
     if (st != PCLHIP_OK) { output.points.clear(); return; }
     for (std::size_t i = 0; i < output.size(); ++i) {
       output[i].normal_x = tmp[4 * i]; output[i].normal_y = tmp[4 * i + 1]; output[i].normal_z = tmp[4 * i + 2];
@@ -273,11 +460,9 @@ class NormalEstimation {
     }
     output.is_dense = (nan == 0);  // normal_3d.hpp:56,63
   }
-  typename search::KdTree<PointInT>::Ptr getSearchMethod() const { return tree_; }
  private:
   Context::Ptr ctx_;
-  typename PointCloud<PointInT>::ConstPtr input_;
-  typename search::KdTree<PointInT>::Ptr tree_;
+  SearchPtr tree_;
   int k_ = 0;
   double radius_ = 0.0;
   float vp_[3] = {0, 0, 0};
@@ -288,227 +473,553 @@ namespace registration {
 
 // pcl::registration::CorrespondenceRejector{Distance,MedianDistance,OneToOne,Trimmed}: parameter holders;
 // the rejection itself runs on the device inside the ICP iteration (pclhip_icp_set_rejectors).
-struct CorrespondenceRejector {
+class CorrespondenceRejector {
+ public:
   using Ptr = std::shared_ptr<CorrespondenceRejector>;
   pclhip_rejector desc{PCLHIP_REJ_DISTANCE, 0.0, 0, 0};
   virtual ~CorrespondenceRejector() = default;
+  const std::string& getClassName() const { return rejection_name_; }
+ protected:
+  std::string rejection_name_;
 };
 struct CorrespondenceRejectorDistance : CorrespondenceRejector {
-  CorrespondenceRejectorDistance() { desc.kind = PCLHIP_REJ_DISTANCE; }
+  CorrespondenceRejectorDistance() { desc.kind = PCLHIP_REJ_DISTANCE; rejection_name_ = "CorrespondenceRejectorDistance"; }
   void setMaximumDistance(float d) { desc.param = d; }  // correspondence_rejection_distance.h:93-97
+  float getMaximumDistance() const { return float(desc.param); }
 };
 struct CorrespondenceRejectorMedianDistance : CorrespondenceRejector {
-  CorrespondenceRejectorMedianDistance() { desc.kind = PCLHIP_REJ_MEDIAN_DISTANCE; desc.param = 1.0; }
+  CorrespondenceRejectorMedianDistance() {
+    desc.kind = PCLHIP_REJ_MEDIAN_DISTANCE; desc.param = 1.0; rejection_name_ = "CorrespondenceRejectorMedianDistance";
+  }
   void setMedianFactor(double f) { desc.param = f; }
+  double getMedianFactor() const { return desc.param; }
 };
 struct CorrespondenceRejectorOneToOne : CorrespondenceRejector {
-  CorrespondenceRejectorOneToOne() { desc.kind = PCLHIP_REJ_ONE_TO_ONE; }
+  CorrespondenceRejectorOneToOne() { desc.kind = PCLHIP_REJ_ONE_TO_ONE; rejection_name_ = "CorrespondenceRejectorOneToOne"; }
 };
 struct CorrespondenceRejectorTrimmed : CorrespondenceRejector {
-  CorrespondenceRejectorTrimmed() { desc.kind = PCLHIP_REJ_TRIMMED; desc.param = 0.5; }
+  CorrespondenceRejectorTrimmed() { desc.kind = PCLHIP_REJ_TRIMMED; desc.param = 0.5; rejection_name_ = "CorrespondenceRejectorTrimmed"; }
   void setOverlapRatio(float r) { desc.param = r; }
+  float getOverlapRatio() const { return float(desc.param); }
   void setMinCorrespondences(unsigned n) { desc.min_correspondences = n; }
+  unsigned getMinCorrespondences() const { return desc.min_correspondences; }
 };
 
-// pcl::registration::CorrespondenceEstimation::determineCorrespondences
+// pcl::registration::TransformationEstimation (transformation_estimation.h:50-125): the four overloads
 template <typename PointSource, typename PointTarget>
-class CorrespondenceEstimation {
- public:
-  explicit CorrespondenceEstimation(Context::Ptr ctx) : ctx_(std::move(ctx)) {}
-  void setInputSource(const typename PointCloud<PointSource>::ConstPtr& c) { source_ = c; }
-  void setInputTarget(const typename PointCloud<PointTarget>::ConstPtr& c) { target_ = c; }
-  void setSearchMethodTarget(const typename search::KdTree<PointTarget>::Ptr& t, bool = false) { tree_ = t; }
-  void determineReciprocalCorrespondences(Correspondences& out, double max_distance = std::sqrt(DBL_MAX)) {
-    reciprocal_ = true;
-    determineCorrespondences(out, max_distance);
-    reciprocal_ = false;
-  }
-  void determineCorrespondences(Correspondences& out, double max_distance = std::sqrt(DBL_MAX)) {
-    out.clear();
-    if (!source_ || !target_) return;
-    if (!tree_) tree_ = std::make_shared<search::KdTree<PointTarget>>(ctx_);
-    if (!tree_->setInputCloud(target_)) return;
-    pclhip_icp* icp = nullptr;
-    if (pclhip_icp_create(tree_->handle(), &icp) != PCLHIP_OK) return;
-    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    double sums[PCLHIP_ICP_NSUMS];
-    if (pclhip_icp_set_source(icp, source_->points.data(), sizeof(PointSource), source_->size()) == PCLHIP_OK &&
-        pclhip_icp_set_reciprocal(icp, reciprocal_ ? 1 : 0) == PCLHIP_OK &&
-        pclhip_icp_iterate(icp, I, max_distance, PCLHIP_ICP_POINT_TO_POINT, sums) == PCLHIP_OK) {
-      const std::size_t n = source_->size();
-      Indices q(n), m(n);
-      std::vector<float> d(n);
-      std::uint64_t cnt = 0;
-      if (pclhip_icp_fetch_correspondences(icp, q.data(), m.data(), d.data(), &cnt) == PCLHIP_OK) {
-        out.resize(cnt);
-        for (std::uint64_t i = 0; i < cnt; ++i) { out[i].index_query = q[i]; out[i].index_match = m[i]; out[i].distance = d[i]; }
-      }
-    }
-    pclhip_icp_destroy(icp);
-  }
- private:
-  Context::Ptr ctx_;
-  typename PointCloud<PointSource>::ConstPtr source_;
-  typename PointCloud<PointTarget>::ConstPtr target_;
-  typename search::KdTree<PointTarget>::Ptr tree_;
-  bool reciprocal_ = false;
-};
-
-}  // namespace registration
-
-// pcl::IterativeClosestPoint<PointSource, PointTarget>; MODE selects the estimator exactly as the
-// reference's two classes do (icp.h:149-151 SVD, icp.h:395-398 point-to-plane LLS).
-template <typename PointSource, typename PointTarget, int MODE = PCLHIP_ICP_POINT_TO_POINT>
-class IterativeClosestPoint {
- public:
-  using PointCloudSource = PointCloud<PointSource>;
-  using PointCloudTarget = PointCloud<PointTarget>;
-  explicit IterativeClosestPoint(Context::Ptr ctx) : ctx_(std::move(ctx)) { pclhip_icp_params_default(&p_); p_.mode = MODE; }
-  ~IterativeClosestPoint() { if (icp_) pclhip_icp_destroy(icp_); }
-  IterativeClosestPoint(const IterativeClosestPoint&) = delete;             // icp.h:168-173
-  IterativeClosestPoint& operator=(const IterativeClosestPoint&) = delete;
-
-  void setInputSource(const typename PointCloudSource::ConstPtr& c) { source_ = c; source_dirty_ = true; }
-  void setInputTarget(const typename PointCloudTarget::ConstPtr& c) { target_ = c; target_dirty_ = true; }
-  void setSearchMethodTarget(const typename search::KdTree<PointTarget>::Ptr& t, bool force_no_recompute = false) {
-    tree_ = t; force_no_recompute_ = force_no_recompute; target_dirty_ = true;
-  }
-  void setMaximumIterations(int n) { p_.max_iterations = n; }
-  void setMaxCorrespondenceDistance(double d) { p_.max_correspondence_distance = d; }
-  void setTransformationEpsilon(double e) { p_.transformation_epsilon = e; }
-  void setTransformationRotationEpsilon(double e) { p_.transformation_rotation_epsilon = e; }
-  void setEuclideanFitnessEpsilon(double e) { p_.euclidean_fitness_epsilon = e; }
-  // Registration::addCorrespondenceRejector (registration.h:430-434), icp.h:251-256
-  void addCorrespondenceRejector(const registration::CorrespondenceRejector::Ptr& r) { rejectors_.push_back(r); filters_dirty_ = true; }
-  void clearCorrespondenceRejectors() { rejectors_.clear(); filters_dirty_ = true; }
-  void setUseReciprocalCorrespondences(bool on) { reciprocal_ = on; filters_dirty_ = true; }
-  // IterativeClosestPointWithNormals::setUseSymmetricObjective / setEnforceSameDirectionNormals
-  // (icp.h:380-428): TransformationEstimationSymmetricPointToPlaneLLS; source AND target need normals
-  void setUseSymmetricObjective(bool on) {
-    static_assert(MODE == PCLHIP_ICP_POINT_TO_PLANE, "only IterativeClosestPointWithNormals has this option");
-    p_.mode = on ? PCLHIP_ICP_SYMMETRIC : PCLHIP_ICP_POINT_TO_PLANE;
-  }
-  bool getUseSymmetricObjective() const { return p_.mode == PCLHIP_ICP_SYMMETRIC; }
-  void setEnforceSameDirectionNormals(bool on) { enforce_same_direction_ = on; filters_dirty_ = true; }
-  bool getEnforceSameDirectionNormals() const { return enforce_same_direction_; }
-  int getMaximumIterations() const { return p_.max_iterations; }
-  double getMaxCorrespondenceDistance() const { return p_.max_correspondence_distance; }
-
-  // Registration::align (registration/include/pcl/registration/impl/registration.hpp:170-221)
-  void align(PointCloudSource& output, const Matrix4f& guess = Matrix4f::Identity()) {
-    converged_ = false;
-    if (!initCompute()) return;
-    pclhip_icp_result r;
-    if (pclhip_icp_align(icp_, &p_, guess.m, &r) != PCLHIP_OK) return;
-    std::memcpy(final_.m, r.final_transformation, sizeof final_.m);
-    converged_ = r.converged != 0;
-    nr_iterations_ = r.nr_iterations;
-    state_ = r.convergence_state;
-    last_mse_ = r.mse;
-    output = *source_;  // icp.hpp:264-267: copy all fields, then transform xyz (+ normals)
-    const std::size_t nrm_off = (MODE == PCLHIP_ICP_POINT_TO_PLANE && sizeof(PointSource) >= 28) ? 16 : 0;
-    pclhip_transform_cloud(ctx_->get(), final_.m, MODE == PCLHIP_ICP_POINT_TO_PLANE ? 1 : 0, source_->points.data(),
-                           output.points.data(), sizeof(PointSource), source_->size(), nrm_off);
-  }
-  Matrix4f getFinalTransformation() const { return final_; }
-  bool hasConverged() const { return converged_; }
-  // Registration::getFitnessScore (registration/include/pcl/registration/impl/registration.hpp:132-168)
-  double getFitnessScore(double max_range = std::numeric_limits<double>::max()) {
-    if (!initCompute()) return std::numeric_limits<double>::max();
-    double score = std::numeric_limits<double>::max();
-    pclhip_icp_fitness_score(icp_, final_.m, max_range, &score, nullptr);
-    return score;
-  }
-  int getNumberOfIterations() const { return nr_iterations_; }
-  int getConvergenceState() const { return state_; }
-  double getLastMSE() const { return last_mse_; }
-  std::string getLastError() const { return ctx_->getLastError(); }
-
- private:
-  // Registration::initCompute (impl/registration.hpp:73-101): (re)build the target tree only when
-  // the target changed and force_no_recompute was not requested
-  bool initCompute() {
-    if (!ctx_ || !ctx_->ok() || !source_ || (!target_ && !tree_)) return false;
-    if (!tree_) tree_ = std::make_shared<search::KdTree<PointTarget>>(ctx_);
-    if (target_dirty_) {
-      if (!(force_no_recompute_ && tree_->handle())) {
-        if (!target_ || !tree_->setInputCloud(target_)) return false;
-      }
-      if (MODE == PCLHIP_ICP_POINT_TO_PLANE && target_ && sizeof(PointTarget) >= 28) {
-        // pcl::PointNormal target: normals live at +16 in every 48-byte record
-        const char* base = reinterpret_cast<const char*>(target_->points.data());
-        if (pclhip_index_set_normals(tree_->handle(), base + 16, sizeof(PointTarget)) != PCLHIP_OK) return false;
-      }
-      if (icp_) { pclhip_icp_destroy(icp_); icp_ = nullptr; }
-      target_dirty_ = false;
-      source_dirty_ = true;
-    }
-    if (!icp_ && pclhip_icp_create(tree_->handle(), &icp_) != PCLHIP_OK) return false;
-    if (source_dirty_) {
-      if (pclhip_icp_set_source(icp_, source_->points.data(), sizeof(PointSource), source_->size()) != PCLHIP_OK) return false;
-      if (MODE == PCLHIP_ICP_POINT_TO_PLANE && sizeof(PointSource) >= 28) {  // pcl::PointNormal source
-        const char* base = reinterpret_cast<const char*>(source_->points.data());
-        if (pclhip_icp_set_source_normals(icp_, base + 16, sizeof(PointSource)) != PCLHIP_OK) return false;
-      }
-      source_dirty_ = false;
-      filters_dirty_ = true;
-    }
-    if (filters_dirty_) {
-      std::vector<pclhip_rejector> list;
-      for (const auto& r : rejectors_) list.push_back(r->desc);
-      if (pclhip_icp_set_rejectors(icp_, list.data(), int(list.size())) != PCLHIP_OK) return false;
-      if (pclhip_icp_set_reciprocal(icp_, reciprocal_ ? 1 : 0) != PCLHIP_OK) return false;
-      if (pclhip_icp_set_enforce_same_direction_normals(icp_, enforce_same_direction_ ? 1 : 0) != PCLHIP_OK) return false;
-      filters_dirty_ = false;
-    }
-    return true;
-  }
-  Context::Ptr ctx_;
-  pclhip_icp_params p_;
-  pclhip_icp* icp_ = nullptr;
-  typename PointCloudSource::ConstPtr source_;
-  typename PointCloudTarget::ConstPtr target_;
-  typename search::KdTree<PointTarget>::Ptr tree_;
-  bool force_no_recompute_ = false, target_dirty_ = true, source_dirty_ = true, filters_dirty_ = true;
-  bool reciprocal_ = false, enforce_same_direction_ = true;
-  std::vector<registration::CorrespondenceRejector::Ptr> rejectors_;
-  Matrix4f final_;
-  bool converged_ = false;
-  int nr_iterations_ = 0, state_ = 0;
-  double last_mse_ = 0;
-};
-
-template <typename PointSource, typename PointTarget>
-using IterativeClosestPointWithNormals = IterativeClosestPoint<PointSource, PointTarget, PCLHIP_ICP_POINT_TO_PLANE>;
-
-namespace registration {
-// TransformationEstimationSVD / PointToPlaneLLS / SymmetricPointToPlaneLLS::estimateRigidTransformation
-// (cloud_src, cloud_tgt, T): pair i = (src[i], tgt[i]) (transformation_estimation.h:71-115).  Normals are
-// read from the PointNormal layout (+16 bytes).
-template <typename PointSource, typename PointTarget, int MODE>
 class TransformationEstimation {
  public:
-  explicit TransformationEstimation(Context::Ptr ctx) : ctx_(std::move(ctx)) {}
-  void setEnforceSameDirectionNormals(bool on) { enforce_ = on; }
-  bool estimateRigidTransformation(const PointCloud<PointSource>& src, const PointCloud<PointTarget>& tgt,
-                                   Matrix4f& T) const {
-    if (src.size() != tgt.size()) return false;  // "Number or points in source differs than target"
-    const char* s = reinterpret_cast<const char*>(src.points.data());
-    const char* t = reinterpret_cast<const char*>(tgt.points.data());
-    const void* sn = (MODE == PCLHIP_ICP_SYMMETRIC && sizeof(PointSource) >= 28) ? s + 16 : nullptr;
-    const void* tn = (MODE != PCLHIP_ICP_POINT_TO_POINT && sizeof(PointTarget) >= 28) ? t + 16 : nullptr;
-    return pclhip_estimate_rigid_transformation(ctx_->get(), MODE, s, sizeof(PointSource), sn, sizeof(PointSource), t,
-                                                sizeof(PointTarget), tn, sizeof(PointTarget), src.size(),
-                                                enforce_ ? 1 : 0, T.m, nullptr) == PCLHIP_OK;
+  using Ptr = std::shared_ptr<TransformationEstimation<PointSource, PointTarget>>;
+  using ConstPtr = std::shared_ptr<const TransformationEstimation<PointSource, PointTarget>>;
+  using Matrix4 = Matrix4f;
+  virtual ~TransformationEstimation() = default;
+  virtual void estimateRigidTransformation(const PointCloud<PointSource>& cloud_src, const PointCloud<PointTarget>& cloud_tgt,
+                                           Matrix4& transformation_matrix) const = 0;
+  virtual void estimateRigidTransformation(const PointCloud<PointSource>& cloud_src, const Indices& indices_src,
+                                           const PointCloud<PointTarget>& cloud_tgt, Matrix4& transformation_matrix) const = 0;
+  virtual void estimateRigidTransformation(const PointCloud<PointSource>& cloud_src, const Indices& indices_src,
+                                           const PointCloud<PointTarget>& cloud_tgt, const Indices& indices_tgt,
+                                           Matrix4& transformation_matrix) const = 0;
+  virtual void estimateRigidTransformation(const PointCloud<PointSource>& cloud_src, const PointCloud<PointTarget>& cloud_tgt,
+                                           const Correspondences& correspondences, Matrix4& transformation_matrix) const = 0;
+};
+
+// The three estimators of the path on the device (pclhip_estimate_rigid_transformation): pair i = (src[i],
+// tgt[i]) after the index lists / correspondences have been resolved (transformation_estimation_svd.hpp:49-125,
+// ..._point_to_plane_lls.hpp:50-130).  Normals are read from the PointNormal layout (+16 bytes).  On failure
+// (size mismatch, missing normals, no device) the matrix is left untouched, as the reference does.
+template <typename PointSource, typename PointTarget, int MODE>
+class DeviceTransformationEstimation : public TransformationEstimation<PointSource, PointTarget> {
+ public:
+  using Matrix4 = Matrix4f;
+  DeviceTransformationEstimation() : ctx_(Context::defaultContext()) {}
+  explicit DeviceTransformationEstimation(Context::Ptr ctx) : ctx_(std::move(ctx)) {}
+  static constexpr int mode() { return MODE; }
+  void setEnforceSameDirectionNormals(bool on) { enforce_ = on; }  // symmetric objective only
+  bool getEnforceSameDirectionNormals() const { return enforce_; }
+  void estimateRigidTransformation(const PointCloud<PointSource>& src, const PointCloud<PointTarget>& tgt,
+                                   Matrix4& T) const override {
+    if (src.size() != tgt.size()) return;  // "Number or points in source differs than target"
+    run(src.points.data(), tgt.points.data(), src.size(), T);
+  }
+  void estimateRigidTransformation(const PointCloud<PointSource>& src, const Indices& indices_src,
+                                   const PointCloud<PointTarget>& tgt, Matrix4& T) const override {
+    if (indices_src.size() != tgt.size()) return;
+    std::vector<PointSource> s;
+    s.reserve(indices_src.size());
+    for (index_t i : indices_src) s.push_back(src[std::size_t(i)]);
+    run(s.data(), tgt.points.data(), s.size(), T);
+  }
+  void estimateRigidTransformation(const PointCloud<PointSource>& src, const Indices& indices_src,
+                                   const PointCloud<PointTarget>& tgt, const Indices& indices_tgt, Matrix4& T) const override {
+    if (indices_src.size() != indices_tgt.size()) return;
+    std::vector<PointSource> s;
+    std::vector<PointTarget> t;
+    s.reserve(indices_src.size());
+    t.reserve(indices_tgt.size());
+    for (index_t i : indices_src) s.push_back(src[std::size_t(i)]);
+    for (index_t i : indices_tgt) t.push_back(tgt[std::size_t(i)]);
+    run(s.data(), t.data(), s.size(), T);
+  }
+  void estimateRigidTransformation(const PointCloud<PointSource>& src, const PointCloud<PointTarget>& tgt,
+                                   const Correspondences& correspondences, Matrix4& T) const override {
+    std::vector<PointSource> s;
+    std::vector<PointTarget> t;
+    s.reserve(correspondences.size());
+    t.reserve(correspondences.size());
+    for (const Correspondence& c : correspondences) {
+      s.push_back(src[std::size_t(c.index_query)]);
+      t.push_back(tgt[std::size_t(c.index_match)]);
+    }
+    run(s.data(), t.data(), s.size(), T);
   }
  private:
+  void run(const PointSource* s, const PointTarget* t, std::size_t n, Matrix4& T) const {
+    if (!ctx_ || !ctx_->ok()) return;
+    const char* sb = reinterpret_cast<const char*>(s);
+    const char* tb = reinterpret_cast<const char*>(t);
+    const void* sn = (MODE == PCLHIP_ICP_SYMMETRIC && has_normal_fields<PointSource>()) ? sb + 16 : nullptr;
+    const void* tn = (MODE != PCLHIP_ICP_POINT_TO_POINT && has_normal_fields<PointTarget>()) ? tb + 16 : nullptr;
+    Matrix4 R;
+    if (pclhip_estimate_rigid_transformation(ctx_->get(), MODE, sb, sizeof(PointSource), sn, sizeof(PointSource), tb,
+                                             sizeof(PointTarget), tn, sizeof(PointTarget), n, enforce_ ? 1 : 0, R.m,
+                                             nullptr) == PCLHIP_OK)
+      T = R;
+  }
   Context::Ptr ctx_;
   bool enforce_ = true;
 };
-template <typename S, typename T> using TransformationEstimationSVD = TransformationEstimation<S, T, PCLHIP_ICP_POINT_TO_POINT>;
-template <typename S, typename T> using TransformationEstimationPointToPlaneLLS = TransformationEstimation<S, T, PCLHIP_ICP_POINT_TO_PLANE>;
-template <typename S, typename T> using TransformationEstimationSymmetricPointToPlaneLLS = TransformationEstimation<S, T, PCLHIP_ICP_SYMMETRIC>;
+template <typename S, typename T> using TransformationEstimationSVD = DeviceTransformationEstimation<S, T, PCLHIP_ICP_POINT_TO_POINT>;
+template <typename S, typename T> using TransformationEstimationPointToPlaneLLS = DeviceTransformationEstimation<S, T, PCLHIP_ICP_POINT_TO_PLANE>;
+template <typename S, typename T> using TransformationEstimationSymmetricPointToPlaneLLS = DeviceTransformationEstimation<S, T, PCLHIP_ICP_SYMMETRIC>;
+
+// pcl::registration::CorrespondenceEstimationBase (correspondence_estimation.h:62-330)
+template <typename PointSource, typename PointTarget>
+class CorrespondenceEstimationBase : public PCLBase<PointSource> {
+ public:
+  using Ptr = std::shared_ptr<CorrespondenceEstimationBase<PointSource, PointTarget>>;
+  using KdTree = search::KdTree<PointTarget>;
+  using KdTreePtr = typename KdTree::Ptr;
+  using PointCloudSourceConstPtr = typename PointCloud<PointSource>::ConstPtr;
+  using PointCloudTargetConstPtr = typename PointCloud<PointTarget>::ConstPtr;
+  void setInputSource(const PointCloudSourceConstPtr& cloud) { source_cloud_updated_ = true; PCLBase<PointSource>::setInputCloud(cloud); }
+  PointCloudSourceConstPtr getInputSource() { return this->input_; }
+  void setInputTarget(const PointCloudTargetConstPtr& cloud) {  // impl/correspondence_estimation.hpp:53-69
+    if (!cloud || cloud->points.empty()) return;
+    target_ = cloud;
+    target_cloud_updated_ = true;
+  }
+  PointCloudTargetConstPtr getInputTarget() { return target_; }
+  void setIndicesSource(const IndicesPtr& indices) { this->setIndices(indices); source_cloud_updated_ = true; }
+  IndicesPtr getIndicesSource() { return this->indices_; }
+  void setIndicesTarget(const IndicesPtr& indices) { target_cloud_updated_ = true; target_indices_ = indices; }
+  IndicesPtr getIndicesTarget() { return target_indices_; }
+  void setSearchMethodTarget(const KdTreePtr& tree, bool force_no_recompute = false) {
+    tree_ = tree;
+    force_no_recompute_ = force_no_recompute;
+    target_cloud_updated_ = true;
+  }
+  KdTreePtr getSearchMethodTarget() const { return tree_; }
+  virtual void determineCorrespondences(Correspondences& correspondences,
+                                        double max_distance = std::numeric_limits<double>::max()) = 0;
+  virtual void determineReciprocalCorrespondences(Correspondences& correspondences,
+                                                  double max_distance = std::numeric_limits<double>::max()) = 0;
+  virtual Ptr clone() const = 0;
+ protected:
+  KdTreePtr tree_;
+  PointCloudTargetConstPtr target_;
+  IndicesPtr target_indices_;
+  bool target_cloud_updated_ = true, source_cloud_updated_ = true, force_no_recompute_ = false;
+  bool initCompute() {  // impl/correspondence_estimation.hpp:71-97
+    if (!target_ || !tree_) return false;
+    if (target_cloud_updated_ && !force_no_recompute_) {
+      if (!(target_indices_ ? tree_->setInputCloud(target_, target_indices_) : tree_->setInputCloud(target_))) return false;
+      target_cloud_updated_ = false;
+    }
+    return PCLBase<PointSource>::initCompute();
+  }
+};
+
+// pcl::registration::CorrespondenceEstimation: all source points in one launch
+template <typename PointSource, typename PointTarget>
+class CorrespondenceEstimation : public CorrespondenceEstimationBase<PointSource, PointTarget> {
+  using Base = CorrespondenceEstimationBase<PointSource, PointTarget>;
+ public:
+  using Ptr = std::shared_ptr<CorrespondenceEstimation<PointSource, PointTarget>>;
+  CorrespondenceEstimation() : CorrespondenceEstimation(Context::defaultContext()) {}
+  explicit CorrespondenceEstimation(Context::Ptr ctx) : ctx_(std::move(ctx)) { this->tree_ = std::make_shared<search::KdTree<PointTarget>>(ctx_); }
+  CorrespondenceEstimation(const CorrespondenceEstimation& o) : Base(o), ctx_(o.ctx_) {}  // the device handle is not shared
+  ~CorrespondenceEstimation() override { if (icp_) pclhip_icp_destroy(icp_); }
+  void determineCorrespondences(Correspondences& out, double max_distance = std::numeric_limits<double>::max()) override {
+    run(out, max_distance, false);
+  }
+  void determineReciprocalCorrespondences(Correspondences& out, double max_distance = std::numeric_limits<double>::max()) override {
+    run(out, max_distance, true);
+  }
+  typename Base::Ptr clone() const override { return std::make_shared<CorrespondenceEstimation<PointSource, PointTarget>>(*this); }
+ private:
+  void run(Correspondences& out, double max_distance, bool reciprocal) {
+    out.clear();
+    if (!this->initCompute() || this->tree_->handle() == nullptr) return;
+    if (icp_ && icp_target_ != this->tree_->handle()) { pclhip_icp_destroy(icp_); icp_ = nullptr; }
+    if (!icp_) {
+      if (pclhip_icp_create(this->tree_->handle(), &icp_) != PCLHIP_OK) return;
+      icp_target_ = this->tree_->handle();
+    }
+    const bool subset = !this->usesAllPoints();
+    static const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double sums[PCLHIP_ICP_NSUMS];
+    const double md = max_distance < 1e150 ? max_distance : 1e150;  // its square must stay finite
+    if (pclhip_icp_set_source_indexed(icp_, this->input_->points.data(), sizeof(PointSource), this->input_->size(),
+                                      subset ? this->indices_->data() : nullptr, subset ? this->indices_->size() : 0) == PCLHIP_OK &&
+        pclhip_icp_set_reciprocal(icp_, reciprocal ? 1 : 0) == PCLHIP_OK &&
+        pclhip_icp_iterate(icp_, I, md, PCLHIP_ICP_POINT_TO_POINT, sums) == PCLHIP_OK) {
+      const std::size_t n = this->input_->size();
+      Indices q(n), m(n);
+      std::vector<float> d(n);
+      std::uint64_t cnt = 0;
+      if (pclhip_icp_fetch_correspondences(icp_, q.data(), m.data(), d.data(), &cnt) == PCLHIP_OK) {
+        out.resize(std::size_t(cnt));
+        for (std::uint64_t i = 0; i < cnt; ++i) out[std::size_t(i)] = Correspondence(q[std::size_t(i)], m[std::size_t(i)], d[std::size_t(i)]);
+      }
+    }
+  }
+  Context::Ptr ctx_;
+  pclhip_icp* icp_ = nullptr;
+  pclhip_index* icp_target_ = nullptr;
+};
+
 }  // namespace registration
+
+// pcl::Registration<PointSource, PointTarget> (registration/include/pcl/registration/registration.h:56-700)
+template <typename PointSource, typename PointTarget>
+class Registration : public PCLBase<PointSource> {
+ public:
+  using Matrix4 = Matrix4f;
+  using PointCloudSource = PointCloud<PointSource>;
+  using PointCloudTarget = PointCloud<PointTarget>;
+  using PointCloudSourceConstPtr = typename PointCloudSource::ConstPtr;
+  using PointCloudTargetConstPtr = typename PointCloudTarget::ConstPtr;
+  using KdTree = search::KdTree<PointTarget>;
+  using KdTreePtr = typename KdTree::Ptr;
+  using PointRepresentationConstPtr = typename PointRepresentation<PointTarget>::ConstPtr;
+  using TransformationEstimation = registration::TransformationEstimation<PointSource, PointTarget>;
+  using TransformationEstimationPtr = typename TransformationEstimation::Ptr;
+  using CorrespondenceEstimation = registration::CorrespondenceEstimationBase<PointSource, PointTarget>;
+  using CorrespondenceEstimationPtr = typename CorrespondenceEstimation::Ptr;
+  using CorrespondenceRejectorPtr = registration::CorrespondenceRejector::Ptr;
+
+  explicit Registration(Context::Ptr ctx)
+      : ctx_(std::move(ctx)), tree_(std::make_shared<KdTree>(ctx_)), correspondences_(std::make_shared<Correspondences>()) {}
+  void setTransformationEstimation(const TransformationEstimationPtr& te) { transformation_estimation_ = te; }  // :144-148
+  void setCorrespondenceEstimation(const CorrespondenceEstimationPtr& ce) { correspondence_estimation_ = ce; }  // :173-177
+  virtual void setInputSource(const PointCloudSourceConstPtr& cloud) {  // impl/registration.hpp:45-56: every call counts
+    if (!cloud || cloud->points.empty()) return;
+    source_cloud_updated_ = true;
+    PCLBase<PointSource>::setInputCloud(cloud);
+  }
+  PointCloudSourceConstPtr getInputSource() { return this->input_; }
+  virtual void setInputTarget(const PointCloudTargetConstPtr& cloud) {  // :58-69
+    if (!cloud || cloud->points.empty()) return;
+    target_ = cloud;
+    target_cloud_updated_ = true;
+  }
+  PointCloudTargetConstPtr getInputTarget() { return target_; }
+  void setIndices(const IndicesPtr& indices) override { PCLBase<PointSource>::setIndices(indices); source_cloud_updated_ = true; }
+  void setIndices(const IndicesConstPtr& indices) override { PCLBase<PointSource>::setIndices(indices); source_cloud_updated_ = true; }
+  void setSearchMethodTarget(const KdTreePtr& tree, bool force_no_recompute = false) {  // :214-221
+    tree_ = tree;
+    force_no_recompute_ = force_no_recompute;
+    target_cloud_updated_ = true;
+  }
+  KdTreePtr getSearchMethodTarget() const { return tree_; }
+  Matrix4 getFinalTransformation() { return final_transformation_; }
+  Matrix4 getLastIncrementalTransformation() { return transformation_; }
+  void setMaximumIterations(int nr_iterations) { max_iterations_ = nr_iterations; }
+  int getMaximumIterations() const { return max_iterations_; }
+  void setMaxCorrespondenceDistance(double d) { corr_dist_threshold_ = d; }
+  double getMaxCorrespondenceDistance() const { return corr_dist_threshold_; }
+  void setTransformationEpsilon(double e) { transformation_epsilon_ = e; }
+  double getTransformationEpsilon() const { return transformation_epsilon_; }
+  void setTransformationRotationEpsilon(double e) { transformation_rotation_epsilon_ = e; }
+  double getTransformationRotationEpsilon() const { return transformation_rotation_epsilon_; }
+  void setEuclideanFitnessEpsilon(double e) { euclidean_fitness_epsilon_ = e; }
+  double getEuclideanFitnessEpsilon() const { return euclidean_fitness_epsilon_; }
+  void setPointRepresentation(const PointRepresentationConstPtr& rep) { point_representation_ = rep; }  // :422
+  void addCorrespondenceRejector(const CorrespondenceRejectorPtr& r) { correspondence_rejectors_.push_back(r); }  // :518-547
+  std::vector<CorrespondenceRejectorPtr> getCorrespondenceRejectors() { return correspondence_rejectors_; }
+  bool removeCorrespondenceRejector(unsigned int i) {
+    if (i >= correspondence_rejectors_.size()) return false;
+    correspondence_rejectors_.erase(correspondence_rejectors_.begin() + i);
+    return true;
+  }
+  void clearCorrespondenceRejectors() { correspondence_rejectors_.clear(); }
+  bool hasConverged() const { return converged_; }
+  const std::string& getClassName() const { return reg_name_; }
+  std::string getLastError() const { return ctx_->getLastError(); }
+
+  void align(PointCloudSource& output) { align(output, Matrix4::Identity()); }
+  void align(PointCloudSource& output, const Matrix4& guess) {  // impl/registration.hpp:178-221
+    converged_ = false;
+    if (!initCompute()) return;
+    output.points.resize(this->indices_->size());
+    for (std::size_t i = 0; i < this->indices_->size(); ++i) output[i] = (*this->input_)[std::size_t((*this->indices_)[i])];
+    output.width = std::uint32_t(output.size());
+    output.height = 1;
+    output.is_dense = this->input_->is_dense;
+    if (point_representation_ && !force_no_recompute_) tree_->setPointRepresentation(point_representation_);
+    final_transformation_ = transformation_ = Matrix4::Identity();
+    computeTransformation(output, guess);
+  }
+  virtual double getFitnessScore(double max_range = std::numeric_limits<double>::max()) = 0;
+
+ protected:
+  bool initCompute() {  // impl/registration.hpp:73-101
+    if (!ctx_ || !ctx_->ok() || !this->input_ || !tree_) return false;
+    if (target_cloud_updated_ && !(force_no_recompute_ && tree_->handle())) {
+      if (!target_ || !tree_->setInputCloud(target_)) return false;
+      target_built_ = true;
+    }
+    target_cloud_updated_ = false;
+    if (!tree_->handle()) return false;
+    if (correspondence_estimation_) correspondence_estimation_->setSearchMethodTarget(tree_, true);
+    return PCLBase<PointSource>::initCompute();
+  }
+  virtual void computeTransformation(PointCloudSource& output, const Matrix4& guess) = 0;  // :678-679
+
+  Context::Ptr ctx_;
+  std::string reg_name_;
+  KdTreePtr tree_;
+  PointCloudTargetConstPtr target_;
+  int nr_iterations_ = 0, max_iterations_ = 10;
+  Matrix4 final_transformation_, transformation_;
+  double transformation_epsilon_ = 0.0, transformation_rotation_epsilon_ = 0.0;
+  double euclidean_fitness_epsilon_ = -std::numeric_limits<double>::max();
+  double corr_dist_threshold_ = std::sqrt(std::numeric_limits<double>::max());
+  bool converged_ = false;
+  int min_number_correspondences_ = 3;
+  CorrespondencesPtr correspondences_;
+  TransformationEstimationPtr transformation_estimation_;
+  CorrespondenceEstimationPtr correspondence_estimation_;
+  std::vector<CorrespondenceRejectorPtr> correspondence_rejectors_;
+  PointRepresentationConstPtr point_representation_;
+  bool target_cloud_updated_ = true, source_cloud_updated_ = true, force_no_recompute_ = false;
+  bool target_built_ = false;  // the tree was (re)built by this object since the device handle was last refreshed
+};
+
+// pcl::IterativeClosestPoint<PointSource, PointTarget> (icp.h:98-347)
+template <typename PointSource, typename PointTarget>
+class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
+  using Base = Registration<PointSource, PointTarget>;
+ public:
+  using PointCloudSource = typename Base::PointCloudSource;
+  using Matrix4 = typename Base::Matrix4;
+  using Ptr = std::shared_ptr<IterativeClosestPoint<PointSource, PointTarget>>;
+  IterativeClosestPoint() : IterativeClosestPoint(Context::defaultContext()) {}
+  explicit IterativeClosestPoint(Context::Ptr ctx) : Base(std::move(ctx)) {  // icp.h:136-151
+    this->reg_name_ = "IterativeClosestPoint";
+    this->transformation_estimation_ = std::make_shared<registration::TransformationEstimationSVD<PointSource, PointTarget>>(this->ctx_);
+    this->correspondence_estimation_ = std::make_shared<registration::CorrespondenceEstimation<PointSource, PointTarget>>(this->ctx_);
+    pclhip_convergence_init(&criteria_);
+  }
+  ~IterativeClosestPoint() override { if (icp_) pclhip_icp_destroy(icp_); }
+  IterativeClosestPoint(const IterativeClosestPoint&) = delete;             // icp.h:168-173
+  IterativeClosestPoint& operator=(const IterativeClosestPoint&) = delete;
+
+  void setUseReciprocalCorrespondences(bool on) { use_reciprocal_correspondence_ = on; }  // icp.h:251-256
+  bool getUseReciprocalCorrespondences() const { return use_reciprocal_correspondence_; }
+  // DefaultConvergenceCriteria options reachable through getConvergeCriteria() in the reference
+  void setMaximumIterationsSimilarTransforms(int n) { max_iterations_similar_transforms_ = n; }
+  void setFailureAfterMaximumIterations(bool f) { failure_after_max_iterations_ = f; }
+  void setAbsoluteMSE(double mse) { mse_threshold_absolute_ = mse; }
+  int getNumberOfIterations() const { return this->nr_iterations_; }
+  int getConvergenceState() const { return criteria_.convergence_state; }
+  double getLastMSE() const { return last_mse_; }
+  // true when the last align() ran the fused device loop, false when it went through the virtual calls
+  bool ranOnDeviceLoop() const { return device_loop_; }
+
+  // Registration::getFitnessScore (registration/include/pcl/registration/impl/registration.hpp:132-168)
+  double getFitnessScore(double max_range = std::numeric_limits<double>::max()) override {
+    if (!this->initCompute() || !ensureHandle(modeOfEstimator() >= 0 ? modeOfEstimator() : PCLHIP_ICP_POINT_TO_POINT))
+      return std::numeric_limits<double>::max();
+    double score = std::numeric_limits<double>::max();
+    pclhip_icp_fitness_score(icp_, this->final_transformation_.m, max_range, &score, nullptr);
+    return score;
+  }
+
+ protected:
+  virtual bool enforceSameDirectionNormals() const { return true; }
+  // which stock estimator is plugged in (its device mode), or -1 for a foreign one
+  int modeOfEstimator() const {
+    using namespace registration;
+    const auto* te = this->transformation_estimation_.get();
+    if (te == nullptr) return -1;
+    // exactly the stock classes: a subclass that overrides them is a foreign estimator like any other
+    if (typeid(*te) == typeid(TransformationEstimationSymmetricPointToPlaneLLS<PointSource, PointTarget>)) return PCLHIP_ICP_SYMMETRIC;
+    if (typeid(*te) == typeid(TransformationEstimationPointToPlaneLLS<PointSource, PointTarget>)) return PCLHIP_ICP_POINT_TO_PLANE;
+    if (typeid(*te) == typeid(TransformationEstimationSVD<PointSource, PointTarget>)) return PCLHIP_ICP_POINT_TO_POINT;
+    return -1;
+  }
+  void fillParams(pclhip_icp_params& p, int mode) const {
+    pclhip_icp_params_default(&p);
+    p.mode = mode;
+    p.max_iterations = this->max_iterations_;
+    p.max_correspondence_distance = this->corr_dist_threshold_;
+    p.transformation_epsilon = this->transformation_epsilon_;
+    p.transformation_rotation_epsilon = this->transformation_rotation_epsilon_;
+    p.euclidean_fitness_epsilon = this->euclidean_fitness_epsilon_;
+    p.min_number_correspondences = this->min_number_correspondences_;
+    p.failure_after_max_iterations = failure_after_max_iterations_ ? 1 : 0;
+    p.max_iterations_similar_transforms = max_iterations_similar_transforms_;
+    p.mse_threshold_absolute = mse_threshold_absolute_;
+  }
+  // device-side registration object bound to the tree; source (and normals) uploaded when they changed
+  bool ensureHandle(int mode) {
+    pclhip_index* ix = this->tree_->handle();
+    if (icp_ && (icp_target_ != ix || this->target_built_)) { pclhip_icp_destroy(icp_); icp_ = nullptr; }
+    if (mode != PCLHIP_ICP_POINT_TO_POINT && has_normal_fields<PointTarget>() && this->target_ &&
+        (this->target_built_ || normals_of_ != this->target_.get())) {  // pcl::PointNormal target: normals at +16
+      const char* base = reinterpret_cast<const char*>(this->target_->points.data());
+      if (pclhip_index_set_normals(ix, base + 16, sizeof(PointTarget)) != PCLHIP_OK) return false;
+      normals_of_ = this->target_.get();
+    }
+    this->target_built_ = false;
+    if (!icp_) {
+      if (pclhip_icp_create(ix, &icp_) != PCLHIP_OK) return false;
+      icp_target_ = ix;
+      this->source_cloud_updated_ = true;
+    }
+    if (this->source_cloud_updated_) {
+      const bool subset = !this->usesAllPoints();
+      if (pclhip_icp_set_source_indexed(icp_, this->input_->points.data(), sizeof(PointSource), this->input_->size(),
+                                        subset ? this->indices_->data() : nullptr, subset ? this->indices_->size() : 0) != PCLHIP_OK)
+        return false;
+      if (has_normal_fields<PointSource>()) {  // pcl::PointNormal source: its normals feed the symmetric objective
+        const char* base = reinterpret_cast<const char*>(this->input_->points.data());
+        if (pclhip_icp_set_source_normals(icp_, base + 16, sizeof(PointSource)) != PCLHIP_OK) return false;
+      }
+      this->source_cloud_updated_ = false;
+    }
+    std::vector<pclhip_rejector> list;
+    for (const auto& r : this->correspondence_rejectors_) list.push_back(r->desc);
+    return pclhip_icp_set_rejectors(icp_, list.data(), int(list.size())) == PCLHIP_OK &&
+           pclhip_icp_set_reciprocal(icp_, use_reciprocal_correspondence_ ? 1 : 0) == PCLHIP_OK &&
+           pclhip_icp_set_enforce_same_direction_normals(icp_, enforceSameDirectionNormals() ? 1 : 0) == PCLHIP_OK;
+  }
+  // IterativeClosestPoint::transformCloud (impl/icp.hpp:49-111), in place on a host cloud
+  virtual void transformCloud(PointCloudSource& cloud, const Matrix4& T, int mode) {
+    pclhip_transform_cloud(this->ctx_->get(), T.m, mode == PCLHIP_ICP_POINT_TO_POINT ? 0 : 1, cloud.points.data(),
+                           cloud.points.data(), sizeof(PointSource), cloud.size(),
+                           (mode != PCLHIP_ICP_POINT_TO_POINT && has_normal_fields<PointSource>()) ? 16 : 0);
+  }
+
+  void computeTransformation(PointCloudSource& output, const Matrix4& guess) override {  // impl/icp.hpp:113-268
+    using namespace registration;
+    const int mode = modeOfEstimator();
+    const auto* cep = this->correspondence_estimation_.get();
+    const bool own_ce = cep != nullptr && typeid(*cep) == typeid(registration::CorrespondenceEstimation<PointSource, PointTarget>);
+    device_loop_ = mode >= 0 && own_ce && this->tree_->hasDefaultRepresentation();
+    if (device_loop_) {
+      if (!ensureHandle(mode)) return;
+      pclhip_icp_params p;
+      fillParams(p, mode);
+      pclhip_icp_result r;
+      if (pclhip_icp_align(icp_, &p, guess.m, &r) != PCLHIP_OK) return;
+      std::memcpy(this->final_transformation_.m, r.final_transformation, sizeof r.final_transformation);
+      std::memcpy(this->transformation_.m, r.last_transformation, sizeof r.last_transformation);
+      this->converged_ = r.converged != 0;
+      this->nr_iterations_ = r.nr_iterations;
+      criteria_.convergence_state = r.convergence_state;
+      last_mse_ = r.mse;
+      output = *this->input_;  // icp.hpp:264-267: all fields of the WHOLE input cloud, then xyz (+ normals) moved
+      transformCloud(output, this->final_transformation_, mode);
+      return;
+    }
+    // ---- a foreign estimator is plugged in: PCL's loop, through the virtual interfaces -------------------
+    if (!this->target_ || !this->transformation_estimation_ || !this->correspondence_estimation_) return;
+    const int tmode = mode >= 0 ? mode : (has_normal_fields<PointSource>() ? PCLHIP_ICP_POINT_TO_PLANE : PCLHIP_ICP_POINT_TO_POINT);
+    auto moved = std::make_shared<PointCloudSource>(output);  // input_transformed (:120-131), the indexed subset
+    this->nr_iterations_ = 0;
+    this->converged_ = false;
+    this->final_transformation_ = guess;
+    bool identity = true;
+    for (int i = 0; i < 16; ++i) identity = identity && guess.m[i] == Matrix4().m[i];
+    if (!identity) transformCloud(*moved, guess, tmode);
+    this->transformation_ = Matrix4::Identity();
+    auto& ce = *this->correspondence_estimation_;
+    ce.setInputTarget(this->target_);  // :145 (the tree itself was handed over in initCompute)
+    ce.setSearchMethodTarget(this->tree_, true);
+    pclhip_icp_params p;
+    fillParams(p, tmode);
+    if (!this->correspondence_rejectors_.empty()) return;  // the rejectors here are device-side parameter holders
+    do {
+      ce.setInputSource(moved);  // :178
+      if (use_reciprocal_correspondence_) ce.determineReciprocalCorrespondences(*this->correspondences_, this->corr_dist_threshold_);
+      else ce.determineCorrespondences(*this->correspondences_, this->corr_dist_threshold_);
+      const std::size_t cnt = this->correspondences_->size();
+      if (int(cnt) < this->min_number_correspondences_) {  // :204-213
+        criteria_.convergence_state = 5;  // CONVERGENCE_CRITERIA_NO_CORRESPONDENCES
+        this->converged_ = false;
+        break;
+      }
+      this->transformation_estimation_->estimateRigidTransformation(*moved, *this->target_, *this->correspondences_,
+                                                                    this->transformation_);  // :216-217
+      transformCloud(*moved, this->transformation_, tmode);                                     // :220
+      this->final_transformation_ = this->transformation_ * this->final_transformation_;        // :223
+      ++this->nr_iterations_;
+      double mse = 0.0;  // calculateMSE, default_convergence_criteria.h:262-270
+      for (const Correspondence& c : *this->correspondences_) mse += double(c.distance);
+      mse /= double(cnt);
+      last_mse_ = mse;
+      this->converged_ = pclhip_convergence_has_converged(&p, &criteria_, this->nr_iterations_, this->transformation_.m, mse) != 0;
+    } while (criteria_.convergence_state == 0);
+    output = *this->input_;
+    transformCloud(output, this->final_transformation_, tmode);
+  }
+
+  bool use_reciprocal_correspondence_ = false;
+  int max_iterations_similar_transforms_ = 0;
+  bool failure_after_max_iterations_ = false;
+  double mse_threshold_absolute_ = 1e-12;
+  pclhip_convergence_state criteria_;
+  double last_mse_ = 0;
+  bool device_loop_ = false;
+  pclhip_icp* icp_ = nullptr;
+  pclhip_index* icp_target_ = nullptr;
+  const void* normals_of_ = nullptr;
+};
+
+// pcl::IterativeClosestPointWithNormals (icp.h:360-440)
+template <typename PointSource, typename PointTarget>
+class IterativeClosestPointWithNormals : public IterativeClosestPoint<PointSource, PointTarget> {
+ public:
+  using Ptr = std::shared_ptr<IterativeClosestPointWithNormals<PointSource, PointTarget>>;
+  IterativeClosestPointWithNormals() : IterativeClosestPointWithNormals(Context::defaultContext()) {}
+  explicit IterativeClosestPointWithNormals(Context::Ptr ctx) : IterativeClosestPoint<PointSource, PointTarget>(std::move(ctx)) {
+    this->reg_name_ = "IterativeClosestPointWithNormals";
+    setUseSymmetricObjective(false);
+  }
+  void setUseSymmetricObjective(bool on) {  // icp.h:380-400
+    use_symmetric_objective_ = on;
+    if (on) {
+      auto te = std::make_shared<registration::TransformationEstimationSymmetricPointToPlaneLLS<PointSource, PointTarget>>(this->ctx_);
+      te->setEnforceSameDirectionNormals(enforce_same_direction_normals_);
+      this->transformation_estimation_ = te;
+    } else {
+      this->transformation_estimation_ =
+          std::make_shared<registration::TransformationEstimationPointToPlaneLLS<PointSource, PointTarget>>(this->ctx_);
+    }
+  }
+  bool getUseSymmetricObjective() const { return use_symmetric_objective_; }
+  void setEnforceSameDirectionNormals(bool on) {  // icp.h:416-428
+    enforce_same_direction_normals_ = on;
+    if (use_symmetric_objective_) setUseSymmetricObjective(true);
+  }
+  bool getEnforceSameDirectionNormals() const { return enforce_same_direction_normals_; }
+ protected:
+  bool enforceSameDirectionNormals() const override { return enforce_same_direction_normals_; }
+  bool use_symmetric_objective_ = false, enforce_same_direction_normals_ = true;
+};
 
 // pcl::io::loadPCDFile / savePCDFile{ASCII,Binary,BinaryCompressed} (io/include/pcl/io/pcd_io.h:685-800)
 // for the point types of this header: records of sizeof(PointT) bytes, normals at +16 when the type has them.
@@ -551,6 +1062,7 @@ template <typename PointT> int savePCDFileBinaryCompressed(const std::string& f,
 // pcl::VoxelGrid<pcl::PointXYZ>
 class VoxelGrid {
  public:
+  VoxelGrid() : VoxelGrid(Context::defaultContext()) {}
   explicit VoxelGrid(Context::Ptr ctx) : ctx_(std::move(ctx)) {}
   void setInputCloud(const PointCloud<PointXYZ>::ConstPtr& c) { input_ = c; }
   void setLeafSize(float lx, float ly, float lz) { leaf_[0] = lx; leaf_[1] = ly; leaf_[2] = lz; }
@@ -570,7 +1082,7 @@ class VoxelGrid {
                                               min_pts_, field_ == "z", lo_, hi_, out.data(), &n);
     if (st == PCLHIP_ERR_OVERFLOW) { output = *input_; return; }
     if (st != PCLHIP_OK) { output.width = 0; return; }
-    out.resize(n);
+    out.resize(std::size_t(n));
     output.points.swap(out);
     output.width = std::uint32_t(n);
   }

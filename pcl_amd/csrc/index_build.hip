@@ -255,6 +255,25 @@ __global__ __launch_bounds__(256) void leaf_disc_kernel(const float4* __restrict
   disc[2 * leaf + 1] = nh;
 }
 
+// per-block sums of the squared diagonals of the leaf boxes (fixed order: the mean is reproducible)
+__global__ __launch_bounds__(256) void leaf_diag_kernel(const Box* __restrict__ box, uint32_t nleaf, double* __restrict__ part) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nleaf; i += gridDim.x * blockDim.x) {
+    const Box b = box[i];
+    const double ex = double(b.hi.x) - b.lo.x, ey = double(b.hi.y) - b.lo.y, ez = double(b.hi.z) - b.lo.z;
+    const double d2 = ex * ex + ey * ey + ez * ez;
+    a += (d2 < 1e30) ? d2 : 0.0;  // the padded last leaf holds sentinels
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (int(threadIdx.x) < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
 // one wavefront per parent node
 __global__ __launch_bounds__(256) void node_box_kernel(const Box* child, uint32_t nchild, Box* parent, uint32_t nparent) {
   const uint32_t node = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
@@ -787,6 +806,21 @@ pclhip_status build_boxes(pclhip_index* ix) {
       ix->disc = nullptr;
       PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->disc, size_t(c) * 2 * sizeof(float4)));
       hipLaunchKernelGGL(leaf_disc_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c, ix->disc);
+      {  // mean squared leaf diagonal: from what stand-off on the discs pay (traverse.hpp)
+        constexpr int NB = 64;
+        double* part = nullptr;
+        PCLHIP_CHECK_HIP(ctx, hipMalloc(&part, NB * sizeof(double)));
+        hipLaunchKernelGGL(leaf_diag_kernel, dim3(NB), dim3(256), 0, s, ix->box[1], c, part);
+        double h[NB];
+        const hipError_t e1 = hipMemcpyAsync(h, part, sizeof h, hipMemcpyDeviceToHost, s);
+        const hipError_t e2 = hipStreamSynchronize(s);
+        (void)hipFree(part);
+        PCLHIP_CHECK_HIP(ctx, e1);
+        PCLHIP_CHECK_HIP(ctx, e2);
+        double sum = 0.0;
+        for (int i = 0; i < NB; ++i) sum += h[i];
+        ix->leaf_diag2 = float(sum / double(c));
+      }
     } else {
       const uint64_t threads = uint64_t(c) * WAVE;
       hipLaunchKernelGGL(node_box_kernel, dim3(unsigned((threads + 255) / 256)), dim3(256), 0, s, ix->box[l - 1],
@@ -847,7 +881,7 @@ pclhip::IndexView pclhip_index::view() const {
     const char* e = getenv("PCLHIP_DISC_FACTOR");
     return e ? float(atof(e)) : 4.0f;
   }();
-  v.disc_factor = factor;
+  v.disc_from = factor * leaf_diag2;
   v.lv = lv_dev;
   for (int l = 0; l < pclhip::MAX_LEVELS; ++l) {
     v.box[l] = box[l];

@@ -51,7 +51,7 @@ struct IndexView {
   const float4* nrm;
   const float4* disc;           // per leaf two float4: (centre.xyz, R) (n.xyz, hn) of the bounded cylinder that holds
                                 // the leaf's points (traverse.hpp: point_disc_lb).  nullptr: search with boxes only.
-  float disc_factor;            // discs are used where wave radius^2 > disc_factor * (leaf diagonal)^2
+  float disc_from;              // discs are used where wave radius^2 > this (a few mean leaf diagonals, squared)
   const LevelInfo* lv;          // [MAX_LEVELS] in device memory; lv[1] = leaves
   const Box* box[MAX_LEVELS];   // the same table in kernel arguments (SGPRs): selected with a
   uint32_t count[MAX_LEVELS];   // wave-uniform switch, no memory access on the traversal's critical path
@@ -133,6 +133,7 @@ struct pclhip_index {
   float* soa = nullptr;
   float4* nrm = nullptr;
   float4* disc = nullptr;
+  float leaf_diag2 = 0.0f;  // mean squared diagonal of the leaf boxes
   uint32_t* rank = nullptr;
   pclhip::Box* box[pclhip::MAX_LEVELS] = {};
   pclhip::LevelInfo* lv_dev = nullptr;

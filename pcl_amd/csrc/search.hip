@@ -990,12 +990,12 @@ __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, con
   if (threadIdx.x == 0) last_s = atomicAdd(done, 1u) == gridDim.x - 1;
   __syncthreads();
   if (!last_s) return;
-  __threadfence();
+  __threadfence();  // acquire: pairs with the release fence each block issued before bumping `done`
   {
     const int t = threadIdx.x % NS, r = threadIdx.x / NS;  // NS == 32: 8 rows of 32 sums
     double a = 0.0;
-    for (uint32_t b = r; b < gridDim.x; b += BLOCK / NS)
-      a += __hip_atomic_load(&partials[size_t(b) * NS + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 8
+    for (uint32_t b = r; b < gridDim.x; b += BLOCK / NS) a += partials[size_t(b) * NS + t];  // plain, coalesced, pipelined
     fold_s[r][t] = a;
     __syncthreads();
     if (r == 0) {

@@ -701,11 +701,9 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
     // farther than a few leaf sizes: closer in, a disc excludes nothing a box does not and costs twice the test.
     bool use_disc = false;
     float4 dcR = make_float4(0, 0, 0, 0), dnh = make_float4(0, 0, 0, 0);
-    if (have_disc && ordered && cl == 1u) {
-      const float ex = hx - lx, ey = hy - ly, ez = hz - lz;
-      const float leaf2 = wave_max_f(has ? __fmaf_rn(ez, ez, __fmaf_rn(ey, ey, ex * ex)) : 0.0f);
-      use_disc = T > ix.disc_factor * leaf2;
-      if (use_disc && has) {
+    if (have_disc && ordered && cl == 1u && T > ix.disc_from) {  // disc_from: a few mean leaf diagonals, squared
+      use_disc = true;
+      if (has) {
         dcR = ix.disc[2 * (first + lane)];
         dnh = ix.disc[2 * (first + lane) + 1];
         lbG = fmaxf(lbG, group_disc_lb(Qlx, Qly, Qlz, Qhx, Qhy, Qhz, Qcx, Qcy, Qcz, rQ, dcR, dnh));

@@ -171,14 +171,33 @@ int main(int argc, char** argv) {
     pclhip_transform_cloud(ctx->get(), G, 1, src.points.data(), tgt.points.data(), sizeof(PointNormal), src.size(), 16);
     Matrix4f T;
     registration::TransformationEstimationSymmetricPointToPlaneLLS<PointNormal, PointNormal> sym(ctx);
-    EXPECT(sym.estimateRigidTransformation(src, tgt, T));
+    sym.estimateRigidTransformation(src, tgt, T);
     for (int i = 0; i < 16; ++i) EXPECT(std::fabs(T.m[i] - G[i]) < 1e-2f);
     registration::TransformationEstimationPointToPlaneLLS<PointNormal, PointNormal> lls(ctx);
-    EXPECT(lls.estimateRigidTransformation(src, tgt, T));
+    T = Matrix4f();
+    lls.estimateRigidTransformation(src, tgt, T);
     for (int i = 0; i < 16; ++i) EXPECT(std::fabs(T.m[i] - G[i]) < 1e-2f);
     registration::TransformationEstimationSVD<PointNormal, PointNormal> svd(ctx);
-    EXPECT(svd.estimateRigidTransformation(src, tgt, T));
+    T = Matrix4f();
+    svd.estimateRigidTransformation(src, tgt, T);
     for (int i = 0; i < 16; ++i) EXPECT(std::fabs(T.m[i] - G[i]) < 1e-4f);
+    // the other three overloads of transformation_estimation.h:74-116, through the abstract base
+    const registration::TransformationEstimation<PointNormal, PointNormal>& base = svd;
+    Indices all(src.size());
+    for (std::size_t i = 0; i < all.size(); ++i) all[i] = index_t(i);
+    Correspondences pairs;
+    for (std::size_t i = 0; i < src.size(); ++i) pairs.emplace_back(index_t(i), index_t(i), 0.0f);
+    Matrix4f Ta, Tb, Tc;
+    base.estimateRigidTransformation(src, all, tgt, Ta);
+    base.estimateRigidTransformation(src, all, tgt, all, Tb);
+    base.estimateRigidTransformation(src, tgt, pairs, Tc);
+    for (int i = 0; i < 16; ++i) EXPECT(Ta.m[i] == T.m[i] && Tb.m[i] == T.m[i] && Tc.m[i] == T.m[i]);
+    Matrix4f untouched;
+    untouched(0, 3) = 42.0f;
+    PointCloud<PointNormal> shorter = tgt;
+    shorter.points.pop_back();
+    base.estimateRigidTransformation(src, shorter, untouched);  // size mismatch: the matrix is left alone
+    EXPECT(untouched(0, 3) == 42.0f);
     // IterativeClosestPointWithNormals + setUseSymmetricObjective on PointNormal clouds: a motion small
     // against the 0.5 grid spacing, so nearest neighbours are the true pairs and the motion is recovered
     const float c = std::cos(0.02f), sn = std::sin(0.02f);
@@ -223,6 +242,119 @@ int main(int argc, char** argv) {
     for (std::size_t i = 0; i < sb.size() && i < source->size(); ++i)
       EXPECT(std::fabs(sb[i].x - (*source)[i].x) <= 1e-7f * std::fabs((*source)[i].x) && sb[i].w == 1.0f);
     EXPECT(io::loadPCDFile(dir + "does_not_exist.pcd", sb) == -1);
+  }
+  {  // the plug structure: default-constructible objects, abstract bases, foreign estimators through virtual calls
+    // a foreign TransformationEstimation (registration.h:144-148): wraps the stock SVD and counts its calls
+    struct CountingSVD : registration::TransformationEstimation<PointXYZ, PointXYZ> {
+      registration::TransformationEstimationSVD<PointXYZ, PointXYZ> inner;
+      mutable int calls = 0;
+      void estimateRigidTransformation(const PointCloud<PointXYZ>& a, const PointCloud<PointXYZ>& b, Matrix4f& T) const override {
+        inner.estimateRigidTransformation(a, b, T);
+      }
+      void estimateRigidTransformation(const PointCloud<PointXYZ>& a, const Indices& ia, const PointCloud<PointXYZ>& b,
+                                       Matrix4f& T) const override { inner.estimateRigidTransformation(a, ia, b, T); }
+      void estimateRigidTransformation(const PointCloud<PointXYZ>& a, const Indices& ia, const PointCloud<PointXYZ>& b,
+                                       const Indices& ib, Matrix4f& T) const override { inner.estimateRigidTransformation(a, ia, b, ib, T); }
+      void estimateRigidTransformation(const PointCloud<PointXYZ>& a, const PointCloud<PointXYZ>& b, const Correspondences& c,
+                                       Matrix4f& T) const override {
+        ++calls;
+        inner.estimateRigidTransformation(a, b, c, T);
+      }
+    };
+    // a foreign CorrespondenceEstimation (registration.h:173-177): the batch search of a Search object it was given
+    struct BatchCE : registration::CorrespondenceEstimationBase<PointXYZ, PointXYZ> {
+      int calls = 0;
+      void determineCorrespondences(Correspondences& out, double max_distance) override {
+        out.clear();
+        ++calls;
+        if (!this->initCompute()) return;
+        const search::Search<PointXYZ>& s = *this->tree_;  // only the abstract interface is used
+        std::vector<Indices> ki;
+        std::vector<std::vector<float>> kd;
+        s.nearestKSearch(*this->input_, Indices(), 1, ki, kd);
+        for (std::size_t i = 0; i < ki.size(); ++i)
+          if (!ki[i].empty() && double(kd[i][0]) <= max_distance * max_distance) out.emplace_back(index_t(i), ki[i][0], kd[i][0]);
+      }
+      void determineReciprocalCorrespondences(Correspondences& out, double d) override { determineCorrespondences(out, d); }
+      Ptr clone() const override { return std::make_shared<BatchCE>(*this); }
+    };
+    IterativeClosestPoint<PointXYZ, PointXYZ> stock;  // default constructor: the default context
+    stock.setInputSource(source);
+    stock.setInputTarget(target);
+    stock.setMaximumIterations(50);
+    stock.setTransformationEpsilon(1e-8);
+    stock.setMaxCorrespondenceDistance(0.05);
+    PointCloud<PointXYZ> out;
+    stock.align(out);
+    EXPECT(stock.hasConverged() && stock.ranOnDeviceLoop());
+    const Matrix4f Ts = stock.getFinalTransformation();
+    const Matrix4f last = stock.getLastIncrementalTransformation();
+    EXPECT(std::fabs(last(0, 0) - 1.0f) < 1e-3f && std::fabs(last(0, 3)) < 1e-3f);  // the last step was tiny
+
+    Registration<PointXYZ, PointXYZ>* reg = nullptr;
+    IterativeClosestPoint<PointXYZ, PointXYZ> plugged;
+    reg = &plugged;                                         // driven through the abstract Registration
+    auto te = std::make_shared<CountingSVD>();
+    auto ce = std::make_shared<BatchCE>();
+    reg->setTransformationEstimation(te);
+    reg->setCorrespondenceEstimation(ce);
+    reg->setInputSource(source);
+    reg->setInputTarget(target);
+    reg->setMaximumIterations(50);
+    reg->setTransformationEpsilon(1e-8);
+    reg->setMaxCorrespondenceDistance(0.05);
+    reg->align(out);
+    EXPECT(reg->hasConverged() && !plugged.ranOnDeviceLoop());
+    EXPECT(te->calls == plugged.getNumberOfIterations() && ce->calls == te->calls && te->calls > 3);
+    EXPECT(plugged.getNumberOfIterations() == stock.getNumberOfIterations());
+    const Matrix4f Tp = reg->getFinalTransformation();
+    for (int i = 0; i < 16; ++i) EXPECT(std::fabs(Tp.m[i] - Ts.m[i]) < 2e-5f);  // same loop, host-side sums order aside
+    EXPECT(out.size() == source->size());
+
+    // PCLBase::setIndices on the registration: only those source points take part
+    auto half = std::make_shared<Indices>();
+    for (int i = 0; i < 397; i += 2) half->push_back(i);
+    stock.setIndices(half);
+    stock.align(out);
+    EXPECT(stock.hasConverged() && out.size() == source->size());
+    const Matrix4f Th = stock.getFinalTransformation();
+    for (int r = 0; r < 3; ++r) EXPECT(std::fabs(Th(r, 3) - Ts(r, 3)) < 3e-3f);
+
+    // a search method used through the abstract base + point representations (kdtree.h:110)
+    search::Search<PointXYZ>::Ptr s = std::make_shared<search::KdTree<PointXYZ>>();
+    EXPECT(s->setInputCloud(target) && s->getName() == "KdTree");
+    Indices idx;
+    std::vector<float> d2;
+    EXPECT(s->nearestKSearch(*source, 7, 3, idx, d2) == 3);
+    auto tree = std::make_shared<search::KdTree<PointXYZ>>();
+    auto xy = std::make_shared<CustomPointRepresentation<PointXYZ>>(2, 0);
+    tree->setPointRepresentation(xy);
+    EXPECT(tree->setInputCloud(target));
+    PointXYZ q = (*target)[17];
+    q.z += 5.0f;
+    EXPECT(tree->nearestKSearch(q, 1, idx, d2) == 1 && idx[0] == 17 && d2[0] == 0.0f);
+    auto weird = std::make_shared<CustomPointRepresentation<PointXYZ>>(3, 1);  // (y, z, w): not a rescaled x y z
+    tree->setPointRepresentation(weird);
+    EXPECT(!tree->setInputCloud(target));                                        // refused, not silently different
+
+    // CorrespondenceEstimationBase: clone() and source / target index subsets
+    registration::CorrespondenceEstimationBase<PointXYZ, PointXYZ>::Ptr base = std::make_shared<registration::CorrespondenceEstimation<PointXYZ, PointXYZ>>();
+    base->setInputSource(source);
+    base->setInputTarget(target);
+    auto some = std::make_shared<Indices>(Indices{3, 10, 200, 396});
+    base->setIndicesSource(some);
+    Correspondences corr;
+    base->determineCorrespondences(corr);
+    EXPECT(corr.size() == 4 && corr[0].index_query == 3 && corr[3].index_query == 396);
+    auto copy = base->clone();
+    Correspondences corr2;
+    copy->determineCorrespondences(corr2);
+    EXPECT(corr2.size() == 4 && corr2[2].index_match == corr[2].index_match);
+    auto evens = std::make_shared<Indices>();
+    for (int i = 0; i < 361; i += 2) evens->push_back(i);
+    base->setIndicesTarget(evens);
+    base->determineCorrespondences(corr);
+    for (const auto& c : corr) EXPECT(c.index_match % 2 == 0);
   }
   std::printf(failures ? "%d FAILURES\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
