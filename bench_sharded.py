@@ -1,0 +1,103 @@
+"""bench.py --config 5: the 100M-point target cut into kd slabs + halo over the ranks.
+
+Every rank indexes its slab of the target plus the halo (pcl_amd.dist.ShardedTarget), holds the whole source,
+serves the source points whose current position lies in its region, and takes part in the per-iteration
+ncclAllReduce of the 32-double record.  `--replicated` runs the comparison point of the survey: the whole target
+indexed on every rank, the source cut into slabs.  Either way the job registers the same two clouds, so `value`
+(correspondences of the whole job per second) is comparable; the run is strong scaling in the number of GPUs.
+"""
+import time
+
+import numpy as np
+
+B_ALG_SEARCH = 40.0
+HBM_PEAK_GBS = 8000.0
+
+
+def run_config5(args, ctx, comm, rank, local_rank, world, fence):
+    import torch
+    import torch.distributed as dist
+    import pcl_amd
+    from pcl_amd import synth
+    from pcl_amd.dist import ShardedTarget, shard_range
+
+    n = args.points or 100_000_000
+    max_dist = 0.1
+    t0 = time.perf_counter()
+    tgt_h = synth.gaussian_surface(n, synth.TARGET_SEED)
+    gen_s = time.perf_counter() - t0
+    T_inv = np.linalg.inv(synth.ground_truth_transform())
+    setup = {}
+    if args.replicated:
+        start, count = shard_range(n, rank, world)
+        src_h = synth.apply_rigid(T_inv, synth.gaussian_surface(count, synth.SOURCE_SEED, start=start))
+        tgt = torch.from_numpy(tgt_h).cuda()
+        tree = pcl_amd.KdTree(ctx)
+        tree.setInputCloud(tgt)
+        ne = pcl_amd.NormalEstimation(ctx)
+        ne.setInputCloud(tgt)
+        ne.setSearchMethod(tree)
+        ne.setKSearch(args.knn)
+        ne.setViewPoint(0, 0, 10)
+        ne.compute(want_output=False)
+        region = None
+        setup.update(index_points=tree.size(), index_build_ms=round(tree.build_ms(), 3), normals_kernel_ms=round(tree.lastKernelMs(), 3))
+    else:
+        src_h = synth.apply_rigid(T_inv, synth.gaussian_surface(n, synth.SOURCE_SEED))
+        t1 = time.perf_counter()
+        st = ShardedTarget(ctx, tgt_h, rank, world, max_dist, k_normals=args.knn, viewpoint=(0, 0, 10))
+        tree, region = st.tree, st.region
+        setup.update(index_points=tree.size(), halo_margin=round(st.margin, 5), kth_neighbour_distance=round(st.kth, 6),
+                     normals_exact=bool(st.normals_exact), index_build_ms=round(tree.build_ms(), 3),
+                     shard_setup_s=round(time.perf_counter() - t1, 2))
+    del tgt_h
+    src = torch.from_numpy(src_h).cuda()
+    icp = pcl_amd.IterativeClosestPointWithNormals(ctx)
+    icp.setSearchMethodTarget(tree, True)
+    icp.setInputSource(src)
+    icp.setMaximumIterations(20)
+    icp.setMaxCorrespondenceDistance(max_dist)
+    icp.setTransformationEpsilon(1e-10)
+    if comm is not None:
+        icp.setCommunicator(comm)
+    if region is not None:
+        icp.setRegion(region)
+    if args.warmup > 0:
+        icp.runSteps(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    steps = icp.runSteps(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    ncorr = float(sum(s["num_correspondences"] for s in steps))       # all-reduced: the whole job's count
+    search_ms = sum(s["search_ms"] for s in steps)
+    avg_kernel_s = search_ms / max(args.steps, 1) / 1e3
+    achieved = B_ALG_SEARCH * (ncorr / max(args.steps, 1) / world) / avg_kernel_s / 1e9
+    return {
+        "metric": "ICP correspondences/sec", "value": round(ncorr / elapsed, 1), "unit": "correspondences/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 search / f64 accumulate",
+        "data": "synthetic",
+        "config": {"workload": "config 5: %d-point synthetic Gaussian-surface target and source, k=%d normals + point-to-plane "
+                               "ICP, max_dist %.2f; %s" %
+                               (n, args.knn, max_dist,
+                                "target replicated, source cut into %d slabs" % world if args.replicated else
+                                "target cut into %d kd slabs + halo, source replicated and routed by current position" % world),
+                   "target_points": n, "source_points": n,
+                   "parallelism": ("source slabs x%d" if args.replicated else "target kd slabs + halo x%d") % world +
+                                  ", ncclAllReduce of the 32-double record per iteration"},
+        "roofline": {"bound": "hbm", "kernel": "icp_search_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "alg_bytes_per_corr": B_ALG_SEARCH, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
+                     "note": "rank 0's launches; achieved counts the correspondences rank 0 serves on average"},
+        "cpu_baseline": None,
+        "per_step": [{"iteration": s["iteration"], "search_ms": round(s["search_ms"], 4), "step_ms": round(s["step_ms"], 4),
+                      "ended": s["alignment_ended"]} for s in steps],
+        "setup": dict(setup, synth_gen_s=round(gen_s, 1)),
+    }

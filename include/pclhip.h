@@ -335,6 +335,37 @@ PCLHIP_API pclhip_status pclhip_comm_allreduce_sum_f64(pclhip_comm* comm, double
 /* attach (or detach with NULL) a communicator; replaces the pclhip_icp_set_allreduce hook when both are set */
 PCLHIP_API pclhip_status pclhip_icp_set_comm(pclhip_icp* icp, pclhip_comm* comm);
 
+/* ---- target sharding: a target cloud spread over the GPUs of a node ------------------------
+ * The target is cut into n_slabs cells of a kd partition of space (recursive bisection at order statistics along
+ * the widest axis: equal point counts, half-open boxes [lo, hi) that tile R^3, unbounded on the outside).  Rank g
+ *   1. selects the target points of its region dilated by a margin >= max_correspondence_distance (the halo) and
+ *      builds its index on them -- pclhip_index_build with that index list, so results keep ORIGINAL indices;
+ *   2. holds the whole source, but serves only the points whose CURRENT position lies in its region
+ *      (pclhip_icp_set_region): such a point finds its true nearest neighbour in the rank's index whenever that
+ *      neighbour is within the margin, and correctly finds none within max_correspondence_distance otherwise;
+ *   3. takes part in the per-iteration all-reduce of the record (pclhip_icp_set_comm); all ranks then apply the
+ *      same transformation, so routing stays consistent without any other exchange.
+ * Correspondences over all ranks are exactly those of a single index over the whole target.
+ * Partitioning and selection are host code (no GPU needed); clouds may be host or device memory.
+ * regions: n_slabs x 6 floats (lo.xyz, hi.xyz), +-inf on unbounded sides. */
+PCLHIP_API pclhip_status pclhip_partition_slabs(const void* points, size_t stride_bytes, uint64_t n, int n_slabs,
+                                                float* regions);
+/* ascending indices of the finite points inside `region` dilated by `margin` per axis (rounded outwards);
+ * *out_count is always set; PCLHIP_ERR_OVERFLOW if it exceeds `capacity` */
+PCLHIP_API pclhip_status pclhip_select_region(const void* points, size_t stride_bytes, uint64_t n,
+                                              const float region[6], double margin, int32_t* out_indices,
+                                              uint64_t capacity, uint64_t* out_count);
+/* the slab whose region holds the point (x >= lo && x < hi per axis), -1 for non-finite points */
+PCLHIP_API int pclhip_region_owner(const float* regions, int n_slabs, const float xyz[3]);
+/* restrict the registration to the source points whose current position lies in `region`; NULL: all points */
+PCLHIP_API pclhip_status pclhip_icp_set_region(pclhip_icp* icp, const float region[6]);
+/* Largest squared distance to the k-th nearest neighbour (the point itself counts as the first, as in
+ * pclhip_normals) over the indexed points inside `box` (lo.xyz, hi.xyz; NULL: all).  With a halo index this
+ * tells whether the normals of the points a rank can be matched to are exact: they are when
+ * sqrt(*out_max_d2) <= margin - max_correspondence_distance (every neighbour then lies inside the halo). */
+PCLHIP_API pclhip_status pclhip_index_kth_distance_max(pclhip_index* index, int k, const float box[6],
+                                                       double* out_max_d2);
+
 /* Registration::getFitnessScore(max_range) (registration/include/pcl/registration/impl/registration.hpp:132-168):
  * the source is transformed by T (row-major 4x4, Transformer::se3 operation order like
  * transformPointCloud), every finite point looks up its nearest target point, and the SQUARED

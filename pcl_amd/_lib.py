@@ -135,6 +135,11 @@ SIGNATURES = {
     "pclhip_comm_size": (C.c_int, [_vp]),
     "pclhip_comm_allreduce_sum_f64": (C.c_int, [_vp, _vp, C.c_int]),
     "pclhip_icp_set_comm": (C.c_int, [_vp, _vp]),
+    "pclhip_partition_slabs": (C.c_int, [_vp, _sz, _u64, C.c_int, C.POINTER(C.c_float)]),
+    "pclhip_select_region": (C.c_int, [_vp, _sz, _u64, C.POINTER(C.c_float), C.c_double, _vp, _u64, C.POINTER(_u64)]),
+    "pclhip_region_owner": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]),
+    "pclhip_icp_set_region": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "pclhip_index_kth_distance_max": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "pclhip_icp_fitness_score": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_double, C.POINTER(C.c_double),
                                            C.POINTER(_u64)]),
     "pclhip_icp_fetch_correspondences": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_u64)]),

@@ -188,6 +188,15 @@ class KdTree:
         sc[:dimensions] = rv
         self._scale = sc
 
+    def kthDistanceMax(self, k, box=None):
+        """pclhip_index_kth_distance_max: the largest k-th-neighbour distance (not squared) over the indexed
+        points inside `box` (lo.xyz, hi.xyz; None: all)."""
+        out = C.c_double(0.0)
+        b = None if box is None else np.ascontiguousarray(box, np.float32).reshape(6)
+        check(self.lib.pclhip_index_kth_distance_max(self.h, int(k), _fp(b) if b is not None else None, C.byref(out)),
+              self.ctx.h)
+        return math.sqrt(out.value)
+
     def size(self):
         return int(self.lib.pclhip_index_size(self.h))
 
@@ -559,6 +568,13 @@ class IterativeClosestPoint:
         if self.h:
             check(self.lib.pclhip_icp_set_comm(self.h, comm.h if comm is not None else None), self.ctx.h)
 
+    def setRegion(self, region):
+        """Target sharding (pclhip_icp_set_region): only the source points whose CURRENT position lies in
+        `region` = (lo.xyz, hi.xyz), half-open, take part on this rank.  None: all points."""
+        self._region = None if region is None else np.ascontiguousarray(region, np.float32).reshape(6)
+        if self.h:
+            check(self.lib.pclhip_icp_set_region(self.h, _fp(self._region) if self._region is not None else None), self.ctx.h)
+
     def runSteps(self, n_steps, guess=None):
         """pclhip_icp_run_steps: exactly n_steps iterations queued back to back on the device, alignments
         restarting on convergence.  Returns the list of per-step dicts."""
@@ -612,6 +628,8 @@ class IterativeClosestPoint:
                 check(self.lib.pclhip_icp_set_allreduce(self.h, self._allreduce, None), self.ctx.h)
             if getattr(self, "_comm", None) is not None:
                 check(self.lib.pclhip_icp_set_comm(self.h, self._comm.h), self.ctx.h)
+            if getattr(self, "_region", None) is not None:
+                check(self.lib.pclhip_icp_set_region(self.h, _fp(self._region)), self.ctx.h)
         if self._src_dirty:
             ptr, stride, n, keep = _cloud(self.src)
             ind = getattr(self, "_src_indices", None)

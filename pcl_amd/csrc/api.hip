@@ -515,6 +515,66 @@ pclhip_status pclhip_gicp_covariances(pclhip_index* ix, int k, double epsilon, d
   return PCLHIP_OK;
 }
 
+namespace {
+// queries = the indexed points themselves; w = sorted position so that result row i belongs to sorted point i
+__global__ void self_query_kernel(const float4* __restrict__ pts, uint32_t n, float4* __restrict__ q) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    float4 p = pts[i];
+    p.w = __uint_as_float(i);
+    q[i] = p;
+  }
+}
+// max over the points inside the box of their k-th neighbour distance; unsigned order == float order for d2 >= 0
+__global__ void kth_max_kernel(const float4* __restrict__ pts, const float* __restrict__ d2, uint32_t n, int k, int has_box,
+                               float lx, float ly, float lz, float hx, float hy, float hz, unsigned int* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  if (has_box && !(p.x >= lx && p.x <= hx && p.y >= ly && p.y <= hy && p.z >= lz && p.z <= hz)) return;
+  const float v = d2[size_t(i) * k + (k - 1)];
+  atomicMax(out, __float_as_uint(v));  // +inf (fewer than k points) dominates, as it should
+}
+}  // namespace
+
+pclhip_status pclhip_index_kth_distance_max(pclhip_index* ix, int k, const float* box, double* out_max_d2) {
+  if (!ix || !out_max_d2) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = ix->ctx;
+  PCLHIP_REQUIRE(ctx, k >= 1, "k must be >= 1");
+  *out_max_d2 = 0.0;
+  if (ix->n == 0) return PCLHIP_OK;
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceScope scope;
+  float4* q = nullptr;
+  int32_t* idx = nullptr;
+  float* d2 = nullptr;
+  unsigned int* mx = nullptr;
+  PCLHIP_CHECK_HIP(ctx, scope.alloc(&q, size_t(ix->n) * sizeof(float4)));
+  PCLHIP_CHECK_HIP(ctx, scope.alloc(&idx, size_t(ix->n) * k * sizeof(int32_t)));
+  PCLHIP_CHECK_HIP(ctx, scope.alloc(&d2, size_t(ix->n) * k * sizeof(float)));
+  PCLHIP_CHECK_HIP(ctx, scope.alloc(&mx, sizeof(unsigned int)));
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(mx, 0, sizeof(unsigned int), ctx->stream));
+  hipLaunchKernelGGL(self_query_kernel, dim3((ix->n + 255) / 256), dim3(256), 0, ctx->stream, ix->pts, ix->n, q);
+  pclhip_status st = launch_knn(ix, q, ix->n, k, idx, d2);
+  if (st != PCLHIP_OK) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return st;
+  }
+  hipLaunchKernelGGL(kth_max_kernel, dim3((ix->n + 255) / 256), dim3(256), 0, ctx->stream, ix->pts, d2, ix->n, k, box ? 1 : 0,
+                     box ? box[0] : 0.f, box ? box[1] : 0.f, box ? box[2] : 0.f, box ? box[3] : 0.f, box ? box[4] : 0.f,
+                     box ? box[5] : 0.f, mx);
+  unsigned int h = 0;
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, mx, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
+  const hipError_t es = hipStreamSynchronize(ctx->stream);
+  PCLHIP_CHECK_HIP(ctx, e);
+  PCLHIP_CHECK_HIP(ctx, es);
+  float f;
+  std::memcpy(&f, &h, sizeof f);
+  *out_max_d2 = double(f);
+  return PCLHIP_OK;
+}
+
 pclhip_status pclhip_index_set_normals(pclhip_index* ix, const void* normals, size_t stride) {
   if (!ix) return PCLHIP_ERR_INVALID;
   pclhip_ctx* ctx = ix->ctx;
@@ -563,8 +623,6 @@ pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out) {
   icp->target = target;
   icp->prev_mse = DBL_MAX;
   if (hipMalloc(&icp->sums_dev, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
-      hipMalloc(&icp->blocks_done, sizeof(unsigned int)) != hipSuccess ||
-      hipMemset(icp->blocks_done, 0, sizeof(unsigned int)) != hipSuccess ||
       hipHostMalloc(&icp->sums_host, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
       // timing markers between kernels of one stream: device-scope release is enough (a system-scope
       // release would write the iteration's dirty lines back to memory at every marker)
@@ -606,7 +664,6 @@ void pclhip_icp_destroy(pclhip_icp* icp) {
   }
   icp_free_source(icp);
   if (icp->sums_dev) (void)hipFree(icp->sums_dev);
-  if (icp->blocks_done) (void)hipFree(icp->blocks_done);
   if (icp->sums_host) (void)hipHostFree(icp->sums_host);
   if (icp->ctl) (void)hipFree(icp->ctl);
   if (icp->ctl_host) (void)hipHostFree(icp->ctl_host);

@@ -167,7 +167,6 @@ struct pclhip_icp {
   float* match_d2 = nullptr;
   double* partials = nullptr;      // [blocks][NSUMS]
   double* sums_dev = nullptr;      // [NSUMS]
-  unsigned int* blocks_done = nullptr;  // accumulate kernel: blocks finished (the last one folds the partials)
   double* sums_host = nullptr;     // pinned
   int grid_blocks = 0;
   pclhip_allreduce_fn allreduce = nullptr;

@@ -770,11 +770,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
     // hint for the descent: the leaf of one lane's seed (any lane: the containment test inside traverse()
     // decides whether the shortcut is valid for the whole wave)
     uint32_t start_leaf = NO_INDEX;
-    if (flags & 2) {
-      const uint64_t hm = __builtin_amdgcn_ballot_w64(valid[0] && seed_pos[0] != NO_INDEX);
-      if (hm != 0) start_leaf = uint32_t(__builtin_amdgcn_readlane(int(seed_pos[0]), __builtin_ctzll(hm))) / LEAF;
-    }
-    traverse<NN1MinT<Q>, SPARSE>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, start_leaf);
+    const uint64_t hm = __builtin_amdgcn_ballot_w64(valid[0] && seed_pos[0] != NO_INDEX);
+    if ((flags & 2) && hm != 0) start_leaf = uint32_t(__builtin_amdgcn_readlane(int(seed_pos[0]), __builtin_ctzll(hm))) / LEAF;
+    // no lane has a seed: the first iteration of an alignment, queries stand off the target -> disc bounds
+    traverse<NN1MinT<Q>, SPARSE>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, start_leaf, hm == 0);
     fast.resolve(ix, qx, qy, qz);
     // ... and their seed target points as soon as the seed positions have arrived
 #pragma unroll
@@ -947,8 +946,7 @@ __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, con
                                                                const IcpControl* __restrict__ ctl,
                                                                float4* __restrict__ src_nrm,
                                                                const float4* __restrict__ src_nrm0, int enforce,
-                                                               double* __restrict__ partials, unsigned int* __restrict__ done,
-                                                               double* __restrict__ sums) {
+                                                               double* __restrict__ partials) {
   __shared__ double red_s[WAVES_PER_BLOCK][NS];
   bool restart = false;
   if (ctl != nullptr) {
@@ -981,31 +979,6 @@ __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, con
     pa.add(p, n1, t, n, match_d2[i], enforce != 0);
   }
   pa.store_block(red_s, partials);
-  // The block that finishes last folds the per-block partials in a fixed order (deterministic for a given
-  // grid): no separate reduction launch.  (Closing the iteration here as well -- icp_solve_step inlined --
-  // would cost this streaming kernel 1 KB of scratch per lane and half its registers.)
-  __shared__ bool last_s;
-  __shared__ double fold_s[BLOCK / NS][NS];
-  __threadfence();
-  if (threadIdx.x == 0) last_s = atomicAdd(done, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!last_s) return;
-  __threadfence();  // acquire: pairs with the release fence each block issued before bumping `done`
-  {
-    const int t = threadIdx.x % NS, r = threadIdx.x / NS;  // NS == 32: 8 rows of 32 sums
-    double a = 0.0;
-#pragma unroll 8
-    for (uint32_t b = r; b < gridDim.x; b += BLOCK / NS) a += partials[size_t(b) * NS + t];  // plain, coalesced, pipelined
-    fold_s[r][t] = a;
-    __syncthreads();
-    if (r == 0) {
-      double v = 0.0;
-#pragma unroll
-      for (int i = 0; i < BLOCK / NS; ++i) v += fold_s[i][t];
-      sums[t] = v;
-    }
-  }
-  if (threadIdx.x == 0) *done = 0;  // ready for the next launch
 }
 
 // TransformationEstimation::estimateRigidTransformation(cloud_src, cloud_tgt) for n given pairs
@@ -1138,7 +1111,7 @@ static void launch_accumulate(pclhip_icp* icp, const IndexView& v, int ga, const
                               const IcpControl* ctl, hipStream_t s) {
   hipLaunchKernelGGL(icp_accumulate_kernel<MODE>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, icp->match_pos,
                      icp->match_d2, keep, M, ctl, icp->src_nrm_cur, icp->src_nrm_sorted0,
-                     icp->enforce_same_direction_normals ? 1 : 0, icp->partials, icp->blocks_done, icp->sums_dev);
+                     icp->enforce_same_direction_normals ? 1 : 0, icp->partials);
 }
 
 // One iteration.  ev == nullptr: the host-driven form (T by value, the caller reads the record back);
@@ -1192,6 +1165,9 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     else
       launch_accumulate<PCLHIP_ICP_POINT_TO_POINT>(icp, v, ga, keep, M, ctl, s);
     (void)hipEventRecord(device_loop ? ev[2] : icp->ev1, s);
+    // (Folding this reduction into the accumulate kernel -- last block done -- was tried: the 2048 device-scope
+    // atomics on one counter cost ~100 us across the 8 XCDs, five times this 20 us launch.)
+    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, ga, icp->sums_dev, ctl);
   } else if (icp->n > 0) {
     int grid = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? resident_blocks(ctx, k_plane, ngroups)
                                                    : resident_blocks(ctx, k_point, ngroups);

@@ -594,7 +594,7 @@ __device__ __forceinline__ float lane_worst(const Policy& pol, const bool* valid
 template <class Policy, bool SPARSE = false, class WL = WaveLds>
 __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, const float* qy, const float* qz,
                                          const bool* valid, Policy& pol, WL& wl, const Box* topbox,
-                                         TraverseStats& ts, uint32_t start_leaf = NO_INDEX) {
+                                         TraverseStats& ts, uint32_t start_leaf = NO_INDEX, bool allow_disc = false) {
   constexpr int QPL = Policy::QPL;
   const int lane = threadIdx.x & (WAVE - 1);
   bool any_valid = false;
@@ -620,7 +620,10 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
   // bounding sphere of the group (for the disc bounds of loose searches), radius rounded up
   const float Qcx = 0.5f * (Qlx + Qhx), Qcy = 0.5f * (Qly + Qhy), Qcz = 0.5f * (Qlz + Qhz);
   const float rQ = __fsqrt_rn(gdiag2) * 0.5000005f + 1e-6f * ((fabsf(Qcx) + fabsf(Qcy)) + fabsf(Qcz));
-  const bool have_disc = ix.disc != nullptr;
+  // Disc bounds pay where queries STAND OFF the indexed surface (the unseeded first iteration of a
+  // registration): the caller says so.  Self-queries (normals) and seeded queries sit on or near the surface,
+  // inside the discs of all the leaves around them, where a disc excludes nothing a box does not.
+  const bool have_disc = allow_disc && ix.disc != nullptr;
   uint2* const stack = wl.stack;
 
   int sp = 0;

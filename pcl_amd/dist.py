@@ -62,3 +62,105 @@ def make_allreduce_hook(device_index, group=None):
                 dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=group)
         return 0
     return hook
+
+
+# ---- target sharding: kd slabs + halo over the ranks -----------------------------------
+# The partition / selection / ownership logic is host code of libpclhip.so (pcl_amd/csrc/shard.cpp): it runs
+# without a GPU, which is what the multi-process CPU tests exercise.
+def _cloud_arg(cloud):
+    import ctypes as C
+    if type(cloud).__module__.startswith("torch"):
+        c = cloud.contiguous()
+        return C.c_void_p(c.data_ptr()), c.shape[1] * 4, c.shape[0], c
+    c = np.ascontiguousarray(cloud, np.float32)
+    return C.c_void_p(c.ctypes.data), c.shape[1] * 4, c.shape[0], c
+
+
+def partition_slabs(cloud, n_slabs):
+    """(n_slabs, 6) float32 regions (lo.xyz, hi.xyz): kd cells of equal point count that tile space."""
+    import ctypes as C
+    from . import _lib
+    ptr, stride, n, keep = _cloud_arg(cloud)
+    reg = np.zeros((int(n_slabs), 6), np.float32)
+    _lib.check(_lib.load().pclhip_partition_slabs(ptr, stride, n, int(n_slabs), reg.ctypes.data_as(C.POINTER(C.c_float))))
+    return reg
+
+
+def select_region(cloud, region, margin):
+    """ascending int32 indices of the finite points of `cloud` inside `region` dilated by `margin`"""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    ptr, stride, n, keep = _cloud_arg(cloud)
+    reg = np.ascontiguousarray(region, np.float32).reshape(6)
+    cnt = C.c_uint64(0)
+    rp = reg.ctypes.data_as(C.POINTER(C.c_float))
+    st = lib.pclhip_select_region(ptr, stride, n, rp, float(margin), None, 0, C.byref(cnt))
+    if st not in (0, -5):
+        _lib.check(st)
+    out = np.empty(int(cnt.value), np.int32)
+    if len(out):
+        _lib.check(lib.pclhip_select_region(ptr, stride, n, rp, float(margin), C.c_void_p(out.ctypes.data), len(out),
+                                            C.byref(cnt)))
+    return out
+
+
+def region_owner(regions, points):
+    """owner slab of every point (x >= lo && x < hi per axis, the kernel's test); -1 for non-finite points"""
+    r = np.asarray(regions, np.float32).reshape(-1, 6)
+    p = np.asarray(points, np.float32)[:, :3]
+    own = np.full(len(p), -1, np.int32)
+    for g in range(len(r)):
+        inside = np.all((p >= r[g, :3]) & (p < r[g, 3:]), axis=1)
+        own[inside] = g
+    return own
+
+
+class ShardedTarget:
+    """This rank's share of a target cloud spread over `world` GPUs: its kd slab plus the halo, indexed on the
+    device (results carry indices into the ORIGINAL cloud), with normals that are exact wherever a query this
+    rank serves can be matched (checked, not assumed).
+
+      margin = max_correspondence_distance + normals_margin
+    The first term makes correspondences exact, the second leaves every matchable point all of its k
+    neighbours inside the halo; `normals_margin` None picks 4x the k-th neighbour distance measured on the slab."""
+
+    def __init__(self, ctx, target, rank, world, max_correspondence_distance, k_normals=0, viewpoint=(0.0, 0.0, 0.0),
+                 normals_margin=None, regions=None):
+        from . import api
+        self.regions = partition_slabs(target, world) if regions is None else np.asarray(regions, np.float32).reshape(world, 6)
+        self.region = self.regions[rank].copy()
+        md = float(max_correspondence_distance)
+        self.tree = api.KdTree(ctx)
+        extra = 0.0 if k_normals <= 0 else (normals_margin if normals_margin is not None else None)
+        if extra is None:  # measure the neighbourhood size on the bare slab first
+            probe = api.KdTree(ctx)
+            probe.setInputCloud(target, select_region(target, self.region, 0.0))
+            extra = 4.0 * probe.kthDistanceMax(k_normals)
+            probe._free()
+        self.margin = md + float(extra)
+        self.indices = select_region(target, self.region, self.margin)
+        self.tree.setInputCloud(target, self.indices)
+        self.normals_exact = None
+        if k_normals > 0:
+            ne = api.NormalEstimation(ctx)
+            ne.setInputCloud(target)
+            ne.setSearchMethod(self.tree)
+            ne.setKSearch(k_normals)
+            ne.setViewPoint(*viewpoint)
+            ne.tree = self.tree
+            self._compute_normals(ne)
+            # every target point a query of this region can be matched to lies within md of the region
+            box = np.concatenate([self.region[:3] - np.float32(md * 1.00002), self.region[3:] + np.float32(md * 1.00002)])
+            self.kth = self.tree.kthDistanceMax(k_normals, box)
+            self.normals_exact = self.kth <= extra
+            if not self.normals_exact:
+                raise RuntimeError("halo too thin for exact normals: k-th neighbour at %.3g, margin beyond max_dist %.3g"
+                                   % (self.kth, extra))
+
+    def _compute_normals(self, ne):
+        import ctypes as C
+        from . import _lib
+        nan = C.c_uint64(0)
+        _lib.check(self.tree.lib.pclhip_normals(self.tree.h, ne.k, ne.vp.ctypes.data_as(C.POINTER(C.c_float)), None, 0,
+                                                C.byref(nan)), self.tree.ctx.h)

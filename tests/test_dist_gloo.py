@@ -99,3 +99,100 @@ def test_two_rank_allreduce_matches_single_process(mode):
         assert np.allclose(rec, ref, rtol=1e-11, atol=1e-12)
         assert np.array_equal(T, out[0][1])               # every rank solves the same system
         assert np.abs(T - _solve(ref, mode)).max() < 1e-7  # and it is the single-process answer
+
+
+# ---- target sharding (kd slabs + halo, pcl_amd/csrc/shard.cpp): exact by construction -------------------
+def _sharded_correspondences(tgt, cur, regions, rank, max_dist):
+    """What rank `rank` emits: the points it owns (the kernel's x >= lo && x < hi test) searched in ITS share of
+    the target (slab + halo); the device search is stood in for by the oracle, everything else is product code."""
+    from oracle import pcl_oracle as orc
+    from pcl_amd.dist import region_owner, select_region
+    idx = select_region(tgt, regions[rank], max_dist)
+    mine = np.nonzero(region_owner(regions, cur) == rank)[0]
+    if len(idx) == 0 or len(mine) == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32), len(idx)
+    q, m, d = orc.KdTree(np.ascontiguousarray(tgt[idx])).correspondences(np.ascontiguousarray(cur[mine]), max_dist, nthreads=2)
+    return mine[q], idx[m], d, len(idx)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_target_equals_single_index(world):
+    from oracle import pcl_oracle as orc
+    from pcl_amd.dist import partition_slabs, region_owner
+    n = 30000
+    tgt = synth.gaussian_surface(n, synth.TARGET_SEED)
+    tgt[17] = np.nan                                   # dropped by every index, owned by nobody
+    tgt[100:120] = tgt[200:220]                        # exact duplicates: ties go to the lower original index
+    src = synth.apply_rigid(np.linalg.inv(synth.ground_truth_transform()), synth.gaussian_surface(n, synth.SOURCE_SEED))
+    regions = partition_slabs(tgt, world)
+    own_t = region_owner(regions, tgt)
+    cnt = np.bincount(own_t[own_t >= 0], minlength=world)
+    assert cnt.sum() == n - 1 and cnt.max() - cnt.min() <= 25 and own_t[17] == -1     # equal counts (duplicates aside)
+    # the regions tile space: every finite point of ANY cloud has exactly one owner
+    probe = np.random.default_rng(0).uniform(-3, 3, (5000, 3)).astype(np.float32)
+    assert (region_owner(regions, probe) >= 0).all()
+    tree = orc.KdTree(tgt)
+    for max_dist, T in ((0.1, np.eye(4)), (0.02, np.eye(4)), (0.1, synth.ground_truth_transform())):
+        cur = synth.apply_rigid(T, src)
+        want = tree.correspondences(cur, max_dist, nthreads=2)
+        got_q, got_m, got_d, halo = [], [], [], 0
+        for r in range(world):
+            q, m, d, h = _sharded_correspondences(tgt, cur, regions, r, max_dist)
+            got_q.append(q); got_m.append(m); got_d.append(d)
+            halo += h
+        order = np.argsort(np.concatenate(got_q), kind="stable")
+        q = np.concatenate(got_q)[order]
+        assert np.array_equal(q, want[0])                                        # every query exactly once
+        assert np.array_equal(np.concatenate(got_m)[order], want[1])             # the same match, ORIGINAL indices
+        assert np.array_equal(np.concatenate(got_d)[order].view(np.uint32), want[2].view(np.uint32))
+        assert halo >= n - 1                                                      # slabs + halos cover the cloud
+
+
+def _shard_worker(rank, world, port, n, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pcl_oracle as orc
+        from pcl_amd.dist import partition_slabs
+        tgt = synth.gaussian_surface(n, synth.TARGET_SEED)
+        src = synth.apply_rigid(np.linalg.inv(synth.ground_truth_transform()), synth.gaussian_surface(n, synth.SOURCE_SEED))
+        # rank 0 partitions, everybody uses ITS answer (as a real job would broadcast the 6 floats per rank)
+        box = [partition_slabs(tgt, world) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        regions = box[0]
+        nrm = orc.KdTree(tgt).normals(tgt, 8, viewpoint=(0, 0, 10), nthreads=2)[0]
+        q, m, d, _ = _sharded_correspondences(tgt, src, regions, rank, 0.1)
+        rec = np.zeros(_lib.NSUMS)
+        _, s27, used = orc.lls_point_to_plane(src, tgt, nrm, q.astype(np.int32), m)
+        rec[:27] = s27
+        rec[27] = d.astype(np.float64).sum()
+        rec[28] = len(q)
+        rec = reduce_record_host(rec)
+        out[rank] = (q, m, rec, _solve(rec, 1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_target_matches_single_process():
+    n, world = 20000, 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_shard_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    from oracle import pcl_oracle as orc
+    tgt = synth.gaussian_surface(n, synth.TARGET_SEED)
+    nrm = orc.KdTree(tgt).normals(tgt, 8, viewpoint=(0, 0, 10), nthreads=2)[0]
+    src = synth.apply_rigid(np.linalg.inv(synth.ground_truth_transform()), synth.gaussian_surface(n, synth.SOURCE_SEED))
+    ref = _local_record(tgt, nrm, src, 1)
+    want = orc.KdTree(tgt).correspondences(src, 0.1, nthreads=2)
+    q = np.concatenate([out[r][0] for r in range(world)])
+    m = np.concatenate([out[r][1] for r in range(world)])
+    order = np.argsort(q, kind="stable")
+    assert np.array_equal(q[order], want[0]) and np.array_equal(m[order], want[1])
+    assert len(out[0][0]) > 0 and len(out[1][0]) > 0                      # both ranks served queries
+    for r in range(world):
+        rec, T = out[r][2], out[r][3]
+        assert rec[28] == ref[28] == n
+        assert np.allclose(rec, ref, rtol=1e-11, atol=1e-12)
+        assert np.array_equal(T, out[0][3])
+        assert np.abs(T - _solve(ref, 1)).max() < 1e-7

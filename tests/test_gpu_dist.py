@@ -62,3 +62,84 @@ def test_allreduce_hook_over_rccl_single_rank():
         assert np.array_equal(results[0][2], results[1][2])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_target_on_device_equals_single_index(world):
+    # Target sharding (kd slabs + halo, include/pclhip.h "target sharding") with the real kernels: the `world`
+    # ranks are played one after the other on this GPU.  Over all ranks the correspondences of every iteration
+    # are those of a single index over the whole target, bit for bit, and the per-rank records add up to the
+    # single-index record (their normals are exact: the halo is checked for that).
+    import pcl_amd
+    from pcl_amd import synth
+    from pcl_amd.dist import ShardedTarget, partition_slabs
+    ctx = pcl_amd.Context(0)
+    n = 300_000
+    tgt, src, _ = synth.icp_pair(n)
+    tree = pcl_amd.KdTree(ctx)
+    tree.setInputCloud(tgt)
+    ne = pcl_amd.NormalEstimation(ctx)
+    ne.setInputCloud(tgt)
+    ne.setSearchMethod(tree)
+    ne.setKSearch(8)
+    ne.setViewPoint(0, 0, 10)
+    ne.compute(want_output=False)
+    one = pcl_amd.IterativeClosestPointWithNormals(ctx)
+    one.setSearchMethodTarget(tree, True)
+    one.setInputSource(src)
+    one.reset()
+    regions = partition_slabs(tgt, world)
+    shards = []
+    for r in range(world):
+        st = ShardedTarget(ctx, tgt, r, world, 0.1, k_normals=8, viewpoint=(0, 0, 10), regions=regions)
+        assert st.normals_exact and st.tree.size() < n and st.margin > 0.1
+        icp = pcl_amd.IterativeClosestPointWithNormals(ctx)
+        icp.setSearchMethodTarget(st.tree, True)
+        icp.setInputSource(src)          # every rank holds the whole source ...
+        icp.setRegion(st.region)         # ... and serves the points whose current position it owns
+        icp.reset()
+        shards.append((st, icp))
+    assert sum(st.tree.size() for st, _ in shards) >= n      # slabs + halos cover the cloud
+    T = np.eye(4, dtype=np.float32)
+    for it in range(4):
+        ref = one.iterate(T, max_dist=0.1)
+        want = one.fetchCorrespondences()
+        total = np.zeros_like(ref)
+        got = []
+        for st, icp in shards:
+            sums = icp.iterate(T, max_dist=0.1)
+            total += sums
+            got.append(icp.fetchCorrespondences())
+        q = np.concatenate([g[0] for g in got])
+        order = np.argsort(q, kind="stable")
+        assert np.array_equal(q[order], want[0]), it                                        # every query once
+        assert np.array_equal(np.concatenate([g[1] for g in got])[order], want[1]), it      # ORIGINAL target indices
+        assert np.array_equal(np.concatenate([g[2] for g in got])[order].view(np.uint32), want[2].view(np.uint32)), it
+        assert total[28] == ref[28] == n
+        assert min(g[0].size for g in got) > 0                                               # every rank had work
+        assert np.allclose(total[:28], ref[:28], rtol=1e-10, atol=1e-12), it
+        T = one.solve(ref)
+
+
+def test_native_comm_and_region_in_the_device_loop():
+    # one rank, all of space as its region, the C-side RCCL all-reduce in every iteration: the device-driven
+    # loop must produce exactly what the plain loop produces
+    import pcl_amd
+    from pcl_amd import synth
+    ctx = pcl_amd.Context(0)
+    tgt, src, _ = synth.icp_pair(100_000)
+    res = []
+    for sharded in (False, True):
+        icp = pcl_amd.IterativeClosestPoint(ctx)
+        icp.setInputTarget(tgt)
+        icp.setInputSource(src)
+        icp.setMaximumIterations(15)
+        icp.setMaxCorrespondenceDistance(0.1)
+        if sharded:
+            comm = pcl_amd.Communicator(ctx, 0, 1, pcl_amd.Communicator.unique_id())
+            icp.setCommunicator(comm)
+            icp.setRegion([-np.inf] * 3 + [np.inf] * 3)
+        icp.align()
+        steps = icp.runSteps(4)
+        res.append((icp.getFinalTransformation().copy(), icp.nr_iterations_, [s["num_correspondences"] for s in steps]))
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1:] == res[1][1:]
