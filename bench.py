@@ -210,7 +210,7 @@ def main():
                                       (world, ", ncclAllReduce of the 32-double record per iteration" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu,
             "per_step": [{"iteration": s["iteration"], "search_ms": round(s["search_ms"], 4),
-                          "step_ms": round(s["step_ms"], 4), "ended": s["alignment_ended"]} for s in steps],
+                          "step_ms": round(s["step_ms"], 4), "ended": s["alignment_ended"], "state": s["state"]} for s in steps],
             "setup": {"index_build_ms": round(build_ms, 3),
                       "index_build_GBps_alg": round(B_ALG_BUILD * n / (build_ms * 1e-3) / 1e9, 1),
                       "normals_kernel_ms": None if normals_ms is None else round(normals_ms, 3),

@@ -98,6 +98,6 @@ def run_config5(args, ctx, comm, rank, local_rank, world, fence):
                      "note": "rank 0's launches; achieved counts the correspondences rank 0 serves on average"},
         "cpu_baseline": None,
         "per_step": [{"iteration": s["iteration"], "search_ms": round(s["search_ms"], 4), "step_ms": round(s["step_ms"], 4),
-                      "ended": s["alignment_ended"]} for s in steps],
+                      "ended": s["alignment_ended"], "state": s["state"]} for s in steps],
         "setup": dict(setup, synth_gen_s=round(gen_s, 1)),
     }

@@ -420,6 +420,20 @@ PCLHIP_API pclhip_status pclhip_voxelgrid(pclhip_ctx* ctx, const void* points, s
                                           int has_z_limits, double z_min, double z_max,
                                           void* out_xyzw, uint64_t* out_n);
 
+/* The same for records that carry normals and for setDownsampleAllData (filters/include/pcl/filters/voxel_grid.h
+ * :293-302, impl/voxel_grid.hpp:790-809).  Input and output records share a layout: x y z at +0 and, when
+ * normals_offset != 0 (pcl::PointNormal: 16, strides 48), normal[3], 0, curvature, 0 0 0 at +normals_offset.
+ *   downsample_all_data != 0: the CentroidPoint accumulators of common/include/pcl/common/impl/accumulators.hpp
+ *        :68-127 -- coordinates averaged, normal = normalised sum of the voxel's normals, curvature averaged;
+ *   downsample_all_data == 0: only the coordinates are averaged, every other field of the output keeps its
+ *        default (0).
+ * Sums run in ascending input index inside a voxel.  out must hold n records of out_stride bytes. */
+PCLHIP_API pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points, size_t stride_bytes, uint64_t n,
+                                             const float leaf[3], uint32_t min_points_per_voxel, int has_z_limits,
+                                             double z_min, double z_max, int downsample_all_data,
+                                             size_t normals_offset, void* out, size_t out_stride_bytes,
+                                             uint64_t* out_n);
+
 /* ---- PCD files (io/src/pcd_io.cpp: PCDReader :115-675, PCDWriter :848-1500) ----------------------
  * The on-disk format either side of the path.  ascii, binary and binary_compressed (LZF, fields stored
  * as struct of arrays) are read straight into the strided records the calls above consume.  Errors are

@@ -155,6 +155,8 @@ SIGNATURES = {
     "pclhip_pcd_write_organized": (C.c_int, [C.c_char_p, _vp, _sz, _sz, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
                                              C.c_int, C.c_int]),
     "pclhip_pcd_read_field": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, _vp, _u64, C.POINTER(_u64)]),
+    "pclhip_voxelgrid_ex": (C.c_int, [_vp, _vp, _sz, _u64, C.POINTER(C.c_float), C.c_uint32, C.c_int, C.c_double,
+                                      C.c_double, C.c_int, _sz, _vp, _sz, C.POINTER(_u64)]),
     "pclhip_voxelgrid": (C.c_int, [_vp, _vp, _sz, _u64, C.POINTER(C.c_float), C.c_uint32, C.c_int,
                                    C.c_double, C.c_double, _vp, C.POINTER(_u64)]),
 }

@@ -935,18 +935,30 @@ class VoxelGrid:
     def setFilterLimits(self, lo, hi):
         self.limits = (float(lo), float(hi))
 
+    def setDownsampleAllData(self, downsample):
+        """voxel_grid.h:293-302: False averages only x, y, z and leaves the other fields of the output at 0"""
+        self.all_data = bool(downsample)
+
+    def getDownsampleAllData(self):
+        return getattr(self, "all_data", True)
+
     def filter(self):
+        """-> [m, 4] (x, y, z, 1) for PointXYZ clouds; clouds with >= 12 columns are pcl::PointNormal records
+        (x y z 1 | nx ny nz 0 | curvature 0 0 0) and come back in the same layout."""
         ptr, stride, n, keep = _cloud(self.cloud)
         cnt = C.c_uint64(0)
         has = self.limits is not None
         lo, hi = self.limits if has else (0.0, 0.0)
+        with_normals = stride >= 48
+        cols = 12 if with_normals else 4
         if _is_torch(self.cloud):
             import torch
-            out = torch.empty((max(n, 1), 4), dtype=torch.float32, device=self.cloud.device)
+            out = torch.empty((max(n, 1), cols), dtype=torch.float32, device=self.cloud.device)
             optr = C.c_void_p(out.data_ptr())
         else:
-            out = np.empty((max(n, 1), 4), np.float32)
+            out = np.empty((max(n, 1), cols), np.float32)
             optr = C.c_void_p(out.ctypes.data)
-        check(self.lib.pclhip_voxelgrid(self.ctx.h, ptr, stride, n, _fp(self.leaf), self.min_pts, int(has),
-                                        lo, hi, optr, C.byref(cnt)), self.ctx.h)
+        check(self.lib.pclhip_voxelgrid_ex(self.ctx.h, ptr, stride, n, _fp(self.leaf), self.min_pts, int(has), lo, hi,
+                                           int(self.getDownsampleAllData()), 16 if with_normals else 0, optr, cols * 4,
+                                           C.byref(cnt)), self.ctx.h)
         return out[:int(cnt.value)]

@@ -11,6 +11,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
@@ -66,7 +67,7 @@ struct VgGrid {
 
 __global__ __launch_bounds__(256) void vg_key_kernel(const void* pts, size_t stride, uint64_t n, VgGrid g, int has_limits,
                                                      double lim_min, double lim_max, uint32_t* keys, uint32_t* vals,
-                                                     unsigned int* n_valid) {
+                                                     unsigned int* n_valid, int sort_bits) {
   const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
   bool ok = false;
   if (i < n) {
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void vg_key_kernel(const void* pts, size_t str
     const float x = p[0], y = p[1], z = p[2];
     ok = isfinite(x) && isfinite(y) && isfinite(z);
     if (ok && has_limits) ok = !((double(z) > lim_max) || (double(z) < lim_min));  // :684-695
-    uint32_t key = 0xFFFFFFFFu;
+    uint32_t key = sort_bits >= 32 ? 0xFFFFFFFFu : ((1u << sort_bits) - 1u);  // rejected: after every voxel id
     if (ok) {  // :713-718
       const int i0 = int(floorf(__fmul_rn(x, g.inv[0])) - float(g.min_b[0]));
       const int i1 = int(floorf(__fmul_rn(y, g.inv[1])) - float(g.min_b[1]));
@@ -84,8 +85,14 @@ __global__ __launch_bounds__(256) void vg_key_kernel(const void* pts, size_t str
     keys[i] = key;
     vals[i] = uint32_t(i);
   }
+  // one atomic per block (a per-wave atomic on a single counter serialises: ~1.8 ms at 10M points)
+  __shared__ unsigned int blk;
+  if (threadIdx.x == 0) blk = 0;
+  __syncthreads();
   const unsigned long long b = __builtin_amdgcn_ballot_w64(ok);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_valid, (unsigned int)__builtin_popcountll(b));
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&blk, (unsigned int)__builtin_popcountll(b));
+  __syncthreads();
+  if (threadIdx.x == 0 && blk) atomicAdd(n_valid, blk);
 }
 
 __global__ void vg_head_kernel(const uint32_t* keys, uint32_t nv, uint32_t* head) {
@@ -105,22 +112,53 @@ __global__ void vg_keep_kernel(const uint32_t* run_start, uint32_t nruns, uint32
   if (r < nruns) keep[r] = ((run_start[r + 1] - run_start[r]) >= min_pts) ? 1u : 0u;
 }
 
-// one thread per voxel: sequential float accumulation in sorted (= ascending input index) order
+// one thread per voxel: sequential float accumulation in sorted (= ascending input index) order.
+// Output records of `ostride` bytes: x y z 1 at +0; with normals (noff != 0, pcl::PointNormal layout) and
+// downsample_all_data the CentroidPoint accumulators of common/include/pcl/common/impl/accumulators.hpp:68-127:
+// normal = normalized sum (Eigen's Vector4f::normalized: v / sqrt(sum of squares); 0/0 -> NaN like Eigen >= 3.3),
+// curvature = sum / n.  Without downsample_all_data only the coordinates are averaged (voxel_grid.hpp:790-799),
+// every other field of the output record keeps its default (0).
 __global__ __launch_bounds__(256) void vg_centroid_kernel(const void* pts, size_t stride, const uint32_t* vals,
                                                           const uint32_t* run_start, const uint32_t* keep,
-                                                          const uint32_t* keep_scan, uint32_t nruns, float4* out) {
+                                                          const uint32_t* keep_scan, uint32_t nruns, void* out,
+                                                          size_t ostride, size_t noff, int all_data) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nruns || !keep[r]) return;
   const uint32_t b = run_start[r], e = run_start[r + 1];
-  float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+  float sx = 0.0f, sy = 0.0f, sz = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f, cv = 0.0f;
+  const bool with_n = noff != 0 && all_data;
   for (uint32_t j = b; j < e; ++j) {
     const float* p = rec(pts, stride, vals[j]);
     sx = __fadd_rn(sx, p[0]);
     sy = __fadd_rn(sy, p[1]);
     sz = __fadd_rn(sz, p[2]);
+    if (with_n) {
+      const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + noff);
+      nx = __fadd_rn(nx, q[0]);
+      ny = __fadd_rn(ny, q[1]);
+      nz = __fadd_rn(nz, q[2]);
+      cv = __fadd_rn(cv, q[4]);
+    }
   }
   const float cnt = float(e - b);
-  out[keep_scan[r] - 1] = make_float4(__fdiv_rn(sx, cnt), __fdiv_rn(sy, cnt), __fdiv_rn(sz, cnt), 1.0f);
+  float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + size_t(keep_scan[r] - 1) * ostride);
+  o[0] = __fdiv_rn(sx, cnt);
+  o[1] = __fdiv_rn(sy, cnt);
+  o[2] = __fdiv_rn(sz, cnt);
+  if (ostride >= 16) o[3] = 1.0f;
+  if (noff != 0) {
+    float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(o) + noff);
+    float a = 0.0f, bb = 0.0f, c = 0.0f, k = 0.0f;
+    if (with_n) {
+      const float len = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+      a = __fdiv_rn(nx, len);
+      bb = __fdiv_rn(ny, len);
+      c = __fdiv_rn(nz, len);
+      k = __fdiv_rn(cv, cnt);
+    }
+    q[0] = a; q[1] = bb; q[2] = c; q[3] = 0.0f;
+    q[4] = k; q[5] = 0.0f; q[6] = 0.0f; q[7] = 0.0f;
+  }
 }
 
 }  // namespace
@@ -131,13 +169,25 @@ using namespace pclhip;
 extern "C" pclhip_status pclhip_voxelgrid(pclhip_ctx* ctx, const void* points, size_t stride, uint64_t n,
                                           const float leaf[3], uint32_t min_points_per_voxel, int has_z_limits,
                                           double z_min, double z_max, void* out_xyzw, uint64_t* out_n) {
+  return pclhip_voxelgrid_ex(ctx, points, stride, n, leaf, min_points_per_voxel, has_z_limits, z_min, z_max, 1, 0, out_xyzw,
+                             16, out_n);
+}
+
+extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points, size_t stride, uint64_t n,
+                                             const float leaf[3], uint32_t min_points_per_voxel, int has_z_limits,
+                                             double z_min, double z_max, int downsample_all_data, size_t normals_offset,
+                                             void* out, size_t out_stride, uint64_t* out_n) {
   if (!ctx || !leaf || !out_n) return PCLHIP_ERR_INVALID;
   *out_n = 0;
   PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
+  PCLHIP_REQUIRE(ctx, out_stride >= 12 && out_stride % 4 == 0, "output stride must be a multiple of 4 and >= 12 bytes");
+  PCLHIP_REQUIRE(ctx, normals_offset == 0 || (normals_offset % 4 == 0 && normals_offset + 32 <= stride &&
+                                              normals_offset + 32 <= out_stride && normals_offset >= 12),
+                 "normals_offset: the 8 floats (normal[4], curvature, pad[3]) must fit both record layouts");
   PCLHIP_REQUIRE(ctx, n < 0x7FFFFFFFull, "cloud too large for int32 indices");
   PCLHIP_REQUIRE(ctx, leaf[0] > 0 && leaf[1] > 0 && leaf[2] > 0, "leaf size must be positive");
   if (n == 0) return PCLHIP_OK;
-  PCLHIP_REQUIRE(ctx, points && out_xyzw, "null buffer");
+  PCLHIP_REQUIRE(ctx, points && out, "null buffer");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   struct Guard {
@@ -153,12 +203,42 @@ extern "C" pclhip_status pclhip_voxelgrid(pclhip_ctx* ctx, const void* points, s
   if (st != PCLHIP_OK) return st;
   guard.p.push_back(owned);
 
+  // One scratch block for everything (the context keeps it between calls: no allocation on a warm context).
+  size_t sort_bytes = 0, scan_bytes = 0;
+  {
+    uint32_t* z = nullptr;
+    PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, z, z, z, z, size_t(n), 0, 32, s));
+    PCLHIP_CHECK_HIP(ctx, rocprim::inclusive_scan(nullptr, scan_bytes, z, z, size_t(n), rocprim::plus<uint32_t>(), s));
+  }
+  auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
+  const int nb = int(std::min<uint64_t>((n + 2047) / 2048, 1024));
+  const size_t o_part = 0;
+  const size_t o_k0 = o_part + align(size_t(nb) * 6 * sizeof(float));
+  const size_t o_k1 = o_k0 + align(n * sizeof(uint32_t));
+  const size_t o_v0 = o_k1 + align(n * sizeof(uint32_t));
+  const size_t o_v1 = o_v0 + align(n * sizeof(uint32_t));
+  const size_t o_head = o_v1 + align(n * sizeof(uint32_t));     // head, later keep
+  const size_t o_scan = o_head + align(n * sizeof(uint32_t));   // scan, later keep_scan
+  const size_t o_runs = o_scan + align(n * sizeof(uint32_t));   // run_start [nruns + 1]
+  const size_t o_cnt = o_runs + align((n + 1) * sizeof(uint32_t));
+  const size_t o_tmp = o_cnt + align(sizeof(unsigned int));
+  const size_t total_bytes = o_tmp + align(std::max(sort_bytes, scan_bytes));
+  st = ensure_scratch(ctx, total_bytes);
+  if (st != PCLHIP_OK) return st;
+  char* base = static_cast<char*>(ctx->scratch);
+  float* d_partial = reinterpret_cast<float*>(base + o_part);
+  uint32_t* k0 = reinterpret_cast<uint32_t*>(base + o_k0);
+  uint32_t* k1 = reinterpret_cast<uint32_t*>(base + o_k1);
+  uint32_t* v0 = reinterpret_cast<uint32_t*>(base + o_v0);
+  uint32_t* v1 = reinterpret_cast<uint32_t*>(base + o_v1);
+  uint32_t* head = reinterpret_cast<uint32_t*>(base + o_head);
+  uint32_t* scan = reinterpret_cast<uint32_t*>(base + o_scan);
+  uint32_t* run_start = reinterpret_cast<uint32_t*>(base + o_runs);
+  unsigned int* d_cnt = reinterpret_cast<unsigned int*>(base + o_cnt);
+  void* tmp = base + o_tmp;
+  size_t tmp_bytes = std::max(sort_bytes, scan_bytes);
+
   // --- bounding box (getMinMax3D) ---
-  int nb = int((n + 2047) / 2048);
-  if (nb > 1024) nb = 1024;
-  float* d_partial = nullptr;
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&d_partial, size_t(nb) * 6 * sizeof(float)));
-  guard.p.push_back(d_partial);
   hipLaunchKernelGGL(vg_minmax_kernel, dim3(nb), dim3(256), 0, s, dp, stride, n, has_z_limits, float(z_min), float(z_max),
                      d_partial);
   std::vector<float> hp(size_t(nb) * 6);
@@ -190,69 +270,53 @@ extern "C" pclhip_status pclhip_voxelgrid(pclhip_ctx* ctx, const void* points, s
   g.mul[1] = div_b[0];
   g.mul[2] = div_b[0] * div_b[1];
 
-  // --- keys + stable sort ---
-  uint32_t *k0, *k1, *v0, *v1, *head, *scan, *run_start, *keep, *keep_scan;
-  unsigned int* d_cnt;
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&k0, n * sizeof(uint32_t))); guard.p.push_back(k0);
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&k1, n * sizeof(uint32_t))); guard.p.push_back(k1);
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&v0, n * sizeof(uint32_t))); guard.p.push_back(v0);
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&v1, n * sizeof(uint32_t))); guard.p.push_back(v1);
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&d_cnt, sizeof(unsigned int))); guard.p.push_back(d_cnt);
+  // --- keys + stable sort.  Voxel ids are < div_b[0] * div_b[1] * div_b[2]: only that many key bits need sorting;
+  // rejected points carry the all-ones key, kept apart by ONE extra bit above the ids.
+  int id_bits = 1;
+  while (id_bits < 32 && (int64_t(1) << id_bits) < int64_t(div_b[0]) * div_b[1] * div_b[2]) ++id_bits;
+  const int sort_bits = id_bits < 32 ? id_bits + 1 : 32;
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
   hipLaunchKernelGGL(vg_key_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, dp, stride, n, g, has_z_limits, z_min,
-                     z_max, k0, v0, d_cnt);
-  size_t temp_bytes = 0;
-  PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, k0, k1, v0, v1, size_t(n), 0, 32, s));
-  void* tmp = nullptr;
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&tmp, temp_bytes > 0 ? temp_bytes : 16)); guard.p.push_back(tmp);
-  PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, temp_bytes, k0, k1, v0, v1, size_t(n), 0, 32, s));
+                     z_max, k0, v0, d_cnt, sort_bits);
+  PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, size_t(n), 0, sort_bits, s));
   unsigned int nv = 0;
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nv, d_cnt, sizeof nv, hipMemcpyDeviceToHost, s));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
   if (nv == 0) return PCLHIP_OK;
 
   // --- runs ---
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&head, size_t(nv) * sizeof(uint32_t))); guard.p.push_back(head);
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&scan, size_t(nv) * sizeof(uint32_t))); guard.p.push_back(scan);
   hipLaunchKernelGGL(vg_head_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, k1, nv, head);
-  size_t scan_bytes = 0;
-  PCLHIP_CHECK_HIP(ctx, rocprim::inclusive_scan(nullptr, scan_bytes, head, scan, size_t(nv), rocprim::plus<uint32_t>(), s));
-  void* stmp = nullptr;
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&stmp, scan_bytes > 0 ? scan_bytes : 16)); guard.p.push_back(stmp);
-  PCLHIP_CHECK_HIP(ctx, rocprim::inclusive_scan(stmp, scan_bytes, head, scan, size_t(nv), rocprim::plus<uint32_t>(), s));
+  PCLHIP_CHECK_HIP(ctx, rocprim::inclusive_scan(tmp, tmp_bytes, head, scan, size_t(nv), rocprim::plus<uint32_t>(), s));
   uint32_t nruns = 0;
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nruns, scan + (nv - 1), sizeof nruns, hipMemcpyDeviceToHost, s));
-  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&run_start, size_t(nruns + 1) * sizeof(uint32_t))); guard.p.push_back(run_start);
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&keep, size_t(nruns) * sizeof(uint32_t))); guard.p.push_back(keep);
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&keep_scan, size_t(nruns) * sizeof(uint32_t))); guard.p.push_back(keep_scan);
   hipLaunchKernelGGL(vg_runstart_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, head, scan, nv, run_start);
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  uint32_t* keep = head;        // head / scan are consumed: reuse them for the per-run arrays (nruns <= nv)
+  uint32_t* keep_scan = scan;
   hipLaunchKernelGGL(vg_keep_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, run_start, nruns, min_points_per_voxel,
                      keep);
-  size_t scan2_bytes = 0;
-  PCLHIP_CHECK_HIP(ctx,
-                   rocprim::inclusive_scan(nullptr, scan2_bytes, keep, keep_scan, size_t(nruns), rocprim::plus<uint32_t>(), s));
-  void* stmp2 = nullptr;
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&stmp2, scan2_bytes > 0 ? scan2_bytes : 16)); guard.p.push_back(stmp2);
-  PCLHIP_CHECK_HIP(ctx,
-                   rocprim::inclusive_scan(stmp2, scan2_bytes, keep, keep_scan, size_t(nruns), rocprim::plus<uint32_t>(), s));
-  uint32_t total = 0;
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&total, keep_scan + (nruns - 1), sizeof total, hipMemcpyDeviceToHost, s));
-  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  PCLHIP_CHECK_HIP(ctx, rocprim::inclusive_scan(tmp, tmp_bytes, keep, keep_scan, size_t(nruns), rocprim::plus<uint32_t>(), s));
+  uint32_t total = nruns;
+  if (min_points_per_voxel > 1) {  // otherwise every run is kept: no need to read the count back
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&total, keep_scan + (nruns - 1), sizeof total, hipMemcpyDeviceToHost, s));
+    PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  }
 
   // --- centroids ---
-  float4* d_out = static_cast<float4*>(out_xyzw);
-  const bool out_dev = is_device_pointer(out_xyzw);
+  void* d_out = out;
+  const bool out_dev = is_device_pointer(out);
   if (!out_dev) {
-    PCLHIP_CHECK_HIP(ctx, hipMalloc(&d_out, size_t(total > 0 ? total : 1) * sizeof(float4)));
+    PCLHIP_CHECK_HIP(ctx, hipMalloc(&d_out, size_t(total > 0 ? total : 1) * out_stride));
     guard.p.push_back(d_out);
   }
   if (total > 0) {
+    if (out_stride != 16 && (normals_offset == 0 || out_stride != normals_offset + 32))
+      PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_out, 0, size_t(total) * out_stride, s));  // fields this filter does not fill
     hipLaunchKernelGGL(vg_centroid_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, dp, stride, v1, run_start, keep,
-                       keep_scan, nruns, d_out);
+                       keep_scan, nruns, d_out, out_stride, normals_offset, downsample_all_data ? 1 : 0);
     PCLHIP_CHECK_HIP(ctx, hipGetLastError());
     if (!out_dev)
-      PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out_xyzw, d_out, size_t(total) * sizeof(float4), hipMemcpyDeviceToHost, s));
+      PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, d_out, size_t(total) * out_stride, hipMemcpyDeviceToHost, s));
   }
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
   *out_n = total;

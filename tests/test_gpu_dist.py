@@ -143,3 +143,29 @@ def test_native_comm_and_region_in_the_device_loop():
         steps = icp.runSteps(4)
         res.append((icp.getFinalTransformation().copy(), icp.nr_iterations_, [s["num_correspondences"] for s in steps]))
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1:] == res[1][1:]
+
+
+def test_sharded_bench_path_single_slab_runs_whole_alignments():
+    # what bench.py --config 5 does on one GPU: one slab (all of space), the source routed through the region
+    # test, the device-driven loop -- the iterations must be those of the plain registration
+    import pcl_amd
+    from pcl_amd import synth
+    from pcl_amd.dist import ShardedTarget
+    ctx = pcl_amd.Context(0)
+    tgt, src, _ = synth.icp_pair(200_000)
+    st = ShardedTarget(ctx, tgt, 0, 1, 0.1, k_normals=8, viewpoint=(0, 0, 10))
+    assert st.tree.size() == len(tgt) and np.all(np.isinf(st.region))
+    res = []
+    for sharded in (True, False):
+        icp = pcl_amd.IterativeClosestPointWithNormals(ctx)
+        icp.setSearchMethodTarget(st.tree, True)
+        icp.setInputSource(src)
+        icp.setMaximumIterations(20)
+        icp.setMaxCorrespondenceDistance(0.1)
+        icp.setTransformationEpsilon(1e-10)
+        if sharded:
+            icp.setRegion(st.region)
+        steps = icp.runSteps(8)
+        res.append([(s["iteration"], s["state"], s["num_correspondences"], s["alignment_ended"]) for s in steps])
+    assert res[0] == res[1]
+    assert [r[0] for r in res[0][:3]] == [1, 2, 3] and res[0][0][2] == len(src)

@@ -574,6 +574,58 @@ def test_voxelgrid_bunny_golden(gpu, orc, bunny, golden):
     assert np.allclose(out[-1, :3], g["last_z"], atol=g["tol"])
 
 
+def test_voxelgrid_pointnormal_and_downsample_all_data(gpu, orc):
+    # VoxelGrid<PointNormal> (test/filters/test_filters.cpp:598-687 runs it on bun0 with normals):
+    # setDownsampleAllData(true) -> CentroidPoint accumulators (accumulators.hpp:68-127: xyz and curvature
+    # averaged, the normal = normalised sum); (false) -> only xyz, the rest zero (voxel_grid.hpp:790-799)
+    import os
+    import pcl_amd
+    root = os.path.dirname(os.path.abspath(__file__))
+    cloud, dense = pcl_amd.loadPCDFile(os.path.join(root, "golden", "pcd", "bun0.pcd"), with_normals=True)
+    assert cloud.shape == (397, 12) and dense
+    want_xyz, ids = orc.voxelgrid(cloud, 0.02)
+    assert len(want_xyz) == 103
+    # per-voxel float32 sums in ascending input order (the order the device and the oracle use)
+    leaf_inv = np.float32(1.0) / np.float32(0.02)
+    ijk = np.floor(cloud[:, :3] * leaf_inv).astype(np.int64)
+    ijk -= np.floor(cloud[:, :3].min(0) * leaf_inv).astype(np.int64)
+    div = ijk.max(0) + 1
+    key = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
+    for all_data in (True, False):
+        vg = pcl_amd.VoxelGrid(gpu)
+        vg.setInputCloud(cloud)
+        vg.setLeafSize(0.02)
+        vg.setDownsampleAllData(all_data)
+        assert vg.getDownsampleAllData() == all_data
+        out = vg.filter()
+        assert out.shape == (103, 12)
+        assert np.array_equal(out[:, :4], want_xyz)                  # the coordinates do not depend on the option
+        if not all_data:
+            assert not out[:, 4:].any()
+            continue
+        for row, k in enumerate(np.unique(key)):
+            pts = cloud[key == k]
+            nsum = np.zeros(3, np.float32)
+            csum = np.float32(0)
+            for p in pts:
+                nsum = (nsum + p[4:7]).astype(np.float32)
+                csum = np.float32(csum + p[8])
+            nrm = nsum / np.float32(np.sqrt(np.float32(nsum[0] * nsum[0] + nsum[1] * nsum[1]) + np.float32(nsum[2] * nsum[2])))
+            assert np.allclose(out[row, 4:7], nrm, rtol=0, atol=2e-7), row
+            assert abs(np.linalg.norm(out[row, 4:7].astype(np.float64)) - 1.0) < 1e-6
+            assert out[row, 8] == np.float32(csum / np.float32(len(pts))) and out[row, 7] == 0 and not out[row, 9:].any()
+    # device-resident PointNormal clouds take the same path
+    import torch
+    vg = pcl_amd.VoxelGrid(gpu)
+    vg.setInputCloud(torch.from_numpy(cloud).cuda())
+    vg.setLeafSize(0.02)
+    dev = vg.filter().cpu().numpy()
+    vg2 = pcl_amd.VoxelGrid(gpu)
+    vg2.setInputCloud(cloud)
+    vg2.setLeafSize(0.02)
+    assert np.array_equal(dev, vg2.filter())
+
+
 def test_voxelgrid_synthetic_bit_exact(gpu, orc):
     import pcl_amd
     tgt, _, _ = pcl_amd.synth.icp_pair(300_000)
