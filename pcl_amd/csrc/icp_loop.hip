@@ -250,9 +250,19 @@ pclhip_status arm_loop(pclhip_icp* icp, const pclhip_icp_params* p, const float*
   c.step = 0;
   c.log_capacity = icp->steps_capacity;
   fill_criteria(p, c.crit);
-  c.st.prev_mse = icp->prev_mse;  // the criteria's memory persists across align() calls, as in the reference
-  c.st.iterations_similar_transforms = icp->iterations_similar_transforms;
-  c.st.convergence_state = icp->convergence_state;
+  if (auto_restart) {
+    // A stream of steps behaves like a fresh registration object aligned again and again: the memory starts
+    // empty and persists from one alignment of the stream to the next, but not across calls -- a call boundary
+    // may cut an alignment short, and resuming with "previous MSE = this very iteration's MSE" would end every
+    // following alignment at its first iteration (ABS_MSE).
+    c.st.prev_mse = DBL_MAX;
+    c.st.iterations_similar_transforms = 0;
+    c.st.convergence_state = cf::NOT_CONVERGED;
+  } else {
+    c.st.prev_mse = icp->prev_mse;  // the criteria's memory persists across align() calls, as in the reference
+    c.st.iterations_similar_transforms = icp->iterations_similar_transforms;
+    c.st.convergence_state = icp->convergence_state;
+  }
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(icp->ctl, icp->ctl_host, sizeof c, hipMemcpyHostToDevice, ctx->stream));
   return PCLHIP_OK;
 }
@@ -428,10 +438,7 @@ extern "C" pclhip_status pclhip_icp_run_steps(pclhip_icp* icp, const pclhip_icp_
     o.kernels_ms = t.kernels_ms;
     o.step_ms = t.step_ms;
     std::memcpy(o.final_transformation, r.final_T, sizeof r.final_T);
-    icp->prev_mse = r.prev_mse;
-    icp->iterations_similar_transforms = r.similar;
-    icp->convergence_state = r.convergence_state;
-    icp->last_kernel_ms = t.kernels_ms;
+    icp->last_kernel_ms = t.kernels_ms;  // (the criteria memory of align() is left alone, see arm_loop)
     icp->last_search_ms = t.search_ms;
     return true;
   });

@@ -1012,23 +1012,43 @@ __global__ __launch_bounds__(BLOCK) void estimate_pairs_kernel(const float4* __r
   pa.store_block(red_s, partials);
 }
 
-// partials[nblocks][NS] -> sums[NS]; fixed summation order (stride-32 lanes, then 32 partial sums in
-// order) so the result does not depend on scheduling
+// partials[nblocks][NS] -> sums[NS]; fixed summation order (row r of 32 takes every 32nd block in four
+// interleaved chains, then the 32 rows are added in order), so the result does not depend on scheduling.
+// With `solve_ctl` the same launch also closes the iteration (icp_solve_step below): no record to exchange,
+// one launch less.
+__device__ void icp_solve_step(IcpControl* __restrict__ ctl, const double* __restrict__ sums,
+                               IcpStepRecord* __restrict__ log);
+
 __global__ __launch_bounds__(1024) void icp_finalize_kernel(const double* __restrict__ partials, int nblocks,
                                                             double* __restrict__ sums,
-                                                            const IcpControl* __restrict__ ctl = nullptr) {
+                                                            const IcpControl* __restrict__ ctl = nullptr,
+                                                            IcpControl* __restrict__ solve_ctl = nullptr,
+                                                            IcpStepRecord* __restrict__ log = nullptr) {
   if (ctl != nullptr && ctl->stop != 0) return;
   __shared__ double red[32][NS + 1];
+  __shared__ double total[NS];
   const int t = threadIdx.x % NS, r = threadIdx.x / NS;  // NS == 32
-  double s = 0.0;
-  for (int b = r; b < nblocks; b += 32) s += partials[size_t(b) * NS + t];
-  red[r][t] = s;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;         // four independent chains: the loads overlap
+  int b = r;
+  for (; b + 96 < nblocks; b += 128) {
+    s0 += partials[size_t(b) * NS + t];
+    s1 += partials[size_t(b + 32) * NS + t];
+    s2 += partials[size_t(b + 64) * NS + t];
+    s3 += partials[size_t(b + 96) * NS + t];
+  }
+  for (; b < nblocks; b += 32) s0 += partials[size_t(b) * NS + t];
+  red[r][t] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (r == 0) {
     double a = 0.0;
 #pragma unroll
     for (int i = 0; i < 32; ++i) a += red[i][t];
     sums[t] = a;
+    total[t] = a;
+  }
+  if (solve_ctl != nullptr) {
+    __syncthreads();
+    if (threadIdx.x == 0) icp_solve_step(solve_ctl, total, log);
   }
 }
 
@@ -1141,6 +1161,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     return (e && atoi(e) == 1) ? 0 : 1;  // default: the two-kernel variant (measured faster)
   }();
   const bool filters = icp->reciprocal || !icp->rejectors.empty();
+  bool solved = false;
   if (icp->n > 0 && (device_loop || unfused || filters || mode == PCLHIP_ICP_SYMMETRIC || icp->region.on)) {
     auto ks = icp_search_kernel<4, 1, true>;
     const int gs = resident_blocks(ctx, ks, ngroups);
@@ -1167,7 +1188,9 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     (void)hipEventRecord(device_loop ? ev[2] : icp->ev1, s);
     // (Folding this reduction into the accumulate kernel -- last block done -- was tried: the 2048 device-scope
     // atomics on one counter cost ~100 us across the 8 XCDs, five times this 20 us launch.)
-    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, ga, icp->sums_dev, ctl);
+    solved = device_loop && !icp_is_sharded(icp);  // no record to exchange: the reduction launch closes the iteration
+    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, ga, icp->sums_dev, ctl,
+                       solved ? icp->ctl : static_cast<IcpControl*>(nullptr), icp->steps);
   } else if (icp->n > 0) {
     int grid = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? resident_blocks(ctx, k_plane, ngroups)
                                                    : resident_blocks(ctx, k_point, ngroups);
@@ -1179,7 +1202,8 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
                        use_max ? 1 : 0, icp->match_pos, icp->match, icp->match_d2, icp->partials, ctx->stats);
     (void)hipEventRecord(icp->ev1, s);
     hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, grid, icp->sums_dev,
-                       static_cast<const IcpControl*>(nullptr));
+                       static_cast<const IcpControl*>(nullptr), static_cast<IcpControl*>(nullptr),
+                       static_cast<IcpStepRecord*>(nullptr));
   } else {
     if (device_loop) {
       (void)hipEventRecord(ev[0], s);
@@ -1193,7 +1217,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   pclhip_status st = allreduce_record(icp);
   if (st != PCLHIP_OK) return st;
   if (device_loop) {
-    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, s, icp->ctl, icp->sums_dev, icp->steps);
+    if (!solved) hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, s, icp->ctl, icp->sums_dev, icp->steps);
     (void)hipEventRecord(ev[3], s);
     PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   }
@@ -1296,7 +1320,9 @@ pclhip_status launch_estimate_pairs(pclhip_ctx* ctx, int mode, const float4* src
   else
     hipLaunchKernelGGL(estimate_pairs_kernel<PCLHIP_ICP_POINT_TO_POINT>, dim3(grid), dim3(BLOCK), 0, s, src, src_nrm, tgt,
                        tgt_nrm, weights, n, enforce ? 1 : 0, dev);
-  hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, dev, grid, dev + size_t(grid) * NS);
+  hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, dev, grid, dev + size_t(grid) * NS,
+                     static_cast<const IcpControl*>(nullptr), static_cast<IcpControl*>(nullptr),
+                     static_cast<IcpStepRecord*>(nullptr));
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(sums, dev + size_t(grid) * NS, NS * sizeof(double), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);

@@ -441,27 +441,22 @@ struct TopKReg {
       }
     }
   }
-  // lane-sparse evaluation from the transposed LDS staging buffer (see traverse(): SPARSE): the lane's own
-  // leaf.  Every lane has a different leaf here, so "does ANY lane want candidate j" is nearly always yes and a
-  // slot-by-slot walk would push all 16 candidates of all lanes through the insertion network (1100+ VALU
-  // per round -- it was 80 % of the normals kernel).  Instead every lane notes which of ITS candidates are not
-  // beyond its current k-th distance (one bit each), and the wave loops while some lane has a bit left, each
-  // lane inserting its own lowest candidate: the network runs max-over-lanes-of-qualifiers times (about 6),
-  // not 16.  The candidate is re-read from LDS by index and its distance recomputed with the same operations
-  // (same bits); a candidate that stopped qualifying meanwhile falls through the network unchanged.
+  // lane-sparse evaluation from the transposed LDS staging buffer (see traverse(): SPARSE): the lane's
+  // own leaf; a candidate goes through the insertion network only if some active lane still wants it.
+  // (Per-lane qualifier masks + an extraction loop -- each lane inserting only ITS qualifying candidates -- were
+  // measured: the k-th distance is loose for most of the traversal, the loop ran ~10 times per round instead of
+  // the hoped-for 6, and the extra registers cost a wave per SIMD: 6.2 -> 8.1 ms for k = 8 normals of 10M points.)
   static constexpr bool LANE_SPARSE = true;
   static constexpr bool NEEDS_W = true;
   __device__ __forceinline__ void leaf_lane(const float* buf, uint32_t slot, uint32_t leaf_id, const float* qx,
                                             const float* qy, const float* qz) {
-    const float4* s = reinterpret_cast<const float4*>(buf) + slot;  // chunk c at s[c * 16]
-    const uint32_t base = leaf_id * LEAF;
-    uint32_t want = 0;
     if (leaf_id != NO_INDEX) {
+      const float4* s = reinterpret_cast<const float4*>(buf) + slot;  // chunk c at s[c * 16]
+      const uint32_t base = leaf_id * LEAF;
       const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
-      const float wd = key_dist(keys[K - 1]);
 #pragma unroll
       for (int c4 = 0; c4 < LEAF / 4; ++c4) {
-        const float4 X = s[c4 * 16], Y = s[(4 + c4) * 16], Z = s[(8 + c4) * 16];
+        const float4 X = s[c4 * 16], Y = s[(4 + c4) * 16], Z = s[(8 + c4) * 16], W = s[(12 + c4) * 16];
         v2f r0, r1;
         {
           const v2f dx = qx2 - v2f{X.x, X.y}, dy = qy2 - v2f{Y.x, Y.y}, dz = qz2 - v2f{Z.x, Z.y};
@@ -475,25 +470,15 @@ struct TopKReg {
           r1 = r1 + dy * dy;
           r1 = r1 + dz * dz;
         }
-        want |= (r0.x <= wd ? 1u : 0u) << (4 * c4);
-        want |= (r0.y <= wd ? 1u : 0u) << (4 * c4 + 1);
-        want |= (r1.x <= wd ? 1u : 0u) << (4 * c4 + 2);
-        want |= (r1.y <= wd ? 1u : 0u) << (4 * c4 + 3);
+        const float ds[4] = {r0.x, r0.y, r1.x, r1.y}, ws[4] = {W.x, W.y, W.z, W.w};
+        const float m = __builtin_fminf(__builtin_fminf(ds[0], ds[1]), __builtin_fminf(ds[2], ds[3]));
+        if (__builtin_amdgcn_ballot_w64(m <= key_dist(keys[K - 1])) == 0) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (__builtin_amdgcn_ballot_w64(ds[j] <= key_dist(keys[K - 1])) != 0)
+            insert(make_key(ds[j], __float_as_uint(ws[j])), base + uint32_t(4 * c4 + j));
+        }
       }
-    }
-    const float* sf = reinterpret_cast<const float*>(s);  // element e of chunk c at sf[c * 64 + e]
-    while (__builtin_amdgcn_ballot_w64(want != 0) != 0) {
-      uint64_t k = KEY_NONE;
-      uint32_t p = NO_INDEX;
-      if (want != 0) {
-        const uint32_t j = uint32_t(__builtin_ctz(want));
-        want &= want - 1u;
-        const uint32_t o = (j >> 2) * 64u + (j & 3u);
-        const float cx = sf[o], cy = sf[4 * 64 + o], cz = sf[8 * 64 + o], cw = sf[12 * 64 + o];
-        k = make_key(l2_simple(qx[0], qy[0], qz[0], cx, cy, cz), __float_as_uint(cw));
-        p = base + j;
-      }
-      insert(k, p);  // KEY_NONE never enters (it is not below any key)
     }
   }
 };

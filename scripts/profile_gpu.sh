@@ -29,3 +29,8 @@ tcc) run pmc_tcc --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum ;;
 esac
 done
 python $REPO/scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1; cat $OUT/summary.txt
+# HBM bytes per launch from the FETCH/WRITE passes, stamped with the commit (bench.py reads profiles/pmc_traffic.json;
+# copy $OUT/pmc_traffic.json there after a run on the GPU box)
+case "$PASSES" in *fetch*write*|*write*fetch*)
+  python $REPO/scripts/make_pmc_traffic.py $OUT "${GRAFT_COMMIT:-$(git -C $REPO rev-parse --short HEAD 2>/dev/null || echo unknown)}" "bench.py $ARGS" ;;
+esac

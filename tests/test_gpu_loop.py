@@ -46,21 +46,30 @@ def test_run_steps_is_align_repeated(gpu, mode):
     T = icp.getFinalTransformation()
     state = icp.getConvergenceState()
     assert k >= 3
-    # the criteria keep their memory across align() calls (as in the reference), so the second alignment
-    # is the steady reference for the stream of steps
+    # the criteria keep their memory across align() calls (as in the reference): a second align() on the same
+    # object is the reference for the SECOND alignment of a stream, which starts like a fresh object
     icp.align()
     k2, T2, state2 = icp.nr_iterations_, icp.getFinalTransformation(), icp.getConvergenceState()
-    steps = icp.runSteps(2 * k2 + 2)
-    assert len(steps) == 2 * k2 + 2
-    assert [s["iteration"] for s in steps[:k2]] == list(range(1, k2 + 1))
-    assert [s["alignment_ended"] for s in steps[:k2]] == [False] * (k2 - 1) + [True]
-    assert steps[k2 - 1]["state"] == state2 and steps[k2 - 1]["converged"]
-    assert np.array_equal(steps[k2 - 1]["final_transformation"], T2)       # same kernels, same bits
-    assert steps[k2]["iteration"] == 1 and not steps[k2]["alignment_ended"]   # the next alignment started
-    assert np.array_equal(steps[2 * k2 - 1]["final_transformation"], T2)
+    steps = icp.runSteps(k + k2 + 2)
+    assert len(steps) == k + k2 + 2
+    assert [s["iteration"] for s in steps[:k]] == list(range(1, k + 1))
+    assert [s["alignment_ended"] for s in steps[:k]] == [False] * (k - 1) + [True]
+    assert steps[k - 1]["state"] == state and steps[k - 1]["converged"]
+    assert np.array_equal(steps[k - 1]["final_transformation"], T)          # same kernels, same bits
+    assert steps[k]["iteration"] == 1 and not steps[k]["alignment_ended"]   # the next alignment started
+    assert [s["iteration"] for s in steps[k:k + k2]] == list(range(1, k2 + 1))
+    assert steps[k + k2 - 1]["state"] == state2 and np.array_equal(steps[k + k2 - 1]["final_transformation"], T2)
     assert all(s["num_correspondences"] == len(src) for s in steps)
     assert all(s["search_ms"] > 0 and s["step_ms"] >= s["kernels_ms"] >= s["search_ms"] for s in steps)
     assert np.abs(T - T2).max() < 1e-5 and state != "NOT_CONVERGED" and abs(k2 - k) <= 1
+    # a call boundary that cuts an alignment short must not leak into the next stream: every stream starts alike
+    a = icp.runSteps(k + 1)
+    b = icp.runSteps(k + 1)
+    assert [(s["iteration"], s["state"]) for s in a] == [(s["iteration"], s["state"]) for s in b]
+    assert [s["iteration"] for s in a] == list(range(1, k + 1)) + [1]
+    # ... and the align() memory is untouched by the streams: a third align() continues from the second
+    icp.align()
+    assert icp.nr_iterations_ == k2 and np.array_equal(icp.getFinalTransformation(), T2)
 
 
 def test_device_loop_matches_host_loop_twin(gpu, tmp_path):
