@@ -103,7 +103,6 @@ struct IcpStepRecord {
   double prev_mse;        // criteria memory after this iteration
   float Tk[16];           // transformation_ of this iteration
   float final_T[16];      // final_transformation_ after it
-  double sums[PCLHIP_ICP_NSUMS];
 };
 
 }  // namespace pclhip

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
                                                         unsigned long long* gstats) {
   __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
+  __shared__ uint32_t nbr_s[WAVES_PER_BLOCK][(K == 8 ? K : 1) * WAVE];  // per-lane neighbour lists of the collection pass
   load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t ngroups = (ix.n + WAVE - 1) / WAVE;
@@ -241,9 +242,62 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
     if (valid) p = ix.pts[i];
     TopKReg<K> pol;
     pol.init(KEY_NONE);
-    {
-      const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
-      const bool vv[1] = {valid};
+    const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
+    const bool vv[1] = {valid};
+    if constexpr (K == 8) {
+      // Two passes instead of one top-K pass with identities.  (1) the k smallest DISTANCES (TopKDist: one
+      // v_med3_f32 per slot and candidate); (2) a tight second traversal that collects the positions of the
+      // candidates up to the k-th distance (CollectLE) -- it starts at the group's own level-2 node whenever the
+      // grown query box allows (start-level shortcut).  The <= k positions are then put into the reference's
+      // (distance, index) order by a 19-comparator network.  Exact distance ties at the k-th distance (more than
+      // k candidates collected) fall back to the one-pass exact policy for that lane.
+      const int wave_id = threadIdx.x / WAVE;
+      TopKDist<K> dist;
+      dist.init();
+      traverse<TopKDist<K>, true>(ix, qx, qy, qz, vv, dist, wl_s[wave_id], topbox_s, ts);
+      CollectLE<K> col;
+      col.thr = (k >= 1 && k <= K) ? dist.d[0] : 0.0f;
+#pragma unroll
+      for (int c = 1; c < K; ++c) col.thr = (c < k) ? dist.d[c] : col.thr;  // d[k - 1]
+      col.cnt = 0;
+      col.over = false;
+      col.list = nbr_s[wave_id] + lane;
+      const uint32_t own_leaf = uniform_u32((g * WAVE) / LEAF);
+      traverse<CollectLE<K>, true>(ix, qx, qy, qz, vv, col, wl_s[wave_id], topbox_s, ts, own_leaf);
+      __builtin_amdgcn_wave_barrier();
+      const bool redo[1] = {valid && col.over};
+      if (valid && !col.over) {
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+          if (uint32_t(c) < col.cnt) {
+            const uint32_t pc = col.list[c * WAVE];
+            const float4 t = ix.pts[pc];
+            pol.keys[c] = make_key(l2_simple(p.x, p.y, p.z, t.x, t.y, t.z), __float_as_uint(t.w));
+            pol.pos[c] = pc;
+          }
+        }
+        // Batcher's odd-even merge sort for 8 keys (19 comparators): ascending (distance, index), empty slots last
+        const auto cx = [&](int a, int b) {
+          const bool sw = pol.keys[b] < pol.keys[a];
+          const uint64_t ka = pol.keys[a], kb = pol.keys[b];
+          const uint32_t pa = pol.pos[a], pb = pol.pos[b];
+          pol.keys[a] = sw ? kb : ka; pol.keys[b] = sw ? ka : kb;
+          pol.pos[a] = sw ? pb : pa; pol.pos[b] = sw ? pa : pb;
+        };
+        cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7);
+        cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7);
+        cx(1, 2); cx(5, 6);
+        cx(0, 4); cx(1, 5); cx(2, 6); cx(3, 7);
+        cx(2, 4); cx(3, 5);
+        cx(1, 2); cx(3, 4); cx(5, 6);
+      }
+      if (__builtin_amdgcn_ballot_w64(redo[0]) != 0) {  // ties at the k-th distance: the exact one-pass policy
+        TopKReg<K> ex;
+        ex.init(KEY_NONE);
+        traverse<TopKReg<K>, true>(ix, qx, qy, qz, redo, ex, wl_s[wave_id], topbox_s, ts);
+        if (redo[0]) pol = ex;
+      }
+    } else {
       traverse<TopKReg<K>, true>(ix, qx, qy, qz, vv, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
     }
     if (valid) {
@@ -1087,8 +1141,6 @@ __device__ void icp_solve_step(IcpControl* __restrict__ ctl, const double* __res
     r.Tk[i] = c.Tk[i];
     r.final_T[i] = c.final_T[i];
   }
-#pragma unroll
-  for (int i = 0; i < NS; ++i) r.sums[i] = sums[i];
   if (ended) {
     if (c.auto_restart) {  // the next launch starts the next alignment from the input cloud and the guess
       c.restart = 1;

@@ -483,6 +483,108 @@ struct TopKReg {
   }
 };
 
+// The k smallest DISTANCES only, sorted ascending.  Without identities to carry, inserting into a sorted run is
+// one v_med3_f32 per slot (new d[j] = median(d[j-1], x, d[j])) instead of the compare + select chains of 64-bit
+// (distance, index) keys with their positions: 8 instructions per candidate for k = 8 where TopKReg needs ~72.
+// Used as the first of two passes (see normals_kernel): it yields the exact k-th distance; CollectLE then
+// gathers the candidates up to that distance.
+template <int K>
+struct TopKDist {
+  float d[K];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int i = 0; i < K; ++i) d[i] = __builtin_inff();
+  }
+  static constexpr int QPL = 1;
+  static constexpr bool LANE_SPARSE = true;
+  static constexpr bool NEEDS_W = false;
+  __device__ __forceinline__ float worst(int) const { return d[K - 1]; }
+  __device__ __forceinline__ void insert(float x) {
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) d[j] = __builtin_amdgcn_fmed3f(d[j - 1], x, d[j]);
+    d[0] = __builtin_fminf(d[0], x);
+  }
+  __device__ __forceinline__ void leaf_lane(const float* buf, uint32_t slot, uint32_t leaf_id, const float* qx,
+                                            const float* qy, const float* qz) {
+    if (leaf_id != NO_INDEX) {
+      const float4* s = reinterpret_cast<const float4*>(buf) + slot;  // chunk c at s[c * 16]
+      const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
+#pragma unroll
+      for (int c4 = 0; c4 < LEAF / 4; ++c4) {
+        const float4 X = s[c4 * 16], Y = s[(4 + c4) * 16], Z = s[(8 + c4) * 16];
+        v2f r0, r1;
+        {
+          const v2f dx = qx2 - v2f{X.x, X.y}, dy = qy2 - v2f{Y.x, Y.y}, dz = qz2 - v2f{Z.x, Z.y};
+          r0 = dx * dx;
+          r0 = r0 + dy * dy;
+          r0 = r0 + dz * dz;
+        }
+        {
+          const v2f dx = qx2 - v2f{X.z, X.w}, dy = qy2 - v2f{Y.z, Y.w}, dz = qz2 - v2f{Z.z, Z.w};
+          r1 = dx * dx;
+          r1 = r1 + dy * dy;
+          r1 = r1 + dz * dz;
+        }
+        insert(r0.x);
+        insert(r0.y);
+        insert(r1.x);
+        insert(r1.y);
+      }
+    }
+  }
+};
+
+// Second pass: sorted positions of every candidate whose distance is <= thr (finite), appended to a per-lane
+// list in LDS (entry c of this lane at list[c * 64]); more than K of them (exact distance ties at the k-th
+// distance) raise `over`, and the caller lets the exact (distance, index) policy decide for that lane.
+template <int K>
+struct CollectLE {
+  float thr;
+  uint32_t cnt;
+  bool over;
+  uint32_t* list;  // LDS, this lane's column
+  static constexpr int QPL = 1;
+  static constexpr bool LANE_SPARSE = true;
+  static constexpr bool NEEDS_W = false;
+  __device__ __forceinline__ float worst(int) const { return thr; }
+  __device__ __forceinline__ void take(float d, uint32_t p) {
+    if (d <= thr && d < __builtin_inff()) {
+      if (cnt < uint32_t(K)) list[cnt * WAVE] = p;
+      else over = true;
+      ++cnt;
+    }
+  }
+  __device__ __forceinline__ void leaf_lane(const float* buf, uint32_t slot, uint32_t leaf_id, const float* qx,
+                                            const float* qy, const float* qz) {
+    if (leaf_id != NO_INDEX) {
+      const float4* s = reinterpret_cast<const float4*>(buf) + slot;
+      const uint32_t base = leaf_id * LEAF;
+      const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
+#pragma unroll
+      for (int c4 = 0; c4 < LEAF / 4; ++c4) {
+        const float4 X = s[c4 * 16], Y = s[(4 + c4) * 16], Z = s[(8 + c4) * 16];
+        v2f r0, r1;
+        {
+          const v2f dx = qx2 - v2f{X.x, X.y}, dy = qy2 - v2f{Y.x, Y.y}, dz = qz2 - v2f{Z.x, Z.y};
+          r0 = dx * dx;
+          r0 = r0 + dy * dy;
+          r0 = r0 + dz * dz;
+        }
+        {
+          const v2f dx = qx2 - v2f{X.z, X.w}, dy = qy2 - v2f{Y.z, Y.w}, dz = qz2 - v2f{Z.z, Z.w};
+          r1 = dx * dx;
+          r1 = r1 + dy * dy;
+          r1 = r1 + dz * dz;
+        }
+        take(r0.x, base + uint32_t(4 * c4));
+        take(r0.y, base + uint32_t(4 * c4 + 1));
+        take(r1.x, base + uint32_t(4 * c4 + 2));
+        take(r1.y, base + uint32_t(4 * c4 + 3));
+      }
+    }
+  }
+};
+
 // top-k for arbitrary k in a per-lane binary max-heap in global memory, layout heap[slot*nq + q]
 // (slot-major so that lanes touching the same slot coalesce).
 struct TopKHeap {
