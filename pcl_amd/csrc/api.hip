@@ -67,6 +67,69 @@ pclhip_status ensure_scratch(pclhip_ctx* ctx, size_t bytes) {
   return PCLHIP_OK;
 }
 
+// ---- context-cached device memory -----------------------------------------------------------------
+hipError_t dev_malloc(pclhip_ctx* ctx, void** p, size_t bytes) {
+  *p = nullptr;
+  if (bytes == 0) bytes = 16;
+  if (ctx == nullptr) return hipMalloc(p, bytes);
+  {
+    std::lock_guard<std::mutex> lock(ctx->cache_mutex);
+    // best fit among the free blocks, but never one more than twice the size asked for
+    size_t best = ctx->cache.size();
+    for (size_t i = 0; i < ctx->cache.size(); ++i) {
+      const size_t b = ctx->cache[i].second;
+      if (b >= bytes && b <= 2 * bytes + (size_t(1) << 20) && (best == ctx->cache.size() || b < ctx->cache[best].second)) best = i;
+    }
+    if (best != ctx->cache.size()) {
+      *p = ctx->cache[best].first;
+      ctx->live[*p] = ctx->cache[best].second;
+      ctx->cached_bytes -= ctx->cache[best].second;
+      ctx->cache.erase(ctx->cache.begin() + long(best));
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {  // out of memory: give the cached blocks back and try once more
+    (void)hipGetLastError();
+    dev_cache_release(ctx);
+    e = hipMalloc(p, bytes);
+  }
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lock(ctx->cache_mutex);
+    ctx->live[*p] = bytes;
+  }
+  return e;
+}
+
+void dev_free(pclhip_ctx* ctx, void* p) {
+  if (p == nullptr) return;
+  if (ctx != nullptr) {
+    std::lock_guard<std::mutex> lock(ctx->cache_mutex);
+    const auto it = ctx->live.find(p);
+    if (it != ctx->live.end()) {
+      const size_t bytes = it->second;
+      ctx->live.erase(it);
+      if (ctx->cached_bytes + bytes <= ctx->cache_limit) {
+        ctx->cache.emplace_back(p, bytes);
+        ctx->cached_bytes += bytes;
+        return;
+      }
+    }
+  }
+  (void)hipFree(p);  // not from the cache (or the cache is full): the plain, synchronising free
+}
+
+void dev_cache_release(pclhip_ctx* ctx) {
+  std::vector<std::pair<void*, size_t>> blocks;
+  {
+    std::lock_guard<std::mutex> lock(ctx->cache_mutex);
+    blocks.swap(ctx->cache);
+    ctx->cached_bytes = 0;
+  }
+  if (!blocks.empty()) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& b : blocks) (void)hipFree(b.first);
+}
+
 namespace {
 
 struct DeviceGuard {  // frees staged copies on scope exit (after the stream has been synchronised)
@@ -227,6 +290,11 @@ static pclhip_status ctx_create_impl(int device, void* stream, bool adopt, pclhi
     PCLHIP_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->own_stream = true;
   }
+  if (const char* e = getenv("PCLHIP_CACHE_MB")) ctx->cache_limit = size_t(strtoull(e, nullptr, 10)) << 20;
+  {  // never hold back more than a quarter of the device's memory
+    const size_t quarter = size_t(prop.totalGlobalMem) / 4;
+    if (ctx->cache_limit > quarter) ctx->cache_limit = quarter;
+  }
   *out = ctx;
   return PCLHIP_OK;
 }
@@ -238,6 +306,7 @@ void pclhip_ctx_destroy(pclhip_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->stats) (void)hipFree(ctx->stats);
   if (ctx->staging) (void)hipFree(ctx->staging);
+  dev_cache_release(ctx);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -300,7 +369,7 @@ pclhip_status pclhip_index_build_scaled(pclhip_ctx* ctx, const void* points, siz
   if (indices && n_indices > 0) {  // untrusted: an index outside the cloud would be a wild device read
     PCLHIP_REQUIRE(ctx, n_indices < 0x7FFFFFFFull, "too many indices");
     int* bad = nullptr;
-    PCLHIP_CHECK_HIP(ctx, hipMalloc(&bad, sizeof(int)));
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &bad, sizeof(int)));
     guard.add(bad);
     PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(check_indices_kernel, dim3(unsigned((n_indices + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -332,8 +401,8 @@ pclhip_status pclhip_index_build_scaled(pclhip_ctx* ctx, const void* points, siz
     (void)hipEventDestroy(e1);
     return s;
   };
-  if (hipMalloc(&ix->pts, size_t(cap) * sizeof(float4)) != hipSuccess ||
-      hipMalloc(&ix->rank, size_t(n > 0 ? n : 1) * sizeof(uint32_t)) != hipSuccess) {
+  if (dev_malloc(ctx, &ix->pts, size_t(cap) * sizeof(float4)) != hipSuccess ||
+      dev_malloc(ctx, &ix->rank, size_t(n > 0 ? n : 1) * sizeof(uint32_t)) != hipSuccess) {
     set_error(ctx, "hipMalloc failed for the index");
     return fail(PCLHIP_ERR_HIP);
   }
@@ -366,15 +435,15 @@ void pclhip_index_destroy(pclhip_index* ix) {
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
   }
-  if (ix->pts) (void)hipFree(ix->pts);
-  if (ix->soa) (void)hipFree(ix->soa);
-  if (ix->nrm) (void)hipFree(ix->nrm);
-  if (ix->disc) (void)hipFree(ix->disc);
-  if (ix->rank) (void)hipFree(ix->rank);
-  if (ix->lv_dev) (void)hipFree(ix->lv_dev);
-  if (ix->topcache) (void)hipFree(ix->topcache);
+  if (ix->pts) (void)dev_free(ix->ctx, ix->pts);
+  if (ix->soa) (void)dev_free(ix->ctx, ix->soa);
+  if (ix->nrm) (void)dev_free(ix->ctx, ix->nrm);
+  if (ix->disc) (void)dev_free(ix->ctx, ix->disc);
+  if (ix->rank) (void)dev_free(ix->ctx, ix->rank);
+  if (ix->lv_dev) (void)dev_free(ix->ctx, ix->lv_dev);
+  if (ix->topcache) (void)dev_free(ix->ctx, ix->topcache);
   for (int l = 0; l < MAX_LEVELS; ++l)
-    if (ix->box[l]) (void)hipFree(ix->box[l]);
+    if (ix->box[l]) (void)dev_free(ix->ctx, ix->box[l]);
   delete ix;
 }
 
@@ -398,7 +467,7 @@ pclhip_status pclhip_knn(pclhip_index* ix, const void* queries, size_t stride, u
   if (st != PCLHIP_OK) return st;
   guard.add(owned);
   float4* qs = nullptr;
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&qs, size_t(nq) * sizeof(float4)));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &qs, size_t(nq) * sizeof(float4)));
   guard.add(qs);
   uint32_t nf = 0;
   float lo[3], hi[3];
@@ -410,11 +479,11 @@ pclhip_status pclhip_knn(pclhip_index* ix, const void* queries, size_t stride, u
   float* d_d2 = out_d2;
   const bool idx_dev = is_device_pointer(out_idx), d2_dev = is_device_pointer(out_d2);
   if (!idx_dev) {
-    PCLHIP_CHECK_HIP(ctx, hipMalloc(&d_idx, cnt * sizeof(int32_t)));
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &d_idx, cnt * sizeof(int32_t)));
     guard.add(d_idx);
   }
   if (!d2_dev) {
-    PCLHIP_CHECK_HIP(ctx, hipMalloc(&d_d2, cnt * sizeof(float)));
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &d_d2, cnt * sizeof(float)));
     guard.add(d_d2);
   }
   st = launch_knn(ix, qs, uint32_t(nq), k, d_idx, d_d2);
@@ -446,7 +515,7 @@ static pclhip_status normals_common(pclhip_index* ix, int k, double radius, cons
   if (out_nan_count) *out_nan_count = nan + (ix->n_orig - ix->n);
   if (out && ix->n_orig > 0) {
     float4* dense = nullptr;
-    PCLHIP_CHECK_HIP(ctx, hipMalloc(&dense, size_t(ix->n_orig) * sizeof(float4)));
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &dense, size_t(ix->n_orig) * sizeof(float4)));
     DeviceGuard guard;
     guard.add(dense);
     hipLaunchKernelGGL(scatter_normals_kernel, dim3(unsigned((ix->n_orig + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -496,14 +565,14 @@ pclhip_status pclhip_gicp_covariances(pclhip_index* ix, int k, double epsilon, d
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   DeviceGuard guard;
   double* cov_sorted = nullptr;
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&cov_sorted, size_t(ix->n) * 9 * sizeof(double)));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &cov_sorted, size_t(ix->n) * 9 * sizeof(double)));
   guard.add(cov_sorted);
   pclhip_status st = launch_gicp_covariances(ix, k, epsilon, cov_sorted);
   if (st != PCLHIP_OK) return st;
   const bool dev = is_device_pointer(out);
   double* dense = out;
   if (!dev) {
-    PCLHIP_CHECK_HIP(ctx, hipMalloc(&dense, size_t(ix->n_orig) * 9 * sizeof(double)));
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &dense, size_t(ix->n_orig) * 9 * sizeof(double)));
     guard.add(dense);
   }
   hipLaunchKernelGGL(scatter_cov_kernel, dim3(unsigned((ix->n_orig + 255) / 256)), dim3(256), 0, ctx->stream, cov_sorted,
@@ -544,7 +613,7 @@ pclhip_status pclhip_index_kth_distance_max(pclhip_index* ix, int k, const float
   *out_max_d2 = 0.0;
   if (ix->n == 0) return PCLHIP_OK;
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-  DeviceScope scope;
+  DeviceScope scope(ctx);
   float4* q = nullptr;
   int32_t* idx = nullptr;
   float* d2 = nullptr;
@@ -587,7 +656,7 @@ pclhip_status pclhip_index_set_normals(pclhip_index* ix, const void* normals, si
   pclhip_status st = to_device(ctx, normals, size_t(ix->n_orig) * stride, &dn, &owned);
   if (st != PCLHIP_OK) return st;
   guard.add(owned);
-  if (!ix->nrm) PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->nrm, size_t(ix->n_pad) * sizeof(float4)));
+  if (!ix->nrm) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->nrm, size_t(ix->n_pad) * sizeof(float4)));
   hipLaunchKernelGGL(gather_normals_kernel, dim3((ix->n_pad + 255) / 256), dim3(256), 0, ctx->stream, dn, stride,
                      ix->pts, ix->n, ix->n_pad, ix->nrm);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
@@ -622,7 +691,7 @@ pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out) {
   icp->ctx = ctx;
   icp->target = target;
   icp->prev_mse = DBL_MAX;
-  if (hipMalloc(&icp->sums_dev, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
+  if (dev_malloc(ctx, &icp->sums_dev, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
       hipHostMalloc(&icp->sums_host, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
       // timing markers between kernels of one stream: device-scope release is enough (a system-scope
       // release would write the iteration's dirty lines back to memory at every marker)
@@ -638,17 +707,17 @@ pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out) {
 }
 
 static void icp_free_source(pclhip_icp* icp) {
-  if (icp->src_sorted0) (void)hipFree(icp->src_sorted0);
-  if (icp->src_cur) (void)hipFree(icp->src_cur);
-  if (icp->src_nrm_sorted0) (void)hipFree(icp->src_nrm_sorted0);
-  if (icp->src_nrm_cur) (void)hipFree(icp->src_nrm_cur);
+  if (icp->src_sorted0) (void)dev_free(icp->ctx, icp->src_sorted0);
+  if (icp->src_cur) (void)dev_free(icp->ctx, icp->src_cur);
+  if (icp->src_nrm_sorted0) (void)dev_free(icp->ctx, icp->src_nrm_sorted0);
+  if (icp->src_nrm_cur) (void)dev_free(icp->ctx, icp->src_nrm_cur);
   icp->src_nrm_sorted0 = icp->src_nrm_cur = nullptr;
-  if (icp->match) (void)hipFree(icp->match);
-  if (icp->match_pos) (void)hipFree(icp->match_pos);
-  if (icp->keep) (void)hipFree(icp->keep);
+  if (icp->match) (void)dev_free(icp->ctx, icp->match);
+  if (icp->match_pos) (void)dev_free(icp->ctx, icp->match_pos);
+  if (icp->keep) (void)dev_free(icp->ctx, icp->keep);
   icp->keep = nullptr;
-  if (icp->match_d2) (void)hipFree(icp->match_d2);
-  if (icp->partials) (void)hipFree(icp->partials);
+  if (icp->match_d2) (void)dev_free(icp->ctx, icp->match_d2);
+  if (icp->partials) (void)dev_free(icp->ctx, icp->partials);
   icp->src_sorted0 = icp->src_cur = nullptr;
   icp->match = nullptr;
   icp->match_pos = nullptr;
@@ -663,9 +732,9 @@ void pclhip_icp_destroy(pclhip_icp* icp) {
     (void)hipStreamSynchronize(icp->ctx->stream);
   }
   icp_free_source(icp);
-  if (icp->sums_dev) (void)hipFree(icp->sums_dev);
+  if (icp->sums_dev) (void)dev_free(icp->ctx, icp->sums_dev);
   if (icp->sums_host) (void)hipHostFree(icp->sums_host);
-  if (icp->ctl) (void)hipFree(icp->ctl);
+  if (icp->ctl) (void)dev_free(icp->ctx, icp->ctl);
   if (icp->ctl_host) (void)hipHostFree(icp->ctl_host);
   if (icp->steps) (void)hipHostFree(icp->steps);
   for (hipEvent_t e : icp->step_events)
@@ -705,7 +774,7 @@ pclhip_status pclhip_icp_set_source_indexed(pclhip_icp* icp, const void* points,
     guard.add(owned);
     if (n_indices > 0) {
       int* bad = nullptr;
-      PCLHIP_CHECK_HIP(ctx, hipMalloc(&bad, sizeof(int)));
+      PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &bad, sizeof(int)));
       guard.add(bad);
       PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
       hipLaunchKernelGGL(check_indices_kernel, dim3(unsigned((n_indices + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -721,16 +790,16 @@ pclhip_status pclhip_icp_set_source_indexed(pclhip_icp* icp, const void* points,
   icp->n = uint32_t(m);
   const size_t cap = m > 0 ? m : 1;
   icp->grid_blocks = icp_grid_blocks(ctx, icp->n);
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->src_sorted0, cap * sizeof(float4)));
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->src_cur, cap * sizeof(float4)));
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->match, cap * sizeof(uint32_t)));
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->match_pos, cap * sizeof(uint32_t)));
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->match_d2, cap * sizeof(float)));
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->partials, size_t(icp->grid_blocks) * PCLHIP_ICP_NSUMS * sizeof(double)));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->src_sorted0, cap * sizeof(float4)));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->src_cur, cap * sizeof(float4)));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->match, cap * sizeof(uint32_t)));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->match_pos, cap * sizeof(uint32_t)));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->match_d2, cap * sizeof(float)));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->partials, size_t(icp->grid_blocks) * PCLHIP_ICP_NSUMS * sizeof(double)));
   uint32_t nf = 0;
   float lo[3], hi[3];
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  DeviceScope timing;
+  DeviceScope timing(ctx);
   PCLHIP_CHECK_HIP(ctx, timing.event(&e0));
   PCLHIP_CHECK_HIP(ctx, timing.event(&e1));
   (void)hipEventRecord(e0, ctx->stream);
@@ -758,8 +827,8 @@ pclhip_status pclhip_icp_set_source_normals(pclhip_icp* icp, const void* normals
   if (st != PCLHIP_OK) return st;
   guard.add(owned);
   const size_t cap = icp->n > 0 ? icp->n : 1;
-  if (!icp->src_nrm_sorted0) PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->src_nrm_sorted0, cap * sizeof(float4)));
-  if (!icp->src_nrm_cur) PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->src_nrm_cur, cap * sizeof(float4)));
+  if (!icp->src_nrm_sorted0) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->src_nrm_sorted0, cap * sizeof(float4)));
+  if (!icp->src_nrm_cur) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->src_nrm_cur, cap * sizeof(float4)));
   if (icp->n > 0) {
     hipLaunchKernelGGL(gather_normals_kernel, dim3((icp->n + 255) / 256), dim3(256), 0, ctx->stream, dn, stride,
                        icp->src_sorted0, icp->n, icp->n, icp->src_nrm_sorted0);
@@ -1067,7 +1136,7 @@ static pclhip_status estimate_pairs_common(pclhip_ctx* ctx, int mode, const void
       if (st != PCLHIP_OK) return st;
       guard.add(owned);
       void* buf = nullptr;
-      PCLHIP_CHECK_HIP(ctx, hipMalloc(&buf, size_t(n) * sizeof(float4)));
+      PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &buf, size_t(n) * sizeof(float4)));
       guard.add(buf);
       packed[a] = static_cast<float4*>(buf);
       hipLaunchKernelGGL(pack_float4_kernel, dim3((uint32_t(n) + 255) / 256), dim3(256), 0, ctx->stream, d, strides[a],
@@ -1133,9 +1202,9 @@ pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_q
   float* dd = nullptr;
   DeviceGuard guard;
   const size_t no = size_t(icp->n_orig);  // dense arrays over the ORIGINAL source records (a subset leaves gaps)
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&dm, no * sizeof(int32_t)));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &dm, no * sizeof(int32_t)));
   guard.add(dm);
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&dd, no * sizeof(float)));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &dd, no * sizeof(float)));
   guard.add(dd);
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(dm, 0xFF, no * sizeof(int32_t), ctx->stream));
   const bool filtered = icp->reciprocal || !icp->rejectors.empty();
@@ -1215,7 +1284,7 @@ pclhip_status pclhip_transform_cloud(pclhip_ctx* ctx, const float* T, int order,
     if (owned && in == out) {
       dout = owned;  // in-place on the staged copy
     } else {
-      PCLHIP_CHECK_HIP(ctx, hipMalloc(&dout, bytes));
+      PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &dout, bytes));
       guard.add(dout);
       // other bytes of each record pass through unchanged
       PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(dout, din, bytes, hipMemcpyDeviceToDevice, ctx->stream));

@@ -202,7 +202,7 @@ constexpr int kRing = 64;  // step records / event quadruples in flight at most
 pclhip_status ensure_loop_state(pclhip_icp* icp) {
   pclhip_ctx* ctx = icp->ctx;
   if (icp->ctl != nullptr) return PCLHIP_OK;
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->ctl, sizeof(IcpControl)));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->ctl, sizeof(IcpControl)));
   PCLHIP_CHECK_HIP(ctx, hipHostMalloc(&icp->ctl_host, sizeof(IcpControl), hipHostMallocDefault));
   PCLHIP_CHECK_HIP(ctx, hipHostMalloc(&icp->steps, sizeof(IcpStepRecord) * kRing, hipHostMallocDefault));
   std::memset(icp->steps, 0, sizeof(IcpStepRecord) * kRing);

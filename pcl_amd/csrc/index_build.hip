@@ -311,12 +311,12 @@ pclhip_status morton_order(pclhip_ctx* ctx, const void* dev_points, size_t strid
     if (out_capacity) {
       unsigned int zero = 0;
       unsigned int* dz = nullptr;
-      PCLHIP_CHECK_HIP(ctx, hipMalloc(&dz, sizeof zero));
+      PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &dz, sizeof zero));
       PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(dz, &zero, sizeof zero, hipMemcpyHostToDevice, s));
       hipLaunchKernelGGL(gather_kernel, dim3((out_capacity + 255) / 256), dim3(256), 0, s, dev_points, stride,
                          (const uint32_t*)nullptr, uint64_t(0), dz, out_sorted, out_capacity, (uint32_t*)nullptr, 0);
       PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-      (void)hipFree(dz);
+      (void)dev_free(ctx, dz);
     }
     *out_n_finite = 0;
     for (int d = 0; d < 3; ++d) lo[d] = hi[d] = 0;
@@ -754,7 +754,7 @@ pclhip_status build_index_from_float4(pclhip_ctx* ctx, const float4* dev_pts_wit
   ix->ctx = ctx;
   ix->n_orig = n;
   const uint32_t cap = ((n + LEAF - 1) / LEAF) * LEAF + LEAF;
-  if (hipMalloc(&ix->pts, size_t(cap) * sizeof(float4)) != hipSuccess) {
+  if (dev_malloc(ctx, &ix->pts, size_t(cap) * sizeof(float4)) != hipSuccess) {
     delete ix;
     set_error(ctx, "hipMalloc failed for the reciprocal index");
     return PCLHIP_ERR_HIP;
@@ -780,7 +780,7 @@ pclhip_status build_boxes(pclhip_index* ix) {
   pclhip_ctx* ctx = ix->ctx;
   hipStream_t s = ctx->stream;
   for (int l = 0; l < MAX_LEVELS; ++l) {
-    if (ix->box[l]) (void)hipFree(ix->box[l]);
+    if (ix->box[l]) (void)dev_free(ctx, ix->box[l]);
     ix->box[l] = nullptr;
     ix->count[l] = 0;
   }
@@ -794,27 +794,27 @@ pclhip_status build_boxes(pclhip_index* ix) {
       return PCLHIP_ERR_INVALID;
     }
     ix->count[l] = c;
-    PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->box[l], size_t(c) * sizeof(Box)));
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->box[l], size_t(c) * sizeof(Box)));
     if (l == 1) {
       const uint32_t threads = c * LEAF;
       hipLaunchKernelGGL(leaf_box_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c, ix->box[1]);
-      if (ix->soa) (void)hipFree(ix->soa);
+      if (ix->soa) (void)dev_free(ctx, ix->soa);
       ix->soa = nullptr;
-      PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->soa, size_t(c) * 4 * LEAF * sizeof(float)));
+      PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->soa, size_t(c) * 4 * LEAF * sizeof(float)));
       hipLaunchKernelGGL(leaf_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, threads, ix->soa);
-      if (ix->disc) (void)hipFree(ix->disc);
+      if (ix->disc) (void)dev_free(ctx, ix->disc);
       ix->disc = nullptr;
-      PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->disc, size_t(c) * 2 * sizeof(float4)));
+      PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->disc, size_t(c) * 2 * sizeof(float4)));
       hipLaunchKernelGGL(leaf_disc_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c, ix->disc);
       {  // mean squared leaf diagonal: from what stand-off on the discs pay (traverse.hpp)
         constexpr int NB = 64;
         double* part = nullptr;
-        PCLHIP_CHECK_HIP(ctx, hipMalloc(&part, NB * sizeof(double)));
+        PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &part, NB * sizeof(double)));
         hipLaunchKernelGGL(leaf_diag_kernel, dim3(NB), dim3(256), 0, s, ix->box[1], c, part);
         double h[NB];
         const hipError_t e1 = hipMemcpyAsync(h, part, sizeof h, hipMemcpyDeviceToHost, s);
         const hipError_t e2 = hipStreamSynchronize(s);
-        (void)hipFree(part);
+        (void)dev_free(ctx, part);
         PCLHIP_CHECK_HIP(ctx, e1);
         PCLHIP_CHECK_HIP(ctx, e2);
         double sum = 0.0;
@@ -842,7 +842,7 @@ pclhip_status build_boxes(pclhip_index* ix) {
     }
     ix->cache_from = from;
     ix->cache_count = total;
-    if (!ix->topcache) PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->topcache, size_t(TOPCACHE_BOXES) * sizeof(Box)));
+    if (!ix->topcache) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->topcache, size_t(TOPCACHE_BOXES) * sizeof(Box)));
     uint32_t off = 0;
     for (int lv = 0; lv < MAX_LEVELS; ++lv) ix->cache_off[lv] = 0;
     for (int lv = from; lv <= ix->top && from < MAX_LEVELS; ++lv) {
@@ -858,7 +858,7 @@ pclhip_status build_boxes(pclhip_index* ix) {
     h[i].count = ix->count[i];
     h[i].pad = 0;
   }
-  if (!ix->lv_dev) PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->lv_dev, sizeof h));
+  if (!ix->lv_dev) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->lv_dev, sizeof h));
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(ix->lv_dev, h, sizeof h, hipMemcpyHostToDevice, s));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));  // h is a stack buffer
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());

@@ -18,7 +18,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/pclhip.h"
@@ -121,6 +124,15 @@ struct pclhip_ctx {
   unsigned long long* stats = nullptr;  // 8 work counters (device), non-null when enabled
   void* staging = nullptr;  // device staging for host inputs
   size_t staging_bytes = 0;
+  // Device allocations of indices, registrations and temporaries are recycled through the context
+  // (pclhip::dev_malloc / dev_free): hipMalloc + hipFree of the ~1 GB a 10M-point index build touches cost more
+  // than the build's kernels.  All work of a context is ordered on its one stream, so a block handed out
+  // again is never still in use.  Bounded by PCLHIP_CACHE_MB (default 16384); 0 turns the cache off.
+  std::vector<std::pair<void*, size_t>> cache;   // free blocks (pointer, bytes)
+  std::unordered_map<void*, size_t> live;         // blocks handed out
+  size_t cached_bytes = 0;
+  size_t cache_limit = size_t(16384) << 20;
+  std::mutex cache_mutex;
 };
 
 struct pclhip_index {
@@ -199,19 +211,31 @@ namespace pclhip {
 
 // ---- error plumbing -----------------------------------------------------------------------
 // Frees device allocations and destroys events on scope exit (every early error return included).
+// context-cached device memory (api.hip): same contract as hipMalloc / hipFree
+hipError_t dev_malloc(pclhip_ctx* ctx, void** p, size_t bytes);
+void dev_free(pclhip_ctx* ctx, void* p);
+void dev_cache_release(pclhip_ctx* ctx);  // really frees every cached block
+template <class T>
+inline hipError_t dev_malloc(pclhip_ctx* ctx, T** p, size_t bytes) {
+  return dev_malloc(ctx, reinterpret_cast<void**>(p), bytes);
+}
+
 struct DeviceScope {
+  pclhip_ctx* ctx = nullptr;
   std::vector<void*> mem;
   std::vector<hipEvent_t> events;
+  DeviceScope() = default;
+  explicit DeviceScope(pclhip_ctx* c) : ctx(c) {}
   ~DeviceScope() {
     for (void* p : mem)
-      if (p) (void)hipFree(p);
+      if (p) dev_free(ctx, p);
     for (hipEvent_t e : events)
       if (e) (void)hipEventDestroy(e);
   }
   template <class T>
   hipError_t alloc(T** ptr, size_t bytes) {
     *ptr = nullptr;
-    const hipError_t e = hipMalloc(reinterpret_cast<void**>(ptr), bytes ? bytes : 16);
+    const hipError_t e = dev_malloc(ctx, reinterpret_cast<void**>(ptr), bytes ? bytes : 16);
     if (e == hipSuccess) mem.push_back(*ptr);
     return e;
   }

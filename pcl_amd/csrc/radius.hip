@@ -165,14 +165,15 @@ struct SubBase {  // segment offsets relative to a chunk's first key
 };
 
 struct Guard {
+  pclhip_ctx* ctx = nullptr;
   std::vector<void*> p;
   ~Guard() {
     for (void* q : p)
-      if (q) (void)hipFree(q);
+      if (q) (void)dev_free(ctx, q);
   }
   template <class T>
   hipError_t alloc(T** ptr, size_t bytes) {
-    hipError_t e = hipMalloc(ptr, bytes ? bytes : 16);
+    hipError_t e = dev_malloc(ctx, ptr, bytes ? bytes : 16);
     if (e == hipSuccess) p.push_back(*ptr);
     return e;
   }
@@ -198,6 +199,7 @@ extern "C" pclhip_status pclhip_radius_search(pclhip_index* ix, const void* quer
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   Guard g;
+  g.ctx = ctx;
   const void* dq = nullptr;
   void* owned = nullptr;
   pclhip_status st = to_device(ctx, queries, size_t(nq) * stride, &dq, &owned);
@@ -275,7 +277,8 @@ pclhip_status pclhip::launch_normals_radius(pclhip_index* ix, double radius, con
   pclhip_ctx* ctx = ix->ctx;
   hipStream_t s = ctx->stream;
   Guard g;
-  if (!ix->nrm) PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->nrm, size_t(ix->n_pad > 0 ? ix->n_pad : 1) * sizeof(float4)));
+  g.ctx = ctx;
+  if (!ix->nrm) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->nrm, size_t(ix->n_pad > 0 ? ix->n_pad : 1) * sizeof(float4)));
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(ix->nrm, 0xFF, size_t(ix->n_pad) * sizeof(float4), s));  // NaN pads
   if (nan_count) *nan_count = 0;
   const uint32_t n = ix->n;

@@ -131,14 +131,15 @@ __global__ void recip_keep_kernel(const float4* __restrict__ cur, const int32_t*
 }
 
 struct Guard {
+  pclhip_ctx* ctx = nullptr;
   std::vector<void*> p;
   ~Guard() {
     for (void* q : p)
-      if (q) (void)hipFree(q);
+      if (q) (void)dev_free(ctx, q);
   }
   template <class T>
   hipError_t alloc(T** ptr, size_t bytes) {
-    hipError_t e = hipMalloc(ptr, bytes ? bytes : 16);
+    hipError_t e = dev_malloc(ctx, ptr, bytes ? bytes : 16);
     if (e == hipSuccess) p.push_back(*ptr);
     return e;
   }
@@ -153,9 +154,10 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
   icp->fetch_order = 0;
   if (n == 0) return PCLHIP_OK;
   const dim3 grid((n + TB - 1) / TB), block(TB);
-  if (!icp->keep) PCLHIP_CHECK_HIP(ctx, hipMalloc(&icp->keep, n));
+  if (!icp->keep) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->keep, n));
   hipLaunchKernelGGL(rej_init_kernel, grid, block, 0, s, icp->match_pos, n, icp->keep);
   Guard g;
+  g.ctx = ctx;
   unsigned int* d_cnt = nullptr;
   PCLHIP_CHECK_HIP(ctx, g.alloc(&d_cnt, sizeof(unsigned int)));
 

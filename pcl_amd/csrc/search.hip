@@ -203,12 +203,12 @@ pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, 
   } else {
     const size_t bytes = size_t(nq) * size_t(k) * sizeof(uint64_t);
     uint64_t* heap = nullptr;
-    PCLHIP_CHECK_HIP(ctx, hipMalloc(&heap, bytes));
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &heap, bytes));
     const int grid = resident_blocks(ctx, knn_heap_kernel, ngroups);
     hipLaunchKernelGGL(knn_heap_kernel, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2,
                        heap, ctx->stats);
     hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(heap);
+    (void)dev_free(ctx, heap);
     PCLHIP_CHECK_HIP(ctx, e);
   }
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
@@ -382,8 +382,8 @@ __global__ void iota_w_kernel(const float4* __restrict__ pts, uint32_t n, float4
 pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_t* nan_count) {
   pclhip_ctx* ctx = ix->ctx;
   hipStream_t s = ctx->stream;
-  DeviceScope scope;
-  if (!ix->nrm) PCLHIP_CHECK_HIP(ctx, hipMalloc(&ix->nrm, size_t(ix->n_pad > 0 ? ix->n_pad : 1) * sizeof(float4)));
+  DeviceScope scope(ctx);
+  if (!ix->nrm) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->nrm, size_t(ix->n_pad > 0 ? ix->n_pad : 1) * sizeof(float4)));
   unsigned long long* d_nan = nullptr;
   PCLHIP_CHECK_HIP(ctx, scope.alloc(&d_nan, sizeof(unsigned long long)));
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_nan, 0, sizeof(unsigned long long), s));
@@ -1362,7 +1362,7 @@ pclhip_status launch_estimate_pairs(pclhip_ctx* ctx, int mode, const float4* src
   hipStream_t s = ctx->stream;
   const int grid = ctx->num_cus * 4;
   double* dev = nullptr;  // partials [grid][NS] + sums [NS]
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&dev, (size_t(grid) + 1) * NS * sizeof(double)));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &dev, (size_t(grid) + 1) * NS * sizeof(double)));
   if (mode == PCLHIP_ICP_POINT_TO_PLANE)
     hipLaunchKernelGGL(estimate_pairs_kernel<PCLHIP_ICP_POINT_TO_PLANE>, dim3(grid), dim3(BLOCK), 0, s, src, src_nrm, tgt,
                        tgt_nrm, weights, n, enforce ? 1 : 0, dev);
@@ -1378,7 +1378,7 @@ pclhip_status launch_estimate_pairs(pclhip_ctx* ctx, int mode, const float4* src
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(sums, dev + size_t(grid) * NS, NS * sizeof(double), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(dev);
+  (void)dev_free(ctx, dev);
   PCLHIP_CHECK_HIP(ctx, e);
   return PCLHIP_OK;
 }

@@ -191,12 +191,14 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   struct Guard {
+    pclhip_ctx* ctx = nullptr;
     std::vector<void*> p;
     ~Guard() {
       for (void* q : p)
-        if (q) (void)hipFree(q);
+        if (q) (void)dev_free(ctx, q);
     }
   } guard;
+  guard.ctx = ctx;
   const void* dp = nullptr;
   void* owned = nullptr;
   pclhip_status st = to_device(ctx, points, size_t(n) * stride, &dp, &owned);
@@ -306,7 +308,7 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   void* d_out = out;
   const bool out_dev = is_device_pointer(out);
   if (!out_dev) {
-    PCLHIP_CHECK_HIP(ctx, hipMalloc(&d_out, size_t(total > 0 ? total : 1) * out_stride));
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &d_out, size_t(total > 0 ? total : 1) * out_stride));
     guard.p.push_back(d_out);
   }
   if (total > 0) {
