@@ -9,6 +9,8 @@
 // The radix sort is rocprim::radix_sort_pairs (one-off per target cloud, not on the per-iteration
 // path); everything else is hand-written.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <cstring>
 #include <string.h>
 
@@ -534,6 +536,117 @@ __global__ __launch_bounds__(256) void kd_cell_split_kernel(const float4* __rest
   if (lane < m) out[base + lane] = p;
 }
 
+// ---- bottom kd rounds in one workgroup ------------------------------------------------------------
+// Segments of <= 4096 points are ordered entirely inside LDS: the rounds that cut a 4096-point segment into
+// four 1024-point slabs, those into 256-point slabs, those into 64-point cells, and the two binary cuts of a
+// cell (see above) run back to back in one launch instead of three radix sorts of the whole cloud plus the
+// cell-split kernel.  Per level: bounding box of every sub-segment -> widest axis -> bitonic sort of
+// (orderable coordinate, position) pairs inside the sub-segment.  The points stay where they are (x, y, z
+// planes in LDS); a 16-bit permutation moves.  Keys are exact float orders, so cells keep disjoint interiors.
+constexpr int KDB_N = 4096;
+constexpr int KDB_THREADS = 1024;
+struct KdBlockLds {
+  float x[KDB_N], y[KDB_N], z[KDB_N];
+  uint32_t key[KDB_N];
+  uint16_t perm[KDB_N];
+  float wbox[KDB_THREADS / WAVE][6];
+};
+
+__global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __restrict__ in, uint32_t n,
+                                                               float4* __restrict__ out, uint32_t top_nsub,
+                                                               uint32_t bottom_nsub) {
+  __shared__ KdBlockLds s;
+  const uint32_t t = threadIdx.x;
+  const uint32_t lane = t & 63u, wave = t >> 6;
+  const uint32_t base = blockIdx.x * uint32_t(KDB_N);
+  if (base >= n) return;
+  const uint32_t cnt = (n - base) < uint32_t(KDB_N) ? (n - base) : uint32_t(KDB_N);
+  for (uint32_t p = t; p < uint32_t(KDB_N); p += KDB_THREADS) {
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (p < cnt) v = in[base + p];
+    s.x[p] = v.x; s.y[p] = v.y; s.z[p] = v.z;
+    s.perm[p] = uint16_t(p);
+  }
+  __syncthreads();
+  for (uint32_t nsub = top_nsub; nsub >= bottom_nsub; nsub = (nsub > 64u) ? nsub / 4u : nsub / 2u) {
+    // (a) bounding box of the sub-segment this thread's four positions belong to
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    uint32_t idx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t p = 4u * t + uint32_t(e);
+      idx[e] = s.perm[p];
+      if (p < cnt) {  // the points of a sub-segment always precede its padding (padding sorts last)
+        const float px = s.x[idx[e]], py = s.y[idx[e]], pz = s.z[idx[e]];
+        lo[0] = fminf(lo[0], px); lo[1] = fminf(lo[1], py); lo[2] = fminf(lo[2], pz);
+        hi[0] = fmaxf(hi[0], px); hi[1] = fmaxf(hi[1], py); hi[2] = fmaxf(hi[2], pz);
+      }
+    }
+    const uint32_t group = nsub / 4u;  // threads per sub-segment: 8 ... 1024
+    const uint32_t inwave = group < 64u ? group : 64u;
+    for (uint32_t o = inwave >> 1; o > 0; o >>= 1) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = fminf(lo[d], __shfl_xor(lo[d], int(o)));
+        hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], int(o)));
+      }
+    }
+    if (group > 64u) {  // wave-uniform: the sub-segment spans several wavefronts
+      if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          s.wbox[wave][d] = lo[d];
+          s.wbox[wave][3 + d] = hi[d];
+        }
+      }
+      __syncthreads();
+      const uint32_t wpg = group / 64u, w0 = (wave / wpg) * wpg;
+      for (uint32_t w = w0; w < w0 + wpg; ++w) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          lo[d] = fminf(lo[d], s.wbox[w][d]);
+          hi[d] = fmaxf(hi[d], s.wbox[w][3 + d]);
+        }
+      }
+    }
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    int a = 0;
+    float best = ex;
+    if (ey > best) { best = ey; a = 1; }
+    if (ez > best) { a = 2; }
+    // (b) keys: the coordinate along that axis in unsigned order; padding sorts last
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t p = 4u * t + uint32_t(e);
+      const float c = a == 0 ? s.x[idx[e]] : (a == 1 ? s.y[idx[e]] : s.z[idx[e]]);
+      s.key[p] = p < cnt ? orderable(c) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    // (c) bitonic sort of (key, perm) inside every sub-segment, ascending
+    for (uint32_t k = 2; k <= nsub; k <<= 1) {
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const uint32_t q = t + uint32_t(e) * KDB_THREADS;
+          const uint32_t i = ((q & ~(j - 1u)) << 1) | (q & (j - 1u));
+          const uint32_t i2 = i | j;
+          const bool up = ((i & (nsub - 1u)) & k) == 0u;
+          const uint32_t ka = s.key[i], kb = s.key[i2];
+          const uint16_t pa = s.perm[i], pb = s.perm[i2];
+          const bool gt = ka > kb || (ka == kb && pa > pb);
+          if (gt == up) {
+            s.key[i] = kb; s.key[i2] = ka;
+            s.perm[i] = pb; s.perm[i2] = pa;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (nsub == 32u) break;  // (guards the unsigned loop condition when bottom_nsub is 32)
+  }
+  for (uint32_t p = t; p < cnt; p += KDB_THREADS) out[base + p] = in[base + s.perm[p]];
+}
+
 // initial compaction: finite selected records first (stable), non-finite ones after them
 // `sc`: per-axis rescale factors of a point representation (1,1,1 normally); an axis with factor 0 does not
 // exist in the representation: its coordinate reads as 0 and need not be finite
@@ -561,11 +674,30 @@ __global__ __launch_bounds__(256) void kd_flag_kernel(const void* pts, size_t st
   if (threadIdx.x == 0 && blk) atomicAdd(n_finite, blk);
 }
 
-__global__ __launch_bounds__(256) void kd_load_kernel(const void* pts, size_t stride, const uint32_t* vals, uint64_t m,
-                                                      float4* out, int ids_from_w, Scale3 sc, int scaled) {
+// the common case needs no compaction at all: count the finite selected records first (read-only pass)
+__global__ __launch_bounds__(256) void kd_count_kernel(const void* pts, size_t stride, const int32_t* sel, uint64_t m,
+                                                       unsigned int* n_finite, Scale3 sc) {
+  unsigned int mine = 0;
+  for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < m; i += uint64_t(gridDim.x) * blockDim.x) {
+    const uint64_t rec = sel ? uint64_t(sel[i]) : i;
+    const float* p = record(pts, stride, rec);
+    const bool fin = (sc.x == 0.0f || isfinite(p[0])) && (sc.y == 0.0f || isfinite(p[1])) && (sc.z == 0.0f || isfinite(p[2]));
+    mine += fin ? 1u : 0u;
+  }
+  __shared__ unsigned int blk;
+  if (threadIdx.x == 0) blk = 0;
+  __syncthreads();
+  if (mine) atomicAdd(&blk, mine);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk) atomicAdd(n_finite, blk);
+}
+
+// vals == nullptr: record j of the selection (or of the cloud) goes to slot j
+__global__ __launch_bounds__(256) void kd_load_kernel(const void* pts, size_t stride, const uint32_t* vals, const int32_t* sel,
+                                                      uint64_t m, float4* out, int ids_from_w, Scale3 sc, int scaled) {
   const uint64_t j = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
   if (j >= m) return;
-  const uint32_t rec = vals[j];
+  const uint32_t rec = vals ? vals[j] : (sel ? uint32_t(sel[j]) : uint32_t(j));
   const float* p = record(pts, stride, rec);
   float x = p[0], y = p[1], z = p[2];
   if (scaled) {  // PointRepresentation::vectorize: coordinate * alpha (common/include/pcl/point_representation.h:150-170)
@@ -649,15 +781,25 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
   // --- compaction: finite records first (stable 1-bit sort of (flag, record)) ---
   uint32_t* f0 = reinterpret_cast<uint32_t*>(k0);
   uint32_t* f1 = reinterpret_cast<uint32_t*>(k1);
-  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(cn, 0, sizeof(unsigned int), s));
-  hipLaunchKernelGGL(kd_flag_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride, dev_sel, m, f0, v0,
-                     cn, sc);
-  PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, temp_bytes, f0, f1, v0, v1, size_t(m), 0, 1, s));
-  hipLaunchKernelGGL(kd_load_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride, v1, m, pa,
-                     ids_from_w ? 1 : 0, sc, scaled);
   unsigned int hn = 0;
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(cn, 0, sizeof(unsigned int), s));
+  {
+    const unsigned grid = unsigned(std::min<uint64_t>((m + 255) / 256, uint64_t(ctx->num_cus) * 16));
+    hipLaunchKernelGGL(kd_count_kernel, dim3(grid), dim3(256), 0, s, dev_points, stride, dev_sel, m, cn, sc);
+  }
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&hn, cn, sizeof hn, hipMemcpyDeviceToHost, s));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  if (uint64_t(hn) == m) {  // every record is finite: slot j <- record j, no compaction sort
+    hipLaunchKernelGGL(kd_load_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride,
+                       (const uint32_t*)nullptr, dev_sel, m, pa, ids_from_w ? 1 : 0, sc, scaled);
+  } else {
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(cn, 0, sizeof(unsigned int), s));
+    hipLaunchKernelGGL(kd_flag_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride, dev_sel, m, f0, v0,
+                       cn, sc);
+    PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, temp_bytes, f0, f1, v0, v1, size_t(m), 0, 1, s));
+    hipLaunchKernelGGL(kd_load_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride, v1,
+                       (const int32_t*)nullptr, m, pa, ids_from_w ? 1 : 0, sc, scaled);
+  }
   const uint32_t nf = hn;
   *out_n_finite = nf;
 
@@ -686,6 +828,20 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
         const char* e = getenv("PCLHIP_KD_LEAF");
         return !(e && strcmp(e, "strip") == 0);
       }();
+      static const bool block_rounds = [] {  // A/B: PCLHIP_KD_BOTTOM=sort keeps one global radix sort per round
+        const char* e = getenv("PCLHIP_KD_BOTTOM");
+        return !(e && strcmp(e, "sort") == 0);
+      }();
+      if (r > 0 && block_rounds && seg_size <= uint64_t(KDB_N)) {  // the remaining rounds fit one workgroup's LDS
+        hipLaunchKernelGGL(kd_block_kernel, dim3(unsigned((uint64_t(nf) + KDB_N - 1) / KDB_N)), dim3(KDB_THREADS), 0, s, cur, nf,
+                           nxt, uint32_t(seg_size), square_leaves ? 32u : 64u);
+        if (keep_nonfinite_at_end && m > nf)
+          PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(nxt + nf, cur + nf, (m - nf) * sizeof(float4), hipMemcpyDeviceToDevice, s));
+        float4* t = cur;
+        cur = nxt;
+        nxt = t;
+        break;
+      }
       if (r == R && r > 0 && square_leaves) {  // 64-point cells: two binary cuts inside one wavefront each
         hipLaunchKernelGGL(kd_cell_split_kernel, dim3(unsigned((uint64_t(nf) + 255) / 256)), dim3(256), 0, s, cur, nf, nxt);
         if (keep_nonfinite_at_end && m > nf)

@@ -254,7 +254,10 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
       const int wave_id = threadIdx.x / WAVE;
       TopKDist<K> dist;
       dist.init();
-      traverse<TopKDist<K>, true>(ix, qx, qy, qz, vv, dist, wl_s[wave_id], topbox_s, ts);
+      const uint32_t own_leaf = uniform_u32((g * WAVE) / LEAF);
+      static_assert(WAVE % LEAF == 0, "a wave's queries are whole leaves");
+      if (valid) dist.seed_own_leaf(ix.soa, i / LEAF, qx, qy, qz);   // lanes i / LEAF = own_leaf ... own_leaf + 3
+      traverse<TopKDist<K>, true>(ix, qx, qy, qz, vv, dist, wl_s[wave_id], topbox_s, ts, own_leaf);
       CollectLE<K> col;
       col.thr = (k >= 1 && k <= K) ? dist.d[0] : 0.0f;
 #pragma unroll
@@ -262,7 +265,6 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
       col.cnt = 0;
       col.over = false;
       col.list = nbr_s[wave_id] + lane;
-      const uint32_t own_leaf = uniform_u32((g * WAVE) / LEAF);
       traverse<CollectLE<K>, true>(ix, qx, qy, qz, vv, col, wl_s[wave_id], topbox_s, ts, own_leaf);
       __builtin_amdgcn_wave_barrier();
       const bool redo[1] = {valid && col.over};

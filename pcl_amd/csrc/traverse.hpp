@@ -504,33 +504,44 @@ struct TopKDist {
     for (int j = K - 1; j > 0; --j) d[j] = __builtin_amdgcn_fmed3f(d[j - 1], x, d[j]);
     d[0] = __builtin_fminf(d[0], x);
   }
+  // the 16 candidates of one leaf block: chunk c (16 bytes) at s[c * STRIDE]
+  template <int STRIDE>
+  __device__ __forceinline__ void block(const float4* s, const float* qx, const float* qy, const float* qz) {
+    const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
+#pragma unroll
+    for (int c4 = 0; c4 < LEAF / 4; ++c4) {
+      const float4 X = s[c4 * STRIDE], Y = s[(4 + c4) * STRIDE], Z = s[(8 + c4) * STRIDE];
+      v2f r0, r1;
+      {
+        const v2f dx = qx2 - v2f{X.x, X.y}, dy = qy2 - v2f{Y.x, Y.y}, dz = qz2 - v2f{Z.x, Z.y};
+        r0 = dx * dx;
+        r0 = r0 + dy * dy;
+        r0 = r0 + dz * dz;
+      }
+      {
+        const v2f dx = qx2 - v2f{X.z, X.w}, dy = qy2 - v2f{Y.z, Y.w}, dz = qz2 - v2f{Z.z, Z.w};
+        r1 = dx * dx;
+        r1 = r1 + dy * dy;
+        r1 = r1 + dz * dz;
+      }
+      insert(r0.x);
+      insert(r0.y);
+      insert(r1.x);
+      insert(r1.y);
+    }
+  }
   __device__ __forceinline__ void leaf_lane(const float* buf, uint32_t slot, uint32_t leaf_id, const float* qx,
                                             const float* qy, const float* qz) {
-    if (leaf_id != NO_INDEX) {
-      const float4* s = reinterpret_cast<const float4*>(buf) + slot;  // chunk c at s[c * 16]
-      const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
-#pragma unroll
-      for (int c4 = 0; c4 < LEAF / 4; ++c4) {
-        const float4 X = s[c4 * 16], Y = s[(4 + c4) * 16], Z = s[(8 + c4) * 16];
-        v2f r0, r1;
-        {
-          const v2f dx = qx2 - v2f{X.x, X.y}, dy = qy2 - v2f{Y.x, Y.y}, dz = qz2 - v2f{Z.x, Z.y};
-          r0 = dx * dx;
-          r0 = r0 + dy * dy;
-          r0 = r0 + dz * dz;
-        }
-        {
-          const v2f dx = qx2 - v2f{X.z, X.w}, dy = qy2 - v2f{Y.z, Y.w}, dz = qz2 - v2f{Z.z, Z.w};
-          r1 = dx * dx;
-          r1 = r1 + dy * dy;
-          r1 = r1 + dz * dz;
-        }
-        insert(r0.x);
-        insert(r0.y);
-        insert(r1.x);
-        insert(r1.y);
-      }
-    }
+    if (leaf_id != NO_INDEX) block<16>(reinterpret_cast<const float4*>(buf) + slot, qx, qy, qz);  // transposed staging
+  }
+  // Self-queries: the lane's OWN leaf is evaluated before the traversal (straight from the SoA copy), so the search
+  // starts with a k-th distance of a few point spacings -- tight mode, below the root -- instead of +inf; the
+  // traversal must then not hand that leaf to this lane again (a distance would be inserted twice).
+  uint32_t exclude = NO_INDEX;
+  __device__ __forceinline__ void seed_own_leaf(const float* soa, uint32_t leaf_id, const float* qx, const float* qy,
+                                                const float* qz) {
+    block<1>(reinterpret_cast<const float4*>(soa + size_t(leaf_id) * LEAF_FLOATS), qx, qy, qz);
+    exclude = leaf_id;
   }
 };
 
@@ -677,6 +688,17 @@ template <class P, class = void>
 struct lane_sparse_of { static constexpr bool value = false; };
 template <class P>
 struct lane_sparse_of<P, decltype(void(P::LANE_SPARSE))> { static constexpr bool value = P::LANE_SPARSE; };
+
+// does this lane's policy still want leaf `id`?  (policies with an `exclude` member have evaluated it already)
+template <class P, class = void>
+struct has_exclude { static constexpr bool value = false; };
+template <class P>
+struct has_exclude<P, decltype(void(P::exclude))> { static constexpr bool value = true; };
+template <class P>
+__device__ __forceinline__ bool pol_wants(const P& pol, uint32_t id) {
+  if constexpr (has_exclude<P>::value) return id != pol.exclude;
+  else return true;
+}
 
 // ---- the traversal --------------------------------------------------------------------------------
 // `wl` is this wave's LDS working set.  Must be called by all 64 lanes.
@@ -900,7 +922,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
               } else {
                 lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
               }
-              bool need = valid[0] && !(lb > pol.worst(0));
+              bool need = valid[0] && !(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w));
               if (__builtin_amdgcn_ballot_w64(need && pid != NO_INDEX) != 0) {
                 if (!landed) {
                   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -938,7 +960,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
             for (uint32_t t = 0; t < nb; ++t) {
               const float4 ea = wl.list[3 * (b0 + t)], eb = wl.list[3 * (b0 + t) + 1];  // broadcast reads
               const float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
-              mask |= (!(lb > pol.worst(0)) ? 1u : 0u) << t;
+              mask |= ((!(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w))) ? 1u : 0u) << t;
             }
             if (!valid[0]) mask = 0;
             while (__builtin_amdgcn_ballot_w64(mask != 0) != 0) {
