@@ -43,10 +43,10 @@ pclhip_status to_device(pclhip_ctx* ctx, const void* p, size_t bytes, const void
     return PCLHIP_OK;
   }
   void* d = nullptr;
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&d, bytes));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &d, bytes));   // every caller releases `owned` with dev_free
   hipError_t e = hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) {
-    (void)hipFree(d);
+    dev_free(ctx, d);
     PCLHIP_CHECK_HIP(ctx, e);
   }
   *owned = d;
@@ -114,6 +114,9 @@ void dev_free(pclhip_ctx* ctx, void* p) {
         ctx->cached_bytes += bytes;
         return;
       }
+    } else {
+      for (const auto& b : ctx->cache)
+        if (b.first == p) return;  // released twice: it already sits in the cache
     }
   }
   (void)hipFree(p);  // not from the cache (or the cache is full): the plain, synchronising free
@@ -132,11 +135,13 @@ void dev_cache_release(pclhip_ctx* ctx) {
 
 namespace {
 
-struct DeviceGuard {  // frees staged copies on scope exit (after the stream has been synchronised)
+struct DeviceGuard {  // releases staged copies and temporaries on scope exit (back to the context's cache)
+  pclhip_ctx* ctx;
   std::vector<void*> ptrs;
+  explicit DeviceGuard(pclhip_ctx* c) : ctx(c) {}
   ~DeviceGuard() {
     for (void* p : ptrs)
-      if (p) (void)hipFree(p);
+      if (p) dev_free(ctx, p);
   }
   void add(void* p) { ptrs.push_back(p); }
 };
@@ -353,7 +358,7 @@ pclhip_status pclhip_index_build_scaled(pclhip_ctx* ctx, const void* points, siz
   PCLHIP_REQUIRE(ctx, n < 0x7FFFFFFFull, "cloud too large for int32 indices");
   PCLHIP_REQUIRE(ctx, n == 0 || points != nullptr, "null point buffer");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-  DeviceGuard guard;
+  DeviceGuard guard(ctx);
   const void* dpts = nullptr;
   void* owned = nullptr;
   pclhip_status st = to_device(ctx, points, size_t(n) * stride, &dpts, &owned);
@@ -460,7 +465,7 @@ pclhip_status pclhip_knn(pclhip_index* ix, const void* queries, size_t stride, u
   if (nq == 0) return PCLHIP_OK;
   PCLHIP_REQUIRE(ctx, queries && out_idx && out_d2, "null buffer");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-  DeviceGuard guard;
+  DeviceGuard guard(ctx);
   const void* dq = nullptr;
   void* owned = nullptr;
   pclhip_status st = to_device(ctx, queries, size_t(nq) * stride, &dq, &owned);
@@ -516,7 +521,7 @@ static pclhip_status normals_common(pclhip_index* ix, int k, double radius, cons
   if (out && ix->n_orig > 0) {
     float4* dense = nullptr;
     PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &dense, size_t(ix->n_orig) * sizeof(float4)));
-    DeviceGuard guard;
+    DeviceGuard guard(ctx);
     guard.add(dense);
     hipLaunchKernelGGL(scatter_normals_kernel, dim3(unsigned((ix->n_orig + 255) / 256)), dim3(256), 0, ctx->stream,
                        ix->nrm, ix->rank, ix->n_orig, dense);
@@ -563,7 +568,7 @@ pclhip_status pclhip_gicp_covariances(pclhip_index* ix, int k, double epsilon, d
   // gicp.hpp:77-83: "Number or points in cloud is less than k_correspondences_"
   PCLHIP_REQUIRE(ctx, uint64_t(k) <= ix->n, "number of points in cloud is less than k_correspondences");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-  DeviceGuard guard;
+  DeviceGuard guard(ctx);
   double* cov_sorted = nullptr;
   PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &cov_sorted, size_t(ix->n) * 9 * sizeof(double)));
   guard.add(cov_sorted);
@@ -650,7 +655,7 @@ pclhip_status pclhip_index_set_normals(pclhip_index* ix, const void* normals, si
   PCLHIP_REQUIRE(ctx, normals != nullptr || ix->n_orig == 0, "null normals");
   PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-  DeviceGuard guard;
+  DeviceGuard guard(ctx);
   const void* dn = nullptr;
   void* owned = nullptr;
   pclhip_status st = to_device(ctx, normals, size_t(ix->n_orig) * stride, &dn, &owned);
@@ -760,7 +765,7 @@ pclhip_status pclhip_icp_set_source_indexed(pclhip_icp* icp, const void* points,
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   icp_free_source(icp);
-  DeviceGuard guard;
+  DeviceGuard guard(ctx);
   const void* dp = nullptr;
   void* owned = nullptr;
   pclhip_status st = to_device(ctx, points, size_t(n) * stride, &dp, &owned);
@@ -820,7 +825,7 @@ pclhip_status pclhip_icp_set_source_normals(pclhip_icp* icp, const void* normals
   PCLHIP_REQUIRE(ctx, normals != nullptr || icp->n == 0, "null normals");
   PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-  DeviceGuard guard;
+  DeviceGuard guard(ctx);
   const void* dn = nullptr;
   void* owned = nullptr;
   pclhip_status st = to_device(ctx, normals, size_t(icp->n_orig) * stride, &dn, &owned);
@@ -1122,7 +1127,7 @@ static pclhip_status estimate_pairs_common(pclhip_ctx* ctx, int mode, const void
   double sums[PCLHIP_ICP_NSUMS];
   std::memset(sums, 0, sizeof sums);
   if (n > 0) {
-    DeviceGuard guard;
+    DeviceGuard guard(ctx);
     const void* in[4] = {src, mode == PCLHIP_ICP_SYMMETRIC ? src_normals : nullptr, tgt,
                          mode != PCLHIP_ICP_POINT_TO_POINT ? tgt_normals : nullptr};
     const size_t strides[4] = {src_stride, src_normals_stride, tgt_stride, tgt_normals_stride};
@@ -1200,7 +1205,7 @@ pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_q
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   int32_t* dm = nullptr;
   float* dd = nullptr;
-  DeviceGuard guard;
+  DeviceGuard guard(ctx);
   const size_t no = size_t(icp->n_orig);  // dense arrays over the ORIGINAL source records (a subset leaves gaps)
   PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &dm, no * sizeof(int32_t)));
   guard.add(dm);
@@ -1271,7 +1276,7 @@ pclhip_status pclhip_transform_cloud(pclhip_ctx* ctx, const float* T, int order,
   if (n == 0) return PCLHIP_OK;
   PCLHIP_REQUIRE(ctx, in && out, "null buffer");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-  DeviceGuard guard;
+  DeviceGuard guard(ctx);
   const size_t bytes = size_t(n) * stride;
   const void* din = nullptr;
   void* owned = nullptr;
