@@ -1,13 +1,15 @@
-// index_build.hip -- GPU construction of the Morton-ordered implicit wide BVH.
+// index_build.hip -- GPU construction of the kd-ordered implicit wide BVH.
 //
-//   bbox reduce -> 63-bit Morton key (21 bits/axis, cubic cells) -> radix sort of (key, index)
-//   pairs -> gather to float4 (w = original index) -> leaf boxes (16 points) -> 64-ary box levels.
+//   finite/selected records -> float4 (w = original index) -> kd order (kd_order below): top rounds by radix
+//   selection + partition (kp_*), bottom rounds inside one workgroup's LDS (kd_block_kernel) -> leaf boxes and
+//   discs (16 points) -> 64-ary box levels.
 //
 // Replaces the build half of pcl::KdTreeFLANN<PointT>::setInputCloud
 // (kdtree/include/pcl/kdtree/impl/kdtree_flann.hpp:99-136,428-498): non-finite points are
 // dropped, an optional index list selects a subset, results refer to original cloud indices.
-// The radix sort is rocprim::radix_sort_pairs (one-off per target cloud, not on the per-iteration
-// path); everything else is hand-written.
+// Hand-written throughout on the default path; rocprim's radix sort is only used by the A/B variants
+// (PCLHIP_KD_TOP=sort, PCLHIP_KD_BOTTOM=sort, PCLHIP_ORDER=morton) and by the compaction of clouds that
+// contain non-finite points.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -383,15 +385,16 @@ pclhip_status morton_order(pclhip_ctx* ctx, const void* dev_points, size_t strid
 
 
 // =================================================================================================
-// kd ordering by radix-sort rounds
+// kd ordering
 // =================================================================================================
 // Z-order (Morton) runs of a 2-D surface embedded in 3-D jump: on the benchmark surface the boxes
 // of 16 consecutive Morton-sorted points overlap 4.6x and a few of them span the whole domain, so
 // one wavefront ends up scanning every leaf.  The order produced here has no jumps: R =
-// ceil(log4(#leaves)) rounds, each round sorts every aligned block of LEAF*4^(R-r+1) points along
-// the widest axis of its bounding box (one radix sort of (block id, float coordinate) keys for the
-// whole cloud), so every aligned block of LEAF*4^j points ends up as one cell of a 4-ary kd
-// partition: leaf boxes do not overlap and 64-point query groups are compact.
+// ceil(log4(#leaves)) rounds, each round cuts every aligned block ("segment") of LEAF*4^(R-r+1) points
+// into four slabs at the quartiles along the widest axis of its bounding box, so every aligned block of
+// LEAF*4^j points ends up as one cell of a 4-ary kd partition: leaf boxes do not overlap and 64-point
+// query groups are compact.  Segments above 4096 points are cut by selection + partition (kp_*), the rest
+// by kd_block_kernel; the variant that radix-sorts (segment, coordinate) keys once per round is kept for A/B.
 namespace {
 
 constexpr int KD_CHUNK_MAX = 4096;

@@ -1,7 +1,7 @@
 // pclhip_internal.hpp -- shared host/device definitions of the MI355X ICP hot path.
 //
 // Data layout in HBM (one pclhip_index):
-//   pts   [n_pad]  float4   target points in 63-bit Morton order; .w = original index (bit cast).
+//   pts   [n_pad]  float4   target points in kd order (index_build.hip); .w = original index (bit cast).
 //                           n_pad = n rounded up to a whole leaf; pad slots hold +FLT_MAX
 //                           sentinels with index 0xFFFFFFFF (distance overflows to +inf).
 //   soa   [n1][4*LEAF] float the same points per leaf as x[16] y[16] z[16] w[16] (256 B): the block a
