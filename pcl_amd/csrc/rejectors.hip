@@ -10,8 +10,6 @@
 #include <cstring>
 #include <string.h>
 
-#include <rocprim/rocprim.hpp>
-
 #include <cfloat>
 #include <cmath>
 
@@ -49,6 +47,93 @@ __global__ void rej_dist_key_kernel(const float* __restrict__ d2, const uint8_t*
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(&blk, (unsigned int)__builtin_popcountll(b));
   __syncthreads();
   if (threadIdx.x == 0 && blk) atomicAdd(count, blk);
+}
+
+// ---- radix selection: the key of rank r among n unsigned keys ------------------------------------------------
+// MedianDistance and Trimmed only need ONE order statistic of the kept distances, not a sorted array: digit
+// passes of 11 bits from the top, each a histogram of the keys that match the prefix chosen so far (per-block
+// LDS histogram merged into a global one) followed by a one-workgroup scan that picks the bin holding the rank.
+struct RsState {
+  unsigned long long prefix;  // key bits decided so far (after the last pass: the key itself)
+  uint32_t rank;              // remaining rank inside the chosen bin
+  uint32_t pad;
+};
+constexpr int RS_BINS = 2048;
+
+template <class K>
+__global__ __launch_bounds__(TB) void rs_hist_kernel(const K* __restrict__ keys, uint32_t n, const RsState* __restrict__ st,
+                                                     int shift, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[RS_BINS];
+  for (int i = threadIdx.x; i < RS_BINS; i += TB) h[i] = 0u;
+  __syncthreads();
+  constexpr int BITS = int(sizeof(K)) * 8;
+  const int up = shift + 11;  // the bits above the digit must equal the prefix
+  const unsigned long long prefix = st->prefix;
+  for (uint32_t i = blockIdx.x * TB + threadIdx.x; i < n; i += gridDim.x * TB) {
+    const unsigned long long k = keys[i];
+    if (up >= BITS || (k >> up) == (prefix >> up)) atomicAdd(&h[uint32_t(k >> shift) & uint32_t(RS_BINS - 1)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < RS_BINS; i += TB)
+    if (h[i]) atomicAdd(hist + i, h[i]);
+}
+
+__global__ __launch_bounds__(256) void rs_pick_kernel(RsState* __restrict__ st, const uint32_t* __restrict__ hist, int shift) {
+  constexpr int PER = RS_BINS / 256;
+  uint32_t c[PER], sum = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    c[j] = hist[threadIdx.x * PER + j];
+    sum += c[j];
+  }
+  __shared__ uint32_t scan[256];
+  scan[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const uint32_t v = threadIdx.x >= uint32_t(o) ? scan[threadIdx.x - o] : 0u;
+    __syncthreads();
+    scan[threadIdx.x] += v;
+    __syncthreads();
+  }
+  const uint32_t rank = st->rank;
+  const uint32_t incl = scan[threadIdx.x], excl = incl - sum;
+  __syncthreads();  // every thread has read st->rank before one of them rewrites it
+  if (rank >= excl && rank < incl) {
+    uint32_t cum = excl;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      if (rank >= cum && rank < cum + c[j]) {
+        st->prefix |= (unsigned long long)(threadIdx.x * PER + j) << shift;
+        st->rank = rank - cum;
+      }
+      cum += c[j];
+    }
+  }
+}
+
+// key of rank `rank` (0-based, rank < n) -> *out; synchronises the stream
+template <class K>
+pclhip_status radix_select(pclhip_ctx* ctx, const K* keys, uint32_t n, uint32_t rank, RsState* st_dev, uint32_t* hist_dev,
+                           K* out) {
+  hipStream_t s = ctx->stream;
+  RsState h;
+  h.prefix = 0;
+  h.rank = rank;
+  h.pad = 0;
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(st_dev, &h, sizeof h, hipMemcpyHostToDevice, s));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));  // `h` is a stack object
+  constexpr int BITS = int(sizeof(K)) * 8;
+  int grid = int((n + TB - 1) / TB);
+  if (grid > ctx->num_cus * 8) grid = ctx->num_cus * 8;
+  for (int shift = ((BITS - 1) / 11) * 11; shift >= 0; shift -= 11) {
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(hist_dev, 0, RS_BINS * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(rs_hist_kernel<K>, dim3(grid), dim3(TB), 0, s, keys, n, st_dev, shift, hist_dev);
+    hipLaunchKernelGGL(rs_pick_kernel, dim3(1), dim3(256), 0, s, st_dev, hist_dev, shift);
+  }
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&h, st_dev, sizeof h, hipMemcpyDeviceToHost, s));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  *out = K(h.prefix);
+  return PCLHIP_OK;
 }
 
 // correspondence_rejection_median_distance.cpp:64-66: keep if double(d) <= median * factor
@@ -195,22 +280,23 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
         break;
       }
       case PCLHIP_REJ_MEDIAN_DISTANCE: {
-        uint32_t *k0 = nullptr, *k1 = nullptr;
+        uint32_t* k0 = nullptr;
+        RsState* rs = nullptr;
+        uint32_t* rs_hist = nullptr;
         PCLHIP_CHECK_HIP(ctx, g.alloc(&k0, size_t(n) * 4));
-        PCLHIP_CHECK_HIP(ctx, g.alloc(&k1, size_t(n) * 4));
+        PCLHIP_CHECK_HIP(ctx, g.alloc(&rs, sizeof(RsState)));
+        PCLHIP_CHECK_HIP(ctx, g.alloc(&rs_hist, RS_BINS * sizeof(uint32_t)));
         PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
         hipLaunchKernelGGL(rej_dist_key_kernel, grid, block, 0, s, icp->match_d2, icp->keep, n, k0, d_cnt);
-        size_t tb = 0;
-        PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb, k0, k1, size_t(n), 0, 32, s));
-        void* tmp = nullptr;
-        PCLHIP_CHECK_HIP(ctx, g.alloc(&tmp, tb));
-        PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_keys(tmp, tb, k0, k1, size_t(n), 0, 32, s));
         unsigned int cnt = 0;
         PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
         PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
         if (cnt == 0) break;
-        uint32_t mbits = 0;
-        PCLHIP_CHECK_HIP(ctx, hipMemcpy(&mbits, k1 + (cnt / 2), sizeof mbits, hipMemcpyDeviceToHost));
+        uint32_t mbits = 0;  // dropped slots carry the largest key, so rank cnt / 2 counts kept distances only
+        {
+          const pclhip_status st = radix_select<uint32_t>(ctx, k0, n, cnt / 2, rs, rs_hist, &mbits);
+          if (st != PCLHIP_OK) return st;
+        }
         float mf;
         std::memcpy(&mf, &mbits, sizeof mf);
         icp->last_median = double(mf);  // nth_element at size/2 (:55-56)
@@ -230,9 +316,8 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
         break;
       }
       case PCLHIP_REJ_TRIMMED: {
-        uint64_t *k0 = nullptr, *k1 = nullptr;
+        uint64_t* k0 = nullptr;
         PCLHIP_CHECK_HIP(ctx, g.alloc(&k0, size_t(n) * 8));
-        PCLHIP_CHECK_HIP(ctx, g.alloc(&k1, size_t(n) * 8));
         PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
         hipLaunchKernelGGL(rej_pair_key_kernel, grid, block, 0, s, icp->src_cur, icp->match_d2, icp->keep, n, k0, d_cnt);
         unsigned int cnt = 0;
@@ -246,14 +331,13 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
           if (nv == 0) {
             PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(icp->keep, 0, n, s));
           } else {
-            size_t tb = 0;
-            PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb, k0, k1, size_t(n), 0, 64, s));
-            void* tmp = nullptr;
-            PCLHIP_CHECK_HIP(ctx, g.alloc(&tmp, tb));
-            PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_keys(tmp, tb, k0, k1, size_t(n), 0, 64, s));
-            uint64_t thr = 0;
-            PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&thr, k1 + (nv - 1), sizeof thr, hipMemcpyDeviceToHost, s));
-            PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+            RsState* rs = nullptr;
+            uint32_t* rs_hist = nullptr;
+            PCLHIP_CHECK_HIP(ctx, g.alloc(&rs, sizeof(RsState)));
+            PCLHIP_CHECK_HIP(ctx, g.alloc(&rs_hist, RS_BINS * sizeof(uint32_t)));
+            uint64_t thr = 0;  // the nv-th smallest (distance, query) key
+            const pclhip_status st = radix_select<uint64_t>(ctx, k0, n, nv - 1, rs, rs_hist, &thr);
+            if (st != PCLHIP_OK) return st;
             hipLaunchKernelGGL(rej_trim_kernel, grid, block, 0, s, icp->src_cur, icp->match_d2, n, thr, icp->keep);
           }
           icp->fetch_order = 2;

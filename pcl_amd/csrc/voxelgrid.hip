@@ -112,6 +112,209 @@ __global__ void vg_keep_kernel(const uint32_t* run_start, uint32_t nruns, uint32
   if (r < nruns) keep[r] = ((run_start[r + 1] - run_start[r]) >= min_pts) ? 1u : 0u;
 }
 
+// ---- dense-grid path: counting sort instead of a radix sort -----------------------------------------------
+// When the voxel grid of the cloud's bounding box has no more cells than about twice the points (the usual
+// down-sampling set-up), the (voxel id, point index) pairs need no comparison sort: count the points of every
+// cell with atomics, scan the counts (cell -> first slot, cell -> run number), drop every point index into its
+// cell's slots, and let the thread that owns a cell put its few indices into ascending order before it sums
+// them -- the same arrays the sorting path produces (vals, run_start), bit-identical centroids, about half the
+// time, and no rocprim.  Clouds with a cell of more than VG_DENSE_MAX_RUN points (coarse leaves) take the sorting path.
+constexpr uint32_t VG_DENSE_MAX_RUN = 4096;  // longest run ordered in LDS by one wavefront
+constexpr uint32_t VG_SHORT_RUN = 16;        // runs up to this length are ordered by their owner thread
+constexpr int SC_BLOCK = 4096, SC_THREADS = 256, SC_PER = SC_BLOCK / SC_THREADS;
+
+__global__ __launch_bounds__(256) void vg_count_kernel(const void* pts, size_t stride, uint64_t n, VgGrid g, int has_limits,
+                                                       double lim_min, double lim_max, uint32_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ cnt, unsigned int* n_valid) {
+  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  bool ok = false;
+  if (i < n) {
+    const float* p = rec(pts, stride, i);
+    const float x = p[0], y = p[1], z = p[2];
+    ok = isfinite(x) && isfinite(y) && isfinite(z);
+    if (ok && has_limits) ok = !((double(z) > lim_max) || (double(z) < lim_min));  // :684-695
+    uint32_t key = 0xFFFFFFFFu;
+    if (ok) {  // :713-718
+      const int i0 = int(floorf(__fmul_rn(x, g.inv[0])) - float(g.min_b[0]));
+      const int i1 = int(floorf(__fmul_rn(y, g.inv[1])) - float(g.min_b[1]));
+      const int i2 = int(floorf(__fmul_rn(z, g.inv[2])) - float(g.min_b[2]));
+      key = uint32_t(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
+      atomicAdd(cnt + key, 1u);
+    }
+    keys[i] = key;
+  }
+  __shared__ unsigned int blk;
+  if (threadIdx.x == 0) blk = 0;
+  __syncthreads();
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(ok);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&blk, (unsigned int)__builtin_popcountll(b));
+  __syncthreads();
+  if (threadIdx.x == 0 && blk) atomicAdd(n_valid, blk);
+}
+
+// Exclusive scans of a[i] ("sum") and of (a[i] != 0) ("runs") over m elements, in three launches:
+// block totals -> scan of the totals (one workgroup) -> per-block scan.  tot[0..2] = total sum, total runs, max a[i].
+__global__ __launch_bounds__(SC_THREADS) void sc_partial_kernel(const uint32_t* __restrict__ a, uint64_t m,
+                                                                uint2* __restrict__ partial, uint32_t* __restrict__ tot) {
+  const uint64_t base = uint64_t(blockIdx.x) * SC_BLOCK + uint64_t(threadIdx.x) * SC_PER;
+  uint32_t s = 0, r = 0, mx = 0;
+#pragma unroll
+  for (int e = 0; e < SC_PER; ++e) {
+    const uint64_t i = base + e;
+    const uint32_t v = i < m ? a[i] : 0u;
+    s += v;
+    r += v != 0u ? 1u : 0u;
+    mx = v > mx ? v : mx;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    r += __shfl_xor(r, o);
+    const uint32_t t = __shfl_xor(mx, o);
+    mx = t > mx ? t : mx;
+  }
+  __shared__ uint32_t ws[SC_THREADS / 64][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { ws[wave][0] = s; ws[wave][1] = r; ws[wave][2] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t S = 0, R = 0, M = 0;
+    for (int w = 0; w < SC_THREADS / 64; ++w) { S += ws[w][0]; R += ws[w][1]; M = ws[w][2] > M ? ws[w][2] : M; }
+    partial[blockIdx.x] = make_uint2(S, R);
+    if (M) atomicMax(tot + 2, M);
+  }
+}
+
+__global__ __launch_bounds__(1024) void sc_top_kernel(uint2* __restrict__ partial, uint32_t nb, uint32_t* __restrict__ tot) {
+  __shared__ uint2 sh[1024];
+  uint2 carry = make_uint2(0u, 0u);
+  for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {
+    const uint32_t i = b0 + threadIdx.x;
+    const uint2 own = i < nb ? partial[i] : make_uint2(0u, 0u);
+    sh[threadIdx.x] = own;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      uint2 v = make_uint2(0u, 0u);
+      if (threadIdx.x >= uint32_t(o)) v = sh[threadIdx.x - o];
+      __syncthreads();
+      sh[threadIdx.x].x += v.x;
+      sh[threadIdx.x].y += v.y;
+      __syncthreads();
+    }
+    const uint2 incl = sh[threadIdx.x];
+    if (i < nb) partial[i] = make_uint2(carry.x + incl.x - own.x, carry.y + incl.y - own.y);
+    const uint2 last = sh[1023];
+    __syncthreads();
+    carry.x += last.x;
+    carry.y += last.y;
+  }
+  if (threadIdx.x == 0) {
+    tot[0] = carry.x;
+    tot[1] = carry.y;
+  }
+}
+
+// out_sum[i], out_run[i] (either may be null); run_start (optional): run_start[run of i] = sum before i for every
+// non-zero a[i], plus the end sentinel run_start[total runs] = total sum
+__global__ __launch_bounds__(SC_THREADS) void sc_apply_kernel(const uint32_t* __restrict__ a, uint64_t m,
+                                                              const uint2* __restrict__ partial, uint32_t* __restrict__ out_sum,
+                                                              uint32_t* __restrict__ out_run, uint32_t* __restrict__ run_start) {
+  const uint64_t base = uint64_t(blockIdx.x) * SC_BLOCK + uint64_t(threadIdx.x) * SC_PER;
+  uint32_t v[SC_PER];
+  uint32_t s = 0, r = 0;
+#pragma unroll
+  for (int e = 0; e < SC_PER; ++e) {
+    const uint64_t i = base + e;
+    v[e] = i < m ? a[i] : 0u;
+    s += v[e];
+    r += v[e] != 0u ? 1u : 0u;
+  }
+  // exclusive scan of (s, r) over the workgroup's threads
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t is = s, ir = r;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t ts = __shfl_up(is, o), tr = __shfl_up(ir, o);
+    if (lane >= o) { is += ts; ir += tr; }
+  }
+  __shared__ uint32_t ws[SC_THREADS / 64][2];
+  if (lane == 63) { ws[wave][0] = is; ws[wave][1] = ir; }
+  __syncthreads();
+  uint32_t bs = 0, br = 0;
+  for (int w = 0; w < wave; ++w) { bs += ws[w][0]; br += ws[w][1]; }
+  const uint2 p = partial[blockIdx.x];
+  uint32_t run_s = p.x + bs + is - s, run_r = p.y + br + ir - r;
+#pragma unroll
+  for (int e = 0; e < SC_PER; ++e) {
+    const uint64_t i = base + e;
+    if (i < m) {
+      if (out_sum) out_sum[i] = run_s;
+      if (out_run) out_run[i] = run_r;
+      if (run_start && v[e] != 0u) run_start[run_r] = run_s;
+      run_s += v[e];
+      run_r += v[e] != 0u ? 1u : 0u;
+      if (run_start && i == m - 1) run_start[run_r] = run_s;
+    }
+  }
+}
+
+// every valid point drops its index into one of its cell's slots (any order: the owner of the cell sorts them)
+__global__ __launch_bounds__(256) void vg_fill_kernel(const uint32_t* __restrict__ keys, uint64_t n,
+                                                      const uint32_t* __restrict__ first, uint32_t* __restrict__ cnt,
+                                                      uint32_t* __restrict__ vals) {
+  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t key = keys[i];
+  if (key == 0xFFFFFFFFu) return;
+  const uint32_t slot = atomicSub(cnt + key, 1u) - 1u;
+  vals[first[key] + slot] = uint32_t(i);
+}
+
+// ascending point indices inside every run: short runs by their owner thread (insertion sort) ...
+__global__ __launch_bounds__(256) void vg_sort_runs_kernel(const uint32_t* __restrict__ run_start, uint32_t nruns,
+                                                           uint32_t* __restrict__ vals) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nruns) return;
+  const uint32_t b = run_start[r], e = run_start[r + 1];
+  if (e - b > VG_SHORT_RUN) return;  // vg_sort_long_runs_kernel
+  for (uint32_t j = b + 1; j < e; ++j) {
+    const uint32_t x = vals[j];
+    uint32_t k = j;
+    while (k > b && vals[k - 1] > x) {
+      vals[k] = vals[k - 1];
+      --k;
+    }
+    vals[k] = x;
+  }
+}
+// ... longer ones (<= VG_DENSE_MAX_RUN) by one wavefront each: bitonic network in LDS
+__global__ __launch_bounds__(64) void vg_sort_long_runs_kernel(const uint32_t* __restrict__ run_start, uint32_t nruns,
+                                                               uint32_t* __restrict__ vals) {
+  __shared__ uint32_t buf[VG_DENSE_MAX_RUN];
+  const uint32_t r = blockIdx.x;
+  const uint32_t b = run_start[r], len = run_start[r + 1] - b;
+  if (len <= VG_SHORT_RUN) return;
+  uint32_t P = 32;
+  while (P < len) P <<= 1;
+  for (uint32_t i = threadIdx.x; i < P; i += 64) buf[i] = i < len ? vals[b + i] : 0xFFFFFFFFu;
+  __syncthreads();
+  for (uint32_t k = 2; k <= P; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t q = threadIdx.x; q < P / 2; q += 64) {
+        const uint32_t i = ((q & ~(j - 1u)) << 1) | (q & (j - 1u)), i2 = i | j;
+        const bool up = (i & k) == 0u || k == P;
+        const uint32_t a = buf[i], c = buf[i2];
+        if ((a > c) == up) {
+          buf[i] = c;
+          buf[i2] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = threadIdx.x; i < len; i += 64) vals[b + i] = buf[i];
+}
+
 // one thread per voxel: sequential float accumulation in sorted (= ascending input index) order.
 // Output records of `ostride` bytes: x y z 1 at +0; with normals (noff != 0, pcl::PointNormal layout) and
 // downsample_all_data the CentroidPoint accumulators of common/include/pcl/common/impl/accumulators.hpp:68-127:
@@ -121,7 +324,7 @@ __global__ void vg_keep_kernel(const uint32_t* run_start, uint32_t nruns, uint32
 __global__ __launch_bounds__(256) void vg_centroid_kernel(const void* pts, size_t stride, const uint32_t* vals,
                                                           const uint32_t* run_start, const uint32_t* keep,
                                                           const uint32_t* keep_scan, uint32_t nruns, void* out,
-                                                          size_t ostride, size_t noff, int all_data) {
+                                                          size_t ostride, size_t noff, int all_data, int excl) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nruns || !keep[r]) return;
   const uint32_t b = run_start[r], e = run_start[r + 1];
@@ -141,7 +344,7 @@ __global__ __launch_bounds__(256) void vg_centroid_kernel(const void* pts, size_
     }
   }
   const float cnt = float(e - b);
-  float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + size_t(keep_scan[r] - 1) * ostride);
+  float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + size_t(excl ? keep_scan[r] : keep_scan[r] - 1) * ostride);  // exclusive / inclusive scan of keep
   o[0] = __fdiv_rn(sx, cnt);
   o[1] = __fdiv_rn(sy, cnt);
   o[2] = __fdiv_rn(sz, cnt);
@@ -272,36 +475,93 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   g.mul[1] = div_b[0];
   g.mul[2] = div_b[0] * div_b[1];
 
-  // --- keys + stable sort.  Voxel ids are < div_b[0] * div_b[1] * div_b[2]: only that many key bits need sorting;
-  // rejected points carry the all-ones key, kept apart by ONE extra bit above the ids.
-  int id_bits = 1;
-  while (id_bits < 32 && (int64_t(1) << id_bits) < int64_t(div_b[0]) * div_b[1] * div_b[2]) ++id_bits;
-  const int sort_bits = id_bits < 32 ? id_bits + 1 : 32;
-  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
-  hipLaunchKernelGGL(vg_key_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, dp, stride, n, g, has_z_limits, z_min,
-                     z_max, k0, v0, d_cnt, sort_bits);
-  PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, size_t(n), 0, sort_bits, s));
-  unsigned int nv = 0;
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nv, d_cnt, sizeof nv, hipMemcpyDeviceToHost, s));
-  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-  if (nv == 0) return PCLHIP_OK;
-
-  // --- runs ---
-  hipLaunchKernelGGL(vg_head_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, k1, nv, head);
-  PCLHIP_CHECK_HIP(ctx, rocprim::inclusive_scan(tmp, tmp_bytes, head, scan, size_t(nv), rocprim::plus<uint32_t>(), s));
-  uint32_t nruns = 0;
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nruns, scan + (nv - 1), sizeof nruns, hipMemcpyDeviceToHost, s));
-  hipLaunchKernelGGL(vg_runstart_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, head, scan, nv, run_start);
-  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-  uint32_t* keep = head;        // head / scan are consumed: reuse them for the per-run arrays (nruns <= nv)
+  // --- runs of equal voxel id: vals (point indices, ascending inside a run), run_start, keep, slots ---
+  const int64_t nvox = int64_t(div_b[0]) * div_b[1] * div_b[2];
+  static const bool allow_dense = [] {  // A/B: PCLHIP_VG=sort keeps the radix sort for every grid
+    const char* e = getenv("PCLHIP_VG");
+    return !(e && strcmp(e, "sort") == 0);
+  }();
+  bool dense = allow_dense && nvox <= std::max<int64_t>(2 * int64_t(n), int64_t(1) << 20);
+  uint32_t* keep = head;        // per-run arrays share the per-point ones of the sorting path (nruns <= nv)
   uint32_t* keep_scan = scan;
-  hipLaunchKernelGGL(vg_keep_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, run_start, nruns, min_points_per_voxel,
-                     keep);
-  PCLHIP_CHECK_HIP(ctx, rocprim::inclusive_scan(tmp, tmp_bytes, keep, keep_scan, size_t(nruns), rocprim::plus<uint32_t>(), s));
-  uint32_t total = nruns;
-  if (min_points_per_voxel > 1) {  // otherwise every run is kept: no need to read the count back
-    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&total, keep_scan + (nruns - 1), sizeof total, hipMemcpyDeviceToHost, s));
+  uint32_t nruns = 0, total = 0;
+  unsigned int nv = 0;
+  int excl = 0;
+  const auto scan_u32 = [&](const uint32_t* a, uint64_t m, uint2* partial, uint32_t* tot, uint32_t* out_sum, uint32_t* out_run,
+                            uint32_t* runs) {
+    const uint32_t nb = uint32_t((m + SC_BLOCK - 1) / SC_BLOCK);
+    hipLaunchKernelGGL(sc_partial_kernel, dim3(nb), dim3(SC_THREADS), 0, s, a, m, partial, tot);
+    hipLaunchKernelGGL(sc_top_kernel, dim3(1), dim3(1024), 0, s, partial, nb, tot);
+    hipLaunchKernelGGL(sc_apply_kernel, dim3(nb), dim3(SC_THREADS), 0, s, a, m, partial, out_sum, out_run, runs);
+  };
+  if (dense) {
+    const uint64_t mmax = std::max<uint64_t>(uint64_t(nvox), n);
+    const size_t o_first = align(size_t(nvox) * 4), o_partial = o_first + align(size_t(nvox) * 4);
+    const size_t o_tot = o_partial + align(((mmax + SC_BLOCK - 1) / SC_BLOCK) * sizeof(uint2));
+    char* db = nullptr;
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &db, o_tot + 256));
+    guard.p.push_back(db);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(db);
+    uint32_t* first = reinterpret_cast<uint32_t*>(db + o_first);
+    uint2* partial = reinterpret_cast<uint2*>(db + o_partial);
+    uint32_t* tot = reinterpret_cast<uint32_t*>(db + o_tot);
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(cnt, 0, size_t(nvox) * 4, s));
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(tot, 0, 16, s));
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
+    hipLaunchKernelGGL(vg_count_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, dp, stride, n, g, has_z_limits, z_min,
+                       z_max, k0, cnt, d_cnt);
+    scan_u32(cnt, uint64_t(nvox), partial, tot, first, nullptr, run_start);
+    uint32_t ht[4] = {0, 0, 0, 0};
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(ht, tot, sizeof ht, hipMemcpyDeviceToHost, s));
     PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+    nv = ht[0];
+    nruns = ht[1];
+    if (nv == 0) return PCLHIP_OK;
+    if (ht[2] > VG_DENSE_MAX_RUN) {
+      dense = false;  // coarse leaves: long runs are ordered by the radix sort below
+    } else {
+      hipLaunchKernelGGL(vg_fill_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, k0, n, first, cnt, v1);
+      hipLaunchKernelGGL(vg_sort_runs_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, run_start, nruns, v1);
+      if (ht[2] > VG_SHORT_RUN)
+        hipLaunchKernelGGL(vg_sort_long_runs_kernel, dim3(nruns), dim3(64), 0, s, run_start, nruns, v1);
+      hipLaunchKernelGGL(vg_keep_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, run_start, nruns, min_points_per_voxel,
+                         keep);
+      PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(tot, 0, 16, s));
+      scan_u32(keep, nruns, partial, tot, keep_scan, nullptr, nullptr);
+      excl = 1;
+      total = nruns;
+      if (min_points_per_voxel > 1) {
+        PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&total, tot, sizeof total, hipMemcpyDeviceToHost, s));
+        PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+      }
+    }
+  }
+  if (!dense) {
+    // keys + stable sort.  Voxel ids are < div_b[0] * div_b[1] * div_b[2]: only that many key bits need sorting;
+    // rejected points carry the all-ones key, kept apart by ONE extra bit above the ids.
+    int id_bits = 1;
+    while (id_bits < 32 && (int64_t(1) << id_bits) < nvox) ++id_bits;
+    const int sort_bits = id_bits < 32 ? id_bits + 1 : 32;
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
+    hipLaunchKernelGGL(vg_key_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, dp, stride, n, g, has_z_limits, z_min,
+                       z_max, k0, v0, d_cnt, sort_bits);
+    PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, size_t(n), 0, sort_bits, s));
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nv, d_cnt, sizeof nv, hipMemcpyDeviceToHost, s));
+    PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+    if (nv == 0) return PCLHIP_OK;
+    hipLaunchKernelGGL(vg_head_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, k1, nv, head);
+    PCLHIP_CHECK_HIP(ctx, rocprim::inclusive_scan(tmp, tmp_bytes, head, scan, size_t(nv), rocprim::plus<uint32_t>(), s));
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nruns, scan + (nv - 1), sizeof nruns, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(vg_runstart_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, head, scan, nv, run_start);
+    PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+    hipLaunchKernelGGL(vg_keep_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, run_start, nruns, min_points_per_voxel,
+                       keep);
+    PCLHIP_CHECK_HIP(ctx, rocprim::inclusive_scan(tmp, tmp_bytes, keep, keep_scan, size_t(nruns), rocprim::plus<uint32_t>(), s));
+    total = nruns;
+    if (min_points_per_voxel > 1) {  // otherwise every run is kept: no need to read the count back
+      PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&total, keep_scan + (nruns - 1), sizeof total, hipMemcpyDeviceToHost, s));
+      PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+    }
   }
 
   // --- centroids ---
@@ -315,7 +575,7 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
     if (out_stride != 16 && (normals_offset == 0 || out_stride != normals_offset + 32))
       PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_out, 0, size_t(total) * out_stride, s));  // fields this filter does not fill
     hipLaunchKernelGGL(vg_centroid_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, dp, stride, v1, run_start, keep,
-                       keep_scan, nruns, d_out, out_stride, normals_offset, downsample_all_data ? 1 : 0);
+                       keep_scan, nruns, d_out, out_stride, normals_offset, downsample_all_data ? 1 : 0, excl);
     PCLHIP_CHECK_HIP(ctx, hipGetLastError());
     if (!out_dev)
       PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, d_out, size_t(total) * out_stride, hipMemcpyDeviceToHost, s));

@@ -140,6 +140,36 @@ def test_knn_lattice_ties_lowest_index(gpu, orc):
         assert np.array_equal(gd, od), k
 
 
+@pytest.mark.parametrize("n", [4095, 4096, 4097, 16384, 16385, 65536 + 17, 300_001])
+def test_knn_index_build_segment_boundaries(gpu, orc, n):
+    # The index build cuts segments above 4096 points by radix selection + partition (ties at a quartile are
+    # split by count) and orders the rest inside one workgroup: sizes around the 4096 / 16384 / 65536 segment
+    # boundaries, with partial last segments, on data full of equal coordinates -- a lattice (every splitter is a
+    # tie), a cloud with one constant axis pair (zero-bit key range in later rounds) and many exact duplicates.
+    rng = np.random.default_rng(n)
+    lattice = np.stack([rng.integers(0, 40, n), rng.integers(0, 40, n), rng.integers(0, 3, n)], 1).astype(np.float32) * 0.25
+    line = np.zeros((n, 3), np.float32)
+    line[:, 0] = rng.normal(size=n).astype(np.float32)
+    line[:, 1] = 0.5
+    dup = rng.uniform(-1, 1, (max(n // 7, 1), 3)).astype(np.float32)[rng.integers(0, max(n // 7, 1), n)]
+    for name, pts in (("lattice", lattice), ("line", line), ("duplicates", dup)):
+        qry = (pts[rng.integers(0, n, 2000)] + rng.normal(scale=0.05, size=(2000, 3))).astype(np.float32)
+        tree = build_tree(gpu, pts)
+        assert tree.size() == n
+        gi, gd = tree.nearestKSearch(qry, 4)
+        oi, od = orc.KdTree(pts).knn(qry, 4)
+        assert np.array_equal(gd, od), (name, n)
+        assert np.array_equal(gi, oi), (name, n)
+        # the same cloud again on the warm context (recycled allocations), with a few non-finite records mixed in
+        bad = pts.copy()
+        bad[rng.integers(0, n, 5)] = np.nan
+        ok = np.isfinite(bad).all(1)
+        gi2, gd2 = build_tree(gpu, bad).nearestKSearch(qry, 4)
+        oi2, od2 = orc.KdTree(bad).knn(qry, 4)
+        assert np.array_equal(gd2, od2) and np.array_equal(gi2, oi2), (name, n)
+        assert ok[gi2[gi2 >= 0]].all()
+
+
 def test_knn_duplicates_and_nonfinite(gpu, orc):
     rng = np.random.default_rng(3)
     pts = rng.normal(0, 1, (5000, 3)).astype(np.float32)
