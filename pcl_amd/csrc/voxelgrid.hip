@@ -1,6 +1,6 @@
 // voxelgrid.hip -- pcl::VoxelGrid<pcl::PointXYZ>::applyFilter on the GPU
 // (filters/include/pcl/filters/impl/voxel_grid.hpp:597-814): bounding box -> int32 voxel id per
-// point (same float expressions, :713-718) -> stable radix sort of (voxel id, point index) -> run
+// point (same float expressions, :713-718) -> stable radix sort of (voxel id, point index) (hand-written, below) -> run
 // boundaries -> per-voxel centroid (float sum / count, common/include/pcl/common/impl/
 // accumulators.hpp:68-85) in ascending voxel id order.  Within a voxel the points are summed in
 // ascending input index order (the stable sort fixes what the reference's spreadsort leaves
@@ -8,8 +8,6 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string.h>
-
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cfloat>
@@ -100,11 +98,11 @@ __global__ void vg_head_kernel(const uint32_t* keys, uint32_t nv, uint32_t* head
   if (j < nv) head[j] = (j == 0 || keys[j] != keys[j - 1]) ? 1u : 0u;
 }
 
-// run_start[r] = first sorted position of run r (r = inclusive_scan(head) - 1)
+// run_start[r] = first sorted position of run r (r = exclusive scan of head)
 __global__ void vg_runstart_kernel(const uint32_t* head, const uint32_t* scan, uint32_t nv, uint32_t* run_start) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < nv && head[j]) run_start[scan[j] - 1] = j;
-  if (j == nv - 1) run_start[scan[j]] = nv;  // end sentinel
+  if (j < nv && head[j]) run_start[scan[j]] = j;
+  if (j == nv - 1) run_start[scan[j] + head[j]] = nv;  // end sentinel
 }
 
 __global__ void vg_keep_kernel(const uint32_t* run_start, uint32_t nruns, uint32_t min_pts, uint32_t* keep) {
@@ -112,45 +110,7 @@ __global__ void vg_keep_kernel(const uint32_t* run_start, uint32_t nruns, uint32
   if (r < nruns) keep[r] = ((run_start[r + 1] - run_start[r]) >= min_pts) ? 1u : 0u;
 }
 
-// ---- dense-grid path: counting sort instead of a radix sort -----------------------------------------------
-// When the voxel grid of the cloud's bounding box has no more cells than about twice the points (the usual
-// down-sampling set-up), the (voxel id, point index) pairs need no comparison sort: count the points of every
-// cell with atomics, scan the counts (cell -> first slot, cell -> run number), drop every point index into its
-// cell's slots, and let the thread that owns a cell put its few indices into ascending order before it sums
-// them -- the same arrays the sorting path produces (vals, run_start), bit-identical centroids, about half the
-// time, and no rocprim.  Clouds with a cell of more than VG_DENSE_MAX_RUN points (coarse leaves) take the sorting path.
-constexpr uint32_t VG_DENSE_MAX_RUN = 4096;  // longest run ordered in LDS by one wavefront
-constexpr uint32_t VG_SHORT_RUN = 16;        // runs up to this length are ordered by their owner thread
 constexpr int SC_BLOCK = 4096, SC_THREADS = 256, SC_PER = SC_BLOCK / SC_THREADS;
-
-__global__ __launch_bounds__(256) void vg_count_kernel(const void* pts, size_t stride, uint64_t n, VgGrid g, int has_limits,
-                                                       double lim_min, double lim_max, uint32_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ cnt, unsigned int* n_valid) {
-  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
-  bool ok = false;
-  if (i < n) {
-    const float* p = rec(pts, stride, i);
-    const float x = p[0], y = p[1], z = p[2];
-    ok = isfinite(x) && isfinite(y) && isfinite(z);
-    if (ok && has_limits) ok = !((double(z) > lim_max) || (double(z) < lim_min));  // :684-695
-    uint32_t key = 0xFFFFFFFFu;
-    if (ok) {  // :713-718
-      const int i0 = int(floorf(__fmul_rn(x, g.inv[0])) - float(g.min_b[0]));
-      const int i1 = int(floorf(__fmul_rn(y, g.inv[1])) - float(g.min_b[1]));
-      const int i2 = int(floorf(__fmul_rn(z, g.inv[2])) - float(g.min_b[2]));
-      key = uint32_t(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
-      atomicAdd(cnt + key, 1u);
-    }
-    keys[i] = key;
-  }
-  __shared__ unsigned int blk;
-  if (threadIdx.x == 0) blk = 0;
-  __syncthreads();
-  const unsigned long long b = __builtin_amdgcn_ballot_w64(ok);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&blk, (unsigned int)__builtin_popcountll(b));
-  __syncthreads();
-  if (threadIdx.x == 0 && blk) atomicAdd(n_valid, blk);
-}
 
 // Exclusive scans of a[i] ("sum") and of (a[i] != 0) ("runs") over m elements, in three launches:
 // block totals -> scan of the totals (one workgroup) -> per-block scan.  tot[0..2] = total sum, total runs, max a[i].
@@ -258,61 +218,91 @@ __global__ __launch_bounds__(SC_THREADS) void sc_apply_kernel(const uint32_t* __
   }
 }
 
-// every valid point drops its index into one of its cell's slots (any order: the owner of the cell sorts them)
-__global__ __launch_bounds__(256) void vg_fill_kernel(const uint32_t* __restrict__ keys, uint64_t n,
-                                                      const uint32_t* __restrict__ first, uint32_t* __restrict__ cnt,
-                                                      uint32_t* __restrict__ vals) {
-  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t key = keys[i];
-  if (key == 0xFFFFFFFFu) return;
-  const uint32_t slot = atomicSub(cnt + key, 1u) - 1u;
-  vals[first[key] + slot] = uint32_t(i);
+// ---- stable LSD radix sort of (u32 key, u32 value) pairs, 8 bits per pass --------------------------------------
+// Per pass: digit histogram of every 4096-key block (rs_hist_kernel, digit-major so that one exclusive scan of the
+// 256 x nblocks table yields the first output slot of every (digit, block)), the scan above, and the scatter:
+// a wavefront owns 1024 consecutive keys as 16 rows of 64; lanes with equal digits find each other with eight
+// ballots, the lowest of them bumps the wave's running count of that digit (LDS, no atomics: one leader per digit
+// and row), so every key gets its rank among the equal digits before it -- index order, hence stable.
+constexpr int RS_KPB = 4096, RS_THREADS = 256, RS_ROWS = RS_KPB / RS_THREADS;  // 16 rows per thread
+
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+                                                             uint32_t nblocks, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * uint32_t(RS_KPB);
+#pragma unroll 4
+  for (int r = 0; r < RS_ROWS; ++r) {
+    const uint32_t i = base + uint32_t(r) * RS_THREADS + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[size_t(threadIdx.x) * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// ascending point indices inside every run: short runs by their owner thread (insertion sort) ...
-__global__ __launch_bounds__(256) void vg_sort_runs_kernel(const uint32_t* __restrict__ run_start, uint32_t nruns,
-                                                           uint32_t* __restrict__ vals) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= nruns) return;
-  const uint32_t b = run_start[r], e = run_start[r + 1];
-  if (e - b > VG_SHORT_RUN) return;  // vg_sort_long_runs_kernel
-  for (uint32_t j = b + 1; j < e; ++j) {
-    const uint32_t x = vals[j];
-    uint32_t k = j;
-    while (k > b && vals[k - 1] > x) {
-      vals[k] = vals[k - 1];
-      --k;
-    }
-    vals[k] = x;
-  }
-}
-// ... longer ones (<= VG_DENSE_MAX_RUN) by one wavefront each: bitonic network in LDS
-__global__ __launch_bounds__(64) void vg_sort_long_runs_kernel(const uint32_t* __restrict__ run_start, uint32_t nruns,
-                                                               uint32_t* __restrict__ vals) {
-  __shared__ uint32_t buf[VG_DENSE_MAX_RUN];
-  const uint32_t r = blockIdx.x;
-  const uint32_t b = run_start[r], len = run_start[r + 1] - b;
-  if (len <= VG_SHORT_RUN) return;
-  uint32_t P = 32;
-  while (P < len) P <<= 1;
-  for (uint32_t i = threadIdx.x; i < P; i += 64) buf[i] = i < len ? vals[b + i] : 0xFFFFFFFFu;
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                                const uint32_t* __restrict__ vals_in, uint32_t n, int shift,
+                                                                uint32_t nblocks, const uint32_t* __restrict__ first,
+                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+  constexpr int WAVES = RS_THREADS / 64;
+  __shared__ uint32_t wcnt[WAVES][256];
+  __shared__ uint32_t goff[256];
+  for (int i = threadIdx.x; i < WAVES * 256; i += RS_THREADS) (&wcnt[0][0])[i] = 0u;
+  goff[threadIdx.x] = first[size_t(threadIdx.x) * nblocks + blockIdx.x];
   __syncthreads();
-  for (uint32_t k = 2; k <= P; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t q = threadIdx.x; q < P / 2; q += 64) {
-        const uint32_t i = ((q & ~(j - 1u)) << 1) | (q & (j - 1u)), i2 = i | j;
-        const bool up = (i & k) == 0u || k == P;
-        const uint32_t a = buf[i], c = buf[i2];
-        if ((a > c) == up) {
-          buf[i] = c;
-          buf[i2] = a;
-        }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const uint32_t base = blockIdx.x * uint32_t(RS_KPB) + wave * uint32_t(RS_ROWS * 64);
+  uint32_t key[RS_ROWS], val[RS_ROWS], rk[RS_ROWS];
+#pragma unroll
+  for (int r = 0; r < RS_ROWS; ++r) {
+    const uint32_t i = base + uint32_t(r) * 64u + lane;
+    const bool ok = i < n;
+    key[r] = ok ? keys_in[i] : 0u;
+    val[r] = ok ? vals_in[i] : 0u;
+    const uint32_t d = (key[r] >> shift) & 255u;
+    unsigned long long peers = __builtin_amdgcn_ballot_w64(ok);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    uint32_t before = 0;
+    if (ok) {
+      const int leader = __builtin_ctzll(peers);
+      if (int(lane) == leader) {
+        before = wcnt[wave][d];
+        wcnt[wave][d] = before + uint32_t(__builtin_popcountll(peers));
       }
-      __syncthreads();
+    }
+    // every lane takes part in the shuffle; lanes without a key read their own (unused) value
+    const int src = ok ? __builtin_ctzll(peers) : int(lane);
+    before = __shfl(before, src);
+    rk[r] = ok ? ((d << 16) | (before + uint32_t(__builtin_popcountll(peers & below)))) : 0xFFFFFFFFu;
+    __builtin_amdgcn_wave_barrier();  // the next row's leader reads what this row's leader wrote
+  }
+  __syncthreads();
+  // digit d of this block: waves in order
+  {
+    const uint32_t d = threadIdx.x;
+    uint32_t run = goff[d];
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      const uint32_t c = wcnt[w][d];
+      wcnt[w][d] = run;
+      run += c;
     }
   }
-  for (uint32_t i = threadIdx.x; i < len; i += 64) vals[b + i] = buf[i];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ROWS; ++r) {
+    if (rk[r] != 0xFFFFFFFFu) {
+      const uint32_t d = rk[r] >> 16, pos = wcnt[wave][d] + (rk[r] & 0xFFFFu);
+      keys_out[pos] = key[r];
+      vals_out[pos] = val[r];
+    }
+  }
 }
 
 // one thread per voxel: sequential float accumulation in sorted (= ascending input index) order.
@@ -324,7 +314,7 @@ __global__ __launch_bounds__(64) void vg_sort_long_runs_kernel(const uint32_t* _
 __global__ __launch_bounds__(256) void vg_centroid_kernel(const void* pts, size_t stride, const uint32_t* vals,
                                                           const uint32_t* run_start, const uint32_t* keep,
                                                           const uint32_t* keep_scan, uint32_t nruns, void* out,
-                                                          size_t ostride, size_t noff, int all_data, int excl) {
+                                                          size_t ostride, size_t noff, int all_data) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nruns || !keep[r]) return;
   const uint32_t b = run_start[r], e = run_start[r + 1];
@@ -344,7 +334,7 @@ __global__ __launch_bounds__(256) void vg_centroid_kernel(const void* pts, size_
     }
   }
   const float cnt = float(e - b);
-  float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + size_t(excl ? keep_scan[r] : keep_scan[r] - 1) * ostride);  // exclusive / inclusive scan of keep
+  float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + size_t(keep_scan[r]) * ostride);  // keep_scan: exclusive scan of keep
   o[0] = __fdiv_rn(sx, cnt);
   o[1] = __fdiv_rn(sy, cnt);
   o[2] = __fdiv_rn(sz, cnt);
@@ -409,14 +399,11 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   guard.p.push_back(owned);
 
   // One scratch block for everything (the context keeps it between calls: no allocation on a warm context).
-  size_t sort_bytes = 0, scan_bytes = 0;
-  {
-    uint32_t* z = nullptr;
-    PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, z, z, z, z, size_t(n), 0, 32, s));
-    PCLHIP_CHECK_HIP(ctx, rocprim::inclusive_scan(nullptr, scan_bytes, z, z, size_t(n), rocprim::plus<uint32_t>(), s));
-  }
   auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
   const int nb = int(std::min<uint64_t>((n + 2047) / 2048, 1024));
+  const uint32_t sort_blocks = uint32_t((n + RS_KPB - 1) / RS_KPB);
+  const size_t table = size_t(256) * sort_blocks;                       // digit histogram of one sorting pass
+  const size_t scan_blocks = (std::max<size_t>(table, n) + SC_BLOCK - 1) / SC_BLOCK;
   const size_t o_part = 0;
   const size_t o_k0 = o_part + align(size_t(nb) * 6 * sizeof(float));
   const size_t o_k1 = o_k0 + align(n * sizeof(uint32_t));
@@ -426,8 +413,11 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   const size_t o_scan = o_head + align(n * sizeof(uint32_t));   // scan, later keep_scan
   const size_t o_runs = o_scan + align(n * sizeof(uint32_t));   // run_start [nruns + 1]
   const size_t o_cnt = o_runs + align((n + 1) * sizeof(uint32_t));
-  const size_t o_tmp = o_cnt + align(sizeof(unsigned int));
-  const size_t total_bytes = o_tmp + align(std::max(sort_bytes, scan_bytes));
+  const size_t o_hist = o_cnt + align(sizeof(unsigned int));
+  const size_t o_first = o_hist + align(table * sizeof(uint32_t));
+  const size_t o_sp = o_first + align(table * sizeof(uint32_t));
+  const size_t o_tot = o_sp + align(scan_blocks * sizeof(uint2));
+  const size_t total_bytes = o_tot + align(4 * sizeof(uint32_t));
   st = ensure_scratch(ctx, total_bytes);
   if (st != PCLHIP_OK) return st;
   char* base = static_cast<char*>(ctx->scratch);
@@ -440,8 +430,18 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   uint32_t* scan = reinterpret_cast<uint32_t*>(base + o_scan);
   uint32_t* run_start = reinterpret_cast<uint32_t*>(base + o_runs);
   unsigned int* d_cnt = reinterpret_cast<unsigned int*>(base + o_cnt);
-  void* tmp = base + o_tmp;
-  size_t tmp_bytes = std::max(sort_bytes, scan_bytes);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(base + o_hist);
+  uint32_t* first = reinterpret_cast<uint32_t*>(base + o_first);
+  uint2* sc_partial = reinterpret_cast<uint2*>(base + o_sp);
+  uint32_t* tot = reinterpret_cast<uint32_t*>(base + o_tot);
+  // exclusive scan of a[0..m) into out_sum (tot[0] = total) -- three small launches (sc_* above)
+  const auto scan_u32 = [&](const uint32_t* a, uint64_t m, uint32_t* out_sum) {
+    const uint32_t blocks = uint32_t((m + SC_BLOCK - 1) / SC_BLOCK);
+    hipLaunchKernelGGL(sc_partial_kernel, dim3(blocks), dim3(SC_THREADS), 0, s, a, m, sc_partial, tot);
+    hipLaunchKernelGGL(sc_top_kernel, dim3(1), dim3(1024), 0, s, sc_partial, blocks, tot);
+    hipLaunchKernelGGL(sc_apply_kernel, dim3(blocks), dim3(SC_THREADS), 0, s, a, m, sc_partial, out_sum,
+                       static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr));
+  };
 
   // --- bounding box (getMinMax3D) ---
   hipLaunchKernelGGL(vg_minmax_kernel, dim3(nb), dim3(256), 0, s, dp, stride, n, has_z_limits, float(z_min), float(z_max),
@@ -475,93 +475,46 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   g.mul[1] = div_b[0];
   g.mul[2] = div_b[0] * div_b[1];
 
-  // --- runs of equal voxel id: vals (point indices, ascending inside a run), run_start, keep, slots ---
+  // --- keys + stable sort.  Voxel ids are < div_b[0] * div_b[1] * div_b[2]: only that many key bits need sorting;
+  // rejected points carry the all-ones key, kept apart by ONE extra bit above the ids.
   const int64_t nvox = int64_t(div_b[0]) * div_b[1] * div_b[2];
-  static const bool allow_dense = [] {  // A/B: PCLHIP_VG=sort keeps the radix sort for every grid
-    const char* e = getenv("PCLHIP_VG");
-    return !(e && strcmp(e, "sort") == 0);
-  }();
-  bool dense = allow_dense && nvox <= std::max<int64_t>(2 * int64_t(n), int64_t(1) << 20);
-  uint32_t* keep = head;        // per-run arrays share the per-point ones of the sorting path (nruns <= nv)
-  uint32_t* keep_scan = scan;
-  uint32_t nruns = 0, total = 0;
-  unsigned int nv = 0;
-  int excl = 0;
-  const auto scan_u32 = [&](const uint32_t* a, uint64_t m, uint2* partial, uint32_t* tot, uint32_t* out_sum, uint32_t* out_run,
-                            uint32_t* runs) {
-    const uint32_t nb = uint32_t((m + SC_BLOCK - 1) / SC_BLOCK);
-    hipLaunchKernelGGL(sc_partial_kernel, dim3(nb), dim3(SC_THREADS), 0, s, a, m, partial, tot);
-    hipLaunchKernelGGL(sc_top_kernel, dim3(1), dim3(1024), 0, s, partial, nb, tot);
-    hipLaunchKernelGGL(sc_apply_kernel, dim3(nb), dim3(SC_THREADS), 0, s, a, m, partial, out_sum, out_run, runs);
-  };
-  if (dense) {
-    const uint64_t mmax = std::max<uint64_t>(uint64_t(nvox), n);
-    const size_t o_first = align(size_t(nvox) * 4), o_partial = o_first + align(size_t(nvox) * 4);
-    const size_t o_tot = o_partial + align(((mmax + SC_BLOCK - 1) / SC_BLOCK) * sizeof(uint2));
-    char* db = nullptr;
-    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &db, o_tot + 256));
-    guard.p.push_back(db);
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(db);
-    uint32_t* first = reinterpret_cast<uint32_t*>(db + o_first);
-    uint2* partial = reinterpret_cast<uint2*>(db + o_partial);
-    uint32_t* tot = reinterpret_cast<uint32_t*>(db + o_tot);
-    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(cnt, 0, size_t(nvox) * 4, s));
-    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(tot, 0, 16, s));
-    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
-    hipLaunchKernelGGL(vg_count_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, dp, stride, n, g, has_z_limits, z_min,
-                       z_max, k0, cnt, d_cnt);
-    scan_u32(cnt, uint64_t(nvox), partial, tot, first, nullptr, run_start);
-    uint32_t ht[4] = {0, 0, 0, 0};
-    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(ht, tot, sizeof ht, hipMemcpyDeviceToHost, s));
-    PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-    nv = ht[0];
-    nruns = ht[1];
-    if (nv == 0) return PCLHIP_OK;
-    if (ht[2] > VG_DENSE_MAX_RUN) {
-      dense = false;  // coarse leaves: long runs are ordered by the radix sort below
-    } else {
-      hipLaunchKernelGGL(vg_fill_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, k0, n, first, cnt, v1);
-      hipLaunchKernelGGL(vg_sort_runs_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, run_start, nruns, v1);
-      if (ht[2] > VG_SHORT_RUN)
-        hipLaunchKernelGGL(vg_sort_long_runs_kernel, dim3(nruns), dim3(64), 0, s, run_start, nruns, v1);
-      hipLaunchKernelGGL(vg_keep_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, run_start, nruns, min_points_per_voxel,
-                         keep);
-      PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(tot, 0, 16, s));
-      scan_u32(keep, nruns, partial, tot, keep_scan, nullptr, nullptr);
-      excl = 1;
-      total = nruns;
-      if (min_points_per_voxel > 1) {
-        PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&total, tot, sizeof total, hipMemcpyDeviceToHost, s));
-        PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-      }
-    }
+  int id_bits = 1;
+  while (id_bits < 32 && (int64_t(1) << id_bits) < nvox) ++id_bits;
+  const int sort_bits = id_bits < 32 ? id_bits + 1 : 32;
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
+  hipLaunchKernelGGL(vg_key_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, dp, stride, n, g, has_z_limits, z_min,
+                     z_max, k0, v0, d_cnt, sort_bits);
+  for (int shift = 0; shift < sort_bits; shift += 8) {  // stable LSD passes (rs_* above), ping-pong k0/v0 <-> k1/v1
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(sort_blocks), dim3(RS_THREADS), 0, s, k0, uint32_t(n), shift, sort_blocks, hist);
+    scan_u32(hist, table, first);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(sort_blocks), dim3(RS_THREADS), 0, s, k0, v0, uint32_t(n), shift, sort_blocks,
+                       first, k1, v1);
+    std::swap(k0, k1);
+    std::swap(v0, v1);
   }
-  if (!dense) {
-    // keys + stable sort.  Voxel ids are < div_b[0] * div_b[1] * div_b[2]: only that many key bits need sorting;
-    // rejected points carry the all-ones key, kept apart by ONE extra bit above the ids.
-    int id_bits = 1;
-    while (id_bits < 32 && (int64_t(1) << id_bits) < nvox) ++id_bits;
-    const int sort_bits = id_bits < 32 ? id_bits + 1 : 32;
-    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
-    hipLaunchKernelGGL(vg_key_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, dp, stride, n, g, has_z_limits, z_min,
-                       z_max, k0, v0, d_cnt, sort_bits);
-    PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, size_t(n), 0, sort_bits, s));
-    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nv, d_cnt, sizeof nv, hipMemcpyDeviceToHost, s));
+  const uint32_t* keys_sorted = k0;   // after the last swap
+  const uint32_t* vals_sorted = v0;
+  unsigned int nv = 0;
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nv, d_cnt, sizeof nv, hipMemcpyDeviceToHost, s));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  if (nv == 0) return PCLHIP_OK;
+
+  // --- runs ---
+  hipLaunchKernelGGL(vg_head_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, keys_sorted, nv, head);
+  scan_u32(head, nv, scan);
+  uint32_t nruns = 0;
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nruns, tot, sizeof nruns, hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(vg_runstart_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, head, scan, nv, run_start);
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  uint32_t* keep = head;        // head / scan are consumed: reuse them for the per-run arrays (nruns <= nv)
+  uint32_t* keep_scan = scan;
+  hipLaunchKernelGGL(vg_keep_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, run_start, nruns, min_points_per_voxel,
+                     keep);
+  scan_u32(keep, nruns, keep_scan);
+  uint32_t total = nruns;
+  if (min_points_per_voxel > 1) {  // otherwise every run is kept: no need to read the count back
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&total, tot, sizeof total, hipMemcpyDeviceToHost, s));
     PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-    if (nv == 0) return PCLHIP_OK;
-    hipLaunchKernelGGL(vg_head_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, k1, nv, head);
-    PCLHIP_CHECK_HIP(ctx, rocprim::inclusive_scan(tmp, tmp_bytes, head, scan, size_t(nv), rocprim::plus<uint32_t>(), s));
-    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nruns, scan + (nv - 1), sizeof nruns, hipMemcpyDeviceToHost, s));
-    hipLaunchKernelGGL(vg_runstart_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, head, scan, nv, run_start);
-    PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-    hipLaunchKernelGGL(vg_keep_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, run_start, nruns, min_points_per_voxel,
-                       keep);
-    PCLHIP_CHECK_HIP(ctx, rocprim::inclusive_scan(tmp, tmp_bytes, keep, keep_scan, size_t(nruns), rocprim::plus<uint32_t>(), s));
-    total = nruns;
-    if (min_points_per_voxel > 1) {  // otherwise every run is kept: no need to read the count back
-      PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&total, keep_scan + (nruns - 1), sizeof total, hipMemcpyDeviceToHost, s));
-      PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-    }
   }
 
   // --- centroids ---
@@ -574,8 +527,8 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   if (total > 0) {
     if (out_stride != 16 && (normals_offset == 0 || out_stride != normals_offset + 32))
       PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_out, 0, size_t(total) * out_stride, s));  // fields this filter does not fill
-    hipLaunchKernelGGL(vg_centroid_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, dp, stride, v1, run_start, keep,
-                       keep_scan, nruns, d_out, out_stride, normals_offset, downsample_all_data ? 1 : 0, excl);
+    hipLaunchKernelGGL(vg_centroid_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, dp, stride, vals_sorted, run_start, keep,
+                       keep_scan, nruns, d_out, out_stride, normals_offset, downsample_all_data ? 1 : 0);
     PCLHIP_CHECK_HIP(ctx, hipGetLastError());
     if (!out_dev)
       PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, d_out, size_t(total) * out_stride, hipMemcpyDeviceToHost, s));
