@@ -617,34 +617,64 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
     float best = ex;
     if (ey > best) { best = ey; a = 1; }
     if (ez > best) { a = 2; }
-    // (b) keys: the coordinate along that axis in unsigned order; padding sorts last
+    // (b) keys: the coordinate along that axis in unsigned order; padding sorts last.  The thread's four
+    // (key, position) pairs live in registers from here on.
+    uint32_t kk[4], pp[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const uint32_t p = 4u * t + uint32_t(e);
       const float c = a == 0 ? s.x[idx[e]] : (a == 1 ? s.y[idx[e]] : s.z[idx[e]]);
-      s.key[p] = p < cnt ? orderable(c) : 0xFFFFFFFFu;
+      kk[e] = p < cnt ? orderable(c) : 0xFFFFFFFFu;
+      pp[e] = idx[e];
     }
-    __syncthreads();
-    // (c) bitonic sort of (key, perm) inside every sub-segment, ascending
+    // (c) bitonic sort of (key, position) inside every sub-segment, ascending.  Element i = 4t + e meets i ^ j:
+    // inside the thread for j < 4, across lanes (shuffle) for j < 256, through LDS above that -- 13 of the 205
+    // stages of a 4096-point block need a workgroup barrier.
     for (uint32_t k = 2; k <= nsub; k <<= 1) {
       for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        uint32_t ok[4], op[4];
+        if (j >= 256u) {
+          __syncthreads();  // earlier readers of key / perm are done
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const uint32_t q = t + uint32_t(e) * KDB_THREADS;
-          const uint32_t i = ((q & ~(j - 1u)) << 1) | (q & (j - 1u));
-          const uint32_t i2 = i | j;
-          const bool up = ((i & (nsub - 1u)) & k) == 0u;
-          const uint32_t ka = s.key[i], kb = s.key[i2];
-          const uint16_t pa = s.perm[i], pb = s.perm[i2];
-          const bool gt = ka > kb || (ka == kb && pa > pb);
-          if (gt == up) {
-            s.key[i] = kb; s.key[i2] = ka;
-            s.perm[i] = pb; s.perm[i2] = pa;
+          for (int e = 0; e < 4; ++e) {
+            s.key[4u * t + uint32_t(e)] = kk[e];
+            s.perm[4u * t + uint32_t(e)] = uint16_t(pp[e]);
+          }
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t ip = (4u * t + uint32_t(e)) ^ j;
+            ok[e] = s.key[ip];
+            op[e] = s.perm[ip];
+          }
+        } else if (j >= 4u) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ok[e] = __shfl_xor(kk[e], int(j >> 2));
+            op[e] = __shfl_xor(pp[e], int(j >> 2));
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ok[e] = j == 1u ? kk[e ^ 1] : kk[e ^ 2];
+            op[e] = j == 1u ? pp[e ^ 1] : pp[e ^ 2];
           }
         }
-        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t i = 4u * t + uint32_t(e);
+          const bool lower = (i & j) == 0u, up = ((i & (nsub - 1u)) & k) == 0u;
+          const bool less = kk[e] < ok[e] || (kk[e] == ok[e] && pp[e] < op[e]);
+          const bool keep_own = (lower == up) == less;   // the lower slot of an ascending pair keeps the smaller one
+          kk[e] = keep_own ? kk[e] : ok[e];
+          pp[e] = keep_own ? pp[e] : op[e];
+        }
       }
     }
+    __syncthreads();  // readers of perm (this level's idx[], the LDS stages) are done
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s.perm[4u * t + uint32_t(e)] = uint16_t(pp[e]);
+    __syncthreads();
     if (nsub == 32u) break;  // (guards the unsigned loop condition when bottom_nsub is 32)
   }
   for (uint32_t p = t; p < cnt; p += KDB_THREADS) out[base + p] = in[base + s.perm[p]];

@@ -64,14 +64,13 @@ struct VgGrid {
 };
 
 __global__ __launch_bounds__(256) void vg_key_kernel(const void* pts, size_t stride, uint64_t n, VgGrid g, int has_limits,
-                                                     double lim_min, double lim_max, uint32_t* keys, uint32_t* vals,
+                                                     double lim_min, double lim_max, uint32_t* keys,
                                                      unsigned int* n_valid, int sort_bits) {
-  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
-  bool ok = false;
-  if (i < n) {
+  unsigned int mine = 0;
+  for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
     const float* p = rec(pts, stride, i);
     const float x = p[0], y = p[1], z = p[2];
-    ok = isfinite(x) && isfinite(y) && isfinite(z);
+    bool ok = isfinite(x) && isfinite(y) && isfinite(z);
     if (ok && has_limits) ok = !((double(z) > lim_max) || (double(z) < lim_min));  // :684-695
     uint32_t key = sort_bits >= 32 ? 0xFFFFFFFFu : ((1u << sort_bits) - 1u);  // rejected: after every voxel id
     if (ok) {  // :713-718
@@ -79,16 +78,16 @@ __global__ __launch_bounds__(256) void vg_key_kernel(const void* pts, size_t str
       const int i1 = int(floorf(__fmul_rn(y, g.inv[1])) - float(g.min_b[1]));
       const int i2 = int(floorf(__fmul_rn(z, g.inv[2])) - float(g.min_b[2]));
       key = uint32_t(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
+      ++mine;
     }
     keys[i] = key;
-    vals[i] = uint32_t(i);
   }
-  // one atomic per block (a per-wave atomic on a single counter serialises: ~1.8 ms at 10M points)
+  // one atomic per block of a grid that is sized to the machine, not to the cloud (39k single-address atomics -- one
+  // per 256 points -- took 0.4 ms of this kernel's 0.45 at 10M points)
   __shared__ unsigned int blk;
   if (threadIdx.x == 0) blk = 0;
   __syncthreads();
-  const unsigned long long b = __builtin_amdgcn_ballot_w64(ok);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&blk, (unsigned int)__builtin_popcountll(b));
+  if (mine) atomicAdd(&blk, mine);
   __syncthreads();
   if (threadIdx.x == 0 && blk) atomicAdd(n_valid, blk);
 }
@@ -260,7 +259,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
     const uint32_t i = base + uint32_t(r) * 64u + lane;
     const bool ok = i < n;
     key[r] = ok ? keys_in[i] : 0u;
-    val[r] = ok ? vals_in[i] : 0u;
+    val[r] = ok ? (vals_in ? vals_in[i] : i) : 0u;   // first pass: the value is the point index
     const uint32_t d = (key[r] >> shift) & 255u;
     unsigned long long peers = __builtin_amdgcn_ballot_w64(ok);
 #pragma unroll
@@ -351,6 +350,67 @@ __global__ __launch_bounds__(256) void vg_centroid_kernel(const void* pts, size_
     }
     q[0] = a; q[1] = bb; q[2] = c; q[3] = 0.0f;
     q[4] = k; q[5] = 0.0f; q[6] = 0.0f; q[7] = 0.0f;
+  }
+}
+
+// The same for LONG runs (coarse leaves: hundreds of points per voxel): one wavefront per run gathers 64 points at
+// a time and every lane adds them up in index order from lane broadcasts -- the float sums stay sequential (and
+// bit-identical), the gathers do not.
+__global__ __launch_bounds__(256) void vg_centroid_wave_kernel(const void* pts, size_t stride, const uint32_t* vals,
+                                                               const uint32_t* run_start, const uint32_t* keep,
+                                                               const uint32_t* keep_scan, uint32_t nruns, void* out,
+                                                               size_t ostride, size_t noff, int all_data) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const bool with_n = noff != 0 && all_data;
+  for (uint32_t r = wave; r < nruns; r += nwaves) {
+    if (!keep[r]) continue;
+    const uint32_t b = run_start[r], e = run_start[r + 1];
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f, cv = 0.0f;
+    for (uint32_t c = b; c < e; c += 64u) {
+      const uint32_t m = (e - c) < 64u ? (e - c) : 64u;
+      float px = 0.0f, py = 0.0f, pz = 0.0f, qx = 0.0f, qy = 0.0f, qz = 0.0f, qc = 0.0f;
+      if (lane < m) {
+        const float* p = rec(pts, stride, vals[c + lane]);
+        px = p[0]; py = p[1]; pz = p[2];
+        if (with_n) {
+          const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + noff);
+          qx = q[0]; qy = q[1]; qz = q[2]; qc = q[4];
+        }
+      }
+      for (uint32_t j = 0; j < m; ++j) {  // j is wave-uniform: v_readlane broadcasts
+        sx = __fadd_rn(sx, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), int(j))));
+        sy = __fadd_rn(sy, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), int(j))));
+        sz = __fadd_rn(sz, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), int(j))));
+        if (with_n) {
+          nx = __fadd_rn(nx, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), int(j))));
+          ny = __fadd_rn(ny, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), int(j))));
+          nz = __fadd_rn(nz, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), int(j))));
+          cv = __fadd_rn(cv, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qc), int(j))));
+        }
+      }
+    }
+    if (lane == 0) {
+      const float cnt = float(e - b);
+      float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + size_t(keep_scan[r]) * ostride);
+      o[0] = __fdiv_rn(sx, cnt);
+      o[1] = __fdiv_rn(sy, cnt);
+      o[2] = __fdiv_rn(sz, cnt);
+      if (ostride >= 16) o[3] = 1.0f;
+      if (noff != 0) {
+        float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(o) + noff);
+        float a = 0.0f, bb = 0.0f, cc = 0.0f, k = 0.0f;
+        if (with_n) {
+          const float len = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+          a = __fdiv_rn(nx, len);
+          bb = __fdiv_rn(ny, len);
+          cc = __fdiv_rn(nz, len);
+          k = __fdiv_rn(cv, cnt);
+        }
+        q[0] = a; q[1] = bb; q[2] = cc; q[3] = 0.0f;
+        q[4] = k; q[5] = 0.0f; q[6] = 0.0f; q[7] = 0.0f;
+      }
+    }
   }
 }
 
@@ -482,13 +542,13 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   while (id_bits < 32 && (int64_t(1) << id_bits) < nvox) ++id_bits;
   const int sort_bits = id_bits < 32 ? id_bits + 1 : 32;
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
-  hipLaunchKernelGGL(vg_key_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, dp, stride, n, g, has_z_limits, z_min,
-                     z_max, k0, v0, d_cnt, sort_bits);
+  hipLaunchKernelGGL(vg_key_kernel, dim3(unsigned(std::min<uint64_t>((n + 255) / 256, uint64_t(ctx->num_cus) * 16))), dim3(256), 0,
+                     s, dp, stride, n, g, has_z_limits, z_min, z_max, k0, d_cnt, sort_bits);
   for (int shift = 0; shift < sort_bits; shift += 8) {  // stable LSD passes (rs_* above), ping-pong k0/v0 <-> k1/v1
     hipLaunchKernelGGL(rs_hist_kernel, dim3(sort_blocks), dim3(RS_THREADS), 0, s, k0, uint32_t(n), shift, sort_blocks, hist);
     scan_u32(hist, table, first);
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(sort_blocks), dim3(RS_THREADS), 0, s, k0, v0, uint32_t(n), shift, sort_blocks,
-                       first, k1, v1);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(sort_blocks), dim3(RS_THREADS), 0, s, k0,
+                       shift == 0 ? static_cast<const uint32_t*>(nullptr) : v0, uint32_t(n), shift, sort_blocks, first, k1, v1);
     std::swap(k0, k1);
     std::swap(v0, v1);
   }
@@ -527,8 +587,14 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   if (total > 0) {
     if (out_stride != 16 && (normals_offset == 0 || out_stride != normals_offset + 32))
       PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_out, 0, size_t(total) * out_stride, s));  // fields this filter does not fill
-    hipLaunchKernelGGL(vg_centroid_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, dp, stride, vals_sorted, run_start, keep,
-                       keep_scan, nruns, d_out, out_stride, normals_offset, downsample_all_data ? 1 : 0);
+    if (uint64_t(nv) > uint64_t(nruns) * 16) {  // long runs on average: a wavefront per run
+      const unsigned blocks = unsigned(std::min<uint64_t>((uint64_t(nruns) + 3) / 4, uint64_t(ctx->num_cus) * 16));
+      hipLaunchKernelGGL(vg_centroid_wave_kernel, dim3(blocks), dim3(256), 0, s, dp, stride, vals_sorted, run_start, keep,
+                         keep_scan, nruns, d_out, out_stride, normals_offset, downsample_all_data ? 1 : 0);
+    } else {
+      hipLaunchKernelGGL(vg_centroid_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, dp, stride, vals_sorted, run_start, keep,
+                         keep_scan, nruns, d_out, out_stride, normals_offset, downsample_all_data ? 1 : 0);
+    }
     PCLHIP_CHECK_HIP(ctx, hipGetLastError());
     if (!out_dev)
       PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, d_out, size_t(total) * out_stride, hipMemcpyDeviceToHost, s));
