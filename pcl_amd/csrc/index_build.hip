@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "pclhip_internal.hpp"
+#include "device_scan.hpp"
 
 namespace pclhip {
 
@@ -993,24 +994,24 @@ struct Scale3 {
   float x, y, z;
 };
 __global__ __launch_bounds__(256) void kd_flag_kernel(const void* pts, size_t stride, const int32_t* sel, uint64_t m,
-                                                      uint32_t* keys, uint32_t* vals, unsigned int* n_finite, Scale3 sc) {
-  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
-  bool fin = false;
-  if (i < m) {
+                                                      uint32_t* __restrict__ flags, Scale3 sc) {
+  for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < m; i += uint64_t(gridDim.x) * blockDim.x) {
     const uint64_t rec = sel ? uint64_t(sel[i]) : i;
     const float* p = record(pts, stride, rec);
-    fin = (sc.x == 0.0f || isfinite(p[0])) && (sc.y == 0.0f || isfinite(p[1])) && (sc.z == 0.0f || isfinite(p[2]));
-    keys[i] = fin ? 0u : 1u;
-    vals[i] = uint32_t(rec);
+    const bool fin = (sc.x == 0.0f || isfinite(p[0])) && (sc.y == 0.0f || isfinite(p[1])) && (sc.z == 0.0f || isfinite(p[2]));
+    flags[i] = fin ? 1u : 0u;
   }
-  // one atomic per block (a per-wave atomic on a single counter serialises: 1.8 ms at 10M points)
-  __shared__ unsigned int blk;
-  if (threadIdx.x == 0) blk = 0;
-  __syncthreads();
-  const unsigned long long b = __builtin_amdgcn_ballot_w64(fin);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&blk, (unsigned int)__builtin_popcountll(b));
-  __syncthreads();
-  if (threadIdx.x == 0 && blk) atomicAdd(n_finite, blk);
+}
+// stable two-way partition: finite records keep their order in front, the others keep theirs behind them
+// (before[i] = exclusive scan of flags = finite records before i)
+__global__ __launch_bounds__(256) void kd_compact_kernel(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ before,
+                                                         const int32_t* sel, uint64_t m, uint32_t nf,
+                                                         uint32_t* __restrict__ vals) {
+  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t rec = sel ? uint32_t(sel[i]) : uint32_t(i);
+  const uint32_t pos = flags[i] ? before[i] : nf + (uint32_t(i) - before[i]);
+  vals[pos] = rec;
 }
 
 // the common case needs no compaction at all: count the finite selected records first (read-only pass)
@@ -1131,11 +1132,15 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
   if (uint64_t(hn) == m) {  // every record is finite: slot j <- record j, no compaction sort
     hipLaunchKernelGGL(kd_load_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride,
                        (const uint32_t*)nullptr, dev_sel, m, pa, ids_from_w ? 1 : 0, sc, scaled);
-  } else {
-    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(cn, 0, sizeof(unsigned int), s));
-    hipLaunchKernelGGL(kd_flag_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride, dev_sel, m, f0, v0,
-                       cn, sc);
-    PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, temp_bytes, f0, f1, v0, v1, size_t(m), 0, 1, s));
+  } else {  // stable compaction: flags -> exclusive scan (device_scan.hpp) -> scatter of the record numbers
+    uint32_t* flags = f0;
+    uint32_t* before = f1;
+    uint2* sc_part = reinterpret_cast<uint2*>(tmp);
+    uint32_t* sc_tot = reinterpret_cast<uint32_t*>(cb);   // 16 bytes of a region that is not in use yet
+    const unsigned grid = unsigned(std::min<uint64_t>((m + 255) / 256, uint64_t(ctx->num_cus) * 16));
+    hipLaunchKernelGGL(kd_flag_kernel, dim3(grid), dim3(256), 0, s, dev_points, stride, dev_sel, m, flags, sc);
+    launch_scan_u32(s, flags, m, sc_part, sc_tot, before);
+    hipLaunchKernelGGL(kd_compact_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, flags, before, dev_sel, m, hn, v1);
     hipLaunchKernelGGL(kd_load_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride, v1,
                        (const int32_t*)nullptr, m, pa, ids_from_w ? 1 : 0, sc, scaled);
   }
@@ -1224,15 +1229,15 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
         const size_t hist_bytes = size_t(nseg) * 3 * KP_BINS * sizeof(uint32_t);
         hipLaunchKernelGGL(kp_param_kernel, dim3(unsigned((uint64_t(nseg) * WAVE + 255) / 256)), dim3(256), 0, s, cb, nchunks,
                            chunks_per_seg, nseg, nf, seg_size, sp, sel);
-        PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(hist, 0, hist_bytes, s));
+        PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(hist, 0, 3 * hist_bytes, s));   // one table per digit pass
+        uint32_t* hist2 = hist + hist_bytes / sizeof(uint32_t);
+        uint32_t* hist3 = hist2 + hist_bytes / sizeof(uint32_t);
         hipLaunchKernelGGL(kp_hist_kernel<1>, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sp, sel, hist);
         hipLaunchKernelGGL(kp_select_kernel<1>, dim3(nseg * 3), dim3(256), 0, s, sp, sel, hist);
-        PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(hist, 0, hist_bytes, s));
-        hipLaunchKernelGGL(kp_hist_kernel<2>, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sp, sel, hist);
-        hipLaunchKernelGGL(kp_select_kernel<2>, dim3(nseg * 3), dim3(256), 0, s, sp, sel, hist);
-        PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(hist, 0, hist_bytes, s));
-        hipLaunchKernelGGL(kp_hist_kernel<3>, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sp, sel, hist);
-        hipLaunchKernelGGL(kp_select_kernel<3>, dim3(nseg * 3), dim3(256), 0, s, sp, sel, hist);
+        hipLaunchKernelGGL(kp_hist_kernel<2>, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sp, sel, hist2);
+        hipLaunchKernelGGL(kp_select_kernel<2>, dim3(nseg * 3), dim3(256), 0, s, sp, sel, hist2);
+        hipLaunchKernelGGL(kp_hist_kernel<3>, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sp, sel, hist3);
+        hipLaunchKernelGGL(kp_select_kernel<3>, dim3(nseg * 3), dim3(256), 0, s, sp, sel, hist3);
         hipLaunchKernelGGL(kp_count_kernel, dim3(nblocks), dim3(KP_THREADS), 0, s, keys, nf, blocks_per_seg, sel, counts);
         hipLaunchKernelGGL(kp_scan_kernel, dim3(nseg), dim3(256), 0, s, counts, nblocks, blocks_per_seg, seg_size, offsets);
         hipLaunchKernelGGL(kp_scatter_kernel, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sel, offsets,
