@@ -1095,7 +1095,10 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
   const uint32_t max_chunks = uint32_t((m + 63) / 64);
   const size_t off_k0 = 0;
   const size_t off_k1 = off_k0 + align(m * sizeof(uint64_t));
-  const size_t off_v0 = off_k1 + align(m * sizeof(uint64_t));
+  // second key buffer of the sorting variants; the partition rounds keep their three digit histograms per segment
+  // here (segments hold >= 16384 points)
+  const size_t hist_room = (size_t(m) / 16384 + 1) * 3 * 3 * KP_BINS * sizeof(uint32_t);
+  const size_t off_v0 = off_k1 + align(std::max<size_t>(m * sizeof(uint64_t), hist_room));
   const size_t off_v1 = off_v0 + align(m * sizeof(uint32_t));
   const size_t off_pa = off_v1 + align(m * sizeof(uint32_t));
   const size_t off_pb = off_pa + align(m * sizeof(float4));
