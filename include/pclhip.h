@@ -434,6 +434,33 @@ PCLHIP_API pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
                                              size_t normals_offset, void* out, size_t out_stride_bytes,
                                              uint64_t* out_n);
 
+/* The grid of a filter run: getMinBoxCoordinates / getMaxBoxCoordinates / getNrDivisions / getDivisionMultiplier
+ * (filters/include/pcl/filters/voxel_grid.h:326-344).  Cell (i, j, k) has the id
+ * (i - min_b[0]) * divb_mul[0] + (j - min_b[1]) * divb_mul[1] + (k - min_b[2]) * divb_mul[2]. */
+typedef struct pclhip_voxelgrid_dims {
+  int32_t min_b[3];
+  int32_t max_b[3];
+  int32_t div_b[3];
+  int32_t divb_mul[3];
+} pclhip_voxelgrid_dims;
+
+/* pclhip_voxelgrid_ex plus setSaveLeafLayout (voxel_grid.h:316, impl/voxel_grid.hpp:752-787): leaf_layout (host
+ * or device, may be NULL) receives, for every cell id, the position of that voxel's centroid in the output or -1
+ * for a cell that is empty or was dropped by min_points_per_voxel; it must hold div_b[0]*div_b[1]*div_b[2] ints
+ * (leaf_layout_capacity is checked).  dims (may be NULL) receives the grid.  Call pclhip_voxelgrid_grid first to
+ * learn how many cells the layout has. */
+PCLHIP_API pclhip_status pclhip_voxelgrid_ex2(pclhip_ctx* ctx, const void* points, size_t stride_bytes, uint64_t n,
+                                              const float leaf[3], uint32_t min_points_per_voxel, int has_z_limits,
+                                              double z_min, double z_max, int downsample_all_data,
+                                              size_t normals_offset, void* out, size_t out_stride_bytes,
+                                              uint64_t* out_n, int32_t* leaf_layout, uint64_t leaf_layout_capacity,
+                                              pclhip_voxelgrid_dims* dims);
+
+/* Only the grid the filter would use for this cloud (bounding box pass, impl/voxel_grid.hpp:613-645). */
+PCLHIP_API pclhip_status pclhip_voxelgrid_grid(pclhip_ctx* ctx, const void* points, size_t stride_bytes, uint64_t n,
+                                               const float leaf[3], int has_z_limits, double z_min, double z_max,
+                                               pclhip_voxelgrid_dims* dims);
+
 /* ---- PCD files (io/src/pcd_io.cpp: PCDReader :115-675, PCDWriter :848-1500) ----------------------
  * The on-disk format either side of the path.  ascii, binary and binary_compressed (LZF, fields stored
  * as struct of arrays) are read straight into the strided records the calls above consume.  Errors are

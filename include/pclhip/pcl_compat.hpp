@@ -29,6 +29,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <array>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -1078,17 +1079,46 @@ class VoxelGrid {
     if (!input_) { output.width = 0; return; }
     std::vector<PointXYZ> out(input_->size());
     std::uint64_t n = 0;
-    const pclhip_status st = pclhip_voxelgrid(ctx_->get(), input_->points.data(), sizeof(PointXYZ), input_->size(), leaf_,
-                                              min_pts_, field_ == "z", lo_, hi_, out.data(), &n);
+    leaf_layout_.clear();
+    dims_ = pclhip_voxelgrid_dims{};
+    if (save_leaf_layout_ && !input_->empty()) {  // one int per grid cell: learn the grid first (bounding-box pass)
+      if (pclhip_voxelgrid_grid(ctx_->get(), input_->points.data(), sizeof(PointXYZ), input_->size(), leaf_, field_ == "z",
+                                lo_, hi_, &dims_) == PCLHIP_OK)
+        leaf_layout_.assign(std::size_t(dims_.div_b[0]) * std::size_t(dims_.div_b[1]) * std::size_t(dims_.div_b[2]), -1);
+    }
+    const pclhip_status st = pclhip_voxelgrid_ex2(ctx_->get(), input_->points.data(), sizeof(PointXYZ), input_->size(), leaf_,
+                                                  min_pts_, field_ == "z", lo_, hi_, 1, 0, out.data(), sizeof(PointXYZ), &n,
+                                                  leaf_layout_.empty() ? nullptr : leaf_layout_.data(), leaf_layout_.size(),
+                                                  &dims_);
     if (st == PCLHIP_ERR_OVERFLOW) { output = *input_; return; }
     if (st != PCLHIP_OK) { output.width = 0; return; }
     out.resize(std::size_t(n));
     output.points.swap(out);
     output.width = std::uint32_t(n);
   }
+  // the grid of the last filter() and the leaf layout (filters/include/pcl/filters/voxel_grid.h:316-421)
+  void setSaveLeafLayout(bool save) { save_leaf_layout_ = save; }
+  std::array<int, 3> getMinBoxCoordinates() const { return {dims_.min_b[0], dims_.min_b[1], dims_.min_b[2]}; }
+  std::array<int, 3> getMaxBoxCoordinates() const { return {dims_.max_b[0], dims_.max_b[1], dims_.max_b[2]}; }
+  std::array<int, 3> getNrDivisions() const { return {dims_.div_b[0], dims_.div_b[1], dims_.div_b[2]}; }
+  std::array<int, 3> getDivisionMultiplier() const { return {dims_.divb_mul[0], dims_.divb_mul[1], dims_.divb_mul[2]}; }
+  std::vector<int> getLeafLayout() const { return std::vector<int>(leaf_layout_.begin(), leaf_layout_.end()); }
+  std::array<int, 3> getGridCoordinates(float x, float y, float z) const {
+    return {int(std::floor(x * (1.0f / leaf_[0]))), int(std::floor(y * (1.0f / leaf_[1]))), int(std::floor(z * (1.0f / leaf_[2])))};
+  }
+  int getCentroidIndexAt(const std::array<int, 3>& ijk) const {
+    long long idx = 0;
+    for (int d = 0; d < 3; ++d) idx += (long long)(ijk[d] - dims_.min_b[d]) * dims_.divb_mul[d];
+    if (idx < 0 || idx >= (long long)leaf_layout_.size()) return -1;
+    return leaf_layout_[std::size_t(idx)];
+  }
+  int getCentroidIndex(const PointXYZ& p) const { return getCentroidIndexAt(getGridCoordinates(p.x, p.y, p.z)); }
  private:
   Context::Ptr ctx_;
   PointCloud<PointXYZ>::ConstPtr input_;
+  bool save_leaf_layout_ = false;
+  std::vector<std::int32_t> leaf_layout_;
+  pclhip_voxelgrid_dims dims_{};
   float leaf_[3] = {0, 0, 0};
   unsigned min_pts_ = 0;
   std::string field_;

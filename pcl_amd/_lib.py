@@ -57,6 +57,10 @@ class ConvergenceState(C.Structure):
     _fields_ = [("prev_mse", C.c_double), ("iterations_similar_transforms", C.c_int), ("convergence_state", C.c_int)]
 
 
+class VoxelGridDims(C.Structure):
+    _fields_ = [("min_b", C.c_int32 * 3), ("max_b", C.c_int32 * 3), ("div_b", C.c_int32 * 3), ("divb_mul", C.c_int32 * 3)]
+
+
 COMM_ID_BYTES = 128
 
 
@@ -157,6 +161,11 @@ SIGNATURES = {
     "pclhip_pcd_read_field": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, _vp, _u64, C.POINTER(_u64)]),
     "pclhip_voxelgrid_ex": (C.c_int, [_vp, _vp, _sz, _u64, C.POINTER(C.c_float), C.c_uint32, C.c_int, C.c_double,
                                       C.c_double, C.c_int, _sz, _vp, _sz, C.POINTER(_u64)]),
+    "pclhip_voxelgrid_ex2": (C.c_int, [_vp, _vp, _sz, _u64, C.POINTER(C.c_float), C.c_uint32, C.c_int, C.c_double,
+                                       C.c_double, C.c_int, _sz, _vp, _sz, C.POINTER(_u64), _vp, _u64,
+                                       C.POINTER(VoxelGridDims)]),
+    "pclhip_voxelgrid_grid": (C.c_int, [_vp, _vp, _sz, _u64, C.POINTER(C.c_float), C.c_int, C.c_double, C.c_double,
+                                        C.POINTER(VoxelGridDims)]),
     "pclhip_voxelgrid": (C.c_int, [_vp, _vp, _sz, _u64, C.POINTER(C.c_float), C.c_uint32, C.c_int,
                                    C.c_double, C.c_double, _vp, C.POINTER(_u64)]),
 }

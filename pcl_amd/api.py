@@ -958,7 +958,51 @@ class VoxelGrid:
         else:
             out = np.empty((max(n, 1), cols), np.float32)
             optr = C.c_void_p(out.ctypes.data)
-        check(self.lib.pclhip_voxelgrid_ex(self.ctx.h, ptr, stride, n, _fp(self.leaf), self.min_pts, int(has), lo, hi,
-                                           int(self.getDownsampleAllData()), 16 if with_normals else 0, optr, cols * 4,
-                                           C.byref(cnt)), self.ctx.h)
+        from ._lib import VoxelGridDims
+        dims = VoxelGridDims()
+        layout = None
+        if getattr(self, "save_leaf_layout", False) and n > 0:
+            # the layout has one int per cell of the grid: ask for the grid first (a bounding-box pass)
+            check(self.lib.pclhip_voxelgrid_grid(self.ctx.h, ptr, stride, n, _fp(self.leaf), int(has), lo, hi,
+                                                 C.byref(dims)), self.ctx.h)
+            layout = np.empty(int(dims.div_b[0]) * int(dims.div_b[1]) * int(dims.div_b[2]), np.int32)
+        check(self.lib.pclhip_voxelgrid_ex2(self.ctx.h, ptr, stride, n, _fp(self.leaf), self.min_pts, int(has), lo, hi,
+                                            int(self.getDownsampleAllData()), 16 if with_normals else 0, optr, cols * 4,
+                                            C.byref(cnt), None if layout is None else C.c_void_p(layout.ctypes.data),
+                                            0 if layout is None else len(layout), C.byref(dims)), self.ctx.h)
+        self._dims = dims
+        self._layout = layout
         return out[:int(cnt.value)]
+
+    # ---- the grid of the last filter() call and the leaf layout (voxel_grid.h:316-420) ----
+    def setSaveLeafLayout(self, save):
+        self.save_leaf_layout = bool(save)
+
+    def getMinBoxCoordinates(self):
+        return np.asarray(self._dims.min_b, np.int32)
+
+    def getMaxBoxCoordinates(self):
+        return np.asarray(self._dims.max_b, np.int32)
+
+    def getNrDivisions(self):
+        return np.asarray(self._dims.div_b, np.int32)
+
+    def getDivisionMultiplier(self):
+        return np.asarray(self._dims.divb_mul, np.int32)
+
+    def getLeafLayout(self):
+        """position (i-min_x) + (j-min_y)*div_x + (k-min_z)*div_x*div_y -> index of that voxel's centroid, -1 if empty"""
+        return np.empty(0, np.int32) if self._layout is None else self._layout
+
+    def getGridCoordinates(self, x, y, z):
+        inv = np.float32(1.0) / self.leaf
+        return np.floor(np.asarray([x, y, z], np.float32) * inv).astype(np.int32)      # voxel_grid.h:402-407
+
+    def getCentroidIndexAt(self, ijk):
+        idx = int(np.dot(np.asarray(ijk, np.int64) - self.getMinBoxCoordinates(), self.getDivisionMultiplier()))
+        if self._layout is None or idx < 0 or idx >= len(self._layout):
+            return -1                                                                   # voxel_grid.h:412-421
+        return int(self._layout[idx])
+
+    def getCentroidIndex(self, p):
+        return self.getCentroidIndexAt(self.getGridCoordinates(p[0], p[1], p[2]))

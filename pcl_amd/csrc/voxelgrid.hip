@@ -197,6 +197,14 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
   }
 }
 
+// setSaveLeafLayout (impl/voxel_grid.hpp:752-787): layout[voxel id] = position of its centroid in the output
+__global__ void vg_layout_kernel(const uint32_t* __restrict__ keys_sorted, const uint32_t* __restrict__ run_start,
+                                 const uint32_t* __restrict__ keep, const uint32_t* __restrict__ keep_scan, uint32_t nruns,
+                                 int32_t* __restrict__ layout) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nruns && keep[r]) layout[keys_sorted[run_start[r]]] = int32_t(keep_scan[r]);
+}
+
 // one thread per voxel: sequential float accumulation in sorted (= ascending input index) order.
 // Output records of `ostride` bytes: x y z 1 at +0; with normals (noff != 0, pcl::PointNormal layout) and
 // downsample_all_data the CentroidPoint accumulators of common/include/pcl/common/impl/accumulators.hpp:68-127:
@@ -323,8 +331,19 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
                                              const float leaf[3], uint32_t min_points_per_voxel, int has_z_limits,
                                              double z_min, double z_max, int downsample_all_data, size_t normals_offset,
                                              void* out, size_t out_stride, uint64_t* out_n) {
+  return pclhip_voxelgrid_ex2(ctx, points, stride, n, leaf, min_points_per_voxel, has_z_limits, z_min, z_max, downsample_all_data,
+                              normals_offset, out, out_stride, out_n, nullptr, 0, nullptr);
+}
+
+extern "C" pclhip_status pclhip_voxelgrid_ex2(pclhip_ctx* ctx, const void* points, size_t stride, uint64_t n,
+                                              const float leaf[3], uint32_t min_points_per_voxel, int has_z_limits,
+                                              double z_min, double z_max, int downsample_all_data, size_t normals_offset,
+                                              void* out, size_t out_stride, uint64_t* out_n, int32_t* leaf_layout,
+                                              uint64_t leaf_layout_capacity, pclhip_voxelgrid_dims* dims) {
   if (!ctx || !leaf || !out_n) return PCLHIP_ERR_INVALID;
   *out_n = 0;
+  if (dims) std::memset(dims, 0, sizeof *dims);
+  const bool dims_only = out == nullptr && dims != nullptr;   // pclhip_voxelgrid_grid
   PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
   PCLHIP_REQUIRE(ctx, out_stride >= 12 && out_stride % 4 == 0, "output stride must be a multiple of 4 and >= 12 bytes");
   PCLHIP_REQUIRE(ctx, normals_offset == 0 || (normals_offset % 4 == 0 && normals_offset + 32 <= stride &&
@@ -333,7 +352,7 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   PCLHIP_REQUIRE(ctx, n < 0x7FFFFFFFull, "cloud too large for int32 indices");
   PCLHIP_REQUIRE(ctx, leaf[0] > 0 && leaf[1] > 0 && leaf[2] > 0, "leaf size must be positive");
   if (n == 0) return PCLHIP_OK;
-  PCLHIP_REQUIRE(ctx, points && out, "null buffer");
+  PCLHIP_REQUIRE(ctx, points && (out || dims_only), "null buffer");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   struct Guard {
@@ -421,6 +440,33 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   g.mul[0] = 1;
   g.mul[1] = div_b[0];
   g.mul[2] = div_b[0] * div_b[1];
+  if (dims) {  // getMinBoxCoordinates / getMaxBoxCoordinates / getNrDivisions / getDivisionMultiplier (voxel_grid.h:326-344)
+    for (int d = 0; d < 3; ++d) {
+      dims->min_b[d] = g.min_b[d];
+      dims->max_b[d] = g.min_b[d] + div_b[d] - 1;
+      dims->div_b[d] = div_b[d];
+      dims->divb_mul[d] = g.mul[d];
+    }
+  }
+  if (dims_only) return PCLHIP_OK;
+  const uint64_t ncells = uint64_t(div_b[0]) * uint64_t(div_b[1]) * uint64_t(div_b[2]);
+  int32_t* d_layout = nullptr;
+  if (leaf_layout) {
+    PCLHIP_REQUIRE(ctx, leaf_layout_capacity >= ncells, "leaf_layout holds fewer than div_b[0] * div_b[1] * div_b[2] cells");
+    d_layout = leaf_layout;
+    if (!is_device_pointer(leaf_layout)) {
+      PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &d_layout, ncells * sizeof(int32_t)));
+      guard.p.push_back(d_layout);
+    }
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_layout, 0xFF, ncells * sizeof(int32_t), s));   // -1: empty cell
+  }
+  const auto layout_out = [&]() -> pclhip_status {  // the host copy of the layout (every return path after this point)
+    if (leaf_layout && d_layout != leaf_layout) {
+      PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(leaf_layout, d_layout, ncells * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return PCLHIP_OK;
+  };
 
   // --- keys + stable sort.  Voxel ids are < div_b[0] * div_b[1] * div_b[2]: only that many key bits need sorting;
   // rejected points carry the all-ones key, kept apart by ONE extra bit above the ids.
@@ -444,7 +490,7 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   unsigned int nv = 0;
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nv, d_cnt, sizeof nv, hipMemcpyDeviceToHost, s));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-  if (nv == 0) return PCLHIP_OK;
+  if (nv == 0) return layout_out();
 
   // --- runs ---
   hipLaunchKernelGGL(vg_head_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, keys_sorted, nv, head);
@@ -463,6 +509,8 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
     PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&total, tot, sizeof total, hipMemcpyDeviceToHost, s));
     PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
   }
+
+  if (d_layout) hipLaunchKernelGGL(vg_layout_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, keys_sorted, run_start, keep, keep_scan, nruns, d_layout);
 
   // --- centroids ---
   void* d_out = out;
@@ -488,5 +536,12 @@ extern "C" pclhip_status pclhip_voxelgrid_ex(pclhip_ctx* ctx, const void* points
   }
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
   *out_n = total;
-  return PCLHIP_OK;
+  return layout_out();
+}
+
+extern "C" pclhip_status pclhip_voxelgrid_grid(pclhip_ctx* ctx, const void* points, size_t stride, uint64_t n, const float leaf[3],
+                                               int has_z_limits, double z_min, double z_max, pclhip_voxelgrid_dims* dims) {
+  if (!dims) return PCLHIP_ERR_INVALID;
+  uint64_t none = 0;
+  return pclhip_voxelgrid_ex2(ctx, points, stride, n, leaf, 0, has_z_limits, z_min, z_max, 1, 0, nullptr, 16, &none, nullptr, 0, dims);
 }

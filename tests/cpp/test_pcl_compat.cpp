@@ -153,6 +153,20 @@ int main(int argc, char** argv) {
     PointCloud<PointXYZ> out;
     grid.filter(out);
     EXPECT(out.size() == 103 && out.width == 103 && out.height == 1 && out.is_dense);
+    // setSaveLeafLayout (voxel_grid.h:316): every kept cell maps to its centroid's position, in ascending cell order
+    grid.setSaveLeafLayout(true);
+    grid.filter(out);
+    const std::vector<int> layout = grid.getLeafLayout();
+    const auto div = grid.getNrDivisions();
+    EXPECT(layout.size() == std::size_t(div[0]) * std::size_t(div[1]) * std::size_t(div[2]));
+    int next = 0;
+    bool ascending = true;
+    for (int v : layout)
+      if (v >= 0) ascending = ascending && (v == next++);
+    EXPECT(ascending && next == 103);
+    EXPECT(grid.getCentroidIndex((*source)[0]) >= 0 && grid.getCentroidIndex((*source)[0]) < 103);
+    const auto mn = grid.getMinBoxCoordinates();
+    EXPECT(grid.getCentroidIndexAt({mn[0] - 1, mn[1], mn[2]}) == -1);
   }
   {  // estimators on explicit pairs: test/registration/test_registration_api.cpp:469-518, :663-712 (1e-2)
     PointCloud<PointNormal> src, tgt;

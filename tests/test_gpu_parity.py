@@ -670,6 +670,52 @@ def test_voxelgrid_synthetic_bit_exact(gpu, orc):
         assert out.shape == ref.shape and np.array_equal(out, ref), (leaf, minpts)
 
 
+def test_voxelgrid_leaf_layout(gpu, orc, bunny):
+    # setSaveLeafLayout (voxel_grid.h:316, impl/voxel_grid.hpp:752-787): layout[cell id] = position of the cell's
+    # centroid in the output, -1 for empty cells and for cells dropped by min_points_per_voxel; cell ids follow
+    # getMinBoxCoordinates / getDivisionMultiplier.  Checked against the voxel ids recomputed here with the
+    # reference's float expressions (:713-718) and against the oracle's centroids.
+    import pcl_amd
+    rng = np.random.default_rng(11)
+    big = np.ones((200_000, 4), np.float32)
+    big[:, :3] = rng.uniform(-1, 1, (200_000, 3)).astype(np.float32) * np.float32([1.0, 0.7, 0.2])
+    for cloud, leaf, min_pts in ((xyz1(bunny["bun0"]), 0.02, 0), (big, 0.05, 0), (big, 0.03, 3)):
+        vg = pcl_amd.VoxelGrid(gpu)
+        vg.setInputCloud(cloud)
+        vg.setLeafSize(leaf)
+        vg.setMinimumPointsNumberPerVoxel(min_pts)
+        vg.setSaveLeafLayout(True)
+        out = vg.filter()
+        ref, ref_ids = orc.voxelgrid(cloud, leaf, min_points_per_voxel=min_pts)
+        assert np.array_equal(out[:, :3], ref[:, :3])
+        layout = vg.getLeafLayout()
+        mn, div, mul = vg.getMinBoxCoordinates(), vg.getNrDivisions(), vg.getDivisionMultiplier()
+        assert len(layout) == int(div[0]) * int(div[1]) * int(div[2])
+        assert np.array_equal(mul, [1, div[0], div[0] * div[1]])
+        assert np.array_equal(vg.getMaxBoxCoordinates(), mn + div - 1)
+        inv = np.float32(1.0) / np.float32(leaf)
+        ijk = np.floor(cloud[:, :3] * inv).astype(np.int64)
+        assert np.array_equal(ijk.min(0), mn) and np.array_equal(ijk.max(0), mn + div - 1)
+        ids = ((ijk - mn) * mul.astype(np.int64)).sum(1)
+        cnt = np.bincount(ids, minlength=len(layout))
+        kept = cnt >= max(min_pts, 1)
+        assert np.array_equal(layout >= 0, kept)                             # exactly the kept cells
+        assert np.array_equal(layout[kept], np.arange(kept.sum()))           # output order = ascending cell id
+        assert len(out) == kept.sum()
+        # the centroid a point's cell maps to lies in that cell (up to rounding of the mean at a cell face)
+        pick = rng.integers(0, len(cloud), 200)
+        for i in pick:
+            j = vg.getCentroidIndex(cloud[i])
+            assert j == layout[ids[i]]
+            if j >= 0:
+                assert np.all(np.abs(np.floor(out[j, :3] * inv) - ijk[i]) <= 1)
+        assert vg.getCentroidIndexAt(mn - 1) == -1
+        # without the flag nothing is kept
+        vg.setSaveLeafLayout(False)
+        vg.filter()
+        assert len(vg.getLeafLayout()) == 0
+
+
 def test_voxelgrid_overflow_refused(gpu):
     import pcl_amd
     pts = np.random.default_rng(4).uniform(-1000, 1000, (100, 3)).astype(np.float32)
