@@ -904,67 +904,51 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
           }
           bool landed = false;
           if (loose) {
-            // Loose bounds (first ICP iterations): the sorted batch is taken in chunks of 8 leaves.  Every lane
-            // first computes ITS OWN lower bound to each leaf of the chunk, then the lanes evaluate best-first:
-            // in every round a lane takes the not yet evaluated leaf of the chunk with its smallest bound that
-            // its current distance cannot exclude.  After the first round every lane has seen the leaf nearest to
-            // IT (not to the group), its bound is within a point spacing of final, and most other leaves of the
-            // chunk drop out without being evaluated; the wave radius collapses at once and cuts the rest of the list.
-            // (The first version walked the list in group order with one pending leaf per lane: the early rounds
-            // all evaluated the same leaf, 15 rounds per wave in the unseeded iteration.)
-            constexpr uint32_t CH = 8;
-            for (uint32_t c0 = 0; c0 < nb && !cut; c0 += CH) {
-              const uint32_t nc = (nb - c0) < CH ? (nb - c0) : CH;
-              float lbv[CH];
-              uint32_t avail = 0;
-#pragma unroll
-              for (uint32_t u = 0; u < CH; ++u) {
-                lbv[u] = INF;
-                if (u < nc && !cut) {  // wave-uniform
-                  const float4 ea = wl.list[3 * (b0 + c0 + u)], eb = wl.list[3 * (b0 + c0 + u) + 1];  // broadcast reads
-                  if (uniform_f32(eb.w) > T) {  // sorted: every remaining leaf is farther than the wave radius
-                    cut = true;
-                  } else {
-                    ++ts.c[1];
-                    float lb;
-                    if (use_disc) {
-                      const float4 es = wl.list[3 * (b0 + c0 + u) + 2];
-                      lb = point_disc_lb(qx[0], qy[0], qz[0], make_float4(ea.x, ea.y, ea.z, wl.rad[b0 + c0 + u]), es);
-                    } else {
-                      lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
-                    }
-                    lbv[u] = lb;
-                    if (valid[0] && !(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w))) avail |= 1u << u;
-                  }
-                }
+            // Loose bounds (first ICP iterations): walk the sorted batch; every lane keeps at most one
+            // pending leaf and a round runs when some lane would need a second one, so bounds tighten
+            // as early as possible and the tail of the list is cut off by the shrinking wave radius.
+            uint32_t pslot = 0, pid = NO_INDEX;
+            for (uint32_t t = 0; t < nb; ++t) {
+              const float4 ea = wl.list[3 * (b0 + t)], eb = wl.list[3 * (b0 + t) + 1];  // broadcast reads
+              if (uniform_f32(eb.w) > T) {  // sorted: every remaining leaf is farther than the wave radius
+                cut = true;
+                break;
               }
-              for (;;) {
-                float best_lb = INF;
-                uint32_t bu = CH;
-                const float w0 = pol.worst(0);
-#pragma unroll
-                for (uint32_t u = 0; u < CH; ++u) {
-                  const bool ok = ((avail >> u) & 1u) != 0u && !(lbv[u] > w0);
-                  if (!ok) avail &= ~(1u << u);       // excluded by now: never again
-                  if (ok && lbv[u] < best_lb) {
-                    best_lb = lbv[u];
-                    bu = u;
-                  }
-                }
-                if (__builtin_amdgcn_ballot_w64(bu != CH) == 0) break;
+              ++ts.c[1];
+              float lb;
+              if (use_disc) {
+                const float4 es = wl.list[3 * (b0 + t) + 2];
+                lb = point_disc_lb(qx[0], qy[0], qz[0], make_float4(ea.x, ea.y, ea.z, wl.rad[b0 + t]), es);
+              } else {
+                lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
+              }
+              bool need = valid[0] && !(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w));
+              if (__builtin_amdgcn_ballot_w64(need && pid != NO_INDEX) != 0) {
                 if (!landed) {
                   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                   landed = true;
                 }
-                uint32_t id = NO_INDEX;
-                if (bu != CH) {
-                  id = __float_as_uint(wl.list[3 * (b0 + c0 + bu)].w);
-                  avail &= ~(1u << bu);
-                }
-                round(c0 + (bu != CH ? bu : 0u), id);
+                const float w0 = pol.worst(0);
+                round(pslot, pid);
+                pid = NO_INDEX;
                 const float now = pol.worst(0);
                 if (__builtin_amdgcn_ballot_w64(valid[0] && now < w0) != 0) T = wave_max_f(valid[0] ? now : 0.0f);
+                need = need && !(lb > now);
               }
+              if (need) {
+                pslot = t;
+                pid = __float_as_uint(ea.w);
+              }
+            }
+            if (__builtin_amdgcn_ballot_w64(pid != NO_INDEX) != 0) {
+              if (!landed) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                landed = true;
+              }
+              const float w0 = pol.worst(0);
+              round(pslot, pid);
+              const float now = pol.worst(0);
+              if (__builtin_amdgcn_ballot_w64(valid[0] && now < w0) != 0) T = wave_max_f(valid[0] ? now : 0.0f);
             }
           } else {
             // Tight bounds (seeded iterations): one branch-free scan builds a per-lane bit mask of the
