@@ -1086,6 +1086,18 @@ __global__ __launch_bounds__(1024) void icp_finalize_kernel(const double* __rest
   const int t = threadIdx.x % NS, r = threadIdx.x / NS;  // NS == 32
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;         // four independent chains: the loads overlap
   int b = r;
+  for (; b + 32 * 15 < nblocks; b += 32 * 16) {  // sixteen rows in flight per thread, summed in the order of the loop below
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = partials[size_t(b + 32 * i) * NS + t];
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+      s0 += v[i];
+      s1 += v[i + 1];
+      s2 += v[i + 2];
+      s3 += v[i + 3];
+    }
+  }
   for (; b + 96 < nblocks; b += 128) {
     s0 += partials[size_t(b) * NS + t];
     s1 += partials[size_t(b + 32) * NS + t];
