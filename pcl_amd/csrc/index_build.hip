@@ -661,12 +661,16 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
             op[e] = j == 1u ? pp[e ^ 1] : pp[e ^ 2];
           }
         }
+        // the lower slot of an ascending pair keeps the smaller (key, position); for j, k >= 4 the direction is the
+        // same for the thread's four elements (i = 4t + e)
+        const uint32_t i0 = 4u * t;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const uint32_t i = 4u * t + uint32_t(e);
+          const uint32_t i = i0 + uint32_t(e);
           const bool lower = (i & j) == 0u, up = ((i & (nsub - 1u)) & k) == 0u;
-          const bool less = kk[e] < ok[e] || (kk[e] == ok[e] && pp[e] < op[e]);
-          const bool keep_own = (lower == up) == less;   // the lower slot of an ascending pair keeps the smaller one
+          const unsigned long long own = ((unsigned long long)kk[e] << 32) | pp[e];
+          const unsigned long long oth = ((unsigned long long)ok[e] << 32) | op[e];
+          const bool keep_own = (lower == up) == (own < oth);
           kk[e] = keep_own ? kk[e] : ok[e];
           pp[e] = keep_own ? pp[e] : op[e];
         }
