@@ -846,12 +846,17 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
       // ---- rank the surviving leaves and publish (box, id, lbG) in LDS --------------------------
       uint32_t rank = uint32_t(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
       if (ordered) {
+        // Exact rank by UNIQUE 32-bit keys: the (non-negative) bound with its six low mantissa bits replaced by the
+        // lane -- one readlane, one compare and one add-with-carry per surviving leaf instead of a two-key
+        // comparison.  The list then carries the truncated bound: it is <= the true one, so "every remaining
+        // leaf is farther than the wave radius" stays a valid cut.
+        const uint32_t key = (__float_as_uint(lbG) & ~63u) | uint32_t(lane);
         rank = 0;
         for (uint64_t m2 = mask; m2; m2 &= m2 - 1) {
-          const int i = __builtin_ctzll(m2);
-          const float s = readlane_f(lbG, i);
-          rank += (s < lbG || (s == lbG && i < lane)) ? 1u : 0u;
+          const uint32_t sk = uint32_t(__builtin_amdgcn_readlane(int(key), __builtin_ctzll(m2)));
+          rank += sk < key ? 1u : 0u;
         }
+        lbG = __uint_as_float(key & ~63u);
       }
       const uint32_t n_alive = uint32_t(__builtin_popcountll(mask));
       if (alive) {
@@ -1052,11 +1057,12 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
       const uint64_t others = mask & ~(1ull << jn);
       if (ordered && __builtin_popcountll(others) > 1) {
         // push the other survivors farthest first so that pops come back nearest first
+        // same unique keys (see the leaf level); the complement of the lane makes equal bounds pop in lane order
+        const uint32_t key = (__float_as_uint(lbG) & ~63u) | uint32_t(63 - lane);
         uint32_t rank = 0;
         for (uint64_t m2 = others; m2; m2 &= m2 - 1) {
-          const int i = __builtin_ctzll(m2);
-          const float s = readlane_f(lbG, i);
-          rank += (s > lbG || (s == lbG && i < lane)) ? 1u : 0u;
+          const uint32_t sk = uint32_t(__builtin_amdgcn_readlane(int(key), __builtin_ctzll(m2)));
+          rank += sk > key ? 1u : 0u;
         }
         if (alive && lane != jn)
           stack[sp + int(rank)] = make_uint2((cl << 28) | (first + uint32_t(lane)), __float_as_uint(lbG));
