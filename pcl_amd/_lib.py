@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpclhip.so")
+LIB_PATH = os.environ.get("PCLHIP_LIB") or os.path.join(_HERE, "libpclhip.so")  # PCLHIP_LIB: A/B runs of two builds
 
 NSUMS = 32
 POINT_TO_POINT = 0
