@@ -1299,3 +1299,37 @@ def test_reference_correspondences_with_cached_search_tree(gpu):
     ce2.setInputSource(cloud1)
     q2, m2, d2 = ce2.determineCorrespondences()
     assert tree2.h.value == h and np.array_equal(m2, m0)
+
+
+# ------------------------------------------------------------------------------------------------
+# unseeded searches from a stand-off (the disc bounds of traverse.hpp), away from the unit cube
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("offset,scale,standoff", [
+    ((0.0, 0.0, 0.0), 1.0, 0.03),            # the bench geometry, a larger stand-off
+    ((1000.0, -2000.0, 500.0), 1.0, 0.02),   # far from the origin: 6e-5 float spacing against 1e-3 point spacing
+    ((0.0, 0.0, 0.0), 250.0, 4.0),           # metres-sized scene
+    ((-3.0, 7.0, 1.0), 0.004, 1e-4),         # millimetre-sized scene
+    ((0.0, 0.0, 0.0), 1.0, 0.3),             # stand-off of the size of the whole surface's relief
+])
+def test_cold_standoff_correspondences_bit_exact(gpu, orc, offset, scale, standoff):
+    # first iteration of a registration (no seeds): every match and squared distance equals the oracle's k = 1 search
+    import pcl_amd
+    n = 150_000
+    off = np.asarray(offset, np.float64)
+    tgt = pcl_amd.synth.gaussian_surface(n, pcl_amd.synth.TARGET_SEED).astype(np.float64)
+    src = pcl_amd.synth.gaussian_surface(n // 2, pcl_amd.synth.SOURCE_SEED).astype(np.float64)
+    th = np.deg2rad(1.5)
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    src[:, :3] = src[:, :3] @ R.T + np.array([0.004, -0.007, 1.0]) * np.array([1, 1, standoff / scale])
+    tgt_f = xyz1((tgt[:, :3] * scale + off).astype(np.float32))
+    src_f = xyz1((src[:, :3] * scale + off).astype(np.float32))
+    icp = pcl_amd.IterativeClosestPoint(gpu)
+    icp.setInputTarget(tgt_f)
+    icp.setInputSource(src_f)
+    icp.reset()
+    icp.iterate(np.eye(4, dtype=np.float32), max_dist=1e6 * scale)
+    q, m, d = icp.fetchCorrespondences()
+    oi, od = orc.KdTree(tgt_f).knn(src_f, 1)
+    assert np.array_equal(q, np.arange(len(src_f)))
+    assert np.array_equal(m, oi[:, 0])
+    assert np.array_equal(d, od[:, 0])
