@@ -136,6 +136,18 @@ PCLHIP_API pclhip_status pclhip_normals(pclhip_index* index, int k, const float 
  * order radiusSearch returns them (ascending distance); fewer than 3 neighbours -> NaN. */
 PCLHIP_API pclhip_status pclhip_normals_radius(pclhip_index* index, double radius, const float viewpoint[3],
                                                void* out, size_t out_stride_bytes, uint64_t* out_nan_count);
+/* The same two searches with a SEARCH SURFACE different from the input cloud, and/or over an index subset of the
+ * input: Feature::setSearchSurface / PCLBase::setIndices (features/include/pcl/features/feature.h:139-153,
+ * impl/feature.hpp:104-118; common/include/pcl/pcl_base.h:102-125) as NormalEstimation::computeFeature uses them
+ * (impl/normal_3d.hpp:48-95): `index` holds the surface; query j is record indices[j] of `queries` (record j when
+ * indices is NULL); its plane is fitted to the surface points the search returns, in that order, and the normal is
+ * flipped towards the viewpoint as seen from the QUERY point.  Exactly one of k >= 1 / radius > 0.
+ * out (host or device): nx,ny,nz,curvature at byte 0 of out_stride_bytes records, one per query; NaN where the query
+ * is non-finite or has fewer than 3 neighbours.  Nothing is retained in the index. */
+PCLHIP_API pclhip_status pclhip_normals_at(pclhip_index* surface, const void* queries, size_t stride_bytes, uint64_t n_queries,
+                                           const int32_t* indices, uint64_t n_indices, int k, double radius,
+                                           const float viewpoint[3], void* out, size_t out_stride_bytes,
+                                           uint64_t* out_nan_count);
 /* GeneralizedIterativeClosestPoint::computeCovariances (registration/include/pcl/registration/impl/gicp.hpp
  * :70-147): for every indexed point the covariance of its k nearest neighbours (k_correspondences_, default
  * 20, <= 32 here), regularised to singular values (1, 1, epsilon) (gicp_epsilon_, default 0.001).

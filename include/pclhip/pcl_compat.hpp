@@ -237,6 +237,22 @@ class Search {
   }
   virtual int radiusSearch(const PointT& point, double radius, Indices& k_indices, std::vector<float>& k_sqr_distances,
                            unsigned int max_nn = 0) const = 0;
+  // queries of another point type (search.h:166-176,287-297): copied by x, y, z
+  template <typename PointTDiff>
+  int nearestKSearchT(const PointTDiff& point, int k, Indices& k_indices, std::vector<float>& k_sqr_distances) const {
+    PointT p{};
+    p.x = point.x; p.y = point.y; p.z = point.z;
+    return nearestKSearch(p, k, k_indices, k_sqr_distances);
+  }
+  template <typename PointTDiff>
+  int radiusSearchT(const PointTDiff& point, double radius, Indices& k_indices, std::vector<float>& k_sqr_distances,
+                    unsigned int max_nn = 0) const {
+    PointT p{};
+    p.x = point.x; p.y = point.y; p.z = point.z;
+    return radiusSearch(p, radius, k_indices, k_sqr_distances, max_nn);
+  }
+  // the device searches a whole batch per launch; host threads play no part (kept for source compatibility)
+  virtual void setNumberOfThreads(unsigned int) {}
   virtual void radiusSearch(const PointCloud<PointT>& cloud, const Indices& indices, double radius,
                             std::vector<Indices>& k_indices, std::vector<std::vector<float>>& k_sqr_distances,
                             unsigned int max_nn = 0) const {
@@ -268,6 +284,12 @@ class KdTree : public Search<PointT> {
   ~KdTree() override { if (index_) pclhip_index_destroy(index_); }
   KdTree(const KdTree&) = delete;
   KdTree& operator=(const KdTree&) = delete;
+  // search/kdtree.h:130-143, kdtree/kdtree.h:306-323: FLANN's eps allows a (1 + eps) approximate search; this index
+  // always answers exactly, which satisfies every eps >= 0.  min_pts_ is stored for the getter (kdtree.h:325-338).
+  void setEpsilon(float eps) { epsilon_ = eps; }
+  float getEpsilon() const { return epsilon_; }
+  void setMinPts(int min_pts) { min_pts_ = min_pts; }
+  int getMinPts() const { return min_pts_; }
 
   // search/include/pcl/search/impl/kdtree.hpp:87-97 -> kdtree_flann.hpp:99-136: always (re)builds, like the
   // reference -- the cloud behind an unchanged pointer may have been modified in place.  Who knows it has not
@@ -415,6 +437,8 @@ class KdTree : public Search<PointT> {
   PointRepresentationConstPtr rep_;
   float scale_[3] = {1, 1, 1};
   bool scaled_ = false, unsupported_ = false;
+  float epsilon_ = 0.0f;
+  int min_pts_ = 1;
 };
 
 }  // namespace search
@@ -429,7 +453,15 @@ class NormalEstimation : public PCLBase<PointInT> {
   void setSearchMethod(const SearchPtr& tree) { tree_ = tree; }
   SearchPtr getSearchMethod() const { return tree_; }
   void setKSearch(int k) { k_ = k; }
+  int getKSearch() const { return k_; }
   void setRadiusSearch(double radius) { radius_ = radius; }
+  double getRadiusSearch() const { return radius_; }
+  double getSearchParameter() const { return k_ >= 1 ? double(k_) : radius_; }  // feature.h:190-197
+  // Feature::setSearchSurface (features/include/pcl/features/feature.h:139-153): neighbours come from this cloud, one normal
+  // per point of the input cloud (or per index, PCLBase::setIndices); unset = the input cloud itself
+  void setSearchSurface(const typename PointCloud<PointInT>::ConstPtr& cloud) { surface_ = cloud; }
+  typename PointCloud<PointInT>::ConstPtr getSearchSurface() const { return surface_; }
+  void getViewPoint(float& x, float& y, float& z) const { x = vp_[0]; y = vp_[1]; z = vp_[2]; }
   // normal_3d.h:255-262 / :328-351: the cloud's sensor origin is the viewpoint until setViewPoint is called
   void setViewPoint(float x, float y, float z) { vp_[0] = x; vp_[1] = y; vp_[2] = z; use_sensor_origin_ = false; }
   void useSensorOriginAsViewPoint() { use_sensor_origin_ = true; }
@@ -443,11 +475,29 @@ class NormalEstimation : public PCLBase<PointInT> {
     if (!tree_) tree_ = std::make_shared<search::KdTree<PointInT>>(ctx_);
     auto* dev = dynamic_cast<search::KdTree<PointInT>*>(tree_.get());
     if (dev == nullptr) return;
-    if (dev->getInputCloud() != input || dev->handle() == nullptr) {  // feature.hpp:125-130
-      if (!dev->setInputCloud(input)) return;
+    const auto& surface = surface_ ? surface_ : input;  // feature.hpp:104-118
+    if (dev->getInputCloud() != surface || dev->handle() == nullptr) {  // feature.hpp:125-130
+      if (!dev->setInputCloud(surface)) return;
     }
     if (use_sensor_origin_) {
       vp_[0] = input->sensor_origin_[0]; vp_[1] = input->sensor_origin_[1]; vp_[2] = input->sensor_origin_[2];
+    }
+    const bool subset = this->indices_ && !this->fake_indices_;
+    if (surface != input || subset) {  // every (selected) input point is a query against the surface
+      const std::size_t m = subset ? this->indices_->size() : input->size();
+      output.resize(m);
+      std::uint64_t nan = 0;
+      std::vector<float> tmp(m * 4);
+      const pclhip_status st = pclhip_normals_at(dev->handle(), input->points.data(), sizeof(PointInT), input->size(),
+                                                 subset ? this->indices_->data() : nullptr, subset ? m : 0, k_ >= 1 ? k_ : 0,
+                                                 k_ >= 1 ? 0.0 : radius_, vp_, tmp.data(), 16, &nan);
+      if (st != PCLHIP_OK) { output.points.clear(); return; }
+      for (std::size_t i = 0; i < m; ++i) {
+        output[i].normal_x = tmp[4 * i]; output[i].normal_y = tmp[4 * i + 1]; output[i].normal_z = tmp[4 * i + 2];
+        output[i].curvature = tmp[4 * i + 3];
+      }
+      output.is_dense = (nan == 0);
+      return;
     }
     output.resize(input->size());
     std::uint64_t nan = 0;
@@ -464,6 +514,7 @@ class NormalEstimation : public PCLBase<PointInT> {
  private:
   Context::Ptr ctx_;
   SearchPtr tree_;
+  typename PointCloud<PointInT>::ConstPtr surface_;
   int k_ = 0;
   double radius_ = 0.0;
   float vp_[3] = {0, 0, 0};
@@ -621,6 +672,21 @@ class CorrespondenceEstimationBase : public PCLBase<PointSource> {
     target_cloud_updated_ = true;
   }
   KdTreePtr getSearchMethodTarget() const { return tree_; }
+  // correspondence_estimation.h:230-262: the reciprocal search's tree over the source.  The device builds its own index of
+  // the (moving) source every iteration, so a tree handed in here is kept for the getter only.
+  using KdTreeReciprocal = search::KdTree<PointSource>;
+  using KdTreeReciprocalPtr = typename KdTreeReciprocal::Ptr;
+  void setSearchMethodSource(const KdTreeReciprocalPtr& tree, bool force_no_recompute = false) {
+    tree_reciprocal_ = tree;
+    force_no_recompute_reciprocal_ = force_no_recompute;
+    source_cloud_updated_ = true;
+  }
+  KdTreeReciprocalPtr getSearchMethodSource() const { return tree_reciprocal_; }
+  // :111-131: estimators that need normals say so; the nearest-neighbour estimator does not
+  virtual bool requiresSourceNormals() const { return false; }
+  virtual bool requiresTargetNormals() const { return false; }
+  // :144-155 (OpenMP threads of the host loop): one device launch covers all points
+  void setNumberOfThreads(unsigned int nr_threads) { num_threads_ = nr_threads; }
   virtual void determineCorrespondences(Correspondences& correspondences,
                                         double max_distance = std::numeric_limits<double>::max()) = 0;
   virtual void determineReciprocalCorrespondences(Correspondences& correspondences,
@@ -630,7 +696,10 @@ class CorrespondenceEstimationBase : public PCLBase<PointSource> {
   KdTreePtr tree_;
   PointCloudTargetConstPtr target_;
   IndicesPtr target_indices_;
+  KdTreeReciprocalPtr tree_reciprocal_;
   bool target_cloud_updated_ = true, source_cloud_updated_ = true, force_no_recompute_ = false;
+  bool force_no_recompute_reciprocal_ = false;
+  unsigned int num_threads_ = 1;
   bool initCompute() {  // impl/correspondence_estimation.hpp:71-97
     if (!target_ || !tree_) return false;
     if (target_cloud_updated_ && !force_no_recompute_) {
@@ -693,6 +762,50 @@ class CorrespondenceEstimation : public CorrespondenceEstimationBase<PointSource
 }  // namespace registration
 
 // pcl::Registration<PointSource, PointTarget> (registration/include/pcl/registration/registration.h:56-700)
+template <typename PointSource, typename PointTarget> class IterativeClosestPoint;
+
+namespace registration {
+// pcl::registration::DefaultConvergenceCriteria<Scalar> (default_convergence_criteria.h:61-286): the option holder a
+// registration hands out through getConvergeCriteria(); hasConverged() itself runs on the device (closed_forms.hpp),
+// its host twin is pclhip_convergence_has_converged.
+class DefaultConvergenceCriteria {
+ public:
+  using Ptr = std::shared_ptr<DefaultConvergenceCriteria>;
+  enum ConvergenceState {  // :73-81
+    CONVERGENCE_CRITERIA_NOT_CONVERGED = 0,
+    CONVERGENCE_CRITERIA_ITERATIONS = 1,
+    CONVERGENCE_CRITERIA_TRANSFORM = 2,
+    CONVERGENCE_CRITERIA_ABS_MSE = 3,
+    CONVERGENCE_CRITERIA_REL_MSE = 4,
+    CONVERGENCE_CRITERIA_NO_CORRESPONDENCES = 5,
+    CONVERGENCE_CRITERIA_FAILURE_AFTER_MAX_ITERATIONS = 6
+  };
+  void setMaximumIterationsSimilarTransforms(int n) { max_iterations_similar_transforms_ = n; }
+  int getMaximumIterationsSimilarTransforms() const { return max_iterations_similar_transforms_; }
+  void setMaximumIterations(int n) { max_iterations_ = n; }
+  int getMaximumIterations() const { return max_iterations_; }
+  void setFailureAfterMaximumIterations(bool f) { failure_after_max_iter_ = f; }
+  bool getFailureAfterMaximumIterations() const { return failure_after_max_iter_; }
+  void setRotationThreshold(double t) { rotation_threshold_ = t; }
+  double getRotationThreshold() const { return rotation_threshold_; }
+  void setTranslationThreshold(double t) { translation_threshold_ = t; }
+  double getTranslationThreshold() const { return translation_threshold_; }
+  void setRelativeMSE(double m) { mse_threshold_relative_ = m; }
+  double getRelativeMSE() const { return mse_threshold_relative_; }
+  void setAbsoluteMSE(double m) { mse_threshold_absolute_ = m; }
+  double getAbsoluteMSE() const { return mse_threshold_absolute_; }
+  ConvergenceState getConvergenceState() const { return ConvergenceState(state_); }
+  void setConvergenceState(ConvergenceState s) { state_ = int(s); }
+ private:
+  template <typename S, typename T> friend class ::pclhip::IterativeClosestPoint;
+  int max_iterations_ = 100, max_iterations_similar_transforms_ = 0;  // :289-316
+  bool failure_after_max_iter_ = false;
+  double rotation_threshold_ = 0.99999, translation_threshold_ = 3e-4 * 3e-4;
+  double mse_threshold_relative_ = 0.00001, mse_threshold_absolute_ = 1e-12;
+  int state_ = 0;
+};
+}  // namespace registration
+
 template <typename PointSource, typename PointTarget>
 class Registration : public PCLBase<PointSource> {
  public:
@@ -734,6 +847,20 @@ class Registration : public PCLBase<PointSource> {
     target_cloud_updated_ = true;
   }
   KdTreePtr getSearchMethodTarget() const { return tree_; }
+  // registration.h:230-262 (the reciprocal search's source tree; see CorrespondenceEstimationBase::setSearchMethodSource)
+  using KdTreeReciprocal = search::KdTree<PointSource>;
+  using KdTreeReciprocalPtr = typename KdTreeReciprocal::Ptr;
+  void setSearchMethodSource(const KdTreeReciprocalPtr& tree, bool force_no_recompute = false) {
+    tree_reciprocal_ = tree;
+    force_no_recompute_reciprocal_ = force_no_recompute;
+    source_cloud_updated_ = true;
+  }
+  KdTreeReciprocalPtr getSearchMethodSource() const { return tree_reciprocal_; }
+  // :300-322: RANSAC refinement parameters; IterativeClosestPoint does not use them (nor does the reference's)
+  void setRANSACIterations(int n) { ransac_iterations_ = n; }
+  double getRANSACIterations() const { return ransac_iterations_; }
+  void setRANSACOutlierRejectionThreshold(double t) { inlier_threshold_ = t; }
+  double getRANSACOutlierRejectionThreshold() const { return inlier_threshold_; }
   Matrix4 getFinalTransformation() { return final_transformation_; }
   Matrix4 getLastIncrementalTransformation() { return transformation_; }
   void setMaximumIterations(int nr_iterations) { max_iterations_ = nr_iterations; }
@@ -806,6 +933,10 @@ class Registration : public PCLBase<PointSource> {
   PointRepresentationConstPtr point_representation_;
   bool target_cloud_updated_ = true, source_cloud_updated_ = true, force_no_recompute_ = false;
   bool target_built_ = false;  // the tree was (re)built by this object since the device handle was last refreshed
+  KdTreeReciprocalPtr tree_reciprocal_;
+  bool force_no_recompute_reciprocal_ = false;
+  int ransac_iterations_ = 0;       // registration.h:570
+  double inlier_threshold_ = 0.05;  // :600
 };
 
 // pcl::IterativeClosestPoint<PointSource, PointTarget> (icp.h:98-347)
@@ -821,6 +952,7 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
     this->reg_name_ = "IterativeClosestPoint";
     this->transformation_estimation_ = std::make_shared<registration::TransformationEstimationSVD<PointSource, PointTarget>>(this->ctx_);
     this->correspondence_estimation_ = std::make_shared<registration::CorrespondenceEstimation<PointSource, PointTarget>>(this->ctx_);
+    convergence_criteria_ = std::make_shared<registration::DefaultConvergenceCriteria>();  // icp.h:144-146
     pclhip_convergence_init(&criteria_);
   }
   ~IterativeClosestPoint() override { if (icp_) pclhip_icp_destroy(icp_); }
@@ -829,10 +961,14 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
 
   void setUseReciprocalCorrespondences(bool on) { use_reciprocal_correspondence_ = on; }  // icp.h:251-256
   bool getUseReciprocalCorrespondences() const { return use_reciprocal_correspondence_; }
-  // DefaultConvergenceCriteria options reachable through getConvergeCriteria() in the reference
-  void setMaximumIterationsSimilarTransforms(int n) { max_iterations_similar_transforms_ = n; }
-  void setFailureAfterMaximumIterations(bool f) { failure_after_max_iterations_ = f; }
-  void setAbsoluteMSE(double mse) { mse_threshold_absolute_ = mse; }
+  // icp.h:180-184: the criteria object; its similar-transforms count, failure-after-max-iterations flag and absolute MSE
+  // threshold are the options a caller sets there (the other thresholds are overwritten from the registration's own
+  // setters at every align(), impl/icp.hpp:157-161)
+  registration::DefaultConvergenceCriteria::Ptr getConvergeCriteria() { return convergence_criteria_; }
+  // shortcuts for the same three options
+  void setMaximumIterationsSimilarTransforms(int n) { convergence_criteria_->setMaximumIterationsSimilarTransforms(n); }
+  void setFailureAfterMaximumIterations(bool f) { convergence_criteria_->setFailureAfterMaximumIterations(f); }
+  void setAbsoluteMSE(double mse) { convergence_criteria_->setAbsoluteMSE(mse); }
   int getNumberOfIterations() const { return this->nr_iterations_; }
   int getConvergenceState() const { return criteria_.convergence_state; }
   double getLastMSE() const { return last_mse_; }
@@ -870,9 +1006,16 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
     p.transformation_rotation_epsilon = this->transformation_rotation_epsilon_;
     p.euclidean_fitness_epsilon = this->euclidean_fitness_epsilon_;
     p.min_number_correspondences = this->min_number_correspondences_;
-    p.failure_after_max_iterations = failure_after_max_iterations_ ? 1 : 0;
-    p.max_iterations_similar_transforms = max_iterations_similar_transforms_;
-    p.mse_threshold_absolute = mse_threshold_absolute_;
+    auto& cc = *convergence_criteria_;
+    p.failure_after_max_iterations = cc.getFailureAfterMaximumIterations() ? 1 : 0;
+    p.max_iterations_similar_transforms = cc.getMaximumIterationsSimilarTransforms();
+    p.mse_threshold_absolute = cc.getAbsoluteMSE();
+    // impl/icp.hpp:157-161: what the loop pushes into the criteria before it starts
+    cc.setMaximumIterations(this->max_iterations_);
+    cc.setRelativeMSE(this->euclidean_fitness_epsilon_);
+    cc.setTranslationThreshold(this->transformation_epsilon_);
+    if (this->transformation_rotation_epsilon_ > 0) cc.setRotationThreshold(this->transformation_rotation_epsilon_);
+    else cc.setRotationThreshold(0.99999);
   }
   // device-side registration object bound to the tree; source (and normals) uploaded when they changed
   bool ensureHandle(int mode) {
@@ -931,6 +1074,7 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
       this->converged_ = r.converged != 0;
       this->nr_iterations_ = r.nr_iterations;
       criteria_.convergence_state = r.convergence_state;
+      convergence_criteria_->setConvergenceState(registration::DefaultConvergenceCriteria::ConvergenceState(r.convergence_state));
       last_mse_ = r.mse;
       output = *this->input_;  // icp.hpp:264-267: all fields of the WHOLE input cloud, then xyz (+ normals) moved
       transformCloud(output, this->final_transformation_, mode);
@@ -974,14 +1118,13 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
       last_mse_ = mse;
       this->converged_ = pclhip_convergence_has_converged(&p, &criteria_, this->nr_iterations_, this->transformation_.m, mse) != 0;
     } while (criteria_.convergence_state == 0);
+    convergence_criteria_->setConvergenceState(registration::DefaultConvergenceCriteria::ConvergenceState(criteria_.convergence_state));
     output = *this->input_;
     transformCloud(output, this->final_transformation_, tmode);
   }
 
   bool use_reciprocal_correspondence_ = false;
-  int max_iterations_similar_transforms_ = 0;
-  bool failure_after_max_iterations_ = false;
-  double mse_threshold_absolute_ = 1e-12;
+  registration::DefaultConvergenceCriteria::Ptr convergence_criteria_;
   pclhip_convergence_state criteria_;
   double last_mse_ = 0;
   bool device_loop_ = false;
@@ -1060,34 +1203,47 @@ template <typename PointT> int savePCDFileBinary(const std::string& f, const Poi
 template <typename PointT> int savePCDFileBinaryCompressed(const std::string& f, const PointCloud<PointT>& c) { return savePCDFile(f, c, 2); }
 }  // namespace io
 
-// pcl::VoxelGrid<pcl::PointXYZ>
+// pcl::VoxelGrid<PointT> (filters/include/pcl/filters/voxel_grid.h:210-533) for pcl::PointXYZ and pcl::PointNormal
+template <typename PointT = PointXYZ>
 class VoxelGrid {
  public:
   VoxelGrid() : VoxelGrid(Context::defaultContext()) {}
   explicit VoxelGrid(Context::Ptr ctx) : ctx_(std::move(ctx)) {}
-  void setInputCloud(const PointCloud<PointXYZ>::ConstPtr& c) { input_ = c; }
+  void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) { input_ = c; }
+  typename PointCloud<PointT>::ConstPtr getInputCloud() const { return input_; }
   void setLeafSize(float lx, float ly, float lz) { leaf_[0] = lx; leaf_[1] = ly; leaf_[2] = lz; }
+  std::array<float, 3> getLeafSize() const { return {leaf_[0], leaf_[1], leaf_[2]}; }
+  // :293-301: false -> only x, y, z are averaged, every other field of the output keeps its default
+  void setDownsampleAllData(bool downsample) { downsample_all_data_ = downsample; }
+  bool getDownsampleAllData() const { return downsample_all_data_; }
   void setMinimumPointsNumberPerVoxel(unsigned n) { min_pts_ = n; }
+  unsigned getMinimumPointsNumberPerVoxel() const { return min_pts_; }
+  // :440-476: pass-through filter on one field before the grid; the device path knows the field "z"
   void setFilterFieldName(const std::string& f) { field_ = f; }
+  const std::string& getFilterFieldName() const { return field_; }
   void setFilterLimits(double lo, double hi) { lo_ = lo; hi_ = hi; }
+  void getFilterLimits(double& lo, double& hi) const { lo = lo_; hi = hi_; }
   // Filter::filter -> applyFilter (filters/include/pcl/filters/impl/voxel_grid.hpp:597-814); when the
   // voxel index would overflow the reference warns and returns the input unchanged (:620-629)
-  void filter(PointCloud<PointXYZ>& output) {
+  void filter(PointCloud<PointT>& output) {
     output.points.clear();
     output.height = 1;
     output.is_dense = true;
     if (!input_) { output.width = 0; return; }
-    std::vector<PointXYZ> out(input_->size());
+    if (!field_.empty() && field_ != "z") { output.width = 0; return; }  // refused, not silently ignored
+    constexpr std::size_t noff = has_normal_fields<PointT>() ? 16 : 0;
+    std::vector<PointT> out(input_->size());
     std::uint64_t n = 0;
     leaf_layout_.clear();
     dims_ = pclhip_voxelgrid_dims{};
     if (save_leaf_layout_ && !input_->empty()) {  // one int per grid cell: learn the grid first (bounding-box pass)
-      if (pclhip_voxelgrid_grid(ctx_->get(), input_->points.data(), sizeof(PointXYZ), input_->size(), leaf_, field_ == "z",
+      if (pclhip_voxelgrid_grid(ctx_->get(), input_->points.data(), sizeof(PointT), input_->size(), leaf_, field_ == "z",
                                 lo_, hi_, &dims_) == PCLHIP_OK)
         leaf_layout_.assign(std::size_t(dims_.div_b[0]) * std::size_t(dims_.div_b[1]) * std::size_t(dims_.div_b[2]), -1);
     }
-    const pclhip_status st = pclhip_voxelgrid_ex2(ctx_->get(), input_->points.data(), sizeof(PointXYZ), input_->size(), leaf_,
-                                                  min_pts_, field_ == "z", lo_, hi_, 1, 0, out.data(), sizeof(PointXYZ), &n,
+    const pclhip_status st = pclhip_voxelgrid_ex2(ctx_->get(), input_->points.data(), sizeof(PointT), input_->size(), leaf_,
+                                                  min_pts_, field_ == "z", lo_, hi_, downsample_all_data_ ? 1 : 0, noff,
+                                                  out.data(), sizeof(PointT), &n,
                                                   leaf_layout_.empty() ? nullptr : leaf_layout_.data(), leaf_layout_.size(),
                                                   &dims_);
     if (st == PCLHIP_ERR_OVERFLOW) { output = *input_; return; }
@@ -1098,6 +1254,7 @@ class VoxelGrid {
   }
   // the grid of the last filter() and the leaf layout (filters/include/pcl/filters/voxel_grid.h:316-421)
   void setSaveLeafLayout(bool save) { save_leaf_layout_ = save; }
+  bool getSaveLeafLayout() const { return save_leaf_layout_; }
   std::array<int, 3> getMinBoxCoordinates() const { return {dims_.min_b[0], dims_.min_b[1], dims_.min_b[2]}; }
   std::array<int, 3> getMaxBoxCoordinates() const { return {dims_.max_b[0], dims_.max_b[1], dims_.max_b[2]}; }
   std::array<int, 3> getNrDivisions() const { return {dims_.div_b[0], dims_.div_b[1], dims_.div_b[2]}; }
@@ -1112,11 +1269,23 @@ class VoxelGrid {
     if (idx < 0 || idx >= (long long)leaf_layout_.size()) return -1;
     return leaf_layout_[std::size_t(idx)];
   }
-  int getCentroidIndex(const PointXYZ& p) const { return getCentroidIndexAt(getGridCoordinates(p.x, p.y, p.z)); }
+  int getCentroidIndex(const PointT& p) const { return getCentroidIndexAt(getGridCoordinates(p.x, p.y, p.z)); }
+  // :353-376: centroid indices of the cells at the given offsets around the reference point's cell
+  std::vector<int> getNeighborCentroidIndices(const PointT& reference_point, const std::vector<std::array<int, 3>>& relative_coordinates) const {
+    const std::array<int, 3> c = getGridCoordinates(reference_point.x, reference_point.y, reference_point.z);
+    std::vector<int> neighbors;
+    for (const auto& r : relative_coordinates) {
+      const std::array<int, 3> cell = {c[0] + r[0], c[1] + r[1], c[2] + r[2]};
+      bool inside = true;  // the reference clamps by min_b_/max_b_
+      for (int d = 0; d < 3; ++d) inside = inside && cell[d] >= dims_.min_b[d] && cell[d] <= dims_.max_b[d];
+      neighbors.push_back(inside ? getCentroidIndexAt(cell) : -1);
+    }
+    return neighbors;
+  }
  private:
   Context::Ptr ctx_;
-  PointCloud<PointXYZ>::ConstPtr input_;
-  bool save_leaf_layout_ = false;
+  typename PointCloud<PointT>::ConstPtr input_;
+  bool save_leaf_layout_ = false, downsample_all_data_ = true;  // voxel_grid.h:501
   std::vector<std::int32_t> leaf_layout_;
   pclhip_voxelgrid_dims dims_{};
   float leaf_[3] = {0, 0, 0};

@@ -1310,6 +1310,51 @@ int64_t orc_normals_knn(const orc_kdtree* t, const float* cloud, int64_t n, int 
   return orc_normals_knn_indices(t, cloud, n, cs, k, vp, NULL, 0, out, out_knn, nthreads);
 }
 
+/* Feature::setSearchSurface (features/include/pcl/features/impl/feature.hpp:104-118,195-229): the tree holds the
+ * SURFACE cloud, the queries come from another cloud (`input_`, restricted to `indices` when given).  computeFeature
+ * (impl/normal_3d.hpp:48-95) then searches the surface around every query, fits the plane to the surface points
+ * found (normal_3d.h:308-322: computePointNormal(*surface_, nn_indices, ...)) and flips the normal towards the
+ * viewpoint as seen from the QUERY point (normal_3d.hpp:66,87: input_->points[idx]). */
+int64_t orc_normals_knn_queries(const orc_kdtree* t, const float* surface, int ss, const float* queries, int64_t nq_cloud,
+                                int qs, const int32_t* indices, int64_t n_indices, int k, const float* vp, float* out,
+                                int32_t* out_knn, int nthreads) {
+  int64_t nan_count = 0;
+  if (nthreads < 1) nthreads = 1;
+  const int64_t nq = indices ? n_indices : nq_cloud;
+#pragma omp parallel num_threads(nthreads) reduction(+ : nan_count)
+  {
+    int32_t* idx = (int32_t*)malloc((size_t)k * sizeof(int32_t));
+    float* d2 = (float*)malloc((size_t)k * sizeof(float));
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t j = 0; j < nq; ++j) {
+      const int64_t i = indices ? (int64_t)indices[j] : j;
+      const float* p = queries + i * qs;
+      float* o = out + 4 * j;
+      int found = 0;
+      if (finite3(p)) found = orc_kdtree_knn(t, p, 1, qs, k, idx, d2, 1);
+      if (out_knn)
+        for (int c = 0; c < k; ++c) out_knn[j * k + c] = (finite3(p) && c < found) ? idx[c] : -1;
+      float cov[9], cen[4];
+      if (!finite3(p) || found < 3 || orc_mean_and_covariance(surface, ss, idx, found, cov, cen) == 0) {
+        o[0] = o[1] = o[2] = o[3] = NAN;
+        ++nan_count;
+        continue;
+      }
+      orc_solve_plane_parameters(cov, &o[0], &o[1], &o[2], &o[3]);
+      float vx = vp[0] - p[0], vy = vp[1] - p[1], vz = vp[2] - p[2]; /* normal_3d.h:169-188 */
+      float cos_theta = (vx * o[0] + vy * o[1] + vz * o[2]);
+      if (cos_theta < 0) {
+        o[0] *= -1;
+        o[1] *= -1;
+        o[2] *= -1;
+      }
+    }
+    free(idx);
+    free(d2);
+  }
+  return nan_count;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 typedef struct {
   uint32_t idx;

@@ -107,6 +107,8 @@ def lib():
         L.orc_normals_knn.argtypes = [vp, fp, C.c_int64, C.c_int, C.c_int, fp, fp, ip, C.c_int]
         L.orc_normals_knn_indices.restype = C.c_int64
         L.orc_normals_knn_indices.argtypes = [vp, fp, C.c_int64, C.c_int, C.c_int, fp, ip, C.c_int64, fp, ip, C.c_int]
+        L.orc_normals_knn_queries.restype = C.c_int64
+        L.orc_normals_knn_queries.argtypes = [vp, fp, C.c_int, fp, C.c_int64, C.c_int, ip, C.c_int64, C.c_int, fp, fp, ip, C.c_int]
         L.orc_voxelgrid.restype = C.c_int64
         L.orc_voxelgrid.argtypes = [fp, C.c_int64, C.c_int, fp, C.c_uint, C.c_int, C.c_double,
                                     C.c_double, fp, ip]
@@ -224,6 +226,21 @@ class KdTree:
                                             _i(ind) if ind is not None else None, nq, _f(out),
                                             _i(knn) if want_knn else None, nthreads or default_threads())
         return (out, knn, nan) if want_knn else (out, nan)
+
+    def normals_at(self, surface, queries, k, viewpoint=(0.0, 0.0, 0.0), indices=None, nthreads=None):
+        """Feature::setSearchSurface: the tree holds `surface`; one normal per query (or per queries[indices]),
+        fitted to the k nearest SURFACE points, flipped towards the viewpoint as seen from the query."""
+        surface, n, ss = _cloud(surface)
+        assert n == self.n, "normals_at(): pass the cloud the tree was built on as the surface"
+        queries, nqc, qs = _cloud(queries)
+        ind = None if indices is None else np.ascontiguousarray(indices, np.int32)
+        nq = nqc if ind is None else len(ind)
+        out = np.empty((nq, 4), np.float32)
+        vp = np.asarray(viewpoint, np.float32)
+        nan = lib().orc_normals_knn_queries(self.h, _f(surface), ss, _f(queries), nqc, qs,
+                                            _i(ind) if ind is not None else None, nq, int(k), _f(vp), _f(out), None,
+                                            nthreads or default_threads())
+        return out, nan
 
 
 def lls_point_to_plane(src, tgt, nrm, q=None, m=None):

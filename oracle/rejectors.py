@@ -123,6 +123,33 @@ def radius_search_bruteforce(tgt, qry, radius, max_nn=0):
             np.concatenate(dd) if dd else np.zeros(0, np.float32))
 
 
+def normals_radius_at(orc, surface, queries, radius, viewpoint=(0.0, 0.0, 0.0)):
+    """The same with a search surface different from the input (Feature::setSearchSurface): neighbours of every
+    query among the SURFACE points, normal flipped as seen from the query.  Small clouds only."""
+    surface = np.ascontiguousarray(surface, np.float32)
+    queries = np.ascontiguousarray(queries, np.float32)
+    off, idx, _ = radius_search_bruteforce(surface, queries, radius)
+    out = np.full((len(queries), 4), np.nan, np.float32)
+    nan = 0
+    vp = np.asarray(viewpoint, np.float32)
+    for i in range(len(queries)):
+        nb = idx[int(off[i]):int(off[i + 1])]
+        if not np.isfinite(queries[i, :3]).all() or len(nb) < 3:
+            nan += 1
+            continue
+        cov, cen, cnt = orc.mean_and_covariance(surface, nb)
+        if cnt == 0:
+            nan += 1
+            continue
+        nx, ny, nz, curv = orc.solve_plane_parameters(cov)
+        v = vp - queries[i, :3]
+        cos_theta = np.float32(v[0] * np.float32(nx) + v[1] * np.float32(ny)) + v[2] * np.float32(nz)
+        if cos_theta < 0:
+            nx, ny, nz = -nx, -ny, -nz
+        out[i] = (nx, ny, nz, curv)
+    return out, nan
+
+
 def normals_radius(orc, cloud, radius, viewpoint=(0.0, 0.0, 0.0)):
     """NormalEstimation with setRadiusSearch (Feature::compute, features/include/pcl/features/impl/feature.hpp
     :140-155 -> normal_3d.hpp:48-95): plane fit over all neighbours within the radius in the order

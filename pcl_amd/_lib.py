@@ -104,6 +104,8 @@ SIGNATURES = {
                                        C.POINTER(_u64)]),
     "pclhip_normals": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), _vp, _sz, C.POINTER(_u64)]),
     "pclhip_normals_radius": (C.c_int, [_vp, C.c_double, C.POINTER(C.c_float), _vp, _sz, C.POINTER(_u64)]),
+    "pclhip_normals_at": (C.c_int, [_vp, _vp, _sz, _u64, _vp, _u64, C.c_int, C.c_double, C.POINTER(C.c_float), _vp, _sz,
+                                    C.POINTER(_u64)]),
     "pclhip_gicp_covariances": (C.c_int, [_vp, C.c_int, C.c_double, _vp]),
     "pclhip_index_set_normals": (C.c_int, [_vp, _vp, _sz]),
     "pclhip_icp_params_default": (None, [C.POINTER(IcpParams)]),

@@ -280,13 +280,39 @@ class NormalEstimation:
         self.radius = 0.0
         self.vp = np.zeros(3, np.float32)  # sensor_origin_ default (normal_3d.h:328-351)
         self.cloud = None
+        self.surface = None
+        self.indices = None
         self.nan_count = 0
 
     def setInputCloud(self, cloud):
         self.cloud = cloud
 
+    def setSearchSurface(self, cloud):
+        """Feature::setSearchSurface (features/include/pcl/features/feature.h:139-153): neighbours are taken from this
+        cloud, normals are computed at the input cloud's points (None: surface == input)."""
+        self.surface = cloud
+
+    def getSearchSurface(self):
+        return self.surface
+
+    def setIndices(self, indices):
+        """PCLBase::setIndices (common/include/pcl/pcl_base.h:102-125): one normal per input[indices[j]]."""
+        self.indices = None if indices is None else np.ascontiguousarray(indices, np.int32)
+
     def setSearchMethod(self, tree):
         self.tree = tree
+
+    def getSearchMethod(self):
+        return self.tree
+
+    def getKSearch(self):
+        return self.k
+
+    def getRadiusSearch(self):
+        return self.radius
+
+    def getViewPoint(self):
+        return tuple(float(v) for v in self.vp)
 
     def setKSearch(self, k):
         self.k = int(k)
@@ -306,6 +332,8 @@ class NormalEstimation:
             raise ValueError("Neither radius nor K defined! Set one of them to a positive number first")
         if self.tree is None:
             self.tree = KdTree(self.ctx)
+        if self.surface is not None or self.indices is not None:
+            return self._compute_at(want_output)
         # feature.hpp:125-130 sets the search surface on the tree.  A tree the caller has already built
         # on this very cloud object is reused (setSearchMethod(tree) after tree.setInputCloud(cloud), the
         # common PCL idiom, would otherwise build twice).
@@ -331,6 +359,29 @@ class NormalEstimation:
                   self.ctx.h)
         self.nan_count = int(nan.value)
         return out
+
+
+    def _compute_at(self, want_output):
+        """search surface != input and / or an index subset of the input (impl/feature.hpp:104-130,
+        impl/normal_3d.hpp:48-95): the tree indexes the surface, every (selected) input point is a query."""
+        surface = self.surface if self.surface is not None else self.cloud
+        if self.tree.h is None or self.tree._cloud_id != (id(surface), None):
+            self.tree.setInputCloud(surface)
+        base, stride, nq, _keep = _cloud(self.cloud)
+        m = nq if self.indices is None else len(self.indices)
+        if _is_torch(self.cloud):
+            import torch
+            out = torch.empty((m, 4), dtype=torch.float32, device=self.cloud.device)
+            optr = C.c_void_p(out.data_ptr())
+        else:
+            out = np.empty((m, 4), np.float32)
+            optr = C.c_void_p(out.ctypes.data)
+        nan = C.c_uint64(0)
+        ind = None if self.indices is None else C.c_void_p(self.indices.ctypes.data)
+        check(self.lib.pclhip_normals_at(self.tree.h, base, stride, nq, ind, 0 if self.indices is None else m, self.k,
+                                         self.radius, _fp(self.vp), optr, 16, C.byref(nan)), self.ctx.h)
+        self.nan_count = int(nan.value)
+        return out if want_output else None
 
 
 class CorrespondenceRejectorDistance:

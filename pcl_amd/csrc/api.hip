@@ -551,6 +551,79 @@ pclhip_status pclhip_normals_radius(pclhip_index* ix, double radius, const float
 }
 
 namespace {
+// query j <- record sel[j] (or j) of a strided cloud, as a dense float4 with w = 1
+__global__ void gather_queries_kernel(const void* pts, size_t stride, const int32_t* __restrict__ sel, uint64_t m,
+                                      float4* __restrict__ out) {
+  const uint64_t j = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  if (j >= m) return;
+  const uint64_t rec = sel ? uint64_t(sel[j]) : j;
+  const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pts) + rec * stride);
+  out[j] = make_float4(p[0], p[1], p[2], 1.0f);
+}
+}  // namespace
+
+pclhip_status pclhip_normals_at(pclhip_index* ix, const void* queries, size_t stride, uint64_t nq, const int32_t* indices,
+                                uint64_t n_indices, int k, double radius, const float viewpoint[3], void* out,
+                                size_t out_stride, uint64_t* out_nan_count) {
+  if (!ix) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = ix->ctx;
+  if (out_nan_count) *out_nan_count = 0;
+  PCLHIP_REQUIRE(ctx, (k >= 1) != (radius > 0.0), "set either k >= 1 or a positive radius");
+  PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
+  PCLHIP_REQUIRE(ctx, out_stride >= 16 && out_stride % 4 == 0, "out stride must be a multiple of 4 and >= 16 bytes");
+  PCLHIP_REQUIRE(ctx, nq < 0x7FFFFFFFull && n_indices < 0x7FFFFFFFull, "too many queries");
+  PCLHIP_REQUIRE(ctx, !ix->scaled, "normals need an index built in the cloud's own coordinates (no rescaling representation)");
+  const uint64_t m = indices ? n_indices : nq;
+  if (m == 0) return PCLHIP_OK;
+  PCLHIP_REQUIRE(ctx, queries && out, "null buffer");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx);
+  const void* dq = nullptr;
+  void* owned = nullptr;
+  pclhip_status st = to_device(ctx, queries, size_t(nq) * stride, &dq, &owned);
+  if (st != PCLHIP_OK) return st;
+  guard.add(owned);
+  const void* dsel = nullptr;
+  if (indices) {  // Feature::setIndices: untrusted, an index outside the cloud would be a wild device read
+    st = to_device(ctx, indices, size_t(n_indices) * sizeof(int32_t), &dsel, &owned);
+    if (st != PCLHIP_OK) return st;
+    guard.add(owned);
+    int* bad = nullptr;
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &bad, sizeof(int)));
+    guard.add(bad);
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(check_indices_kernel, dim3(unsigned((n_indices + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<const int32_t*>(dsel), n_indices, nq, bad);
+    int hbad = 0;
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PCLHIP_REQUIRE(ctx, hbad == 0, "indices must lie in [0, n)");
+  }
+  float4 *qd = nullptr, *dense = nullptr;
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &qd, size_t(m) * sizeof(float4)));
+  guard.add(qd);
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &dense, size_t(m) * sizeof(float4)));
+  guard.add(dense);
+  hipLaunchKernelGGL(gather_queries_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, dq, stride,
+                     static_cast<const int32_t*>(dsel), m, qd);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  const float zero[3] = {0, 0, 0};
+  uint64_t nan = 0;
+  if (ix->n == 0) {  // nothing to search: every normal is NaN (Feature::compute on an empty surface)
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(dense, 0xFF, size_t(m) * sizeof(float4), ctx->stream));
+    nan = m;
+  } else {
+    st = launch_normals_at(ix, qd, uint32_t(m), k >= 1 ? k : 0, radius, viewpoint ? viewpoint : zero, dense, &nan);
+    if (st != PCLHIP_OK) {
+      (void)hipStreamSynchronize(ctx->stream);
+      return st;
+    }
+  }
+  if (out_nan_count) *out_nan_count = nan;
+  return copy_out_strided(ctx, out, out_stride, dense, sizeof(float4), m);
+}
+
+namespace {
 __global__ void scatter_cov_kernel(const double* __restrict__ cov_sorted, const uint32_t* __restrict__ rank, uint64_t n_orig,
                                    double* __restrict__ dense) {
   const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;

@@ -293,6 +293,12 @@ pclhip_status launch_estimate_pairs(pclhip_ctx* ctx, int mode, const float4* src
                                     const float4* tgt, const float4* tgt_nrm, const float* weights, uint32_t n, bool enforce,
                                     double* sums);
 pclhip_status launch_normals_radius(pclhip_index* ix, double radius, const float vp[3], uint64_t* nan_count);
+// normals at arbitrary query points (Feature::setSearchSurface): `queries` dense float4 in slot order; the radius form
+// takes them in kd order with w = slot
+pclhip_status launch_normals_at(pclhip_index* ix, const float4* queries, uint32_t nq, int k, double radius, const float vp[3],
+                                float4* out, uint64_t* nan_count);
+pclhip_status launch_normals_radius_at(pclhip_index* ix, const float4* queries_sorted, uint32_t nq, double radius,
+                                       const float vp[3], float4* out, uint64_t* nan_count);
 pclhip_status launch_gicp_covariances(pclhip_index* ix, int k, double eps, double* cov_sorted);
 pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double max_range, double* score,
                                    uint64_t* nr);

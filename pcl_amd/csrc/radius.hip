@@ -125,7 +125,10 @@ __global__ void radius_emit_kernel(const uint64_t* __restrict__ keys, const unsi
 // Feature::compute, impl/feature.hpp:140-155): plane fit over ALL neighbours within the radius, in the
 // order radiusSearch returns them (ascending distance, ties by index).  One thread per query walks its
 // sorted segment; fewer than 3 neighbours -> NaN (normal_3d.h:308-322).
+// `q`: the queries (the index's own points for search surface == input); by_slot: the result goes to out[q[i].w] (queries
+// of another cloud, Feature::setSearchSurface) instead of out[i].
 __global__ __launch_bounds__(BLOCK) void normals_from_radius_kernel(IndexView ix, const uint32_t* __restrict__ rank,
+                                                                    const float4* __restrict__ q, int by_slot,
                                                                     const uint64_t* __restrict__ keys,
                                                                     const unsigned long long* __restrict__ offsets,
                                                                     unsigned long long base, uint32_t q_begin,
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(BLOCK) void normals_from_radius_kernel(IndexView ix
                                                                     unsigned long long* __restrict__ nan_count) {
   const uint32_t i = q_begin + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= q_end) return;
-  const float4 p = ix.pts[i];
+  const float4 p = q[i];
   const unsigned long long b = offsets[i] - base, cnt = offsets[i + 1] - offsets[i];
   const float qnan = __builtin_nanf("");
   float4 out;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(BLOCK) void normals_from_radius_kernel(IndexView ix
     flip_to_viewpoint(p.x, p.y, p.z, vx, vy, vz, nx, ny, nz);
     out = make_float4(nx, ny, nz, curv);
   }
-  nrm_sorted[i] = out;
+  nrm_sorted[by_slot ? __float_as_uint(p.w) : i] = out;
 }
 
 struct SubBase {  // segment offsets relative to a chunk's first key
@@ -273,17 +276,37 @@ extern "C" pclhip_status pclhip_radius_search(pclhip_index* ix, const void* quer
 
 // NormalEstimation::setRadiusSearch path.  Neighbour lists are materialised chunk by chunk (at most
 // ~2^27 (distance, index) keys = 2 GB of sort buffers at a time), never for the whole cloud at once.
+static pclhip_status normals_radius_impl(pclhip_index* ix, const float4* queries, uint32_t nq, double radius, const float vp[3],
+                                         float4* out, uint64_t* nan_count);
+
 pclhip_status pclhip::launch_normals_radius(pclhip_index* ix, double radius, const float vp[3], uint64_t* nan_count) {
+  return normals_radius_impl(ix, nullptr, ix->n, radius, vp, nullptr, nan_count);
+}
+
+pclhip_status pclhip::launch_normals_radius_at(pclhip_index* ix, const float4* queries_sorted, uint32_t nq, double radius,
+                                               const float vp[3], float4* out, uint64_t* nan_count) {
+  return normals_radius_impl(ix, queries_sorted, nq, radius, vp, out, nan_count);
+}
+
+// queries == nullptr: the index's own points, normals kept in the index (search surface == input); else `nq` queries
+// in kd order with w = output slot, normals to out[slot]
+static pclhip_status normals_radius_impl(pclhip_index* ix, const float4* queries, uint32_t nq, double radius, const float vp[3],
+                                         float4* out, uint64_t* nan_count) {
   pclhip_ctx* ctx = ix->ctx;
   hipStream_t s = ctx->stream;
   Guard g;
   g.ctx = ctx;
-  if (!ix->nrm) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->nrm, size_t(ix->n_pad > 0 ? ix->n_pad : 1) * sizeof(float4)));
-  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(ix->nrm, 0xFF, size_t(ix->n_pad) * sizeof(float4), s));  // NaN pads
+  const bool self = queries == nullptr;
+  if (self) {
+    if (!ix->nrm) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->nrm, size_t(ix->n_pad > 0 ? ix->n_pad : 1) * sizeof(float4)));
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(ix->nrm, 0xFF, size_t(ix->n_pad) * sizeof(float4), s));  // NaN pads
+  }
   if (nan_count) *nan_count = 0;
-  const uint32_t n = ix->n;
+  const uint32_t n = nq;
+  const float4* q = self ? ix->pts : queries;
+  float4* dst = self ? ix->nrm : out;
   if (n == 0) {
-    ix->has_normals = true;
+    if (self) ix->has_normals = true;
     return PCLHIP_OK;
   }
   const float r2 = float(radius * radius);  // kdtree_flann.hpp:398
@@ -306,7 +329,7 @@ pclhip_status pclhip::launch_normals_radius(pclhip_index* ix, double radius, con
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   (void)hipEventRecord(e0, s);
-  hipLaunchKernelGGL((radius_kernel<false, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, v, ix->pts, n, r2, counts,
+  hipLaunchKernelGGL((radius_kernel<false, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, v, q, n, r2, counts,
                      (const unsigned long long*)nullptr, (uint64_t*)nullptr, 0u, 0ull);
   size_t tb = 0;
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(wide + n, 0, 8, s));
@@ -338,7 +361,7 @@ pclhip_status pclhip::launch_normals_radius(pclhip_index* ix, double radius, con
     const uint32_t a = cuts[c], b = cuts[c + 1];
     const unsigned long long base = h_off[a], nkeys = h_off[b] - h_off[a];
     if (nkeys > 0) {
-      hipLaunchKernelGGL((radius_kernel<true, true>), dim3(grid_for(b - a)), dim3(BLOCK), 0, s, v, ix->pts, b, r2, counts, off,
+      hipLaunchKernelGGL((radius_kernel<true, true>), dim3(grid_for(b - a)), dim3(BLOCK), 0, s, v, q, b, r2, counts, off,
                          k0, a, base);
       // segment offsets of this chunk, relative to its first key: sort with begin/end iterators shifted by base
       const SubBase sub{base};
@@ -353,8 +376,8 @@ pclhip_status pclhip::launch_normals_radius(pclhip_index* ix, double radius, con
       }
       PCLHIP_CHECK_HIP(ctx, rocprim::segmented_radix_sort_keys(stmp, sb, k0, k1, size_t(nkeys), b - a, begin_it, end_it, 0, 64, s));
     }
-    hipLaunchKernelGGL(normals_from_radius_kernel, dim3((b - a + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, v, ix->rank, k1, off,
-                       base, a, b, vp[0], vp[1], vp[2], ix->nrm, d_nan);
+    hipLaunchKernelGGL(normals_from_radius_kernel, dim3((b - a + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, v, ix->rank, q, self ? 0 : 1, k1,
+                       off, base, a, b, vp[0], vp[1], vp[2], dst, d_nan);
   }
   (void)hipEventRecord(e1, s);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
@@ -366,6 +389,6 @@ pclhip_status pclhip::launch_normals_radius(pclhip_index* ix, double radius, con
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (nan_count) *nan_count = h;
-  ix->has_normals = true;
+  if (self) ix->has_normals = true;
   return PCLHIP_OK;
 }

@@ -371,6 +371,44 @@ __global__ __launch_bounds__(BLOCK) void normals_from_knn_kernel(IndexView ix, i
   nrm_sorted[i] = out;
 }
 
+// Feature::setSearchSurface / setIndices (features/include/pcl/features/impl/feature.hpp:104-118): the index is the
+// SURFACE, the queries are another cloud.  Row j of `knn` holds the original surface ids of query j's neighbours in
+// the order the search returns them; the plane is fitted to those surface points (normal_3d.h:308-322) and the
+// normal flipped towards the viewpoint as seen from the QUERY point (impl/normal_3d.hpp:66,87).
+__global__ __launch_bounds__(BLOCK) void normals_at_kernel(IndexView ix, int k, const uint32_t* __restrict__ rank,
+                                                           const float4* __restrict__ q, uint32_t nq,
+                                                           const int32_t* __restrict__ knn, float vx, float vy, float vz,
+                                                           float4* __restrict__ out,
+                                                           unsigned long long* __restrict__ nan_count) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nq) return;
+  const float4 p = q[j];
+  const int32_t* nb = knn + size_t(j) * k;
+  int found = 0;
+  for (int c = 0; c < k; ++c) found += (nb[c] >= 0);
+  const float qnan = __builtin_nanf("");
+  float4 o;
+  if (found < 3 || !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {
+    o = make_float4(qnan, qnan, qnan, qnan);
+    atomicAdd(nan_count, 1ull);
+  } else {
+    Cov cv;
+    const float4 p0 = ix.pts[rank[nb[0]]];
+    cv.start(p0.x, p0.y, p0.z);
+    for (int c = 0; c < found; ++c) {
+      const float4 pc = ix.pts[rank[nb[c]]];
+      cv.add(pc.x, pc.y, pc.z);
+    }
+    float cov[9];
+    cv.finish(found, cov);
+    float nx, ny, nz, curv;
+    solve_plane(cov, nx, ny, nz, curv);
+    flip_to_viewpoint(p.x, p.y, p.z, vx, vy, vz, nx, ny, nz);
+    o = make_float4(nx, ny, nz, curv);
+  }
+  out[j] = o;
+}
+
 __global__ void iota_w_kernel(const float4* __restrict__ pts, uint32_t n, float4* __restrict__ q) {
   // queries = the sorted points with w = SORTED position, so knn results land at row `sorted pos`
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,6 +472,45 @@ pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_
   if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ix->last_kernel_ms = ms;
   if (nan_count) *nan_count = h;
   ix->has_normals = true;
+  return PCLHIP_OK;
+}
+
+// queries: `nq` dense float4 records in slot order (device); out: one float4 (normal, curvature) per slot
+pclhip_status launch_normals_at(pclhip_index* ix, const float4* queries, uint32_t nq, int k, double radius, const float vp[3],
+                                float4* out, uint64_t* nan_count) {
+  pclhip_ctx* ctx = ix->ctx;
+  hipStream_t s = ctx->stream;
+  if (nan_count) *nan_count = 0;
+  if (nq == 0) return PCLHIP_OK;
+  DeviceScope scope(ctx);
+  float4* qs = nullptr;  // the queries in kd order (compact 64-query groups), w = slot
+  PCLHIP_CHECK_HIP(ctx, scope.alloc(&qs, size_t(nq) * sizeof(float4)));
+  uint32_t nf = 0;
+  float lo[3], hi[3];
+  pclhip_status st = spatial_order(ctx, queries, sizeof(float4), nq, nullptr, 0, qs, nq, &nf, lo, hi, true, nullptr);
+  if (st != PCLHIP_OK) return st;
+  if (k < 1) return launch_normals_radius_at(ix, qs, nq, radius, vp, out, nan_count);
+  unsigned long long* d_nan = nullptr;
+  int32_t* nb = nullptr;
+  float* nd = nullptr;
+  PCLHIP_CHECK_HIP(ctx, scope.alloc(&d_nan, sizeof(unsigned long long)));
+  PCLHIP_CHECK_HIP(ctx, scope.alloc(&nb, size_t(nq) * k * sizeof(int32_t)));
+  PCLHIP_CHECK_HIP(ctx, scope.alloc(&nd, size_t(nq) * k * sizeof(float)));
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_nan, 0, sizeof(unsigned long long), s));
+  st = launch_knn(ix, qs, nq, k, nb, nd);
+  if (st != PCLHIP_OK) {
+    (void)hipStreamSynchronize(s);  // nothing may still use the scope's buffers when they are freed
+    return st;
+  }
+  hipLaunchKernelGGL(normals_at_kernel, dim3((nq + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, ix->view(), k, ix->rank, queries, nq,
+                     nb, vp[0], vp[1], vp[2], out, d_nan);
+  unsigned long long h = 0;
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, d_nan, sizeof h, hipMemcpyDeviceToHost, s);
+  const hipError_t es = hipStreamSynchronize(s);  // always drain the stream before the scope frees its buffers
+  PCLHIP_CHECK_HIP(ctx, e);
+  PCLHIP_CHECK_HIP(ctx, es);
+  if (nan_count) *nan_count = h;
   return PCLHIP_OK;
 }
 

@@ -147,7 +147,7 @@ int main(int argc, char** argv) {
     EXPECT(reg.hasConverged() && reg.getNumberOfIterations() > 1);
   }
   {  // VoxelGrid 103
-    VoxelGrid grid(ctx);
+    VoxelGrid<PointXYZ> grid(ctx);
     grid.setLeafSize(0.02f, 0.02f, 0.02f);
     grid.setInputCloud(source);
     PointCloud<PointXYZ> out;
@@ -167,6 +167,104 @@ int main(int argc, char** argv) {
     EXPECT(grid.getCentroidIndex((*source)[0]) >= 0 && grid.getCentroidIndex((*source)[0]) < 103);
     const auto mn = grid.getMinBoxCoordinates();
     EXPECT(grid.getCentroidIndexAt({mn[0] - 1, mn[1], mn[2]}) == -1);
+  }
+  {  // VoxelGrid<PointNormal>: all fields averaged (default) against coordinates only (voxel_grid.h:293-301)
+    auto cloud = std::make_shared<PointCloud<PointNormal>>();
+    for (std::size_t i = 0; i < source->size(); ++i) {
+      PointNormal p;
+      p.x = (*source)[i].x; p.y = (*source)[i].y; p.z = (*source)[i].z;
+      p.normal_x = 0.0f; p.normal_y = 0.0f; p.normal_z = 1.0f; p.curvature = 0.25f;
+      cloud->push_back(p);
+    }
+    VoxelGrid<PointNormal> grid(ctx);
+    grid.setLeafSize(0.02f, 0.02f, 0.02f);
+    grid.setInputCloud(cloud);
+    EXPECT(grid.getDownsampleAllData() && grid.getLeafSize()[1] == 0.02f && grid.getMinimumPointsNumberPerVoxel() == 0);
+    PointCloud<PointNormal> all, xyz_only;
+    grid.filter(all);
+    grid.setDownsampleAllData(false);
+    grid.filter(xyz_only);
+    EXPECT(all.size() == 103 && xyz_only.size() == 103);
+    bool same_xyz = true, normals_ok = true, defaults_ok = true;
+    for (std::size_t i = 0; i < all.size() && i < xyz_only.size(); ++i) {
+      same_xyz = same_xyz && all[i].x == xyz_only[i].x && all[i].y == xyz_only[i].y && all[i].z == xyz_only[i].z;
+      normals_ok = normals_ok && all[i].normal_z == 1.0f && all[i].normal_x == 0.0f && all[i].curvature == 0.25f;
+      defaults_ok = defaults_ok && xyz_only[i].normal_z == 0.0f && xyz_only[i].curvature == 0.0f;
+    }
+    EXPECT(same_xyz && normals_ok && defaults_ok);
+    grid.setFilterFieldName("intensity");  // a field the device path does not filter on: refused, not ignored
+    grid.filter(all);
+    EXPECT(all.size() == 0);
+  }
+  {  // NormalEstimation with a search surface and an index subset (feature.h:139-153, pcl_base.h:102-125)
+    auto tree = std::make_shared<search::KdTree<PointXYZ>>(ctx);
+    NormalEstimation<PointXYZ> ne(ctx);
+    ne.setSearchMethod(tree);
+    ne.setKSearch(10);
+    ne.setViewPoint(0.0f, 0.0f, 10.0f);
+    ne.setInputCloud(target);
+    PointCloud<Normal> self, same, sub, cross;
+    ne.compute(self);
+    EXPECT(self.size() == target->size());
+    ne.setSearchSurface(target);  // the input itself as an explicit surface: the same normals through the query path
+    auto every_third = std::make_shared<Indices>();
+    for (std::size_t i = 0; i < target->size(); i += 3) every_third->push_back(index_t(i));
+    ne.setIndices(every_third);
+    ne.compute(sub);
+    EXPECT(sub.size() == every_third->size());
+    bool equal = true;
+    for (std::size_t j = 0; j < sub.size(); ++j) {
+      const Normal& a = sub[j];
+      const Normal& b = self[std::size_t((*every_third)[j])];
+      equal = equal && a.normal_x == b.normal_x && a.normal_y == b.normal_y && a.normal_z == b.normal_z && a.curvature == b.curvature;
+    }
+    EXPECT(equal);
+    NormalEstimation<PointXYZ> ne2(ctx);  // normals AT the source points from the target surface
+    ne2.setKSearch(10);
+    ne2.setViewPoint(0.0f, 0.0f, 10.0f);
+    ne2.setInputCloud(source);
+    ne2.setSearchSurface(target);
+    ne2.compute(cross);
+    EXPECT(cross.size() == source->size() && ne2.getSearchSurface() == target && ne2.getKSearch() == 10);
+    bool unit = true;
+    for (std::size_t j = 0; j < cross.size(); ++j) {
+      const float l = cross[j].normal_x * cross[j].normal_x + cross[j].normal_y * cross[j].normal_y + cross[j].normal_z * cross[j].normal_z;
+      unit = unit && std::fabs(l - 1.0f) < 1e-4f;
+    }
+    EXPECT(unit);
+  }
+  {  // the criteria object of the reference (icp.h:180-184) and the stored-only options of Registration / KdTree
+    IterativeClosestPoint<PointXYZ, PointXYZ> reg(ctx);
+    reg.setInputSource(source);
+    reg.setInputTarget(target);
+    reg.setMaximumIterations(3);
+    reg.getConvergeCriteria()->setFailureAfterMaximumIterations(true);
+    reg.setRANSACIterations(5);
+    reg.setRANSACOutlierRejectionThreshold(0.1);
+    EXPECT(reg.getRANSACIterations() == 5 && reg.getRANSACOutlierRejectionThreshold() == 0.1);
+    PointCloud<PointXYZ> out;
+    reg.align(out);
+    // three iterations do not converge the bunny pair: with the flag set that is a failure, not a convergence
+    EXPECT(!reg.hasConverged());
+    EXPECT(reg.getConvergeCriteria()->getConvergenceState() ==
+           registration::DefaultConvergenceCriteria::CONVERGENCE_CRITERIA_FAILURE_AFTER_MAX_ITERATIONS);
+    EXPECT(reg.getConvergeCriteria()->getMaximumIterations() == 3);
+    auto tree = std::make_shared<search::KdTree<PointXYZ>>(ctx);
+    tree->setEpsilon(0.1f);
+    tree->setMinPts(3);
+    EXPECT(tree->getEpsilon() == 0.1f && tree->getMinPts() == 3);
+    EXPECT(tree->setInputCloud(target));
+    Indices idx;
+    std::vector<float> d2;
+    PointNormal q;
+    q.x = (*target)[5].x; q.y = (*target)[5].y; q.z = (*target)[5].z;
+    EXPECT(tree->nearestKSearchT(q, 1, idx, d2) == 1 && idx[0] == 5 && d2[0] == 0.0f);
+    registration::CorrespondenceEstimation<PointXYZ, PointXYZ> ce(ctx);
+    EXPECT(!ce.requiresSourceNormals() && !ce.requiresTargetNormals());
+    ce.setNumberOfThreads(8);
+    auto src_tree = std::make_shared<search::KdTree<PointXYZ>>(ctx);
+    ce.setSearchMethodSource(src_tree);
+    EXPECT(ce.getSearchMethodSource() == src_tree);
   }
   {  // estimators on explicit pairs: test/registration/test_registration_api.cpp:469-518, :663-712 (1e-2)
     PointCloud<PointNormal> src, tgt;

@@ -1333,3 +1333,72 @@ def test_cold_standoff_correspondences_bit_exact(gpu, orc, offset, scale, stando
     assert np.array_equal(q, np.arange(len(src_f)))
     assert np.array_equal(m, oi[:, 0])
     assert np.array_equal(d, od[:, 0])
+
+
+# ------------------------------------------------------------------------------------------------
+# NormalEstimation with a search surface other than the input, and over an index subset
+# (Feature::setSearchSurface / PCLBase::setIndices as NormalEstimation::computeFeature uses them)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [8, 15, 40])
+def test_normals_search_surface_vs_oracle(gpu, orc, k):
+    import pcl_amd
+    surface = pcl_amd.synth.gaussian_surface(120_000, pcl_amd.synth.TARGET_SEED)
+    queries = pcl_amd.synth.gaussian_surface(15_000, pcl_amd.synth.SOURCE_SEED).copy()
+    queries[:, 2] += np.float32(0.002)        # the queries are not surface points
+    queries[33, 0] = np.inf                   # a non-finite query: NaN row (normal_3d.hpp:60-66)
+    ne = pcl_amd.NormalEstimation(gpu)
+    ne.setInputCloud(queries)
+    ne.setSearchSurface(surface)
+    ne.setKSearch(k)
+    ne.setViewPoint(0.3, -0.2, 5)
+    got = ne.compute()
+    otree = orc.KdTree(surface)
+    want, nan = otree.normals_at(surface, queries, k, viewpoint=(0.3, -0.2, 5))
+    assert got.shape == (len(queries), 4) and ne.nan_count == nan == 1 and np.all(np.isnan(got[33]))
+    ok = ~np.isnan(want[:, 0])
+    dots = np.sum(got[ok, :3] * want[ok, :3], axis=1)   # same tolerances as test_normals_vs_oracle
+    assert dots.min() > 1 - 1e-5, dots.min()
+    assert np.abs(got[ok, 3] - want[ok, 3]).max() < 1e-5
+    # an index subset of the input (with a repeated index): row j belongs to queries[indices[j]]
+    ind = np.concatenate([np.arange(0, len(queries), 7), [5, 5]]).astype(np.int32)
+    ne.setIndices(ind)
+    sub = ne.compute()
+    assert sub.shape == (len(ind), 4)
+    assert np.array_equal(sub, got[ind], equal_nan=True)
+    want_sub, _ = otree.normals_at(surface, queries, k, viewpoint=(0.3, -0.2, 5), indices=ind)
+    assert np.array_equal(np.isnan(sub[:, 0]), np.isnan(want_sub[:, 0]))
+    # an index subset with the input as its own surface equals the rows of the all-points run
+    ne2 = pcl_amd.NormalEstimation(gpu)
+    ne2.setInputCloud(surface)
+    ne2.setKSearch(k)
+    ne2.setViewPoint(0.3, -0.2, 5)
+    full = ne2.compute()
+    pick = np.arange(3, len(surface), 1001).astype(np.int32)
+    ne2.setIndices(pick)
+    part = ne2.compute()
+    assert np.array_equal(part, full[pick], equal_nan=True)
+    with pytest.raises(pcl_amd.PclHipError):     # an index outside the input cloud is refused, not read
+        ne2.setIndices(np.array([0, len(surface)], np.int32))
+        ne2.compute()
+
+
+def test_normals_search_surface_radius_vs_oracle(gpu, orc, bunny):
+    import pcl_amd
+    from oracle import rejectors as rej
+    surface = xyz1(bunny["bun0"])
+    queries = xyz1(bunny["bun4"]).copy()
+    queries[7, 2] = np.nan
+    for radius in (0.01, 0.03):
+        ne = pcl_amd.NormalEstimation(gpu)
+        ne.setInputCloud(queries)
+        ne.setSearchSurface(surface)
+        ne.setRadiusSearch(radius)
+        ne.setViewPoint(0, 0, 10)
+        got = ne.compute()
+        want, nan = rej.normals_radius_at(orc, surface, queries, radius, viewpoint=(0, 0, 10))
+        assert ne.nan_count == nan
+        bad = np.isnan(want[:, 0])
+        assert np.array_equal(np.isnan(got[:, 0]), bad)
+        dots = np.sum(got[~bad, :3] * want[~bad, :3], axis=1)
+        assert dots.min() >= 1 - 1e-5
+        assert np.abs(got[~bad, 3] - want[~bad, 3]).max() < 1e-5

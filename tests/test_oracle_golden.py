@@ -321,3 +321,26 @@ def test_gicp_covariances_properties():
     assert np.allclose(cov, np.transpose(cov, (0, 2, 1)))
     with pytest.raises(ValueError):
         orc.KdTree(pts[:5]).gicp_covariances(pts[:5], k=20)
+
+
+def test_oracle_normals_with_search_surface_is_consistent():
+    # Feature::setSearchSurface restated (orc_normals_knn_queries): with the input as its own surface it is the plain
+    # NormalEstimation; with other queries the plane comes from the SURFACE points and the flip from the QUERY point
+    import pcl_amd
+    from oracle import pcl_oracle as orc
+    cloud = pcl_amd.synth.gaussian_surface(4000, pcl_amd.synth.TARGET_SEED)
+    tree = orc.KdTree(cloud)
+    a, na = tree.normals(cloud, 10, viewpoint=(0, 0, 10))
+    b, nb = tree.normals_at(cloud, cloud, 10, viewpoint=(0, 0, 10))
+    assert na == nb == 0 and np.array_equal(a, b)
+    ind = np.arange(1, 4000, 13, dtype=np.int32)
+    assert np.array_equal(tree.normals_at(cloud, cloud, 10, viewpoint=(0, 0, 10), indices=ind)[0], a[ind])
+    q = cloud[:50].copy()
+    q[:, 2] += np.float32(0.5)                       # queries above the sheet ...
+    up, _ = tree.normals_at(cloud, q, 10, viewpoint=(0, 0, 10))
+    down, _ = tree.normals_at(cloud, q, 10, viewpoint=(0, 0, -10))
+    assert np.all(up[:, 2] > 0) and np.array_equal(down[:, :3], -up[:, :3])   # ... flipped as seen from the query
+    idx, _ = tree.knn(q, 10)
+    cov, cen, cnt = orc.mean_and_covariance(cloud, idx[0])
+    n0 = np.array(orc.solve_plane_parameters(cov)[:3], np.float32)
+    assert cnt == 10 and abs(abs(float(np.dot(n0, up[0, :3]))) - 1) < 1e-6      # the plane of the SURFACE neighbours
