@@ -423,10 +423,15 @@ PCLHIP_API pclhip_status pclhip_transform_cloud(pclhip_ctx* ctx, const float T[1
 
 /* ---- VoxelGrid ----------------------------------------------------------------------------------
  * Replaces pcl::VoxelGrid<pcl::PointXYZ>::applyFilter (filters/include/pcl/filters/impl/
- * voxel_grid.hpp:597-814) with downsample_all_data, optional z-field limits
- * (setFilterFieldName("z") + setFilterLimits).  Output: ascending voxel id, records x,y,z,1
+ * voxel_grid.hpp:597-814) with downsample_all_data and the optional pass-through filter in front of
+ * the grid (setFilterFieldName + setFilterLimits + setFilterLimitsNegative, voxel_grid.h:440-476;
+ * impl/voxel_grid.hpp:513-590,684-695).  `has_z_limits`: 0 = no filter; 1 = keep z inside [z_min, z_max];
+ * generally bit 0 = on, bit 1 = negative (cut the points INSIDE the interval instead), bits 8..15 = 1 + position
+ * of the filter field inside the record, counted in floats (0 = the z coordinate; PCLHIP_VOXELGRID_LIMITS
+ * composes it).  Output: ascending voxel id, records x,y,z,1
  * (16 B).  out must hold n records; *out_n receives the count.  Returns PCLHIP_ERR_OVERFLOW when
  * the reference would refuse (:620-629). */
+#define PCLHIP_VOXELGRID_LIMITS(float_index_of_field, negative) (1 | ((negative) ? 2 : 0) | (((float_index_of_field) + 1) << 8))
 PCLHIP_API pclhip_status pclhip_voxelgrid(pclhip_ctx* ctx, const void* points, size_t stride_bytes,
                                           uint64_t n, const float leaf[3], uint32_t min_points_per_voxel,
                                           int has_z_limits, double z_min, double z_max,

@@ -1218,11 +1218,13 @@ class VoxelGrid {
   bool getDownsampleAllData() const { return downsample_all_data_; }
   void setMinimumPointsNumberPerVoxel(unsigned n) { min_pts_ = n; }
   unsigned getMinimumPointsNumberPerVoxel() const { return min_pts_; }
-  // :440-476: pass-through filter on one field before the grid; the device path knows the field "z"
+  // :440-476: pass-through filter on one field of the point type before the grid is laid out
   void setFilterFieldName(const std::string& f) { field_ = f; }
   const std::string& getFilterFieldName() const { return field_; }
   void setFilterLimits(double lo, double hi) { lo_ = lo; hi_ = hi; }
   void getFilterLimits(double& lo, double& hi) const { lo = lo_; hi = hi_; }
+  void setFilterLimitsNegative(bool negative) { negative_ = negative; }  // true: keep what lies OUTSIDE the interval
+  bool getFilterLimitsNegative() const { return negative_; }
   // Filter::filter -> applyFilter (filters/include/pcl/filters/impl/voxel_grid.hpp:597-814); when the
   // voxel index would overflow the reference warns and returns the input unchanged (:620-629)
   void filter(PointCloud<PointT>& output) {
@@ -1230,19 +1232,20 @@ class VoxelGrid {
     output.height = 1;
     output.is_dense = true;
     if (!input_) { output.width = 0; return; }
-    if (!field_.empty() && field_ != "z") { output.width = 0; return; }  // refused, not silently ignored
+    const int limits = limitFlags();
+    if (limits < 0) { output.width = 0; return; }  // "could not find field": refused, not silently ignored
     constexpr std::size_t noff = has_normal_fields<PointT>() ? 16 : 0;
     std::vector<PointT> out(input_->size());
     std::uint64_t n = 0;
     leaf_layout_.clear();
     dims_ = pclhip_voxelgrid_dims{};
     if (save_leaf_layout_ && !input_->empty()) {  // one int per grid cell: learn the grid first (bounding-box pass)
-      if (pclhip_voxelgrid_grid(ctx_->get(), input_->points.data(), sizeof(PointT), input_->size(), leaf_, field_ == "z",
+      if (pclhip_voxelgrid_grid(ctx_->get(), input_->points.data(), sizeof(PointT), input_->size(), leaf_, limits,
                                 lo_, hi_, &dims_) == PCLHIP_OK)
         leaf_layout_.assign(std::size_t(dims_.div_b[0]) * std::size_t(dims_.div_b[1]) * std::size_t(dims_.div_b[2]), -1);
     }
     const pclhip_status st = pclhip_voxelgrid_ex2(ctx_->get(), input_->points.data(), sizeof(PointT), input_->size(), leaf_,
-                                                  min_pts_, field_ == "z", lo_, hi_, downsample_all_data_ ? 1 : 0, noff,
+                                                  min_pts_, limits, lo_, hi_, downsample_all_data_ ? 1 : 0, noff,
                                                   out.data(), sizeof(PointT), &n,
                                                   leaf_layout_.empty() ? nullptr : leaf_layout_.data(), leaf_layout_.size(),
                                                   &dims_);
@@ -1283,9 +1286,25 @@ class VoxelGrid {
     return neighbors;
   }
  private:
+  // the `has_z_limits` word of the C ABI: where the named field sits in PointT (point_types.hpp:315-321, 843-853)
+  int limitFlags() const {
+    if (field_.empty()) return 0;
+    int idx = -1;
+    if (field_ == "x") idx = 0;
+    else if (field_ == "y") idx = 1;
+    else if (field_ == "z") idx = 2;
+    else if (has_normal_fields<PointT>()) {
+      if (field_ == "normal_x") idx = 4;
+      else if (field_ == "normal_y") idx = 5;
+      else if (field_ == "normal_z") idx = 6;
+      else if (field_ == "curvature") idx = 8;
+    }
+    return idx < 0 ? -1 : PCLHIP_VOXELGRID_LIMITS(idx, negative_);
+  }
   Context::Ptr ctx_;
   typename PointCloud<PointT>::ConstPtr input_;
   bool save_leaf_layout_ = false, downsample_all_data_ = true;  // voxel_grid.h:501
+  bool negative_ = false;
   std::vector<std::int32_t> leaf_layout_;
   pclhip_voxelgrid_dims dims_{};
   float leaf_[3] = {0, 0, 0};

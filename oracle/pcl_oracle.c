@@ -1361,6 +1361,11 @@ typedef struct {
   int32_t pt;
 } vox_pair;
 
+static int vox_limit_field(int limits) {
+  const int f = (limits >> 8) & 0xFF;
+  return f ? f - 1 : 2;
+}
+
 static int vox_cmp(const void* a, const void* b) {
   const vox_pair* x = (const vox_pair*)a;
   const vox_pair* y = (const vox_pair*)b;
@@ -1377,8 +1382,13 @@ int64_t orc_voxelgrid(const float* cloud, int64_t n, int cs, const float* leaf,
   const float fmin_ = (float)lim_min, fmax_ = (float)lim_max; /* voxel_grid.hpp:615 casts */
   for (int64_t i = 0; i < n; ++i) {
     const float* p = cloud + i * cs;
-    if (has_limits) { /* voxel_grid.hpp:549-553: the field is z */
-      if ((p[2] > fmax_) || (p[2] < fmin_)) continue;
+    if (has_limits) { /* voxel_grid.hpp:535-553: the field (bits 8..15: 1 + float position, 0 = z), negative = bit 1 */
+      const float v = p[vox_limit_field(has_limits)];
+      if (has_limits & 2) {
+        if ((v < fmax_) && (v > fmin_)) continue;
+      } else {
+        if ((v > fmax_) || (v < fmin_)) continue;
+      }
     }
     if (!finite3(p)) continue;
     for (int d = 0; d < 3; ++d) {
@@ -1403,8 +1413,13 @@ int64_t orc_voxelgrid(const float* cloud, int64_t n, int cs, const float* leaf,
   for (int64_t i = 0; i < n; ++i) {
     const float* p = cloud + i * cs;
     if (!finite3(p)) continue;
-    if (has_limits) { /* :684-695, double limits against the float value */
-      if (((double)p[2] > lim_max) || ((double)p[2] < lim_min)) continue;
+    if (has_limits) { /* :675-695, double limits against the float value */
+      const double v = (double)p[vox_limit_field(has_limits)];
+      if (has_limits & 2) {
+        if ((v < lim_max) && (v > lim_min)) continue;
+      } else {
+        if ((v > lim_max) || (v < lim_min)) continue;
+      }
     }
     /* :713-718 */
     int i0 = (int)(floorf(p[0] * inv[0]) - (float)min_b[0]);

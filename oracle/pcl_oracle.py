@@ -393,7 +393,8 @@ def solve_plane_parameters(cov):
     return tuple(o.value for o in out)
 
 
-def voxelgrid(cloud, leaf, min_points_per_voxel=0, limits=None):
+def voxelgrid(cloud, leaf, min_points_per_voxel=0, limits=None, field=2, negative=False):
+    """limits=(lo, hi): the pass-through filter on float `field` of the record (2 = z), `negative` = cut the inside"""
     cloud, n, cs = _cloud(cloud)
     leaf3 = np.asarray(leaf, np.float32)
     if leaf3.ndim == 0:
@@ -402,7 +403,8 @@ def voxelgrid(cloud, leaf, min_points_per_voxel=0, limits=None):
     ids = np.empty(max(n, 1), np.int32)
     has = limits is not None
     lo, hi = (limits if has else (0.0, 0.0))
-    m = lib().orc_voxelgrid(_f(cloud), n, cs, _f(leaf3), int(min_points_per_voxel), int(has),
+    flags = (1 | (2 if negative else 0) | ((int(field) + 1) << 8)) if has else 0
+    m = lib().orc_voxelgrid(_f(cloud), n, cs, _f(leaf3), int(min_points_per_voxel), flags,
                             float(lo), float(hi), _f(out), _i(ids))
     if m < 0:
         return None, None

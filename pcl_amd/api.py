@@ -961,14 +961,21 @@ def savePCDFile(path, cloud, mode="binary", precision=8, width=None, height=None
 
 
 class VoxelGrid:
-    """pcl::VoxelGrid<pcl::PointXYZ> (downsample_all_data, optional z limits)."""
+    """pcl::VoxelGrid<PointT> for pcl::PointXYZ ((n, 4) clouds) and pcl::PointNormal ((n, 12) clouds): leaf size,
+    minimum points per voxel, downsample_all_data, the pass-through filter on one field, the leaf layout."""
+
+    _FLT_MAX = float(np.finfo(np.float32).max)
+    # position of a field inside the record, in floats (point_types.hpp:315-321, 843-853)
+    _FIELDS = {"x": 0, "y": 1, "z": 2, "normal_x": 4, "normal_y": 5, "normal_z": 6, "curvature": 8}
 
     def __init__(self, ctx=None):
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
         self.leaf = np.zeros(3, np.float32)
         self.min_pts = 0
-        self.limits = None
+        self.field = ""                                  # voxel_grid.h:503-512: no filter until a field is named
+        self.limits = (-self._FLT_MAX, self._FLT_MAX)
+        self.negative = False
         self.cloud = None
 
     def setInputCloud(self, cloud):
@@ -980,11 +987,39 @@ class VoxelGrid:
     def setMinimumPointsNumberPerVoxel(self, n):
         self.min_pts = int(n)
 
+    def getLeafSize(self):
+        return tuple(float(v) for v in self.leaf)
+
+    def getMinimumPointsNumberPerVoxel(self):
+        return self.min_pts
+
     def setFilterFieldName(self, name):
-        assert name == "z", "only the z field is supported on the accelerated path"
+        """voxel_grid.h:440-444: points are filtered on this field before the grid is laid out ("" = no filter)"""
+        self.field = str(name)
+
+    def getFilterFieldName(self):
+        return self.field
 
     def setFilterLimits(self, lo, hi):
         self.limits = (float(lo), float(hi))
+
+    def getFilterLimits(self):
+        return self.limits
+
+    def setFilterLimitsNegative(self, negative):
+        """voxel_grid.h:468-476: True keeps the points OUTSIDE (limit_min, limit_max) instead of those inside"""
+        self.negative = bool(negative)
+
+    def getFilterLimitsNegative(self):
+        return self.negative
+
+    def _limit_flags(self, stride):
+        if not self.field:
+            return 0
+        idx = self._FIELDS.get(self.field)
+        if idx is None or (idx + 1) * 4 > stride or (idx > 2 and stride < 48):
+            raise ValueError("[pcl::VoxelGrid] could not find field '%s' in this point type" % self.field)
+        return 1 | (2 if self.negative else 0) | ((idx + 1) << 8)
 
     def setDownsampleAllData(self, downsample):
         """voxel_grid.h:293-302: False averages only x, y, z and leaves the other fields of the output at 0"""
@@ -998,8 +1033,8 @@ class VoxelGrid:
         (x y z 1 | nx ny nz 0 | curvature 0 0 0) and come back in the same layout."""
         ptr, stride, n, keep = _cloud(self.cloud)
         cnt = C.c_uint64(0)
-        has = self.limits is not None
-        lo, hi = self.limits if has else (0.0, 0.0)
+        has = self._limit_flags(stride)
+        lo, hi = self.limits
         with_normals = stride >= 48
         cols = 12 if with_normals else 4
         if _is_torch(self.cloud):

@@ -23,6 +23,14 @@ __device__ __forceinline__ const float* rec(const void* base, size_t stride, uin
   return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + i * stride);
 }
 
+// The pass-through filter in front of the grid (setFilterFieldName / setFilterLimits / setFilterLimitsNegative,
+// voxel_grid.h:440-476): `limits` = 0 off; bit 0 on, bit 1 negative, bits 8..15 = 1 + position of the field in the
+// record counted in floats (0: the z coordinate, as the flag meant before it carried a field).
+__device__ __forceinline__ int limit_field(int limits) {
+  const int f = (limits >> 8) & 0xFF;
+  return f ? f - 1 : 2;
+}
+
 // getMinMax3D with the optional field filter (voxel_grid.hpp:513-590; limits cast to float, :615)
 __global__ __launch_bounds__(256) void vg_minmax_kernel(const void* pts, size_t stride, uint64_t n, int has_limits,
                                                         float fmin_, float fmax_, float* partial) {
@@ -30,7 +38,14 @@ __global__ __launch_bounds__(256) void vg_minmax_kernel(const void* pts, size_t 
   for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
     const float* p = rec(pts, stride, i);
     const float x = p[0], y = p[1], z = p[2];
-    if (has_limits && ((z > fmax_) || (z < fmin_))) continue;
+    if (has_limits) {  // voxel_grid.hpp:513-590: the field's value against the limits cast to float
+      const float v = p[limit_field(has_limits)];
+      if (has_limits & 2) {  // filter_limit_negative_: points INSIDE the interval are cut
+        if ((v < fmax_) && (v > fmin_)) continue;
+      } else if ((v > fmax_) || (v < fmin_)) {
+        continue;
+      }
+    }
     if (!(isfinite(x) && isfinite(y) && isfinite(z))) continue;
     lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
     hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
@@ -72,7 +87,10 @@ __global__ __launch_bounds__(256) void vg_key_kernel(const void* pts, size_t str
     const float* p = rec(pts, stride, i);
     const float x = p[0], y = p[1], z = p[2];
     bool ok = isfinite(x) && isfinite(y) && isfinite(z);
-    if (ok && has_limits) ok = !((double(z) > lim_max) || (double(z) < lim_min));  // :684-695
+    if (ok && has_limits) {  // :684-695: double limits against the float value
+      const double v = double(p[limit_field(has_limits)]);
+      ok = (has_limits & 2) ? !((v < lim_max) && (v > lim_min)) : !((v > lim_max) || (v < lim_min));
+    }
     uint32_t key = sort_bits >= 32 ? 0xFFFFFFFFu : ((1u << sort_bits) - 1u);  // rejected: after every voxel id
     if (ok) {  // :713-718
       const int i0 = int(floorf(__fmul_rn(x, g.inv[0])) - float(g.min_b[0]));
@@ -351,6 +369,9 @@ extern "C" pclhip_status pclhip_voxelgrid_ex2(pclhip_ctx* ctx, const void* point
                  "normals_offset: the 8 floats (normal[4], curvature, pad[3]) must fit both record layouts");
   PCLHIP_REQUIRE(ctx, n < 0x7FFFFFFFull, "cloud too large for int32 indices");
   PCLHIP_REQUIRE(ctx, leaf[0] > 0 && leaf[1] > 0 && leaf[2] > 0, "leaf size must be positive");
+  PCLHIP_REQUIRE(ctx, has_z_limits == 0 || ((has_z_limits & 1) && (has_z_limits & ~0xFF03) == 0 &&
+                                           size_t(((has_z_limits >> 8) & 0xFF) ? ((has_z_limits >> 8) & 0xFF) : 3) * 4 <= stride),
+                 "filter limits: bit 0 on, bit 1 negative, bits 8..15 = 1 + float position of the field inside the record");
   if (n == 0) return PCLHIP_OK;
   PCLHIP_REQUIRE(ctx, points && (out || dims_only), "null buffer");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));

@@ -192,9 +192,22 @@ int main(int argc, char** argv) {
       defaults_ok = defaults_ok && xyz_only[i].normal_z == 0.0f && xyz_only[i].curvature == 0.0f;
     }
     EXPECT(same_xyz && normals_ok && defaults_ok);
-    grid.setFilterFieldName("intensity");  // a field the device path does not filter on: refused, not ignored
+    grid.setFilterFieldName("intensity");  // not a field of pcl::PointNormal: refused, not ignored
     grid.filter(all);
     EXPECT(all.size() == 0);
+    // the pass-through filter on another field, and its negative: the two halves partition the cloud's voxels' points
+    grid.setDownsampleAllData(true);
+    grid.setFilterFieldName("y");
+    grid.setFilterLimits(0.10, 1.0);
+    PointCloud<PointNormal> upper, lower;
+    grid.filter(upper);
+    grid.setFilterLimitsNegative(true);
+    EXPECT(grid.getFilterLimitsNegative());
+    grid.filter(lower);
+    bool split = upper.size() > 0 && lower.size() > 0;
+    for (const auto& p : upper.points) split = split && p.y >= 0.10f;
+    for (const auto& p : lower.points) split = split && p.y <= 0.10f;
+    EXPECT(split);
   }
   {  // NormalEstimation with a search surface and an index subset (feature.h:139-153, pcl_base.h:102-125)
     auto tree = std::make_shared<search::KdTree<PointXYZ>>(ctx);

@@ -1402,3 +1402,43 @@ def test_normals_search_surface_radius_vs_oracle(gpu, orc, bunny):
         dots = np.sum(got[~bad, :3] * want[~bad, :3], axis=1)
         assert dots.min() >= 1 - 1e-5
         assert np.abs(got[~bad, 3] - want[~bad, 3]).max() < 1e-5
+
+
+@pytest.mark.parametrize("field,col,lo,hi", [("x", 0, -0.4, 0.25), ("z", 2, 0.02, 0.11), ("curvature", 8, 0.01, 0.03)])
+@pytest.mark.parametrize("negative", [False, True])
+def test_voxelgrid_filter_field_and_negative_limits(gpu, orc, field, col, lo, hi, negative):
+    # the pass-through filter in front of the grid (voxel_grid.h:440-476, impl/voxel_grid.hpp:513-590,684-695): any
+    # field of the point type, inside or outside the interval; centroids bit-exact against the oracle
+    import pcl_amd
+    n = 200_000
+    cloud = np.zeros((n, 12), np.float32)
+    cloud[:, :4] = pcl_amd.synth.gaussian_surface(n, pcl_amd.synth.TARGET_SEED)
+    rng = np.random.default_rng(11)
+    cloud[:, 4:7] = rng.normal(size=(n, 3)).astype(np.float32)
+    cloud[:, 8] = rng.uniform(0, 0.05, n).astype(np.float32)
+    cloud[::977, col] = np.nan if col > 2 else cloud[::977, col]   # a NaN field value passes both forms of the test
+    vg = pcl_amd.VoxelGrid(gpu)
+    vg.setInputCloud(cloud)
+    vg.setLeafSize(0.01)
+    vg.setFilterFieldName(field)
+    vg.setFilterLimits(lo, hi)
+    vg.setFilterLimitsNegative(negative)
+    assert vg.getFilterFieldName() == field and vg.getFilterLimits() == (lo, hi) and vg.getFilterLimitsNegative() == negative
+    out = vg.filter()
+    want, _ = orc.voxelgrid(cloud, 0.01, limits=(lo, hi), field=col, negative=negative)
+    assert len(want) > 1000 and np.array_equal(out[:, :4], want)
+    if col <= 2 and not negative:   # every centroid lies inside the interval of its filter coordinate
+        assert out[:, col].min() >= np.float32(lo) and out[:, col].max() <= np.float32(hi)
+    # a field the point type does not have is refused (the reference logs "could not find field" and stops)
+    vg4 = pcl_amd.VoxelGrid(gpu)
+    vg4.setInputCloud(np.ascontiguousarray(cloud[:, :4]))
+    vg4.setLeafSize(0.01)
+    vg4.setFilterFieldName("curvature")
+    with pytest.raises(ValueError):
+        vg4.filter()
+    # limits without a field name do nothing (voxel_grid.hpp:612-616: the filter is keyed on the name)
+    vg5 = pcl_amd.VoxelGrid(gpu)
+    vg5.setInputCloud(np.ascontiguousarray(cloud[:, :4]))
+    vg5.setLeafSize(0.01)
+    vg5.setFilterLimits(lo, hi)
+    assert np.array_equal(vg5.filter(), orc.voxelgrid(cloud[:, :4], 0.01)[0])
