@@ -6,6 +6,6 @@ from . import synth  # noqa: F401
 from ._lib import (POINT_TO_PLANE, POINT_TO_POINT, SYMMETRIC, PclHipError, PclHipUnavailable)  # noqa: F401
 from .api import (Communicator, Context, CorrespondenceEstimation, CorrespondenceRejectorDistance,  # noqa: F401
                   CorrespondenceRejectorMedianDistance, CorrespondenceRejectorOneToOne,
-                  CorrespondenceRejectorTrimmed, IterativeClosestPoint,
+                  CorrespondenceRejectorTrimmed, DefaultConvergenceCriteria, IterativeClosestPoint,
                   IterativeClosestPointWithNormals, KdTree, NormalEstimation, VoxelGrid,
                   default_context, estimateRigidTransformation, getPCDHeader, loadPCDField, loadPCDFile, savePCDFile)

@@ -147,16 +147,45 @@ class KdTree:
         self.lib = self.ctx.lib
         self.h = None
         self._cloud_id = None
+        self._cloud = None
+        self._indices = None
         self.n_cloud = 0
+        self._sorted = bool(sorted_results)
+        self._epsilon = 0.0
         self.ctx._adopt(self)
 
     def _release(self):
         self._free()
 
+    # search/include/pcl/search/search.h:96-142, search/kdtree.h:110-143
+    def getName(self):
+        return "KdTree"
+
+    def getInputCloud(self):
+        return self._cloud
+
+    def getIndices(self):
+        return self._indices
+
+    def setSortedResults(self, sorted_results):
+        """search.h:104-110: results always come back ascending by distance here, which satisfies either setting."""
+        self._sorted = bool(sorted_results)
+
+    def getSortedResults(self):
+        return self._sorted
+
+    def setEpsilon(self, eps):
+        """search/kdtree.h:130-143: FLANN's (1 + eps) approximate search; this index always answers exactly."""
+        self._epsilon = float(eps)
+
+    def getEpsilon(self):
+        return self._epsilon
+
     def setInputCloud(self, cloud, indices=None):
         # search/include/pcl/search/impl/kdtree.hpp:87-97 -> kdtree_flann.hpp:99-136: ALWAYS rebuilds, like
         # the reference (the array may have been modified in place since the last call).  Callers that know
         # the cloud is unchanged keep the tree and pass it with setSearchMethodTarget(tree, True).
+        self._cloud, self._indices = cloud, indices
         key = (id(cloud), None if indices is None else id(indices))
         self._free()
         ptr, stride, n, keep = _cloud(cloud)
@@ -394,6 +423,9 @@ class CorrespondenceRejectorDistance:
     def setMaximumDistance(self, d):
         self.param = float(d)
 
+    def getMaximumDistance(self):
+        return self.param
+
 
 class CorrespondenceRejectorMedianDistance:
     """pcl::registration::CorrespondenceRejectorMedianDistance."""
@@ -405,6 +437,9 @@ class CorrespondenceRejectorMedianDistance:
 
     def setMedianFactor(self, f):
         self.param = float(f)
+
+    def getMedianFactor(self):
+        return self.param
 
     def getMedianDistance(self):
         return self.median_distance_
@@ -428,8 +463,14 @@ class CorrespondenceRejectorTrimmed:
     def setOverlapRatio(self, r):
         self.param = float(r)
 
+    def getOverlapRatio(self):
+        return self.param
+
     def setMinCorrespondences(self, n):
         self.min_corr = int(n)
+
+    def getMinCorrespondences(self):
+        return self.min_corr
 
 
 def _set_filters(lib, ctx, h, rejectors, reciprocal):
@@ -510,6 +551,50 @@ class CorrespondenceEstimation:
             self.lib.pclhip_icp_destroy(h)
 
 
+class DefaultConvergenceCriteria:
+    """pcl::registration::DefaultConvergenceCriteria (default_convergence_criteria.h:61-286) as a view of a
+    registration's parameter block: hasConverged() itself runs on the device (closed_forms.hpp)."""
+
+    def __init__(self, reg):
+        self._reg = reg
+
+    def setMaximumIterationsSimilarTransforms(self, n):
+        self._reg.p.max_iterations_similar_transforms = int(n)
+
+    def getMaximumIterationsSimilarTransforms(self):
+        return int(self._reg.p.max_iterations_similar_transforms)
+
+    def setFailureAfterMaximumIterations(self, f):
+        self._reg.p.failure_after_max_iterations = int(bool(f))
+
+    def getFailureAfterMaximumIterations(self):
+        return bool(self._reg.p.failure_after_max_iterations)
+
+    def setAbsoluteMSE(self, mse):
+        self._reg.p.mse_threshold_absolute = float(mse)
+
+    def getAbsoluteMSE(self):
+        return float(self._reg.p.mse_threshold_absolute)
+
+    # the remaining thresholds are overwritten from the registration's own setters at every align()
+    # (impl/icp.hpp:157-161): the getters show what the loop will use
+    def getMaximumIterations(self):
+        return int(self._reg.p.max_iterations)
+
+    def getRelativeMSE(self):
+        return float(self._reg.p.euclidean_fitness_epsilon)
+
+    def getTranslationThreshold(self):
+        return float(self._reg.p.transformation_epsilon)
+
+    def getRotationThreshold(self):
+        e = float(self._reg.p.transformation_rotation_epsilon)
+        return e if e > 0 else 0.99999
+
+    def getConvergenceState(self):
+        return self._reg.getConvergenceState()
+
+
 class IterativeClosestPoint:
     """pcl::IterativeClosestPoint<PointXYZ, PointXYZ> (TransformationEstimationSVD)."""
     MODE = POINT_TO_POINT
@@ -585,14 +670,81 @@ class IterativeClosestPoint:
     def setEuclideanFitnessEpsilon(self, e):
         self.p.euclidean_fitness_epsilon = float(e)
 
+    # --- getters of registration.h:190-330 ---
+    def getClassName(self):
+        return type(self).__name__
+
+    def getInputSource(self):
+        return self.src
+
+    def getInputTarget(self):
+        return self.target
+
+    def getSearchMethodTarget(self):
+        return self.tree
+
+    def setSearchMethodSource(self, tree, force_no_recompute=False):
+        """registration.h:230-250: the reciprocal search's tree over the source.  The device indexes the moving
+        source itself every iteration; the object is kept for the getter."""
+        self._tree_source = tree
+
+    def getSearchMethodSource(self):
+        return getattr(self, "_tree_source", None)
+
+    def getMaximumIterations(self):
+        return int(self.p.max_iterations)
+
+    def getMaxCorrespondenceDistance(self):
+        return float(self.p.max_correspondence_distance)
+
+    def getTransformationEpsilon(self):
+        return float(self.p.transformation_epsilon)
+
+    def getTransformationRotationEpsilon(self):
+        return float(self.p.transformation_rotation_epsilon)
+
+    def getEuclideanFitnessEpsilon(self):
+        return float(self.p.euclidean_fitness_epsilon)
+
+    def setRANSACIterations(self, n):
+        """registration.h:300-322: stored; IterativeClosestPoint does not use them (nor does the reference's)."""
+        self._ransac_iterations = int(n)
+
+    def getRANSACIterations(self):
+        return getattr(self, "_ransac_iterations", 0)
+
+    def setRANSACOutlierRejectionThreshold(self, t):
+        self._inlier_threshold = float(t)
+
+    def getRANSACOutlierRejectionThreshold(self):
+        return getattr(self, "_inlier_threshold", 0.05)
+
+    def getConvergeCriteria(self):
+        """icp.h:180-184: the DefaultConvergenceCriteria options a caller reaches through the criteria object."""
+        return DefaultConvergenceCriteria(self)
+
     def addCorrespondenceRejector(self, rejector):
         """Registration::addCorrespondenceRejector (registration.h:430-434)."""
         self.rejectors.append(rejector)
         self._filters_dirty = True
 
+    def getCorrespondenceRejectors(self):
+        return list(self.rejectors)
+
+    def removeCorrespondenceRejector(self, i):
+        """registration.h:536-544: False when there is no i-th rejector."""
+        if i < 0 or i >= len(self.rejectors):
+            return False
+        del self.rejectors[i]
+        self._filters_dirty = True
+        return True
+
     def clearCorrespondenceRejectors(self):
         self.rejectors = []
         self._filters_dirty = True
+
+    def getUseReciprocalCorrespondences(self):
+        return self.use_reciprocal
 
     def setUseReciprocalCorrespondences(self, on):
         """icp.h:251-256."""
@@ -1063,6 +1215,9 @@ class VoxelGrid:
     # ---- the grid of the last filter() call and the leaf layout (voxel_grid.h:316-420) ----
     def setSaveLeafLayout(self, save):
         self.save_leaf_layout = bool(save)
+
+    def getSaveLeafLayout(self):
+        return getattr(self, "save_leaf_layout", False)
 
     def getMinBoxCoordinates(self):
         return np.asarray(self._dims.min_b, np.int32)

@@ -1442,3 +1442,38 @@ def test_voxelgrid_filter_field_and_negative_limits(gpu, orc, field, col, lo, hi
     vg5.setLeafSize(0.01)
     vg5.setFilterLimits(lo, hi)
     assert np.array_equal(vg5.filter(), orc.voxelgrid(cloud[:, :4], 0.01)[0])
+
+
+def test_registration_options_through_the_criteria_object(gpu, bunny):
+    # icp.getConvergeCriteria()->setFailureAfterMaximumIterations(true) (icp.h:180-184,
+    # default_convergence_criteria.hpp:65-71): hitting the iteration limit is then a failure, not a convergence
+    import pcl_amd
+    def run(fail):
+        icp = pcl_amd.IterativeClosestPoint(gpu)
+        icp.setInputSource(xyz1(bunny["bun0"]))
+        icp.setInputTarget(xyz1(bunny["bun4"]))
+        icp.setMaximumIterations(3)
+        cc = icp.getConvergeCriteria()
+        cc.setFailureAfterMaximumIterations(fail)
+        assert cc.getFailureAfterMaximumIterations() == fail and cc.getMaximumIterations() == 3
+        assert cc.getRotationThreshold() == 0.99999 and cc.getAbsoluteMSE() == 1e-12
+        icp.align()
+        return icp
+    a, b = run(False), run(True)
+    assert a.hasConverged() and a.getConvergenceState() == "ITERATIONS"
+    assert not b.hasConverged() and b.getConvergenceState() == "FAILURE_AFTER_MAX_ITERATIONS"
+    assert b.getConvergeCriteria().getConvergenceState() == b.getConvergenceState()
+    assert np.array_equal(a.getFinalTransformation(), b.getFinalTransformation())
+    # stored-only options and list management of registration.h
+    a.setRANSACIterations(7)
+    a.setRANSACOutlierRejectionThreshold(0.2)
+    assert a.getRANSACIterations() == 7 and a.getRANSACOutlierRejectionThreshold() == 0.2
+    r1, r2 = pcl_amd.CorrespondenceRejectorDistance(), pcl_amd.CorrespondenceRejectorTrimmed()
+    r1.setMaximumDistance(0.05)
+    r2.setOverlapRatio(0.8)
+    a.addCorrespondenceRejector(r1)
+    a.addCorrespondenceRejector(r2)
+    assert a.getCorrespondenceRejectors() == [r1, r2] and r1.getMaximumDistance() == 0.05 and r2.getOverlapRatio() == 0.8
+    assert a.removeCorrespondenceRejector(0) and not a.removeCorrespondenceRejector(5)
+    assert a.getCorrespondenceRejectors() == [r2]
+    assert a.getMaximumIterations() == 3 and a.getClassName() == "IterativeClosestPoint"
