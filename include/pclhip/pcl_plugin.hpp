@@ -13,17 +13,31 @@
 //        override the protected computeTransformation (registration.h:678-679, icp.h:292-293): the whole loop
 //        of impl/icp.hpp:113-268 runs on the device
 //
+//   pclhip::plugin::NormalEstimationHIP<In,Out>          : pcl::NormalEstimation<In,Out>
+//        overrides computeFeature (features/include/pcl/features/normal_3d.h:398-399), like NormalEstimationOMP
+//        (normal_3d_omp.h:53): k / radius, search surface, indices and view point stay PCL's own members
+//   pclhip::plugin::VoxelGridHIP<PointT>                 : pcl::VoxelGrid<PointT>
+//        overrides applyFilter (filters/include/pcl/filters/voxel_grid.h:529-530): leaf size, field filter,
+//        downsample_all_data, minimum points and the leaf layout stay PCL's own members
+//   pclhip::plugin::TransformationEstimationHIP<S,T,MODE> : pcl::registration::TransformationEstimation<S,T,float>
+//        the four overloads of transformation_estimation.h:74-116 on explicit pairs
+//
 // Compiled and run here against tests/cpp/pcl_mock (a stand-in for the PCL base classes with the same
 // signatures; PCL itself needs Eigen/Boost/FLANN, which this image lacks): tests/cpp/test_pcl_plugin.cpp.
 // Matrices cross the boundary through operator()(row, col) only, so Eigen's storage order does not matter.
 #pragma once
 
+#include <pcl/common/io.h>
+#include <pcl/features/normal_3d.h>
+#include <pcl/filters/voxel_grid.h>
 #include <pcl/registration/correspondence_estimation.h>
 #include <pcl/registration/icp.h>
+#include <pcl/registration/transformation_estimation.h>
 #include <pcl/search/kdtree.h>
 
 #include <cstdint>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -435,6 +449,197 @@ class IterativeClosestPointWithNormalsHIP
  protected:
   bool enforceSameDirectionNormals() const override { return this->getEnforceSameDirectionNormals(); }
 };
+
+// ---- NormalEstimation ---------------------------------------------------------------------------------
+// Feature::compute (impl/feature.hpp:195-229) has already run initCompute when computeFeature is called: the tree
+// indexes surface_, indices_ holds the queries, exactly one of k_ / search_radius_ is set.  The tree must be a
+// KdTreeHIP (Feature::setSearchMethod); with any other search object the CPU implementation of the base runs.
+template <typename PointInT, typename PointOutT>
+class NormalEstimationHIP : public pcl::NormalEstimation<PointInT, PointOutT> {
+  using Base = pcl::NormalEstimation<PointInT, PointOutT>;
+ public:
+  using Ptr = std::shared_ptr<NormalEstimationHIP<PointInT, PointOutT>>;
+  using PointCloudOut = typename Base::PointCloudOut;
+  explicit NormalEstimationHIP(Device::Ptr dev = Device::instance()) {
+    this->feature_name_ = "NormalEstimationHIP";
+    this->setSearchMethod(std::make_shared<KdTreeHIP<PointInT>>(std::move(dev)));
+  }
+  // why the last compute() ran PCL's own loop instead of the device ("" = it ran on the device)
+  const std::string& deferredReason() const { return deferred_; }
+ protected:
+  void computeFeature(PointCloudOut& output) override {  // impl/normal_3d.hpp:48-95
+    auto* dev_tree = dynamic_cast<KdTreeHIP<PointInT>*>(this->tree_.get());
+    if (dev_tree == nullptr || dev_tree->handle() == nullptr || !dev_tree->representationSupported()) {
+      deferred_ = "the search method is not a KdTreeHIP";
+      Base::computeFeature(output);
+      return;
+    }
+    deferred_.clear();
+    const std::size_t m = this->indices_->size();
+    std::vector<float> tmp(m * 4);
+    std::uint64_t nan = 0;
+    const float vp[3] = {this->vpx_, this->vpy_, this->vpz_};
+    const bool all = this->fake_indices_;
+    pclhip_status st;
+    if (this->fake_surface_ && all) {  // surface == input, every point: the fused kernel, normals kept in the index
+      st = (this->k_ != 0) ? pclhip_normals(dev_tree->handle(), this->k_, vp, tmp.data(), 16, &nan)
+                           : pclhip_normals_radius(dev_tree->handle(), this->search_radius_, vp, tmp.data(), 16, &nan);
+    } else {
+      st = pclhip_normals_at(dev_tree->handle(), this->input_->points.data(), sizeof(PointInT), this->input_->size(),
+                             all ? nullptr : this->indices_->data(), all ? 0 : m, this->k_, this->k_ != 0 ? 0.0 : this->search_radius_,
+                             vp, tmp.data(), 16, &nan);
+    }
+    if (st != PCLHIP_OK) {
+      const float qnan = std::numeric_limits<float>::quiet_NaN();
+      for (auto& v : tmp) v = qnan;
+      nan = m;
+    }
+    for (std::size_t i = 0; i < m; ++i) {  // normal_3d.hpp:60-66,79-91
+      output[i].normal[0] = tmp[4 * i]; output[i].normal[1] = tmp[4 * i + 1]; output[i].normal[2] = tmp[4 * i + 2];
+      output[i].curvature = tmp[4 * i + 3];
+    }
+    if (nan != 0) output.is_dense = false;
+  }
+ private:
+  std::string deferred_;
+};
+
+// ---- VoxelGrid ----------------------------------------------------------------------------------------
+template <typename PointT>
+class VoxelGridHIP : public pcl::VoxelGrid<PointT> {
+  using Base = pcl::VoxelGrid<PointT>;
+ public:
+  using Ptr = std::shared_ptr<VoxelGridHIP<PointT>>;
+  using PointCloud = typename pcl::Filter<PointT>::PointCloud;
+  explicit VoxelGridHIP(Device::Ptr dev = Device::instance()) : dev_(std::move(dev)) { this->filter_name_ = "VoxelGridHIP"; }
+  const std::string& deferredReason() const { return deferred_; }
+ protected:
+  void applyFilter(PointCloud& output) override {  // impl/voxel_grid.hpp:597-814
+    deferred_.clear();
+    if (!dev_ || !dev_->ok()) deferred_ = "no device";
+    else if (!this->fake_indices_) deferred_ = "an index subset of the input";  // the device path filters whole clouds
+    if (!deferred_.empty()) {
+      Base::applyFilter(output);
+      return;
+    }
+    output.height = 1;
+    output.is_dense = true;
+    int limits = 0;
+    if (!this->filter_field_name_.empty()) {  // :664-673 -> the field's place inside PointT
+      std::vector<pcl::PCLPointField> fields;
+      const int idx = pcl::getFieldIndex<PointT>(this->filter_field_name_, fields);
+      if (idx < 0 || fields[std::size_t(idx)].offset % 4 != 0) {  // "[applyFilter] Invalid filter field name": the reference stops too
+        output.width = 0;
+        output.points.clear();
+        return;
+      }
+      limits = PCLHIP_VOXELGRID_LIMITS(int(fields[std::size_t(idx)].offset / 4), this->filter_limit_negative_);
+    }
+    const float leaf[3] = {this->leaf_size_[0], this->leaf_size_[1], this->leaf_size_[2]};
+    const auto& in = *this->input_;
+    pclhip_voxelgrid_dims d{};
+    this->leaf_layout_.clear();
+    std::vector<std::int32_t> layout;
+    if (this->save_leaf_layout_ && !in.points.empty() &&
+        pclhip_voxelgrid_grid(dev_->get(), in.points.data(), sizeof(PointT), in.size(), leaf, limits, this->filter_limit_min_,
+                              this->filter_limit_max_, &d) == PCLHIP_OK)
+      layout.assign(std::size_t(d.div_b[0]) * std::size_t(d.div_b[1]) * std::size_t(d.div_b[2]), -1);
+    std::vector<PointT> out(in.size());
+    std::uint64_t n = 0;
+    const pclhip_status st = pclhip_voxelgrid_ex2(dev_->get(), in.points.data(), sizeof(PointT), in.size(), leaf,
+                                                  this->min_points_per_voxel_, limits, this->filter_limit_min_,
+                                                  this->filter_limit_max_, this->downsample_all_data_ ? 1 : 0,
+                                                  has_normal_fields<PointT>() ? 16 : 0, out.data(), sizeof(PointT), &n,
+                                                  layout.empty() ? nullptr : layout.data(), layout.size(), &d);
+    if (st == PCLHIP_ERR_OVERFLOW) {  // :620-629: "Leaf size is too small ... Integer indices would overflow"
+      output = in;
+      return;
+    }
+    if (st != PCLHIP_OK) {
+      output.width = 0;
+      output.points.clear();
+      return;
+    }
+    out.resize(std::size_t(n));
+    output.points.swap(out);
+    output.width = std::uint32_t(n);
+    for (int a = 0; a < 3; ++a) {  // :632-647: the grid the getters report
+      this->min_b_[a] = d.min_b[a]; this->max_b_[a] = d.max_b[a]; this->div_b_[a] = d.div_b[a]; this->divb_mul_[a] = d.divb_mul[a];
+    }
+    this->min_b_[3] = this->max_b_[3] = 0; this->div_b_[3] = 1; this->divb_mul_[3] = 0;
+    this->leaf_layout_.assign(layout.begin(), layout.end());
+  }
+ private:
+  Device::Ptr dev_;
+  std::string deferred_;
+};
+
+// ---- transformation estimators on explicit pairs ---------------------------------------------------------
+// MODE: PCLHIP_ICP_POINT_TO_POINT (TransformationEstimationSVD), PCLHIP_ICP_POINT_TO_PLANE (...PointToPlaneLLS),
+// PCLHIP_ICP_SYMMETRIC (...SymmetricPointToPlaneLLS); normals are the point types' own fields at +16.
+template <typename PointSource, typename PointTarget, int MODE>
+class TransformationEstimationHIP : public pcl::registration::TransformationEstimation<PointSource, PointTarget, float> {
+  using Base = pcl::registration::TransformationEstimation<PointSource, PointTarget, float>;
+ public:
+  using Matrix4 = typename Base::Matrix4;
+  explicit TransformationEstimationHIP(Device::Ptr dev = Device::instance()) : dev_(std::move(dev)) {}
+  void setEnforceSameDirectionNormals(bool on) { enforce_ = on; }  // symmetric objective (..._symmetric_point_to_plane_lls.h:123)
+  bool getEnforceSameDirectionNormals() const { return enforce_; }
+  void estimateRigidTransformation(const pcl::PointCloud<PointSource>& src, const pcl::PointCloud<PointTarget>& tgt,
+                                   Matrix4& T) const override {
+    if (src.size() != tgt.size()) return;  // "Number or points in source differs than target!": T untouched
+    run(src.points.data(), tgt.points.data(), src.size(), T);
+  }
+  void estimateRigidTransformation(const pcl::PointCloud<PointSource>& src, const pcl::Indices& is,
+                                   const pcl::PointCloud<PointTarget>& tgt, Matrix4& T) const override {
+    if (is.size() != tgt.size()) return;
+    std::vector<PointSource> s;
+    for (pcl::index_t i : is) s.push_back(src[std::size_t(i)]);
+    run(s.data(), tgt.points.data(), s.size(), T);
+  }
+  void estimateRigidTransformation(const pcl::PointCloud<PointSource>& src, const pcl::Indices& is,
+                                   const pcl::PointCloud<PointTarget>& tgt, const pcl::Indices& it, Matrix4& T) const override {
+    if (is.size() != it.size()) return;
+    std::vector<PointSource> s;
+    std::vector<PointTarget> t;
+    for (pcl::index_t i : is) s.push_back(src[std::size_t(i)]);
+    for (pcl::index_t i : it) t.push_back(tgt[std::size_t(i)]);
+    run(s.data(), t.data(), s.size(), T);
+  }
+  void estimateRigidTransformation(const pcl::PointCloud<PointSource>& src, const pcl::PointCloud<PointTarget>& tgt,
+                                   const pcl::Correspondences& corr, Matrix4& T) const override {
+    std::vector<PointSource> s;
+    std::vector<PointTarget> t;
+    for (const pcl::Correspondence& c : corr) {
+      s.push_back(src[std::size_t(c.index_query)]);
+      t.push_back(tgt[std::size_t(c.index_match)]);
+    }
+    run(s.data(), t.data(), s.size(), T);
+  }
+ private:
+  void run(const PointSource* s, const PointTarget* t, std::size_t n, Matrix4& T) const {
+    if (!dev_ || !dev_->ok() || n == 0) return;
+    static_assert(MODE == PCLHIP_ICP_POINT_TO_POINT || (has_normal_fields<PointTarget>() &&
+                  (MODE != PCLHIP_ICP_SYMMETRIC || has_normal_fields<PointSource>())),
+                  "point-to-plane estimators need normals in the target (and, symmetric, in the source) point type");
+    const char* sb = reinterpret_cast<const char*>(s);
+    const char* tb = reinterpret_cast<const char*>(t);
+    float m[16];
+    if (pclhip_estimate_rigid_transformation(dev_->get(), MODE, sb, sizeof(PointSource),
+                                             has_normal_fields<PointSource>() ? sb + 16 : nullptr, sizeof(PointSource), tb,
+                                             sizeof(PointTarget), has_normal_fields<PointTarget>() ? tb + 16 : nullptr,
+                                             sizeof(PointTarget), n, enforce_ ? 1 : 0, m, nullptr) != PCLHIP_OK)
+      return;
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) T(r, c) = m[4 * r + c];
+  }
+  Device::Ptr dev_;
+  bool enforce_ = true;
+};
+template <typename S, typename T> using TransformationEstimationSVDHIP = TransformationEstimationHIP<S, T, PCLHIP_ICP_POINT_TO_POINT>;
+template <typename S, typename T> using TransformationEstimationPointToPlaneLLSHIP = TransformationEstimationHIP<S, T, PCLHIP_ICP_POINT_TO_PLANE>;
+template <typename S, typename T>
+using TransformationEstimationSymmetricPointToPlaneLLSHIP = TransformationEstimationHIP<S, T, PCLHIP_ICP_SYMMETRIC>;
 
 }  // namespace plugin
 }  // namespace pclhip

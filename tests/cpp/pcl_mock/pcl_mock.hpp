@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <limits>
 #include <memory>
 #include <string>
@@ -24,6 +25,7 @@ struct Matrix {
   const S& operator()(int r, int c) const { return d[r * C + c]; }
   S& operator[](int i) { return d[i]; }
   const S& operator[](int i) const { return d[i]; }
+  S coeff(int i) const { return d[i]; }
   static Matrix Identity() {
     Matrix m;
     for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = S(1);
@@ -45,6 +47,10 @@ struct Matrix {
 };
 using Matrix4f = Matrix<float, 4, 4>;
 using Vector4f = Matrix<float, 4, 1>;
+using Vector3f = Matrix<float, 3, 1>;
+using Vector4i = Matrix<int, 4, 1>;
+using Vector3i = Matrix<int, 3, 1>;
+using Array4f = Matrix<float, 4, 1>;
 struct Quaternionf {
   float w_ = 1, x_ = 0, y_ = 0, z_ = 0;
   static Quaternionf Identity() { return Quaternionf(); }
@@ -804,6 +810,273 @@ class IterativeClosestPointWithNormals : public IterativeClosestPoint<PointSourc
  protected:
   bool use_symmetric_objective_ = false;
   bool enforce_same_direction_normals_ = true;
+};
+
+
+// common/include/pcl/PCLPointField.h:12-35, common/include/pcl/common/io.h:78-96 (the field list of a point type)
+struct PCLPointField {
+  std::string name;
+  std::uint32_t offset = 0;
+  std::uint8_t datatype = 0;
+  std::uint32_t count = 0;
+  enum PointFieldTypes { FLOAT32 = 7 };
+};
+template <typename PointT> inline std::vector<PCLPointField> getFields();
+template <> inline std::vector<PCLPointField> getFields<PointXYZ>() {
+  return {{"x", 0, PCLPointField::FLOAT32, 1}, {"y", 4, PCLPointField::FLOAT32, 1}, {"z", 8, PCLPointField::FLOAT32, 1}};
+}
+template <> inline std::vector<PCLPointField> getFields<PointNormal>() {  // impl/point_types.hpp:843-853
+  return {{"x", 0, PCLPointField::FLOAT32, 1},         {"y", 4, PCLPointField::FLOAT32, 1},
+          {"z", 8, PCLPointField::FLOAT32, 1},         {"normal_x", 16, PCLPointField::FLOAT32, 1},
+          {"normal_y", 20, PCLPointField::FLOAT32, 1}, {"normal_z", 24, PCLPointField::FLOAT32, 1},
+          {"curvature", 32, PCLPointField::FLOAT32, 1}};
+}
+template <typename PointT> inline int getFieldIndex(const std::string& field_name, std::vector<PCLPointField>& fields) {
+  fields = getFields<PointT>();
+  for (std::size_t i = 0; i < fields.size(); ++i)
+    if (fields[i].name == field_name) return int(i);
+  return -1;
+}
+struct PointIndices { PCLHeader header; Indices indices; };
+template <typename PointT> inline void copyPointCloud(const PointCloud<PointT>& in, PointCloud<PointT>& out) { out = in; }
+
+// features/include/pcl/features/feature.h:100-316, impl/feature.hpp:95-229
+template <typename PointInT, typename PointOutT>
+class Feature : public PCLBase<PointInT> {
+ public:
+  using PCLBase<PointInT>::indices_;
+  using PCLBase<PointInT>::input_;
+  using BaseClass = PCLBase<PointInT>;
+  using Ptr = shared_ptr<Feature<PointInT, PointOutT>>;
+  using ConstPtr = shared_ptr<const Feature<PointInT, PointOutT>>;
+  using KdTree = pcl::search::Search<PointInT>;
+  using KdTreePtr = typename KdTree::Ptr;
+  using PointCloudIn = pcl::PointCloud<PointInT>;
+  using PointCloudInPtr = typename PointCloudIn::Ptr;
+  using PointCloudInConstPtr = typename PointCloudIn::ConstPtr;
+  using PointCloudOut = pcl::PointCloud<PointOutT>;
+  using SearchMethodSurface = std::function<int(const PointCloudIn& cloud, std::size_t index, double, pcl::Indices&, std::vector<float>&)>;
+
+  Feature() : search_parameter_(0), search_radius_(0), k_(0), fake_surface_(false) {}
+  inline void setSearchSurface(const PointCloudInConstPtr& cloud) { surface_ = cloud; fake_surface_ = false; }
+  inline PointCloudInConstPtr getSearchSurface() const { return surface_; }
+  inline void setSearchMethod(const KdTreePtr& tree) { tree_ = tree; }
+  inline KdTreePtr getSearchMethod() const { return tree_; }
+  inline double getSearchParameter() const { return search_parameter_; }
+  inline void setKSearch(int k) { k_ = k; }
+  inline int getKSearch() const { return k_; }
+  inline void setRadiusSearch(double radius) { search_radius_ = radius; }
+  inline double getRadiusSearch() const { return search_radius_; }
+  void compute(PointCloudOut& output) {  // impl/feature.hpp:195-229
+    if (!initCompute()) {
+      output.width = output.height = 0;
+      output.points.clear();
+      return;
+    }
+    output.header = input_->header;
+    if (output.size() != indices_->size()) output.resize(indices_->size());
+    if (indices_->size() != input_->points.size() || input_->width * input_->height == 0) {
+      output.width = std::uint32_t(indices_->size());
+      output.height = 1;
+    } else {
+      output.width = input_->width;
+      output.height = input_->height;
+    }
+    output.is_dense = input_->is_dense;
+    computeFeature(output);
+    deinitCompute();
+  }
+ protected:
+  std::string feature_name_;
+  SearchMethodSurface search_method_surface_;
+  PointCloudInConstPtr surface_;
+  KdTreePtr tree_;
+  double search_parameter_;
+  double search_radius_;
+  int k_;
+  inline const std::string& getClassName() const { return feature_name_; }
+  virtual bool initCompute() {  // impl/feature.hpp:95-178
+    if (!PCLBase<PointInT>::initCompute()) return false;
+    if (input_->points.empty()) { deinitCompute(); return false; }
+    if (!surface_) { fake_surface_ = true; surface_ = input_; }
+    if (!tree_) mock_no_cpu_path("pcl::search::autoSelectMethod");
+    if (tree_->getInputCloud() != surface_) {
+      if (!tree_->setInputCloud(surface_)) return false;
+    }
+    if (search_radius_ != 0.0) {
+      if (k_ != 0) { deinitCompute(); return false; }  // "Both radius and K defined!"
+      search_parameter_ = search_radius_;
+      search_method_surface_ = [this](const PointCloudIn& cloud, std::size_t index, double radius, pcl::Indices& k_indices,
+                                      std::vector<float>& k_distances) {
+        return tree_->radiusSearch(cloud, index_t(index), radius, k_indices, k_distances, 0);
+      };
+    } else {
+      if (k_ == 0) { deinitCompute(); return false; }  // "Neither radius nor K defined!"
+      search_parameter_ = k_;
+      search_method_surface_ = [this](const PointCloudIn& cloud, std::size_t index, double k, pcl::Indices& k_indices,
+                                      std::vector<float>& k_distances) {
+        return tree_->nearestKSearch(cloud, index_t(index), int(k), k_indices, k_distances);
+      };
+    }
+    return true;
+  }
+  virtual bool deinitCompute() {
+    if (fake_surface_) { surface_.reset(); fake_surface_ = false; }
+    return true;
+  }
+  bool fake_surface_;
+  inline int searchForNeighbors(std::size_t index, double parameter, pcl::Indices& indices, std::vector<float>& distances) const {
+    return search_method_surface_(*input_, index, parameter, indices, distances);
+  }
+ private:
+  virtual void computeFeature(PointCloudOut& output) = 0;
+};
+
+// features/include/pcl/features/normal_3d.h:236-410
+template <typename PointInT, typename PointOutT>
+class NormalEstimation : public Feature<PointInT, PointOutT> {
+ public:
+  using Ptr = shared_ptr<NormalEstimation<PointInT, PointOutT>>;
+  using ConstPtr = shared_ptr<const NormalEstimation<PointInT, PointOutT>>;
+  using Feature<PointInT, PointOutT>::feature_name_;
+  using Feature<PointInT, PointOutT>::getClassName;
+  using Feature<PointInT, PointOutT>::indices_;
+  using Feature<PointInT, PointOutT>::input_;
+  using Feature<PointInT, PointOutT>::surface_;
+  using Feature<PointInT, PointOutT>::k_;
+  using Feature<PointInT, PointOutT>::search_radius_;
+  using Feature<PointInT, PointOutT>::search_parameter_;
+  using PointCloudOut = typename Feature<PointInT, PointOutT>::PointCloudOut;
+  using PointCloudConstPtr = typename Feature<PointInT, PointOutT>::PointCloudInConstPtr;
+
+  NormalEstimation() { feature_name_ = "NormalEstimation"; }
+  ~NormalEstimation() override = default;
+  inline void setInputCloud(const PointCloudConstPtr& cloud) override {
+    input_ = cloud;
+    if (use_sensor_origin_) {
+      vpx_ = input_->sensor_origin_.coeff(0);
+      vpy_ = input_->sensor_origin_.coeff(1);
+      vpz_ = input_->sensor_origin_.coeff(2);
+    }
+  }
+  inline void setViewPoint(float vpx, float vpy, float vpz) { vpx_ = vpx; vpy_ = vpy; vpz_ = vpz; use_sensor_origin_ = false; }
+  inline void getViewPoint(float& vpx, float& vpy, float& vpz) { vpx = vpx_; vpy = vpy_; vpz = vpz_; }
+  inline void useSensorOriginAsViewPoint() {
+    use_sensor_origin_ = true;
+    if (input_) {
+      vpx_ = input_->sensor_origin_.coeff(0); vpy_ = input_->sensor_origin_.coeff(1); vpz_ = input_->sensor_origin_.coeff(2);
+    } else {
+      vpx_ = 0; vpy_ = 0; vpz_ = 0;
+    }
+  }
+ protected:
+  void computeFeature(PointCloudOut&) override { mock_no_cpu_path("pcl::NormalEstimation::computeFeature"); }
+  float vpx_{0.0f}, vpy_{0.0f}, vpz_{0.0f};
+  bool use_sensor_origin_{true};
+};
+
+// filters/include/pcl/filters/filter.h:78-206
+template <typename PointT>
+class Filter : public PCLBase<PointT> {
+ public:
+  using Ptr = shared_ptr<Filter<PointT>>;
+  using ConstPtr = shared_ptr<const Filter<PointT>>;
+  using PointCloud = pcl::PointCloud<PointT>;
+  using PointCloudPtr = typename PointCloud::Ptr;
+  using PointCloudConstPtr = typename PointCloud::ConstPtr;
+  Filter(bool extract_removed_indices = false) : removed_indices_(new Indices), extract_removed_indices_(extract_removed_indices) {}
+  inline IndicesConstPtr const getRemovedIndices() const { return removed_indices_; }
+  inline void getRemovedIndices(PointIndices& pi) { pi.indices = *removed_indices_; }
+  inline void filter(PointCloud& output) {
+    if (!initCompute()) return;
+    if (input_.get() == &output) {  // cloud_in = cloud_out
+      PointCloud output_temp;
+      applyFilter(output_temp);
+      output_temp.header = input_->header;
+      output_temp.sensor_origin_ = input_->sensor_origin_;
+      output_temp.sensor_orientation_ = input_->sensor_orientation_;
+      pcl::copyPointCloud(output_temp, output);
+    } else {
+      output.header = input_->header;
+      output.sensor_origin_ = input_->sensor_origin_;
+      output.sensor_orientation_ = input_->sensor_orientation_;
+      applyFilter(output);
+    }
+    deinitCompute();
+  }
+ protected:
+  using PCLBase<PointT>::indices_;
+  using PCLBase<PointT>::input_;
+  using PCLBase<PointT>::initCompute;
+  using PCLBase<PointT>::deinitCompute;
+  IndicesPtr removed_indices_;
+  std::string filter_name_;
+  bool extract_removed_indices_;
+  virtual void applyFilter(PointCloud& output) = 0;
+  inline const std::string& getClassName() const { return filter_name_; }
+};
+
+// filters/include/pcl/filters/voxel_grid.h:210-533 (members and the setters / getters the binding relies on)
+template <typename PointT>
+class VoxelGrid : public Filter<PointT> {
+ protected:
+  using Filter<PointT>::filter_name_;
+  using Filter<PointT>::getClassName;
+  using Filter<PointT>::input_;
+  using Filter<PointT>::indices_;
+  using PointCloud = typename Filter<PointT>::PointCloud;
+ public:
+  using Ptr = shared_ptr<VoxelGrid<PointT>>;
+  using ConstPtr = shared_ptr<const VoxelGrid<PointT>>;
+  VoxelGrid() { filter_name_ = "VoxelGrid"; }
+  ~VoxelGrid() override = default;
+  inline void setLeafSize(const Eigen::Vector4f& leaf_size) {
+    leaf_size_ = leaf_size;
+    if (leaf_size_[3] == 0) leaf_size_[3] = 1;
+    for (int d = 0; d < 4; ++d) inverse_leaf_size_[d] = 1.0f / leaf_size_[d];
+  }
+  inline void setLeafSize(float lx, float ly, float lz) {
+    leaf_size_[0] = lx; leaf_size_[1] = ly; leaf_size_[2] = lz;
+    if (leaf_size_[3] == 0) leaf_size_[3] = 1;
+    for (int d = 0; d < 4; ++d) inverse_leaf_size_[d] = 1.0f / leaf_size_[d];
+  }
+  inline Eigen::Vector3f getLeafSize() const { Eigen::Vector3f v; v[0] = leaf_size_[0]; v[1] = leaf_size_[1]; v[2] = leaf_size_[2]; return v; }
+  inline void setDownsampleAllData(bool downsample) { downsample_all_data_ = downsample; }
+  inline bool getDownsampleAllData() const { return downsample_all_data_; }
+  inline void setMinimumPointsNumberPerVoxel(unsigned int min_points_per_voxel) { min_points_per_voxel_ = min_points_per_voxel; }
+  inline unsigned int getMinimumPointsNumberPerVoxel() const { return min_points_per_voxel_; }
+  inline void setSaveLeafLayout(bool save_leaf_layout) { save_leaf_layout_ = save_leaf_layout; }
+  inline bool getSaveLeafLayout() const { return save_leaf_layout_; }
+  inline Eigen::Vector3i getMinBoxCoordinates() const { return head3(min_b_); }
+  inline Eigen::Vector3i getMaxBoxCoordinates() const { return head3(max_b_); }
+  inline Eigen::Vector3i getNrDivisions() const { return head3(div_b_); }
+  inline Eigen::Vector3i getDivisionMultiplier() const { return head3(divb_mul_); }
+  inline int getCentroidIndex(const PointT& p) const {  // voxel_grid.h:349-355
+    return leaf_layout_.at(std::size_t((int(std::floor(p.x * inverse_leaf_size_[0])) - min_b_[0]) * divb_mul_[0] +
+                                       (int(std::floor(p.y * inverse_leaf_size_[1])) - min_b_[1]) * divb_mul_[1] +
+                                       (int(std::floor(p.z * inverse_leaf_size_[2])) - min_b_[2]) * divb_mul_[2]));
+  }
+  inline std::vector<int> getLeafLayout() const { return leaf_layout_; }
+  inline void setFilterFieldName(const std::string& field_name) { filter_field_name_ = field_name; }
+  inline std::string const getFilterFieldName() const { return filter_field_name_; }
+  inline void setFilterLimits(const double& limit_min, const double& limit_max) { filter_limit_min_ = limit_min; filter_limit_max_ = limit_max; }
+  inline void getFilterLimits(double& limit_min, double& limit_max) const { limit_min = filter_limit_min_; limit_max = filter_limit_max_; }
+  inline void setFilterLimitsNegative(const bool limit_negative) { filter_limit_negative_ = limit_negative; }
+  inline bool getFilterLimitsNegative() const { return filter_limit_negative_; }
+ protected:
+  static Eigen::Vector3i head3(const Eigen::Vector4i& v) { Eigen::Vector3i r; r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; return r; }
+  Eigen::Vector4f leaf_size_;
+  Eigen::Array4f inverse_leaf_size_;
+  bool downsample_all_data_{true};
+  bool save_leaf_layout_{false};
+  std::vector<int> leaf_layout_;
+  Eigen::Vector4i min_b_, max_b_, div_b_, divb_mul_;
+  std::string filter_field_name_;
+  double filter_limit_min_{std::numeric_limits<float>::lowest()};
+  double filter_limit_max_{std::numeric_limits<float>::max()};
+  bool filter_limit_negative_{false};
+  unsigned int min_points_per_voxel_{0};
+  void applyFilter(PointCloud&) override { mock_no_cpu_path("pcl::VoxelGrid::applyFilter"); }
 };
 
 }  // namespace pcl

@@ -250,6 +250,151 @@ int main(int argc, char** argv) {
     EXPECT(!reg->getUseSymmetricObjective());
   }
 
+  {  // 7. NormalEstimationHIP through pcl::Feature::compute (feature.hpp:195-229 -> the overridden computeFeature)
+    auto tgt = load_xyz<pcl::PointXYZ>(argv[2]);
+    auto src = load_xyz<pcl::PointXYZ>(argv[1]);
+    std::shared_ptr<pcl::NormalEstimation<pcl::PointXYZ, pcl::Normal>> ne(new NormalEstimationHIP<pcl::PointXYZ, pcl::Normal>(dev));
+    pcl::Feature<pcl::PointXYZ, pcl::Normal>& feature = *ne;  // what a PCL pipeline holds
+    ne->setViewPoint(0.0f, 0.0f, 10.0f);
+    feature.setInputCloud(tgt);
+    feature.setKSearch(10);
+    pcl::PointCloud<pcl::Normal> self, sub, cross;
+    feature.compute(self);
+    EXPECT(self.size() == tgt->size() && self.is_dense);
+    std::ifstream fn(argv[4]);  // the Python side's k = 10 normals of the same cloud, same view point
+    bool same = true;
+    for (std::size_t i = 0; i < self.size(); ++i) {
+      float nx, ny, nz;
+      fn >> nx >> ny >> nz;
+      same = same && std::fabs(self[i].normal_x * nx + self[i].normal_y * ny + self[i].normal_z * nz) > 1.0f - 1e-5f;
+    }
+    EXPECT(same);
+    pcl::IndicesPtr every_third(new pcl::Indices);
+    for (std::size_t i = 0; i < tgt->size(); i += 3) every_third->push_back(pcl::index_t(i));
+    feature.setIndices(every_third);   // PCLBase::setIndices: one normal per index
+    feature.compute(sub);
+    EXPECT(sub.size() == every_third->size() && sub.width == sub.size() && sub.height == 1);
+    bool equal = true;
+    for (std::size_t j = 0; j < sub.size(); ++j) {
+      const pcl::Normal& a = sub[j];
+      const pcl::Normal& b = self[std::size_t((*every_third)[j])];
+      equal = equal && a.normal_x == b.normal_x && a.normal_y == b.normal_y && a.normal_z == b.normal_z && a.curvature == b.curvature;
+    }
+    EXPECT(equal);
+    std::shared_ptr<pcl::NormalEstimation<pcl::PointXYZ, pcl::Normal>> ne2(new NormalEstimationHIP<pcl::PointXYZ, pcl::Normal>(dev));
+    ne2->setViewPoint(0.0f, 0.0f, 10.0f);
+    ne2->setInputCloud(src);          // normals AT the source points ...
+    ne2->setSearchSurface(tgt);       // ... from the target surface (Feature::setSearchSurface)
+    ne2->setRadiusSearch(0.03);
+    ne2->compute(cross);
+    EXPECT(cross.size() == src->size());
+    int finite = 0;
+    bool unit = true;
+    for (std::size_t j = 0; j < cross.size(); ++j) {
+      if (std::isnan(cross[j].normal_x)) continue;
+      ++finite;
+      const float l = cross[j].normal_x * cross[j].normal_x + cross[j].normal_y * cross[j].normal_y + cross[j].normal_z * cross[j].normal_z;
+      unit = unit && std::fabs(l - 1.0f) < 1e-4f && cross[j].normal_z * (10.0f - (*src)[j].z) + cross[j].normal_x * (0.0f - (*src)[j].x) +
+                                                          cross[j].normal_y * (0.0f - (*src)[j].y) >= 0.0f;
+    }
+    EXPECT(finite > int(cross.size()) / 2 && unit);
+    auto* hip = dynamic_cast<NormalEstimationHIP<pcl::PointXYZ, pcl::Normal>*>(ne2.get());
+    EXPECT(hip != nullptr && hip->deferredReason().empty());
+    ne2->setKSearch(5);               // both K and radius: Feature::initCompute refuses (feature.hpp:131-140)
+    ne2->compute(cross);
+    EXPECT(cross.size() == 0);
+  }
+
+  {  // 8. VoxelGridHIP through pcl::Filter::filter (filter.h:121-144 -> the overridden applyFilter)
+    auto src = load_xyz<pcl::PointXYZ>(argv[1]);
+    std::shared_ptr<pcl::VoxelGrid<pcl::PointXYZ>> grid(new VoxelGridHIP<pcl::PointXYZ>(dev));
+    pcl::Filter<pcl::PointXYZ>& filter = *grid;
+    grid->setLeafSize(0.02f, 0.02f, 0.02f);
+    grid->setSaveLeafLayout(true);
+    filter.setInputCloud(src);
+    pcl::PointCloud<pcl::PointXYZ> out;
+    filter.filter(out);
+    EXPECT(out.size() == 103 && out.width == 103 && out.height == 1 && out.is_dense);  // test/filters/test_filters.cpp:566-596
+    const auto div = grid->getNrDivisions();
+    EXPECT(grid->getLeafLayout().size() == std::size_t(div[0]) * std::size_t(div[1]) * std::size_t(div[2]));
+    const int c0 = grid->getCentroidIndex((*src)[0]);
+    EXPECT(c0 >= 0 && c0 < 103);
+    // the pass-through filter and its negative, PCL's own setters: the two halves come from disjoint sets of points
+    grid->setSaveLeafLayout(false);
+    grid->setFilterFieldName("y");
+    grid->setFilterLimits(0.10, 1.0);
+    pcl::PointCloud<pcl::PointXYZ> upper, lower;
+    filter.filter(upper);
+    grid->setFilterLimitsNegative(true);
+    filter.filter(lower);
+    bool split = upper.size() > 0 && lower.size() > 0;
+    for (const auto& p : upper.points) split = split && p.y >= 0.10f;
+    for (const auto& p : lower.points) split = split && p.y <= 0.10f;
+    EXPECT(split);
+    grid->setFilterFieldName("curvature");  // not a field of pcl::PointXYZ
+    filter.filter(out);
+    EXPECT(out.size() == 0);
+    // cloud_in == cloud_out (filter.h:126-134)
+    pcl::PointCloud<pcl::PointXYZ>::Ptr inplace(new pcl::PointCloud<pcl::PointXYZ>(*src));
+    grid->setFilterFieldName("");
+    filter.setInputCloud(inplace);
+    filter.filter(*inplace);
+    EXPECT(inplace->size() == 103);
+    // pcl::PointNormal: all fields, then coordinates only (voxel_grid.h:293-301)
+    auto srcn = load_xyz<pcl::PointNormal>(argv[1]);
+    for (auto& p : srcn->points) { p.normal_z = 1.0f; p.curvature = 0.5f; }
+    VoxelGridHIP<pcl::PointNormal> gridn(dev);
+    gridn.setLeafSize(0.02f, 0.02f, 0.02f);
+    gridn.setInputCloud(srcn);
+    pcl::PointCloud<pcl::PointNormal> all, xyz_only;
+    gridn.filter(all);
+    gridn.setDownsampleAllData(false);
+    gridn.filter(xyz_only);
+    bool fields = all.size() == 103 && xyz_only.size() == 103;
+    for (std::size_t i = 0; fields && i < all.size(); ++i)
+      fields = all[i].normal_z == 1.0f && all[i].curvature == 0.5f && xyz_only[i].normal_z == 0.0f && xyz_only[i].curvature == 0.0f &&
+               all[i].x == xyz_only[i].x;
+    EXPECT(fields);
+  }
+
+  {  // 9. the estimators on explicit pairs through pcl::registration::TransformationEstimation (transformation_estimation.h:74-116)
+    pcl::PointCloud<pcl::PointNormal> a, b;
+    const float G[16] = {0.9938f, 0.0988f, 0.0517f, 0.1000f, -0.0997f, 0.9949f, 0.0149f, -0.2000f,
+                         -0.0500f, -0.0200f, 0.9986f, 0.3000f, 0, 0, 0, 1};
+    for (float x = -5.0f; x <= 5.0f; x += 0.5f)
+      for (float y = -5.0f; y <= 5.0f; y += 0.5f) {
+        pcl::PointNormal p;
+        p.x = x; p.y = y; p.z = 0.1f * x * x + 0.2f * x * y - 0.3f * y + 1.0f;
+        float nx = -0.2f * x - 0.2f, ny = 0.6f * y - 0.2f, nz = 1.0f;
+        const float m = std::sqrt(nx * nx + ny * ny + nz * nz);
+        p.normal_x = nx / m; p.normal_y = ny / m; p.normal_z = nz / m;
+        a.push_back(p);
+      }
+    b = a;
+    pclhip_transform_cloud(dev->get(), G, 1, a.points.data(), b.points.data(), sizeof(pcl::PointNormal), a.size(), 16);
+    using TE = pcl::registration::TransformationEstimation<pcl::PointNormal, pcl::PointNormal, float>;
+    const TransformationEstimationSVDHIP<pcl::PointNormal, pcl::PointNormal> svd(dev);
+    const TransformationEstimationPointToPlaneLLSHIP<pcl::PointNormal, pcl::PointNormal> lls(dev);
+    const TransformationEstimationSymmetricPointToPlaneLLSHIP<pcl::PointNormal, pcl::PointNormal> sym(dev);
+    const TE* estimators[3] = {&svd, &lls, &sym};
+    const float tol[3] = {1e-4f, 1e-2f, 1e-2f};  // test/registration/test_registration_api.cpp:383-424, :469-518, :663-712
+    pcl::Indices all(a.size());
+    pcl::Correspondences pairs;
+    for (std::size_t i = 0; i < a.size(); ++i) { all[i] = pcl::index_t(i); pairs.emplace_back(pcl::index_t(i), pcl::index_t(i), 0.0f); }
+    for (int e = 0; e < 3; ++e) {
+      TE::Matrix4 T0 = TE::Matrix4::Identity(), T1 = T0, T2 = T0, T3 = T0;
+      estimators[e]->estimateRigidTransformation(a, b, T0);
+      estimators[e]->estimateRigidTransformation(a, all, b, T1);
+      estimators[e]->estimateRigidTransformation(a, all, b, all, T2);
+      estimators[e]->estimateRigidTransformation(a, b, pairs, T3);
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+          EXPECT(std::fabs(T0(r, c) - G[4 * r + c]) < tol[e]);
+          EXPECT(T1(r, c) == T0(r, c) && T2(r, c) == T0(r, c) && T3(r, c) == T0(r, c));
+        }
+    }
+  }
+
   if (failures == 0) std::printf("ALL OK\n");
   return failures == 0 ? 0 : 1;
 }
