@@ -102,25 +102,6 @@ __device__ __forceinline__ float point_disc_lb(float qx, float qy, float qz, con
   const float gn = fmaxf((a - e) - nh.w, 0.0f);
   return __fmaf_rn(gt, gt, gn * gn) * DISC_SHRINK;
 }
-// The same for every query q of a group with bounding box [Ql, Qh] (centre Qc, half diagonal rQ, rounded up)
-// against every point p of the disc: along n the gap between the interval n.(q - c) takes over the box and
-// [-hn, hn]; across n the distance of the centres less both radii.  Both hold for the same pair (q, p).
-__device__ __forceinline__ float group_disc_lb(float Qlx, float Qly, float Qlz, float Qhx, float Qhy, float Qhz, float Qcx,
-                                               float Qcy, float Qcz, float rQ, const float4 cR, const float4 nh) {
-  const float lx = Qlx - cR.x, ly = Qly - cR.y, lz = Qlz - cR.z, hx = Qhx - cR.x, hy = Qhy - cR.y, hz = Qhz - cR.z;
-  const float ax = nh.x * lx, bx = nh.x * hx, ay = nh.y * ly, by = nh.y * hy, az = nh.z * lz, bz = nh.z * hz;
-  const float smin = (fminf(ax, bx) + fminf(ay, by)) + fminf(az, bz);
-  const float smax = (fmaxf(ax, bx) + fmaxf(ay, by)) + fmaxf(az, bz);
-  const float eb = 1e-6f * ((fmaxf(fabsf(lx), fabsf(hx)) + fmaxf(fabsf(ly), fabsf(hy))) + fmaxf(fabsf(lz), fabsf(hz)));
-  const float gn = fmaxf(fmaxf(smin, -smax) - nh.w - eb, 0.0f);
-  const float dx = Qcx - cR.x, dy = Qcy - cR.y, dz = Qcz - cR.z;
-  const float r2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
-  const float a_hi = fabsf(__fmaf_rn(nh.z, dz, __fmaf_rn(nh.y, dy, __fmul_rn(nh.x, dx)))) + 1e-6f * ((fabsf(dx) + fabsf(dy)) + fabsf(dz));
-  const float b2 = fmaxf(__fmaf_rn(r2, 0.999999f, -(a_hi * a_hi) * 1.000003f), 0.0f);
-  const float gt = fmaxf(__fmaf_rn(__fsqrt_rn(b2), 0.999999f, -(rQ + cR.w)), 0.0f);
-  return __fmaf_rn(gt, gt, gn * gn) * DISC_SHRINK;
-}
-
 // ---- wavefront reductions (all 64 lanes must be active) ---------------------------------------
 // DPP butterflies (no LDS traffic, plain VALU latency): quad_perm swaps, row_half_mirror and
 // row_mirror leave every row of 16 lanes holding its row result; row_bcast15/31 then fold the four
@@ -744,9 +725,6 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
   wave_min3_max4(lx0, ly0, lz0, hx0, hy0, hz0, T);
   const float Qlx = lx0, Qly = ly0, Qlz = lz0, Qhx = hx0, Qhy = hy0, Qhz = hz0;
   const float gdiag2 = (Qhx - Qlx) * (Qhx - Qlx) + (Qhy - Qly) * (Qhy - Qly) + (Qhz - Qlz) * (Qhz - Qlz);
-  // bounding sphere of the group (for the disc bounds of loose searches), radius rounded up
-  const float Qcx = 0.5f * (Qlx + Qhx), Qcy = 0.5f * (Qly + Qhy), Qcz = 0.5f * (Qlz + Qhz);
-  const float rQ = __fsqrt_rn(gdiag2) * 0.5000005f + 1e-6f * ((fabsf(Qcx) + fabsf(Qcy)) + fabsf(Qcz));
   // Disc bounds pay where queries STAND OFF the indexed surface (the unseeded first iteration of a
   // registration): the caller says so.  Self-queries (normals) and seeded queries sit on or near the surface,
   // inside the discs of all the leaves around them, where a disc excludes nothing a box does not.
@@ -836,7 +814,9 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
       if (has) {
         dcR = ix.disc[2 * (first + lane)];
         dnh = ix.disc[2 * (first + lane) + 1];
-        lbG = fmaxf(lbG, group_disc_lb(Qlx, Qly, Qlz, Qhx, Qhy, Qhz, Qcx, Qcy, Qcz, rQ, dcR, dnh));
+        // (a group-level disc bound -- smallest stand-off over the group against the largest radius -- was here: at a
+        // stand-off every slack in it is multiplied by the stand-off, it excluded nothing the box bound does not, and
+        // cost 45 instructions per scan; the lanes' own disc tests below are what prunes)
       }
     }
     const bool alive = has && !(lbG > T);
