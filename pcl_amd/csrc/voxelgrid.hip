@@ -129,8 +129,8 @@ __global__ void vg_keep_kernel(const uint32_t* run_start, uint32_t nruns, uint32
 }
 
 // ---- stable LSD radix sort of (u32 key, u32 value) pairs, 8 bits per pass --------------------------------------
-// Per pass: digit histogram of every 4096-key block (rs_hist_kernel, digit-major so that one exclusive scan of the
-// 256 x nblocks table yields the first output slot of every (digit, block)), the scan above, and the scatter:
+// Per pass: digit histogram of every 4096-key block (rs_hist_kernel, digit-major), the scan of every digit's row over
+// the blocks (rs_rowscan_kernel: first output slot of (digit, block) relative to the digit's first), and the scatter:
 // a wavefront owns 1024 consecutive keys as 16 rows of 64; lanes with equal digits find each other with eight
 // ballots, the lowest of them bumps the wave's running count of that digit (LDS, no atomics: one leader per digit
 // and row), so every key gets its rank among the equal digits before it -- index order, hence stable.
@@ -151,17 +151,65 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
   hist[size_t(threadIdx.x) * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
+// Offsets of one sorting pass in ONE launch: workgroup d scans row d of the digit-major table in place of the generic
+// three-launch scan of all 256 x nblocks counters (first[d][b] = keys of digit d in the blocks before b) and leaves the
+// row total; the scatter kernel adds the totals of the smaller digits itself (256 values, scanned in LDS).
+__global__ __launch_bounds__(256) void rs_rowscan_kernel(const uint32_t* __restrict__ hist, uint32_t nblocks,
+                                                         uint32_t* __restrict__ first, uint32_t* __restrict__ rowtot) {
+  const uint32_t* row = hist + size_t(blockIdx.x) * nblocks;
+  uint32_t* out = first + size_t(blockIdx.x) * nblocks;
+  const uint32_t per = (nblocks + 255u) / 256u;
+  const uint32_t b0 = threadIdx.x * per, b1 = (b0 + per < nblocks) ? b0 + per : nblocks;
+  uint32_t sum = 0;
+  for (uint32_t b = b0; b < b1; ++b) sum += row[b];
+  // exclusive scan of the 256 chunk sums: wave scans, then the four wave totals
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o);
+    if (lane >= uint32_t(o)) inc += t;
+  }
+  __shared__ uint32_t wtot[4];
+  if (lane == 63u) wtot[wave] = inc;
+  __syncthreads();
+  uint32_t before = inc - sum;
+  for (uint32_t w = 0; w < wave; ++w) before += wtot[w];
+  for (uint32_t b = b0; b < b1; ++b) {
+    const uint32_t v = row[b];
+    out[b] = before;
+    before += v;
+  }
+  if (threadIdx.x == 255) rowtot[blockIdx.x] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+}
+
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in, uint32_t n, int shift,
                                                                 uint32_t nblocks, const uint32_t* __restrict__ first,
+                                                                const uint32_t* __restrict__ rowtot,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
   constexpr int WAVES = RS_THREADS / 64;
+  static_assert(RS_THREADS == 256, "one thread per digit");
   __shared__ uint32_t wcnt[WAVES][256];
   __shared__ uint32_t goff[256];
-  for (int i = threadIdx.x; i < WAVES * 256; i += RS_THREADS) (&wcnt[0][0])[i] = 0u;
-  goff[threadIdx.x] = first[size_t(threadIdx.x) * nblocks + blockIdx.x];
-  __syncthreads();
+  __shared__ uint32_t dtot[WAVES];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < WAVES * 256; i += RS_THREADS) (&wcnt[0][0])[i] = 0u;
+  {  // keys of smaller digits (exclusive scan of the 256 row totals) + keys of this digit in earlier blocks
+    const uint32_t tot = rowtot[threadIdx.x];
+    uint32_t inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o);
+      if (lane >= uint32_t(o)) inc += t;
+    }
+    if (lane == 63u) dtot[wave] = inc;
+    __syncthreads();
+    uint32_t base = inc - tot;
+    for (uint32_t w = 0; w < wave; ++w) base += dtot[w];
+    goff[threadIdx.x] = base + first[size_t(threadIdx.x) * nblocks + blockIdx.x];
+  }
+  __syncthreads();
   const unsigned long long below = (1ull << lane) - 1ull;
   const uint32_t base = blockIdx.x * uint32_t(RS_KPB) + wave * uint32_t(RS_ROWS * 64);
   uint32_t key[RS_ROWS], val[RS_ROWS], rk[RS_ROWS];
@@ -410,7 +458,8 @@ extern "C" pclhip_status pclhip_voxelgrid_ex2(pclhip_ctx* ctx, const void* point
   const size_t o_first = o_hist + align(table * sizeof(uint32_t));
   const size_t o_sp = o_first + align(table * sizeof(uint32_t));
   const size_t o_tot = o_sp + align(scan_blocks * sizeof(uint2));
-  const size_t total_bytes = o_tot + align(4 * sizeof(uint32_t));
+  const size_t o_rowtot = o_tot + align(4 * sizeof(uint32_t));
+  const size_t total_bytes = o_rowtot + align(256 * sizeof(uint32_t));
   st = ensure_scratch(ctx, total_bytes);
   if (st != PCLHIP_OK) return st;
   char* base = static_cast<char*>(ctx->scratch);
@@ -427,6 +476,7 @@ extern "C" pclhip_status pclhip_voxelgrid_ex2(pclhip_ctx* ctx, const void* point
   uint32_t* first = reinterpret_cast<uint32_t*>(base + o_first);
   uint2* sc_partial = reinterpret_cast<uint2*>(base + o_sp);
   uint32_t* tot = reinterpret_cast<uint32_t*>(base + o_tot);
+  uint32_t* rowtot = reinterpret_cast<uint32_t*>(base + o_rowtot);
   // exclusive scan of a[0..m) into out_sum (tot[0] = total): device_scan.hpp
   const auto scan_u32 = [&](const uint32_t* a, uint64_t m, uint32_t* out_sum) { launch_scan_u32(s, a, m, sc_partial, tot, out_sum); };
 
@@ -500,9 +550,10 @@ extern "C" pclhip_status pclhip_voxelgrid_ex2(pclhip_ctx* ctx, const void* point
                      s, dp, stride, n, g, has_z_limits, z_min, z_max, k0, d_cnt, sort_bits);
   for (int shift = 0; shift < sort_bits; shift += 8) {  // stable LSD passes (rs_* above), ping-pong k0/v0 <-> k1/v1
     hipLaunchKernelGGL(rs_hist_kernel, dim3(sort_blocks), dim3(RS_THREADS), 0, s, k0, uint32_t(n), shift, sort_blocks, hist);
-    scan_u32(hist, table, first);
+    hipLaunchKernelGGL(rs_rowscan_kernel, dim3(256), dim3(256), 0, s, hist, sort_blocks, first, rowtot);
     hipLaunchKernelGGL(rs_scatter_kernel, dim3(sort_blocks), dim3(RS_THREADS), 0, s, k0,
-                       shift == 0 ? static_cast<const uint32_t*>(nullptr) : v0, uint32_t(n), shift, sort_blocks, first, k1, v1);
+                       shift == 0 ? static_cast<const uint32_t*>(nullptr) : v0, uint32_t(n), shift, sort_blocks, first, rowtot,
+                       k1, v1);
     std::swap(k0, k1);
     std::swap(v0, v1);
   }
