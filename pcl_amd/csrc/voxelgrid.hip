@@ -381,6 +381,77 @@ __global__ __launch_bounds__(256) void vg_centroid_wave_kernel(const void* pts, 
   }
 }
 
+// Four runs per wavefront, one per row of 16 lanes: a row gathers 16 points of its run at a time and every lane of the
+// row adds them up in index order from row broadcasts (ds_bpermute) -- the same sequential float sums, a quarter of the
+// broadcast + add instructions per point of the wave-per-run form.
+__global__ __launch_bounds__(256) void vg_centroid_row_kernel(const void* pts, size_t stride, const uint32_t* vals,
+                                                              const uint32_t* run_start, const uint32_t* keep,
+                                                              const uint32_t* keep_scan, uint32_t nruns, void* out,
+                                                              size_t ostride, size_t noff, int all_data) {
+  const uint32_t lane = threadIdx.x & 63u, sub = lane & 15u, rowbase = lane & ~15u;
+  const uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, nrows = (gridDim.x * blockDim.x) >> 4;
+  const bool with_n = noff != 0 && all_data;
+  const uint32_t rounds = (nruns + nrows - 1) / nrows;  // every row of a wave takes part in every shuffle
+  for (uint32_t it = 0; it < rounds; ++it) {
+    const uint32_t r = it * nrows + row;
+    const bool live = r < nruns && keep[r] != 0;
+    const uint32_t b = live ? run_start[r] : 0u, e = live ? run_start[r + 1] : 0u;
+    const uint32_t len = e - b;
+    uint32_t longest = len;  // over the four rows of the wave
+    longest = max(longest, uint32_t(__shfl_xor(int(longest), 16)));
+    longest = max(longest, uint32_t(__shfl_xor(int(longest), 32)));
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f, cv = 0.0f;
+    for (uint32_t c = 0; c < longest; c += 16u) {
+      float px = 0.0f, py = 0.0f, pz = 0.0f, qx = 0.0f, qy = 0.0f, qz = 0.0f, qc = 0.0f;
+      if (c + sub < len) {
+        const float* p = rec(pts, stride, vals[b + c + sub]);
+        px = p[0]; py = p[1]; pz = p[2];
+        if (with_n) {
+          const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + noff);
+          qx = q[0]; qy = q[1]; qz = q[2]; qc = q[4];
+        }
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 16u; ++j) {
+        const int src = int(rowbase + j);
+        const float vx = __shfl(px, src), vy = __shfl(py, src), vz = __shfl(pz, src);
+        const bool on = c + j < len;  // the same for the 16 lanes of a row
+        sx = on ? __fadd_rn(sx, vx) : sx;
+        sy = on ? __fadd_rn(sy, vy) : sy;
+        sz = on ? __fadd_rn(sz, vz) : sz;
+        if (with_n) {  // wave-uniform
+          const float wx = __shfl(qx, src), wy = __shfl(qy, src), wz = __shfl(qz, src), wc = __shfl(qc, src);
+          nx = on ? __fadd_rn(nx, wx) : nx;
+          ny = on ? __fadd_rn(ny, wy) : ny;
+          nz = on ? __fadd_rn(nz, wz) : nz;
+          cv = on ? __fadd_rn(cv, wc) : cv;
+        }
+      }
+    }
+    if (live && sub == 0u) {
+      const float cnt = float(len);
+      float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + size_t(keep_scan[r]) * ostride);
+      o[0] = __fdiv_rn(sx, cnt);
+      o[1] = __fdiv_rn(sy, cnt);
+      o[2] = __fdiv_rn(sz, cnt);
+      if (ostride >= 16) o[3] = 1.0f;
+      if (noff != 0) {
+        float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(o) + noff);
+        float a = 0.0f, bb = 0.0f, cc = 0.0f, k = 0.0f;
+        if (with_n) {
+          const float l = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+          a = __fdiv_rn(nx, l);
+          bb = __fdiv_rn(ny, l);
+          cc = __fdiv_rn(nz, l);
+          k = __fdiv_rn(cv, cnt);
+        }
+        q[0] = a; q[1] = bb; q[2] = cc; q[3] = 0.0f;
+        q[4] = k; q[5] = 0.0f; q[6] = 0.0f; q[7] = 0.0f;
+      }
+    }
+  }
+}
+
 }  // namespace
 }  // namespace pclhip
 
@@ -594,9 +665,17 @@ extern "C" pclhip_status pclhip_voxelgrid_ex2(pclhip_ctx* ctx, const void* point
   if (total > 0) {
     if (out_stride != 16 && (normals_offset == 0 || out_stride != normals_offset + 32))
       PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_out, 0, size_t(total) * out_stride, s));  // fields this filter does not fill
-    if (uint64_t(nv) > uint64_t(nruns) * 16) {  // long runs on average: a wavefront per run
+    static const int centroid_form = [] {  // A/B: PCLHIP_VG_CENTROID=wave keeps the wavefront-per-run kernel for long runs
+      const char* e = getenv("PCLHIP_VG_CENTROID");
+      return (e && !strcmp(e, "wave")) ? 1 : 0;
+    }();
+    if (uint64_t(nv) > uint64_t(nruns) * 16 && centroid_form == 1) {  // long runs on average: a wavefront per run
       const unsigned blocks = unsigned(std::min<uint64_t>((uint64_t(nruns) + 3) / 4, uint64_t(ctx->num_cus) * 16));
       hipLaunchKernelGGL(vg_centroid_wave_kernel, dim3(blocks), dim3(256), 0, s, dp, stride, vals_sorted, run_start, keep,
+                         keep_scan, nruns, d_out, out_stride, normals_offset, downsample_all_data ? 1 : 0);
+    } else if (uint64_t(nv) > uint64_t(nruns) * 8) {  // runs of a row's size and more: a row of 16 lanes per run
+      const unsigned blocks = unsigned(std::min<uint64_t>((uint64_t(nruns) + 15) / 16, uint64_t(ctx->num_cus) * 16));
+      hipLaunchKernelGGL(vg_centroid_row_kernel, dim3(blocks), dim3(256), 0, s, dp, stride, vals_sorted, run_start, keep,
                          keep_scan, nruns, d_out, out_stride, normals_offset, downsample_all_data ? 1 : 0);
     } else {
       hipLaunchKernelGGL(vg_centroid_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, dp, stride, vals_sorted, run_start, keep,
