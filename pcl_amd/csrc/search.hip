@@ -1322,6 +1322,11 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     }
     int ga = ctx->num_cus * 8;
     if (ga > icp->grid_blocks) ga = icp->grid_blocks;
+    {  // small clouds: no more blocks than give every thread ~4 points -- each block leaves a row of partial sums that the
+       // single-workgroup reduction has to read (2048 rows cost it more than the sums of a 65k-point cloud)
+      const int need = int((uint64_t(icp->n) + 1023u) / 1024u);
+      if (ga > need) ga = need < 64 ? 64 : need;
+    }
     if (mode == PCLHIP_ICP_POINT_TO_PLANE)
       launch_accumulate<PCLHIP_ICP_POINT_TO_PLANE>(icp, v, ga, keep, M, ctl, s);
     else if (mode == PCLHIP_ICP_SYMMETRIC)
