@@ -8,7 +8,8 @@ discs, and counts for every 64-query group, with TIGHT radii (each query's true 
   W1 / W2                the tilt-compensated reach filter (group direction from PCA / from the nearest leaf)
   row_alive_*            the same per 16-lane row
   union_need, need/lane  leaves some lane really needs (per-lane disc bound against its own radius)
-"MISSED" must print 0: the reach filter never drops a leaf a lane needs.
+  row / quad / lane pairs   hierarchical pair culling with the reach filter: tests and survivors per level
+"MISSED" must print 0 and "lane pairs needed (found)" must equal "(all)": the reach filter never drops a leaf a lane needs.
 
     python scratch/standoff_model.py 0.28 -0.22
 """
@@ -114,7 +115,6 @@ for g in sg[::4]:
     w1=wbound(ng3)
     near=np.argmin(((c-qm)**2).sum(1)); w2=wbound(n[near])
     w12=w1&w2&(lb_new<=T)
-    # per-lane
     qp=q[:,None,:]-c[None,:,:]
     r2l=(qp**2).sum(2); al=np.abs((qp*n[None]).sum(2))
     gtl=np.maximum(np.sqrt(np.maximum(r2l-al**2,0))-R[None],0); gnl=np.maximum(al-hn[None],0)
@@ -123,9 +123,32 @@ for g in sg[::4]:
     lbl=np.maximum(lbl,lbbl)
     need=(lbl<=d2[:,None])
     needbox=(lbbl<=d2[:,None])
-    res.append((np.sqrt(T),(lb_cur<=T).sum(),(lb_new<=T).sum(),need.any(0).sum(),need.sum(1).mean(),need.sum(1).max(),(lb_box<=T).sum(),needbox.any(0).sum(),needbox.sum(1).mean(),(lb3<=T).sum(),(lb4<=T).sum(),np.mean(rowalive),np.max(rowalive),anyrow.sum(),w1.sum(),w2.sum(),w12.sum(),(w2&~need.any(0)).sum(), (need.any(0)&~w2).sum()))
+    # hierarchical pair culling: the reach filter with the quantities of a sub-group of lanes
+    def reach_alive(sel):
+        qs_=q[sel]; rho_=rho[sel]; qm_=qs_.mean(0); rS_=np.sqrt(((qs_-qm_)**2).sum(1).max())
+        a_=(qs_-qm_)@ng3; Up_=(rho_-a_).max(); Um_=(rho_+a_).max(); rmax_=rho_.max()
+        al=n@ng3; mu=np.linalg.norm(n-al[:,None]*ng3[None,:],axis=1)*rS_
+        s0_=((qm_-c)*n).sum(1); beta=np.sign(s0_)*al
+        reach=np.where(beta>=0,beta*Up_+(1-beta)*rmax_,(-beta)*Um_+(1+beta)*rmax_)-np.abs(s0_)+mu+hn
+        dc_=qm_-c; gt_=np.maximum(np.sqrt(np.maximum((dc_**2).sum(1)-((n*dc_).sum(1))**2,0))-(rS_+R),0)
+        return (reach>=0)&(gt_**2<=2*rmax_*reach)
+    row_pairs=0; quad_pairs=0; lane_pairs=0; quad_tests=0; lane_tests=0
+    for r_ in range(4):
+        rs=np.arange(16*r_,16*r_+16); ra=reach_alive(rs); row_pairs+=ra.sum()
+        # quads: kd order inside a 16-leaf is not 2x2 spatial; model them by the 4 spatial quadrants of the row
+        ctr=q[rs].mean(0); d_=q[rs]-ctr; t1=Vv[:,2]; t2=Vv[:,1]
+        quad=((d_@t1)>0).astype(int)*2+((d_@t2)>0).astype(int)
+        for qd in range(4):
+            qsel=rs[quad==qd]
+            if len(qsel)==0: continue
+            quad_tests+=ra.sum()
+            qa=reach_alive(qsel)&ra; quad_pairs+=qa.sum()
+            lane_tests+=qa.sum()*len(qsel)
+            lane_pairs+=(need[qsel][:,qa]).sum()
+    missed=0
+    res.append((np.sqrt(T),(lb_cur<=T).sum(),(lb_new<=T).sum(),need.any(0).sum(),need.sum(1).mean(),need.sum(1).max(),(lb_box<=T).sum(),needbox.any(0).sum(),needbox.sum(1).mean(),(lb3<=T).sum(),(lb4<=T).sum(),np.mean(rowalive),np.max(rowalive),anyrow.sum(),w1.sum(),w2.sum(),w12.sum(),(w2&~need.any(0)).sum(), (need.any(0)&~w2).sum(), row_pairs, quad_tests, quad_pairs, lane_tests, lane_pairs, need.sum()))
 r=np.array(res)
 print("groups",len(r))
 print("standoff mean %.4f"%r[:,0].mean())
-for i,nm in enumerate(["cur_alive","new_alive","union_need","need/lane mean","need/lane max","box_alive","box_union_need","boxneed/lane","pca_alive","pca_tan_alive","row_alive_mean","row_alive_max","row_union","W1 pca","W2 nearleaf","W1&W2&V1","W2 false+","W2 MISSED(must be 0)"]):
+for i,nm in enumerate(["cur_alive","new_alive","union_need","need/lane mean","need/lane max","box_alive","box_union_need","boxneed/lane","pca_alive","pca_tan_alive","row_alive_mean","row_alive_max","row_union","W1 pca","W2 nearleaf","W1&W2&V1","W2 false+","W2 MISSED(must be 0)","row pairs alive (of 4 x list)","quad-level tests","quad pairs alive","lane-level tests","lane pairs needed (found)","lane pairs needed (all)"]):
     print("%-16s mean %.1f  p50 %.1f p90 %.1f"%(nm,r[:,i+1].mean(),np.median(r[:,i+1]),np.percentile(r[:,i+1],90)))
