@@ -29,7 +29,11 @@ namespace pclhip {
 // worst case for n < 2^31 points (int32 indices): 134M leaves -> levels of 2.1M, 32768, 512 and 8 boxes;
 // the virtual root's scan pushes <= 7, every interior node below it <= 63 siblings: 7 + 3 * 63 = 196
 constexpr int STACK_ENTRIES = 208;
-constexpr int LEAF_BATCH = 16;         // leaves staged in LDS at a time (16 x 256 B = 4 KB)
+constexpr int LEAF_BATCH = 16;
+#ifndef PCLHIP_PAIR_MODE
+#define PCLHIP_PAIR_MODE 1
+#endif
+constexpr bool pair_mode = PCLHIP_PAIR_MODE != 0;  // A/B: -DPCLHIP_PAIR_MODE=0 walks whole disc lists the sequential way         // leaves staged in LDS at a time (16 x 256 B = 4 KB)
 constexpr int LEAF_FLOATS = 4 * LEAF;  // x[16] y[16] z[16] w[16]
 
 // Per-wavefront LDS working set: traversal stack (1.6 KB), ranked leaf list (3.25 KB), staged candidate
@@ -102,6 +106,48 @@ __device__ __forceinline__ float point_disc_lb(float qx, float qy, float qz, con
   const float gn = fmaxf((a - e) - nh.w, 0.0f);
   return __fmaf_rn(gt, gt, gn * gn) * DISC_SHRINK;
 }
+// ---- row filter for disc leaves (pair mode of the loose path, see traverse()) -------------------------------
+// A lower bound for a whole GROUP of queries standing h off a sheet takes the smallest stand-off against the largest
+// radius, and every slack in it is multiplied by the stand-off: r^2 < 2 h slack keeps ~70 leaves alive per 64-query
+// group where the lanes need ~16.  What a lane needs is decided by d_i - lb_i, in which h_i^2 cancels; the filter
+// below therefore bounds the per-lane REACH over a set S of lanes (here: a row of 16).  With rho_i = sqrt(worst_i), a
+// direction ng (any vector; the patch normal is the useful one), the set's centre C and radius rS, w_i = q_i - C,
+// a_i = ng.w_i and the decomposition n = alpha ng + m of the disc normal:
+//     sigma_i = n.(q_i - c) = s0 + alpha a_i + m.w_i,   s0 = n.(C - c),   |m.w_i| <= |m| rS
+//     g_i = max(|sigma_i| - hn, 0)  is the lane's gap along n;  lane i needs the leaf only if  g_i <= rho_i  and
+//     lat_i^2 <= rho_i^2 - g_i^2 = (rho_i - g_i)(rho_i + g_i) <= 2 rho_max (rho_i - g_i)
+//     rho_i - g_i <= rho_i - sgn(s0) sigma_i + hn <= (rho_i - beta a_i) - |s0| + |m| rS + hn,   beta = sgn(s0) alpha
+//     rho_i - beta a_i <= |beta| U(+/-) + (1 - |beta|) rho_max,   U+ = max_S (rho_i - a_i),  U- = max_S (rho_i + a_i)
+// so a leaf whose lateral gap gt to the set (centre distance across n less both radii) has gt^2 > 2 rho_max reach, or
+// whose reach is negative, is needed by no lane of S.  Every rounding is covered by explicit allowances as in
+// point_disc_lb.  (scratch/standoff_model.py: 356 (row, leaf) pairs -> 64 alive per group at the bench's stand-off.)
+struct RowReach {
+  float cx, cy, cz, rS;  // centre and radius of the row's queries (radius rounded up)
+  float Up, Um, rho;     // U+, U-, rho_max of the row (rounded up)
+};
+__device__ __forceinline__ bool row_reach_alive(const RowReach& rr, float ngx, float ngy, float ngz, const float4 cR,
+                                                const float4 nh) {
+  const float dx = rr.cx - cR.x, dy = rr.cy - cR.y, dz = rr.cz - cR.z;
+  const float r2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+  const float s0 = __fmaf_rn(nh.z, dz, __fmaf_rn(nh.y, dy, __fmul_rn(nh.x, dx)));
+  const float e = 1e-6f * ((fabsf(dx) + fabsf(dy)) + fabsf(dz));  // rounding of the dot product
+  const float as0 = fabsf(s0);
+  const float a_hi = as0 + e;
+  // across n: |d|^2 - (n.d / |n|)^2 with |n|^2 >= 1 - 1e-6 (the build shrinks n by 4e-7)
+  const float b2 = fmaxf(__fmaf_rn(r2, 0.999999f, -(a_hi * a_hi) * 1.000003f), 0.0f);
+  const float gt = fmaxf(__fmaf_rn(__fsqrt_rn(b2), 0.999999f, -(rr.rS + cR.w)), 0.0f);
+  const float alpha = fminf(fmaxf(__fmaf_rn(nh.z, ngz, __fmaf_rn(nh.y, ngy, __fmul_rn(nh.x, ngx))), -1.0f), 1.0f);
+  const float mx = __fmaf_rn(-alpha, ngx, nh.x), my = __fmaf_rn(-alpha, ngy, nh.y), mz = __fmaf_rn(-alpha, ngz, nh.z);
+  const float mlen = __fsqrt_rn(__fmaf_rn(mz, mz, __fmaf_rn(my, my, __fmul_rn(mx, mx)))) * 1.000001f + 2e-6f;
+  const float beta = s0 < 0.0f ? -alpha : alpha;
+  const float ab = fabsf(beta);
+  const float U = beta < 0.0f ? rr.Um : rr.Up;
+  float reach = __fmaf_rn(ab, U, (1.0f - ab) * rr.rho) - (as0 - e) + __fmaf_rn(mlen, rr.rS, nh.w);
+  reach += 4e-6f * ((((rr.rho + as0) + (rr.rS + nh.w)) + fabsf(rr.Up)) + fabsf(rr.Um));
+  reach = fminf(reach, 1e30f);  // degenerate discs carry FLT_MAX: keep the product below finite
+  return reach >= 0.0f && gt * gt <= 2.00002f * rr.rho * reach;
+}
+
 // ---- wavefront reductions (all 64 lanes must be active) ---------------------------------------
 // DPP butterflies (no LDS traffic, plain VALU latency): quad_perm swaps, row_half_mirror and
 // row_mirror leave every row of 16 lanes holding its row result; row_bcast15/31 then fold the four
@@ -156,6 +202,25 @@ __device__ __forceinline__ void wave_min3_max4(float& a0, float& a1, float& a2, 
   b3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b3), 63));
 }
 #undef PCLHIP_DPP_STEP7
+// reductions over every ROW of 16 lanes (each lane ends up with its row's result): three chains at once, which interleave,
+// so no wait states are needed between the steps
+#define PCLHIP_ROW_STEP3(O0, O1, O2, CTRL) \
+  O0 " %0, %0, %0 " CTRL "\n\t"           \
+  O1 " %1, %1, %1 " CTRL "\n\t"           \
+  O2 " %2, %2, %2 " CTRL "\n\t"
+#define PCLHIP_ROW_REDUCE3(O0, O1, O2)                                                       \
+  "s_nop 1\n\t" PCLHIP_ROW_STEP3(O0, O1, O2, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") \
+      PCLHIP_ROW_STEP3(O0, O1, O2, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")           \
+          PCLHIP_ROW_STEP3(O0, O1, O2, "row_half_mirror row_mask:0xf bank_mask:0xf")           \
+              PCLHIP_ROW_STEP3(O0, O1, O2, "row_mirror row_mask:0xf bank_mask:0xf") "s_nop 1"
+__device__ __forceinline__ void row_max3_f(float& a, float& b, float& c) {
+  asm volatile(PCLHIP_ROW_REDUCE3("v_max_f32_dpp", "v_max_f32_dpp", "v_max_f32_dpp") : "+v"(a), "+v"(b), "+v"(c));
+}
+__device__ __forceinline__ void row_min3_f(float& a, float& b, float& c) {
+  asm volatile(PCLHIP_ROW_REDUCE3("v_min_f32_dpp", "v_min_f32_dpp", "v_min_f32_dpp") : "+v"(a), "+v"(b), "+v"(c));
+}
+#undef PCLHIP_ROW_REDUCE3
+#undef PCLHIP_ROW_STEP3
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -871,22 +936,115 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         const float before = pol.worst(0);
         const bool loose = ordered;
         bool cut = false;
-        for (uint32_t b0 = 0; b0 < n_alive && !cut; b0 += LEAF_BATCH) {
-          const uint32_t nb = (n_alive - b0) < uint32_t(LEAF_BATCH) ? (n_alive - b0) : uint32_t(LEAF_BATCH);
-          {
-            const uint32_t slot = uint32_t(lane) & 15u;
-            uint32_t leaf_id = 0;
-            if (slot < nb) leaf_id = __float_as_uint(wl.list[3 * (b0 + slot)].w);
+        // LDS-DMA of the candidate blocks of list entries [b0, b0 + nb) into the (transposed) staging buffer
+        const auto stage = [&](uint32_t b0, uint32_t nb) {
+          const uint32_t slot = uint32_t(lane) & 15u;
+          uint32_t leaf_id = 0;
+          if (slot < nb) leaf_id = __float_as_uint(wl.list[3 * (b0 + slot)].w);
 #pragma unroll
-            for (int i = 0; i < NCHUNK / 4; ++i) {
-              if (slot < nb) {
-                const float* src = ix.soa + size_t(leaf_id) * LEAF_FLOATS + (i * 4 + (lane >> 4)) * 4;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(wl.buf + i * (WAVE * 4)), 16,
-                                                 0, 0);
-              }
+          for (int i = 0; i < NCHUNK / 4; ++i) {
+            if (slot < nb) {
+              const float* src = ix.soa + size_t(leaf_id) * LEAF_FLOATS + (i * 4 + (lane >> 4)) * 4;
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                               (__attribute__((address_space(3))) void*)(wl.buf + i * (WAVE * 4)), 16, 0,
+                                               0);
             }
           }
+        };
+        for (uint32_t b0 = 0; b0 < n_alive && !cut; b0 += LEAF_BATCH) {
+          const uint32_t nb = (n_alive - b0) < uint32_t(LEAF_BATCH) ? (n_alive - b0) : uint32_t(LEAF_BATCH);
+          if (b0 != 0 && use_disc && pair_mode) {
+            // ---- pair mode: the rest of a disc list after its first batch --------------------------------------------
+            // The first batch (the 16 leaves nearest to the group) has given every lane a radius close to its final one.
+            // From here the remaining (lane, leaf) pairs are culled hierarchically instead of one leaf at a time for all
+            // 64 lanes: (row of 16 lanes, leaf) pairs by the reach filter, 64 pairs per pass; then every lane tests only
+            // the leaves alive for ITS row; then the needed leaves are evaluated, lane-sparse, batch by batch.  Nothing
+            // tightens inside this block, which is why it only follows a first batch walked the sequential way (starting
+            // later lists of the group in pair mode was measured: 15 -> 24 evaluation rounds, 3.10 -> 3.65 ms).
+            const float BIGF = 3.402823466e+38f;
+            RowReach rr;
+            float ngx = 0.0f, ngy = 0.0f, ngz = 0.0f;
+            {
+              // the row's queries: bounding box -> centre and radius (rounded up); invalid lanes take no part
+              float l0 = valid[0] ? qx[0] : BIGF, l1 = valid[0] ? qy[0] : BIGF, l2 = valid[0] ? qz[0] : BIGF;
+              float h0 = valid[0] ? qx[0] : -BIGF, h1 = valid[0] ? qy[0] : -BIGF, h2 = valid[0] ? qz[0] : -BIGF;
+              row_min3_f(l0, l1, l2);
+              row_max3_f(h0, h1, h2);
+              const bool any = !(l0 > h0);
+              rr.cx = any ? 0.5f * (l0 + h0) : 0.0f;
+              rr.cy = any ? 0.5f * (l1 + h1) : 0.0f;
+              rr.cz = any ? 0.5f * (l2 + h2) : 0.0f;
+              const float ex = any ? h0 - l0 : 0.0f, ey = any ? h1 - l1 : 0.0f, ez = any ? h2 - l2 : 0.0f;
+              rr.rS = __fsqrt_rn((ex * ex + ey * ey) + ez * ez) * 0.5000005f +
+                      1e-6f * ((fabsf(rr.cx) + fabsf(rr.cy)) + fabsf(rr.cz));
+              // group direction: the four rows are the quadrants of the 64-query patch (kd order), the cross product of
+              // the two diagonals of their centres is its normal.  Any direction is valid; a poor one only filters less.
+              const float r0x = readlane_f(rr.cx, 0), r0y = readlane_f(rr.cy, 0), r0z = readlane_f(rr.cz, 0);
+              const float r1x = readlane_f(rr.cx, 16), r1y = readlane_f(rr.cy, 16), r1z = readlane_f(rr.cz, 16);
+              const float r2x = readlane_f(rr.cx, 32), r2y = readlane_f(rr.cy, 32), r2z = readlane_f(rr.cz, 32);
+              const float r3x = readlane_f(rr.cx, 48), r3y = readlane_f(rr.cy, 48), r3z = readlane_f(rr.cz, 48);
+              const float ux = r3x - r0x, uy = r3y - r0y, uz = r3z - r0z, vx = r2x - r1x, vy = r2y - r1y, vz = r2z - r1z;
+              const float cxn = uy * vz - uz * vy, cyn = uz * vx - ux * vz, czn = ux * vy - uy * vx;
+              const float l2n = cxn * cxn + cyn * cyn + czn * czn;
+              if (l2n > 1e-30f && l2n < 1e30f) {
+                const float il = __frsqrt_rn(l2n);
+                ngx = cxn * il;
+                ngy = cyn * il;
+                ngz = czn * il;
+              }
+              const float a_own = (ngx * (qx[0] - rr.cx) + ngy * (qy[0] - rr.cy)) + ngz * (qz[0] - rr.cz);
+              const float rho = __fsqrt_rn(valid[0] ? pol.worst(0) : 0.0f) * 1.000004f;
+              rr.Up = valid[0] ? rho - a_own : -BIGF;
+              rr.Um = valid[0] ? rho + a_own : -BIGF;
+              rr.rho = valid[0] ? rho : 0.0f;
+              row_max3_f(rr.Up, rr.Um, rr.rho);
+            }
+            // (row, leaf) pairs: lane (r, s) tests entry e0 + s for row r; a row keeps its 16 bits of every ballot
+            const uint32_t sub = uint32_t(lane) & 15u, rshift = (uint32_t(lane) >> 4) * 16u;
+            uint64_t rowmask = 0;
+            for (uint32_t e0 = b0; e0 < n_alive; e0 += 16u) {
+              const uint32_t e = e0 + sub;
+              bool al = false;
+              if (e < n_alive) {
+                const float4 ea = wl.list[3 * e], eb = wl.list[3 * e + 1], es = wl.list[3 * e + 2];
+                al = !(eb.w > T) && (!(rr.rho < 1e30f) ||
+                                     row_reach_alive(rr, ngx, ngy, ngz, make_float4(ea.x, ea.y, ea.z, wl.rad[e]), es));
+              }
+              const uint64_t bal = __builtin_amdgcn_ballot_w64(al);
+              rowmask |= ((bal >> rshift) & 0xFFFFull) << e0;
+            }
+            // (lane, leaf) pairs: every lane walks the entries alive for its row
+            uint64_t todo = valid[0] ? rowmask : 0ull, lanemask = 0;
+            while (__builtin_amdgcn_ballot_w64(todo != 0) != 0) {
+              ++ts.c[1];
+              const bool has = todo != 0;
+              const uint32_t e = has ? uint32_t(__builtin_ctzll(todo)) : b0;
+              todo &= todo - 1ull;  // 0 stays 0
+              const float4 ea = wl.list[3 * e], es = wl.list[3 * e + 2];
+              const float lb = point_disc_lb(qx[0], qy[0], qz[0], make_float4(ea.x, ea.y, ea.z, wl.rad[e]), es);
+              const bool need = has && !(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w));
+              lanemask |= need ? (1ull << e) : 0ull;
+            }
+            // evaluation, 16 staged leaves at a time, every lane its own
+            for (uint32_t c0 = b0; c0 < n_alive; c0 += LEAF_BATCH) {
+              uint32_t m16 = uint32_t((lanemask >> c0) & 0xFFFFull);
+              if (__builtin_amdgcn_ballot_w64(m16 != 0) == 0) continue;
+              const uint32_t cn = (n_alive - c0) < uint32_t(LEAF_BATCH) ? (n_alive - c0) : uint32_t(LEAF_BATCH);
+              stage(c0, cn);
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              while (__builtin_amdgcn_ballot_w64(m16 != 0) != 0) {
+                uint32_t slot = 0, id = NO_INDEX;
+                if (m16 != 0) {
+                  slot = uint32_t(__builtin_ctz(m16));
+                  id = __float_as_uint(wl.list[3 * (c0 + slot)].w);
+                  m16 &= m16 - 1u;
+                }
+                round(slot, id);
+              }
+            }
+            break;  // the list is done
+          }
+          stage(b0, nb);
           bool landed = false;
           if (loose) {
             // Loose bounds (first ICP iterations): walk the sorted batch; every lane keeps at most one
