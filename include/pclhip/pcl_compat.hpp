@@ -521,6 +521,21 @@ class NormalEstimation : public PCLBase<PointInT> {
   bool use_sensor_origin_ = true;
 };
 
+// pcl::NormalEstimationOMP<PointInT, PointOutT> (features/include/pcl/features/normal_3d_omp.h:53-113): the same
+// computation; the thread count of the host loop has no meaning for the one-launch device path and is only stored
+template <typename PointInT>
+class NormalEstimationOMP : public NormalEstimation<PointInT> {
+ public:
+  explicit NormalEstimationOMP(unsigned int nr_threads = 0) : NormalEstimation<PointInT>() { setNumberOfThreads(nr_threads); }
+  explicit NormalEstimationOMP(Context::Ptr ctx, unsigned int nr_threads = 0) : NormalEstimation<PointInT>(std::move(ctx)) {
+    setNumberOfThreads(nr_threads);
+  }
+  void setNumberOfThreads(unsigned int nr_threads = 0) { threads_ = nr_threads; }
+  unsigned int getNumberOfThreads() const { return threads_; }
+ private:
+  unsigned int threads_ = 0;
+};
+
 namespace registration {
 
 // pcl::registration::CorrespondenceRejector{Distance,MedianDistance,OneToOne,Trimmed}: parameter holders;

@@ -232,6 +232,16 @@ int main(int argc, char** argv) {
       equal = equal && a.normal_x == b.normal_x && a.normal_y == b.normal_y && a.normal_z == b.normal_z && a.curvature == b.curvature;
     }
     EXPECT(equal);
+    NormalEstimationOMP<PointXYZ> omp(ctx, 8);  // normal_3d_omp.h: the same normals whatever the thread count
+    omp.setSearchMethod(tree);
+    omp.setKSearch(10);
+    omp.setViewPoint(0.0f, 0.0f, 10.0f);
+    omp.setInputCloud(target);
+    omp.compute(same);
+    bool omp_equal = same.size() == self.size() && omp.getNumberOfThreads() == 8;
+    for (std::size_t j = 0; omp_equal && j < same.size(); ++j)
+      omp_equal = same[j].normal_x == self[j].normal_x && same[j].normal_z == self[j].normal_z && same[j].curvature == self[j].curvature;
+    EXPECT(omp_equal);
     NormalEstimation<PointXYZ> ne2(ctx);  // normals AT the source points from the target surface
     ne2.setKSearch(10);
     ne2.setViewPoint(0.0f, 0.0f, 10.0f);
