@@ -958,6 +958,7 @@ pclhip_status pclhip_icp_reset(pclhip_icp* icp) {
                                            hipMemcpyDeviceToDevice, ctx->stream));
     // no seeds from a previous alignment: the first iteration searches from scratch
     PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(icp->match_pos, 0xFF, size_t(icp->n) * sizeof(uint32_t), ctx->stream));
+    icp->seeds_cleared = true;
   }
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PCLHIP_OK;

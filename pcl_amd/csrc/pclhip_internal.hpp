@@ -176,6 +176,7 @@ struct pclhip_icp {
   uint32_t* match = nullptr;       // per sorted source slot: ORIGINAL target index or NO_INDEX
   uint32_t* match_pos = nullptr;   // ... and its sorted position (seed of the next iteration)
   float* match_d2 = nullptr;
+  bool seeds_cleared = false;       // match_pos was just reset (pclhip_icp_reset): the next host-driven launch is a cold one
   double* partials = nullptr;      // [blocks][NSUMS]
   double* sums_dev = nullptr;      // [NSUMS]
   double* sums_host = nullptr;     // pinned

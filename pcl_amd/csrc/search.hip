@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "traverse.hpp"
+#include "standoff.hpp"
 #include "normals_math.hpp"
 #include <mutex>
 #include <unordered_map>
@@ -820,6 +821,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
   if (ctl != nullptr) {
     if (ctl->stop != 0) return;  // the alignment ended before this (speculatively queued) launch
     restart = ctl->restart != 0;
+    if (restart && (flags & 4) != 0) return;  // icp_cold_search_kernel, queued next to this launch, takes a first iteration
 #pragma unroll
     for (int i = 0; i < 12; ++i) T.m[i] = ctl->T_apply[i];
   }
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
   // software pipeline: the next group's points, seed positions and seed target points are already
   // in flight while the current group is searched
   uint32_t gl = sched.first();
-  uint32_t g = (gl < sched.groups_per_xcd) ? sched.global(gl) : ngroups;
+  uint32_t g = (gl < sched.end()) ? sched.global(gl) : ngroups;
   float4 p_n[Q], t_n[Q];
   uint32_t sp_n[Q];
 #pragma unroll
@@ -867,7 +869,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
     }
     // next group: issue its points + seed positions now ...
     gl += sched.step();
-    const uint32_t g2 = (gl < sched.groups_per_xcd) ? sched.global(gl) : ngroups;
+    const uint32_t g2 = (gl < sched.end()) ? sched.global(gl) : ngroups;
     bool next_ok[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -941,6 +943,100 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
       }
     }
     g = g2;
+  }
+  flush_stats(ts, gstats);
+}
+
+// The launch WITHOUT seeds (first iteration of an alignment), for indices that carry leaf discs: every wave owns a
+// run of consecutive -- spatially adjacent -- groups and seeds each from its predecessor's matches (standoff.hpp:
+// collect / cull / evaluate); whatever that path gives up on goes through traverse() with the bounds reached so
+// far.  Same outputs as icp_search_kernel, bit for bit.  In the device-driven loop both kernels are queued every
+// iteration and the one the control block does not call for falls through (flags bit 4 of icp_search_kernel).
+__global__ __launch_bounds__(BLOCK, 4) void icp_cold_search_kernel(IndexView ix, float4* __restrict__ cur,
+                                                                   const float4* __restrict__ src0, uint32_t ns, Mat34 T,
+                                                                   const IcpControl* __restrict__ ctl, RegionBox region,
+                                                                   int order, float bound, int flags,
+                                                                   uint32_t* __restrict__ match_pos,
+                                                                   uint32_t* __restrict__ match,
+                                                                   float* __restrict__ match_d2, unsigned long long* gstats) {
+  bool restart = false;
+  if (ctl != nullptr) {
+    if (ctl->stop != 0 || ctl->restart == 0) return;  // not the first iteration of an alignment
+    restart = true;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T.m[i] = ctl->T_apply[i];
+  }
+  const float4* in = restart ? src0 : cur;
+  const int use_max = flags & 1;
+  __shared__ WaveLdsT<3072> wl_s[WAVES_PER_BLOCK];
+  __shared__ Box topbox_s[TOPCACHE_BOXES];
+  load_top_cache(ix, topbox_s);
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const uint32_t ngroups = (ns + WAVE - 1) / WAVE;
+  const GroupSchedule sched(ngroups, true);
+  TraverseStats ts;
+  PrevGroup prev = {0.0f, 0.0f, 0.0f, NO_INDEX};
+  uint32_t gl = sched.first();
+  float4 p_n = make_float4(0, 0, 0, 0);
+  {
+    const uint32_t g0 = (gl < sched.end()) ? sched.global(gl) : ngroups;
+    if (g0 < ngroups && g0 * WAVE + lane < ns) p_n = in[g0 * WAVE + lane];
+  }
+  for (; gl < sched.end(); ++gl) {
+    const uint32_t g = sched.global(gl);
+    if (g >= ngroups) break;
+    float4 p = p_n;
+    const uint32_t i = g * WAVE + lane;
+    const bool in_range = i < ns;
+    {  // the next group's points are in flight while this one is searched
+      const uint32_t g2 = (gl + 1u < sched.end()) ? sched.global(gl + 1u) : ngroups;
+      p_n = make_float4(0, 0, 0, 0);
+      if (g2 < ngroups && g2 * WAVE + lane < ns) p_n = in[g2 * WAVE + lane];
+    }
+    NN1Min fast;
+    fast.init(bound);
+    bool valid = in_range && isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+    if (valid) {
+      const float x = xform_row(T.m[0], T.m[1], T.m[2], T.m[3], p.x, p.y, p.z, order);
+      const float y = xform_row(T.m[4], T.m[5], T.m[6], T.m[7], p.x, p.y, p.z, order);
+      const float z = xform_row(T.m[8], T.m[9], T.m[10], T.m[11], p.x, p.y, p.z, order);
+      p.x = x; p.y = y; p.z = z;
+      cur[i] = p;
+      if (region.on) valid = in_region(region, x, y, z);  // target sharding: see icp_search_kernel
+    } else if (in_range && restart) {
+      cur[i] = p;  // non-finite points travel unchanged (icp.hpp:97-98)
+    }
+    const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
+    const bool vv[1] = {valid};
+    uint32_t hint = NO_INDEX;
+    const bool done = standoff_search(ix, p.x, p.y, p.z, valid, fast, wl_s[wave], topbox_s, ts, prev, (flags & 2) != 0, hint);
+    if (!done) traverse<NN1Min, true>(ix, qx, qy, qz, vv, fast, wl_s[wave], topbox_s, ts, (flags & 2) ? hint : NO_INDEX, true);
+    fast.resolve(ix, qx, qy, qz);
+    NN1 pol;
+    pol.soa = ix.soa;
+    pol.key = KEY_NONE;
+    pol.pos = fast.bestpos[0];
+    if (fast.bestpos[0] != NO_INDEX) pol.key = make_key(fast.best[0], __float_as_uint(ix.pts[fast.bestpos[0]].w));
+    {
+      const bool redo[1] = {valid && (fast.tie[0] || (fast.bestpos[0] == NO_INDEX && !use_max))};
+      if (__builtin_amdgcn_ballot_w64(redo[0]) != 0) {  // exact (distance, index) policy for tie lanes
+        NN1 ex = pol;
+        traverse<NN1, true>(ix, qx, qy, qz, redo, ex, wl_s[wave], topbox_s, ts);
+        if (redo[0]) pol = ex;
+      }
+    }
+    const uint32_t mid = key_index(pol.key);
+    const bool found = valid && mid != NO_INDEX;
+    if (in_range) {
+      match[i] = found ? mid : NO_INDEX;
+      match_pos[i] = found ? pol.pos : NO_INDEX;
+      match_d2[i] = found ? key_dist(pol.key) : __builtin_inff();
+    }
+    prev.x = p.x;
+    prev.y = p.y;
+    prev.z = p.z;
+    prev.pos = found ? pol.pos : NO_INDEX;
   }
   flush_stats(ts, gstats);
 }
@@ -1259,6 +1355,16 @@ __global__ void icp_solve_kernel(IcpControl* __restrict__ ctl, const double* __r
   if (threadIdx.x == 0 && blockIdx.x == 0) icp_solve_step(ctl, sums, log);
 }
 
+// flags of the search kernels: 1 a finite maximum distance is set, 2 seeded descents may start below the root
+// (search_skip_flag), 4 (icp_search_kernel, device-driven loop) a first iteration belongs to icp_cold_search_kernel
+static bool standoff_enabled() {  // A/B: PCLHIP_STANDOFF=0 keeps traverse() for launches without seeds
+  static const bool f = [] {
+    const char* e = getenv("PCLHIP_STANDOFF");
+    return !(e && atoi(e) == 0);
+  }();
+  return f;
+}
+
 static int search_skip_flag() {
   static const int skip = [] {  // A/B: PCLHIP_ICP_SKIP=0 always descends from the root
     const char* e = getenv("PCLHIP_ICP_SKIP");
@@ -1308,10 +1414,23 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   if (icp->n > 0 && (device_loop || unfused || filters || mode == PCLHIP_ICP_SYMMETRIC || icp->region.on)) {
     auto ks = icp_search_kernel<4, 1, true>;
     const int gs = resident_blocks(ctx, ks, ngroups);
+    // launches without seeds go through the stand-off kernel when the index carries leaf discs: the host-driven loop
+    // knows which launch that is (pclhip_icp_reset cleared the seeds); the device-driven loop queues both kernels and
+    // the control block decides on the device
+    const bool standoff = standoff_enabled() && v.disc != nullptr && search_skip_flag() != 0;
+    const bool cold = standoff && !device_loop && icp->seeds_cleared;
+    icp->seeds_cleared = false;
+    const int kflags = (use_max ? 1 : 0) | search_skip_flag();
     (void)hipEventRecord(device_loop ? ev[0] : icp->ev0, s);
-    hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl, icp->region,
-                       order, bound, (use_max ? 1 : 0) | search_skip_flag(), icp->match_pos, icp->match, icp->match_d2,
-                       ctx->stats);
+    if (!cold)
+      hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl, icp->region,
+                         order, bound, kflags | ((standoff && device_loop) ? 4 : 0), icp->match_pos, icp->match,
+                         icp->match_d2, ctx->stats);
+    if (cold || (standoff && device_loop)) {
+      const int gc = resident_blocks(ctx, icp_cold_search_kernel, ngroups);
+      hipLaunchKernelGGL(icp_cold_search_kernel, dim3(gc), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M,
+                         ctl, icp->region, order, bound, kflags, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+    }
     (void)hipEventRecord(device_loop ? ev[1] : icp->ev_mid, s);
     icp->mid_recorded = true;
     const uint8_t* keep = nullptr;
