@@ -69,7 +69,7 @@ class Context:
         """Read (then re-arm or disable) the traversal work counters."""
         out = (C.c_uint64 * 8)()
         check(self.lib.pclhip_ctx_stats(self.h, int(enable), out), self.h)
-        names = ("nodes", "leaves_group", "leaves_allpairs", "pushes", "groups")
+        names = ("nodes", "leaves_group", "leaves_allpairs", "pushes", "groups", "so_done", "so_list", "so_union")
         return {n: int(out[i]) for i, n in enumerate(names)}
 
     def close(self):

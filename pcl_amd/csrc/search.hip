@@ -952,10 +952,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
 // collect / cull / evaluate); whatever that path gives up on goes through traverse() with the bounds reached so
 // far.  Same outputs as icp_search_kernel, bit for bit.  In the device-driven loop both kernels are queued every
 // iteration and the one the control block does not call for falls through (flags bit 4 of icp_search_kernel).
-__global__ __launch_bounds__(BLOCK, 4) void icp_cold_search_kernel(IndexView ix, float4* __restrict__ cur,
+#ifndef PCLHIP_COLD_MINW
+#define PCLHIP_COLD_MINW 4
+#endif
+__global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_cold_search_kernel(IndexView ix, float4* __restrict__ cur,
                                                                    const float4* __restrict__ src0, uint32_t ns, Mat34 T,
                                                                    const IcpControl* __restrict__ ctl, RegionBox region,
-                                                                   int order, float bound, int flags,
+                                                                   int order, float bound, int flags, float so_from,
                                                                    uint32_t* __restrict__ match_pos,
                                                                    uint32_t* __restrict__ match,
                                                                    float* __restrict__ match_d2, unsigned long long* gstats) {
@@ -976,7 +979,8 @@ __global__ __launch_bounds__(BLOCK, 4) void icp_cold_search_kernel(IndexView ix,
   const uint32_t ngroups = (ns + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups, true);
   TraverseStats ts;
-  PrevGroup prev = {0.0f, 0.0f, 0.0f, NO_INDEX};
+  PrevGroup prev;
+  prev.init();
   uint32_t gl = sched.first();
   float4 p_n = make_float4(0, 0, 0, 0);
   {
@@ -1010,8 +1014,15 @@ __global__ __launch_bounds__(BLOCK, 4) void icp_cold_search_kernel(IndexView ix,
     const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
     const bool vv[1] = {valid};
     uint32_t hint = NO_INDEX;
-    const bool done = standoff_search(ix, p.x, p.y, p.z, valid, fast, wl_s[wave], topbox_s, ts, prev, (flags & 2) != 0, hint);
-    if (!done) traverse<NN1Min, true>(ix, qx, qy, qz, vv, fast, wl_s[wave], topbox_s, ts, (flags & 2) ? hint : NO_INDEX, true);
+    const bool done =
+        standoff_search(ix, p.x, p.y, p.z, valid, fast, wl_s[wave], topbox_s, ts, prev, (flags & 2) != 0, so_from, hint);
+#if defined(PCLHIP_SO_PROFILE) || defined(PCLHIP_SO_REASONS)
+    const uint64_t so_t0 = clock64();
+    TraverseStats ts_fb;
+#else
+    TraverseStats& ts_fb = ts;
+#endif
+    if (!done) traverse<NN1Min, true>(ix, qx, qy, qz, vv, fast, wl_s[wave], topbox_s, ts_fb, (flags & 2) ? hint : NO_INDEX, true);
     fast.resolve(ix, qx, qy, qz);
     NN1 pol;
     pol.soa = ix.soa;
@@ -1022,7 +1033,7 @@ __global__ __launch_bounds__(BLOCK, 4) void icp_cold_search_kernel(IndexView ix,
       const bool redo[1] = {valid && (fast.tie[0] || (fast.bestpos[0] == NO_INDEX && !use_max))};
       if (__builtin_amdgcn_ballot_w64(redo[0]) != 0) {  // exact (distance, index) policy for tie lanes
         NN1 ex = pol;
-        traverse<NN1, true>(ix, qx, qy, qz, redo, ex, wl_s[wave], topbox_s, ts);
+        traverse<NN1, true>(ix, qx, qy, qz, redo, ex, wl_s[wave], topbox_s, ts_fb);
         if (redo[0]) pol = ex;
       }
     }
@@ -1033,10 +1044,14 @@ __global__ __launch_bounds__(BLOCK, 4) void icp_cold_search_kernel(IndexView ix,
       match_pos[i] = found ? pol.pos : NO_INDEX;
       match_d2[i] = found ? key_dist(pol.key) : __builtin_inff();
     }
-    prev.x = p.x;
-    prev.y = p.y;
-    prev.z = p.z;
-    prev.pos = found ? pol.pos : NO_INDEX;
+    prev.record(p.x, p.y, p.z, found ? pol.pos : NO_INDEX);
+#if defined(PCLHIP_SO_PROFILE)
+    ts.c[7] += uint32_t(clock64() - so_t0);
+    if (!done) ++ts.c[4];
+#elif defined(PCLHIP_SO_REASONS)
+    (void)so_t0;
+    if (!done) ++ts.c[4];
+#endif
   }
   flush_stats(ts, gstats);
 }
@@ -1428,8 +1443,14 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
                          icp->match_d2, ctx->stats);
     if (cold || (standoff && device_loop)) {
       const int gc = resident_blocks(ctx, icp_cold_search_kernel, ngroups);
+      // wave radii (squared) up to so_from stay with traverse(): the groups that sit on the surface
+      static const float so_factor = [] {
+        const char* e = getenv("PCLHIP_SO_FACTOR");
+        return e ? float(atof(e)) : 1.0f;
+      }();
       hipLaunchKernelGGL(icp_cold_search_kernel, dim3(gc), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M,
-                         ctl, icp->region, order, bound, kflags, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+                         ctl, icp->region, order, bound, kflags, so_factor * icp->target->leaf_diag2, icp->match_pos,
+                         icp->match, icp->match_d2, ctx->stats);
     }
     (void)hipEventRecord(device_loop ? ev[1] : icp->ev_mid, s);
     icp->mid_recorded = true;

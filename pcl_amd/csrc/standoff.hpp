@@ -28,11 +28,47 @@
 // list[]; cull: union slots in list[] / rad[]; evaluate: staging in buf[] (the ids are dead by then).
 #pragma once
 
+#include <cstddef>
+
 #include "traverse.hpp"
 
 namespace pclhip {
 
-constexpr uint32_t SO_LIST_CAP = 512;   // collected leaf ids (9 bits of the row-seed keys)
+// -DPCLHIP_SO_PROFILE (scripts/build_variant.sh): the work counters become clock64() ticks per stage --
+// [0] seed, [1] collect, [2] group cull, [3] row seeds, [5] row cull, [6] lane cull, [7] evaluation + the rest of the
+// kernel's group loop (fallback, resolve, ties, stores)
+// -DPCLHIP_SO_REASONS: the counters become the number of groups that left the path at each exit --
+// [0] no finite radius, [1] radius below `from2`, [2] list overflow, [3] frontier overflow, [5] disc overflow,
+// [6] union overflow, [7] done
+#ifdef PCLHIP_SO_REASONS
+#define SO_WHY(i) ++ts.c[i]
+#else
+#define SO_WHY(i) (void)0
+#endif
+#ifdef PCLHIP_SO_MARK
+#define SO_MARK(name) asm volatile("; SO_MARK " name)
+#else
+#define SO_MARK(name) (void)0
+#endif
+#if defined(PCLHIP_SO_PROFILE)
+#define SO_LAP(i)                          \
+  do {                                     \
+    const uint64_t so_now = clock64();     \
+    ts.c[i] += uint32_t(so_now - so_t);    \
+    so_t = so_now;                         \
+  } while (0)
+#define SO_COUNT(expr) (void)0
+#elif defined(PCLHIP_SO_STATS)  // per-step work counters ([0] nodes, [1] lane-cull steps, [2] evaluation rounds, [3] pushes)
+#define SO_LAP(i) (void)0
+#define SO_COUNT(expr) expr
+#else  // the default build only counts per group: [4] groups, [5] groups finished here, [6] collected leaves, [7] union slots
+#define SO_LAP(i) (void)0
+#define SO_COUNT(expr) (void)0
+#endif
+
+constexpr uint32_t SO_LIST_CAP = 768;   // collected leaf ids (they fill the 3 KB staging area)
+constexpr uint32_t SO_DISC_CAP = 124;   // disc entries (32 B) in LDS at a time: bytes [0, 3968) of the wave's block
+constexpr uint32_t SO_SURV_CAP = 192;   // ids of the leaves that pass the group cull: bytes [4224, 4992)
 constexpr uint32_t SO_UNION_CAP = 64;   // union slots: one bit each in the per-row / per-lane masks
 
 // DPP row operations through the builtin (the compiler places the wait states); used once or twice per group
@@ -112,6 +148,54 @@ __device__ __forceinline__ RowReach row_reach_of(const RowGeom& g, float qx, flo
   return rr;
 }
 
+// v_sqrt_f32 as it is (1 ulp, denormal results flushed towards zero): every use below rounds its result towards
+// the conservative side by a relative 1e-6 (sixteen times the error) or more, as the bounds in traverse.hpp do after
+// their correctly rounded square roots.
+__device__ __forceinline__ float so_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// row_reach_alive (traverse.hpp) with so_sqrt: same bound, same allowances
+__device__ __forceinline__ bool so_reach_alive(const RowReach& rr, float ngx, float ngy, float ngz, const float4 cR,
+                                               const float4 nh) {
+  const float dx = rr.cx - cR.x, dy = rr.cy - cR.y, dz = rr.cz - cR.z;
+  const float r2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+  const float s0 = __fmaf_rn(nh.z, dz, __fmaf_rn(nh.y, dy, __fmul_rn(nh.x, dx)));
+  const float e = 1e-6f * ((fabsf(dx) + fabsf(dy)) + fabsf(dz));  // rounding of the dot product
+  const float as0 = fabsf(s0);
+  const float a_hi = as0 + e;
+  const float b2 = fmaxf(__fmaf_rn(r2, 0.999999f, -(a_hi * a_hi) * 1.000003f), 0.0f);
+  const float gt = fmaxf(__fmaf_rn(so_sqrt(b2), 0.999998f, -(rr.rS + cR.w)), 0.0f);
+  const float alpha = fminf(fmaxf(__fmaf_rn(nh.z, ngz, __fmaf_rn(nh.y, ngy, __fmul_rn(nh.x, ngx))), -1.0f), 1.0f);
+  const float mx = __fmaf_rn(-alpha, ngx, nh.x), my = __fmaf_rn(-alpha, ngy, nh.y), mz = __fmaf_rn(-alpha, ngz, nh.z);
+  const float mlen = so_sqrt(__fmaf_rn(mz, mz, __fmaf_rn(my, my, __fmul_rn(mx, mx)))) * 1.000002f + 2e-6f;
+  const float beta = s0 < 0.0f ? -alpha : alpha;
+  const float ab = fabsf(beta);
+  const float U = beta < 0.0f ? rr.Um : rr.Up;
+  float reach = __fmaf_rn(ab, U, (1.0f - ab) * rr.rho) - (as0 - e) + __fmaf_rn(mlen, rr.rS, nh.w);
+  reach += 4e-6f * ((((rr.rho + as0) + (rr.rS + nh.w)) + fabsf(rr.Up)) + fabsf(rr.Um));
+  reach = fminf(reach, 1e30f);  // degenerate discs carry FLT_MAX: keep the product below finite
+  return reach >= 0.0f && gt * gt <= 2.00002f * rr.rho * reach;
+}
+
+// point_disc_lb (traverse.hpp) for TWO discs at once: the same operations component by component, on packed
+// registers (v_pk_add / v_pk_mul / v_pk_fma_f32) where the instruction set has them, with so_sqrt
+__device__ __forceinline__ v2f so_disc_lb2(float qx, float qy, float qz, const float4 c0, const float4 n0, const float4 c1,
+                                           const float4 n1) {
+  const v2f dx = v2f{qx, qx} - v2f{c0.x, c1.x}, dy = v2f{qy, qy} - v2f{c0.y, c1.y}, dz = v2f{qz, qz} - v2f{c0.z, c1.z};
+  const v2f r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+  const v2f nx = {n0.x, n1.x}, ny = {n0.y, n1.y}, nz = {n0.z, n1.z};
+  const v2f dot = __builtin_elementwise_fma(nz, dz, __builtin_elementwise_fma(ny, dy, nx * dx));
+  const v2f a = {fabsf(dot.x), fabsf(dot.y)};
+  const v2f e = v2f{(fabsf(dx.x) + fabsf(dy.x)) + fabsf(dz.x), (fabsf(dx.y) + fabsf(dy.y)) + fabsf(dz.y)} * 1e-6f;
+  const v2f a_hi = a + e;  // >= |n.q'|
+  const v2f t = (a_hi * a_hi) * -1.000003f;
+  const v2f b2 = __builtin_elementwise_fma(r2, v2f{0.999999f, 0.999999f}, t);
+  const v2f sq = {so_sqrt(fmaxf(b2.x, 0.0f)), so_sqrt(fmaxf(b2.y, 0.0f))};
+  const v2f gtr = __builtin_elementwise_fma(sq, v2f{0.999998f, 0.999998f}, -v2f{c0.w, c1.w});
+  const v2f gnr = (a - e) - v2f{n0.w, n1.w};
+  const v2f gt = {fmaxf(gtr.x, 0.0f), fmaxf(gtr.y, 0.0f)}, gn = {fmaxf(gnr.x, 0.0f), fmaxf(gnr.y, 0.0f)};
+  return __builtin_elementwise_fma(gt, gt, gn * gn) * DISC_SHRINK;
+}
+
 // LDS-DMA of up to 16 leaf blocks (x[16] y[16] z[16]: twelve 16-byte chunks each) into a 3 KB staging area,
 // transposed: chunk c of the leaf in slot s lands at ((c * 16 + s) * 16) bytes (see traverse(): SPARSE).
 // `leaf_id`: the leaf of slot (lane & 15), NO_INDEX for an empty slot.
@@ -127,51 +211,114 @@ __device__ __forceinline__ void so_stage(const IndexView& ix, float* dst, uint32
   }
 }
 
-// The previous group of this wave: its queries (as searched) and their matches -- where the seed comes from.
+// LDS-DMA of up to 8 leaf blocks, slot-minor with stride 8: chunk c of the leaf in slot s lands at ((c * 8 + s) * 16)
+// bytes of a 1.5 KB area (read with NN1MinT::leaf_at<8>).  `leaf_id`: the leaf of slot (lane & 7).
+__device__ __forceinline__ void so_stage8(const IndexView& ix, float* dst, uint32_t leaf_id) {
+  const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 8 + (lane >> 3);
+    if (leaf_id != NO_INDEX && c < 12) {
+      const float* src = ix.soa + size_t(leaf_id) * LEAF_FLOATS + c * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + i * (WAVE * 4)), 16, 0, 0);
+    }
+  }
+}
+
+// Where the seed comes from: the previous group of this wave (every lane's query as searched and its match), and a
+// history of one (query, match) pair of each of the wave's last 64 groups, one per lane -- consecutive groups of the
+// kd order are usually neighbours, but a quarter of the steps jump, and then an older group is the nearer one.
 struct PrevGroup {
   float x, y, z;
   uint32_t pos;  // sorted position of the lane's match, NO_INDEX if none
+  float hx, hy, hz;
+  uint32_t hpos;  // history entry of this lane
+  uint32_t count; // groups recorded so far (wave-uniform)
+  __device__ __forceinline__ void init() {
+    x = y = z = hx = hy = hz = 0.0f;
+    pos = hpos = NO_INDEX;
+    count = 0;
+  }
+  // after a group: qx/qy/qz as searched, `mpos` the lane's match position or NO_INDEX
+  __device__ __forceinline__ void record(float qx, float qy, float qz, uint32_t mpos) {
+    x = qx;
+    y = qy;
+    z = qz;
+    pos = mpos;
+    const uint64_t fm = __builtin_amdgcn_ballot_w64(mpos != NO_INDEX);
+    if (fm != 0) {
+      // a lane from the middle of the group's kd order when it has a match, else the first that has
+      const int src = (fm >> 32) & 1ull ? 32 : __builtin_ctzll(fm);
+      const float rx = readlane_f(qx, src), ry = readlane_f(qy, src), rz = readlane_f(qz, src);
+      const uint32_t rp = uint32_t(__builtin_amdgcn_readlane(int(mpos), src));
+      if (uint32_t(threadIdx.x & (WAVE - 1)) == (count & 63u)) {
+        hx = rx;
+        hy = ry;
+        hz = rz;
+        hpos = rp;
+      }
+      ++count;
+    }
+  }
 };
 
 // Returns true when the group is done (pol holds every valid lane's exact minimum, up to the tie / resolve steps the
 // caller runs anyway); false when the caller has to run traverse() -- pol then holds valid bounds and seeds.
-// `seed_leaf_out`: leaf of the seed (a start hint for the fallback).  Must be called by all 64 lanes.
+// `from2`: wave radii (squared) up to this go to traverse() (next to the surface a disc excludes little a box does
+// not).  `seed_leaf_out`: leaf of the seed (a start hint for the fallback).  Must be called by all 64 lanes.
 template <class WL>
 __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, float qy, float qz, bool valid, NN1Min& pol,
                                                 WL& wl, const Box* topbox, TraverseStats& ts, const PrevGroup& prev,
-                                                bool allow_skip, uint32_t& seed_leaf_out) {
+                                                bool allow_skip, float from2, uint32_t& seed_leaf_out) {
+  // the wave's LDS block, stage by stage (bytes): [0, 1664) two frontier buffers while collecting; [0, 3968) the disc
+  // entries (32 B each) from the group cull on; [3968, 4224) ids of the union slots; [4224, 4992) ids of the group
+  // cull's survivors; buf [4992, 8064) the collected ids, then the staging area of the evaluations
   static_assert(WL::BUF_FLOATS >= 768, "staging / id area: 3 KB");
+  static_assert(sizeof(wl.stack) == 1664 && sizeof(wl.list) == 3072 && sizeof(wl.rad) == 256, "LDS plan of standoff.hpp");
+  static_assert(offsetof(WL, list) == 1664 && offsetof(WL, rad) == 4736, "LDS plan of standoff.hpp");
   const int lane = threadIdx.x & (WAVE - 1);
-  const uint32_t sub = uint32_t(lane) & 15u, row = uint32_t(lane) >> 4;
+  const uint32_t sub = uint32_t(lane) & 15u;
   const float BIG = 3.402823466e+38f;
   const float INF = __builtin_inff();
   seed_leaf_out = NO_INDEX;
   if (__builtin_amdgcn_ballot_w64(valid) == 0 || ix.n == 0) return true;
   const float qxa[1] = {qx}, qya[1] = {qy}, qza[1] = {qz};
-
+#ifdef PCLHIP_SO_PROFILE
+  uint64_t so_t = clock64();
+#endif
   // ---- group box -------------------------------------------------------------------------------------------------
   float lx0 = valid ? qx : BIG, ly0 = valid ? qy : BIG, lz0 = valid ? qz : BIG;
   float hx0 = valid ? qx : -BIG, hy0 = valid ? qy : -BIG, hz0 = valid ? qz : -BIG, dummy = 0.0f;
   wave_min3_max4(lx0, ly0, lz0, hx0, hy0, hz0, dummy);
   const float Qlx = lx0, Qly = ly0, Qlz = lz0, Qhx = hx0, Qhy = hy0, Qhz = hz0;
+  const float Cx = 0.5f * (Qlx + Qhx), Cy = 0.5f * (Qly + Qhy), Cz = 0.5f * (Qlz + Qhz);
 
   // ---- 0. seed ---------------------------------------------------------------------------------------------------
   uint32_t seed_pos = NO_INDEX;
   {
-    const float Cx = 0.5f * (Qlx + Qhx), Cy = 0.5f * (Qly + Qhy), Cz = 0.5f * (Qlz + Qhz);
-    const bool pok = prev.pos != NO_INDEX;
-    if (__builtin_amdgcn_ballot_w64(pok) != 0) {
+    const bool pok = prev.pos != NO_INDEX, hok = prev.hpos != NO_INDEX;
+    if (__builtin_amdgcn_ballot_w64(pok || hok) != 0) {
       const float dx = prev.x - Cx, dy = prev.y - Cy, dz = prev.z - Cz;
-      const float d = pok ? (dx * dx + dy * dy) + dz * dz : INF;
+      const float ex = prev.hx - Cx, ey = prev.hy - Cy, ez = prev.hz - Cz;
+      const float d1 = pok ? (dx * dx + dy * dy) + dz * dz : INF;
+      const float d2 = hok ? (ex * ex + ey * ey) + ez * ez : INF;
+      const float d = fminf(d1, d2);
+      const uint32_t cand = d1 <= d2 ? prev.pos : prev.hpos;
       const float m = wave_min_f(d);
-      const uint64_t at = __builtin_amdgcn_ballot_w64(pok && d == m);
-      if (at != 0) seed_pos = uint32_t(__builtin_amdgcn_readlane(int(prev.pos), __builtin_ctzll(at)));
+      const uint64_t at = __builtin_amdgcn_ballot_w64((pok || hok) && d == m);
+      if (at != 0) seed_pos = uint32_t(__builtin_amdgcn_readlane(int(cand), __builtin_ctzll(at)));
     }
     if (seed_pos == NO_INDEX) {
-      // no previous group (first of the wave's chunk) or it had no match: the exact neighbour of ONE lane
+      // no previous group (first of the wave's chunk) or none with a match: the exact neighbour of ONE lane
       const uint64_t vm = __builtin_amdgcn_ballot_w64(valid);
       const bool one[1] = {valid && lane == __builtin_ctzll(vm)};
-      traverse<NN1Min, true>(ix, qxa, qya, qza, one, pol, wl, topbox, ts, NO_INDEX, true);
+#if defined(PCLHIP_SO_PROFILE) || defined(PCLHIP_SO_REASONS)
+      TraverseStats seed_ts;
+#else
+      TraverseStats& seed_ts = ts;
+#endif
+      traverse<NN1Min, true>(ix, qxa, qya, qza, one, pol, wl, topbox, seed_ts, NO_INDEX, true);
       pol.resolve(ix, qxa, qya, qza);
       seed_pos = uint32_t(__builtin_amdgcn_readlane(int(pol.bestpos[0]), __builtin_ctzll(vm)));
     }
@@ -181,51 +328,56 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
     const float4 t = ix.pts[seed_pos];  // wave-uniform address
     if (valid) pol.seed(0, l2_simple(qx, qy, qz, t.x, t.y, t.z), seed_pos);
   }
-  const float T = wave_max_f(valid ? pol.worst(0) : 0.0f);  // wave radius (squared); fixed from here on
-  if (!(T < INF)) return false;
-  if (!(T > ix.disc_from)) return false;  // next to the surface a disc excludes nothing a box does not: traverse()
-
-  uint2* const stack = wl.stack;
-  uint32_t* const ids = reinterpret_cast<uint32_t*>(wl.buf);
-  float* const area_b = reinterpret_cast<float*>(wl.list);  // 3 KB: staging of the row seeds, then the union slots
-
-  // ---- 1. collect ------------------------------------------------------------------------------------------------
-  uint32_t level = uint32_t(ix.top) + 1u, node = 0u;  // virtual root above the top level
-  if (allow_skip && seed_leaf_out != NO_INDEX) {       // start below the root when the search ball fits (see traverse())
-    const auto inside = [&](const Box& b) {
-      const float d = fminf(fminf(fminf(Qlx - b.lo.x, b.hi.x - Qhx), fminf(Qly - b.lo.y, b.hi.y - Qhy)),
-                            fminf(Qlz - b.lo.z, b.hi.z - Qhz));
-      return d > 0.0f && d * d * 0.999999f > T;
-    };
-    const bool has2 = ix.top >= 2, has3 = ix.top >= 3;
-    Box b2 = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)}, b3 = b2;
-    if (has2) b2 = ix.box[2][seed_leaf_out >> 6];
-    if (has3) b3 = ix.box[3][seed_leaf_out >> 12];
-    if (has2 && inside(b2)) {
-      level = 2u;
-      node = seed_leaf_out >> 6;
-    } else if (has3 && inside(b3)) {
-      level = 3u;
-      node = seed_leaf_out >> 12;
-    }
+  const float T = wave_max_f(valid ? pol.worst(0) : 0.0f);  // wave radius (squared); fixed while collecting
+  SO_LAP(0);
+  SO_MARK("seed_end");
+  if (!(T < INF)) {
+    SO_WHY(0);
+    return false;
   }
+  if (!(T > from2)) {
+    SO_WHY(1);
+    return false;
+  }
+
+  char* const lds = reinterpret_cast<char*>(&wl);
+  uint32_t* const ids = reinterpret_cast<uint32_t*>(wl.buf);
+  float4* const dl = reinterpret_cast<float4*>(lds);  // disc entry e: dl[2e] = (centre, R), dl[2e+1] = (normal, hn)
+  uint32_t* const idu = reinterpret_cast<uint32_t*>(lds + 3968);
+  uint32_t* const sid = reinterpret_cast<uint32_t*>(lds + 4224);
+  static_assert(32 * SO_DISC_CAP == 3968 && 3968 + 4 * SO_UNION_CAP == 4224 && 4224 + 4 * SO_SURV_CAP == 4992, "LDS plan");
+  static_assert(offsetof(WL, buf) == 4992, "LDS plan");
+
+  // ---- 1. collect: breadth first, the box rows of up to four nodes in flight together ------------------------------
   uint32_t n = 0;
   {
-    int sp = 0;
-    bool have = true;
-    for (;;) {
-      if (!have) {
-        if (sp == 0) break;
-        --sp;
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t ex = uniform_u32(stack[sp].x);
-        level = ex >> 28;
-        node = ex & 0x0FFFFFFFu;
+    uint32_t* fr_cur = reinterpret_cast<uint32_t*>(lds);
+    uint32_t* fr_next = reinterpret_cast<uint32_t*>(lds + 832);
+    constexpr uint32_t FR_CAP = 208;
+    uint32_t level = uint32_t(ix.top) + 1u, node0 = 0u;  // virtual root above the top level
+    if (allow_skip && seed_leaf_out != NO_INDEX) {        // start below the root when the search ball fits (see traverse())
+      const auto inside = [&](const Box& b) {
+        const float d = fminf(fminf(fminf(Qlx - b.lo.x, b.hi.x - Qhx), fminf(Qly - b.lo.y, b.hi.y - Qhy)),
+                              fminf(Qlz - b.lo.z, b.hi.z - Qhz));
+        return d > 0.0f && d * d * 0.999999f > T;
+      };
+      const bool has2 = ix.top >= 2, has3 = ix.top >= 3;
+      Box b2 = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)}, b3 = b2;
+      if (has2) b2 = ix.box[2][seed_leaf_out >> 6];
+      if (has3) b3 = ix.box[3][seed_leaf_out >> 12];
+      if (has2 && inside(b2)) {
+        level = 2u;
+        node0 = seed_leaf_out >> 6;
+      } else if (has3 && inside(b3)) {
+        level = 3u;
+        node0 = seed_leaf_out >> 12;
       }
-      have = false;
-      ++ts.c[0];
+    }
+    if (lane == 0) fr_cur[0] = node0;
+    uint32_t ncur = 1;
+    for (;;) {
+      __builtin_amdgcn_wave_barrier();
       const uint32_t cl = level - 1u;  // level of the children
-      const uint32_t first = node * FANOUT;
       const Box* level_box = ix.box[1];
       uint32_t total = ix.count[1], coff = 0;
 #pragma unroll
@@ -236,161 +388,262 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
           coff = ix.cache_off[l];
         }
       }
-      const uint32_t nchild = (total - first) < uint32_t(FANOUT) ? (total - first) : uint32_t(FANOUT);
-      const bool has = uint32_t(lane) < nchild;
-      float lx = 0, ly = 0, lz = 0, hx = 0, hy = 0, hz = 0;
-      if (int(cl) >= ix.cache_from) {  // upper levels: boxes come from the block's LDS copy
-        if (has) {
-          const Box b = topbox[coff + first + lane];
-          lx = b.lo.x; ly = b.lo.y; lz = b.lo.z;
-          hx = b.hi.x; hy = b.hi.y; hz = b.hi.z;
+      const bool cached = int(cl) >= ix.cache_from;  // upper levels: boxes come from the block's LDS copy
+      uint32_t nnext = 0;
+      for (uint32_t k = 0; k < ncur; k += 4u) {
+        uint32_t first[4], nchild[4];
+        Box b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // unconditional loads (clamped indices): all four rows are in flight together
+          const uint32_t kk = (k + uint32_t(j)) < ncur ? (k + uint32_t(j)) : (ncur - 1u);
+          first[j] = uniform_u32(fr_cur[kk]) * FANOUT;
+          nchild[j] = (total - first[j]) < uint32_t(FANOUT) ? (total - first[j]) : uint32_t(FANOUT);
+          const uint32_t at = first[j] + (uint32_t(lane) < nchild[j] ? uint32_t(lane) : nchild[j] - 1u);
+          b[j] = cached ? topbox[coff + at] : level_box[at];
         }
-      } else if (has) {
-        const Box b = level_box[first + lane];
-        lx = b.lo.x; ly = b.lo.y; lz = b.lo.z;
-        hx = b.hi.x; hy = b.hi.y; hz = b.hi.z;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (k + uint32_t(j) < ncur) {
+            SO_COUNT(++ts.c[0]);
+            const bool has = uint32_t(lane) < nchild[j];
+            const float lbG = box_box_lb(Qlx, Qly, Qlz, Qhx, Qhy, Qhz, b[j].lo.x, b[j].lo.y, b[j].lo.z, b[j].hi.x, b[j].hi.y,
+                                         b[j].hi.z);
+            const bool alive = has && !(lbG > T);
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(alive);
+            if (mask != 0) {
+              const uint32_t cnt = uint32_t(__builtin_popcountll(mask));
+              const uint32_t pre = uint32_t(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
+              if (cl == 1u) {
+                if (n + cnt > SO_LIST_CAP) {
+                  SO_WHY(2);
+                  return false;
+                }
+                if (alive) ids[n + pre] = first[j] + uint32_t(lane);
+                n += cnt;
+              } else {
+                if (nnext + cnt > FR_CAP) {
+                  SO_WHY(3);
+                  return false;
+                }
+                if (alive) fr_next[nnext + pre] = first[j] + uint32_t(lane);
+                nnext += cnt;
+                SO_COUNT(ts.c[3] += cnt);
+              }
+            }
+          }
+        }
       }
-      const float lbG = has ? box_box_lb(Qlx, Qly, Qlz, Qhx, Qhy, Qhz, lx, ly, lz, hx, hy, hz) : INF;
-      const bool alive = has && !(lbG > T);
-      const uint64_t mask = __builtin_amdgcn_ballot_w64(alive);
-      if (mask == 0) continue;
-      const uint32_t cnt = uint32_t(__builtin_popcountll(mask));
-      const uint32_t pre = uint32_t(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
-      if (cl == 1u) {
-        if (n + cnt > SO_LIST_CAP) return false;
-        if (alive) ids[n + pre] = first + uint32_t(lane);
-        n += cnt;
-      } else {
-        if (alive) stack[sp + int(pre)] = make_uint2((cl << 28) | (first + uint32_t(lane)), 0u);
-        sp += int(cnt);
-        ts.c[3] += cnt;
-      }
+      if (cl == 1u || nnext == 0) break;
+      uint32_t* const t2 = fr_cur;
+      fr_cur = fr_next;
+      fr_next = t2;
+      ncur = nnext;
+      level = cl;
     }
   }
   __builtin_amdgcn_wave_barrier();
+  SO_LAP(1);
+  SO_MARK("collect_end");
   if (n == 0) {  // nothing within the wave radius (a finite maximum distance and no seed inside it)
     ++ts.c[4];
     return true;
   }
 
-  // ---- 2. row seeds ----------------------------------------------------------------------------------------------
+  // ---- 2. group cull: lane j <-> collected leaf l0 + j; the leaves that pass the reach filter of the WHOLE group (the
+  // same bound with the maxima over all 64 lanes) are kept: ids in `sid`, the discs of the first SO_DISC_CAP of them in
+  // LDS (`dl`) -- every later stage reads them from there
   const RowGeom geo = row_geometry(qx, qy, qz, valid);
-  uint32_t id1 = NO_INDEX, id2 = NO_INDEX;
+  const uint32_t row = uint32_t(lane) >> 4;
+  uint32_t ms = 0;  // survivors
   {
-    uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;  // the lane's two smallest (distance | entry) keys
-    for (uint32_t e0 = 0; e0 < n; e0 += 16u) {
-      const uint32_t e = e0 + sub;
-      if (e < n) {
-        const float4 c = ix.disc[2 * size_t(ids[e])];
-        const float dx = geo.cx - c.x, dy = geo.cy - c.y, dz = geo.cz - c.z;
-        const float d = (dx * dx + dy * dy) + dz * dz;  // >= 0: its bit pattern orders like the value
-        const uint32_t key = (__float_as_uint(d) & ~0x1FFu) | e;
-        m2 = min(m2, max(m1, key));
-        m1 = min(m1, key);
-      }
-    }
-    const uint32_t r1 = row_min_u32(m1);
-    const uint32_t r2 = row_min_u32(m1 == r1 ? m2 : m1);
-    if (geo.any && r1 != 0xFFFFFFFFu) id1 = ids[r1 & 0x1FFu];
-    if (geo.any && r2 != 0xFFFFFFFFu) id2 = ids[r2 & 0x1FFu];
-    // slot 2 * row + k <- the row's k-th seed leaf; the ids travel through the (now idle) stack area
-    uint32_t* const tmp = reinterpret_cast<uint32_t*>(stack);
-    if (sub == 0u) {
-      tmp[2 * row] = id1;
-      tmp[2 * row + 1] = id2;
-    }
-    __builtin_amdgcn_wave_barrier();
-    so_stage(ix, area_b, sub < 8u ? tmp[sub] : NO_INDEX);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (uint32_t k = 0; k < 2; ++k) {
-      const uint32_t id = valid ? (k == 0 ? id1 : id2) : NO_INDEX;
-      if (__builtin_amdgcn_ballot_w64(id != NO_INDEX) != 0) {
-        ++ts.c[2];
-        pol.leaf_lane(area_b, 2 * row + k, id, qxa, qya, qza);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-
-  // ---- 3. row cull: (row, leaf) pairs, 64 per pass; leaves alive for any row -> union slots ------------------------
-  const RowReach rr = row_reach_of(geo, qx, qy, qz, valid, pol.worst(0));
-  uint32_t ucnt = 0;
-  uint64_t rowmask;
-  {
-    uint32_t acc_lo = 0, acc_hi = 0;  // this lane's own alive pairs as union-slot bits
-    for (uint32_t e0 = 0; e0 < n; e0 += 16u) {
-      const uint32_t e = e0 + sub;
-      bool al = false;
-      uint32_t id = 0;
-      float4 cR = make_float4(0, 0, 0, 0), nh = cR;
-      if (e < n) {
-        id = ids[e];
-        cR = ix.disc[2 * size_t(id)];
-        nh = ix.disc[2 * size_t(id) + 1];
-        al = geo.any && (!(rr.rho < 1e30f) || row_reach_alive(rr, geo.ngx, geo.ngy, geo.ngz, cR, nh));
-      }
+    RowReach gq;
+    gq.cx = Cx;
+    gq.cy = Cy;
+    gq.cz = Cz;
+    const float ex = Qhx - Qlx, ey = Qhy - Qly, ez = Qhz - Qlz;
+    gq.rS = so_sqrt((ex * ex + ey * ey) + ez * ez) * 0.5000005f + 1e-6f * ((fabsf(Cx) + fabsf(Cy)) + fabsf(Cz));
+    const float a_own = (geo.ngx * (qx - Cx) + geo.ngy * (qy - Cy)) + geo.ngz * (qz - Cz);
+    const float rho = so_sqrt(valid ? pol.worst(0) : 0.0f) * 1.000004f;
+    gq.Up = wave_max_f(valid ? rho - a_own : -BIG);
+    gq.Um = wave_max_f(valid ? rho + a_own : -BIG);
+    gq.rho = wave_max_f(valid ? rho : 0.0f);
+    for (uint32_t l0 = 0; l0 < n; l0 += WAVE) {
+      const uint32_t e = l0 + uint32_t(lane);
+      const uint32_t id = ids[e < n ? e : n - 1u];
+      const float4 cR = ix.disc[2 * size_t(id)], nh = ix.disc[2 * size_t(id) + 1];
+      const bool al = e < n && (!(gq.rho < 1e30f) || so_reach_alive(gq, geo.ngx, geo.ngy, geo.ngz, cR, nh));
       const uint64_t bal = __builtin_amdgcn_ballot_w64(al);
       if (bal == 0) continue;
-      const uint32_t any16 = uint32_t((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull);
-      const uint32_t cnt = uint32_t(__builtin_popcount(any16));
-      if (ucnt + cnt > SO_UNION_CAP) return false;
-      const uint32_t u = ucnt + uint32_t(__builtin_popcount(any16 & ((1u << sub) - 1u)));
-      // the same entry is held by one lane of every row: the lowest alive row writes the slot
-      const uint64_t below = bal & ((1ull << lane) - 1ull) & (0x0001000100010001ull << sub);
-      if (al && below == 0) {
-        wl.list[3 * u] = make_float4(cR.x, cR.y, cR.z, __uint_as_float(id));
-        wl.list[3 * u + 2] = nh;
-        wl.rad[u] = cR.w;
+      const uint32_t cnt = uint32_t(__builtin_popcountll(bal));
+      if (ms + cnt > SO_SURV_CAP) {
+        SO_WHY(5);
+        return false;
       }
-      if (al) {  // u < 64
-        const uint64_t bit = 1ull << u;
-        acc_lo |= uint32_t(bit);
-        acc_hi |= uint32_t(bit >> 32);
+      const uint32_t at = ms + uint32_t(__builtin_popcountll(bal & ((1ull << lane) - 1ull)));
+      if (al) {
+        sid[at] = id;
+        if (at < SO_DISC_CAP) {
+          dl[2 * at] = cR;
+          dl[2 * at + 1] = nh;
+        }
       }
-      ucnt += cnt;
+      ms += cnt;
     }
-    rowmask = (uint64_t(row_or_u32(acc_hi)) << 32) | uint64_t(row_or_u32(acc_lo));
   }
   __builtin_amdgcn_wave_barrier();
+  SO_LAP(2);
+  SO_MARK("gcull_end");
 
-  // ---- 4. lane cull: every lane against the slots alive for its row --------------------------------------------------
-  uint64_t lanemask = 0;
-  {
-    uint64_t todo = valid ? rowmask : 0ull;
-    while (__builtin_amdgcn_ballot_w64(todo != 0) != 0) {
-      ++ts.c[1];
-      const bool has = todo != 0;
-      const uint32_t e = has ? uint32_t(__builtin_ctzll(todo)) : 0u;
-      todo &= todo - 1ull;  // 0 stays 0
-      const float4 ea = wl.list[3 * e], es = wl.list[3 * e + 2];
-      const float lb = point_disc_lb(qx, qy, qz, make_float4(ea.x, ea.y, ea.z, wl.rad[e]), es);
-      const uint32_t id = __float_as_uint(ea.w);
-      const bool need = has && !(lb > pol.worst(0)) && id != id1 && id != id2;  // the row seeds are done
-      lanemask |= need ? (1ull << e) : 0ull;
-    }
-  }
-
-  // ---- 5. evaluation, 16 staged leaves at a time, every lane its own -------------------------------------------------
-  for (uint32_t c0 = 0; c0 < ucnt; c0 += LEAF_BATCH) {
-    uint32_t m16 = uint32_t((lanemask >> c0) & 0xFFFFull);
-    if (__builtin_amdgcn_ballot_w64(m16 != 0) == 0) continue;
-    const uint32_t cn = (ucnt - c0) < uint32_t(LEAF_BATCH) ? (ucnt - c0) : uint32_t(LEAF_BATCH);
-    so_stage(ix, wl.buf, sub < cn ? __float_as_uint(wl.list[3 * (c0 + sub)].w) : NO_INDEX);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    while (__builtin_amdgcn_ballot_w64(m16 != 0) != 0) {
-      uint32_t slot = 0, id = NO_INDEX;
-      if (m16 != 0) {
-        slot = uint32_t(__builtin_ctz(m16));
-        id = __float_as_uint(wl.list[3 * (c0 + slot)].w);
-        m16 &= m16 - 1u;
+  uint32_t id1 = NO_INDEX, id2 = NO_INDEX;  // the row's seed leaves (evaluated in the first batch)
+  uint32_t stat_union = 0;
+  // the survivors in batches of <= SO_DISC_CAP discs (one batch but for the widest stand-offs), every batch in segments
+  // of <= 64 union slots
+  for (uint32_t b0 = 0; b0 < ms; b0 += SO_DISC_CAP) {
+    const uint32_t m = (ms - b0) < SO_DISC_CAP ? (ms - b0) : SO_DISC_CAP;
+    if (b0 != 0) {  // later batches: their discs were not kept
+      for (uint32_t e0 = 0; e0 < m; e0 += WAVE) {
+        const uint32_t e = e0 + uint32_t(lane);
+        if (e < m) {
+          const uint32_t id = sid[b0 + e];
+          dl[2 * e] = ix.disc[2 * size_t(id)];
+          dl[2 * e + 1] = ix.disc[2 * size_t(id) + 1];
+        }
       }
-      ++ts.c[2];
-      pol.leaf_lane(wl.buf, slot, id, qxa, qya, qza);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      // ---- 3. row seeds (first batch): every row evaluates the two surviving leaves nearest to its centre ----------
+      uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;  // the lane's two smallest (distance | entry) keys
+      for (uint32_t e0 = 0; e0 < m; e0 += 16u) {
+        const uint32_t e = e0 + sub;
+        if (e < m) {
+          const float4 c = dl[2 * e];
+          const float dx = geo.cx - c.x, dy = geo.cy - c.y, dz = geo.cz - c.z;
+          const float d = (dx * dx + dy * dy) + dz * dz;  // >= 0: its bit pattern orders like the value
+          const uint32_t key = (__float_as_uint(d) & ~0x7Fu) | e;  // e < SO_DISC_CAP <= 128
+          m2 = min(m2, max(m1, key));
+          m1 = min(m1, key);
+        }
+      }
+      const uint32_t r1 = row_min_u32(m1);
+      const uint32_t r2 = row_min_u32(m1 == r1 ? m2 : m1);
+      if (geo.any && r1 != 0xFFFFFFFFu) id1 = sid[r1 & 0x7Fu];
+      if (geo.any && r2 != 0xFFFFFFFFu) id2 = sid[r2 & 0x7Fu];
+      // slot 2 * row + k <- the row's k-th seed leaf; the slot ids travel through the idle union-id area
+      if (sub == 0u) {
+        idu[2 * row] = id1;
+        idu[2 * row + 1] = id2;
+      }
+      __builtin_amdgcn_wave_barrier();
+      so_stage8(ix, wl.buf, idu[lane & 7]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (uint32_t k = 0; k < 2; ++k) {
+        const uint32_t id = valid ? (k == 0 ? id1 : id2) : NO_INDEX;
+        if (__builtin_amdgcn_ballot_w64(id != NO_INDEX) != 0) {
+          SO_COUNT(++ts.c[2]);
+          pol.template leaf_at<8>(reinterpret_cast<const float4*>(wl.buf) + (2 * row + k), id, qxa, qya, qza);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    SO_LAP(3);
+    SO_MARK("rowseed_end");
+
+    for (uint32_t c = 0; c < m;) {
+      // ---- 4. row cull: (row, leaf) pairs, 64 per pass; leaves alive for any row -> union slots, compacted in place
+      const RowReach rr = row_reach_of(geo, qx, qy, qz, valid, pol.worst(0));  // the radii of NOW
+      uint32_t ucnt = 0;
+      uint64_t rowmask;
+      {
+        uint32_t acc_lo = 0, acc_hi = 0;  // this lane's own alive pairs as union-slot bits
+        for (; c < m && ucnt + 16u <= SO_UNION_CAP; c += 16u) {
+          const uint32_t e = c + sub, ec = e < m ? e : m - 1u;
+          const float4 cR = dl[2 * ec], nh = dl[2 * ec + 1];
+          const uint32_t id = sid[b0 + ec];
+          const bool al = e < m && geo.any && (!(rr.rho < 1e30f) || so_reach_alive(rr, geo.ngx, geo.ngy, geo.ngz, cR, nh));
+          const uint64_t bal = __builtin_amdgcn_ballot_w64(al);
+          __builtin_amdgcn_wave_barrier();  // the pass has read its 16 entries before slots <= them are rewritten
+          if (bal == 0) continue;
+          const uint32_t any16 = uint32_t((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull);
+          const uint32_t u = ucnt + uint32_t(__builtin_popcount(any16 & ((1u << sub) - 1u)));
+          // the same entry is held by one lane of every row: the lowest alive row writes the slot (u <= e: in place)
+          const uint64_t below = bal & ((1ull << lane) - 1ull) & (0x0001000100010001ull << sub);
+          if (al && below == 0) {
+            dl[2 * u] = cR;
+            dl[2 * u + 1] = nh;
+            idu[u] = id;
+          }
+          if (al) {  // u < 64
+            const uint64_t bit = 1ull << u;
+            acc_lo |= uint32_t(bit);
+            acc_hi |= uint32_t(bit >> 32);
+          }
+          ucnt += uint32_t(__builtin_popcount(any16));
+        }
+        rowmask = (uint64_t(row_or_u32(acc_hi)) << 32) | uint64_t(row_or_u32(acc_lo));
+      }
+      __builtin_amdgcn_wave_barrier();
+      SO_LAP(5);
+      SO_MARK("rowcull_end");
+      stat_union += ucnt;
+      if (ucnt == 0) continue;
+
+      // ---- 5. lane cull: every lane against the slots alive for its row, two per step (packed math) -----------------
+      uint64_t lanemask = 0;
+      {
+        uint64_t todo = valid ? rowmask : 0ull;
+        while (__builtin_amdgcn_ballot_w64(todo != 0) != 0) {
+          SO_COUNT(++ts.c[1]);
+          const bool has0 = todo != 0;
+          const uint32_t e0 = has0 ? uint32_t(__builtin_ctzll(todo)) : 0u;
+          todo &= todo - 1ull;  // 0 stays 0
+          const bool has1 = todo != 0;
+          const uint32_t e1 = has1 ? uint32_t(__builtin_ctzll(todo)) : e0;
+          todo &= todo - 1ull;
+          const float4 a0 = dl[2 * e0], s0 = dl[2 * e0 + 1], a1 = dl[2 * e1], s1 = dl[2 * e1 + 1];
+          const v2f lb = so_disc_lb2(qx, qy, qz, a0, s0, a1, s1);
+          const uint32_t i0 = idu[e0], i1 = idu[e1];
+          const float w = pol.worst(0);
+          const bool need0 = has0 && !(lb.x > w) && i0 != id1 && i0 != id2;  // the row seeds are done
+          const bool need1 = has1 && !(lb.y > w) && i1 != id1 && i1 != id2;
+          lanemask |= (need0 ? (1ull << e0) : 0ull) | (need1 ? (1ull << e1) : 0ull);
+        }
+      }
+      SO_LAP(6);
+      SO_MARK("lanecull_end");
+
+      // ---- 6. evaluation, 16 staged leaves at a time, every lane its own ---------------------------------------------
+      for (uint32_t c0 = 0; c0 < ucnt; c0 += LEAF_BATCH) {
+        uint32_t m16 = uint32_t((lanemask >> c0) & 0xFFFFull);
+        if (__builtin_amdgcn_ballot_w64(m16 != 0) == 0) continue;
+        const uint32_t cn = (ucnt - c0) < uint32_t(LEAF_BATCH) ? (ucnt - c0) : uint32_t(LEAF_BATCH);
+        so_stage(ix, wl.buf, sub < cn ? idu[c0 + sub] : NO_INDEX);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        while (__builtin_amdgcn_ballot_w64(m16 != 0) != 0) {
+          uint32_t slot = 0, id = NO_INDEX;
+          if (m16 != 0) {
+            slot = uint32_t(__builtin_ctz(m16));
+            id = idu[c0 + slot];
+            m16 &= m16 - 1u;
+          }
+          SO_COUNT(++ts.c[2]);
+          pol.leaf_lane(wl.buf, slot, id, qxa, qya, qza);
+        }
+      }
+      SO_LAP(7);
+      SO_MARK("eval_end");
     }
   }
+  SO_WHY(7);
   ++ts.c[4];
+#if !defined(PCLHIP_SO_PROFILE) && !defined(PCLHIP_SO_REASONS)
+  ++ts.c[5];
+  ts.c[6] += n;
+  ts.c[7] += stat_union;
+#else
+  (void)stat_union;
+#endif
   return true;
 }
 

@@ -383,13 +383,24 @@ struct NN1MinT {
   static constexpr bool NEEDS_W = false;
   __device__ __forceinline__ void leaf_lane(const float* buf, uint32_t slot, uint32_t leaf_id, const float* qx,
                                             const float* qy, const float* qz) {
+    // transposed staging: chunk c of slot s at s[c * 16]
+    leaf_at<16>(reinterpret_cast<const float4*>(buf) + slot, leaf_id, qx, qy, qz);
+  }
+  // the same straight from the index's SoA copy (chunk c at s[c]): a leaf that is not staged
+  __device__ __forceinline__ void leaf_global(const float* soa, uint32_t leaf_id, const float* qx, const float* qy,
+                                              const float* qz) {
+    leaf_at<1>(reinterpret_cast<const float4*>(soa + size_t(leaf_id != NO_INDEX ? leaf_id : 0u) * (4 * LEAF)), leaf_id, qx,
+               qy, qz);
+  }
+  template <int STRIDE>
+  __device__ __forceinline__ void leaf_at(const float4* s, uint32_t leaf_id, const float* qx, const float* qy,
+                                          const float* qz) {
     if (leaf_id != NO_INDEX) {
-      const float4* s = reinterpret_cast<const float4*>(buf) + slot;  // chunk c at s[c * 16]
       const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
       float m = __builtin_inff();
 #pragma unroll
       for (int c4 = 0; c4 < LEAF / 4; ++c4) {
-        const float4 X = s[c4 * 16], Y = s[(LEAF / 4 + c4) * 16], Z = s[(2 * (LEAF / 4) + c4) * 16];
+        const float4 X = s[c4 * STRIDE], Y = s[(LEAF / 4 + c4) * STRIDE], Z = s[(2 * (LEAF / 4) + c4) * STRIDE];
         {
           const v2f dx = qx2 - v2f{X.x, X.y}, dy = qy2 - v2f{Y.x, Y.y}, dz = qz2 - v2f{Z.x, Z.y};
           v2f r = dx * dx;
@@ -724,9 +735,10 @@ struct TopKHeap {
 
 // Optional work counters (wave-uniform, live in SGPRs; flushed by the kernels when the context asked
 // for statistics).  [0] interior nodes scanned, [1] leaves that passed the group test, [2] leaves
-// that passed the per-lane test (= 16-candidate all-pairs blocks), [3] stack pushes, [4] groups.
+// that passed the per-lane test (= 16-candidate all-pairs blocks), [3] stack pushes, [4] groups; the stand-off path
+// (standoff.hpp) adds [5] groups it finished, [6] leaves it collected, [7] union slots after the row cull.
 struct TraverseStats {
-  uint32_t c[5] = {0, 0, 0, 0, 0};
+  uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // does the policy offer the lane-sparse leaf evaluation?
@@ -1223,7 +1235,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
 __device__ __forceinline__ void flush_stats(const TraverseStats& ts, unsigned long long* g) {
   if (g != nullptr && (threadIdx.x & (WAVE - 1)) == 0) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) atomicAdd(g + i, (unsigned long long)ts.c[i]);
+    for (int i = 0; i < 8; ++i) atomicAdd(g + i, (unsigned long long)ts.c[i]);
   }
 }
 

@@ -25,7 +25,7 @@ import csv, glob, collections
 for f in sorted(glob.glob("$OUT/*counter_collection.csv")):
     per = collections.defaultdict(lambda: collections.defaultdict(float)); dur = {}
     for r in csv.DictReader(open(f)):
-        if "icp_search" not in r["Kernel_Name"]: continue
+        if "search_kernel" not in r["Kernel_Name"] or "icp_" not in r["Kernel_Name"]: continue
         per[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
         dur[int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     ids = sorted(per)
