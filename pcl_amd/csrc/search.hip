@@ -808,28 +808,25 @@ __device__ __forceinline__ bool in_region(const RegionBox& r, float x, float y, 
   return x >= r.lo[0] && x < r.hi[0] && y >= r.lo[1] && y < r.hi[1] && z >= r.lo[2] && z < r.hi[2];
 }
 
-template <int MINW, int Q, bool SPARSE>
-__global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, float4* __restrict__ cur,
-                                                                 const float4* __restrict__ src0, uint32_t ns,
-                                                                 Mat34 T, const IcpControl* __restrict__ ctl,
-                                                                 RegionBox region, int order, float bound, int flags,
-                                                                 uint32_t* __restrict__ match_pos,
-                                                                 uint32_t* __restrict__ match,
-                                                                 float* __restrict__ match_d2,
-                                                                 unsigned long long* gstats) {
+// no policy of the ICP search kernels stages the w chunks: 3 KB of staging per wave (see WaveLdsT)
+typedef WaveLdsT<3072> IcpWaveLds;
+
+template <int Q, bool SPARSE>
+__device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __restrict__ cur,
+                                                const float4* __restrict__ src0, uint32_t ns, Mat34 T,
+                                                const IcpControl* __restrict__ ctl, const RegionBox& region, int order,
+                                                float bound, int flags, uint32_t* __restrict__ match_pos,
+                                                uint32_t* __restrict__ match, float* __restrict__ match_d2,
+                                                unsigned long long* gstats, IcpWaveLds* wl_s, Box* topbox_s) {
   bool restart = false;
   if (ctl != nullptr) {
     if (ctl->stop != 0) return;  // the alignment ended before this (speculatively queued) launch
     restart = ctl->restart != 0;
-    if (restart && (flags & 4) != 0) return;  // icp_cold_search_kernel, queued next to this launch, takes a first iteration
 #pragma unroll
     for (int i = 0; i < 12; ++i) T.m[i] = ctl->T_apply[i];
   }
   const float4* in = restart ? src0 : cur;  // may alias cur (written below, other groups only)
   const int use_max = flags & 1;        // a finite max correspondence distance is set
-  // no policy of this kernel stages the w chunks: 3 KB of staging per wave (see WaveLdsT)
-  __shared__ WaveLdsT<3072> wl_s[WAVES_PER_BLOCK];
-  __shared__ Box topbox_s[TOPCACHE_BOXES];
   load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
@@ -950,29 +947,23 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
 // The launch WITHOUT seeds (first iteration of an alignment), for indices that carry leaf discs: every wave owns a
 // run of consecutive -- spatially adjacent -- groups and seeds each from its predecessor's matches (standoff.hpp:
 // collect / cull / evaluate); whatever that path gives up on goes through traverse() with the bounds reached so
-// far.  Same outputs as icp_search_kernel, bit for bit.  In the device-driven loop both kernels are queued every
-// iteration and the one the control block does not call for falls through (flags bit 4 of icp_search_kernel).
-#ifndef PCLHIP_COLD_MINW
-#define PCLHIP_COLD_MINW 4
-#endif
-__global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_cold_search_kernel(IndexView ix, float4* __restrict__ cur,
-                                                                   const float4* __restrict__ src0, uint32_t ns, Mat34 T,
-                                                                   const IcpControl* __restrict__ ctl, RegionBox region,
-                                                                   int order, float bound, int flags, float so_from,
-                                                                   uint32_t* __restrict__ match_pos,
-                                                                   uint32_t* __restrict__ match,
-                                                                   float* __restrict__ match_d2, unsigned long long* gstats) {
+// far.  Same outputs as the seeded search, bit for bit.
+__device__ __forceinline__ void icp_cold_search_body(const IndexView& ix, float4* __restrict__ cur,
+                                                     const float4* __restrict__ src0, uint32_t ns, Mat34 T,
+                                                     const IcpControl* __restrict__ ctl, const RegionBox& region, int order,
+                                                     float bound, int flags, float so_from,
+                                                     uint32_t* __restrict__ match_pos, uint32_t* __restrict__ match,
+                                                     float* __restrict__ match_d2, unsigned long long* gstats,
+                                                     IcpWaveLds* wl_s, Box* topbox_s) {
   bool restart = false;
   if (ctl != nullptr) {
-    if (ctl->stop != 0 || ctl->restart == 0) return;  // not the first iteration of an alignment
-    restart = true;
+    if (ctl->stop != 0) return;
+    restart = true;  // the device-driven loop only comes here for the first iteration of an alignment
 #pragma unroll
     for (int i = 0; i < 12; ++i) T.m[i] = ctl->T_apply[i];
   }
   const float4* in = restart ? src0 : cur;
   const int use_max = flags & 1;
-  __shared__ WaveLdsT<3072> wl_s[WAVES_PER_BLOCK];
-  __shared__ Box topbox_s[TOPCACHE_BOXES];
   load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
@@ -1054,6 +1045,52 @@ __global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_cold_search_kerne
 #endif
   }
   flush_stats(ts, gstats);
+}
+
+// The kernels: the seeded search alone (host-driven iterations, fitness score), the stand-off search alone
+// (host-driven first iteration), and both behind the control block of the device-driven loop -- one launch per
+// iteration, IcpControl::restart picks the body on the device (registers and LDS are the maximum of the two bodies,
+// which is what either needs anyway).
+template <int MINW, int Q, bool SPARSE>
+__global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, float4* __restrict__ cur,
+                                                                 const float4* __restrict__ src0, uint32_t ns,
+                                                                 Mat34 T, const IcpControl* __restrict__ ctl,
+                                                                 RegionBox region, int order, float bound, int flags,
+                                                                 uint32_t* __restrict__ match_pos,
+                                                                 uint32_t* __restrict__ match,
+                                                                 float* __restrict__ match_d2,
+                                                                 unsigned long long* gstats) {
+  __shared__ IcpWaveLds wl_s[WAVES_PER_BLOCK];
+  __shared__ Box topbox_s[TOPCACHE_BOXES];
+  icp_search_body<Q, SPARSE>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
+                             topbox_s);
+}
+
+#ifndef PCLHIP_COLD_MINW
+#define PCLHIP_COLD_MINW 4
+#endif
+__global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_cold_search_kernel(
+    IndexView ix, float4* __restrict__ cur, const float4* __restrict__ src0, uint32_t ns, Mat34 T,
+    const IcpControl* __restrict__ ctl, RegionBox region, int order, float bound, int flags, float so_from,
+    uint32_t* __restrict__ match_pos, uint32_t* __restrict__ match, float* __restrict__ match_d2, unsigned long long* gstats) {
+  __shared__ IcpWaveLds wl_s[WAVES_PER_BLOCK];
+  __shared__ Box topbox_s[TOPCACHE_BOXES];
+  icp_cold_search_body(ix, cur, src0, ns, T, ctl, region, order, bound, flags, so_from, match_pos, match, match_d2, gstats,
+                       wl_s, topbox_s);
+}
+
+__global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_search_dual_kernel(
+    IndexView ix, float4* __restrict__ cur, const float4* __restrict__ src0, uint32_t ns, Mat34 T,
+    const IcpControl* __restrict__ ctl, RegionBox region, int order, float bound, int flags, float so_from,
+    uint32_t* __restrict__ match_pos, uint32_t* __restrict__ match, float* __restrict__ match_d2, unsigned long long* gstats) {
+  __shared__ IcpWaveLds wl_s[WAVES_PER_BLOCK];
+  __shared__ Box topbox_s[TOPCACHE_BOXES];
+  if (ctl->restart != 0)
+    icp_cold_search_body(ix, cur, src0, ns, T, ctl, region, order, bound, flags, so_from, match_pos, match, match_d2, gstats,
+                         wl_s, topbox_s);
+  else
+    icp_search_body<1, true>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
+                             topbox_s);
 }
 
 // Per-pair terms of the three transformation estimators, accumulated per lane in fp64 and reduced in a
@@ -1371,7 +1408,7 @@ __global__ void icp_solve_kernel(IcpControl* __restrict__ ctl, const double* __r
 }
 
 // flags of the search kernels: 1 a finite maximum distance is set, 2 seeded descents may start below the root
-// (search_skip_flag), 4 (icp_search_kernel, device-driven loop) a first iteration belongs to icp_cold_search_kernel
+// (search_skip_flag)
 static bool standoff_enabled() {  // A/B: PCLHIP_STANDOFF=0 keeps traverse() for launches without seeds
   static const bool f = [] {
     const char* e = getenv("PCLHIP_STANDOFF");
@@ -1429,28 +1466,32 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   if (icp->n > 0 && (device_loop || unfused || filters || mode == PCLHIP_ICP_SYMMETRIC || icp->region.on)) {
     auto ks = icp_search_kernel<4, 1, true>;
     const int gs = resident_blocks(ctx, ks, ngroups);
-    // launches without seeds go through the stand-off kernel when the index carries leaf discs: the host-driven loop
-    // knows which launch that is (pclhip_icp_reset cleared the seeds); the device-driven loop queues both kernels and
-    // the control block decides on the device
+    // launches without seeds go through the stand-off search when the index carries leaf discs: the host-driven loop
+    // knows which launch that is (pclhip_icp_reset cleared the seeds); in the device-driven loop the control block
+    // picks the body on the device (icp_search_dual_kernel)
     const bool standoff = standoff_enabled() && v.disc != nullptr && search_skip_flag() != 0;
     const bool cold = standoff && !device_loop && icp->seeds_cleared;
     icp->seeds_cleared = false;
     const int kflags = (use_max ? 1 : 0) | search_skip_flag();
+    // wave radii (squared) up to so_from stay with traverse(): the groups that sit on the surface
+    static const float so_factor = [] {
+      const char* e = getenv("PCLHIP_SO_FACTOR");
+      return e ? float(atof(e)) : 1.0f;
+    }();
+    const float so_from = so_factor * icp->target->leaf_diag2;
     (void)hipEventRecord(device_loop ? ev[0] : icp->ev0, s);
-    if (!cold)
-      hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl, icp->region,
-                         order, bound, kflags | ((standoff && device_loop) ? 4 : 0), icp->match_pos, icp->match,
-                         icp->match_d2, ctx->stats);
-    if (cold || (standoff && device_loop)) {
+    if (standoff && device_loop) {
+      const int gd = resident_blocks(ctx, icp_search_dual_kernel, ngroups);
+      hipLaunchKernelGGL(icp_search_dual_kernel, dim3(gd), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl,
+                         icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+    } else if (cold) {
       const int gc = resident_blocks(ctx, icp_cold_search_kernel, ngroups);
-      // wave radii (squared) up to so_from stay with traverse(): the groups that sit on the surface
-      static const float so_factor = [] {
-        const char* e = getenv("PCLHIP_SO_FACTOR");
-        return e ? float(atof(e)) : 1.0f;
-      }();
       hipLaunchKernelGGL(icp_cold_search_kernel, dim3(gc), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M,
-                         ctl, icp->region, order, bound, kflags, so_factor * icp->target->leaf_diag2, icp->match_pos,
-                         icp->match, icp->match_d2, ctx->stats);
+                         ctl, icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2,
+                         ctx->stats);
+    } else {
+      hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl, icp->region,
+                         order, bound, kflags, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
     }
     (void)hipEventRecord(device_loop ? ev[1] : icp->ev_mid, s);
     icp->mid_recorded = true;

@@ -176,22 +176,24 @@ __device__ __forceinline__ bool so_reach_alive(const RowReach& rr, float ngx, fl
   return reach >= 0.0f && gt * gt <= 2.00002f * rr.rho * reach;
 }
 
-// point_disc_lb (traverse.hpp) for TWO discs at once: the same operations component by component, on packed
-// registers (v_pk_add / v_pk_mul / v_pk_fma_f32) where the instruction set has them, with so_sqrt
-__device__ __forceinline__ v2f so_disc_lb2(float qx, float qy, float qz, const float4 c0, const float4 n0, const float4 c1,
-                                           const float4 n1) {
-  const v2f dx = v2f{qx, qx} - v2f{c0.x, c1.x}, dy = v2f{qy, qy} - v2f{c0.y, c1.y}, dz = v2f{qz, qz} - v2f{c0.z, c1.z};
+// point_disc_lb (traverse.hpp) for the TWO discs of a union pair block at once: the same operations component by
+// component on packed registers (v_pk_add / v_pk_mul / v_pk_fma_f32), with so_sqrt, and the rounding allowance of the
+// dot product taken from the largest |component| (3e-6 max >= 1e-6 sum).  A pair block is 64 bytes, the components of
+// slots 2p and 2p + 1 interleaved so that every packed operand is one register pair of a 16-byte read:
+//   P0 = (cx0 cx1 cy0 cy1)  P1 = (cz0 cz1 R0 R1)  P2 = (nx0 nx1 ny0 ny1)  P3 = (nz0 nz1 hn0 hn1)
+__device__ __forceinline__ v2f so_disc_lb2(float qx, float qy, float qz, const float4 P0, const float4 P1, const float4 P2,
+                                           const float4 P3) {
+  const v2f dx = v2f{qx, qx} - v2f{P0.x, P0.y}, dy = v2f{qy, qy} - v2f{P0.z, P0.w}, dz = v2f{qz, qz} - v2f{P1.x, P1.y};
   const v2f r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-  const v2f nx = {n0.x, n1.x}, ny = {n0.y, n1.y}, nz = {n0.z, n1.z};
-  const v2f dot = __builtin_elementwise_fma(nz, dz, __builtin_elementwise_fma(ny, dy, nx * dx));
+  const v2f dot = __builtin_elementwise_fma(v2f{P3.x, P3.y}, dz, __builtin_elementwise_fma(v2f{P2.z, P2.w}, dy, v2f{P2.x, P2.y} * dx));
   const v2f a = {fabsf(dot.x), fabsf(dot.y)};
-  const v2f e = v2f{(fabsf(dx.x) + fabsf(dy.x)) + fabsf(dz.x), (fabsf(dx.y) + fabsf(dy.y)) + fabsf(dz.y)} * 1e-6f;
+  const v2f e = v2f{fmaxf(fmaxf(fabsf(dx.x), fabsf(dy.x)), fabsf(dz.x)), fmaxf(fmaxf(fabsf(dx.y), fabsf(dy.y)), fabsf(dz.y))} * 3e-6f;
   const v2f a_hi = a + e;  // >= |n.q'|
   const v2f t = (a_hi * a_hi) * -1.000003f;
   const v2f b2 = __builtin_elementwise_fma(r2, v2f{0.999999f, 0.999999f}, t);
   const v2f sq = {so_sqrt(fmaxf(b2.x, 0.0f)), so_sqrt(fmaxf(b2.y, 0.0f))};
-  const v2f gtr = __builtin_elementwise_fma(sq, v2f{0.999998f, 0.999998f}, -v2f{c0.w, c1.w});
-  const v2f gnr = (a - e) - v2f{n0.w, n1.w};
+  const v2f gtr = __builtin_elementwise_fma(sq, v2f{0.999998f, 0.999998f}, -v2f{P1.z, P1.w});
+  const v2f gnr = (a - e) - v2f{P3.z, P3.w};
   const v2f gt = {fmaxf(gtr.x, 0.0f), fmaxf(gtr.y, 0.0f)}, gn = {fmaxf(gnr.x, 0.0f), fmaxf(gnr.y, 0.0f)};
   return __builtin_elementwise_fma(gt, gt, gn * gn) * DISC_SHRINK;
 }
@@ -377,6 +379,7 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
     uint32_t ncur = 1;
     for (;;) {
       __builtin_amdgcn_wave_barrier();
+      ncur = uniform_u32(ncur);
       const uint32_t cl = level - 1u;  // level of the children
       const Box* level_box = ix.box[1];
       uint32_t total = ix.count[1], coff = 0;
@@ -390,20 +393,21 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
       }
       const bool cached = int(cl) >= ix.cache_from;  // upper levels: boxes come from the block's LDS copy
       uint32_t nnext = 0;
-      for (uint32_t k = 0; k < ncur; k += 4u) {
-        uint32_t first[4], nchild[4];
-        Box b[4];
+      for (uint32_t k = 0; k < ncur; k += 2u) {
+        // two nodes per step: both box rows are in flight together (unconditional loads, clamped indices)
+        const bool two = k + 1u < ncur;
+        uint32_t first[2], nchild[2];
+        Box b[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {  // unconditional loads (clamped indices): all four rows are in flight together
-          const uint32_t kk = (k + uint32_t(j)) < ncur ? (k + uint32_t(j)) : (ncur - 1u);
-          first[j] = uniform_u32(fr_cur[kk]) * FANOUT;
+        for (int j = 0; j < 2; ++j) {
+          first[j] = uniform_u32(fr_cur[(j == 1 && two) ? k + 1u : k]) * FANOUT;
           nchild[j] = (total - first[j]) < uint32_t(FANOUT) ? (total - first[j]) : uint32_t(FANOUT);
           const uint32_t at = first[j] + (uint32_t(lane) < nchild[j] ? uint32_t(lane) : nchild[j] - 1u);
           b[j] = cached ? topbox[coff + at] : level_box[at];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (k + uint32_t(j) < ncur) {
+        for (int j = 0; j < 2; ++j) {
+          if (j == 0 || two) {
             SO_COUNT(++ts.c[0]);
             const bool has = uint32_t(lane) < nchild[j];
             const float lbG = box_box_lb(Qlx, Qly, Qlz, Qhx, Qhy, Qhz, b[j].lo.x, b[j].lo.y, b[j].lo.z, b[j].hi.x, b[j].hi.y,
@@ -442,6 +446,7 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
     }
   }
   __builtin_amdgcn_wave_barrier();
+  n = uniform_u32(n);
   SO_LAP(1);
   SO_MARK("collect_end");
   if (n == 0) {  // nothing within the wave radius (a finite maximum distance and no seed inside it)
@@ -491,6 +496,7 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
     }
   }
   __builtin_amdgcn_wave_barrier();
+  ms = uniform_u32(ms);
   SO_LAP(2);
   SO_MARK("gcull_end");
 
@@ -569,9 +575,16 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
           const uint32_t u = ucnt + uint32_t(__builtin_popcount(any16 & ((1u << sub) - 1u)));
           // the same entry is held by one lane of every row: the lowest alive row writes the slot (u <= e: in place)
           const uint64_t below = bal & ((1ull << lane) - 1ull) & (0x0001000100010001ull << sub);
-          if (al && below == 0) {
-            dl[2 * u] = cR;
-            dl[2 * u + 1] = nh;
+          if (al && below == 0) {  // pair block u / 2, half u & 1 (see so_disc_lb2)
+            float* const w = reinterpret_cast<float*>(lds) + 16u * (u >> 1) + (u & 1u);
+            w[0] = cR.x;
+            w[2] = cR.y;
+            w[4] = cR.z;
+            w[6] = cR.w;
+            w[8] = nh.x;
+            w[10] = nh.y;
+            w[12] = nh.z;
+            w[14] = nh.w;
             idu[u] = id;
           }
           if (al) {  // u < 64
@@ -584,32 +597,34 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
         rowmask = (uint64_t(row_or_u32(acc_hi)) << 32) | uint64_t(row_or_u32(acc_lo));
       }
       __builtin_amdgcn_wave_barrier();
+      ucnt = uniform_u32(ucnt);  // wave-uniform by construction: keep it in a scalar register
       SO_LAP(5);
       SO_MARK("rowcull_end");
       stat_union += ucnt;
       if (ucnt == 0) continue;
 
-      // ---- 5. lane cull: every lane against the slots alive for its row, two per step (packed math) -----------------
-      uint64_t lanemask = 0;
+      // ---- 5. lane cull: every lane runs the disc bound against the union slots alive for its row, a pair block per
+      // step (packed math); the walk is wave-uniform -- a row keeps most of the union alive at a stand-off, so skipping
+      // per lane would cost more mask arithmetic than the tests it saves
+      uint32_t lm_lo = 0, lm_hi = 0;  // lanemask: bit u = this lane has to evaluate union slot u
       {
-        uint64_t todo = valid ? rowmask : 0ull;
-        while (__builtin_amdgcn_ballot_w64(todo != 0) != 0) {
+        const float w = pol.worst(0);
+        const uint32_t rm_lo = valid ? uint32_t(rowmask) : 0u, rm_hi = valid ? uint32_t(rowmask >> 32) : 0u;
+        for (uint32_t b = 0; b < ucnt; b += 2u) {  // b = 2p
           SO_COUNT(++ts.c[1]);
-          const bool has0 = todo != 0;
-          const uint32_t e0 = has0 ? uint32_t(__builtin_ctzll(todo)) : 0u;
-          todo &= todo - 1ull;  // 0 stays 0
-          const bool has1 = todo != 0;
-          const uint32_t e1 = has1 ? uint32_t(__builtin_ctzll(todo)) : e0;
-          todo &= todo - 1ull;
-          const float4 a0 = dl[2 * e0], s0 = dl[2 * e0 + 1], a1 = dl[2 * e1], s1 = dl[2 * e1 + 1];
-          const v2f lb = so_disc_lb2(qx, qy, qz, a0, s0, a1, s1);
-          const uint32_t i0 = idu[e0], i1 = idu[e1];
-          const float w = pol.worst(0);
-          const bool need0 = has0 && !(lb.x > w) && i0 != id1 && i0 != id2;  // the row seeds are done
-          const bool need1 = has1 && !(lb.y > w) && i1 != id1 && i1 != id2;
-          lanemask |= (need0 ? (1ull << e0) : 0ull) | (need1 ? (1ull << e1) : 0ull);
+          const uint32_t rbits = ((b < 32u ? rm_lo : rm_hi) >> (b & 31u)) & 3u;
+          if (__builtin_amdgcn_ballot_w64(rbits != 0) == 0) continue;
+          const float4* const P = dl + 2u * b;  // 4 float4 per pair block
+          const v2f lb = so_disc_lb2(qx, qy, qz, P[0], P[1], P[2], P[3]);
+          const uint2 ii = *reinterpret_cast<const uint2*>(idu + b);
+          const bool need0 = (rbits & 1u) != 0 && !(lb.x > w) && ii.x != id1 && ii.x != id2;  // the row seeds are done
+          const bool need1 = (rbits & 2u) != 0 && !(lb.y > w) && ii.y != id1 && ii.y != id2;
+          const uint32_t nb = ((need0 ? 1u : 0u) | (need1 ? 2u : 0u)) << (b & 31u);
+          if (b < 32u) lm_lo |= nb;
+          else lm_hi |= nb;
         }
       }
+      const uint64_t lanemask = (uint64_t(lm_hi) << 32) | uint64_t(lm_lo);
       SO_LAP(6);
       SO_MARK("lanecull_end");
 
