@@ -1,83 +1,20 @@
-"""Randomised self-check (not part of the test suite): VoxelGrid (leaf sizes, pass-through filter on any field, negative limits,
-minimum points per voxel, PointXYZ / PointNormal records) and NormalEstimation with a search surface / index subset against
-the oracle.  python scratch/fuzz_filters.py [seed] [rounds]"""
+"""Randomised self-check (open-ended; tests/test_gpu_fuzz.py runs a bounded slice of the same rounds under -m gpu): VoxelGrid
+(leaf sizes, pass-through filter on any field, negative limits, minimum points per voxel, PointXYZ / PointNormal records)
+and NormalEstimation with a search surface / index subset against the oracle.  python scratch/fuzz_filters.py [seed] [rounds]"""
 import sys, numpy as np
 sys.path.insert(0, '.')
 import pcl_amd
 from oracle import pcl_oracle as orc
+from tests.fuzz_lib import filters_round
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 rng = np.random.default_rng(seed)
 ctx = pcl_amd.Context(0)
-FIELDS = {"x": 0, "y": 1, "z": 2, "normal_x": 4, "normal_y": 5, "normal_z": 6, "curvature": 8}
 bad = 0
 for it in range(rounds):
-    n = int(rng.choice([1, 50, 3000, 40000, 300000]))
-    wide = rng.random() < 0.5
-    cloud = np.zeros((n, 12 if wide else 4), np.float32)
-    kind = int(rng.integers(0, 3))
-    if kind == 0:   xyz = rng.uniform(-1, 1, (n, 3))
-    elif kind == 1: xyz = pcl_amd.synth.gaussian_surface(n, int(rng.integers(1, 1 << 30)))[:, :3]
-    else:           xyz = rng.normal(size=(n, 3)) * np.array([5.0, 0.2, 1.0])
-    cloud[:, :3] = (xyz * float(10 ** rng.uniform(-1, 1)) + rng.uniform(-3, 3, 3)).astype(np.float32)
-    cloud[:, 3] = 1
-    if wide:
-        cloud[:, 4:7] = rng.normal(size=(n, 3)).astype(np.float32)
-        cloud[:, 8] = rng.uniform(0, 1, n).astype(np.float32)
-    if n > 20 and rng.random() < 0.3:
-        cloud[rng.integers(0, n, 3), rng.integers(0, 3)] = np.nan
-    ext = float(np.nanmax(cloud[:, :3]) - np.nanmin(cloud[:, :3])) + 1e-6
-    leaf = (ext * 10 ** rng.uniform(-2.2, -0.3, 3)).astype(np.float32)
-    vg = pcl_amd.VoxelGrid(ctx)
-    vg.setInputCloud(cloud)
-    vg.setLeafSize(*[float(v) for v in leaf])
-    minpts = int(rng.choice([0, 0, 1, 2, 5]))
-    vg.setMinimumPointsNumberPerVoxel(minpts)
-    kw = {}
-    if rng.random() < 0.6:
-        name = str(rng.choice([f for f, c in FIELDS.items() if c < cloud.shape[1]]))
-        col = FIELDS[name]
-        lo, hi = sorted(np.nanquantile(cloud[:, col], rng.uniform(0, 1, 2)).tolist())
-        neg = bool(rng.random() < 0.4)
-        vg.setFilterFieldName(name); vg.setFilterLimits(lo, hi); vg.setFilterLimitsNegative(neg)
-        kw = dict(limits=(lo, hi), field=col, negative=neg)
-    vg.setDownsampleAllData(bool(rng.random() < 0.5))
-    try:
-        out = vg.filter()
-        want, _ = orc.voxelgrid(cloud, leaf, min_points_per_voxel=minpts, **kw)
-        if want is None:
-            ok = False; why = "oracle refused, device did not"
-        else:
-            ok = np.array_equal(out[:, :4], want, equal_nan=True); why = "%d voxels" % len(want)
-    except pcl_amd.PclHipError as e:
-        want, _ = orc.voxelgrid(cloud, leaf, min_points_per_voxel=minpts, **kw)
-        ok = want is None; why = "both refuse (overflow)" if ok else "device refused: %s" % e
-    msg = "it %2d n=%6d wide=%d %s  voxelgrid %s (%s)" % (it, n, wide, kw, "ok" if ok else "MISMATCH", why)
-    # normals at other points / an index subset, k-NN mode
-    k = int(rng.choice([3, 8, 10, 20, 33]))
-    if n >= 50:
-        nq = int(rng.choice([1, 64, 700, 20000]))
-        q = cloud[rng.integers(0, n, nq), :4].copy()
-        q[:, :3] += (rng.normal(size=(nq, 3)) * ext * 1e-3).astype(np.float32)
-        ind = rng.integers(0, nq, max(1, nq // 3)).astype(np.int32) if rng.random() < 0.5 else None
-        ne = pcl_amd.NormalEstimation(ctx)
-        ne.setInputCloud(q); ne.setSearchSurface(cloud[:, :4].copy()); ne.setKSearch(k); ne.setViewPoint(0.5, -1.0, 20.0)
-        ne.setIndices(ind)
-        got = ne.compute()
-        surf = ne.getSearchSurface()
-        want, nan = orc.KdTree(surf).normals_at(surf, q, k, viewpoint=(0.5, -1.0, 20.0), indices=ind)
-        good = ~np.isnan(want[:, 0])
-        okn = np.array_equal(np.isnan(got[:, 0]), ~good) and ne.nan_count == nan
-        if okn and good.any():
-            # ill-conditioned plane fits (near-degenerate neighbourhoods) amplify the libm differences: compare where the
-            # oracle's own curvature says the plane is defined
-            sel = good & (want[:, 3] < 0.2)
-            dots = np.sum(got[sel, :3] * want[sel, :3], axis=1)
-            okn = (not sel.any()) or (np.abs(dots).min() > 1 - 1e-3 and np.median(np.abs(got[sel, 3] - want[sel, 3])) < 1e-5)
-        msg += "  normals_at k=%d nq=%d idx=%s %s" % (k, nq, ind is not None, "ok" if okn else "MISMATCH")
-        ok = ok and okn
+    ok, msg = filters_round(ctx, orc, rng)
     bad += 0 if ok else 1
-    print(msg, flush=True)
+    print("it %2d %s" % (it, msg), flush=True)
 print("FUZZ filters seed %d: %d / %d rounds with a mismatch" % (seed, bad, rounds))
 sys.exit(1 if bad else 0)

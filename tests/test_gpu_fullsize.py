@@ -90,9 +90,16 @@ def test_config2_correspondences_and_svd_bit_exact_at_2e20(gpu, orc):
     # umeyama's moments is what separates the two, not the search
     ref_f = orc.icp_align(otree, tgt, src, mode=0, acc_double=0, **ICP_KW)
     gap = frob(ref_f["T"], ref["T"])
+    to_float_order = frob(icp.getFinalTransformation(), ref_f["T"])
     print("config 2: |T_gpu - T_oracle(double sums)|_F = %.3g ; float-sum vs double-sum oracle gap = %.3g ; "
-          "iterations %d" % (frob(icp.getFinalTransformation(), ref["T"]), gap, ref["iterations"]))
-    assert gap < 5e-3
+          "|T_gpu - T_oracle(reference-order float sums)|_F = %.3g = %.0f %% of the 1e-5 contract ; iterations %d" %
+          (frob(icp.getFinalTransformation(), ref["T"]), gap, to_float_order, 100.0 * to_float_order / 1e-5,
+           ref["iterations"]))
+    # the contract itself (north_star: 1e-5 Frobenius of the CPU path), against the oracle variant that sums in the
+    # reference's own float order -- not only against the double-sum variant the device arithmetic coincides with
+    assert ref_f["iterations"] == ref["iterations"]
+    assert to_float_order < 1e-5
+    assert gap < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------

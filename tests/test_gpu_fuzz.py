@@ -1,0 +1,164 @@
+"""Adversarial evidence where the driver runs it (`-m gpu`): bounded slices of the randomised device-vs-oracle rounds
+(tests/fuzz_lib.py; scratch/fuzz_*.py run the same rounds open-ended) and the degenerate inputs the inexact bounds of
+the search carry allowances for -- the leaf discs (traverse.hpp: point_disc_lb, row_reach_alive) and the stand-off path
+(standoff.hpp) that uses them for launches without seeds.
+
+Bar: bit-exact (indices and squared distances) against the oracle's exact search.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fuzz_lib import filters_round, knn_icp_round  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import pcl_amd
+    return pcl_amd.Context(0)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pcl_oracle
+    return pcl_oracle
+
+
+def xyz1(a):
+    out = np.ones((len(a), 4), np.float32)
+    out[:, :3] = np.asarray(a, np.float64)[:, :3].astype(np.float32)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# bounded fuzz slices (fixed seeds; clouds of at most 70k points so that a slice stays within seconds)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [11, 12])
+def test_fuzz_knn_and_icp_correspondences_slice(gpu, orc, seed):
+    rng = np.random.default_rng(seed)
+    log = []
+    for it in range(6):
+        ok, msg = knn_icp_round(gpu, orc, rng, sizes=(1, 2, 15, 16, 17, 63, 64, 65, 1000, 4096, 4097, 20000, 70000))
+        log.append(msg)
+        assert ok, "\n".join(log)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_fuzz_voxelgrid_and_surface_normals_slice(gpu, orc, seed):
+    rng = np.random.default_rng(seed)
+    log = []
+    for it in range(5):
+        ok, msg = filters_round(gpu, orc, rng, sizes=(1, 50, 3000, 40000))
+        log.append(msg)
+        assert ok, "\n".join(log)
+
+
+# ------------------------------------------------------------------------------------------------
+# degenerate inputs of the unseeded (stand-off) search
+# ------------------------------------------------------------------------------------------------
+def cold_correspondences(gpu, tgt, src, max_dist=None):
+    import pcl_amd
+    icp = pcl_amd.IterativeClosestPoint(gpu)
+    icp.setInputTarget(tgt)
+    icp.setInputSource(src)
+    icp.reset()
+    icp.iterate(np.eye(4, dtype=np.float32), max_dist=max_dist)
+    return icp.fetchCorrespondences()
+
+
+def check_cold(gpu, orc, tgt, src, what, max_dist=None):
+    q, m, d = cold_correspondences(gpu, tgt, src, max_dist)
+    big = np.sqrt(np.finfo(np.float64).max)
+    oq, om, od = orc.KdTree(tgt).correspondences(src, max_dist=max_dist if max_dist is not None else big)
+    assert np.array_equal(q, oq), what
+    bad = np.nonzero(m != om)[0]
+    assert len(bad) == 0, (what, len(bad), q[bad[:5]], m[bad[:5]], om[bad[:5]], d[bad[:5]], od[bad[:5]])
+    assert np.array_equal(d.view(np.uint32), od.view(np.uint32)), what
+
+
+def sheet(n, seed, z=0.0):
+    rng = np.random.default_rng(seed)
+    p = np.c_[rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), np.full(n, z)]
+    return p
+
+
+def test_cold_search_collinear_leaves(gpu, orc):
+    # every leaf of 16 consecutive kd-ordered points lies on a line: discs of zero radius across the line, directions of
+    # least variance that are not unique
+    rng = np.random.default_rng(5)
+    lines = []
+    for i in range(600):
+        a = rng.uniform(-1, 1, 3) * np.array([1, 1, 0.05])
+        u = rng.normal(size=3)
+        u /= np.linalg.norm(u)
+        lines.append(a + np.outer(np.linspace(0, 0.02, 32), u))
+    tgt = xyz1(np.concatenate(lines))
+    src = xyz1(sheet(20000, 6, z=0.4) + np.array([0.01, -0.02, 0.0]))
+    check_cold(gpu, orc, tgt, src, "collinear leaves")
+    # and exactly collinear in float: points on the x axis only
+    tgt2 = xyz1(np.c_[np.linspace(-1, 1, 5000), np.zeros(5000), np.zeros(5000)])
+    check_cold(gpu, orc, tgt2, src, "one exact line")
+
+
+def test_cold_search_duplicate_only_leaves(gpu, orc):
+    # leaves whose 16 points coincide (degenerate discs: zero radius, zero thickness), with ties between the copies
+    rng = np.random.default_rng(7)
+    sites = sheet(400, 8) + np.c_[np.zeros(400), np.zeros(400), 0.05 * rng.normal(size=400)]
+    tgt = xyz1(np.repeat(sites, 48, axis=0))
+    src = xyz1(sheet(15000, 9, z=0.6))
+    check_cold(gpu, orc, tgt, src, "duplicate-only leaves")
+    # a single site repeated: every query ties between all copies, the lowest index has to win
+    tgt1 = xyz1(np.repeat(np.array([[0.25, -0.5, 0.125]]), 300, axis=0))
+    check_cold(gpu, orc, tgt1, src, "one site, 300 copies")
+
+
+def test_cold_search_far_from_the_origin(gpu, orc):
+    # coordinates of 1e6 with a unit-sized scene: float spacing 0.0625, so the clouds collapse onto a lattice full of
+    # duplicates and exact distance ties, and every rounding allowance of the disc bounds is at its largest
+    import pcl_amd
+    off = np.array([1.0e6, -1.0e6, 1.0e6])
+    tgt = xyz1(pcl_amd.synth.gaussian_surface(60000, 31)[:, :3].astype(np.float64) + off)
+    src = xyz1(pcl_amd.synth.gaussian_surface(20000, 32)[:, :3].astype(np.float64) + off + np.array([0.0, 0.0, 0.5]))
+    check_cold(gpu, orc, tgt, src, "offset 1e6")
+    # millimetre leaves at a kilometre: 1e3 offset, 1e-3 point spacing
+    off2 = np.array([1.0e3, 2.0e3, -1.0e3])
+    tgt2 = xyz1(pcl_amd.synth.gaussian_surface(60000, 33)[:, :3].astype(np.float64) * 0.05 + off2)
+    src2 = xyz1(pcl_amd.synth.gaussian_surface(20000, 34)[:, :3].astype(np.float64) * 0.05 + off2 + np.array([0, 0, 0.004]))
+    check_cold(gpu, orc, tgt2, src2, "offset 1e3, scene 0.1")
+
+
+def test_cold_search_tiny_targets(gpu, orc):
+    src = xyz1(sheet(5000, 41, z=0.3))
+    for n in (1, 2, 3, 17):
+        tgt = xyz1(sheet(n, 42 + n))
+        check_cold(gpu, orc, tgt, src, "%d-point target" % n)
+        check_cold(gpu, orc, tgt, src, "%d-point target, bounded" % n, max_dist=0.5)
+
+
+def test_cold_search_standoff_ten_scene_sizes(gpu, orc):
+    import pcl_amd
+    tgt = xyz1(pcl_amd.synth.gaussian_surface(80000, 51)[:, :3])
+    src = xyz1(pcl_amd.synth.gaussian_surface(20000, 52)[:, :3].astype(np.float64) + np.array([3.0, -2.0, 20.0]))
+    check_cold(gpu, orc, tgt, src, "stand-off 10 scene sizes")
+    # ... and a volume instead of a sheet: discs as thick as they are wide
+    rng = np.random.default_rng(53)
+    blob = xyz1(rng.normal(size=(60000, 3)) * 0.1)
+    check_cold(gpu, orc, blob, src, "volumetric target from afar")
+    check_cold(gpu, orc, blob, xyz1(rng.normal(size=(20000, 3)) * 0.3), "volumetric target, queries inside")
+
+
+def test_cold_search_lattice_with_exact_ties(gpu, orc):
+    # a regular lattice target and queries above the cell centres: four equidistant neighbours each, lowest index wins
+    g = np.arange(-40, 40, dtype=np.float64) * 0.025
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    tgt = xyz1(np.c_[X.ravel(), Y.ravel(), np.zeros(X.size)])
+    c = (np.arange(-39, 39, dtype=np.float64) + 0.5) * 0.025
+    CX, CY = np.meshgrid(c, c, indexing="ij")
+    src = xyz1(np.c_[CX.ravel(), CY.ravel(), np.full(CX.size, 0.25)])
+    check_cold(gpu, orc, tgt, src, "lattice, queries above the cell centres")
+    check_cold(gpu, orc, tgt, src, "lattice, bounded", max_dist=0.2505)
