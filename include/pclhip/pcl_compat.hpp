@@ -36,6 +36,7 @@
 #include <memory>
 #include <string>
 #include <typeinfo>
+#include <type_traits>
 #include <vector>
 
 #include "../pclhip.h"
@@ -62,7 +63,15 @@ struct alignas(16) PointNormal {
   float curvature = 0, pad1[3] = {0, 0, 0};
 };
 static_assert(sizeof(PointXYZ) == 16 && sizeof(Normal) == 32 && sizeof(PointNormal) == 48, "PCL record sizes");
-template <typename PointT> constexpr bool has_normal_fields() { return sizeof(PointT) >= 48; }
+// This header has exactly two point types, PointXYZ (16 bytes) and PointNormal (48 bytes: normal at +16, curvature at
+// +32); their size tells them apart.  (The binding to real PCL classifies a type by its field list instead:
+// pcl_plugin.hpp, record_layout.)
+template <typename PointT> constexpr bool has_normal_fields() {
+  static_assert(std::is_same<PointT, PointXYZ>::value || std::is_same<PointT, PointNormal>::value ||
+                    std::is_same<PointT, Normal>::value,
+                "pcl_compat.hpp: PointXYZ / PointNormal / Normal records only");
+  return sizeof(PointT) >= 48;
+}
 
 template <typename PointT>
 struct PointCloud {

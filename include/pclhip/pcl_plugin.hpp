@@ -67,7 +67,46 @@ class Device {
   pclhip_ctx* ctx_ = nullptr;
 };
 
-template <typename PointT> constexpr bool has_normal_fields() { return sizeof(PointT) >= 48; }  // PointNormal layout
+// What the device kernels know of a record: (x, y, z) floats at +0, and of PointNormal's extras the normal at +16 and
+// the curvature at +32.  A point type is classified by its field list (common/include/pcl/common/io.h:78-96), not by
+// its size: PointXYZI / PointXYZRGB carry fields the device path would drop, and the 48-byte PointXYZRGBNormal /
+// PointXYZINormal / PointSurfel keep their curvature at +36 / +44 with rgb or intensity at +32.
+struct RecordLayout {
+  bool xyz_at_0 = false;         // x, y, z FLOAT32 at +0, +4, +8
+  bool normal_at_16 = false;     // normal_x, normal_y, normal_z FLOAT32 at +16, +20, +24
+  bool curvature_at_32 = false;  // curvature FLOAT32 at +32
+  bool other_fields = false;     // anything else (or one of the above somewhere else)
+};
+template <typename PointT>
+inline const RecordLayout& record_layout() {
+  static const RecordLayout layout = [] {
+    RecordLayout L;
+    std::vector<pcl::PCLPointField> fields;
+    (void)pcl::getFieldIndex<PointT>("x", fields);
+    unsigned xyz = 0, nrm = 0;
+    for (const pcl::PCLPointField& f : fields) {
+      const bool f32 = f.datatype == pcl::PCLPointField::FLOAT32 && f.count <= 1;
+      const auto at = [&](const char* name, std::uint32_t offset) { return f.name == name && f.offset == offset && f32; };
+      if (at("x", 0)) xyz |= 1u;
+      else if (at("y", 4)) xyz |= 2u;
+      else if (at("z", 8)) xyz |= 4u;
+      else if (at("normal_x", 16)) nrm |= 1u;
+      else if (at("normal_y", 20)) nrm |= 2u;
+      else if (at("normal_z", 24)) nrm |= 4u;
+      else if (at("curvature", 32)) L.curvature_at_32 = true;
+      else L.other_fields = true;
+    }
+    L.xyz_at_0 = xyz == 7u;
+    L.normal_at_16 = nrm == 7u && sizeof(PointT) >= 32;
+    if (nrm != 0 && nrm != 7u) L.other_fields = true;
+    L.curvature_at_32 = L.curvature_at_32 && sizeof(PointT) >= 36;
+    return L;
+  }();
+  return layout;
+}
+// large enough for the normal (a necessary condition, for static_asserts); has_normal_fields() is the real test
+template <typename PointT> constexpr bool record_fits_normals() { return sizeof(PointT) >= 32; }
+template <typename PointT> inline bool has_normal_fields() { return record_layout<PointT>().normal_at_16; }
 
 // ---- search backend ---------------------------------------------------------------------------------
 template <typename PointT>
@@ -88,6 +127,7 @@ class KdTreeHIP : public pcl::search::KdTree<PointT> {
   // search/include/pcl/search/impl/kdtree.hpp:87-97: always rebuilds, like the reference
   bool setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) override {
     if (index_) { pclhip_index_destroy(index_); index_ = nullptr; }
+    ++generation_;  // users that cache device state per index compare this, not the handle (a new index may reuse the address)
     this->input_ = cloud;
     this->indices_ = indices;
     if (!dev_ || !dev_->ok() || !cloud) return false;
@@ -197,11 +237,13 @@ class KdTreeHIP : public pcl::search::KdTree<PointT> {
     return int(total);
   }
   pclhip_index* handle() const { return index_; }
+  std::uint64_t generation() const { return generation_; }  // bumped by every setInputCloud
   const Device::Ptr& device() const { return dev_; }
 
  private:
   Device::Ptr dev_;
   pclhip_index* index_ = nullptr;
+  std::uint64_t generation_ = 0;
   PointRepresentationConstPtr rep_;
   float scale_[3] = {1, 1, 1};
   bool scaled_ = false, unsupported_ = false;
@@ -238,12 +280,14 @@ class CorrespondenceEstimationHIP : public pcl::registration::CorrespondenceEsti
     if (!this->initCompute()) return;  // PCL's own bookkeeping: (re)builds the target tree when it changed
     auto* tree = dynamic_cast<KdTreeHIP<PointTarget>*>(this->tree_.get());
     if (tree == nullptr || tree->handle() == nullptr) { this->deinitCompute(); return; }  // needs the HIP search backend
-    if (icp_ && icp_target_ != tree->handle()) { pclhip_icp_destroy(icp_); icp_ = nullptr; }
+    if (icp_ && (icp_target_ != tree->handle() || icp_generation_ != tree->generation())) { pclhip_icp_destroy(icp_); icp_ = nullptr; }
     if (!icp_) {
       if (pclhip_icp_create(tree->handle(), &icp_) != PCLHIP_OK) { this->deinitCompute(); return; }
       icp_target_ = tree->handle();
+      icp_generation_ = tree->generation();
     }
-    const bool subset = this->indices_ && this->indices_->size() != this->input_->size();
+    // a user-set index list (any size, any order, duplicates allowed) -- not the one PCLBase::initCompute fills in
+    const bool subset = this->indices_ && !this->fake_indices_;
     static const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     double sums[PCLHIP_ICP_NSUMS];
     // the squared distances of ALL pairs up to max_distance are wanted: pass the distance itself
@@ -257,14 +301,27 @@ class CorrespondenceEstimationHIP : public pcl::registration::CorrespondenceEsti
       std::vector<float> d(n);
       std::uint64_t cnt = 0;
       if (pclhip_icp_fetch_correspondences(icp_, q.data(), m.data(), d.data(), &cnt) == PCLHIP_OK) {
-        out.reserve(size_t(cnt));
-        for (std::uint64_t i = 0; i < cnt; ++i) out.emplace_back(q[size_t(i)], m[size_t(i)], d[size_t(i)]);
+        if (!subset) {  // ascending by index_query: the order of the reference's loop over all points
+          out.reserve(size_t(cnt));
+          for (std::uint64_t i = 0; i < cnt; ++i) out.emplace_back(q[size_t(i)], m[size_t(i)], d[size_t(i)]);
+        } else {
+          // the reference emits one correspondence per ENTRY of indices_, in that order (impl/correspondence_estimation.hpp
+          // :160-216): the device returns every distinct query once, ascending -- map back through the list
+          std::vector<std::int64_t> at(n, -1);
+          for (std::uint64_t i = 0; i < cnt; ++i) at[size_t(q[size_t(i)])] = std::int64_t(i);
+          out.reserve(this->indices_->size());
+          for (const pcl::index_t idx : *this->indices_) {
+            const std::int64_t i = (idx >= 0 && size_t(idx) < n) ? at[size_t(idx)] : -1;
+            if (i >= 0) out.emplace_back(idx, m[size_t(i)], d[size_t(i)]);
+          }
+        }
       }
     }
     this->deinitCompute();
   }
   pclhip_icp* icp_ = nullptr;
   pclhip_index* icp_target_ = nullptr;
+  std::uint64_t icp_generation_ = 0;
 };
 
 // ---- the whole loop on the device ------------------------------------------------------------------------
@@ -347,7 +404,9 @@ class RegistrationHIP : public Base {
     const auto* ce = this->correspondence_estimation_.get();
     const bool own_ce = ce == nullptr || dynamic_cast<const CorrespondenceEstimationHIP<PointSource, PointTarget, float>*>(ce) ||
                         dynamic_cast<const CorrespondenceEstimation<PointSource, PointTarget, float>*>(ce);
-    if (tree == nullptr || tree->handle() == nullptr) deferred_ = "the target search method is not a KdTreeHIP";
+    if (!record_layout<PointSource>().xyz_at_0 || !record_layout<PointTarget>().xyz_at_0)
+      deferred_ = "a point type without (x, y, z) floats at offset 0";
+    else if (tree == nullptr || tree->handle() == nullptr) deferred_ = "the target search method is not a KdTreeHIP";
     else if (!tree->representationSupported()) deferred_ = "the point representation is not a rescaled (x, y, z)";
     else if (kind == FOREIGN) deferred_ = "foreign TransformationEstimation";
     else if (!own_ce) deferred_ = "foreign CorrespondenceEstimation";
@@ -358,10 +417,13 @@ class RegistrationHIP : public Base {
       Base::computeTransformation(output, guess);
       return;
     }
-    if (icp_ && icp_target_ != tree->handle()) { pclhip_icp_destroy(icp_); icp_ = nullptr; }
+    // device state is cached per BUILD of the target index (KdTreeHIP::generation), not per handle address: a rebuilt
+    // index may land on the freed address, and it has neither the normals nor this registration attached
+    if (icp_ && (icp_target_ != tree->handle() || icp_generation_ != tree->generation())) { pclhip_icp_destroy(icp_); icp_ = nullptr; }
     if (!icp_) {
       if (pclhip_icp_create(tree->handle(), &icp_) != PCLHIP_OK) return;
       icp_target_ = tree->handle();
+      icp_generation_ = tree->generation();
       source_uploaded_ = nullptr;
       target_normals_of_ = nullptr;
     }
@@ -370,8 +432,9 @@ class RegistrationHIP : public Base {
       if (pclhip_index_set_normals(tree->handle(), base + 16, sizeof(PointTarget)) != PCLHIP_OK) return;
       target_normals_of_ = this->target_.get();
     }
-    const bool subset = this->indices_ && this->indices_->size() != this->input_->size();
-    if (source_uploaded_ != this->input_.get() || this->source_cloud_updated_ || subset != source_subset_) {
+    // a user-set index list: PCLBase::setIndices does not flag the source as updated, so a subset is uploaded every time
+    const bool subset = this->indices_ && !this->fake_indices_;
+    if (source_uploaded_ != this->input_.get() || this->source_cloud_updated_ || subset || source_subset_) {
       if (pclhip_icp_set_source_indexed(icp_, this->input_->points.data(), sizeof(PointSource), this->input_->size(),
                                         subset ? this->indices_->data() : nullptr, subset ? this->indices_->size() : 0) != PCLHIP_OK)
         return;
@@ -418,6 +481,7 @@ class RegistrationHIP : public Base {
  private:
   pclhip_icp* icp_ = nullptr;
   pclhip_index* icp_target_ = nullptr;
+  std::uint64_t icp_generation_ = 0;
   const void* source_uploaded_ = nullptr;
   const void* target_normals_of_ = nullptr;
   bool source_subset_ = false;
@@ -513,15 +577,30 @@ class VoxelGridHIP : public pcl::VoxelGrid<PointT> {
   using PointCloud = typename pcl::Filter<PointT>::PointCloud;
   explicit VoxelGridHIP(Device::Ptr dev = Device::instance()) : dev_(std::move(dev)) { this->filter_name_ = "VoxelGridHIP"; }
   const std::string& deferredReason() const { return deferred_; }
+  // Why the next filter() call would run pcl::VoxelGrid's own applyFilter instead of the device path ("" = it would
+  // not).  With setDownsampleAllData(true) the reference averages EVERY field of the point type
+  // (impl/voxel_grid.hpp:760-800, CentroidPoint); the device path averages the coordinates and PointNormal's normal and
+  // curvature, so any other field list goes back to the reference.  Coordinates only: any type with xyz at +0.
+  std::string whyDeferred() const {
+    const RecordLayout& rec = record_layout<PointT>();
+    if (!dev_ || !dev_->ok()) return "no device";
+    if (this->indices_ && !this->fake_indices_) return "an index subset of the input";  // the device path filters whole clouds
+    if (!rec.xyz_at_0) return "a point type without (x, y, z) floats at offset 0";
+    if (this->downsample_all_data_ && (rec.other_fields || rec.normal_at_16 != rec.curvature_at_32))
+      return "setDownsampleAllData(true) on a point type with fields beyond PointXYZ's or PointNormal's";
+    return "";
+  }
  protected:
   void applyFilter(PointCloud& output) override {  // impl/voxel_grid.hpp:597-814
     deferred_.clear();
-    if (!dev_ || !dev_->ok()) deferred_ = "no device";
-    else if (!this->fake_indices_) deferred_ = "an index subset of the input";  // the device path filters whole clouds
+    deferred_ = whyDeferred();
     if (!deferred_.empty()) {
       Base::applyFilter(output);
       return;
     }
+    // the extras the device averages along with the coordinates: PointNormal's, and only those
+    const RecordLayout& rec = record_layout<PointT>();
+    const std::size_t extras_at = (this->downsample_all_data_ && rec.normal_at_16 && rec.curvature_at_32) ? 16 : 0;
     output.height = 1;
     output.is_dense = true;
     int limits = 0;
@@ -549,7 +628,7 @@ class VoxelGridHIP : public pcl::VoxelGrid<PointT> {
     const pclhip_status st = pclhip_voxelgrid_ex2(dev_->get(), in.points.data(), sizeof(PointT), in.size(), leaf,
                                                   this->min_points_per_voxel_, limits, this->filter_limit_min_,
                                                   this->filter_limit_max_, this->downsample_all_data_ ? 1 : 0,
-                                                  has_normal_fields<PointT>() ? 16 : 0, out.data(), sizeof(PointT), &n,
+                                                  extras_at, out.data(), sizeof(PointT), &n,
                                                   layout.empty() ? nullptr : layout.data(), layout.size(), &d);
     if (st == PCLHIP_ERR_OVERFLOW) {  // :620-629: "Leaf size is too small ... Integer indices would overflow"
       output = in;
@@ -619,9 +698,12 @@ class TransformationEstimationHIP : public pcl::registration::TransformationEsti
  private:
   void run(const PointSource* s, const PointTarget* t, std::size_t n, Matrix4& T) const {
     if (!dev_ || !dev_->ok() || n == 0) return;
-    static_assert(MODE == PCLHIP_ICP_POINT_TO_POINT || (has_normal_fields<PointTarget>() &&
-                  (MODE != PCLHIP_ICP_SYMMETRIC || has_normal_fields<PointSource>())),
+    static_assert(MODE == PCLHIP_ICP_POINT_TO_POINT || (record_fits_normals<PointTarget>() &&
+                  (MODE != PCLHIP_ICP_SYMMETRIC || record_fits_normals<PointSource>())),
                   "point-to-plane estimators need normals in the target (and, symmetric, in the source) point type");
+    if (!record_layout<PointSource>().xyz_at_0 || !record_layout<PointTarget>().xyz_at_0) return;
+    if (MODE != PCLHIP_ICP_POINT_TO_POINT && !has_normal_fields<PointTarget>()) return;  // normals elsewhere in the record
+    if (MODE == PCLHIP_ICP_SYMMETRIC && !has_normal_fields<PointSource>()) return;
     const char* sb = reinterpret_cast<const char*>(s);
     const char* tb = reinterpret_cast<const char*>(t);
     float m[16];

@@ -1613,10 +1613,11 @@ pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double ma
   const uint32_t ngroups = (n + WAVE - 1) / WAVE;
   const int gs = resident_blocks(ctx, icp_search_kernel<4, 1, true>, ngroups);
   // transformPointCloud(cloud, out, Matrix4) is Transformer::se3 (transforms.hpp:109-123): order 1
-  RegionBox all;
-  all.on = 0;
+  // target sharding: this rank scores the source points whose position under T lies in its region (every point has
+  // exactly one owner), against its slab + halo index; the (sum, count) pairs are summed over the ranks below
   hipLaunchKernelGGL((icp_search_kernel<4, 1, true>), dim3(gs), dim3(BLOCK), 0, s, v, cur, static_cast<const float4*>(cur), n,
-                     M, static_cast<const IcpControl*>(nullptr), all, 1, __builtin_inff(), 0, pos, id, d2, ctx->stats);
+                     M, static_cast<const IcpControl*>(nullptr), icp->region, 1, __builtin_inff(), 0, pos, id, d2,
+                     ctx->stats);
   hipLaunchKernelGGL(fitness_partial_kernel, dim3(gr), dim3(BLOCK), 0, s, d2, n, max_range, part);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   std::vector<double> h(size_t(gr) * 2);
@@ -1626,6 +1627,18 @@ pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double ma
   for (int b = 0; b < gr; ++b) {
     sum += h[size_t(b) * 2];
     cnt += h[size_t(b) * 2 + 1];
+  }
+  if (icp_is_sharded(icp)) {  // source slabs or target regions: one score for the whole registration
+    std::memset(icp->sums_host, 0, NS * sizeof(double));
+    icp->sums_host[0] = sum;
+    icp->sums_host[1] = cnt;
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(icp->sums_dev, icp->sums_host, NS * sizeof(double), hipMemcpyHostToDevice, s));
+    const pclhip_status ar = allreduce_record(icp);
+    if (ar != PCLHIP_OK) return ar;
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(icp->sums_host, icp->sums_dev, NS * sizeof(double), hipMemcpyDeviceToHost, s));
+    PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+    sum = icp->sums_host[0];
+    cnt = icp->sums_host[1];
   }
   *nr = uint64_t(cnt);
   if (cnt > 0.0) *score = sum / cnt;

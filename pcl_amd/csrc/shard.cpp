@@ -66,6 +66,17 @@ void bisect(const HostCloud& c, std::vector<uint32_t>& ids, size_t begin, size_t
     *out = r;
     return;
   }
+  if (end == begin) {
+    // no points to cut (fewer finite points than slabs, or every point of the parent tied at its cut): no cut is
+    // invented -- the first part keeps the whole cell, the others get an empty one ([hi, hi) on x owns no point), so
+    // the regions still tile space with exactly one owner per point
+    out[0] = r;
+    for (int p = 1; p < parts; ++p) {
+      out[p] = r;
+      out[p].lo[0] = r.hi[0];
+    }
+    return;
+  }
   // widest axis of the points themselves (the region may be unbounded)
   float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
   float mx[3] = {-mn[0], -mn[0], -mn[0]};
@@ -84,8 +95,8 @@ void bisect(const HostCloud& c, std::vector<uint32_t>& ids, size_t begin, size_t
   const int left_parts = parts / 2, right_parts = parts - left_parts;
   const size_t count = end - begin;
   size_t k = begin + count * size_t(left_parts) / size_t(parts);  // order statistic at the cut
-  float cut = 0.5f * (std::isfinite(r.lo[axis]) ? r.lo[axis] : 0.0f) + 0.5f * (std::isfinite(r.hi[axis]) ? r.hi[axis] : 0.0f);
-  if (count > 0) {
+  float cut = 0.0f;
+  {
     if (k >= end) k = end - 1;
     // (coordinate, index) order: the cut value is the same whatever order the ids arrive in
     auto less = [&](uint32_t a, uint32_t b) {

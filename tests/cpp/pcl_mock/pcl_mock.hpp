@@ -88,6 +88,20 @@ struct alignas(16) PointNormal {
   PointNormal() : data{0, 0, 0, 1.0f}, data_n{0, 0, 0, 0}, data_c{0, 0, 0, 0} {}
 };
 static_assert(sizeof(PointXYZ) == 16 && sizeof(Normal) == 32 && sizeof(PointNormal) == 48, "PCL record sizes");
+// two layouts the device path must NOT take for PointNormal's: impl/point_types.hpp:390-400 (intensity at +16) and
+// :885-925 (rgb at +32, curvature at +36)
+struct alignas(16) PointXYZI {
+  union { float data[4]; struct { float x, y, z; }; };
+  union { struct { float intensity; }; float data_c[4]; };
+  PointXYZI() : data{0, 0, 0, 1.0f}, data_c{0, 0, 0, 0} {}
+};
+struct alignas(16) PointXYZRGBNormal {
+  union { float data[4]; struct { float x, y, z; }; };
+  union { float data_n[4]; float normal[3]; struct { float normal_x, normal_y, normal_z; }; };
+  union { struct { float rgb; float curvature; }; float data_c[4]; };
+  PointXYZRGBNormal() : data{0, 0, 0, 1.0f}, data_n{0, 0, 0, 0}, data_c{0, 0, 0, 0} {}
+};
+static_assert(sizeof(PointXYZI) == 32 && sizeof(PointXYZRGBNormal) == 48, "PCL record sizes");
 
 struct PCLHeader { std::uint32_t seq = 0; std::uint64_t stamp = 0; std::string frame_id; };
 
@@ -830,6 +844,16 @@ template <> inline std::vector<PCLPointField> getFields<PointNormal>() {  // imp
           {"z", 8, PCLPointField::FLOAT32, 1},         {"normal_x", 16, PCLPointField::FLOAT32, 1},
           {"normal_y", 20, PCLPointField::FLOAT32, 1}, {"normal_z", 24, PCLPointField::FLOAT32, 1},
           {"curvature", 32, PCLPointField::FLOAT32, 1}};
+}
+template <> inline std::vector<PCLPointField> getFields<PointXYZI>() {
+  return {{"x", 0, PCLPointField::FLOAT32, 1}, {"y", 4, PCLPointField::FLOAT32, 1}, {"z", 8, PCLPointField::FLOAT32, 1},
+          {"intensity", 16, PCLPointField::FLOAT32, 1}};
+}
+template <> inline std::vector<PCLPointField> getFields<PointXYZRGBNormal>() {
+  return {{"x", 0, PCLPointField::FLOAT32, 1},         {"y", 4, PCLPointField::FLOAT32, 1},
+          {"z", 8, PCLPointField::FLOAT32, 1},         {"normal_x", 16, PCLPointField::FLOAT32, 1},
+          {"normal_y", 20, PCLPointField::FLOAT32, 1}, {"normal_z", 24, PCLPointField::FLOAT32, 1},
+          {"rgb", 32, PCLPointField::FLOAT32, 1},      {"curvature", 36, PCLPointField::FLOAT32, 1}};
 }
 template <typename PointT> inline int getFieldIndex(const std::string& field_name, std::vector<PCLPointField>& fields) {
   fields = getFields<PointT>();

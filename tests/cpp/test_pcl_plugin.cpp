@@ -158,6 +158,22 @@ int main(int argc, char** argv) {
     ce->setIndicesSource(some);
     ce->determineCorrespondences(corr);
     EXPECT(corr.size() == 4 && corr[0].index_query == 3 && corr[3].index_query == 396 && corr[2].index_match == gold[200]);
+    // one correspondence per ENTRY of the list, in the list's order, duplicates included
+    // (impl/correspondence_estimation.hpp:160-216 loops over indices_)
+    pcl::IndicesPtr shuffled(new pcl::Indices{396, 3, 200, 3, 10});
+    ce->setIndicesSource(shuffled);
+    ce->determineCorrespondences(corr);
+    bool order = corr.size() == 5;
+    for (std::size_t i = 0; order && i < 5; ++i)
+      order = corr[i].index_query == (*shuffled)[i] && corr[i].index_match == gold[std::size_t((*shuffled)[i])];
+    EXPECT(order);
+    // a list as long as the cloud is still a list: a permutation comes back in its own order
+    pcl::IndicesPtr reversed(new pcl::Indices);
+    for (int i = 396; i >= 0; --i) reversed->push_back(i);
+    ce->setIndicesSource(reversed);
+    ce->determineCorrespondences(corr);
+    EXPECT(corr.size() == 397 && corr.front().index_query == 396 && corr.back().index_query == 0 &&
+           corr.front().index_match == gold[396]);
   }
 
   // test/registration/test_registration.cpp:251-269 (tests/golden/golden.json: icp_bunny)
@@ -210,6 +226,23 @@ int main(int argc, char** argv) {
     const auto T3 = reg->getFinalTransformation();
     for (int r = 0; r < 3; ++r) EXPECT(std::fabs(T3(r, 3) - G[4 * r + 3]) < 1e-2);  // half the points: the same pose, roughly
     EXPECT(reg->getFitnessScore() < 0.001);
+    // another list of the SAME size (PCLBase::setIndices does not flag the source as updated): the device must not keep
+    // the old subset -- twenty points near one end of the scan cannot give the pose of the whole scan
+    pcl::IndicesPtr other(new pcl::Indices);
+    for (int i = 0; i < 199; ++i) other->push_back(i < 20 ? i : 19);
+    reg->setIndices(other);
+    reg->align(out);
+    const auto T4 = reg->getFinalTransformation();
+    bool differs = false;
+    for (int r = 0; r < 3; ++r) differs = differs || T4(r, 3) != T3(r, 3);
+    EXPECT(hip->deferredReason().empty() && differs);
+    // the target cloud modified in place and set again: the index is rebuilt (often at the freed address) and the
+    // registration must follow the rebuild, not the address
+    reg->setIndices(half);
+    reg->setInputTarget(target);
+    reg->align(out);
+    const auto T5 = reg->getFinalTransformation();
+    for (int r = 0; r < 3; ++r) EXPECT(T5(r, 3) == T3(r, 3));
   }
 
   {  // 5. what the binding cannot express is handed to PCL's own loop -- never silently replaced.  (The mock has
@@ -355,6 +388,35 @@ int main(int argc, char** argv) {
       fields = all[i].normal_z == 1.0f && all[i].curvature == 0.5f && xyz_only[i].normal_z == 0.0f && xyz_only[i].curvature == 0.0f &&
                all[i].x == xyz_only[i].x;
     EXPECT(fields);
+    // point types the device path must hand back to pcl::VoxelGrid when every field is to be averaged: PointXYZI (a field
+    // the device would drop), PointXYZRGBNormal (48 bytes like PointNormal, but rgb at +32 and the curvature at +36)
+    using pclhip::plugin::record_layout;
+    EXPECT(record_layout<pcl::PointXYZ>().xyz_at_0 && !record_layout<pcl::PointXYZ>().other_fields &&
+           !record_layout<pcl::PointXYZ>().normal_at_16);
+    EXPECT(record_layout<pcl::PointNormal>().normal_at_16 && record_layout<pcl::PointNormal>().curvature_at_32 &&
+           !record_layout<pcl::PointNormal>().other_fields);
+    EXPECT(record_layout<pcl::PointXYZI>().xyz_at_0 && record_layout<pcl::PointXYZI>().other_fields &&
+           !pclhip::plugin::has_normal_fields<pcl::PointXYZI>());
+    EXPECT(record_layout<pcl::PointXYZRGBNormal>().normal_at_16 && !record_layout<pcl::PointXYZRGBNormal>().curvature_at_32 &&
+           record_layout<pcl::PointXYZRGBNormal>().other_fields);
+    auto srci = load_xyz<pcl::PointXYZI>(argv[1]);
+    for (auto& p : srci->points) p.intensity = 7.0f;
+    VoxelGridHIP<pcl::PointXYZI> gridi(dev);
+    gridi.setLeafSize(0.02f, 0.02f, 0.02f);
+    gridi.setInputCloud(srci);
+    EXPECT(!gridi.whyDeferred().empty());  // downsample_all_data_ is the default: the reference averages the intensity
+    gridi.setDownsampleAllData(false);      // coordinates only: the device path, the other fields stay default
+    EXPECT(gridi.whyDeferred().empty());
+    pcl::PointCloud<pcl::PointXYZI> outi;
+    gridi.filter(outi);
+    bool xyzi = outi.size() == 103 && gridi.deferredReason().empty();
+    for (std::size_t i = 0; xyzi && i < outi.size(); ++i) xyzi = outi[i].intensity == 0.0f && outi[i].x == xyz_only[i].x;
+    EXPECT(xyzi);
+    VoxelGridHIP<pcl::PointXYZRGBNormal> gridc(dev);
+    gridc.setInputCloud(load_xyz<pcl::PointXYZRGBNormal>(argv[1]));
+    EXPECT(!gridc.whyDeferred().empty());
+    gridc.setDownsampleAllData(false);
+    EXPECT(gridc.whyDeferred().empty());
   }
 
   {  // 9. the estimators on explicit pairs through pcl::registration::TransformationEstimation (transformation_estimation.h:74-116)

@@ -148,6 +148,30 @@ def test_sharded_target_equals_single_index(world):
         assert halo >= n - 1                                                      # slabs + halos cover the cloud
 
 
+@pytest.mark.parametrize("cloud,n_slabs", [
+    (np.array([[-2.5, 1.0, 0.5, 1.0]], np.float32), 4),                                  # one point, negative x, four slabs
+    (np.array([[7.0, -1.0, 2.0, 1.0], [7.0, -1.0, 2.0, 1.0]], np.float32), 3),            # fewer distinct points than slabs
+    (np.tile(np.array([[0.25, 0.5, -0.75, 1.0]], np.float32), (64, 1)), 8),               # every coordinate duplicated
+    (np.c_[np.repeat(np.array([-3.0, -3.0, 5.0], np.float32), 50), np.zeros(150, np.float32), np.zeros(150, np.float32),
+           np.ones(150, np.float32)].astype(np.float32), 5),                             # heavy ties at the cuts
+    (np.zeros((0, 4), np.float32), 3),                                                    # an empty cloud
+])
+def test_partition_slabs_tiles_space_whatever_the_cloud(cloud, n_slabs):
+    # the regions tile space with exactly one owner per point even when there is nothing to cut: no region with lo > hi,
+    # no overlap (the C owner test takes the first match, the Python one the last: they have to agree)
+    from pcl_amd.dist import partition_slabs, region_owner
+    regions = partition_slabs(cloud, n_slabs)
+    assert regions.shape == (n_slabs, 6) and (regions[:, :3] <= regions[:, 3:]).all()
+    probe = np.random.default_rng(1).uniform(-10, 10, (4000, 3)).astype(np.float32)
+    probe = np.concatenate([probe, cloud[:, :3]]) if len(cloud) else probe
+    inside = np.stack([np.all((probe >= regions[g, :3]) & (probe < regions[g, 3:]), axis=1) for g in range(n_slabs)])
+    assert (inside.sum(0) == 1).all()                       # exactly one owner, first match == last match
+    assert (region_owner(regions, probe) >= 0).all()
+    if len(cloud):
+        own = region_owner(regions, cloud)
+        assert (own >= 0).all()
+
+
 def _shard_worker(rank, world, port, n, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -119,6 +119,18 @@ def test_sharded_target_on_device_equals_single_index(world):
         assert min(g[0].size for g in got) > 0                                               # every rank had work
         assert np.allclose(total[:28], ref[:28], rtol=1e-10, atol=1e-12), it
         T = one.solve(ref)
+    # getFitnessScore under target sharding: a rank scores the points it owns under the given transform (against its slab
+    # + halo), so the ranks' (sum, count) pairs add up to the single-index score -- what the all-reduce of a real
+    # multi-rank run sums (here the ranks are played one after the other, so the sum is taken by hand)
+    for max_range in (1e-6, 0.01):
+        want = one.getFitnessScore(max_range, transform=T)
+        nr_want = one.fitness_points
+        parts = []
+        for st, icp in shards:
+            sc = icp.getFitnessScore(max_range, transform=T)
+            parts.append((sc * icp.fitness_points if icp.fitness_points else 0.0, icp.fitness_points))
+        assert sum(p[1] for p in parts) == nr_want and nr_want > 0
+        assert abs(sum(p[0] for p in parts) / nr_want - want) <= 1e-12 * want
 
 
 def test_native_comm_and_region_in_the_device_loop():
