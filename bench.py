@@ -175,7 +175,10 @@ def main():
     avg_kernel_s = search_ms / max(args.steps, 1) / 1e3
     corr_per_launch_local = ncorr / max(args.steps, 1) / world
     achieved = B_ALG_SEARCH * corr_per_launch_local / avg_kernel_s / 1e9
-    roofline = {"bound": "hbm", "kernel": "icp_search_kernel", "achieved": round(achieved, 2),
+    roofline = {"bound": "hbm",
+                "kernel": "icp_search_dual_kernel (one launch per iteration: the stand-off body for the first iteration of an "
+                          "alignment, the seeded body after it; both are averaged here as the steps mix them)",
+                "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": None, "alg_bytes_per_corr": B_ALG_SEARCH, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
                 "iteration_kernels_ms": round(kernel_ms / max(args.steps, 1), 4),
@@ -188,7 +191,10 @@ def main():
             tj = json.load(open(traffic_file))
             roofline["traffic"] = tj.get("icp_search_bytes_per_launch")
             roofline["traffic_source"] = {"file": "profiles/pmc_traffic.json", "commit": tj.get("commit"),
-                                          "date": tj.get("date")}
+                                          "date": tj.get("date"), "command": tj.get("command"),
+                                          "note": "NOT measured in this run: FETCH_SIZE / WRITE_SIZE need their own "
+                                                  "rocprofv3 --pmc passes; this is the per-launch average of those passes "
+                                                  "of the same command at the commit named here"}
         except Exception:
             pass
 
@@ -219,10 +225,15 @@ def main():
                           "step_ms": round(s["step_ms"], 4), "ended": s["alignment_ended"], "state": s["state"]} for s in steps],
             "setup": {"index_build_ms": round(build_ms, 3), "index_build_first_ms": round(build_first_ms, 3),
                       "index_build_GBps_alg": round(B_ALG_BUILD * n / (build_ms * 1e-3) / 1e9, 1),
+                      "index_build_roofline_frac": round(B_ALG_BUILD * n / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                       "normals_kernel_ms": None if normals_ms is None else round(normals_ms, 3),
                       "normals_kernel_first_ms": None if normals_first_ms is None else round(normals_first_ms, 3),
                       "normals_GBps_alg": None if normals_ms is None else
                       round(B_ALG_NORMALS * n / (normals_ms * 1e-3) / 1e9, 1),
+                      "normals_roofline_frac": None if normals_ms is None else
+                      round(B_ALG_NORMALS * n / (normals_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                      "iteration_roofline_frac": round(B_ALG_ITER[mode] * corr_per_launch_local /
+                                                       (kernel_ms / max(args.steps, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                       "source_order_ms": round(source_order_ms, 3),
                       "synth_gen_s": round(gen_s, 1), "commit": git_head()},
         }
@@ -314,6 +325,26 @@ def run_pipeline(args, ctx, comm, tgt, src, n, rank, world, fence, gen_s):
     }
 
 
+def host_cpus():
+    """(hardware threads, physical cores) of this box: cpu_baseline.cores is the number of THREADS the oracle ran on."""
+    threads = os.cpu_count() or 1
+    cores = set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return threads, (len(cores) or None)
+
+
 def cpu_pipeline(args, tgt, src):
     """config 4 on the host cores: the oracle's VoxelGrid (single thread, as in PCL) + kd-tree + normals + ICP."""
     from oracle import pcl_oracle as orc
@@ -328,7 +359,9 @@ def cpu_pipeline(args, tgt, src):
     r = orc.icp_align(tree, ft, fs, mode=1, tgt_normals=nrm, max_iterations=20, nthreads=cores,
                       max_correspondence_distance=0.1, transformation_epsilon=1e-10)
     t2 = time.perf_counter()
-    return {"value": round(2.0 * len(tgt_h) / (t2 - t0), 1), "unit": "input points/s", "cores": cores, "kind": "port",
+    return {"value": round(2.0 * len(tgt_h) / (t2 - t0), 1), "unit": "input points/s", "cores": cores,
+            "threads_used": cores, "host_hardware_threads": host_cpus()[0], "host_physical_cores": host_cpus()[1],
+            "kind": "port",
             "sample": "the same two %d-point clouds, whole pipeline once: VoxelGrid %.2f s (1 thread, as in PCL), "
                       "kd-tree + k=%d normals + %d ICP iterations %.2f s (search on %d threads)" %
                       (len(tgt_h), t1 - t0, args.knn, r["iterations"], t2 - t1, cores)}
@@ -358,6 +391,7 @@ def cpu_baseline(args, mode, n, tgt, src):
     r1 = orc.icp_align(tree, tgt, src[:m1], max_iterations=1, nthreads=1, **kw)
     per_iter1 = r1["seconds_total"] / max(r1["iterations"], 1)
     return {"value": round(r["num_correspondences"] / per_iter, 1), "unit": "correspondences/s", "cores": cores,
+            "threads_used": cores, "host_hardware_threads": host_cpus()[0], "host_physical_cores": host_cpus()[1],
             "kind": "port",
             "sample": "the bench's own %d-point target and %d-point source, %d ICP iterations on %d threads "
                       "(search %.3f s + serial estimate/transform %.3f s per iteration); 1 thread: one iteration over "

@@ -63,6 +63,12 @@ PCLHIP_API void* pclhip_ctx_stream(const pclhip_ctx* ctx);
 PCLHIP_API void pclhip_ctx_destroy(pclhip_ctx* ctx);
 PCLHIP_API const char* pclhip_last_error(const pclhip_ctx* ctx /* may be NULL */);
 PCLHIP_API pclhip_status pclhip_ctx_synchronize(pclhip_ctx* ctx);
+/* Reserve `bytes` of device memory as the context's arena: index arrays, registration state and every temporary are
+ * carved out of it (what does not fit falls back to hipMalloc), so the first index build of a context costs what a
+ * rebuild costs.  Without this call the context reserves 288 bytes per point of the first cloud of a million points or
+ * more that it sees (PCLHIP_ARENA_MB overrides; 0 = no arena).  No PCL counterpart: PCL's containers allocate on the
+ * host (common/include/pcl/point_cloud.h:393-409); this is the device side of that. */
+PCLHIP_API pclhip_status pclhip_ctx_reserve(pclhip_ctx* ctx, uint64_t bytes);
 PCLHIP_API const char* pclhip_version(void);
 /* Optional traversal work counters (diagnostics): enable != 0 allocates/zeroes 8 device counters
  * that every search kernel of this context adds to; out (8 x uint64, may be NULL) receives the

@@ -65,6 +65,10 @@ class Context:
     def synchronize(self):
         check(self.lib.pclhip_ctx_synchronize(self.h), self.h)
 
+    def reserve(self, nbytes):
+        """Reserve the context's device arena up front (pclhip_ctx_reserve); automatic for the first large cloud otherwise."""
+        check(self.lib.pclhip_ctx_reserve(self.h, int(nbytes)), self.h)
+
     def stats(self, enable=True):
         """Read (then re-arm or disable) the traversal work counters."""
         out = (C.c_uint64 * 8)()

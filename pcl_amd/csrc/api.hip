@@ -56,24 +56,96 @@ pclhip_status to_device(pclhip_ctx* ctx, const void* p, size_t bytes, const void
 
 pclhip_status ensure_scratch(pclhip_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->scratch_bytes) return PCLHIP_OK;
-  if (ctx->scratch) {
-    PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(ctx->scratch);
+  if (ctx->scratch) {  // stream-ordered like every other block of the context: no synchronisation needed
+    dev_free(ctx, ctx->scratch);
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
   }
-  PCLHIP_CHECK_HIP(ctx, hipMalloc(&ctx->scratch, bytes));
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ctx->scratch, bytes));
   ctx->scratch_bytes = bytes;
   return PCLHIP_OK;
 }
 
 // ---- context-cached device memory -----------------------------------------------------------------
+namespace {
+constexpr size_t ARENA_ALIGN = 256;
+// first fit in the arena's free ranges (the caller holds cache_mutex); nullptr when nothing fits
+void* arena_take(pclhip_ctx* ctx, size_t bytes) {
+  for (auto it = ctx->arena_free.begin(); it != ctx->arena_free.end(); ++it) {
+    if (it->second < bytes) continue;
+    const size_t off = it->first, rest = it->second - bytes;
+    ctx->arena_free.erase(it);
+    if (rest > 0) ctx->arena_free.emplace(off + bytes, rest);
+    return ctx->arena + off;
+  }
+  return nullptr;
+}
+void arena_give(pclhip_ctx* ctx, void* p, size_t bytes) {
+  size_t off = size_t(static_cast<char*>(p) - ctx->arena);
+  auto next = ctx->arena_free.lower_bound(off);
+  if (next != ctx->arena_free.begin()) {  // merge with the range before
+    auto prev = std::prev(next);
+    if (prev->first + prev->second == off) {
+      off = prev->first;
+      bytes += prev->second;
+      ctx->arena_free.erase(prev);
+    }
+  }
+  if (next != ctx->arena_free.end() && off + bytes == next->first) {  // ... and the one after
+    bytes += next->second;
+    ctx->arena_free.erase(next);
+  }
+  ctx->arena_free.emplace(off, bytes);
+}
+bool in_arena(const pclhip_ctx* ctx, const void* p) {
+  return ctx->arena != nullptr && static_cast<const char*>(p) >= ctx->arena &&
+         static_cast<const char*>(p) < ctx->arena + ctx->arena_bytes;
+}
+}  // namespace
+
+pclhip_status reserve_arena(pclhip_ctx* ctx, size_t bytes) {
+  std::lock_guard<std::mutex> lock(ctx->cache_mutex);
+  if (ctx->arena != nullptr || bytes == 0) return PCLHIP_OK;
+  bytes = (bytes + ARENA_ALIGN - 1) & ~(ARENA_ALIGN - 1);
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return PCLHIP_ERR_HIP;  // not fatal: allocations go through hipMalloc + the block cache
+  }
+  ctx->arena = static_cast<char*>(p);
+  ctx->arena_bytes = bytes;
+  ctx->arena_free.clear();
+  ctx->arena_free.emplace(size_t(0), bytes);
+  return PCLHIP_OK;
+}
+
+// Device bytes a registration pipeline holds per point of its largest cloud: the index (points, SoA copy, normals,
+// boxes, discs, rank: ~60), the build's and the source ordering's scratch (~100), the source arrays of a registration
+// (copies, matches, distances: ~50) and a VoxelGrid pass (~60) -- 288 with slack.  PCLHIP_ARENA_MB overrides (0: none).
+void dev_reserve_for_points(pclhip_ctx* ctx, uint64_t points) {
+  if (ctx == nullptr || ctx->arena_tried || ctx->arena != nullptr || points < 1000000ull) return;
+  ctx->arena_tried = true;
+  size_t want = size_t(points) * 288;
+  if (const char* e = getenv("PCLHIP_ARENA_MB")) want = size_t(strtoull(e, nullptr, 10)) << 20;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 2) want = free_b / 2;
+  if (want > 0) (void)reserve_arena(ctx, want);
+}
+
 hipError_t dev_malloc(pclhip_ctx* ctx, void** p, size_t bytes) {
   *p = nullptr;
   if (bytes == 0) bytes = 16;
   if (ctx == nullptr) return hipMalloc(p, bytes);
   {
     std::lock_guard<std::mutex> lock(ctx->cache_mutex);
+    if (ctx->arena != nullptr) {
+      const size_t rounded = (bytes + ARENA_ALIGN - 1) & ~(ARENA_ALIGN - 1);
+      if (void* a = arena_take(ctx, rounded)) {
+        *p = a;
+        ctx->live[a] = rounded;
+        return hipSuccess;
+      }
+    }
     // best fit among the free blocks, but never one more than twice the size asked for
     size_t best = ctx->cache.size();
     for (size_t i = 0; i < ctx->cache.size(); ++i) {
@@ -109,12 +181,17 @@ void dev_free(pclhip_ctx* ctx, void* p) {
     if (it != ctx->live.end()) {
       const size_t bytes = it->second;
       ctx->live.erase(it);
+      if (in_arena(ctx, p)) {  // all work of the context is ordered on its stream: the range can be handed out again
+        arena_give(ctx, p, bytes);
+        return;
+      }
       if (ctx->cached_bytes + bytes <= ctx->cache_limit) {
         ctx->cache.emplace_back(p, bytes);
         ctx->cached_bytes += bytes;
         return;
       }
     } else {
+      if (in_arena(ctx, p)) return;  // released twice
       for (const auto& b : ctx->cache)
         if (b.first == p) return;  // released twice: it already sits in the cache
     }
@@ -252,6 +329,25 @@ float float_at_most(double v) {  // largest float <= v  (v >= 0)
 }  // namespace
 }  // namespace pclhip
 
+namespace pclhip {
+// The runtime loads a translation unit's code object at the first use of one of its kernels: that is a context's
+// business, not the first timed launch's (the driver's fresh box showed the first index build at 12x the steady one).
+// PCLHIP_PRELOAD=0 leaves it lazy.
+void preload_code_objects(pclhip_ctx* ctx) {
+  static const bool on = [] {
+    const char* e = getenv("PCLHIP_PRELOAD");
+    return !(e && atoi(e) == 0);
+  }();
+  if (!on) return;
+  preload_search_kernels(ctx);
+  preload_index_build_kernels();
+  preload_voxelgrid_kernels();
+  preload_rejector_kernels();
+  preload_radius_kernels();
+  (void)hipGetLastError();
+}
+}  // namespace pclhip
+
 extern "C" {
 
 const char* pclhip_version(void) { return "pclhip 0.1 (gfx950)"; }
@@ -300,18 +396,30 @@ static pclhip_status ctx_create_impl(int device, void* stream, bool adopt, pclhi
     const size_t quarter = size_t(prop.totalGlobalMem) / 4;
     if (ctx->cache_limit > quarter) ctx->cache_limit = quarter;
   }
+  preload_code_objects(ctx);
   *out = ctx;
   return PCLHIP_OK;
+}
+
+
+pclhip_status pclhip_ctx_reserve(pclhip_ctx* ctx, uint64_t bytes) {
+  if (!ctx) return PCLHIP_ERR_INVALID;
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->arena_tried = true;
+  const pclhip_status st = pclhip::reserve_arena(ctx, size_t(bytes));
+  if (st != PCLHIP_OK) pclhip::set_error(ctx, "could not reserve the arena (allocations fall back to hipMalloc)");
+  return st;
 }
 
 void pclhip_ctx_destroy(pclhip_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->scratch) dev_free(ctx, ctx->scratch);
   if (ctx->stats) (void)hipFree(ctx->stats);
   if (ctx->staging) (void)hipFree(ctx->staging);
   dev_cache_release(ctx);
+  if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -358,6 +466,7 @@ pclhip_status pclhip_index_build_scaled(pclhip_ctx* ctx, const void* points, siz
   PCLHIP_REQUIRE(ctx, n < 0x7FFFFFFFull, "cloud too large for int32 indices");
   PCLHIP_REQUIRE(ctx, n == 0 || points != nullptr, "null point buffer");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  dev_reserve_for_points(ctx, n);  // the context's arena, sized by its first large cloud
   DeviceGuard guard(ctx);
   const void* dpts = nullptr;
   void* owned = nullptr;
@@ -836,6 +945,7 @@ pclhip_status pclhip_icp_set_source_indexed(pclhip_icp* icp, const void* points,
   PCLHIP_REQUIRE(ctx, n < 0x7FFFFFFFull, "cloud too large for int32 indices");
   PCLHIP_REQUIRE(ctx, n == 0 || points != nullptr, "null point buffer");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  dev_reserve_for_points(ctx, n);
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   icp_free_source(icp);
   DeviceGuard guard(ctx);

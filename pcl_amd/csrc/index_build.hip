@@ -1459,6 +1459,12 @@ pclhip_status build_boxes(pclhip_index* ix) {
   return PCLHIP_OK;
 }
 
+
+void preload_index_build_kernels() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(bbox_final_kernel));
+}
+
 }  // namespace pclhip
 
 pclhip::IndexView pclhip_index::view() const {

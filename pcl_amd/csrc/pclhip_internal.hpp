@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -31,7 +32,8 @@ namespace pclhip {
 
 constexpr int LEAF = 16;        // points per leaf (candidates broadcast through SGPRs)
 constexpr int FANOUT = 64;      // children per internal node = one per lane of a wavefront
-constexpr int MAX_LEVELS = 8;   // 16 * 64^7 points
+constexpr int MAX_LEVELS = 6;   // levels 1..5: 16 * 64^5 points, far beyond the int32 indices of the API (2^31 points: 134M leaves ->
+                                // 2.1M, 32768, 512, 8 boxes).  Every entry costs the kernels four scalar registers.
 constexpr int WAVE = 64;
 constexpr uint32_t NO_INDEX = 0xFFFFFFFFu;
 constexpr int TOPCACHE_BOXES = 176;  // 5.5 KB of LDS per block
@@ -133,6 +135,13 @@ struct pclhip_ctx {
   size_t cached_bytes = 0;
   size_t cache_limit = size_t(16384) << 20;
   std::mutex cache_mutex;
+  // One reservation in front of that cache (pclhip_ctx_reserve; made automatically for the first cloud of a million
+  // points or more): allocations are carved out of it (first fit, freed ranges coalesce), so a context's FIRST index
+  // build pays one hipMalloc instead of some forty.  What does not fit goes the way above.
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  std::map<size_t, size_t> arena_free;  // offset -> bytes of the free ranges
+  bool arena_tried = false;             // the automatic reservation was attempted (once per context)
 };
 
 struct pclhip_index {
@@ -216,6 +225,17 @@ namespace pclhip {
 hipError_t dev_malloc(pclhip_ctx* ctx, void** p, size_t bytes);
 void dev_free(pclhip_ctx* ctx, void* p);
 void dev_cache_release(pclhip_ctx* ctx);  // really frees every cached block
+pclhip_status reserve_arena(pclhip_ctx* ctx, size_t bytes);
+// reserve the context's arena for clouds of `points` points (no-op when one exists or PCLHIP_ARENA_MB=0)
+void dev_reserve_for_points(pclhip_ctx* ctx, uint64_t points);
+// load the code objects of every translation unit now (hipFuncGetAttributes of one kernel each), not inside the first
+// timed launch
+void preload_code_objects(pclhip_ctx* ctx);
+void preload_search_kernels(pclhip_ctx* ctx);
+void preload_index_build_kernels();
+void preload_voxelgrid_kernels();
+void preload_rejector_kernels();
+void preload_radius_kernels();
 template <class T>
 inline hipError_t dev_malloc(pclhip_ctx* ctx, T** p, size_t bytes) {
   return dev_malloc(ctx, reinterpret_cast<void**>(p), bytes);

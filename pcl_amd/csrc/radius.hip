@@ -183,6 +183,10 @@ struct Guard {
 };
 
 }  // namespace
+void preload_radius_kernels() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(widen_counts_kernel));
+}
 }  // namespace pclhip
 
 using namespace pclhip;

@@ -354,4 +354,8 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
   return PCLHIP_OK;
 }
 
+void preload_rejector_kernels() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(rs_pick_kernel));
+}
 }  // namespace pclhip

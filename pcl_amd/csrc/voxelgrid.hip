@@ -453,6 +453,10 @@ __global__ __launch_bounds__(256) void vg_centroid_row_kernel(const void* pts, s
 }
 
 }  // namespace
+void preload_voxelgrid_kernels() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(vg_key_kernel));
+}
 }  // namespace pclhip
 
 using namespace pclhip;
@@ -494,6 +498,7 @@ extern "C" pclhip_status pclhip_voxelgrid_ex2(pclhip_ctx* ctx, const void* point
   if (n == 0) return PCLHIP_OK;
   PCLHIP_REQUIRE(ctx, points && (out || dims_only), "null buffer");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  dev_reserve_for_points(ctx, n);
   hipStream_t s = ctx->stream;
   struct Guard {
     pclhip_ctx* ctx = nullptr;

@@ -27,8 +27,8 @@ for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
         name_of[r["Dispatch_Id"]] = r["Kernel_Name"]
     for (disp, counter), v in acc.items():
         k = name_of[disp]
-        short = "icp_search" if "icp_search_kernel" in k else "icp_accumulate" if "icp_accumulate_kernel" in k else \
-            "normals" if "normals_kernel" in k else None
+        short = "icp_search" if ("search_kernel" in k or "search_dual_kernel" in k) and "icp_" in k else \
+            "icp_accumulate" if "icp_accumulate_kernel" in k else "normals" if "normals_kernel" in k else None
         if short:
             per[short][counter].append(v)
 out = {"commit": commit, "date": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "command": cmd,

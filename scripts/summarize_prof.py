@@ -8,7 +8,7 @@ import os
 import sys
 
 d = sys.argv[1]
-KEYS = ("icp_search", "icp_accumulate", "icp_iterate", "normals_kernel", "knn_reg", "knn_heap", "vg_", "kd_", "radix", "finalize")
+KEYS = ("icp_search", "icp_cold_search", "icp_accumulate", "icp_iterate", "normals_kernel", "knn_reg", "knn_heap", "vg_", "kd_", "radix", "finalize")
 for f in sorted(glob.glob(os.path.join(d, "*kernel_stats.csv"))):
     print("# kernel stats (%s)" % os.path.basename(f))
     for r in list(csv.DictReader(open(f)))[:14]:
