@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--knn", type=int, default=8, help="k of NormalEstimation")
     ap.add_argument("--replicated", action="store_true", help="config 5: replicate the target instead of sharding it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-align", action="store_true", help="skip the host-boundary timing (examples/bench_pcl_align.cpp)")
     return ap.parse_args()
 
 
@@ -203,6 +204,9 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # an N=1 figure (it would stall the other ranks)
             cpu = cpu_baseline(args, mode, n, tgt_h, src_h)
+        boundary = None
+        if not args.no_host_align and world == 1:
+            boundary = host_align(mode, tgt_h, src_h)
         name = {2: "config 2: 2^20-point clouds, k=1 NN + point-to-point ICP (SVD)",
                 3: "config 3: 10M-point clouds, k=%d NormalEstimation + point-to-plane ICP" % args.knn}[cfg]
         out = {
@@ -235,6 +239,10 @@ def main():
                       "iteration_roofline_frac": round(B_ALG_ITER[mode] * corr_per_launch_local /
                                                        (kernel_ms / max(args.steps, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                       "source_order_ms": round(source_order_ms, 3),
+                      # pcl::Registration::align() from HOST pcl::PointClouds through the real-PCL binding (mock build)
+                      "host_align_ms": None if not boundary or "align_first" not in boundary else
+                      round(boundary["align_first"]["total_ms"], 3),
+                      "host_align": boundary,
                       "synth_gen_s": round(gen_s, 1), "commit": git_head()},
         }
     finish(out, rank, world)
@@ -323,6 +331,35 @@ def run_pipeline(args, ctx, comm, tgt, src, n, rank, world, fence, gen_s):
         "result": {"T_minus_T_gt_frobenius": float(np.linalg.norm(info["T"] - synth.ground_truth_transform()))},
         "setup": {"synth_gen_s": round(gen_s, 1), "commit": git_head()},
     }
+
+
+def host_align(mode, tgt_h, src_h):
+    """The boundary a PCL user sees: examples/bench_pcl_align.cpp drives pcl::Registration::align() on
+    IterativeClosestPoint[WithNormals]HIP with HOST pcl::PointClouds of the bench's own clouds (compiled against the PCL
+    mock: PCL's classes with their real signatures).  Returns its JSON (milliseconds per stage) or a note on failure."""
+    import tempfile
+    try:
+        d = tempfile.mkdtemp(prefix="pclhip_align_")
+        exe = os.path.join(d, "bench_pcl_align")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "tests", "cpp", "pcl_mock"),
+                               os.path.join(ROOT, "examples", "bench_pcl_align.cpp"), "-o", exe,
+                               "-L" + os.path.join(ROOT, "pcl_amd"), "-lpclhip",
+                               "-Wl,-rpath," + os.path.join(ROOT, "pcl_amd")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        tgt_h.astype(np.float32).tofile(os.path.join(d, "t.f32"))
+        src_h.astype(np.float32).tofile(os.path.join(d, "s.f32"))
+        out = subprocess.run([exe, os.path.join(d, "t.f32"), os.path.join(d, "s.f32"), str(len(tgt_h)), str(mode)],
+                             capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        res = json.loads(line[-1]) if line else {"error": (out.stderr or out.stdout)[-300:]}
+        for f in ("t.f32", "s.f32", "bench_pcl_align"):
+            try:
+                os.remove(os.path.join(d, f))
+            except OSError:
+                pass
+        return res
+    except Exception as e:  # no compiler on the box, ...: the bench line does not depend on it
+        return {"error": repr(e)[:300]}
 
 
 def host_cpus():

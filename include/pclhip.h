@@ -97,6 +97,13 @@ PCLHIP_API pclhip_status pclhip_index_build(pclhip_ctx* ctx, const void* points,
 PCLHIP_API pclhip_status pclhip_index_build_scaled(pclhip_ctx* ctx, const void* points, size_t stride_bytes,
                                                    uint64_t n, const int32_t* indices, uint64_t n_indices,
                                                    const float scale[3], pclhip_index** out);
+/* The same, and the records' own normals -- (nx, ny, nz, curvature) at `normals_offset_bytes` inside every record, 0 =
+ * none -- attached to the index from the same upload (pclhip_index_set_normals would stage the cloud a second time):
+ * pcl::PointNormal clouds as IterativeClosestPointWithNormals takes them (registration/include/pcl/registration/icp.h
+ * :330-345; the normals sit at +16). */
+PCLHIP_API pclhip_status pclhip_index_build_ex(pclhip_ctx* ctx, const void* points, size_t stride_bytes, uint64_t n,
+                                               const int32_t* indices, uint64_t n_indices, const float* scale,
+                                               size_t normals_offset_bytes, pclhip_index** out);
 PCLHIP_API void pclhip_index_destroy(pclhip_index* index);
 /* number of finite points indexed */
 PCLHIP_API uint64_t pclhip_index_size(const pclhip_index* index);
@@ -426,6 +433,13 @@ PCLHIP_API pclhip_status pclhip_estimate_rigid_transformation_weighted(
 PCLHIP_API pclhip_status pclhip_transform_cloud(pclhip_ctx* ctx, const float T[16], int order,
                                                 const void* in, void* out, size_t stride_bytes,
                                                 uint64_t n, size_t normals_offset_bytes);
+/* The same for the SOURCE cloud of a registration: when `in` is the host buffer pclhip_icp_set_source[_indexed] was
+ * given (same address, stride and count), the records staged on the device then are used and nothing is uploaded
+ * again -- the moved cloud IterativeClosestPoint::computeTransformation hands back (impl/icp.hpp:264-267:
+ * output = *input_, then transformCloud) costs one download.  Any other `in` behaves like pclhip_transform_cloud. */
+PCLHIP_API pclhip_status pclhip_icp_transform_source(pclhip_icp* icp, const float T[16], int order,
+                                                     const void* in, void* out, size_t stride_bytes,
+                                                     uint64_t n, size_t normals_offset_bytes);
 
 /* ---- VoxelGrid ----------------------------------------------------------------------------------
  * Replaces pcl::VoxelGrid<pcl::PointXYZ>::applyFilter (filters/include/pcl/filters/impl/

@@ -35,6 +35,7 @@
 #include <pcl/registration/transformation_estimation.h>
 #include <pcl/search/kdtree.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -132,10 +133,18 @@ class KdTreeHIP : public pcl::search::KdTree<PointT> {
     this->indices_ = indices;
     if (!dev_ || !dev_->ok() || !cloud) return false;
     const bool use_idx = indices && !indices->empty();
-    return pclhip_index_build_scaled(dev_->get(), cloud->points.data(), sizeof(PointT), cloud->size(),
-                                     use_idx ? indices->data() : nullptr, use_idx ? indices->size() : 0,
-                                     scaled_ ? scale_ : nullptr, &index_) == PCLHIP_OK;
+    // PointNormal-like records bring their normals along in the same upload (point-to-plane targets)
+    const RecordLayout& rec = record_layout<PointT>();
+    const bool with_normals = rec.normal_at_16 && rec.curvature_at_32;
+    normals_from_ = nullptr;
+    const bool ok = pclhip_index_build_ex(dev_->get(), cloud->points.data(), sizeof(PointT), cloud->size(),
+                                          use_idx ? indices->data() : nullptr, use_idx ? indices->size() : 0,
+                                          scaled_ ? scale_ : nullptr, with_normals ? 16 : 0, &index_) == PCLHIP_OK;
+    if (ok && with_normals) normals_from_ = cloud.get();
+    return ok;
   }
+  // the cloud whose own normals the index carries (nullptr: none attached by setInputCloud)
+  const void* normalsFrom() const { return normals_from_; }
   // The index is three-dimensional: a representation is honoured when it is x, y, z (or a prefix of them)
   // with per-axis rescale factors (kdtree.h:110 -> KdTreeFLANN::setPointRepresentation); anything else is
   // refused loudly -- searches would silently mean something different.
@@ -244,6 +253,7 @@ class KdTreeHIP : public pcl::search::KdTree<PointT> {
   Device::Ptr dev_;
   pclhip_index* index_ = nullptr;
   std::uint64_t generation_ = 0;
+  const void* normals_from_ = nullptr;
   PointRepresentationConstPtr rep_;
   float scale_[3] = {1, 1, 1};
   bool scaled_ = false, unsupported_ = false;
@@ -335,6 +345,12 @@ class RegistrationHIP : public Base {
   ~RegistrationHIP() override { if (icp_) pclhip_icp_destroy(icp_); }
   // Why the last align() ran where it ran: "" = device; otherwise the reason it deferred to PCL's CPU loop.
   const std::string& deferredReason() const { return deferred_; }
+  // Host wall time of the parts of the last computeTransformation (milliseconds): what the boundary costs a PCL user
+  // next to the iterations themselves.  upload: target normals + source records to the device (0 when they were
+  // resident); loop: pclhip_icp_align (source ordering included when the source was new); output: the moved cloud.
+  struct Timings { double upload_ms = 0, loop_ms = 0, output_ms = 0; };
+  const Timings& lastTimings() const { return timings_; }
+  int iterations() const { return this->nr_iterations_; }  // of the last align() (PCL keeps nr_iterations_ protected)
   // Registration::getFitnessScore (impl/registration.hpp:132-168) on the device (after an align())
   double getFitnessScore(double max_range = std::numeric_limits<double>::max()) override {
     if (!icp_) return Base::getFitnessScore(max_range);
@@ -419,6 +435,10 @@ class RegistrationHIP : public Base {
     }
     // device state is cached per BUILD of the target index (KdTreeHIP::generation), not per handle address: a rebuilt
     // index may land on the freed address, and it has neither the normals nor this registration attached
+    using Clock = std::chrono::steady_clock;
+    const auto ms = [](Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const Clock::time_point t_start = Clock::now();
+    timings_ = Timings();
     if (icp_ && (icp_target_ != tree->handle() || icp_generation_ != tree->generation())) { pclhip_icp_destroy(icp_); icp_ = nullptr; }
     if (!icp_) {
       if (pclhip_icp_create(tree->handle(), &icp_) != PCLHIP_OK) return;
@@ -427,6 +447,8 @@ class RegistrationHIP : public Base {
       source_uploaded_ = nullptr;
       target_normals_of_ = nullptr;
     }
+    if (kind != SVD && tree->normalsFrom() == static_cast<const void*>(this->target_.get()))
+      target_normals_of_ = this->target_.get();  // KdTreeHIP::setInputCloud attached them from its own upload
     if (kind != SVD && target_normals_of_ != this->target_.get()) {  // pcl::PointNormal: normals at +16
       const char* base = reinterpret_cast<const char*>(this->target_->points.data());
       if (pclhip_index_set_normals(tree->handle(), base + 16, sizeof(PointTarget)) != PCLHIP_OK) return;
@@ -465,17 +487,32 @@ class RegistrationHIP : public Base {
     float g[16];
     to_rows(guess, g);
     pclhip_icp_result r;
+    const Clock::time_point t_loop = Clock::now();
+    timings_.upload_ms = ms(t_start, t_loop);
     if (pclhip_icp_align(icp_, &p, g, &r) != PCLHIP_OK) return;
+    const Clock::time_point t_out = Clock::now();
+    timings_.loop_ms = ms(t_loop, t_out);
     from_rows(r.final_transformation, this->final_transformation_);
     from_rows(r.last_transformation, this->transformation_);
     this->nr_iterations_ = r.nr_iterations;
     this->converged_ = r.converged != 0;
     using Criteria = DefaultConvergenceCriteria<float>;
     this->convergence_criteria_->setConvergenceState(static_cast<typename Criteria::ConvergenceState>(r.convergence_state));
-    output = *this->input_;  // impl/icp.hpp:264-267: the whole input cloud, moved by the final transformation
-    pclhip_transform_cloud(tree->device()->get(), r.final_transformation, kind == SVD ? 0 : 1, this->input_->points.data(),
-                           output.points.data(), sizeof(PointSource), output.size(),
-                           (kind != SVD && has_normal_fields<PointSource>()) ? 16 : 0);
+    // impl/icp.hpp:264-267: the whole input cloud, moved by the final transformation.  (pcl::Registration::align hands
+    // computeTransformation a copy of the input already -- registration.hpp:190-205 -- so the records are only copied
+    // again when the caller's cloud is not that copy.)
+    if (&output != this->input_.get() && (output.size() != this->input_->size() || output.points.data() == nullptr))
+      output = *this->input_;
+    else if (&output != this->input_.get()) {
+      output.header = this->input_->header;
+      output.width = this->input_->width;
+      output.height = this->input_->height;
+      output.is_dense = this->input_->is_dense;
+    }
+    pclhip_icp_transform_source(icp_, r.final_transformation, kind == SVD ? 0 : 1, this->input_->points.data(),
+                                output.points.data(), sizeof(PointSource), output.size(),
+                                (kind != SVD && has_normal_fields<PointSource>()) ? 16 : 0);
+    timings_.output_ms = ms(t_out, Clock::now());
   }
 
  private:
@@ -486,6 +523,7 @@ class RegistrationHIP : public Base {
   const void* target_normals_of_ = nullptr;
   bool source_subset_ = false;
   std::string deferred_;
+  Timings timings_;
 };
 
 template <typename PointSource, typename PointTarget>

@@ -97,6 +97,8 @@ SIGNATURES = {
     "pclhip_ctx_stats": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64)]),
     "pclhip_index_build": (C.c_int, [_vp, _vp, _sz, _u64, _vp, _u64, C.POINTER(_vp)]),
     "pclhip_index_build_scaled": (C.c_int, [_vp, _vp, _sz, _u64, _vp, _u64, C.POINTER(C.c_float), C.POINTER(_vp)]),
+    "pclhip_index_build_ex": (C.c_int, [_vp, _vp, _sz, _u64, _vp, _u64, C.POINTER(C.c_float), _sz, C.POINTER(_vp)]),
+    "pclhip_icp_transform_source": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int, _vp, _vp, _sz, _u64, _sz]),
     "pclhip_index_destroy": (None, [_vp]),
     "pclhip_index_size": (_u64, [_vp]),
     "pclhip_index_build_ms": (C.c_double, [_vp]),

@@ -355,6 +355,8 @@ const char* pclhip_version(void) { return "pclhip 0.1 (gfx950)"; }
 const char* pclhip_last_error(const pclhip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
 
 static pclhip_status ctx_create_impl(int device, void* stream, bool adopt, pclhip_ctx** out);
+static pclhip_status transform_cloud_impl(pclhip_ctx* ctx, const float* T, int order, const void* in, const void* resident,
+                                          void* out, size_t stride, uint64_t n, size_t normals_offset_bytes);
 
 pclhip_status pclhip_ctx_create(int device, void* stream, pclhip_ctx** out) {
   return ctx_create_impl(device, stream, stream != nullptr, out);
@@ -459,7 +461,15 @@ pclhip_status pclhip_index_build(pclhip_ctx* ctx, const void* points, size_t str
 pclhip_status pclhip_index_build_scaled(pclhip_ctx* ctx, const void* points, size_t stride, uint64_t n,
                                         const int32_t* indices, uint64_t n_indices, const float* scale,
                                         pclhip_index** out) {
+  return pclhip_index_build_ex(ctx, points, stride, n, indices, n_indices, scale, 0, out);
+}
+
+pclhip_status pclhip_index_build_ex(pclhip_ctx* ctx, const void* points, size_t stride, uint64_t n,
+                                    const int32_t* indices, uint64_t n_indices, const float* scale,
+                                    size_t normals_offset_bytes, pclhip_index** out) {
   if (!ctx || !out) return PCLHIP_ERR_INVALID;
+  PCLHIP_REQUIRE(ctx, normals_offset_bytes == 0 || (normals_offset_bytes % 4 == 0 && normals_offset_bytes + 16 <= stride),
+                 "the normals (nx, ny, nz, curvature: 16 bytes) must lie inside the record");
   if (scale) PCLHIP_REQUIRE(ctx, std::isfinite(scale[0]) && std::isfinite(scale[1]) && std::isfinite(scale[2]), "non-finite rescale value");
   *out = nullptr;
   PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
@@ -539,6 +549,15 @@ pclhip_status pclhip_index_build_scaled(pclhip_ctx* ctx, const void* points, siz
   ix->build_ms = ms;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  if (normals_offset_bytes != 0 && n > 0) {
+    // the records are on the device already (staged for the build, or the caller's device buffer): the normals come
+    // from the same copy -- a host cloud of PointNormal records is uploaded once, not twice
+    st = pclhip_index_set_normals(ix, static_cast<const char*>(dpts) + normals_offset_bytes, stride);
+    if (st != PCLHIP_OK) {
+      pclhip_index_destroy(ix);
+      return st;
+    }
+  }
   *out = ix;
   return PCLHIP_OK;
 }
@@ -894,6 +913,11 @@ pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out) {
 }
 
 static void icp_free_source(pclhip_icp* icp) {
+  if (icp->src_records) (void)dev_free(icp->ctx, icp->src_records);
+  icp->src_records = nullptr;
+  icp->src_records_host = nullptr;
+  icp->src_records_stride = 0;
+  icp->src_records_n = 0;
   if (icp->src_sorted0) (void)dev_free(icp->ctx, icp->src_sorted0);
   if (icp->src_cur) (void)dev_free(icp->ctx, icp->src_cur);
   if (icp->src_nrm_sorted0) (void)dev_free(icp->ctx, icp->src_nrm_sorted0);
@@ -953,7 +977,14 @@ pclhip_status pclhip_icp_set_source_indexed(pclhip_icp* icp, const void* points,
   void* owned = nullptr;
   pclhip_status st = to_device(ctx, points, size_t(n) * stride, &dp, &owned);
   if (st != PCLHIP_OK) return st;
-  guard.add(owned);
+  if (owned != nullptr) {
+    // a host cloud: its staged copy stays with the registration, so that the moved cloud an alignment hands back
+    // (pclhip_icp_transform_source) does not upload the same records again
+    icp->src_records = owned;
+    icp->src_records_host = points;
+    icp->src_records_stride = stride;
+    icp->src_records_n = n;
+  }
   const void* dsel = nullptr;
   if (indices) {  // PCLBase::setIndices / setIndicesSource: only these points take part
     PCLHIP_REQUIRE(ctx, n_indices < 0x7FFFFFFFull, "too many indices");
@@ -1454,6 +1485,21 @@ pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_q
 
 pclhip_status pclhip_transform_cloud(pclhip_ctx* ctx, const float* T, int order, const void* in, void* out,
                                      size_t stride, uint64_t n, size_t normals_offset_bytes) {
+  return transform_cloud_impl(ctx, T, order, in, nullptr, out, stride, n, normals_offset_bytes);
+}
+
+pclhip_status pclhip_icp_transform_source(pclhip_icp* icp, const float* T, int order, const void* in, void* out,
+                                          size_t stride, uint64_t n, size_t normals_offset_bytes) {
+  if (!icp) return PCLHIP_ERR_INVALID;
+  const bool resident = icp->src_records != nullptr && in == icp->src_records_host && stride == icp->src_records_stride &&
+                        n == icp->src_records_n;
+  return transform_cloud_impl(icp->ctx, T, order, in, resident ? icp->src_records : nullptr, out, stride, n,
+                              normals_offset_bytes);
+}
+
+// `resident`: a device copy of the records at `in` that is known to be current (or nullptr: `in` is staged)
+static pclhip_status transform_cloud_impl(pclhip_ctx* ctx, const float* T, int order, const void* in, const void* resident,
+                                          void* out, size_t stride, uint64_t n, size_t normals_offset_bytes) {
   if (!ctx || !T) return PCLHIP_ERR_INVALID;
   PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
   PCLHIP_REQUIRE(ctx, normals_offset_bytes == 0 || normals_offset_bytes + 12 <= stride, "bad normals offset");
@@ -1462,9 +1508,10 @@ pclhip_status pclhip_transform_cloud(pclhip_ctx* ctx, const float* T, int order,
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   DeviceGuard guard(ctx);
   const size_t bytes = size_t(n) * stride;
-  const void* din = nullptr;
+  const void* din = resident;
   void* owned = nullptr;
-  pclhip_status st = to_device(ctx, in, bytes, &din, &owned);
+  pclhip_status st = PCLHIP_OK;
+  if (din == nullptr) st = to_device(ctx, in, bytes, &din, &owned);
   if (st != PCLHIP_OK) return st;
   guard.add(owned);
   void* dout = out;

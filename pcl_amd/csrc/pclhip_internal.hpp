@@ -177,6 +177,11 @@ struct pclhip_icp {
   pclhip_index* target = nullptr;
   uint64_t n_orig = 0;       // source records
   uint32_t n = 0;            // source points (all records; non-finite ones are flagged invalid)
+  // the staged device copy of a HOST source cloud's records (all fields), kept for pclhip_icp_transform_source
+  void* src_records = nullptr;
+  const void* src_records_host = nullptr;
+  size_t src_records_stride = 0;
+  uint64_t src_records_n = 0;
   float4* src_sorted0 = nullptr;   // Morton-ordered input (w = original index), pristine
   float4* src_cur = nullptr;       // working copy (input_transformed)
   float4* src_nrm_sorted0 = nullptr;  // source normals in the same order (symmetric objective), pristine

@@ -1,7 +1,7 @@
 """Compact A/B line: runs bench.py (config 3, no CPU baseline) and prints per-iteration mean search_ms + setup."""
 import json, subprocess, sys, collections
 steps = sys.argv[1] if len(sys.argv) > 1 else "10"
-out = subprocess.run([sys.executable, "bench.py", "--steps", steps, "--warmup", "5", "--no-cpu-baseline"] + sys.argv[2:],
+out = subprocess.run([sys.executable, "bench.py", "--steps", steps, "--warmup", "5", "--no-cpu-baseline", "--no-host-align"] + sys.argv[2:],
                      capture_output=True, text=True)
 line = [l for l in out.stdout.splitlines() if l.startswith("{")]
 if not line:
