@@ -7,16 +7,15 @@
 // Replaces the build half of pcl::KdTreeFLANN<PointT>::setInputCloud
 // (kdtree/include/pcl/kdtree/impl/kdtree_flann.hpp:99-136,428-498): non-finite points are
 // dropped, an optional index list selects a subset, results refer to original cloud indices.
-// Hand-written throughout on the default path; rocprim's radix sort is only used by the A/B variants
-// (PCLHIP_KD_TOP=sort, PCLHIP_KD_BOTTOM=sort, PCLHIP_ORDER=morton) and by the compaction of clouds that
-// contain non-finite points.
+// Hand-written throughout (no rocprim): the sorting variants of rounds 1 and 2 (a global radix sort per kd round, a
+// Morton order) lived here behind environment switches for A/B runs and were removed in round 3 -- DESIGN.md section 3
+// keeps their measurements.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstring>
 #include <string.h>
 
-#include <rocprim/rocprim.hpp>
 
 #include <cfloat>
 #include <cstdlib>
@@ -29,9 +28,6 @@
 namespace pclhip {
 
 namespace {
-
-constexpr int BB_BLOCK = 256;
-constexpr int BB_MAX_BLOCKS = 1024;
 
 __device__ __forceinline__ const float* record(const void* base, size_t stride, uint64_t i) {
   return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + i * stride);
@@ -46,112 +42,6 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
-}
-
-// partial[b] = {lo.xyz, hi.xyz} over the finite selected records handled by block b
-__global__ __launch_bounds__(BB_BLOCK) void bbox_partial_kernel(const void* pts, size_t stride, const int32_t* sel,
-                                                                uint64_t m, float* partial) {
-  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < m; i += uint64_t(gridDim.x) * blockDim.x) {
-    const float* p = record(pts, stride, sel ? uint64_t(sel[i]) : i);
-    const float x = p[0], y = p[1], z = p[2];
-    if (isfinite(x) && isfinite(y) && isfinite(z)) {
-      lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
-      hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
-    }
-  }
-  __shared__ float s[BB_BLOCK / 64][6];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const float a = wave_min(lo[d]), b = wave_max(hi[d]);
-    if (lane == 0) {
-      s[wave][d] = a;
-      s[wave][3 + d] = b;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    float v = s[0][threadIdx.x];
-    for (int w = 1; w < BB_BLOCK / 64; ++w) v = threadIdx.x < 3 ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
-    partial[blockIdx.x * 6 + threadIdx.x] = v;
-  }
-}
-
-// bbox[0..5] = lo, hi ; bbox[6] = scale (cells per unit), bbox[7] unused
-__global__ void bbox_final_kernel(const float* partial, int nblocks, float* bbox) {
-  const int t = threadIdx.x;
-  if (t < 6) {
-    float v = partial[t];
-    for (int b = 1; b < nblocks; ++b) v = t < 3 ? fminf(v, partial[b * 6 + t]) : fmaxf(v, partial[b * 6 + t]);
-    bbox[t] = v;
-  }
-  __syncthreads();
-  if (t == 0) {
-    const float ex = fmaxf(fmaxf(bbox[3] - bbox[0], bbox[4] - bbox[1]), bbox[5] - bbox[2]);
-    bbox[6] = (ex > 0.0f && isfinite(ex)) ? (2097152.0f / ex) : 0.0f;  // 2^21 cells along the longest axis
-    bbox[7] = 0.0f;
-  }
-}
-
-__device__ __forceinline__ uint64_t spread3(uint32_t v) {  // 21 bits -> every third bit
-  uint64_t x = v & 0x1FFFFFu;
-  x = (x | x << 32) & 0x1F00000000FFFFull;
-  x = (x | x << 16) & 0x1F0000FF0000FFull;
-  x = (x | x << 8) & 0x100F00F00F00F00Full;
-  x = (x | x << 4) & 0x10C30C30C30C30C3ull;
-  x = (x | x << 2) & 0x1249249249249249ull;
-  return x;
-}
-
-__global__ __launch_bounds__(256) void morton_kernel(const void* pts, size_t stride, const int32_t* sel, uint64_t m,
-                                                     const float* bbox, uint64_t* keys, uint32_t* vals,
-                                                     unsigned int* n_finite) {
-  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
-  bool fin = false;
-  if (i < m) {
-    const uint64_t rec = sel ? uint64_t(sel[i]) : i;
-    const float* p = record(pts, stride, rec);
-    const float x = p[0], y = p[1], z = p[2];
-    uint64_t key = ~0ull;
-    if (isfinite(x) && isfinite(y) && isfinite(z)) {
-      fin = true;
-      const float sc = bbox[6];
-      const float fx = (x - bbox[0]) * sc, fy = (y - bbox[1]) * sc, fz = (z - bbox[2]) * sc;
-      const uint32_t qx = uint32_t(fminf(fmaxf(fx, 0.0f), 2097151.0f));
-      const uint32_t qy = uint32_t(fminf(fmaxf(fy, 0.0f), 2097151.0f));
-      const uint32_t qz = uint32_t(fminf(fmaxf(fz, 0.0f), 2097151.0f));
-      key = spread3(qx) | (spread3(qy) << 1) | (spread3(qz) << 2);
-    }
-    keys[i] = key;
-    vals[i] = uint32_t(rec);
-  }
-  // one atomic per block (a per-wave atomic on a single counter serialises: 1.8 ms at 10M points)
-  __shared__ unsigned int blk;
-  if (threadIdx.x == 0) blk = 0;
-  __syncthreads();
-  const unsigned long long b = __builtin_amdgcn_ballot_w64(fin);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&blk, (unsigned int)__builtin_popcountll(b));
-  __syncthreads();
-  if (threadIdx.x == 0 && blk) atomicAdd(n_finite, blk);
-}
-
-// sorted[j] = (xyz of record vals[j], bits(vals[j])); rank[vals[j]] = j for the finite ones
-__global__ __launch_bounds__(256) void gather_kernel(const void* pts, size_t stride, const uint32_t* vals, uint64_t m,
-                                                     const unsigned int* n_finite, float4* out, uint32_t out_cap,
-                                                     uint32_t* rank, int keep_nonfinite) {
-  const uint64_t j = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
-  if (j >= out_cap) return;
-  const uint32_t nf = *n_finite;
-  const uint64_t live = keep_nonfinite ? m : nf;
-  if (j < live) {
-    const uint32_t rec = vals[j];
-    const float* p = record(pts, stride, rec);
-    out[j] = make_float4(p[0], p[1], p[2], __uint_as_float(rec));
-    if (rank && j < nf) rank[rec] = uint32_t(j);
-  } else {
-    out[j] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(NO_INDEX));  // sentinel pad
-  }
 }
 
 // one 16-lane group per leaf
@@ -357,96 +247,6 @@ __global__ __launch_bounds__(256) void node_box_kernel(const Box* child, uint32_
 
 }  // namespace
 
-pclhip_status morton_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
-                           const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
-                           uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
-                           uint32_t* rank_or_null) {
-  hipStream_t s = ctx->stream;
-  const uint64_t m = dev_sel ? n_sel : n_records;
-  if (m == 0) {
-    if (out_capacity) {
-      unsigned int zero = 0;
-      unsigned int* dz = nullptr;
-      PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &dz, sizeof zero));
-      PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(dz, &zero, sizeof zero, hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(gather_kernel, dim3((out_capacity + 255) / 256), dim3(256), 0, s, dev_points, stride,
-                         (const uint32_t*)nullptr, uint64_t(0), dz, out_sorted, out_capacity, (uint32_t*)nullptr, 0);
-      PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-      (void)dev_free(ctx, dz);
-    }
-    *out_n_finite = 0;
-    for (int d = 0; d < 3; ++d) lo[d] = hi[d] = 0;
-    return PCLHIP_OK;
-  }
-  // workspace: keys x2, vals x2, bbox partials, bbox, counter, rocprim temp
-  size_t temp_bytes = 0;
-  {
-    uint64_t* kn = nullptr;
-    uint32_t* vn = nullptr;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, temp_bytes, kn, kn, vn, vn, size_t(m), 0, 64, s);
-    PCLHIP_CHECK_HIP(ctx, e);
-  }
-  auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
-  const size_t off_k0 = 0;
-  const size_t off_k1 = off_k0 + align(m * sizeof(uint64_t));
-  const size_t off_v0 = off_k1 + align(m * sizeof(uint64_t));
-  const size_t off_v1 = off_v0 + align(m * sizeof(uint32_t));
-  const size_t off_pb = off_v1 + align(m * sizeof(uint32_t));
-  const size_t off_bb = off_pb + align(size_t(BB_MAX_BLOCKS) * 6 * sizeof(float));
-  const size_t off_cn = off_bb + align(8 * sizeof(float));
-  const size_t off_tmp = off_cn + align(sizeof(unsigned int));
-  const size_t total = off_tmp + align(temp_bytes);
-  pclhip_status st = ensure_scratch(ctx, total);
-  if (st != PCLHIP_OK) return st;
-  char* base = static_cast<char*>(ctx->scratch);
-  uint64_t* k0 = reinterpret_cast<uint64_t*>(base + off_k0);
-  uint64_t* k1 = reinterpret_cast<uint64_t*>(base + off_k1);
-  uint32_t* v0 = reinterpret_cast<uint32_t*>(base + off_v0);
-  uint32_t* v1 = reinterpret_cast<uint32_t*>(base + off_v1);
-  float* pb = reinterpret_cast<float*>(base + off_pb);
-  float* bb = reinterpret_cast<float*>(base + off_bb);
-  unsigned int* cn = reinterpret_cast<unsigned int*>(base + off_cn);
-  void* tmp = base + off_tmp;
-
-  int nb = int((m + BB_BLOCK * 8 - 1) / (BB_BLOCK * 8));
-  if (nb > BB_MAX_BLOCKS) nb = BB_MAX_BLOCKS;
-  if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(BB_BLOCK), 0, s, dev_points, stride, dev_sel, m, pb);
-  hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, s, pb, nb, bb);
-  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(cn, 0, sizeof(unsigned int), s));
-  hipLaunchKernelGGL(morton_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride, dev_sel, m, bb,
-                     k0, v0, cn);
-  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
-  PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, temp_bytes, k0, k1, v0, v1, size_t(m), 0, 64, s));
-  if (rank_or_null) PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(rank_or_null, 0xFF, n_records * sizeof(uint32_t), s));
-  hipLaunchKernelGGL(gather_kernel, dim3((out_capacity + 255) / 256), dim3(256), 0, s, dev_points, stride, v1, m, cn,
-                     out_sorted, out_capacity, rank_or_null, keep_nonfinite_at_end ? 1 : 0);
-  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
-  float hb[8];
-  unsigned int hn = 0;
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(hb, bb, sizeof hb, hipMemcpyDeviceToHost, s));
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&hn, cn, sizeof hn, hipMemcpyDeviceToHost, s));
-  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-  *out_n_finite = hn;
-  for (int d = 0; d < 3; ++d) {
-    lo[d] = hb[d];
-    hi[d] = hb[3 + d];
-  }
-  return PCLHIP_OK;
-}
-
-
-// =================================================================================================
-// kd ordering
-// =================================================================================================
-// Z-order (Morton) runs of a 2-D surface embedded in 3-D jump: on the benchmark surface the boxes
-// of 16 consecutive Morton-sorted points overlap 4.6x and a few of them span the whole domain, so
-// one wavefront ends up scanning every leaf.  The order produced here has no jumps: R =
-// ceil(log4(#leaves)) rounds, each round cuts every aligned block ("segment") of LEAF*4^(R-r+1) points
-// into four slabs at the quartiles along the widest axis of its bounding box, so every aligned block of
-// LEAF*4^j points ends up as one cell of a 4-ary kd partition: leaf boxes do not overlap and 64-point
-// query groups are compact.  Segments above 4096 points are cut by selection + partition (kp_*), the rest
-// by kd_block_kernel; the variant that radix-sorts (segment, coordinate) keys once per round is kept for A/B.
 namespace {
 
 constexpr int KD_CHUNK_MAX = 4096;
@@ -479,60 +279,13 @@ __global__ __launch_bounds__(256) void kd_chunk_box_kernel(const float4* __restr
   }
 }
 
-// one wavefront per segment: reduce its chunk boxes, pick the widest axis
-__global__ __launch_bounds__(256) void kd_axis_kernel(const Box* __restrict__ chunk_box, uint32_t nchunks,
-                                                      uint32_t chunks_per_seg, uint32_t nseg,
-                                                      uint8_t* __restrict__ axis) {
-  const uint32_t sgm = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-  const uint32_t lane = threadIdx.x & 63;
-  if (sgm >= nseg) return;
-  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  const uint64_t b = uint64_t(sgm) * chunks_per_seg;
-  uint64_t e = b + chunks_per_seg;
-  if (e > nchunks) e = nchunks;
-  for (uint64_t i = b + lane; i < e; i += WAVE) {
-    const Box bx = chunk_box[i];
-    lo[0] = fminf(lo[0], bx.lo.x); lo[1] = fminf(lo[1], bx.lo.y); lo[2] = fminf(lo[2], bx.lo.z);
-    hi[0] = fmaxf(hi[0], bx.hi.x); hi[1] = fmaxf(hi[1], bx.hi.y); hi[2] = fmaxf(hi[2], bx.hi.z);
-  }
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    lo[d] = wave_min(lo[d]);
-    hi[d] = wave_max(hi[d]);
-  }
-  if (lane == 0) {
-    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-    uint8_t a = 0;
-    float best = ex;
-    if (ey > best) { best = ey; a = 1; }
-    if (ez > best) { a = 2; }
-    axis[sgm] = a;
-  }
-}
 
 __device__ __forceinline__ uint32_t orderable(float f) {
   const uint32_t u = __float_as_uint(f);
   return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 
-__global__ __launch_bounds__(256) void kd_key_kernel(const float4* __restrict__ pts, uint32_t n, uint64_t seg_size,
-                                                     const uint8_t* __restrict__ axis, uint64_t* __restrict__ keys,
-                                                     uint32_t* __restrict__ vals) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t sgm = uint32_t(uint64_t(i) / seg_size);
-  const float4 p = pts[i];
-  const uint8_t a = axis[sgm];
-  const float c = a == 0 ? p.x : (a == 1 ? p.y : p.z);
-  keys[i] = (uint64_t(sgm) << 32) | orderable(c);
-  vals[i] = i;
-}
 
-__global__ __launch_bounds__(256) void kd_permute_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ vals,
-                                                         uint32_t n, float4* __restrict__ out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = in[vals[i]];
-}
 
 // ---- last kd round in a wavefront -----------------------------------------------------------------
 // The rounds above cut every segment into four slabs along its widest axis.  Done once more at the bottom
@@ -1138,14 +891,8 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
     PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
     return PCLHIP_OK;
   }
-  size_t temp_bytes = 0, temp32 = 0;
-  {
-    uint64_t* kn = nullptr;
-    uint32_t* vn = nullptr;
-    PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, kn, kn, vn, vn, size_t(m), 0, 64, s));
-    PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp32, vn, vn, vn, vn, size_t(m), 0, 1, s));
-    if (temp32 > temp_bytes) temp_bytes = temp32;
-  }
+  // scratch of the stable compaction of non-finite records: the partials of one scan (device_scan.hpp)
+  const size_t temp_bytes = size_t((m + SC_BLOCK - 1) / SC_BLOCK) * sizeof(uint2);
   auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
   const uint32_t max_chunks = uint32_t((m + 63) / 64);
   const size_t off_k0 = 0;
@@ -1172,7 +919,6 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
   float4* pa = reinterpret_cast<float4*>(base + off_pa);
   float4* pb = reinterpret_cast<float4*>(base + off_pb);
   Box* cb = reinterpret_cast<Box*>(base + off_cb);
-  uint8_t* ax = reinterpret_cast<uint8_t*>(base + off_ax);
   unsigned int* cn = reinterpret_cast<unsigned int*>(base + off_cn);
   void* tmp = base + off_tmp;
 
@@ -1226,17 +972,9 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
       const uint32_t nchunks = uint32_t((uint64_t(nf) + chunk - 1) / chunk);
       const uint32_t chunks_per_seg = uint32_t(seg_size / chunk);
       const uint32_t nseg = uint32_t((uint64_t(nf) + seg_size - 1) / seg_size);
-      static const bool square_leaves = [] {  // A/B: PCLHIP_KD_LEAF=strip keeps the four-slab cut at the bottom too
-        const char* e = getenv("PCLHIP_KD_LEAF");
-        return !(e && strcmp(e, "strip") == 0);
-      }();
-      static const bool block_rounds = [] {  // A/B: PCLHIP_KD_BOTTOM=sort keeps one global radix sort per round
-        const char* e = getenv("PCLHIP_KD_BOTTOM");
-        return !(e && strcmp(e, "sort") == 0);
-      }();
-      if (r > 0 && block_rounds && seg_size <= uint64_t(KDB_N)) {  // the remaining rounds fit one workgroup's LDS
+      if (r > 0 && seg_size <= uint64_t(KDB_N)) {  // the remaining rounds fit one workgroup's LDS
         hipLaunchKernelGGL(kd_block_kernel, dim3(unsigned((uint64_t(nf) + KDB_N - 1) / KDB_N)), dim3(KDB_THREADS), 0, s, cur, nf,
-                           nxt, uint32_t(seg_size), square_leaves ? 32u : 64u);
+                           nxt, uint32_t(seg_size), 32u);
         if (keep_nonfinite_at_end && m > nf)
           PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(nxt + nf, cur + nf, (m - nf) * sizeof(float4), hipMemcpyDeviceToDevice, s));
         float4* t = cur;
@@ -1244,7 +982,7 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
         nxt = t;
         break;
       }
-      if (r == R && r > 0 && square_leaves) {  // 64-point cells: two binary cuts inside one wavefront each
+      if (r == R && r > 0) {  // 64-point cells: two binary cuts inside one wavefront each
         hipLaunchKernelGGL(kd_cell_split_kernel, dim3(unsigned((uint64_t(nf) + 255) / 256)), dim3(256), 0, s, cur, nf, nxt);
         if (keep_nonfinite_at_end && m > nf)
           PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(nxt + nf, cur + nf, (m - nf) * sizeof(float4), hipMemcpyDeviceToDevice, s));
@@ -1271,11 +1009,7 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
         }
         continue;
       }
-      static const bool partition_rounds = [] {  // A/B: PCLHIP_KD_TOP=sort keeps the radix sort of (segment, coordinate)
-        const char* e = getenv("PCLHIP_KD_TOP");
-        return !(e && strcmp(e, "sort") == 0);
-      }();
-      if (partition_rounds && chunk == uint32_t(KP_BLOCK) && seg_size % KP_BLOCK == 0) {
+      if (chunk == uint32_t(KP_BLOCK) && seg_size % KP_BLOCK == 0) {
         // selection + partition round (see kp_* above): blocks of 4096 points, each inside one segment
         const uint32_t nblocks = nchunks, blocks_per_seg = chunks_per_seg;
         uint32_t* keys = reinterpret_cast<uint32_t*>(k0);
@@ -1307,19 +1041,10 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
         nxt = t;
         continue;
       }
-      hipLaunchKernelGGL(kd_axis_kernel, dim3(unsigned((uint64_t(nseg) * WAVE + 255) / 256)), dim3(256), 0, s, cb, nchunks,
-                         chunks_per_seg, nseg, ax);
-      hipLaunchKernelGGL(kd_key_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, cur, nf, seg_size, ax, k0, v0);
-      int seg_bits = 0;
-      while ((uint64_t(1) << seg_bits) < uint64_t(nseg)) ++seg_bits;
-      PCLHIP_CHECK_HIP(ctx, rocprim::radix_sort_pairs(tmp, temp_bytes, k0, k1, v0, v1, size_t(nf), 0, 32 + seg_bits, s));
-      hipLaunchKernelGGL(kd_permute_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, cur, v1, nf, nxt);
-      // the non-finite tail (if kept) rides along unchanged
-      if (keep_nonfinite_at_end && m > nf)
-        PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(nxt + nf, cur + nf, (m - nf) * sizeof(float4), hipMemcpyDeviceToDevice, s));
-      float4* t = cur;
-      cur = nxt;
-      nxt = t;
+      // every segment above KDB_N points is a multiple of KP_BLOCK (16 * 4^j >= 4096) and everything below goes
+      // through kd_block_kernel: no other round shape exists
+      set_error(ctx, "kd order: unexpected round shape");
+      return PCLHIP_ERR_STATE;
     }
   }
   const uint64_t live = keep_nonfinite_at_end ? m : nf;
@@ -1334,10 +1059,6 @@ pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stri
                             const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
                             uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
                             uint32_t* rank_or_null, const float* scale) {
-  const char* e = getenv("PCLHIP_ORDER");
-  if (e && strcmp(e, "morton") == 0 && scale == nullptr)
-    return morton_order(ctx, dev_points, stride, n_records, dev_sel, n_sel, out_sorted, out_capacity, out_n_finite, lo, hi,
-                        keep_nonfinite_at_end, rank_or_null);
   return kd_order(ctx, dev_points, stride, n_records, dev_sel, n_sel, out_sorted, out_capacity, out_n_finite, lo, hi,
                   keep_nonfinite_at_end, rank_or_null, false, scale);
 }
@@ -1462,7 +1183,7 @@ pclhip_status build_boxes(pclhip_index* ix) {
 
 void preload_index_build_kernels() {
   hipFuncAttributes a;
-  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(bbox_final_kernel));
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(leaf_box_kernel));
 }
 
 }  // namespace pclhip

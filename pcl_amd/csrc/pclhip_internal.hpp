@@ -297,18 +297,13 @@ bool is_device_pointer(const void* p);
 pclhip_status ensure_scratch(pclhip_ctx* ctx, size_t bytes);
 
 // ---- build steps (index_build.hip) ----------------------------------------------------------
-// Sort `n` records (strided, device) into Morton order.  Outputs: sorted float4 (w = original
-// index), number of finite points, bbox.  `sel` optionally selects a subset (device int32).
-pclhip_status morton_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
-                           const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted,
-                           uint32_t out_capacity, uint32_t* out_n_finite, float lo[3], float hi[3],
-                           bool keep_nonfinite_at_end, uint32_t* rank_or_null);
-// Same contract, kd order by radix-sort rounds (the production order; see index_build.hip).
+// Sort `n` records (strided, device) into kd order (index_build.hip).  Outputs: sorted float4 (w = original index),
+// number of finite points, bbox.  `sel` optionally selects a subset (device int32).
 pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
                        const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
                        uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
                        uint32_t* rank_or_null, bool ids_from_w = false, const float* scale = nullptr);
-// dispatches on PCLHIP_ORDER=morton|kd (default kd); morton is kept for A/B measurements only
+// the order of indices and sources alike: kd_order without ids taken from w
 pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, uint64_t n_records,
                             const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
                             uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,

@@ -2,19 +2,18 @@
 // Replaces pcl::KdTreeFLANN<PointT>::radiusSearch (kdtree/include/pcl/kdtree/impl/kdtree_flann.hpp
 // :372-414): all indexed points with squared distance < float(radius*radius) (FLANN's
 // RadiusResultSet keeps `dist < radius`), ascending by (distance, index), optionally only the
-// max_nn nearest.  Two traversals (count, then fill at exclusive-scan offsets) + one segmented
-// radix sort of (distance, index) keys.
+// max_nn nearest.  Two traversals (count, then fill at exclusive-scan offsets) + one segmented sort of
+// (distance, index) keys -- scan and sort hand-written (segsort.hpp).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string.h>
-
-#include <rocprim/rocprim.hpp>
 
 #include <cfloat>
 #include <cmath>
 
 #include "traverse.hpp"
 #include "normals_math.hpp"
+#include "segsort.hpp"
 
 namespace pclhip {
 namespace {
@@ -98,15 +97,6 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(IndexView ix, const float
   }
 }
 
-__global__ void clamp_counts_kernel(const uint32_t* counts, uint32_t nq, uint32_t max_nn, unsigned long long* clamped) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nq) clamped[i] = (max_nn && counts[i] > max_nn) ? max_nn : counts[i];
-}
-__global__ void widen_counts_kernel(const uint32_t* counts, uint32_t nq, unsigned long long* wide) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nq) wide[i] = counts[i];
-}
-
 // sorted full segments -> (possibly truncated) output CSR
 __global__ void radius_emit_kernel(const uint64_t* __restrict__ keys, const unsigned long long* __restrict__ full_off,
                                    const unsigned long long* __restrict__ out_off, uint32_t nq,
@@ -162,10 +152,6 @@ __global__ __launch_bounds__(BLOCK) void normals_from_radius_kernel(IndexView ix
   nrm_sorted[by_slot ? __float_as_uint(p.w) : i] = out;
 }
 
-struct SubBase {  // segment offsets relative to a chunk's first key
-  unsigned long long base;
-  __host__ __device__ unsigned long long operator()(unsigned long long x) const { return x - base; }
-};
 
 struct Guard {
   pclhip_ctx* ctx = nullptr;
@@ -185,7 +171,7 @@ struct Guard {
 }  // namespace
 void preload_radius_kernels() {
   hipFuncAttributes a;
-  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(widen_counts_kernel));
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(radius_emit_kernel));
 }
 }  // namespace pclhip
 
@@ -236,15 +222,8 @@ extern "C" pclhip_status pclhip_radius_search(pclhip_index* ix, const void* quer
   hipLaunchKernelGGL(radius_kernel<false>, dim3(grid), dim3(BLOCK), 0, s, v, qs, n, r2, counts,
                      (const unsigned long long*)nullptr, (uint64_t*)nullptr);
   // exclusive scans of the full counts (segment starts) and of the clamped counts (output CSR)
-  size_t tb = 0;
-  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(wide + n, 0, 8, s));
-  PCLHIP_CHECK_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, wide, full_off, 0ull, size_t(n + 1), rocprim::plus<unsigned long long>(), s));
-  void* tmp = nullptr;
-  PCLHIP_CHECK_HIP(ctx, g.alloc(&tmp, tb));
-  hipLaunchKernelGGL(widen_counts_kernel, dim3((n + 255) / 256), dim3(256), 0, s, counts, n, wide);
-  PCLHIP_CHECK_HIP(ctx, rocprim::exclusive_scan(tmp, tb, wide, full_off, 0ull, size_t(n + 1), rocprim::plus<unsigned long long>(), s));
-  hipLaunchKernelGGL(clamp_counts_kernel, dim3((n + 255) / 256), dim3(256), 0, s, counts, n, max_nn, wide);
-  PCLHIP_CHECK_HIP(ctx, rocprim::exclusive_scan(tmp, tb, wide, out_off, 0ull, size_t(n + 1), rocprim::plus<unsigned long long>(), s));
+  launch_exclusive_scan_u64(s, counts, n, 0u, wide, full_off);
+  launch_exclusive_scan_u64(s, counts, n, max_nn, wide, out_off);
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out_offsets, out_off, size_t(n + 1) * 8, hipMemcpyDeviceToHost, s));
   unsigned long long full_total = 0;
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&full_total, full_off + n, 8, hipMemcpyDeviceToHost, s));
@@ -256,21 +235,18 @@ extern "C" pclhip_status pclhip_radius_search(pclhip_index* ix, const void* quer
     set_error(ctx, "radius search: output capacity too small (out_total holds the required size)");
     return PCLHIP_ERR_OVERFLOW;
   }
-  uint64_t *k0 = nullptr, *k1 = nullptr;
+  uint64_t* k0 = nullptr;
   PCLHIP_CHECK_HIP(ctx, g.alloc(&k0, size_t(full_total) * 8));
-  PCLHIP_CHECK_HIP(ctx, g.alloc(&k1, size_t(full_total) * 8));
   hipLaunchKernelGGL(radius_kernel<true>, dim3(grid), dim3(BLOCK), 0, s, v, qs, n, r2, counts, full_off, k0);
-  size_t sb = 0;
-  PCLHIP_CHECK_HIP(ctx, rocprim::segmented_radix_sort_keys(nullptr, sb, k0, k1, size_t(full_total), n, full_off, full_off + 1, 0, 64, s));
-  void* stmp = nullptr;
-  PCLHIP_CHECK_HIP(ctx, g.alloc(&stmp, sb));
-  PCLHIP_CHECK_HIP(ctx, rocprim::segmented_radix_sort_keys(stmp, sb, k0, k1, size_t(full_total), n, full_off, full_off + 1, 0, 64, s));
+  uint32_t* long_list = nullptr;
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&long_list, size_t(n + 1) * 4));  // [n]: the counter
+  launch_segmented_sort_u64(s, ctx->num_cus, k0, full_off, 0ull, 0u, n, long_list, long_list + n);
   int32_t* d_idx = out_idx;
   float* d_d2 = out_d2;
   const bool idx_dev = is_device_pointer(out_idx), d2_dev = is_device_pointer(out_d2);
   if (!idx_dev) PCLHIP_CHECK_HIP(ctx, g.alloc(&d_idx, size_t(total) * 4));
   if (!d2_dev) PCLHIP_CHECK_HIP(ctx, g.alloc(&d_d2, size_t(total) * 4));
-  hipLaunchKernelGGL(radius_emit_kernel, dim3(n), dim3(64), 0, s, k1, full_off, out_off, n, d_idx, d_d2);
+  hipLaunchKernelGGL(radius_emit_kernel, dim3(n), dim3(64), 0, s, k0, full_off, out_off, n, d_idx, d_d2);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   if (!idx_dev) PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out_idx, d_idx, size_t(total) * 4, hipMemcpyDeviceToHost, s));
   if (!d2_dev) PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out_d2, d_d2, size_t(total) * 4, hipMemcpyDeviceToHost, s));
@@ -335,13 +311,7 @@ static pclhip_status normals_radius_impl(pclhip_index* ix, const float4* queries
   (void)hipEventRecord(e0, s);
   hipLaunchKernelGGL((radius_kernel<false, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, v, q, n, r2, counts,
                      (const unsigned long long*)nullptr, (uint64_t*)nullptr, 0u, 0ull);
-  size_t tb = 0;
-  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(wide + n, 0, 8, s));
-  PCLHIP_CHECK_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, wide, off, 0ull, size_t(n + 1), rocprim::plus<unsigned long long>(), s));
-  void* tmp = nullptr;
-  PCLHIP_CHECK_HIP(ctx, g.alloc(&tmp, tb));
-  hipLaunchKernelGGL(widen_counts_kernel, dim3((n + 255) / 256), dim3(256), 0, s, counts, n, wide);
-  PCLHIP_CHECK_HIP(ctx, rocprim::exclusive_scan(tmp, tb, wide, off, 0ull, size_t(n + 1), rocprim::plus<unsigned long long>(), s));
+  launch_exclusive_scan_u64(s, counts, n, 0u, wide, off);
   std::vector<unsigned long long> h_off(size_t(n) + 1);
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(h_off.data(), off, h_off.size() * 8, hipMemcpyDeviceToHost, s));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
@@ -356,31 +326,20 @@ static pclhip_status normals_radius_impl(pclhip_index* ix, const float4* queries
     cuts.push_back(b);
     a = b;
   }
-  uint64_t *k0 = nullptr, *k1 = nullptr;
+  uint64_t* k0 = nullptr;
   PCLHIP_CHECK_HIP(ctx, g.alloc(&k0, size_t(max_keys) * 8));
-  PCLHIP_CHECK_HIP(ctx, g.alloc(&k1, size_t(max_keys) * 8));
-  void* stmp = nullptr;
-  size_t stmp_bytes = 0;
+  uint32_t* long_list = nullptr;
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&long_list, size_t(n + 1) * 4));  // [n]: the counter
   for (size_t c = 0; c + 1 < cuts.size(); ++c) {
     const uint32_t a = cuts[c], b = cuts[c + 1];
     const unsigned long long base = h_off[a], nkeys = h_off[b] - h_off[a];
     if (nkeys > 0) {
       hipLaunchKernelGGL((radius_kernel<true, true>), dim3(grid_for(b - a)), dim3(BLOCK), 0, s, v, q, b, r2, counts, off,
                          k0, a, base);
-      // segment offsets of this chunk, relative to its first key: sort with begin/end iterators shifted by base
-      const SubBase sub{base};
-      auto begin_it = rocprim::make_transform_iterator(off + a, sub);
-      auto end_it = rocprim::make_transform_iterator(off + a + 1, sub);
-      size_t sb = 0;
-      PCLHIP_CHECK_HIP(ctx, rocprim::segmented_radix_sort_keys(nullptr, sb, k0, k1, size_t(nkeys), b - a, begin_it, end_it, 0, 64, s));
-      if (sb > stmp_bytes) {
-        PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-        PCLHIP_CHECK_HIP(ctx, g.alloc(&stmp, sb));
-        stmp_bytes = sb;
-      }
-      PCLHIP_CHECK_HIP(ctx, rocprim::segmented_radix_sort_keys(stmp, sb, k0, k1, size_t(nkeys), b - a, begin_it, end_it, 0, 64, s));
+      // the chunk's segments start at off[a .. b] - base
+      launch_segmented_sort_u64(s, ctx->num_cus, k0, off, base, a, b, long_list, long_list + n);
     }
-    hipLaunchKernelGGL(normals_from_radius_kernel, dim3((b - a + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, v, ix->rank, q, self ? 0 : 1, k1,
+    hipLaunchKernelGGL(normals_from_radius_kernel, dim3((b - a + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, v, ix->rank, q, self ? 0 : 1, k0,
                        off, base, a, b, vp[0], vp[1], vp[2], dst, d_nan);
   }
   (void)hipEventRecord(e1, s);

@@ -1419,9 +1419,7 @@ static bool standoff_enabled() {  // A/B: PCLHIP_STANDOFF=0 keeps traverse() for
 
 static int search_skip_flag() {
   static const int skip = [] {  // A/B: PCLHIP_ICP_SKIP=0 always descends from the root
-    const char* e = getenv("PCLHIP_ICP_SKIP");
-    const char* o = getenv("PCLHIP_ORDER");  // the shortcut relies on the kd order (disjoint cells)
-    if (o && !strcmp(o, "morton")) return 0;
+    const char* e = getenv("PCLHIP_ICP_SKIP");  // (the shortcut relies on the kd order: cells with disjoint interiors)
     return (e && atoi(e) == 0) ? 0 : 2;
   }();
   return skip;
