@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--points", type=int, default=0, help="override the config's points per cloud (per GPU)")
     ap.add_argument("--knn", type=int, default=8, help="k of NormalEstimation")
     ap.add_argument("--replicated", action="store_true", help="config 5: replicate the target instead of sharding it")
+    ap.add_argument("--rejectors", default="", help="comma list of median,trimmed,one_to_one,distance: the rejector chain "
+                                                     "inside the device-driven loop (configs 2/3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-align", action="store_true", help="skip the host-boundary timing (examples/bench_pcl_align.cpp)")
     return ap.parse_args()
@@ -154,6 +156,21 @@ def main():
     icp.setTransformationEpsilon(1e-10)
     if comm is not None:
         icp.setCommunicator(comm)
+    for name in [r for r in args.rejectors.split(",") if r]:
+        if name == "median":
+            rej = pcl_amd.CorrespondenceRejectorMedianDistance()
+            rej.setMedianFactor(2.0)
+        elif name == "trimmed":
+            rej = pcl_amd.CorrespondenceRejectorTrimmed()
+            rej.setOverlapRatio(0.9)
+        elif name == "one_to_one":
+            rej = pcl_amd.CorrespondenceRejectorOneToOne()
+        elif name == "distance":
+            rej = pcl_amd.CorrespondenceRejectorDistance()
+            rej.setMaximumDistance(0.05)
+        else:
+            raise SystemExit("unknown rejector %r" % name)
+        icp.addCorrespondenceRejector(rej)
     source_order_ms = icp.sourceOrderMs()
 
     if args.warmup > 0:
@@ -220,6 +237,7 @@ def main():
                                           "(BASELINE.json; `value` is the whole-job aggregate, ms/iteration = ms_per_step, "
                                           "HBM GB/s = roofline.achieved)",
                        "points_per_gpu": n, "target_points": n, "mode": "p2plane" if mode == 1 else "p2point",
+                       "rejectors": args.rejectors or None,
                        "loop": "device-driven (pclhip_icp_run_steps): search, accumulate, reduce, solve + convergence "
                                "kernels queued back to back",
                        "parallelism": "source slab sharded x%d, target replicated%s" %

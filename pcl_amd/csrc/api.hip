@@ -348,6 +348,23 @@ void preload_code_objects(pclhip_ctx* ctx) {
 }
 }  // namespace pclhip
 
+pclhip_status pclhip::sharded_filters_ok(pclhip_icp* icp) {
+  pclhip_ctx* ctx = icp->ctx;
+  if (icp_is_sharded(icp)) {
+    // With the source sharded over ranks, MedianDistance / Trimmed thresholds, OneToOne conflicts and the
+    // reciprocal test would be evaluated per slab, which is not what a single-GPU (or the reference's) run
+    // computes.  Only per-pair filters (Distance) commute with the sharding.
+    bool global_filter = icp->reciprocal;
+    for (const pclhip_rejector& r : icp->rejectors) global_filter = global_filter || r.kind != PCLHIP_REJ_DISTANCE;
+    if (global_filter) {
+      set_error(ctx, "multi-GPU (all-reduce) iterations support only the Distance rejector: MedianDistance, Trimmed, "
+                     "OneToOne and reciprocal correspondences need cloud-global decisions");
+      return PCLHIP_ERR_STATE;
+    }
+  }
+  return PCLHIP_OK;
+}
+
 extern "C" {
 
 const char* pclhip_version(void) { return "pclhip 0.1 (gfx950)"; }
@@ -945,6 +962,8 @@ void pclhip_icp_destroy(pclhip_icp* icp) {
   icp_free_source(icp);
   if (icp->sums_dev) (void)dev_free(icp->ctx, icp->sums_dev);
   if (icp->sums_host) (void)hipHostFree(icp->sums_host);
+  if (icp->rej_state) (void)dev_free(icp->ctx, icp->rej_state);
+  if (icp->rej_state_host) (void)hipHostFree(icp->rej_state_host);
   if (icp->ctl) (void)dev_free(icp->ctx, icp->ctl);
   if (icp->ctl_host) (void)hipHostFree(icp->ctl_host);
   if (icp->steps) (void)hipHostFree(icp->steps);
@@ -1080,7 +1099,11 @@ pclhip_status pclhip_icp_set_rejectors(pclhip_icp* icp, const pclhip_rejector* l
   return PCLHIP_OK;
 }
 
-double pclhip_icp_last_median_distance(const pclhip_icp* icp) { return icp ? icp->last_median : 0.0; }
+double pclhip_icp_last_median_distance(const pclhip_icp* icp) {
+  if (!icp || !icp->rej_state_host) return 0.0;
+  (void)hipStreamSynchronize(icp->ctx->stream);  // the chain mirrors its state to pinned memory stream-ordered
+  return icp->rej_state_host->median;
+}
 
 pclhip_status pclhip_icp_set_reciprocal(pclhip_icp* icp, int enable) {
   if (!icp) return PCLHIP_ERR_INVALID;
@@ -1121,17 +1144,9 @@ pclhip_status pclhip_icp_iterate(pclhip_icp* icp, const float T_prev[16], double
     return PCLHIP_ERR_STATE;
   }
   PCLHIP_REQUIRE(ctx, icp->src_cur != nullptr, "no source cloud set");
-  if (icp_is_sharded(icp)) {
-    // With the source sharded over ranks, MedianDistance / Trimmed thresholds, OneToOne conflicts and the
-    // reciprocal test would be evaluated per slab, which is not what a single-GPU (or the reference's) run
-    // computes.  Only per-pair filters (Distance) commute with the sharding.
-    bool global_filter = icp->reciprocal;
-    for (const pclhip_rejector& r : icp->rejectors) global_filter = global_filter || r.kind != PCLHIP_REJ_DISTANCE;
-    if (global_filter) {
-      set_error(ctx, "multi-GPU (all-reduce) iterations support only the Distance rejector: MedianDistance, Trimmed, "
-                     "OneToOne and reciprocal correspondences need cloud-global decisions");
-      return PCLHIP_ERR_STATE;
-    }
+  {
+    const pclhip_status sf = sharded_filters_ok(icp);
+    if (sf != PCLHIP_OK) return sf;
   }
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   // correspondence_estimation.hpp:161,176: drop if double(d2) > max_dist*max_dist
@@ -1178,14 +1193,19 @@ pclhip_status pclhip_icp_align(pclhip_icp* icp, const pclhip_icp_params* params,
   pclhip_ctx* ctx = icp->ctx;
   static const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   std::memset(res, 0, sizeof *res);
-  // The plain loop runs on the device (icp_loop.hip): no read-back, host solve or reset copy between
-  // iterations.  Rejectors and reciprocal correspondences need host decisions per iteration and use the
-  // host-driven loop below (also selectable with PCLHIP_ICP_HOST_LOOP=1 for A/B and for the twin test).
+  // The loop runs on the device (icp_loop.hip): no read-back, host solve or reset copy between iterations; a
+  // rejector chain is part of it (its counts, ranks and thresholds stay in device memory, rejectors.hip).  Reciprocal
+  // correspondences build a source index per iteration, which synchronises: they use the host-driven loop below
+  // (also selectable with PCLHIP_ICP_HOST_LOOP=1 for A/B and for the twin test).
   static const bool host_loop = [] {
     const char* e = getenv("PCLHIP_ICP_HOST_LOOP");
     return e && atoi(e) == 1;
   }();
-  if (!host_loop && !icp->reciprocal && icp->rejectors.empty()) {
+  {
+    const pclhip_status sf = sharded_filters_ok(icp);
+    if (sf != PCLHIP_OK) return sf;
+  }
+  if (!host_loop && !icp->reciprocal) {
     if (params->mode != PCLHIP_ICP_POINT_TO_POINT && params->mode != PCLHIP_ICP_POINT_TO_PLANE &&
         params->mode != PCLHIP_ICP_SYMMETRIC) {
       set_error(ctx, "unknown ICP mode");
@@ -1448,6 +1468,7 @@ pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_q
       d.push_back(hd[i]);
     }
   const size_t c = q.size();
+  if (filtered && icp->trim_pending && icp->rej_state_host && icp->rej_state_host->trimmed) icp->fetch_order = 2;
   if (filtered && icp->fetch_order != 0 && c > 1) {
     // the reference's output order after the chain: ONE_TO_ONE sorts by (match, distance)
     // (correspondence_rejection_one_to_one.cpp:49-51), TRIMMED by distance (..._trimmed.cpp:53-56)

@@ -95,6 +95,18 @@ struct IcpControl {
   cf::CriteriaState st;
 };
 
+// Device-resident state of one pass of the rejector chain (rejectors.hip): counts, ranks and thresholds never visit the
+// host between the kernels of a chain.
+struct RejState {
+  unsigned int count;      // pairs alive in front of the last selecting rejector
+  int mode;                // of that rejector: 0 nothing to filter, 1 threshold, 2 drop everything
+  unsigned int trimmed;    // a Trimmed rejector of the chain cut the list (it then comes back ordered by distance)
+  unsigned int pad;
+  unsigned long long key;  // the selected key (distance bits, or (distance, query) for Trimmed)
+  double median;           // MedianDistance: the median distance ...
+  double threshold;        // ... times the factor
+};
+
 // One record per completed iteration, written by icp_solve_kernel into pinned host memory.
 struct IcpStepRecord {
   int step;               // running index
@@ -212,6 +224,9 @@ struct pclhip_icp {
   uint8_t* keep = nullptr;        // per sorted source slot: correspondence survives the chain
   double last_median = 0;
   int fetch_order = 0;            // 0 by query, 1 by (match, distance), 2 by distance
+  bool trim_pending = false;      // a Trimmed rejector ran: fetch_order becomes 2 if rej_state_host->trimmed says it cut
+  pclhip::RejState* rej_state = nullptr;       // device
+  pclhip::RejState* rej_state_host = nullptr;  // pinned mirror, valid after a stream synchronisation
   // device-driven loop (icp_loop.hip)
   pclhip::IcpControl* ctl = nullptr;        // device
   pclhip::IcpControl* ctl_host = nullptr;   // pinned staging copy used to arm the loop
@@ -327,6 +342,8 @@ pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double ma
 pclhip_status icp_align_device(pclhip_icp* icp, const pclhip_icp_params* params, const float* guess,
                                pclhip_icp_result* res);
 bool icp_is_sharded(const pclhip_icp* icp);
+// under sharding only per-pair filters (the Distance rejector) are allowed: PCLHIP_ERR_STATE otherwise
+pclhip_status sharded_filters_ok(pclhip_icp* icp);
 
 // ---- kernels launched from api.cpp ----------------------------------------------------------
 pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, int k,

@@ -111,34 +111,70 @@ __global__ __launch_bounds__(256) void rs_pick_kernel(RsState* __restrict__ st, 
   }
 }
 
-// key of rank `rank` (0-based, rank < n) -> *out; synchronises the stream
+// The chain runs stream-ordered, without the host in between (it is part of the device-driven loop): the count of kept
+// pairs, the rank it implies, the selected key and the threshold derived from it stay in device memory (pclhip::RejState,
+// one per registration; mirrored to pinned memory for the getters).
+//   MedianDistance: rank = count / 2 (nth_element at size/2, correspondence_rejection_median_distance.cpp:55-56),
+//                   threshold = median * factor in double (:64-66)
+//   Trimmed:        nv = max(floor(float(ratio) * float(count)), min_correspondences) (correspondence_rejection_trimmed.cpp
+//                   :47-50); nothing to do when nv >= count, everything dropped when nv == 0, else rank = nv - 1
+__global__ void rej_prepare_kernel(RejState* __restrict__ st, RsState* __restrict__ rs, const unsigned int* __restrict__ count,
+                                   int kind, double param, unsigned int min_corr) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned int cnt = *count;
+  unsigned int rank = 0;
+  int mode = 0;  // 0 nothing to filter, 1 threshold at `rank`, 2 drop everything
+  if (kind == PCLHIP_REJ_MEDIAN_DISTANCE) {
+    mode = cnt > 0 ? 1 : 0;
+    rank = cnt / 2;
+  } else {  // PCLHIP_REJ_TRIMMED
+    const float prod = __fmul_rn(float(param), float(cnt));
+    unsigned int nv = (unsigned int)floorf(prod);
+    if (nv < min_corr) nv = min_corr;
+    if (nv < cnt) {
+      mode = nv == 0 ? 2 : 1;
+      rank = nv == 0 ? 0 : nv - 1;
+      st->trimmed = 1;
+    }
+  }
+  st->count = cnt;
+  st->mode = mode;
+  rs->prefix = 0;
+  rs->rank = rank;
+  rs->pad = 0;
+}
+
+// after the digit passes: the selected key, and what MedianDistance makes of it
+__global__ void rej_threshold_kernel(RejState* __restrict__ st, const RsState* __restrict__ rs, int kind, double param) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->key = rs->prefix;
+  if (kind == PCLHIP_REJ_MEDIAN_DISTANCE && st->mode == 1) {
+    const double median = double(__uint_as_float(uint32_t(rs->prefix)));
+    st->median = median;
+    st->threshold = median * param;
+  }
+}
+
+// key of the rank rs->rank (set by rej_prepare_kernel) -> rs->prefix, stream-ordered
 template <class K>
-pclhip_status radix_select(pclhip_ctx* ctx, const K* keys, uint32_t n, uint32_t rank, RsState* st_dev, uint32_t* hist_dev,
-                           K* out) {
+void radix_select_queued(pclhip_ctx* ctx, const K* keys, uint32_t n, RsState* rs, uint32_t* hist_dev) {
   hipStream_t s = ctx->stream;
-  RsState h;
-  h.prefix = 0;
-  h.rank = rank;
-  h.pad = 0;
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(st_dev, &h, sizeof h, hipMemcpyHostToDevice, s));
-  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));  // `h` is a stack object
   constexpr int BITS = int(sizeof(K)) * 8;
   int grid = int((n + TB - 1) / TB);
   if (grid > ctx->num_cus * 8) grid = ctx->num_cus * 8;
   for (int shift = ((BITS - 1) / 11) * 11; shift >= 0; shift -= 11) {
-    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(hist_dev, 0, RS_BINS * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(rs_hist_kernel<K>, dim3(grid), dim3(TB), 0, s, keys, n, st_dev, shift, hist_dev);
-    hipLaunchKernelGGL(rs_pick_kernel, dim3(1), dim3(256), 0, s, st_dev, hist_dev, shift);
+    (void)hipMemsetAsync(hist_dev, 0, RS_BINS * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(rs_hist_kernel<K>, dim3(grid), dim3(TB), 0, s, keys, n, rs, shift, hist_dev);
+    hipLaunchKernelGGL(rs_pick_kernel, dim3(1), dim3(256), 0, s, rs, hist_dev, shift);
   }
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&h, st_dev, sizeof h, hipMemcpyDeviceToHost, s));
-  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-  *out = K(h.prefix);
-  return PCLHIP_OK;
 }
 
 // correspondence_rejection_median_distance.cpp:64-66: keep if double(d) <= median * factor
-__global__ void rej_median_kernel(const float* __restrict__ d2, uint32_t n, double thr, uint8_t* __restrict__ keep) {
+__global__ void rej_median_kernel(const float* __restrict__ d2, uint32_t n, const RejState* __restrict__ st,
+                                  uint8_t* __restrict__ keep) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (st->mode != 1) return;
+  const double thr = st->threshold;
   if (i < n && keep[i] && !(double(d2[i]) <= thr)) keep[i] = 0;
 }
 
@@ -163,11 +199,14 @@ __global__ void rej_pair_key_kernel(const float4* __restrict__ cur, const float*
 
 // correspondence_rejection_trimmed.cpp:53-58: keep the n smallest (distance, query) keys
 __global__ void rej_trim_kernel(const float4* __restrict__ cur, const float* __restrict__ d2, uint32_t n,
-                                uint64_t thr_key, uint8_t* __restrict__ keep) {
+                                const RejState* __restrict__ st, uint8_t* __restrict__ keep) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int mode = st->mode;
+  if (mode == 0) return;  // nv >= count: the list passes unchanged
+  const uint64_t thr_key = st->key;
   if (i < n && keep[i]) {
     const uint64_t k = (uint64_t(__float_as_uint(d2[i])) << 32) | __float_as_uint(cur[i].w);
-    if (k > thr_key) keep[i] = 0;
+    if (mode == 2 || k > thr_key) keep[i] = 0;
   }
 }
 
@@ -232,6 +271,8 @@ struct Guard {
 
 }  // namespace
 
+// `queued`: the caller is the device-driven loop -- nothing here may wait for the stream.  (The reciprocal test builds a
+// source index per call, which synchronises: the device-driven loop does not take it.)
 pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool use_max) {
   pclhip_ctx* ctx = icp->ctx;
   hipStream_t s = ctx->stream;
@@ -240,11 +281,21 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
   if (n == 0) return PCLHIP_OK;
   const dim3 grid((n + TB - 1) / TB), block(TB);
   if (!icp->keep) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->keep, n));
+  if (!icp->rej_state) {
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->rej_state, sizeof(RejState)));
+    PCLHIP_CHECK_HIP(ctx, hipHostMalloc(&icp->rej_state_host, sizeof(RejState), hipHostMallocDefault));
+    std::memset(icp->rej_state_host, 0, sizeof(RejState));
+  }
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(icp->rej_state, 0, sizeof(RejState), s));
   hipLaunchKernelGGL(rej_init_kernel, grid, block, 0, s, icp->match_pos, n, icp->keep);
-  Guard g;
+  Guard g;  // stream-ordered temporaries: released to the context when this returns, re-used only by later work of the stream
   g.ctx = ctx;
   unsigned int* d_cnt = nullptr;
+  RsState* rs = nullptr;
+  uint32_t* rs_hist = nullptr;
   PCLHIP_CHECK_HIP(ctx, g.alloc(&d_cnt, sizeof(unsigned int)));
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&rs, sizeof(RsState)));
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&rs_hist, RS_BINS * sizeof(uint32_t)));
 
   if (icp->reciprocal) {
     // source index over the CURRENT (transformed) source, ids = original source indices (.w of cur)
@@ -272,6 +323,7 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
     PCLHIP_CHECK_HIP(ctx, e);
   }
 
+  bool trimmed_in_chain = false;
   for (const pclhip_rejector& r : icp->rejectors) {
     switch (r.kind) {
       case PCLHIP_REJ_DISTANCE: {
@@ -281,26 +333,14 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
       }
       case PCLHIP_REJ_MEDIAN_DISTANCE: {
         uint32_t* k0 = nullptr;
-        RsState* rs = nullptr;
-        uint32_t* rs_hist = nullptr;
         PCLHIP_CHECK_HIP(ctx, g.alloc(&k0, size_t(n) * 4));
-        PCLHIP_CHECK_HIP(ctx, g.alloc(&rs, sizeof(RsState)));
-        PCLHIP_CHECK_HIP(ctx, g.alloc(&rs_hist, RS_BINS * sizeof(uint32_t)));
         PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
+        // dropped slots carry the largest key, so rank count / 2 counts kept distances only
         hipLaunchKernelGGL(rej_dist_key_kernel, grid, block, 0, s, icp->match_d2, icp->keep, n, k0, d_cnt);
-        unsigned int cnt = 0;
-        PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
-        PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-        if (cnt == 0) break;
-        uint32_t mbits = 0;  // dropped slots carry the largest key, so rank cnt / 2 counts kept distances only
-        {
-          const pclhip_status st = radix_select<uint32_t>(ctx, k0, n, cnt / 2, rs, rs_hist, &mbits);
-          if (st != PCLHIP_OK) return st;
-        }
-        float mf;
-        std::memcpy(&mf, &mbits, sizeof mf);
-        icp->last_median = double(mf);  // nth_element at size/2 (:55-56)
-        hipLaunchKernelGGL(rej_median_kernel, grid, block, 0, s, icp->match_d2, n, icp->last_median * r.param, icp->keep);
+        hipLaunchKernelGGL(rej_prepare_kernel, dim3(1), dim3(1), 0, s, icp->rej_state, rs, d_cnt, int(r.kind), r.param, 0u);
+        radix_select_queued<uint32_t>(ctx, k0, n, rs, rs_hist);
+        hipLaunchKernelGGL(rej_threshold_kernel, dim3(1), dim3(1), 0, s, icp->rej_state, rs, int(r.kind), r.param);
+        hipLaunchKernelGGL(rej_median_kernel, grid, block, 0, s, icp->match_d2, n, icp->rej_state, icp->keep);
         break;
       }
       case PCLHIP_REJ_ONE_TO_ONE: {
@@ -313,6 +353,7 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
         hipLaunchKernelGGL(rej_o2o_keep_kernel, grid, block, 0, s, icp->src_cur, icp->match, icp->match_d2, n, best,
                            icp->keep);
         icp->fetch_order = 1;
+        trimmed_in_chain = false;  // whatever an earlier Trimmed did to the order, this one re-orders the list
         break;
       }
       case PCLHIP_REJ_TRIMMED: {
@@ -320,28 +361,12 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
         PCLHIP_CHECK_HIP(ctx, g.alloc(&k0, size_t(n) * 8));
         PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
         hipLaunchKernelGGL(rej_pair_key_kernel, grid, block, 0, s, icp->src_cur, icp->match_d2, icp->keep, n, k0, d_cnt);
-        unsigned int cnt = 0;
-        PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, s));
-        PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-        // :47-50 float product, floor, max with nr_min_correspondences_
-        volatile float prod = float(r.param) * float(cnt);
-        unsigned int nv = (unsigned int)std::floor(prod);
-        if (nv < r.min_correspondences) nv = r.min_correspondences;
-        if (nv < cnt) {
-          if (nv == 0) {
-            PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(icp->keep, 0, n, s));
-          } else {
-            RsState* rs = nullptr;
-            uint32_t* rs_hist = nullptr;
-            PCLHIP_CHECK_HIP(ctx, g.alloc(&rs, sizeof(RsState)));
-            PCLHIP_CHECK_HIP(ctx, g.alloc(&rs_hist, RS_BINS * sizeof(uint32_t)));
-            uint64_t thr = 0;  // the nv-th smallest (distance, query) key
-            const pclhip_status st = radix_select<uint64_t>(ctx, k0, n, nv - 1, rs, rs_hist, &thr);
-            if (st != PCLHIP_OK) return st;
-            hipLaunchKernelGGL(rej_trim_kernel, grid, block, 0, s, icp->src_cur, icp->match_d2, n, thr, icp->keep);
-          }
-          icp->fetch_order = 2;
-        }
+        hipLaunchKernelGGL(rej_prepare_kernel, dim3(1), dim3(1), 0, s, icp->rej_state, rs, d_cnt, int(r.kind), r.param,
+                           r.min_correspondences);
+        radix_select_queued<uint64_t>(ctx, k0, n, rs, rs_hist);  // the nv-th smallest (distance, query) key
+        hipLaunchKernelGGL(rej_threshold_kernel, dim3(1), dim3(1), 0, s, icp->rej_state, rs, int(r.kind), r.param);
+        hipLaunchKernelGGL(rej_trim_kernel, grid, block, 0, s, icp->src_cur, icp->match_d2, n, icp->rej_state, icp->keep);
+        trimmed_in_chain = true;  // the list comes back sorted by distance IF it was cut (RejState::trimmed says so)
         break;
       }
       default:
@@ -350,7 +375,9 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
     }
   }
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
-  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));  // scratch is released when `g` goes out of scope
+  icp->trim_pending = trimmed_in_chain;
+  // the getters (last median, order of the fetched list) read the pinned mirror after a synchronisation of their own
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(icp->rej_state_host, icp->rej_state, sizeof(RejState), hipMemcpyDeviceToHost, s));
   return PCLHIP_OK;
 }
 

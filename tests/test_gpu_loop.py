@@ -126,15 +126,53 @@ print("RESULT" + json.dumps(out))
             assert np.abs(np.asarray(a["last"]) - np.asarray(b["last"])).max() < 2e-6, name
 
 
-def test_run_steps_refuses_rejectors_and_reports_no_correspondences(gpu):
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pcl_oracle
+    return pcl_oracle
+
+
+def test_rejector_chain_runs_inside_the_device_loop(gpu, orc):
+    # MedianDistance / Trimmed / OneToOne / Distance between search and estimation, with every count, rank and threshold
+    # kept in device memory (rejectors.hip): the device-driven alignment equals the oracle's loop over the same chain
+    # (impl/icp.hpp:187-201), and runSteps replays it step for step
+    import pcl_amd
+    from oracle import rejectors as orej
+    tgt, src, _ = pcl_amd.synth.icp_pair(40_000)
+
+    def chain():
+        a = pcl_amd.CorrespondenceRejectorMedianDistance(); a.setMedianFactor(1.5)
+        b = pcl_amd.CorrespondenceRejectorTrimmed(); b.setOverlapRatio(0.8)
+        c = pcl_amd.CorrespondenceRejectorOneToOne()
+        d = pcl_amd.CorrespondenceRejectorDistance(); d.setMaximumDistance(0.05)
+        return [a, b, c, d]
+
+    icp = _make_icp(gpu, tgt, src, 0)
+    for r in chain():
+        icp.addCorrespondenceRejector(r)
+    icp.align()
+    assert icp.hasConverged()
+    T_dev, it_dev = icp.getFinalTransformation().copy(), icp.nr_iterations_
+    ref = orej.icp_with_filters(orc, tgt, src, 0,
+                                rejectors=[lambda q, m, d: orej.reject_median_distance(q, m, d, 1.5),
+                                           lambda q, m, d: orej.reject_trimmed(q, m, d, 0.8),
+                                           orej.reject_one_to_one,
+                                           lambda q, m, d: orej.reject_distance(q, m, d, 0.05)],
+                                max_iterations=20, max_correspondence_distance=0.1, transformation_epsilon=1e-10)
+    assert it_dev == ref["iterations"]
+    assert np.abs(T_dev - ref["T"]).max() < 2e-5
+    steps = icp.runSteps(it_dev)
+    assert steps[-1]["alignment_ended"] and [s["iteration"] for s in steps] == list(range(1, it_dev + 1))
+    assert np.abs(steps[-1]["final_transformation"] - T_dev).max() < 1e-7
+    # reciprocal correspondences still need the host between iterations (a source index per iteration)
+    icp.setUseReciprocalCorrespondences(True)
+    with pytest.raises(pcl_amd.PclHipError, match="reciprocal"):
+        icp.runSteps(1)
+
+
+def test_run_steps_reports_no_correspondences(gpu):
     import pcl_amd
     tgt, src, _ = pcl_amd.synth.icp_pair(5_000)
-    icp = _make_icp(gpu, tgt, src, 0)
-    rej = pcl_amd.CorrespondenceRejectorMedianDistance()
-    rej.setMedianFactor(2.0)
-    icp.addCorrespondenceRejector(rej)
-    with pytest.raises(pcl_amd.PclHipError, match="rejectors"):
-        icp.runSteps(3)
     # nothing within reach: every step is an alignment that ends at once with NO_CORRESPONDENCES
     far = src.copy()
     far[:, 0] += 100.0
