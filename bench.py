@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--replicated", action="store_true", help="config 5: replicate the target instead of sharding it")
     ap.add_argument("--rejectors", default="", help="comma list of median,trimmed,one_to_one,distance: the rejector chain "
                                                      "inside the device-driven loop (configs 2/3)")
+    ap.add_argument("--reciprocal", action="store_true", help="reciprocal correspondences inside the device-driven loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-align", action="store_true", help="skip the host-boundary timing (examples/bench_pcl_align.cpp)")
     return ap.parse_args()
@@ -171,6 +172,8 @@ def main():
         else:
             raise SystemExit("unknown rejector %r" % name)
         icp.addCorrespondenceRejector(rej)
+    if args.reciprocal:
+        icp.setUseReciprocalCorrespondences(True)
     source_order_ms = icp.sourceOrderMs()
 
     if args.warmup > 0:
@@ -237,7 +240,7 @@ def main():
                                           "(BASELINE.json; `value` is the whole-job aggregate, ms/iteration = ms_per_step, "
                                           "HBM GB/s = roofline.achieved)",
                        "points_per_gpu": n, "target_points": n, "mode": "p2plane" if mode == 1 else "p2point",
-                       "rejectors": args.rejectors or None,
+                       "rejectors": args.rejectors or None, "reciprocal": bool(args.reciprocal),
                        "loop": "device-driven (pclhip_icp_run_steps): search, accumulate, reduce, solve + convergence "
                                "kernels queued back to back",
                        "parallelism": "source slab sharded x%d, target replicated%s" %

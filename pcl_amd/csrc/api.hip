@@ -930,6 +930,10 @@ pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out) {
 }
 
 static void icp_free_source(pclhip_icp* icp) {
+  if (icp->src_index) pclhip_index_destroy(icp->src_index);
+  icp->src_index = nullptr;
+  if (icp->src_slot_of_orig) (void)dev_free(icp->ctx, icp->src_slot_of_orig);
+  icp->src_slot_of_orig = nullptr;
   if (icp->src_records) (void)dev_free(icp->ctx, icp->src_records);
   icp->src_records = nullptr;
   icp->src_records_host = nullptr;
@@ -1194,9 +1198,9 @@ pclhip_status pclhip_icp_align(pclhip_icp* icp, const pclhip_icp_params* params,
   static const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   std::memset(res, 0, sizeof *res);
   // The loop runs on the device (icp_loop.hip): no read-back, host solve or reset copy between iterations; a
-  // rejector chain is part of it (its counts, ranks and thresholds stay in device memory, rejectors.hip).  Reciprocal
-  // correspondences build a source index per iteration, which synchronises: they use the host-driven loop below
-  // (also selectable with PCLHIP_ICP_HOST_LOOP=1 for A/B and for the twin test).
+  // rejector chain and reciprocal correspondences are part of it (counts, ranks and thresholds stay in device memory; the
+  // source index of the reciprocal test is built once and refitted per iteration: rejectors.hip).  The host-driven loop
+  // below remains for A/B and for the twin test (PCLHIP_ICP_HOST_LOOP=1).
   static const bool host_loop = [] {
     const char* e = getenv("PCLHIP_ICP_HOST_LOOP");
     return e && atoi(e) == 1;
@@ -1205,7 +1209,7 @@ pclhip_status pclhip_icp_align(pclhip_icp* icp, const pclhip_icp_params* params,
     const pclhip_status sf = sharded_filters_ok(icp);
     if (sf != PCLHIP_OK) return sf;
   }
-  if (!host_loop && !icp->reciprocal) {
+  if (!host_loop) {
     if (params->mode != PCLHIP_ICP_POINT_TO_POINT && params->mode != PCLHIP_ICP_POINT_TO_PLANE &&
         params->mode != PCLHIP_ICP_SYMMETRIC) {
       set_error(ctx, "unknown ICP mode");

@@ -408,8 +408,6 @@ extern "C" pclhip_status pclhip_icp_run_steps(pclhip_icp* icp, const pclhip_icp_
   if (!icp || !params || n_steps < 0 || (n_steps > 0 && !out_steps)) return PCLHIP_ERR_INVALID;
   pclhip_ctx* ctx = icp->ctx;
   PCLHIP_REQUIRE(ctx, icp->src_cur != nullptr, "no source cloud set");
-  PCLHIP_REQUIRE(ctx, !icp->reciprocal,
-                 "pclhip_icp_run_steps drives the device loop: rejector chains yes, reciprocal correspondences no");
   {
     const pclhip_status sf = sharded_filters_ok(icp);
     if (sf != PCLHIP_OK) return sf;

@@ -1181,6 +1181,33 @@ pclhip_status build_boxes(pclhip_index* ix) {
 }
 
 
+// The boxes of an index whose points MOVED (same count, same order): leaf boxes, the SoA copy and the upper levels are
+// recomputed from ix->pts; nothing is allocated and nothing waits for the stream.  The order stays a valid grouping
+// under a rigid motion, but the leaves are no longer cells of an axis-aligned kd partition: searches of such an index
+// must start at the root (no start-level shortcut) and it carries no discs.
+pclhip_status refit_boxes(pclhip_index* ix) {
+  pclhip_ctx* ctx = ix->ctx;
+  hipStream_t s = ctx->stream;
+  if (ix->top < 1 || ix->box[1] == nullptr || ix->soa == nullptr) {
+    set_error(ctx, "refit of an index that was never built");
+    return PCLHIP_ERR_STATE;
+  }
+  const uint32_t c1 = ix->count[1];
+  const uint32_t threads = c1 * LEAF;
+  hipLaunchKernelGGL(leaf_box_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c1, ix->box[1]);
+  hipLaunchKernelGGL(leaf_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, threads, ix->soa);
+  for (int l = 2; l <= ix->top; ++l) {
+    const uint64_t th = uint64_t(ix->count[l]) * WAVE;
+    hipLaunchKernelGGL(node_box_kernel, dim3(unsigned((th + 255) / 256)), dim3(256), 0, s, ix->box[l - 1], ix->count[l - 1],
+                       ix->box[l], ix->count[l]);
+  }
+  for (int lv = ix->cache_from; lv <= ix->top && ix->cache_from < MAX_LEVELS; ++lv)
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(ix->topcache + ix->cache_off[lv], ix->box[lv], size_t(ix->count[lv]) * sizeof(Box),
+                                         hipMemcpyDeviceToDevice, s));
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  return PCLHIP_OK;
+}
+
 void preload_index_build_kernels() {
   hipFuncAttributes a;
   (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(leaf_box_kernel));

@@ -224,6 +224,10 @@ struct pclhip_icp {
   uint8_t* keep = nullptr;        // per sorted source slot: correspondence survives the chain
   double last_median = 0;
   int fetch_order = 0;            // 0 by query, 1 by (match, distance), 2 by distance
+  // reciprocal correspondences: an index over the SOURCE, built once per source cloud and refitted to the moved cloud
+  // every iteration (rejectors.hip); src_slot_of_orig: original source index -> slot of src_cur
+  pclhip_index* src_index = nullptr;
+  uint32_t* src_slot_of_orig = nullptr;
   bool trim_pending = false;      // a Trimmed rejector ran: fetch_order becomes 2 if rej_state_host->trimmed says it cut
   pclhip::RejState* rej_state = nullptr;       // device
   pclhip::RejState* rej_state_host = nullptr;  // pinned mirror, valid after a stream synchronisation
@@ -324,6 +328,7 @@ pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stri
                             uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
                             uint32_t* rank_or_null, const float* scale = nullptr);
 pclhip_status build_boxes(pclhip_index* ix);
+pclhip_status refit_boxes(pclhip_index* ix);  // the points of a built index moved: boxes again, stream-ordered
 int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns);
 pclhip_status launch_estimate_pairs(pclhip_ctx* ctx, int mode, const float4* src, const float4* src_nrm,
                                     const float4* tgt, const float4* tgt_nrm, const float* weights, uint32_t n, bool enforce,
@@ -346,8 +351,9 @@ bool icp_is_sharded(const pclhip_icp* icp);
 pclhip_status sharded_filters_ok(pclhip_icp* icp);
 
 // ---- kernels launched from api.cpp ----------------------------------------------------------
+// timed = false: no events, no wait (k <= 32): the launch is queued and the call returns
 pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, int k,
-                         int32_t* out_idx_sorted, float* out_d2_sorted);
+                         int32_t* out_idx_sorted, float* out_d2_sorted, bool timed = true);
 pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_t* nan_count);
 pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d2, bool use_max,
                                  int mode, hipEvent_t* step_events = nullptr);

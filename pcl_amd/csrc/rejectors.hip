@@ -243,6 +243,21 @@ __global__ void recip_query_kernel(const float4* __restrict__ tgt_pts, const uin
   }
   q[i] = v;
 }
+// slot of every original source index inside the kd-ordered source arrays (src_sorted0 / src_cur)
+__global__ void recip_slot_kernel(const float4* __restrict__ src_sorted0, uint32_t n, uint32_t* __restrict__ slot_of_orig) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) slot_of_orig[__float_as_uint(src_sorted0[j].w)] = j;
+}
+// the source index's points (its own kd order, w = original index) take the coordinates the cloud has NOW
+__global__ void recip_gather_kernel(float4* __restrict__ ix_pts, uint32_t n, const uint32_t* __restrict__ slot_of_orig,
+                                    const float4* __restrict__ cur) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float w = ix_pts[i].w;
+    const float4 c = cur[slot_of_orig[__float_as_uint(w)]];
+    ix_pts[i] = make_float4(c.x, c.y, c.z, w);
+  }
+}
 // impl/correspondence_estimation.hpp:265-266: drop if d_reciprocal > max^2 or the reciprocal NN is not the query
 __global__ void recip_keep_kernel(const float4* __restrict__ cur, const int32_t* __restrict__ r_idx,
                                   const float* __restrict__ r_d2, uint32_t n, float max_d2, int use_max,
@@ -271,8 +286,8 @@ struct Guard {
 
 }  // namespace
 
-// `queued`: the caller is the device-driven loop -- nothing here may wait for the stream.  (The reciprocal test builds a
-// source index per call, which synchronises: the device-driven loop does not take it.)
+// Nothing here waits for the stream (the chain is part of the device-driven loop); the one exception is the first use
+// of reciprocal correspondences with a source cloud, which builds the source index.
 pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool use_max) {
   pclhip_ctx* ctx = icp->ctx;
   hipStream_t s = ctx->stream;
@@ -298,29 +313,35 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
   PCLHIP_CHECK_HIP(ctx, g.alloc(&rs_hist, RS_BINS * sizeof(uint32_t)));
 
   if (icp->reciprocal) {
-    // source index over the CURRENT (transformed) source, ids = original source indices (.w of cur)
-    pclhip_index* src_ix = nullptr;
-    pclhip_status st = build_index_from_float4(ctx, icp->src_cur, n, &src_ix);
-    if (st != PCLHIP_OK) return st;
+    // An index over the source: built ONCE per source cloud (from the pristine, kd-ordered copy; ids = original source
+    // indices), then refitted to the moved cloud every iteration -- its points are gathered from src_cur and only the
+    // boxes are recomputed (refit_boxes), stream-ordered.  The answers are exact nearest neighbours with (distance,
+    // index) ties like any other index's: they do not depend on how well the boxes fit.
+    if (icp->src_index == nullptr) {
+      pclhip_status st = build_index_from_float4(ctx, icp->src_sorted0, n, &icp->src_index);  // synchronises: once
+      if (st != PCLHIP_OK) return st;
+      if (icp->src_index->disc) (void)dev_free(ctx, icp->src_index->disc);  // discs describe the cloud where it was built
+      icp->src_index->disc = nullptr;
+      PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->src_slot_of_orig, size_t(icp->n_orig > 0 ? icp->n_orig : 1) * 4));
+      hipLaunchKernelGGL(recip_slot_kernel, grid, block, 0, s, icp->src_sorted0, n, icp->src_slot_of_orig);
+    }
+    pclhip_index* const src_ix = icp->src_index;
+    if (src_ix->n > 0) {
+      hipLaunchKernelGGL(recip_gather_kernel, dim3((src_ix->n + TB - 1) / TB), block, 0, s, src_ix->pts, src_ix->n,
+                         icp->src_slot_of_orig, icp->src_cur);
+      pclhip_status st = refit_boxes(src_ix);
+      if (st != PCLHIP_OK) return st;
+    }
     float4* q = nullptr;
     int32_t* r_idx = nullptr;
     float* r_d2 = nullptr;
-    hipError_t e1 = g.alloc(&q, size_t(n) * sizeof(float4)), e2 = g.alloc(&r_idx, size_t(n) * sizeof(int32_t)),
-               e3 = g.alloc(&r_d2, size_t(n) * sizeof(float));
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-      pclhip_index_destroy(src_ix);
-      set_error(ctx, "hipMalloc failed in the reciprocal filter");
-      return PCLHIP_ERR_HIP;
-    }
+    PCLHIP_CHECK_HIP(ctx, g.alloc(&q, size_t(n) * sizeof(float4)));
+    PCLHIP_CHECK_HIP(ctx, g.alloc(&r_idx, size_t(n) * sizeof(int32_t)));
+    PCLHIP_CHECK_HIP(ctx, g.alloc(&r_d2, size_t(n) * sizeof(float)));
     hipLaunchKernelGGL(recip_query_kernel, grid, block, 0, s, icp->target->pts, icp->match_pos, icp->keep, n, q);
-    st = launch_knn(src_ix, q, n, 1, r_idx, r_d2);  // rows = slots (q.w), results = original source ids
-    if (st == PCLHIP_OK)
-      hipLaunchKernelGGL(recip_keep_kernel, grid, block, 0, s, icp->src_cur, r_idx, r_d2, n, max_d2, use_max ? 1 : 0,
-                         icp->keep);
-    hipError_t e = hipStreamSynchronize(s);
-    pclhip_index_destroy(src_ix);
+    const pclhip_status st = launch_knn(src_ix, q, n, 1, r_idx, r_d2, false);  // rows = slots (q.w), results = original source ids
     if (st != PCLHIP_OK) return st;
-    PCLHIP_CHECK_HIP(ctx, e);
+    hipLaunchKernelGGL(recip_keep_kernel, grid, block, 0, s, icp->src_cur, r_idx, r_d2, n, max_d2, use_max ? 1 : 0, icp->keep);
   }
 
   bool trimmed_in_chain = false;

@@ -171,19 +171,22 @@ static int resident_blocks(pclhip_ctx* ctx, K kernel, uint32_t ngroups) {
 }
 
 pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, int k, int32_t* out_idx,
-                         float* out_d2) {
+                         float* out_d2, bool timed) {
   pclhip_ctx* ctx = ix->ctx;
   if (nq == 0) return PCLHIP_OK;
   const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
   const IndexView v = ix->view();
   hipStream_t s = ctx->stream;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
-  (void)hipEventRecord(e0, s);
+  if (timed) {
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+  }
   struct Timer {
     pclhip_index* ix; hipEvent_t a, b; hipStream_t s;
     ~Timer() {
+      if (a == nullptr) return;  // an untimed launch: nothing to wait for
       (void)hipEventRecord(b, s);
       if (hipEventSynchronize(b) == hipSuccess) { float ms = 0; if (hipEventElapsedTime(&ms, a, b) == hipSuccess) ix->last_kernel_ms = ms; }
       (void)hipEventDestroy(a); (void)hipEventDestroy(b);

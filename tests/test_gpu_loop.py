@@ -164,10 +164,21 @@ def test_rejector_chain_runs_inside_the_device_loop(gpu, orc):
     steps = icp.runSteps(it_dev)
     assert steps[-1]["alignment_ended"] and [s["iteration"] for s in steps] == list(range(1, it_dev + 1))
     assert np.abs(steps[-1]["final_transformation"] - T_dev).max() < 1e-7
-    # reciprocal correspondences still need the host between iterations (a source index per iteration)
+    # reciprocal correspondences (impl/correspondence_estimation.hpp:220-311) on top of the chain: the source index is
+    # built once and refitted to the moved cloud every iteration, all of it queued -- same answer as the oracle's loop
     icp.setUseReciprocalCorrespondences(True)
-    with pytest.raises(pcl_amd.PclHipError, match="reciprocal"):
-        icp.runSteps(1)
+    icp.align()
+    ref2 = orej.icp_with_filters(orc, tgt, src, 0, reciprocal=True,
+                                 rejectors=[lambda q, m, d: orej.reject_median_distance(q, m, d, 1.5),
+                                            lambda q, m, d: orej.reject_trimmed(q, m, d, 0.8),
+                                            orej.reject_one_to_one,
+                                            lambda q, m, d: orej.reject_distance(q, m, d, 0.05)],
+                                 max_iterations=20, max_correspondence_distance=0.1, transformation_epsilon=1e-10)
+    assert icp.nr_iterations_ == ref2["iterations"]
+    assert np.abs(icp.getFinalTransformation() - ref2["T"]).max() < 2e-5
+    steps = icp.runSteps(icp.nr_iterations_)
+    assert steps[-1]["alignment_ended"]
+    assert np.abs(steps[-1]["final_transformation"] - icp.getFinalTransformation()).max() < 1e-7
 
 
 def test_run_steps_reports_no_correspondences(gpu):
