@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <string.h>
 
@@ -202,22 +203,40 @@ __global__ __launch_bounds__(256) void leaf_disc_kernel(const float4* __restrict
 }
 
 // per-block sums of the squared diagonals of the leaf boxes (fixed order: the mean is reproducible)
-__global__ __launch_bounds__(256) void leaf_diag_kernel(const Box* __restrict__ box, uint32_t nleaf, double* __restrict__ part) {
-  __shared__ double red[256];
-  double a = 0.0;
+// part[b] = sum of squared leaf diagonals; part[nb + b] / part[2 nb + b] = sums of the discs' half thickness / radius
+// (how thin the leaves are against their width: what the disc bounds live on)
+__global__ __launch_bounds__(256) void leaf_diag_kernel(const Box* __restrict__ box, const float4* __restrict__ disc,
+                                                        uint32_t nleaf, double* __restrict__ part) {
+  __shared__ double red[3][256];
+  double a = 0.0, hsum = 0.0, rsum = 0.0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nleaf; i += gridDim.x * blockDim.x) {
     const Box b = box[i];
     const double ex = double(b.hi.x) - b.lo.x, ey = double(b.hi.y) - b.lo.y, ez = double(b.hi.z) - b.lo.z;
     const double d2 = ex * ex + ey * ey + ez * ez;
     a += (d2 < 1e30) ? d2 : 0.0;  // the padded last leaf holds sentinels
+    const float R = disc[2 * size_t(i)].w, hn = disc[2 * size_t(i) + 1].w;
+    if (R < 1e30f && hn < 1e30f) {  // degenerate discs carry FLT_MAX
+      hsum += double(hn);
+      rsum += double(R);
+    }
   }
-  red[threadIdx.x] = a;
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = hsum;
+  red[2][threadIdx.x] = rsum;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (int(threadIdx.x) < o) red[threadIdx.x] += red[threadIdx.x + o];
+    if (int(threadIdx.x) < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+      red[2][threadIdx.x] += red[2][threadIdx.x + o];
+    }
     __syncthreads();
   }
-  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = red[0][0];
+    part[gridDim.x + blockIdx.x] = red[1][0];
+    part[2 * gridDim.x + blockIdx.x] = red[2][0];
+  }
 }
 
 // one wavefront per parent node
@@ -1124,17 +1143,26 @@ pclhip_status build_boxes(pclhip_index* ix) {
       {  // mean squared leaf diagonal: from what stand-off on the discs pay (traverse.hpp)
         constexpr int NB = 64;
         double* part = nullptr;
-        PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &part, NB * sizeof(double)));
-        hipLaunchKernelGGL(leaf_diag_kernel, dim3(NB), dim3(256), 0, s, ix->box[1], c, part);
-        double h[NB];
+        PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &part, 3 * NB * sizeof(double)));
+        hipLaunchKernelGGL(leaf_diag_kernel, dim3(NB), dim3(256), 0, s, ix->box[1], ix->disc, c, part);
+        double h[3 * NB];
         const hipError_t e1 = hipMemcpyAsync(h, part, sizeof h, hipMemcpyDeviceToHost, s);
         const hipError_t e2 = hipStreamSynchronize(s);
         (void)dev_free(ctx, part);
         PCLHIP_CHECK_HIP(ctx, e1);
         PCLHIP_CHECK_HIP(ctx, e2);
-        double sum = 0.0;
-        for (int i = 0; i < NB; ++i) sum += h[i];
+        double sum = 0.0, hs = 0.0, rs = 0.0;
+        for (int i = 0; i < NB; ++i) {
+          sum += h[i];
+          hs += h[NB + i];
+          rs += h[2 * NB + i];
+        }
         ix->leaf_diag2 = float(sum / double(c));
+        ix->disc_thickness = rs > 0.0 ? float(hs / rs) : 1.0f;
+        static const bool debug = getenv("PCLHIP_INDEX_DEBUG") != nullptr;
+        if (debug)
+          std::fprintf(stderr, "pclhip index: %u points, %u leaves, mean leaf diagonal^2 %.4g, disc thickness ratio %.4f\n",
+                       ix->n, c, double(ix->leaf_diag2), double(ix->disc_thickness));
       }
     } else {
       const uint64_t threads = uint64_t(c) * WAVE;

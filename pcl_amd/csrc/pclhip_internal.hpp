@@ -166,6 +166,7 @@ struct pclhip_index {
   float4* nrm = nullptr;
   float4* disc = nullptr;
   float leaf_diag2 = 0.0f;  // mean squared diagonal of the leaf boxes
+  float disc_thickness = 1.0f;  // sum of the discs' half thicknesses / sum of their radii: how thin the leaves are
   uint32_t* rank = nullptr;
   pclhip::Box* box[pclhip::MAX_LEVELS] = {};
   pclhip::LevelInfo* lv_dev = nullptr;

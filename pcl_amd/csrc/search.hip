@@ -1010,6 +1010,7 @@ __device__ __forceinline__ void icp_cold_search_body(const IndexView& ix, float4
     uint32_t hint = NO_INDEX;
     const bool done =
         standoff_search(ix, p.x, p.y, p.z, valid, fast, wl_s[wave], topbox_s, ts, prev, (flags & 2) != 0, so_from, hint);
+    prev.outcome(done);
 #if defined(PCLHIP_SO_PROFILE) || defined(PCLHIP_SO_REASONS)
     const uint64_t so_t0 = clock64();
     TraverseStats ts_fb;
@@ -1470,7 +1471,25 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     // launches without seeds go through the stand-off search when the index carries leaf discs: the host-driven loop
     // knows which launch that is (pclhip_icp_reset cleared the seeds); in the device-driven loop the control block
     // picks the body on the device (icp_search_dual_kernel)
-    const bool standoff = standoff_enabled() && v.disc != nullptr && search_skip_flag() != 0;
+    // The stand-off search culls by leaf discs: it pays where the leaves are THIN against their width (a surface sampled
+    // well above its noise: thickness ratio ~0.1 at the bench's 10M points).  Where the noise is of the order of the point
+    // spacing (ratio 0.3 at 100M points of the same surface) every query needs tens of leaves whatever the bound, the
+    // lists outgrow the LDS, and the seeded search is the faster one (measured: 76 against 108 ms at 100M).
+    static const float so_thick = [] {
+      const char* e = getenv("PCLHIP_SO_THICKNESS");
+      return e ? float(atof(e)) : 0.2f;
+    }();
+    // ... and where the target index stays cache-resident under the chunked schedule: every wave works in a region of its
+    // own (that is what lets a group borrow its predecessor's match), so the 4096 resident waves touch 4096 scattered
+    // neighbourhoods at a time instead of one window per XCD.  Measured on the bench surface: 2.7 against 3.2 ms for
+    // the seeded search at 10M points (0.56 GB of index), 7.2 against 5.4 ms at 15M (0.84 GB) with the same lists per
+    // group -- beyond the gate below launches without seeds keep the interleaved schedule and traverse().
+    static const size_t so_max_bytes = [] {
+      const char* e = getenv("PCLHIP_SO_MAX_MB");
+      return size_t(e ? strtoull(e, nullptr, 10) : 640ull) << 20;
+    }();
+    const bool standoff = standoff_enabled() && v.disc != nullptr && search_skip_flag() != 0 &&
+                          icp->target->disc_thickness < so_thick && size_t(icp->target->n_pad) * 56u <= so_max_bytes;
     const bool cold = standoff && !device_loop && icp->seeds_cleared;
     icp->seeds_cleared = false;
     const int kflags = (use_max ? 1 : 0) | search_skip_flag();

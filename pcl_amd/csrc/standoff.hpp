@@ -237,10 +237,34 @@ struct PrevGroup {
   float hx, hy, hz;
   uint32_t hpos;  // history entry of this lane
   uint32_t count; // groups recorded so far (wave-uniform)
+  // Back-off: where the stand-off is so wide (or the surface so thick against the spacing) that the lists outgrow the
+  // LDS, every attempt costs a collect that is thrown away.  Three give-ups in a row and the next six groups of the wave
+  // go straight to traverse() -- still seeded, which is most of what a tight start buys there -- before it tries again.
+  uint32_t fail_streak, skip;
+  bool attempted;  // the last standoff_search went past the back-off gate (only those count as give-ups)
   __device__ __forceinline__ void init() {
     x = y = z = hx = hy = hz = 0.0f;
     pos = hpos = NO_INDEX;
     count = 0;
+    fail_streak = 0;
+    skip = 0;
+    attempted = false;
+  }
+  __device__ __forceinline__ bool skip_now() {  // wave-uniform
+    attempted = skip == 0;
+    if (skip == 0) return false;
+    --skip;
+    return true;
+  }
+  __device__ __forceinline__ void outcome(bool done) {
+    if (!attempted) return;
+    attempted = false;
+    if (done) {
+      fail_streak = 0;
+    } else if (++fail_streak >= 3u) {
+      fail_streak = 0;
+      skip = 6;
+    }
   }
   // after a group: qx/qy/qz as searched, `mpos` the lane's match position or NO_INDEX
   __device__ __forceinline__ void record(float qx, float qy, float qz, uint32_t mpos) {
@@ -271,7 +295,7 @@ struct PrevGroup {
 // not).  `seed_leaf_out`: leaf of the seed (a start hint for the fallback).  Must be called by all 64 lanes.
 template <class WL>
 __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, float qy, float qz, bool valid, NN1Min& pol,
-                                                WL& wl, const Box* topbox, TraverseStats& ts, const PrevGroup& prev,
+                                                WL& wl, const Box* topbox, TraverseStats& ts, PrevGroup& prev,
                                                 bool allow_skip, float from2, uint32_t& seed_leaf_out) {
   // the wave's LDS block, stage by stage (bytes): [0, 1664) two frontier buffers while collecting; [0, 3968) the disc
   // entries (32 B each) from the group cull on; [3968, 4224) ids of the union slots; [4224, 4992) ids of the group
@@ -341,6 +365,7 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
     SO_WHY(1);
     return false;
   }
+  if (prev.skip_now()) return false;  // backing off: the lanes are seeded, traverse() does the rest
 
   char* const lds = reinterpret_cast<char*>(&wl);
   uint32_t* const ids = reinterpret_cast<uint32_t*>(wl.buf);
