@@ -1,14 +1,35 @@
 #!/bin/bash
-# Round-end evidence on the GPU box: tests, trace + PMC passes, bench lines of configs 3 / 2 / 4, work counters.
-# Usage (through gpurun): bash scripts/final_evidence.sh   -> gpurun_out/final2/, gpurun_out/prof_r2final2/
+# Round-end evidence on the GPU box: tests, trace + PMC passes of the DRIVER's bench command, bench lines of configs
+# 3 / 2 / 4 (+ the rejector / reciprocal lines), work counters, per-stage profile of the stand-off search.
+# Usage (through gpurun): GRAFT_COMMIT=$(git rev-parse --short HEAD) bash scripts/final_evidence.sh [tag]
+#   -> gpurun_out/<tag>/, gpurun_out/prof_<tag>/
 set -u
-mkdir -p gpurun_out/final2
-export GRAFT_COMMIT=${GRAFT_COMMIT:-unknown}   # the snapshot has no .git: pass the commit in (GRAFT_COMMIT=$(git rev-parse --short HEAD))
-python -m pytest tests -m gpu -q > gpurun_out/final2/tests.log 2>&1; tail -1 gpurun_out/final2/tests.log
-bash scripts/profile_gpu.sh r2final2 "trace sq1 fetch write" --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/final2/prof.log 2>&1
-cp gpurun_out/prof_r2final2/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
-python bench.py > gpurun_out/final2/bench3.json 2> gpurun_out/final2/bench3.err
-python bench.py --config 2 > gpurun_out/final2/bench2.json 2> gpurun_out/final2/bench2.err
-python bench.py --config 4 > gpurun_out/final2/bench4.json 2> gpurun_out/final2/bench4.err
-python scratch/stats_probe.py 10000000 > gpurun_out/final2/stats.log 2>&1
-cp profiles/pmc_traffic.json gpurun_out/final2/pmc_traffic.json
+TAG=${1:-r3final}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export GRAFT_COMMIT=${GRAFT_COMMIT:-unknown}   # the snapshot has no .git: pass the commit in
+python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; tail -1 $OUT/tests.log
+bash scripts/profile_gpu.sh $TAG "trace sq1 sq2 fetch write" > $OUT/prof.log 2>&1
+cp gpurun_out/prof_$TAG/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
+cp gpurun_out/prof_$TAG/summary.txt $OUT/prof_summary.txt 2>/dev/null
+python bench.py > $OUT/bench3.json 2> $OUT/bench3.err
+python bench.py --config 2 > $OUT/bench2.json 2> $OUT/bench2.err
+python bench.py --config 4 > $OUT/bench4.json 2> $OUT/bench4.err
+python bench.py --no-cpu-baseline --no-host-align --rejectors median,trimmed > $OUT/bench3_rejectors.json 2> $OUT/bench3_rejectors.err
+python bench.py --no-cpu-baseline --no-host-align --reciprocal > $OUT/bench3_reciprocal.json 2> $OUT/bench3_reciprocal.err
+PCLHIP_LIB=pcl_amd/variants/libpclhip_stats.so python scratch/stats_probe.py 10000000 > $OUT/stats.log 2>&1
+PCLHIP_LIB=pcl_amd/variants/libpclhip_prof.so python scratch/stats_probe.py 10000000 2>&1 | grep "it0" > $OUT/standoff_stage_ticks.log
+PCLHIP_LIB=pcl_amd/variants/libpclhip_why.so python scratch/stats_probe.py 10000000 2>&1 | grep "it0" > $OUT/standoff_exits.log
+bash scripts/profile_iter.sh $TAG > $OUT/prof_iter.log 2>&1; cp gpurun_out/prof_$TAG/per_iter.txt $OUT/per_iter.txt 2>/dev/null
+python scratch/first_probe.py > $OUT/first_call.log 2>&1
+python scratch/misc_probe.py > $OUT/misc.log 2>&1
+cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
+for f in $OUT/bench*.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    print(sys.argv[1].split('/')[-1], "ms_per_step", d["ms_per_step"], "value %.4g" % d["value"], "frac", d.get("roofline", {}).get("frac"))
+except Exception as e:
+    print(sys.argv[1], "unreadable:", e)
+PY
+done
