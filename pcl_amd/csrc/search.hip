@@ -1521,7 +1521,12 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
       if (st != PCLHIP_OK) return st;
       keep = icp->keep;
     }
-    int ga = ctx->num_cus * 8;
+    static const int acc_per_cu = [] {  // A/B: blocks of the streaming accumulate kernel per CU (rows the reduction reads)
+      const char* e = getenv("PCLHIP_ACC_BLOCKS_PER_CU");
+      const int v = e ? atoi(e) : 4;
+      return v >= 1 && v <= 8 ? v : 4;
+    }();
+    int ga = ctx->num_cus * acc_per_cu;
     if (ga > icp->grid_blocks) ga = icp->grid_blocks;
     {  // small clouds: no more blocks than give every thread ~4 points -- each block leaves a row of partial sums that the
        // single-workgroup reduction has to read (2048 rows cost it more than the sums of a 65k-point cloud)
