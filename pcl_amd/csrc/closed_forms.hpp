@@ -31,30 +31,48 @@ PCLHIP_HD void swap_(T& a, T& b) {
   b = t;
 }
 
-// Doolittle LU with partial pivoting on a 6x6, then forward/back substitution.
+// Doolittle LU with partial pivoting on a 6x6, then forward/back substitution.  Every array index is a compile-time
+// constant after unrolling (the pivot row is swapped in by predicated exchanges with each candidate row), so on
+// the device the system lives in registers: a row index known only at run time would put it in scratch memory,
+// and the one thread that closes an ICP iteration would wait out a memory round trip per element.
 PCLHIP_HD bool lu_solve6(double A[6][6], double b[6], double x[6]) {
+#pragma unroll
   for (int c = 0; c < 6; ++c) {
     int p = c;
     double best = fabs(A[c][c]);
+#pragma unroll
     for (int r = c + 1; r < 6; ++r)
       if (fabs(A[r][c]) > best) {
         best = fabs(A[r][c]);
         p = r;
       }
     if (best == 0.0) return false;
-    if (p != c) {
-      for (int j = 0; j < 6; ++j) swap_(A[c][j], A[p][j]);
-      swap_(b[c], b[p]);
+#pragma unroll
+    for (int r = c + 1; r < 6; ++r) {
+      const bool sw = p == r;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double u = A[c][j], v = A[r][j];
+        A[c][j] = sw ? v : u;
+        A[r][j] = sw ? u : v;
+      }
+      const double u = b[c], v = b[r];
+      b[c] = sw ? v : u;
+      b[r] = sw ? u : v;
     }
+#pragma unroll
     for (int r = c + 1; r < 6; ++r) {
       const double f = A[r][c] / A[c][c];
       A[r][c] = f;
+#pragma unroll
       for (int j = c + 1; j < 6; ++j) A[r][j] -= f * A[c][j];
       b[r] -= f * b[c];
     }
   }
+#pragma unroll
   for (int i = 5; i >= 0; --i) {
     double s = b[i];
+#pragma unroll
     for (int j = i + 1; j < 6; ++j) s -= A[i][j] * x[j];
     x[i] = s / A[i][i];
   }
@@ -68,22 +86,27 @@ PCLHIP_HD void jacobi_eig3(double A[3][3], double V[3][3], double w[3]) {
   for (int sweep = 0; sweep < 64; ++sweep) {
     const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
     if (off < 1e-300) break;
+#pragma unroll
     for (int p = 0; p < 2; ++p)
+#pragma unroll
       for (int q = p + 1; q < 3; ++q) {
         if (A[p][q] == 0.0) continue;
         const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
         const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
         const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
         for (int k = 0; k < 3; ++k) {  // A <- A * J
           const double akp = A[k][p], akq = A[k][q];
           A[k][p] = c * akp - s * akq;
           A[k][q] = s * akp + c * akq;
         }
+#pragma unroll
         for (int k = 0; k < 3; ++k) {  // A <- J^T * A
           const double apk = A[p][k], aqk = A[q][k];
           A[p][k] = c * apk - s * aqk;
           A[q][k] = s * apk + c * aqk;
         }
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
           const double vkp = V[k][p], vkq = V[k][q];
           V[k][p] = c * vkp - s * vkq;
@@ -117,14 +140,28 @@ PCLHIP_HD void rotation_from_sigma(const double sigma[3][3], double R[3][3]) {
     }
   double V[3][3], w[3];
   jacobi_eig3(AtA, V, w);
-  int ord[3] = {0, 1, 2};  // descending eigenvalues
+  // descending eigenvalues: selection by exchanges of whole (value, vector) pairs -- constant indices only
+#pragma unroll
   for (int i = 0; i < 2; ++i)
-    for (int j = i + 1; j < 3; ++j)
-      if (w[ord[j]] > w[ord[i]]) swap_(ord[i], ord[j]);
+#pragma unroll
+    for (int j = i + 1; j < 3; ++j) {
+      const bool sw = w[j] > w[i];
+      const double wi = w[i], wj = w[j];
+      w[i] = sw ? wj : wi;
+      w[j] = sw ? wi : wj;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double vi = V[r][i], vj = V[r][j];
+        V[r][i] = sw ? vj : vi;
+        V[r][j] = sw ? vi : vj;
+      }
+    }
   double Vs[3][3], sv[3];
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
-    sv[c] = sqrt(w[ord[c]] > 0 ? w[ord[c]] : 0.0);
-    for (int r = 0; r < 3; ++r) Vs[r][c] = V[r][ord[c]];
+    sv[c] = sqrt(w[c] > 0 ? w[c] : 0.0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Vs[r][c] = V[r][c];
   }
   if (det3(Vs) < 0)  // keep V a proper rotation; the sign moves into U, U S V^T is unchanged
     for (int r = 0; r < 3; ++r) Vs[r][2] = -Vs[r][2];
@@ -144,10 +181,14 @@ PCLHIP_HD void rotation_from_sigma(const double sigma[3][3], double R[3][3]) {
     double u0[3] = {U[0][0], U[1][0], U[2][0]}, u1[3], u2[3];
     if (!(sv[1] > tol)) {
       int mi = 0;
+      double least = fabs(u0[0]);
+#pragma unroll
       for (int d = 1; d < 3; ++d)
-        if (fabs(u0[d]) < fabs(u0[mi])) mi = d;
-      double e[3] = {0, 0, 0};
-      e[mi] = 1.0;
+        if (fabs(u0[d]) < least) {
+          least = fabs(u0[d]);
+          mi = d;
+        }
+      const double e[3] = {mi == 0 ? 1.0 : 0.0, mi == 1 ? 1.0 : 0.0, mi == 2 ? 1.0 : 0.0};
       cross3(u0, e, u1);
       const double n = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
       for (int d = 0; d < 3; ++d) U[d][1] = u1[d] / n;
@@ -184,17 +225,18 @@ PCLHIP_HD void solve_point_to_plane(const double* s, float* T) {
   load_normal_system(s, A, b);
   if (!lu_solve6(A, b, x))
     for (int i = 0; i < 6; ++i) x[i] = nan("");  // singular system: Eigen's inverse() yields non-finite too
-  const double al = x[0], be = x[1], ga = x[2];
+  // each sine and cosine once (the products below are the reference's expressions, same operand order)
+  const double sa = sin(x[0]), ca = cos(x[0]), sb = sin(x[1]), cb = cos(x[1]), sg = sin(x[2]), cg = cos(x[2]);
   zero16(T);
-  T[0] = float(cos(ga) * cos(be));
-  T[1] = float(-sin(ga) * cos(al) + cos(ga) * sin(be) * sin(al));
-  T[2] = float(sin(ga) * sin(al) + cos(ga) * sin(be) * cos(al));
-  T[4] = float(sin(ga) * cos(be));
-  T[5] = float(cos(ga) * cos(al) + sin(ga) * sin(be) * sin(al));
-  T[6] = float(-cos(ga) * sin(al) + sin(ga) * sin(be) * cos(al));
-  T[8] = float(-sin(be));
-  T[9] = float(cos(be) * sin(al));
-  T[10] = float(cos(be) * cos(al));
+  T[0] = float(cg * cb);
+  T[1] = float(-sg * ca + cg * sb * sa);
+  T[2] = float(sg * sa + cg * sb * ca);
+  T[4] = float(sg * cb);
+  T[5] = float(cg * ca + sg * sb * sa);
+  T[6] = float(-cg * sa + sg * sb * ca);
+  T[8] = float(-sb);
+  T[9] = float(cb * sa);
+  T[10] = float(cb * ca);
   T[3] = float(x[3]);
   T[7] = float(x[4]);
   T[11] = float(x[5]);

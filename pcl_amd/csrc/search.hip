@@ -5,6 +5,8 @@
 // keeps the reference's operation order and rounding (see traverse.hpp and the citations below).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -228,7 +230,12 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
                                                         float4* __restrict__ nrm_sorted,
                                                         unsigned long long* __restrict__ nan_count,
                                                         unsigned long long* gstats) {
-  __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
+  // k <= 8: 3 KB of staging (neither pass stages the original indices) + 1.75 KB of recorded leaves per lane, which the
+  // exact policy of tie lanes may overwrite with its fourth KB of staging -- the records are used up by then.  52 KB per
+  // block: three blocks per CU, as before (at 53 KB only two were resident: 3.9 against 2.6 ms)
+  constexpr int REC_AT = 3072 / 4;  // first float of the records inside the staging buffer
+  typedef typename std::conditional<K == 8, WaveLdsT<3072 + REC_CAP * WAVE * 4>, WaveLds>::type NrmWaveLds;
+  __shared__ NrmWaveLds wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
   __shared__ uint32_t nbr_s[WAVES_PER_BLOCK][(K == 8 ? K : 1) * WAVE];  // per-lane neighbour lists of the collection pass
   load_top_cache(ix, topbox_s);
@@ -248,20 +255,35 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
     pol.init(KEY_NONE);
     const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
     const bool vv[1] = {valid};
+#ifdef PCLHIP_NRM_PROFILE  // -DPCLHIP_NRM_PROFILE: counters 5/6/7 become clock64() ticks of pass 1 / pass 2 / the plane fit
+    uint64_t nrm_t = clock64();
+#define NRM_LAP(i)                              \
+  do {                                          \
+    const uint64_t nrm_now = clock64();         \
+    ts.c[i] += uint32_t(nrm_now - nrm_t);       \
+    nrm_t = nrm_now;                            \
+  } while (0)
+#else
+#define NRM_LAP(i) (void)0
+#endif
     if constexpr (K == 8) {
       // Two passes instead of one top-K pass with identities.  (1) the k smallest DISTANCES (TopKDist: one
-      // v_med3_f32 per slot and candidate); (2) a tight second traversal that collects the positions of the
-      // candidates up to the k-th distance (CollectLE) -- it starts at the group's own level-2 node whenever the
-      // grown query box allows (start-level shortcut).  The <= k positions are then put into the reference's
-      // (distance, index) order by a 19-comparator network.  Exact distance ties at the k-th distance (more than
-      // k candidates collected) fall back to the one-pass exact policy for that lane.
+      // v_med3_f32 per slot and candidate), remembering per lane the leaves that contributed; (2) every lane reads
+      // ITS remembered leaves again, straight from the index, and collects the positions of the candidates up to the
+      // k-th distance (CollectLE) -- no second walk (it cost as much as the first: 33k against 36k ticks per group).
+      // The <= k positions are then put into the reference's (distance, index) order by a 19-comparator network.
+      // Exact distance ties at the k-th distance (more than k candidates collected) fall back to the one-pass exact
+      // policy for that lane; a lane with more than REC_CAP contributing leaves sends its wave through the tight
+      // second traversal this replaced.
       const int wave_id = threadIdx.x / WAVE;
       TopKDist<K> dist;
-      dist.init();
+      uint32_t* const rec = reinterpret_cast<uint32_t*>(wl_s[wave_id].buf + REC_AT) + lane;
+      dist.init(rec);
       const uint32_t own_leaf = uniform_u32((g * WAVE) / LEAF);
       static_assert(WAVE % LEAF == 0, "a wave's queries are whole leaves");
       if (valid) dist.seed_own_leaf(ix.soa, i / LEAF, qx, qy, qz);   // lanes i / LEAF = own_leaf ... own_leaf + 3
       traverse<TopKDist<K>, true>(ix, qx, qy, qz, vv, dist, wl_s[wave_id], topbox_s, ts, own_leaf);
+      NRM_LAP(5);
       CollectLE<K> col;
       col.thr = (k >= 1 && k <= K) ? dist.d[0] : 0.0f;
 #pragma unroll
@@ -269,7 +291,22 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
       col.cnt = 0;
       col.over = false;
       col.list = nbr_s[wave_id] + lane;
-      traverse<CollectLE<K>, true>(ix, qx, qy, qz, vv, col, wl_s[wave_id], topbox_s, ts, own_leaf);
+      [[maybe_unused]] const uint32_t nrec = valid ? dist.nrec : 0u;
+#ifndef PCLHIP_NRM_REWALK  // A/B: -DPCLHIP_NRM_REWALK keeps the second traversal
+      if (__builtin_amdgcn_ballot_w64(nrec > REC_CAP) == 0) {
+        __builtin_amdgcn_wave_barrier();
+        uint32_t id = valid ? i / LEAF : NO_INDEX;  // the own leaf (seed_own_leaf), then the records
+        for (uint32_t r = 0;; ++r) {
+          col.leaf_global(ix.soa, id, qx, qy, qz);
+          if (__builtin_amdgcn_ballot_w64(r < nrec) == 0) break;
+          id = (r < nrec) ? rec[r * WAVE] : NO_INDEX;
+        }
+      } else
+#endif
+      {
+        traverse<CollectLE<K>, true>(ix, qx, qy, qz, vv, col, wl_s[wave_id], topbox_s, ts, own_leaf);
+      }
+      NRM_LAP(6);
       __builtin_amdgcn_wave_barrier();
       const bool redo[1] = {valid && col.over};
       if (valid && !col.over) {
@@ -337,7 +374,9 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
       }
       nrm_sorted[i] = out;
     }
+    NRM_LAP(7);
   }
+#undef NRM_LAP
   flush_stats(ts, gstats);
 }
 
@@ -1301,42 +1340,48 @@ __global__ __launch_bounds__(BLOCK) void estimate_pairs_kernel(const float4* __r
 // interleaved chains, then the 32 rows are added in order), so the result does not depend on scheduling.
 // With `solve_ctl` the same launch also closes the iteration (icp_solve_step below): no record to exchange,
 // one launch less.
-__device__ void icp_solve_step(IcpControl* __restrict__ ctl, const double* __restrict__ sums,
-                               IcpStepRecord* __restrict__ log);
+__device__ __forceinline__ void icp_solve_step(IcpControl* __restrict__ ctl, const double* __restrict__ sums,
+                                               IcpStepRecord* __restrict__ log);
 
-__global__ __launch_bounds__(1024) void icp_finalize_kernel(const double* __restrict__ partials, int nblocks,
-                                                            double* __restrict__ sums,
-                                                            const IcpControl* __restrict__ ctl = nullptr,
-                                                            IcpControl* __restrict__ solve_ctl = nullptr,
-                                                            IcpStepRecord* __restrict__ log = nullptr) {
+// The thread that closes the iteration afterwards keeps the 6x6 system, the control block and the step record in
+// registers (94 of the 128 a 1024-thread block leaves per lane): icp_solve_step is inlined here -- as a called function
+// it was allocated on its own and went through 1 KB of scratch per call, 70 us for this launch instead of ~20.
+constexpr int FINALIZE_THREADS = 1024;
+__global__ __launch_bounds__(FINALIZE_THREADS) void icp_finalize_kernel(const double* __restrict__ partials, int nblocks,
+                                                                        double* __restrict__ sums,
+                                                                        const IcpControl* __restrict__ ctl = nullptr,
+                                                                        IcpControl* __restrict__ solve_ctl = nullptr,
+                                                                        IcpStepRecord* __restrict__ log = nullptr) {
   if (ctl != nullptr && ctl->stop != 0) return;
   __shared__ double red[32][NS + 1];
   __shared__ double total[NS];
-  const int t = threadIdx.x % NS, r = threadIdx.x / NS;  // NS == 32
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;         // four independent chains: the loads overlap
-  int b = r;
-  for (; b + 32 * 15 < nblocks; b += 32 * 16) {  // sixteen rows in flight per thread, summed in the order of the loop below
-    double v[16];
+  const int t = threadIdx.x % NS;  // NS == 32
+  for (int r = threadIdx.x / NS; r < 32; r += FINALIZE_THREADS / NS) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains: the loads overlap
+    int b = r;
+    for (; b + 32 * 15 < nblocks; b += 32 * 16) {  // sixteen rows in flight per thread, summed in the order of the loop below
+      double v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = partials[size_t(b + 32 * i) * NS + t];
+      for (int i = 0; i < 16; ++i) v[i] = partials[size_t(b + 32 * i) * NS + t];
 #pragma unroll
-    for (int i = 0; i < 16; i += 4) {
-      s0 += v[i];
-      s1 += v[i + 1];
-      s2 += v[i + 2];
-      s3 += v[i + 3];
+      for (int i = 0; i < 16; i += 4) {
+        s0 += v[i];
+        s1 += v[i + 1];
+        s2 += v[i + 2];
+        s3 += v[i + 3];
+      }
     }
+    for (; b + 96 < nblocks; b += 128) {
+      s0 += partials[size_t(b) * NS + t];
+      s1 += partials[size_t(b + 32) * NS + t];
+      s2 += partials[size_t(b + 64) * NS + t];
+      s3 += partials[size_t(b + 96) * NS + t];
+    }
+    for (; b < nblocks; b += 32) s0 += partials[size_t(b) * NS + t];
+    red[r][t] = (s0 + s1) + (s2 + s3);
   }
-  for (; b + 96 < nblocks; b += 128) {
-    s0 += partials[size_t(b) * NS + t];
-    s1 += partials[size_t(b + 32) * NS + t];
-    s2 += partials[size_t(b + 64) * NS + t];
-    s3 += partials[size_t(b + 96) * NS + t];
-  }
-  for (; b < nblocks; b += 32) s0 += partials[size_t(b) * NS + t];
-  red[r][t] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (r == 0) {
+  if (threadIdx.x < NS) {
     double a = 0.0;
 #pragma unroll
     for (int i = 0; i < 32; ++i) a += red[i][t];
@@ -1352,8 +1397,8 @@ __global__ __launch_bounds__(1024) void icp_finalize_kernel(const double* __rest
 // Closes an iteration on the device: closed form of the estimator on the (all-reduced) record, final = Tk *
 // final, DefaultConvergenceCriteria, and the control words of the next launch (impl/icp.hpp:204-238).
 // One thread: ~2k double operations, a few microseconds -- the point is that nothing leaves the GPU.
-__device__ void icp_solve_step(IcpControl* __restrict__ ctl, const double* __restrict__ sums,
-                               IcpStepRecord* __restrict__ log) {
+__device__ __forceinline__ void icp_solve_step(IcpControl* __restrict__ ctl, const double* __restrict__ sums,
+                                               IcpStepRecord* __restrict__ log) {
   if (ctl->stop != 0) return;
   IcpControl c = *ctl;
   IcpStepRecord r;
@@ -1406,7 +1451,7 @@ __device__ void icp_solve_step(IcpControl* __restrict__ ctl, const double* __res
   __threadfence_system();
 }
 
-__global__ void icp_solve_kernel(IcpControl* __restrict__ ctl, const double* __restrict__ sums,
+__global__ __launch_bounds__(64) void icp_solve_kernel(IcpControl* __restrict__ ctl, const double* __restrict__ sums,
                                  IcpStepRecord* __restrict__ log) {
   if (threadIdx.x == 0 && blockIdx.x == 0) icp_solve_step(ctl, sums, log);
 }
@@ -1543,7 +1588,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     // (Folding this reduction into the accumulate kernel -- last block done -- was tried: the 2048 device-scope
     // atomics on one counter cost ~100 us across the 8 XCDs, five times this 20 us launch.)
     solved = device_loop && !icp_is_sharded(icp);  // no record to exchange: the reduction launch closes the iteration
-    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, ga, icp->sums_dev, ctl,
+    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(FINALIZE_THREADS), 0, s, icp->partials, ga, icp->sums_dev, ctl,
                        solved ? icp->ctl : static_cast<IcpControl*>(nullptr), icp->steps);
   } else if (icp->n > 0) {
     int grid = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? resident_blocks(ctx, k_plane, ngroups)
@@ -1555,7 +1600,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound,
                        use_max ? 1 : 0, icp->match_pos, icp->match, icp->match_d2, icp->partials, ctx->stats);
     (void)hipEventRecord(icp->ev1, s);
-    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, icp->partials, grid, icp->sums_dev,
+    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(FINALIZE_THREADS), 0, s, icp->partials, grid, icp->sums_dev,
                        static_cast<const IcpControl*>(nullptr), static_cast<IcpControl*>(nullptr),
                        static_cast<IcpStepRecord*>(nullptr));
   } else {
@@ -1687,7 +1732,7 @@ pclhip_status launch_estimate_pairs(pclhip_ctx* ctx, int mode, const float4* src
   else
     hipLaunchKernelGGL(estimate_pairs_kernel<PCLHIP_ICP_POINT_TO_POINT>, dim3(grid), dim3(BLOCK), 0, s, src, src_nrm, tgt,
                        tgt_nrm, weights, n, enforce ? 1 : 0, dev);
-  hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(1024), 0, s, dev, grid, dev + size_t(grid) * NS,
+  hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(FINALIZE_THREADS), 0, s, dev, grid, dev + size_t(grid) * NS,
                      static_cast<const IcpControl*>(nullptr), static_cast<IcpControl*>(nullptr),
                      static_cast<IcpStepRecord*>(nullptr));
   hipError_t e = hipGetLastError();

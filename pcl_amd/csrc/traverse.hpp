@@ -33,6 +33,9 @@ constexpr int LEAF_BATCH = 16;
 #ifndef PCLHIP_PAIR_MODE
 #define PCLHIP_PAIR_MODE 1
 #endif
+#ifndef PCLHIP_RETEST
+#define PCLHIP_RETEST 0  // A/B: re-tests of a popped leaf against the lane's tightened bound in the tight-bounds scan
+#endif
 constexpr bool pair_mode = PCLHIP_PAIR_MODE != 0;  // A/B: -DPCLHIP_PAIR_MODE=0 walks whole disc lists the sequential way         // leaves staged in LDS at a time (16 x 256 B = 4 KB)
 constexpr int LEAF_FLOATS = 4 * LEAF;  // x[16] y[16] z[16] w[16]
 
@@ -545,12 +548,26 @@ struct TopKReg {
 // (distance, index) keys with their positions: 8 instructions per candidate for k = 8 where TopKReg needs ~72.
 // Used as the first of two passes (see normals_kernel): it yields the exact k-th distance; CollectLE then
 // gathers the candidates up to that distance.
+// Every leaf that MAY hold one of the final k neighbours is remembered per lane (`rec`, entry r of this lane at
+// rec[r * 64] in LDS): a leaf is recorded when its nearest point is not beyond the lane's k-th distance of that moment.
+// The final k-th distance is never larger, so a point within it -- one that ties with it included -- lies in a recorded
+// leaf, and the second pass reads those leaves again instead of walking the index a second time.
+// (The lane's own leaf, evaluated before the traversal, is not in the list: the caller knows it.)
+constexpr uint32_t REC_CAP = 7;  // recorded leaves per lane; a lane that needs more sends its wave through the traversal
 template <int K>
 struct TopKDist {
   float d[K];
-  __device__ __forceinline__ void init() {
+  uint32_t* rec;   // LDS, this lane's column (nullptr: nothing is recorded)
+  uint32_t nrec;   // leaves this lane would have recorded (> REC_CAP: the list is incomplete)
+  __device__ __forceinline__ void init(uint32_t* rec_column = nullptr) {
 #pragma unroll
     for (int i = 0; i < K; ++i) d[i] = __builtin_inff();
+    rec = rec_column;
+    nrec = 0;
+  }
+  __device__ __forceinline__ void record(uint32_t leaf_id) {
+    if (nrec < REC_CAP) rec[nrec * WAVE] = leaf_id;
+    ++nrec;
   }
   static constexpr int QPL = 1;
   static constexpr bool LANE_SPARSE = true;
@@ -562,9 +579,11 @@ struct TopKDist {
     d[0] = __builtin_fminf(d[0], x);
   }
   // the 16 candidates of one leaf block: chunk c (16 bytes) at s[c * STRIDE]
+  // returns the smallest of the 16 distances
   template <int STRIDE>
-  __device__ __forceinline__ void block(const float4* s, const float* qx, const float* qy, const float* qz) {
+  __device__ __forceinline__ float block(const float4* s, const float* qx, const float* qy, const float* qz) {
     const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
+    float m = __builtin_inff();
 #pragma unroll
     for (int c4 = 0; c4 < LEAF / 4; ++c4) {
       const float4 X = s[c4 * STRIDE], Y = s[(4 + c4) * STRIDE], Z = s[(8 + c4) * STRIDE];
@@ -581,15 +600,21 @@ struct TopKDist {
         r1 = r1 + dy * dy;
         r1 = r1 + dz * dz;
       }
+      m = __builtin_fminf(__builtin_fminf(m, r0.x), __builtin_fminf(r0.y, __builtin_fminf(r1.x, r1.y)));
       insert(r0.x);
       insert(r0.y);
       insert(r1.x);
       insert(r1.y);
     }
+    return m;
   }
   __device__ __forceinline__ void leaf_lane(const float* buf, uint32_t slot, uint32_t leaf_id, const float* qx,
                                             const float* qy, const float* qz) {
-    if (leaf_id != NO_INDEX) block<16>(reinterpret_cast<const float4*>(buf) + slot, qx, qy, qz);  // transposed staging
+    if (leaf_id != NO_INDEX) {
+      const float before = d[K - 1];
+      const float m = block<16>(reinterpret_cast<const float4*>(buf) + slot, qx, qy, qz);  // transposed staging
+      if (rec != nullptr && m <= before) record(leaf_id);
+    }
   }
   // Self-queries: the lane's OWN leaf is evaluated before the traversal (straight from the SoA copy), so the search
   // starts with a k-th distance of a few point spacings -- tight mode, below the root -- instead of +inf; the
@@ -624,13 +649,23 @@ struct CollectLE {
   }
   __device__ __forceinline__ void leaf_lane(const float* buf, uint32_t slot, uint32_t leaf_id, const float* qx,
                                             const float* qy, const float* qz) {
+    leaf_at<16>(reinterpret_cast<const float4*>(buf) + slot, leaf_id, qx, qy, qz);  // transposed staging
+  }
+  // the same straight from the index's SoA copy: the lane's own leaf, not one of a staged batch
+  __device__ __forceinline__ void leaf_global(const float* soa, uint32_t leaf_id, const float* qx, const float* qy,
+                                              const float* qz) {
+    leaf_at<1>(reinterpret_cast<const float4*>(soa + size_t(leaf_id != NO_INDEX ? leaf_id : 0u) * LEAF_FLOATS), leaf_id, qx,
+               qy, qz);
+  }
+  template <int STRIDE>
+  __device__ __forceinline__ void leaf_at(const float4* s, uint32_t leaf_id, const float* qx, const float* qy,
+                                          const float* qz) {
     if (leaf_id != NO_INDEX) {
-      const float4* s = reinterpret_cast<const float4*>(buf) + slot;
       const uint32_t base = leaf_id * LEAF;
       const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
 #pragma unroll
       for (int c4 = 0; c4 < LEAF / 4; ++c4) {
-        const float4 X = s[c4 * 16], Y = s[(4 + c4) * 16], Z = s[(8 + c4) * 16];
+        const float4 X = s[c4 * STRIDE], Y = s[(4 + c4) * STRIDE], Z = s[(8 + c4) * STRIDE];
         v2f r0, r1;
         {
           const v2f dx = qx2 - v2f{X.x, X.y}, dy = qy2 - v2f{Y.x, Y.y}, dz = qz2 - v2f{Z.x, Z.y};
@@ -1118,6 +1153,9 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
               mask |= ((!(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w))) ? 1u : 0u) << t;
             }
             if (!valid[0]) mask = 0;
+#if PCLHIP_RETEST
+            const float w_mask = pol.worst(0);  // the lane's bound when its mask was built
+#endif
             while (__builtin_amdgcn_ballot_w64(mask != 0) != 0) {
               if (!landed) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1129,6 +1167,29 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
                 id = __float_as_uint(wl.list[3 * (b0 + slot)].w);
                 mask &= mask - 1u;
               }
+#if PCLHIP_RETEST
+              // A lane whose bound has tightened since the scan looks at its popped leaf again (its own list entry, not
+              // a broadcast) and moves on to its next one if the leaf fell out: the rounds of a batch follow the lane
+              // with the most leaves, and that is a lane whose first bound was loose.
+#pragma unroll
+              for (int again = 0; again < PCLHIP_RETEST; ++again) {
+                const bool look = id != NO_INDEX && pol.worst(0) < w_mask;
+                if (__builtin_amdgcn_ballot_w64(look) == 0) break;
+                bool out = false;
+                if (look) {
+                  const float4 ea = wl.list[3 * (b0 + slot)], eb = wl.list[3 * (b0 + slot) + 1];
+                  out = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z) > pol.worst(0);
+                }
+                if (out) {
+                  id = NO_INDEX;
+                  if (mask != 0) {
+                    slot = uint32_t(__builtin_ctz(mask));
+                    id = __float_as_uint(wl.list[3 * (b0 + slot)].w);
+                    mask &= mask - 1u;
+                  }
+                }
+              }
+#endif
               round(slot, id);
             }
           }

@@ -13,4 +13,7 @@ for s in d.get("per_step", []):
 print("ms_per_step %.4f  search/iter: %s  avg_kernel %.4f frac %.4f" % (
     d["ms_per_step"], " ".join("%d:%.3f" % (k, sum(v) / len(v)) for k, v in sorted(by.items())),
     d["roofline"]["avg_kernel_ms"], d["roofline"]["frac"]))
+ov = [s["step_ms"] - s["search_ms"] for s in d.get("per_step", [])]
+if ov:
+    print("accumulate+finalize per iteration: %.4f ms" % (sum(ov) / len(ov)))
 print("setup", {k: v for k, v in d["setup"].items() if k.endswith("_ms")})
