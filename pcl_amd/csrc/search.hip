@@ -230,14 +230,13 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
                                                         float4* __restrict__ nrm_sorted,
                                                         unsigned long long* __restrict__ nan_count,
                                                         unsigned long long* gstats) {
-  // k <= 8: 3 KB of staging (neither pass stages the original indices) + 1.75 KB of recorded leaves per lane, which the
-  // exact policy of tie lanes may overwrite with its fourth KB of staging -- the records are used up by then.  52 KB per
-  // block: three blocks per CU, as before (at 53 KB only two were resident: 3.9 against 2.6 ms)
+  // k <= 8: 3 KB of staging (neither pass stages the original indices) + 3.75 KB of records per wave (TopKDist), which
+  // the exact policy of tie lanes may overwrite with its fourth KB of staging -- the records are used up by then.  52 KB
+  // per block: three blocks per CU (at 53 KB only two were resident: 3.9 against 2.6 ms)
   constexpr int REC_AT = 3072 / 4;  // first float of the records inside the staging buffer
-  typedef typename std::conditional<K == 8, WaveLdsT<3072 + REC_CAP * WAVE * 4>, WaveLds>::type NrmWaveLds;
+  typedef typename std::conditional<K == 8, WaveLdsT<3072 + REC_BYTES>, WaveLds>::type NrmWaveLds;
   __shared__ NrmWaveLds wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
-  __shared__ uint32_t nbr_s[WAVES_PER_BLOCK][(K == 8 ? K : 1) * WAVE];  // per-lane neighbour lists of the collection pass
   load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t ngroups = (ix.n + WAVE - 1) / WAVE;
@@ -284,36 +283,84 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
       if (valid) dist.seed_own_leaf(ix.soa, i / LEAF, qx, qy, qz);   // lanes i / LEAF = own_leaf ... own_leaf + 3
       traverse<TopKDist<K>, true>(ix, qx, qy, qz, vv, dist, wl_s[wave_id], topbox_s, ts, own_leaf);
       NRM_LAP(5);
-      CollectLE<K> col;
-      col.thr = (k >= 1 && k <= K) ? dist.d[0] : 0.0f;
+      float thr = (k >= 1 && k <= K) ? dist.d[0] : 0.0f;
 #pragma unroll
-      for (int c = 1; c < K; ++c) col.thr = (c < k) ? dist.d[c] : col.thr;  // d[k - 1]
-      col.cnt = 0;
-      col.over = false;
-      col.list = nbr_s[wave_id] + lane;
+      for (int c = 1; c < K; ++c) thr = (c < k) ? dist.d[c] : thr;  // d[k - 1]
       [[maybe_unused]] const uint32_t nrec = valid ? dist.nrec : 0u;
+#ifdef PCLHIP_NRM_STATS  // counters 5/6/7: waves with an overflowing lane, largest list of the wave, records of all lanes
+      {
+        uint32_t mx = nrec, sm = nrec;
+        for (int o = 32; o > 0; o >>= 1) {
+          mx = max(mx, uint32_t(__shfl_xor(int(mx), o)));
+          sm += uint32_t(__shfl_xor(int(sm), o));
+        }
+        ts.c[5] += mx > REC_CAP ? 1u : 0u;
+        ts.c[6] += mx;
+        ts.c[7] += sm;
+      }
+#endif
+      uint32_t cand[K];  // positions of the candidates up to the k-th distance, any order
+      uint32_t ncand = 0;
+#pragma unroll
+      for (int c = 0; c < K; ++c) cand[c] = NO_INDEX;
 #ifndef PCLHIP_NRM_REWALK  // A/B: -DPCLHIP_NRM_REWALK keeps the second traversal
-      if (__builtin_amdgcn_ballot_w64(nrec > REC_CAP) == 0) {
+      // (a lane without a finite k-th distance -- fewer than k points in reach -- has no threshold to compare against)
+      if (__builtin_amdgcn_ballot_w64(valid && (nrec > REC_CAP || !(thr < __builtin_inff()))) == 0) {
         __builtin_amdgcn_wave_barrier();
-        uint32_t id = valid ? i / LEAF : NO_INDEX;  // the own leaf (seed_own_leaf), then the records
-        for (uint32_t r = 0;; ++r) {
-          col.leaf_global(ix.soa, id, qx, qy, qz);
-          if (__builtin_amdgcn_ballot_w64(r < nrec) == 0) break;
-          id = (r < nrec) ? rec[r * WAVE] : NO_INDEX;
+        CollectCodes cc;
+        cc.thr = thr;
+        cc.cnt = 0;
+        cc.codes = 0;
+        // the records that still matter: nearest point not beyond the FINAL k-th distance
+        uint32_t rel = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < REC_CAP; ++r) {
+          const float m = __uint_as_float(rec[(REC_MIN_ROW + r) * WAVE]);
+          rel |= (r < nrec && m <= thr) ? (1u << r) : 0u;
+        }
+        uint32_t id = valid ? i / LEAF : NO_INDEX, row = REC_CAP;  // the own leaf (seed_own_leaf) first
+        for (;;) {
+          cc.leaf(ix.soa, id, row, qx, qy, qz);
+          if (__builtin_amdgcn_ballot_w64(rel != 0) == 0) break;
+          id = NO_INDEX;
+          if (rel != 0) {
+            row = uint32_t(__builtin_ctz(rel));
+            id = rec[row * WAVE];
+            rel &= rel - 1u;
+          }
+        }
+        ncand = cc.cnt;
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+          if (uint32_t(c) < ncand) {
+            const uint32_t code = uint32_t(cc.codes >> (8 * c)) & 0xFFu;
+            const uint32_t r = code >> 4;
+            const uint32_t leaf = (r == REC_CAP) ? i / LEAF : rec[r * WAVE];
+            cand[c] = leaf * LEAF + (code & 15u);
+          }
         }
       } else
 #endif
       {
+        CollectLE<K> col;
+        col.thr = thr;
+        col.cnt = 0;
+        col.over = false;
+        col.list = rec;  // rows [0, 8) of the records: incomplete, or not needed
         traverse<CollectLE<K>, true>(ix, qx, qy, qz, vv, col, wl_s[wave_id], topbox_s, ts, own_leaf);
+        __builtin_amdgcn_wave_barrier();
+        ncand = col.cnt;
+#pragma unroll
+        for (int c = 0; c < K; ++c)
+          if (uint32_t(c) < ncand) cand[c] = col.list[c * WAVE];
       }
       NRM_LAP(6);
-      __builtin_amdgcn_wave_barrier();
-      const bool redo[1] = {valid && col.over};
-      if (valid && !col.over) {
+      const bool redo[1] = {valid && ncand > uint32_t(K)};
+      if (valid && ncand <= uint32_t(K)) {
 #pragma unroll
         for (int c = 0; c < K; ++c) {
-          if (uint32_t(c) < col.cnt) {
-            const uint32_t pc = col.list[c * WAVE];
+          if (uint32_t(c) < ncand) {
+            const uint32_t pc = cand[c];
             const float4 t = ix.pts[pc];
             pol.keys[c] = make_key(l2_simple(p.x, p.y, p.z, t.x, t.y, t.z), __float_as_uint(t.w));
             pol.pos[c] = pc;
@@ -894,6 +941,17 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
       if (sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
     }
   }
+#ifdef PCLHIP_ICP_PROFILE  // counters 5/6/7 become clock64() ticks: up to the traversal / the traversal / after it
+  uint64_t icp_t = clock64();
+#define ICP_LAP(i)                              \
+  do {                                          \
+    const uint64_t icp_now = clock64();         \
+    ts.c[i] += uint32_t(icp_now - icp_t);       \
+    icp_t = icp_now;                            \
+  } while (0)
+#else
+#define ICP_LAP(i) (void)0
+#endif
   while (g < ngroups) {
     float4 p[Q], t0[Q];
     uint32_t seed_pos[Q];
@@ -947,7 +1005,9 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
     const uint64_t hm = __builtin_amdgcn_ballot_w64(valid[0] && seed_pos[0] != NO_INDEX);
     if ((flags & 2) && hm != 0) start_leaf = uint32_t(__builtin_amdgcn_readlane(int(seed_pos[0]), __builtin_ctzll(hm))) / LEAF;
     // no lane has a seed: the first iteration of an alignment, queries stand off the target -> disc bounds
+    ICP_LAP(5);
     traverse<NN1MinT<Q>, SPARSE>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, start_leaf, hm == 0);
+    ICP_LAP(6);
     fast.resolve(ix, qx, qy, qz);
     // ... and their seed target points as soon as the seed positions have arrived
 #pragma unroll
@@ -982,7 +1042,9 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
       }
     }
     g = g2;
+    ICP_LAP(7);
   }
+#undef ICP_LAP
   flush_stats(ts, gstats);
 }
 

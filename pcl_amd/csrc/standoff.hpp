@@ -66,6 +66,10 @@ namespace pclhip {
 #define SO_COUNT(expr) (void)0
 #endif
 
+#ifndef PCLHIP_SO_BATCHCULL
+#define PCLHIP_SO_BATCHCULL 1  // A/B: 0 culls all union slots of a segment before the first evaluation
+#endif
+
 constexpr uint32_t SO_LIST_CAP = 768;   // collected leaf ids (they fill the 3 KB staging area)
 constexpr uint32_t SO_DISC_CAP = 124;   // disc entries (32 B) in LDS at a time: bytes [0, 3968) of the wave's block
 constexpr uint32_t SO_SURV_CAP = 192;   // ids of the leaves that pass the group cull: bytes [4224, 4992)
@@ -628,6 +632,45 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
       stat_union += ucnt;
       if (ucnt == 0) continue;
 
+#if PCLHIP_SO_BATCHCULL
+      // ---- 5 + 6. lane cull and evaluation, 16 union slots at a time: every lane runs the disc bound against the slots
+      // alive for its row -- a pair block per step (packed math), against its radius of NOW, which the batches before have
+      // tightened -- and evaluates what it could not exclude.  The batch's leaves are on their way into the staging area
+      // while the tests run.  (The walk over the pair blocks is wave-uniform: a row keeps most of the union alive at a
+      // stand-off, so skipping per lane would cost more mask arithmetic than the tests it saves.)
+      for (uint32_t c0 = 0; c0 < ucnt; c0 += LEAF_BATCH) {
+        const uint32_t rm16 = valid ? uint32_t((rowmask >> c0) & 0xFFFFull) : 0u;
+        if (__builtin_amdgcn_ballot_w64(rm16 != 0) == 0) continue;
+        const uint32_t cn = (ucnt - c0) < uint32_t(LEAF_BATCH) ? (ucnt - c0) : uint32_t(LEAF_BATCH);
+        so_stage(ix, wl.buf, sub < cn ? idu[c0 + sub] : NO_INDEX);
+        uint32_t m16 = 0;
+        const float w = pol.worst(0);
+        for (uint32_t b = 0; b < cn; b += 2u) {
+          SO_COUNT(++ts.c[1]);
+          const uint32_t rbits = (rm16 >> b) & 3u;
+          if (__builtin_amdgcn_ballot_w64(rbits != 0) == 0) continue;
+          const float4* const P = dl + 2u * (c0 + b);  // 4 float4 per pair block
+          const v2f lb = so_disc_lb2(qx, qy, qz, P[0], P[1], P[2], P[3]);
+          const uint2 ii = *reinterpret_cast<const uint2*>(idu + c0 + b);
+          const bool need0 = (rbits & 1u) != 0 && !(lb.x > w) && ii.x != id1 && ii.x != id2;  // the row seeds are done
+          const bool need1 = (rbits & 2u) != 0 && !(lb.y > w) && ii.y != id1 && ii.y != id2;
+          m16 |= ((need0 ? 1u : 0u) | (need1 ? 2u : 0u)) << b;
+        }
+        SO_LAP(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        while (__builtin_amdgcn_ballot_w64(m16 != 0) != 0) {
+          uint32_t slot = 0, id = NO_INDEX;
+          if (m16 != 0) {
+            slot = uint32_t(__builtin_ctz(m16));
+            id = idu[c0 + slot];
+            m16 &= m16 - 1u;
+          }
+          SO_COUNT(++ts.c[2]);
+          pol.leaf_lane(wl.buf, slot, id, qxa, qya, qza);
+        }
+        SO_LAP(7);
+      }
+#else
       // ---- 5. lane cull: every lane runs the disc bound against the union slots alive for its row, a pair block per
       // step (packed math); the walk is wave-uniform -- a row keeps most of the union alive at a stand-off, so skipping
       // per lane would cost more mask arithmetic than the tests it saves
@@ -671,6 +714,7 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
           pol.leaf_lane(wl.buf, slot, id, qxa, qya, qza);
         }
       }
+#endif
       SO_LAP(7);
       SO_MARK("eval_end");
     }

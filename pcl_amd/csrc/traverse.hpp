@@ -33,9 +33,6 @@ constexpr int LEAF_BATCH = 16;
 #ifndef PCLHIP_PAIR_MODE
 #define PCLHIP_PAIR_MODE 1
 #endif
-#ifndef PCLHIP_RETEST
-#define PCLHIP_RETEST 0  // A/B: re-tests of a popped leaf against the lane's tightened bound in the tight-bounds scan
-#endif
 constexpr bool pair_mode = PCLHIP_PAIR_MODE != 0;  // A/B: -DPCLHIP_PAIR_MODE=0 walks whole disc lists the sequential way         // leaves staged in LDS at a time (16 x 256 B = 4 KB)
 constexpr int LEAF_FLOATS = 4 * LEAF;  // x[16] y[16] z[16] w[16]
 
@@ -554,10 +551,13 @@ struct TopKReg {
 // leaf, and the second pass reads those leaves again instead of walking the index a second time.
 // (The lane's own leaf, evaluated before the traversal, is not in the list: the caller knows it.)
 constexpr uint32_t REC_CAP = 7;  // recorded leaves per lane; a lane that needs more sends its wave through the traversal
+constexpr uint32_t REC_MIN_ROW = 8;                          // the ids' rows fill 2 KB: the list of that traversal
+constexpr uint32_t REC_BYTES = (REC_MIN_ROW + REC_CAP) * WAVE * 4;  // per wave
 template <int K>
 struct TopKDist {
   float d[K];
-  uint32_t* rec;   // LDS, this lane's column (nullptr: nothing is recorded)
+  uint32_t* rec;   // LDS, this lane's column (nullptr: nothing is recorded): ids in rows [0, REC_CAP), the leaves'
+                   // smallest distances in rows [REC_MIN_ROW, REC_MIN_ROW + REC_CAP)
   uint32_t nrec;   // leaves this lane would have recorded (> REC_CAP: the list is incomplete)
   __device__ __forceinline__ void init(uint32_t* rec_column = nullptr) {
 #pragma unroll
@@ -565,8 +565,11 @@ struct TopKDist {
     rec = rec_column;
     nrec = 0;
   }
-  __device__ __forceinline__ void record(uint32_t leaf_id) {
-    if (nrec < REC_CAP) rec[nrec * WAVE] = leaf_id;
+  __device__ __forceinline__ void record(uint32_t leaf_id, float nearest) {
+    if (nrec < REC_CAP) {
+      rec[nrec * WAVE] = leaf_id;
+      rec[(REC_MIN_ROW + nrec) * WAVE] = __float_as_uint(nearest);
+    }
     ++nrec;
   }
   static constexpr int QPL = 1;
@@ -600,7 +603,10 @@ struct TopKDist {
         r1 = r1 + dy * dy;
         r1 = r1 + dz * dz;
       }
-      m = __builtin_fminf(__builtin_fminf(m, r0.x), __builtin_fminf(r0.y, __builtin_fminf(r1.x, r1.y)));
+      const float m4 = __builtin_fminf(__builtin_fminf(r0.x, r0.y), __builtin_fminf(r1.x, r1.y));
+      m = __builtin_fminf(m, m4);
+      // (skipping the four insertions when no active lane's list can change -- one ballot per chunk -- was measured:
+      // 2.12 against 2.08 ms, the branch costs more than the medians it saves)
       insert(r0.x);
       insert(r0.y);
       insert(r1.x);
@@ -613,7 +619,7 @@ struct TopKDist {
     if (leaf_id != NO_INDEX) {
       const float before = d[K - 1];
       const float m = block<16>(reinterpret_cast<const float4*>(buf) + slot, qx, qy, qz);  // transposed staging
-      if (rec != nullptr && m <= before) record(leaf_id);
+      if (rec != nullptr && m <= before) record(leaf_id, m);
     }
   }
   // Self-queries: the lane's OWN leaf is evaluated before the traversal (straight from the SoA copy), so the search
@@ -683,6 +689,58 @@ struct CollectLE {
         take(r0.y, base + uint32_t(4 * c4 + 1));
         take(r1.x, base + uint32_t(4 * c4 + 2));
         take(r1.y, base + uint32_t(4 * c4 + 3));
+      }
+    }
+  }
+};
+
+// The second pass without a walk: the lane reads ONE leaf (its own, or one it recorded in the first pass) straight from
+// the index's SoA copy and appends every candidate up to thr (finite) as an 8-bit code -- (row of the record << 4) | slot
+// in the leaf -- to a 64-bit register: eight codes, more candidates than that are only counted.  Same distance arithmetic
+// as every other policy; "d <= thr" is read off the sign of thr - d (a difference of floats is negative exactly when
+// d > thr), sixteen of them shifted into one mask.
+struct CollectCodes {
+  float thr;
+  uint32_t cnt;
+  uint64_t codes;
+  __device__ __forceinline__ void leaf(const float* soa, uint32_t leaf_id, uint32_t row, const float* qx, const float* qy,
+                                       const float* qz) {
+    uint32_t hits = 0;  // bit 15 - j: point j is a candidate
+    if (leaf_id != NO_INDEX) {
+      const float4* s = reinterpret_cast<const float4*>(soa + size_t(leaf_id) * LEAF_FLOATS);
+      const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]}, t2 = {thr, thr};
+      uint32_t over = 0;
+#pragma unroll
+      for (int c4 = 0; c4 < LEAF / 4; ++c4) {
+        const float4 X = s[c4], Y = s[4 + c4], Z = s[8 + c4];
+        v2f r0, r1;
+        {
+          const v2f dx = qx2 - v2f{X.x, X.y}, dy = qy2 - v2f{Y.x, Y.y}, dz = qz2 - v2f{Z.x, Z.y};
+          r0 = dx * dx;
+          r0 = r0 + dy * dy;
+          r0 = r0 + dz * dz;
+        }
+        {
+          const v2f dx = qx2 - v2f{X.z, X.w}, dy = qy2 - v2f{Y.z, Y.w}, dz = qz2 - v2f{Z.z, Z.w};
+          r1 = dx * dx;
+          r1 = r1 + dy * dy;
+          r1 = r1 + dz * dz;
+        }
+        const v2f u0 = t2 - r0, u1 = t2 - r1;
+        over = __builtin_amdgcn_alignbit(over, __float_as_uint(u0.x), 31);  // (over << 1) | sign
+        over = __builtin_amdgcn_alignbit(over, __float_as_uint(u0.y), 31);
+        over = __builtin_amdgcn_alignbit(over, __float_as_uint(u1.x), 31);
+        over = __builtin_amdgcn_alignbit(over, __float_as_uint(u1.y), 31);
+      }
+      hits = ~over & 0xFFFFu;
+    }
+    while (__builtin_amdgcn_ballot_w64(hits != 0) != 0) {
+      if (hits != 0) {
+        const uint32_t b = 31u - uint32_t(__builtin_clz(hits));  // ascending slots
+        const uint64_t code = uint64_t((row << 4) | (15u - b));
+        if (cnt < 8u) codes |= code << (8u * cnt);
+        ++cnt;
+        hits &= ~(1u << b);
       }
     }
   }
@@ -1153,9 +1211,6 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
               mask |= ((!(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w))) ? 1u : 0u) << t;
             }
             if (!valid[0]) mask = 0;
-#if PCLHIP_RETEST
-            const float w_mask = pol.worst(0);  // the lane's bound when its mask was built
-#endif
             while (__builtin_amdgcn_ballot_w64(mask != 0) != 0) {
               if (!landed) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1167,29 +1222,8 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
                 id = __float_as_uint(wl.list[3 * (b0 + slot)].w);
                 mask &= mask - 1u;
               }
-#if PCLHIP_RETEST
-              // A lane whose bound has tightened since the scan looks at its popped leaf again (its own list entry, not
-              // a broadcast) and moves on to its next one if the leaf fell out: the rounds of a batch follow the lane
-              // with the most leaves, and that is a lane whose first bound was loose.
-#pragma unroll
-              for (int again = 0; again < PCLHIP_RETEST; ++again) {
-                const bool look = id != NO_INDEX && pol.worst(0) < w_mask;
-                if (__builtin_amdgcn_ballot_w64(look) == 0) break;
-                bool out = false;
-                if (look) {
-                  const float4 ea = wl.list[3 * (b0 + slot)], eb = wl.list[3 * (b0 + slot) + 1];
-                  out = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z) > pol.worst(0);
-                }
-                if (out) {
-                  id = NO_INDEX;
-                  if (mask != 0) {
-                    slot = uint32_t(__builtin_ctz(mask));
-                    id = __float_as_uint(wl.list[3 * (b0 + slot)].w);
-                    mask &= mask - 1u;
-                  }
-                }
-              }
-#endif
+              // (Re-testing a popped leaf against the lane's tightened bound, up to two pops per round, was measured: the
+              // rounds of a batch did not get fewer -- 2.60 against 2.56 ms for the normals, +2 % on the seeded searches.)
               round(slot, id);
             }
           }
