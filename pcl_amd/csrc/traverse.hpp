@@ -1199,6 +1199,12 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
               if (__builtin_amdgcn_ballot_w64(valid[0] && now < w0) != 0) T = wave_max_f(valid[0] ? now : 0.0f);
             }
           } else {
+            // (Deferring these evaluations -- queueing the leaf ids per lane in LDS across batches and nodes and reading
+            // the leaves straight from the index when a queue fills up or the search ends -- was measured: the rounds
+            // then follow the largest number of leaves any one lane needs instead of the sum of the batches' maxima
+            // (lanes are active in 14 of 64 slots of a round in the normals, 20 of 64 in a converged ICP iteration), but
+            // every round waits for the index instead of finding its leaves staged under the box tests, and the bounds
+            // tighten later: 0.565 -> 0.645 ms for a converged iteration, 2.07 -> 2.02 ms for the normals.)
             // Tight bounds (seeded iterations): one branch-free scan builds a per-lane bit mask of the
             // batch's leaves the lane's bound cannot exclude (the box tests pipeline freely), then every
             // lane pops its leaves in rounds.  Rounds per node ~ max over lanes of the leaves a lane
