@@ -550,7 +550,10 @@ struct TopKReg {
 // The final k-th distance is never larger, so a point within it -- one that ties with it included -- lies in a recorded
 // leaf, and the second pass reads those leaves again instead of walking the index a second time.
 // (The lane's own leaf, evaluated before the traversal, is not in the list: the caller knows it.)
-constexpr uint32_t REC_CAP = 7;  // recorded leaves per lane; a lane that needs more sends its wave through the traversal
+#ifndef PCLHIP_REC_CAP
+#define PCLHIP_REC_CAP 7  // (a build with 1 drives most waves through the fallback: scripts/final_evidence.sh tests it)
+#endif
+constexpr uint32_t REC_CAP = PCLHIP_REC_CAP;  // recorded leaves per lane; a lane that needs more sends its wave through the traversal
 constexpr uint32_t REC_MIN_ROW = 8;                          // the ids' rows fill 2 KB: the list of that traversal
 constexpr uint32_t REC_BYTES = (REC_MIN_ROW + REC_CAP) * WAVE * 4;  // per wave
 template <int K>

@@ -20,6 +20,12 @@ python bench.py --no-cpu-baseline --no-host-align --reciprocal > $OUT/bench3_rec
 PCLHIP_LIB=pcl_amd/variants/libpclhip_stats.so python scratch/stats_probe.py 10000000 > $OUT/stats.log 2>&1
 PCLHIP_LIB=pcl_amd/variants/libpclhip_prof.so python scratch/stats_probe.py 10000000 2>&1 | grep "it0" > $OUT/standoff_stage_ticks.log
 PCLHIP_LIB=pcl_amd/variants/libpclhip_why.so python scratch/stats_probe.py 10000000 2>&1 | grep "it0" > $OUT/standoff_exits.log
+# tick profiles of the normals kernel (pass 1 / pass 2 / plane fit) and of the seeded search body (before / traversal / after)
+PCLHIP_LIB=pcl_amd/variants/libpclhip_nrmprof.so python scratch/stats_probe.py 10000000 2>&1 | grep "normals" > $OUT/normals_stage_ticks.log
+PCLHIP_LIB=pcl_amd/variants/libpclhip_icpprof.so python scratch/stats_probe.py 10000000 2>&1 | grep "icp it" > $OUT/seeded_stage_ticks.log
+PCLHIP_LIB=pcl_amd/variants/libpclhip_lanes.so python scratch/stats_probe.py 10000000 2>&1 | grep -E "normals|icp it" > $OUT/active_lanes_per_round.log
+# the normals' fallback paths (records overflowing, exact policy): a build with one record per lane, same tests
+PCLHIP_LIB=pcl_amd/variants/libpclhip_rec1.so python -m pytest tests -m gpu -q -k "normal or Normal or fuzz" > $OUT/tests_rec1.log 2>&1; tail -1 $OUT/tests_rec1.log
 bash scripts/profile_iter.sh $TAG > $OUT/prof_iter.log 2>&1; cp gpurun_out/prof_$TAG/per_iter.txt $OUT/per_iter.txt 2>/dev/null
 python scratch/first_probe.py > $OUT/first_call.log 2>&1
 python scratch/misc_probe.py > $OUT/misc.log 2>&1
