@@ -132,6 +132,29 @@ void dev_reserve_for_points(pclhip_ctx* ctx, uint64_t points) {
   if (want > 0) (void)reserve_arena(ctx, want);
 }
 
+hipError_t pinned_malloc(pclhip_ctx* ctx, void** p, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lock(ctx->cache_mutex);
+    for (size_t i = 0; i < ctx->pinned_cache.size(); ++i)
+      if (ctx->pinned_cache[i].second == bytes) {
+        *p = ctx->pinned_cache[i].first;
+        ctx->pinned_cache.erase(ctx->pinned_cache.begin() + long(i));
+        return hipSuccess;
+      }
+  }
+  return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+
+void pinned_free(pclhip_ctx* ctx, void* p, size_t bytes) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lock(ctx->cache_mutex);
+  if (ctx->pinned_cache.size() < 64 && bytes <= (size_t(1) << 20)) {
+    ctx->pinned_cache.emplace_back(p, bytes);
+    return;
+  }
+  (void)hipHostFree(p);
+}
+
 hipError_t dev_malloc(pclhip_ctx* ctx, void** p, size_t bytes) {
   *p = nullptr;
   if (bytes == 0) bytes = 16;
@@ -438,6 +461,8 @@ void pclhip_ctx_destroy(pclhip_ctx* ctx) {
   if (ctx->stats) (void)hipFree(ctx->stats);
   if (ctx->staging) (void)hipFree(ctx->staging);
   dev_cache_release(ctx);
+  for (auto& b : ctx->pinned_cache) (void)hipHostFree(b.first);
+  ctx->pinned_cache.clear();
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -915,7 +940,7 @@ pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out) {
   icp->target = target;
   icp->prev_mse = DBL_MAX;
   if (dev_malloc(ctx, &icp->sums_dev, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
-      hipHostMalloc(&icp->sums_host, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
+      pinned_malloc(ctx, &icp->sums_host, PCLHIP_ICP_NSUMS * sizeof(double)) != hipSuccess ||
       // timing markers between kernels of one stream: device-scope release is enough (a system-scope
       // release would write the iteration's dirty lines back to memory at every marker)
       hipEventCreateWithFlags(&icp->ev0, hipEventReleaseToDevice) != hipSuccess ||
@@ -965,12 +990,12 @@ void pclhip_icp_destroy(pclhip_icp* icp) {
   }
   icp_free_source(icp);
   if (icp->sums_dev) (void)dev_free(icp->ctx, icp->sums_dev);
-  if (icp->sums_host) (void)hipHostFree(icp->sums_host);
+  if (icp->sums_host) pinned_free(icp->ctx, icp->sums_host, PCLHIP_ICP_NSUMS * sizeof(double));
   if (icp->rej_state) (void)dev_free(icp->ctx, icp->rej_state);
-  if (icp->rej_state_host) (void)hipHostFree(icp->rej_state_host);
+  if (icp->rej_state_host) pinned_free(icp->ctx, icp->rej_state_host, sizeof(pclhip::RejState));
   if (icp->ctl) (void)dev_free(icp->ctx, icp->ctl);
-  if (icp->ctl_host) (void)hipHostFree(icp->ctl_host);
-  if (icp->steps) (void)hipHostFree(icp->steps);
+  if (icp->ctl_host) pinned_free(icp->ctx, icp->ctl_host, sizeof(pclhip::IcpControl));
+  if (icp->steps) pinned_free(icp->ctx, icp->steps, sizeof(pclhip::IcpStepRecord) * size_t(icp->steps_capacity));
   for (hipEvent_t e : icp->step_events)
     if (e) (void)hipEventDestroy(e);
   if (icp->ev0) (void)hipEventDestroy(icp->ev0);

@@ -203,8 +203,8 @@ pclhip_status ensure_loop_state(pclhip_icp* icp) {
   pclhip_ctx* ctx = icp->ctx;
   if (icp->ctl != nullptr) return PCLHIP_OK;
   PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->ctl, sizeof(IcpControl)));
-  PCLHIP_CHECK_HIP(ctx, hipHostMalloc(&icp->ctl_host, sizeof(IcpControl), hipHostMallocDefault));
-  PCLHIP_CHECK_HIP(ctx, hipHostMalloc(&icp->steps, sizeof(IcpStepRecord) * kRing, hipHostMallocDefault));
+  PCLHIP_CHECK_HIP(ctx, pinned_malloc(ctx, &icp->ctl_host, sizeof(IcpControl)));
+  PCLHIP_CHECK_HIP(ctx, pinned_malloc(ctx, &icp->steps, sizeof(IcpStepRecord) * kRing));
   std::memset(icp->steps, 0, sizeof(IcpStepRecord) * kRing);
   icp->steps_capacity = kRing;
   icp->step_events.assign(size_t(kRing) * 4, nullptr);

@@ -147,6 +147,9 @@ struct pclhip_ctx {
   size_t cached_bytes = 0;
   size_t cache_limit = size_t(16384) << 20;
   std::mutex cache_mutex;
+  // Small pinned host blocks (control blocks, step rings, mirrored states of the registrations) are kept for the
+  // context's lifetime: hipHostFree synchronises the device (170 us each, three per registration object).
+  std::vector<std::pair<void*, size_t>> pinned_cache;  // free blocks (pointer, bytes)
   // One reservation in front of that cache (pclhip_ctx_reserve; made automatically for the first cloud of a million
   // points or more): allocations are carved out of it (first fit, freed ranges coalesce), so a context's FIRST index
   // build pays one hipMalloc instead of some forty.  What does not fit goes the way above.
@@ -248,6 +251,12 @@ namespace pclhip {
 // Frees device allocations and destroys events on scope exit (every early error return included).
 // context-cached device memory (api.hip): same contract as hipMalloc / hipFree
 hipError_t dev_malloc(pclhip_ctx* ctx, void** p, size_t bytes);
+hipError_t pinned_malloc(pclhip_ctx* ctx, void** p, size_t bytes);  // hipHostMalloc through the context's cache
+void pinned_free(pclhip_ctx* ctx, void* p, size_t bytes);
+template <class T>
+inline hipError_t pinned_malloc(pclhip_ctx* ctx, T** p, size_t bytes) {
+  return pinned_malloc(ctx, reinterpret_cast<void**>(p), bytes);
+}
 void dev_free(pclhip_ctx* ctx, void* p);
 void dev_cache_release(pclhip_ctx* ctx);  // really frees every cached block
 pclhip_status reserve_arena(pclhip_ctx* ctx, size_t bytes);

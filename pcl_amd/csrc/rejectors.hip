@@ -298,7 +298,7 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
   if (!icp->keep) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->keep, n));
   if (!icp->rej_state) {
     PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->rej_state, sizeof(RejState)));
-    PCLHIP_CHECK_HIP(ctx, hipHostMalloc(&icp->rej_state_host, sizeof(RejState), hipHostMallocDefault));
+    PCLHIP_CHECK_HIP(ctx, pinned_malloc(ctx, &icp->rej_state_host, sizeof(RejState)));
     std::memset(icp->rej_state_host, 0, sizeof(RejState));
   }
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(icp->rej_state, 0, sizeof(RejState), s));

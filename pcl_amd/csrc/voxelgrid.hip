@@ -111,16 +111,20 @@ __global__ __launch_bounds__(256) void vg_key_kernel(const void* pts, size_t str
   if (threadIdx.x == 0 && blk) atomicAdd(n_valid, blk);
 }
 
-__global__ void vg_head_kernel(const uint32_t* keys, uint32_t nv, uint32_t* head) {
+// (the number of valid points nv <= n is read from device memory: the host does not wait for it before these launches)
+__global__ void vg_head_kernel(const uint32_t* keys, uint32_t n, const unsigned int* __restrict__ nv_dev, uint32_t* head) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < nv) head[j] = (j == 0 || keys[j] != keys[j - 1]) ? 1u : 0u;
+  const uint32_t nv = *nv_dev;
+  if (j < n) head[j] = (j < nv && (j == 0 || keys[j] != keys[j - 1])) ? 1u : 0u;
 }
 
 // run_start[r] = first sorted position of run r (r = exclusive scan of head)
-__global__ void vg_runstart_kernel(const uint32_t* head, const uint32_t* scan, uint32_t nv, uint32_t* run_start) {
+__global__ void vg_runstart_kernel(const uint32_t* head, const uint32_t* scan, const unsigned int* __restrict__ nv_dev,
+                                   uint32_t* run_start) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nv = *nv_dev;
   if (j < nv && head[j]) run_start[scan[j]] = j;
-  if (j == nv - 1) run_start[scan[j] + head[j]] = nv;  // end sentinel
+  if (nv != 0 && j == nv - 1) run_start[scan[j] + head[j]] = nv;  // end sentinel
 }
 
 __global__ void vg_keep_kernel(const uint32_t* run_start, uint32_t nruns, uint32_t min_pts, uint32_t* keep) {
@@ -635,18 +639,18 @@ extern "C" pclhip_status pclhip_voxelgrid_ex2(pclhip_ctx* ctx, const void* point
   }
   const uint32_t* keys_sorted = k0;   // after the last swap
   const uint32_t* vals_sorted = v0;
+  // --- runs --- (sized for all n points; the kernels read the number of valid ones from the device: one host
+  // synchronisation for both counts instead of two)
+  const uint32_t n32 = uint32_t(n);
+  hipLaunchKernelGGL(vg_head_kernel, dim3((n32 + 255) / 256), dim3(256), 0, s, keys_sorted, n32, d_cnt, head);
+  scan_u32(head, n, scan);
   unsigned int nv = 0;
+  uint32_t nruns = 0;
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nv, d_cnt, sizeof nv, hipMemcpyDeviceToHost, s));
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nruns, tot, sizeof nruns, hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(vg_runstart_kernel, dim3((n32 + 255) / 256), dim3(256), 0, s, head, scan, d_cnt, run_start);
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
   if (nv == 0) return layout_out();
-
-  // --- runs ---
-  hipLaunchKernelGGL(vg_head_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, keys_sorted, nv, head);
-  scan_u32(head, nv, scan);
-  uint32_t nruns = 0;
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&nruns, tot, sizeof nruns, hipMemcpyDeviceToHost, s));
-  hipLaunchKernelGGL(vg_runstart_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, head, scan, nv, run_start);
-  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
   uint32_t* keep = head;        // head / scan are consumed: reuse them for the per-run arrays (nruns <= nv)
   uint32_t* keep_scan = scan;
   hipLaunchKernelGGL(vg_keep_kernel, dim3((nruns + 255) / 256), dim3(256), 0, s, run_start, nruns, min_points_per_voxel,
