@@ -138,6 +138,8 @@ __global__ void vg_keep_kernel(const uint32_t* run_start, uint32_t nruns, uint32
 // a wavefront owns 1024 consecutive keys as 16 rows of 64; lanes with equal digits find each other with eight
 // ballots, the lowest of them bumps the wave's running count of that digit (LDS, no atomics: one leader per digit
 // and row), so every key gets its rank among the equal digits before it -- index order, hence stable.
+// (Digits of 10 bits -- two passes instead of three for the 20 key bits of a 0.01 grid over the bench's cloud -- were
+// measured: 1024 bins scatter into shorter segments and need 20 KB of LDS per block, 1.10 against 0.93 ms per cloud.)
 constexpr int RS_KPB = 4096, RS_THREADS = 256, RS_ROWS = RS_KPB / RS_THREADS;  // 16 rows per thread
 
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
