@@ -26,6 +26,10 @@ PCLHIP_LIB=pcl_amd/variants/libpclhip_icpprof.so python scratch/stats_probe.py 1
 PCLHIP_LIB=pcl_amd/variants/libpclhip_lanes.so python scratch/stats_probe.py 10000000 2>&1 | grep -E "normals|icp it" > $OUT/active_lanes_per_round.log
 # the normals' fallback paths (records overflowing, exact policy): a build with one record per lane, same tests
 PCLHIP_LIB=pcl_amd/variants/libpclhip_rec1.so python -m pytest tests -m gpu -q -k "normal or Normal or fuzz" > $OUT/tests_rec1.log 2>&1; tail -1 $OUT/tests_rec1.log
+# randomised rounds against the oracle on the final build (scratch/fuzz_*.py <seed> <rounds>)
+for seed in 11 12; do timeout 200 python scratch/fuzz_knn.py $seed 30 2>&1 | tail -1; done > $OUT/fuzz_knn.log
+for seed in 11 12; do timeout 200 python scratch/fuzz_filters.py $seed 25 2>&1 | tail -1; done > $OUT/fuzz_filters.log
+cat $OUT/fuzz_knn.log $OUT/fuzz_filters.log
 bash scripts/profile_iter.sh $TAG > $OUT/prof_iter.log 2>&1; cp gpurun_out/prof_$TAG/per_iter.txt $OUT/per_iter.txt 2>/dev/null
 python scratch/first_probe.py > $OUT/first_call.log 2>&1
 python scratch/misc_probe.py > $OUT/misc.log 2>&1
