@@ -226,7 +226,7 @@ pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, 
 // =================================================================================================
 
 template <int K>
-__global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, float vx, float vy, float vz,
+__global__ __launch_bounds__(BLOCK, (K == 8 && PCLHIP_NRM_WAVES >= 4) ? 4 : 1) void normals_kernel(IndexView ix, int k, float vx, float vy, float vz,
                                                         float4* __restrict__ nrm_sorted,
                                                         unsigned long long* __restrict__ nan_count,
                                                         unsigned long long* gstats) {
@@ -234,7 +234,8 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
   // the exact policy of tie lanes may overwrite with its fourth KB of staging -- the records are used up by then.  52 KB
   // per block: three blocks per CU (at 53 KB only two were resident: 3.9 against 2.6 ms)
   constexpr int REC_AT = 3072 / 4;  // first float of the records inside the staging buffer
-  typedef typename std::conditional<K == 8, WaveLdsT<3072 + REC_BYTES>, WaveLds>::type NrmWaveLds;
+  typedef typename std::conditional<PCLHIP_NRM_WAVES >= 4, WaveLdsBoxT<3072 + REC_BYTES>, WaveLdsT<3072 + REC_BYTES>>::type Nrm8Lds;
+  typedef typename std::conditional<K == 8, Nrm8Lds, WaveLds>::type NrmWaveLds;
   __shared__ NrmWaveLds wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
   load_top_cache(ix, topbox_s);
@@ -313,10 +314,14 @@ __global__ __launch_bounds__(BLOCK) void normals_kernel(IndexView ix, int k, flo
         cc.codes = 0;
         // the records that still matter: nearest point not beyond the FINAL k-th distance
         uint32_t rel = 0;
+        if constexpr (REC_MINS) {
 #pragma unroll
-        for (uint32_t r = 0; r < REC_CAP; ++r) {
-          const float m = __uint_as_float(rec[(REC_MIN_ROW + r) * WAVE]);
-          rel |= (r < nrec && m <= thr) ? (1u << r) : 0u;
+          for (uint32_t r = 0; r < REC_CAP; ++r) {
+            const float m = __uint_as_float(rec[(REC_MIN_ROW + r) * WAVE]);
+            rel |= (r < nrec && m <= thr) ? (1u << r) : 0u;
+          }
+        } else {
+          rel = (1u << nrec) - 1u;  // nrec <= REC_CAP here
         }
         uint32_t id = valid ? i / LEAF : NO_INDEX, row = REC_CAP;  // the own leaf (seed_own_leaf) first
         for (;;) {

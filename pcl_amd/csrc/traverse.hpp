@@ -42,11 +42,24 @@ constexpr int LEAF_FLOATS = 4 * LEAF;  // x[16] y[16] z[16] w[16]
 template <int BUF_BYTES>
 struct __attribute__((aligned(16))) WaveLdsT {
   static constexpr int BUF_FLOATS = BUF_BYTES / 4;
+  static constexpr int LIST_STRIDE = 3;  // float4 per ranked leaf
   uint2 stack[STACK_ENTRIES];
   float4 list[3 * FANOUT];  // per ranked leaf: seeded searches (lo.xyz, id) (hi.xyz, lbG) (-);
                             // loose searches (disc centre.xyz, id) (-, -, -, lbG) (disc normal.xyz, hn), R in rad[]
   float rad[FANOUT];
   float buf[BUF_FLOATS];
+  __device__ __forceinline__ float* radii() { return rad; }
+};
+// The same for searches that never bound leaves by their discs (self-queries: the normals): two float4 per ranked leaf
+// and no radii -- 1.25 KB less per wave.  traverse() reads LIST_STRIDE and never takes the disc branches with it.
+template <int BUF_BYTES>
+struct __attribute__((aligned(16))) WaveLdsBoxT {
+  static constexpr int BUF_FLOATS = BUF_BYTES / 4;
+  static constexpr int LIST_STRIDE = 2;
+  uint2 stack[STACK_ENTRIES];
+  float4 list[2 * FANOUT];
+  float buf[BUF_FLOATS];
+  __device__ __forceinline__ float* radii() { return buf; }  // never dereferenced (no discs with this layout)
 };
 typedef WaveLdsT<LEAF_BATCH * LEAF_FLOATS * 4> WaveLds;  // 4 KB of staging: x y z w chunks of 16 leaves
 
@@ -555,7 +568,11 @@ struct TopKReg {
 #endif
 constexpr uint32_t REC_CAP = PCLHIP_REC_CAP;  // recorded leaves per lane; a lane that needs more sends its wave through the traversal
 constexpr uint32_t REC_MIN_ROW = 8;                          // the ids' rows fill 2 KB: the list of that traversal
-constexpr uint32_t REC_BYTES = (REC_MIN_ROW + REC_CAP) * WAVE * 4;  // per wave
+#ifndef PCLHIP_NRM_WAVES
+#define PCLHIP_NRM_WAVES 4  // waves per SIMD of normals_kernel<8>: 4 = box-only LDS layout, records without their minima
+#endif
+constexpr bool REC_MINS = PCLHIP_NRM_WAVES < 4;  // keep every record's nearest distance (filters the second pass)
+constexpr uint32_t REC_BYTES = (REC_MIN_ROW + (REC_MINS ? REC_CAP : 0u)) * WAVE * 4;  // per wave
 template <int K>
 struct TopKDist {
   float d[K];
@@ -571,7 +588,7 @@ struct TopKDist {
   __device__ __forceinline__ void record(uint32_t leaf_id, float nearest) {
     if (nrec < REC_CAP) {
       rec[nrec * WAVE] = leaf_id;
-      rec[(REC_MIN_ROW + nrec) * WAVE] = __float_as_uint(nearest);
+      if constexpr (REC_MINS) rec[(REC_MIN_ROW + nrec) * WAVE] = __float_as_uint(nearest);
     }
     ++nrec;
   }
@@ -901,7 +918,9 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
   // Disc bounds pay where queries STAND OFF the indexed surface (the unseeded first iteration of a
   // registration): the caller says so.  Self-queries (normals) and seeded queries sit on or near the surface,
   // inside the discs of all the leaves around them, where a disc excludes nothing a box does not.
-  const bool have_disc = allow_disc && ix.disc != nullptr;
+  constexpr int LS = WL::LIST_STRIDE;  // 3: (box | disc centre, id) (box, bound) (disc normal); 2: boxes only
+  const bool have_disc = LS == 3 && allow_disc && ix.disc != nullptr;
+  float* const rad = wl.radii();
   uint2* const stack = wl.stack;
 
   int sp = 0;
@@ -1014,13 +1033,13 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
       const uint32_t n_alive = uint32_t(__builtin_popcountll(mask));
       if (alive) {
         if (use_disc) {
-          wl.list[3 * rank] = make_float4(dcR.x, dcR.y, dcR.z, __uint_as_float(first + uint32_t(lane)));
-          wl.list[3 * rank + 1] = make_float4(0.0f, 0.0f, 0.0f, lbG);
-          wl.list[3 * rank + 2] = dnh;
-          wl.rad[rank] = dcR.w;
+          wl.list[LS * rank] = make_float4(dcR.x, dcR.y, dcR.z, __uint_as_float(first + uint32_t(lane)));
+          wl.list[LS * rank + 1] = make_float4(0.0f, 0.0f, 0.0f, lbG);
+          wl.list[LS * rank + 2] = dnh;
+          rad[rank] = dcR.w;
         } else {
-          wl.list[3 * rank] = make_float4(lx, ly, lz, __uint_as_float(first + uint32_t(lane)));
-          wl.list[3 * rank + 1] = make_float4(hx, hy, hz, lbG);
+          wl.list[LS * rank] = make_float4(lx, ly, lz, __uint_as_float(first + uint32_t(lane)));
+          wl.list[LS * rank + 1] = make_float4(hx, hy, hz, lbG);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -1048,7 +1067,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         const auto stage = [&](uint32_t b0, uint32_t nb) {
           const uint32_t slot = uint32_t(lane) & 15u;
           uint32_t leaf_id = 0;
-          if (slot < nb) leaf_id = __float_as_uint(wl.list[3 * (b0 + slot)].w);
+          if (slot < nb) leaf_id = __float_as_uint(wl.list[LS * (b0 + slot)].w);
 #pragma unroll
           for (int i = 0; i < NCHUNK / 4; ++i) {
             if (slot < nb) {
@@ -1114,9 +1133,9 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
               const uint32_t e = e0 + sub;
               bool al = false;
               if (e < n_alive) {
-                const float4 ea = wl.list[3 * e], eb = wl.list[3 * e + 1], es = wl.list[3 * e + 2];
+                const float4 ea = wl.list[LS * e], eb = wl.list[LS * e + 1], es = wl.list[LS * e + 2];
                 al = !(eb.w > T) && (!(rr.rho < 1e30f) ||
-                                     row_reach_alive(rr, ngx, ngy, ngz, make_float4(ea.x, ea.y, ea.z, wl.rad[e]), es));
+                                     row_reach_alive(rr, ngx, ngy, ngz, make_float4(ea.x, ea.y, ea.z, rad[e]), es));
               }
               const uint64_t bal = __builtin_amdgcn_ballot_w64(al);
               rowmask |= ((bal >> rshift) & 0xFFFFull) << e0;
@@ -1128,8 +1147,8 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
               const bool has = todo != 0;
               const uint32_t e = has ? uint32_t(__builtin_ctzll(todo)) : b0;
               todo &= todo - 1ull;  // 0 stays 0
-              const float4 ea = wl.list[3 * e], es = wl.list[3 * e + 2];
-              const float lb = point_disc_lb(qx[0], qy[0], qz[0], make_float4(ea.x, ea.y, ea.z, wl.rad[e]), es);
+              const float4 ea = wl.list[LS * e], es = wl.list[LS * e + 2];
+              const float lb = point_disc_lb(qx[0], qy[0], qz[0], make_float4(ea.x, ea.y, ea.z, rad[e]), es);
               const bool need = has && !(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w));
               lanemask |= need ? (1ull << e) : 0ull;
             }
@@ -1144,7 +1163,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
                 uint32_t slot = 0, id = NO_INDEX;
                 if (m16 != 0) {
                   slot = uint32_t(__builtin_ctz(m16));
-                  id = __float_as_uint(wl.list[3 * (c0 + slot)].w);
+                  id = __float_as_uint(wl.list[LS * (c0 + slot)].w);
                   m16 &= m16 - 1u;
                 }
                 round(slot, id);
@@ -1160,7 +1179,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
             // as early as possible and the tail of the list is cut off by the shrinking wave radius.
             uint32_t pslot = 0, pid = NO_INDEX;
             for (uint32_t t = 0; t < nb; ++t) {
-              const float4 ea = wl.list[3 * (b0 + t)], eb = wl.list[3 * (b0 + t) + 1];  // broadcast reads
+              const float4 ea = wl.list[LS * (b0 + t)], eb = wl.list[LS * (b0 + t) + 1];  // broadcast reads
               if (uniform_f32(eb.w) > T) {  // sorted: every remaining leaf is farther than the wave radius
                 cut = true;
                 break;
@@ -1168,8 +1187,8 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
               ++ts.c[1];
               float lb;
               if (use_disc) {
-                const float4 es = wl.list[3 * (b0 + t) + 2];
-                lb = point_disc_lb(qx[0], qy[0], qz[0], make_float4(ea.x, ea.y, ea.z, wl.rad[b0 + t]), es);
+                const float4 es = wl.list[LS * (b0 + t) + 2];
+                lb = point_disc_lb(qx[0], qy[0], qz[0], make_float4(ea.x, ea.y, ea.z, rad[b0 + t]), es);
               } else {
                 lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
               }
@@ -1215,7 +1234,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
             ts.c[1] += nb;
             uint32_t mask = 0;
             for (uint32_t t = 0; t < nb; ++t) {
-              const float4 ea = wl.list[3 * (b0 + t)], eb = wl.list[3 * (b0 + t) + 1];  // broadcast reads
+              const float4 ea = wl.list[LS * (b0 + t)], eb = wl.list[LS * (b0 + t) + 1];  // broadcast reads
               const float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
               mask |= ((!(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w))) ? 1u : 0u) << t;
             }
@@ -1228,7 +1247,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
               uint32_t slot = 0, id = NO_INDEX;
               if (mask != 0) {
                 slot = uint32_t(__builtin_ctz(mask));
-                id = __float_as_uint(wl.list[3 * (b0 + slot)].w);
+                id = __float_as_uint(wl.list[LS * (b0 + slot)].w);
                 mask &= mask - 1u;
               }
               // (Re-testing a popped leaf against the lane's tightened bound, up to two pops per round, was measured: the
@@ -1254,7 +1273,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         for (int t = 0; t < (LEAF_BATCH * LEAF_FLOATS * 4) / (WAVE * 16); ++t) {  // 4 instructions
           const uint32_t slot = uint32_t(t) * (WAVE / 16) + uint32_t(lane) / 16u;
           if (slot < nb) {
-            const uint32_t leaf_id = __float_as_uint(wl.list[3 * (b0 + slot)].w);
+            const uint32_t leaf_id = __float_as_uint(wl.list[LS * (b0 + slot)].w);
             const float* src = ix.soa + size_t(leaf_id) * LEAF_FLOATS + (lane & 15) * 4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(wl.buf + t * (WAVE * 4)), 16, 0,
@@ -1263,7 +1282,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         }
         bool landed = false;
         for (uint32_t t = 0; t < nb; ++t) {
-          const float4 ea = wl.list[3 * (b0 + t)], eb = wl.list[3 * (b0 + t) + 1];  // broadcast reads
+          const float4 ea = wl.list[LS * (b0 + t)], eb = wl.list[LS * (b0 + t) + 1];  // broadcast reads
           if (uniform_f32(eb.w) > T) {
             if (ordered) {  // sorted: every remaining leaf is farther than the wave radius
               cut = true;
@@ -1277,8 +1296,8 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
           for (int q = 0; q < QPL; ++q) {
             float lb;
             if (use_disc) {
-              const float4 es = wl.list[3 * (b0 + t) + 2];
-              lb = point_disc_lb(qx[q], qy[q], qz[q], make_float4(ea.x, ea.y, ea.z, wl.rad[b0 + t]), es);
+              const float4 es = wl.list[LS * (b0 + t) + 2];
+              lb = point_disc_lb(qx[q], qy[q], qz[q], make_float4(ea.x, ea.y, ea.z, rad[b0 + t]), es);
             } else {
               lb = point_box_lb(qx[q], qy[q], qz[q], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
             }
