@@ -959,6 +959,8 @@ static void icp_free_source(pclhip_icp* icp) {
   icp->src_index = nullptr;
   if (icp->src_slot_of_orig) (void)dev_free(icp->ctx, icp->src_slot_of_orig);
   icp->src_slot_of_orig = nullptr;
+  if (icp->src_pos_of_slot) (void)dev_free(icp->ctx, icp->src_pos_of_slot);
+  icp->src_pos_of_slot = nullptr;
   if (icp->src_records) (void)dev_free(icp->ctx, icp->src_records);
   icp->src_records = nullptr;
   icp->src_records_host = nullptr;

@@ -229,9 +229,11 @@ struct pclhip_icp {
   double last_median = 0;
   int fetch_order = 0;            // 0 by query, 1 by (match, distance), 2 by distance
   // reciprocal correspondences: an index over the SOURCE, built once per source cloud and refitted to the moved cloud
-  // every iteration (rejectors.hip); src_slot_of_orig: original source index -> slot of src_cur
+  // every iteration (rejectors.hip); src_slot_of_orig: original source index -> slot of src_cur; src_pos_of_slot: slot
+  // of src_cur -> position of that point inside the source index (the seed of the reciprocal search)
   pclhip_index* src_index = nullptr;
   uint32_t* src_slot_of_orig = nullptr;
+  uint32_t* src_pos_of_slot = nullptr;
   bool trim_pending = false;      // a Trimmed rejector ran: fetch_order becomes 2 if rej_state_host->trimmed says it cut
   pclhip::RejState* rej_state = nullptr;       // device
   pclhip::RejState* rej_state_host = nullptr;  // pinned mirror, valid after a stream synchronisation
@@ -370,6 +372,12 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
 // sums icp->sums_dev over the ranks on the context's stream (native RCCL communicator or the hook); no-op
 // for a single-GPU registration
 pclhip_status allreduce_record(pclhip_icp* icp);
+// The reciprocal test as one seeded search (search.hip): slot i asks the SOURCE index for the nearest neighbour of its
+// matched target point, seeded by source point i itself (position pos_of_slot[i]), and drops the pair unless that is
+// the answer (impl/correspondence_estimation.hpp:247-270).  Stream-ordered, no wait.
+pclhip_status launch_recip_search(pclhip_index* src_ix, const float4* tgt_pts, const uint32_t* match_pos,
+                                  const uint32_t* pos_of_slot, const float4* cur, uint32_t n, float max_d2, bool use_max,
+                                  uint8_t* keep);
 // rejectors.hip: reciprocal filter + rejector chain on icp->keep (stream-ordered, may synchronise)
 pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool use_max);
 // kd order of float4 records whose .w already holds the point's id (used for the reciprocal index)

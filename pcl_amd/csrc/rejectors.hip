@@ -230,19 +230,6 @@ __global__ void rej_o2o_keep_kernel(const float4* __restrict__ cur, const uint32
   }
 }
 
-// reciprocal: queries = matched target points, id = this slot's original source index
-__global__ void recip_query_kernel(const float4* __restrict__ tgt_pts, const uint32_t* __restrict__ match_pos,
-                                   const uint8_t* __restrict__ keep, uint32_t n, float4* __restrict__ q) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float qn = __builtin_nanf("");
-  float4 v = make_float4(qn, qn, qn, __uint_as_float(i));  // .w = output row (this slot)
-  if (keep[i]) {
-    const float4 t = tgt_pts[match_pos[i]];
-    v.x = t.x; v.y = t.y; v.z = t.z;
-  }
-  q[i] = v;
-}
 // slot of every original source index inside the kd-ordered source arrays (src_sorted0 / src_cur)
 __global__ void recip_slot_kernel(const float4* __restrict__ src_sorted0, uint32_t n, uint32_t* __restrict__ slot_of_orig) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,15 +245,11 @@ __global__ void recip_gather_kernel(float4* __restrict__ ix_pts, uint32_t n, con
     ix_pts[i] = make_float4(c.x, c.y, c.z, w);
   }
 }
-// impl/correspondence_estimation.hpp:265-266: drop if d_reciprocal > max^2 or the reciprocal NN is not the query
-__global__ void recip_keep_kernel(const float4* __restrict__ cur, const int32_t* __restrict__ r_idx,
-                                  const float* __restrict__ r_d2, uint32_t n, float max_d2, int use_max,
-                                  uint8_t* __restrict__ keep) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && keep[i]) {
-    const bool ok = r_idx[i] >= 0 && uint32_t(r_idx[i]) == __float_as_uint(cur[i].w) && !(use_max && r_d2[i] > max_d2);
-    if (!ok) keep[i] = 0;
-  }
+// position of every slot's point inside the source index (w = original index on both sides)
+__global__ void recip_pos_kernel(const float4* __restrict__ ix_pts, uint32_t n, const uint32_t* __restrict__ slot_of_orig,
+                                 uint32_t* __restrict__ pos_of_slot) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) pos_of_slot[slot_of_orig[__float_as_uint(ix_pts[p].w)]] = p;
 }
 
 struct Guard {
@@ -324,6 +307,13 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
       icp->src_index->disc = nullptr;
       PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->src_slot_of_orig, size_t(icp->n_orig > 0 ? icp->n_orig : 1) * 4));
       hipLaunchKernelGGL(recip_slot_kernel, grid, block, 0, s, icp->src_sorted0, n, icp->src_slot_of_orig);
+      // where the index keeps every slot's point: the seed of the slot's reciprocal search (points the index left out --
+      // non-finite ones -- have no match and are never asked for)
+      PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->src_pos_of_slot, size_t(n) * 4));
+      PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(icp->src_pos_of_slot, 0xFF, size_t(n) * 4, s));
+      if (icp->src_index->n > 0)
+        hipLaunchKernelGGL(recip_pos_kernel, dim3((icp->src_index->n + TB - 1) / TB), block, 0, s, icp->src_index->pts,
+                           icp->src_index->n, icp->src_slot_of_orig, icp->src_pos_of_slot);
     }
     pclhip_index* const src_ix = icp->src_index;
     if (src_ix->n > 0) {
@@ -332,16 +322,10 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
       pclhip_status st = refit_boxes(src_ix);
       if (st != PCLHIP_OK) return st;
     }
-    float4* q = nullptr;
-    int32_t* r_idx = nullptr;
-    float* r_d2 = nullptr;
-    PCLHIP_CHECK_HIP(ctx, g.alloc(&q, size_t(n) * sizeof(float4)));
-    PCLHIP_CHECK_HIP(ctx, g.alloc(&r_idx, size_t(n) * sizeof(int32_t)));
-    PCLHIP_CHECK_HIP(ctx, g.alloc(&r_d2, size_t(n) * sizeof(float)));
-    hipLaunchKernelGGL(recip_query_kernel, grid, block, 0, s, icp->target->pts, icp->match_pos, icp->keep, n, q);
-    const pclhip_status st = launch_knn(src_ix, q, n, 1, r_idx, r_d2, false);  // rows = slots (q.w), results = original source ids
+    // one seeded search of the source index per surviving pair; the test itself is fused into it (search.hip)
+    const pclhip_status st = launch_recip_search(src_ix, icp->target->pts, icp->match_pos, icp->src_pos_of_slot, icp->src_cur,
+                                                 n, max_d2, use_max, icp->keep);
     if (st != PCLHIP_OK) return st;
-    hipLaunchKernelGGL(recip_keep_kernel, grid, block, 0, s, icp->src_cur, r_idx, r_d2, n, max_d2, use_max ? 1 : 0, icp->keep);
   }
 
   bool trimmed_in_chain = false;

@@ -447,13 +447,27 @@ struct NN1MinT {
       if (unres[q]) {
         const float4* s = reinterpret_cast<const float4*>(ix.soa + size_t(bestpos[q] / LEAF) * LEAF_FLOATS);
         uint32_t hit = 0;
+        // the 16 distances on packed v_pk_* math, exactly as the evaluation computed them (scalar: +0.7 % per converged iteration)
+        const v2f qx2 = {qx[q], qx[q]}, qy2 = {qy[q], qy[q]}, qz2 = {qz[q], qz[q]};
 #pragma unroll
         for (int c4 = 0; c4 < LEAF / 4; ++c4) {
           const float4 X = s[c4], Y = s[LEAF / 4 + c4], Z = s[2 * (LEAF / 4) + c4];
-          hit |= (l2_simple(qx[q], qy[q], qz[q], X.x, Y.x, Z.x) == best[q] ? 1u : 0u) << (4 * c4);
-          hit |= (l2_simple(qx[q], qy[q], qz[q], X.y, Y.y, Z.y) == best[q] ? 1u : 0u) << (4 * c4 + 1);
-          hit |= (l2_simple(qx[q], qy[q], qz[q], X.z, Y.z, Z.z) == best[q] ? 1u : 0u) << (4 * c4 + 2);
-          hit |= (l2_simple(qx[q], qy[q], qz[q], X.w, Y.w, Z.w) == best[q] ? 1u : 0u) << (4 * c4 + 3);
+          {
+            const v2f dx = qx2 - v2f{X.x, X.y}, dy = qy2 - v2f{Y.x, Y.y}, dz = qz2 - v2f{Z.x, Z.y};
+            v2f r = dx * dx;
+            r = r + dy * dy;
+            r = r + dz * dz;
+            hit |= (r.x == best[q] ? 1u : 0u) << (4 * c4);
+            hit |= (r.y == best[q] ? 1u : 0u) << (4 * c4 + 1);
+          }
+          {
+            const v2f dx = qx2 - v2f{X.z, X.w}, dy = qy2 - v2f{Y.z, Y.w}, dz = qz2 - v2f{Z.z, Z.w};
+            v2f r = dx * dx;
+            r = r + dy * dy;
+            r = r + dz * dz;
+            hit |= (r.x == best[q] ? 1u : 0u) << (4 * c4 + 2);
+            hit |= (r.y == best[q] ? 1u : 0u) << (4 * c4 + 3);
+          }
         }
         // hit == 0 cannot happen (identical operations); if it ever did, the exact policy takes over
         tie[q] = tie[q] || hit == 0u || (hit & (hit - 1u)) != 0u;

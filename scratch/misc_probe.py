@@ -16,6 +16,12 @@ print("   voxels:", len(out))
 tree = pcl_amd.KdTree(ctx)
 timed("index build (wall, incl. alloc)", lambda: (tree.__setattr__('_cloud_id', None), tree.setInputCloud(cloud)))
 print("   build_ms (gpu events): %.2f" % tree.build_ms())
+src = torch.from_numpy(synth.apply_rigid(np.linalg.inv(synth.ground_truth_transform()), synth.gaussian_surface(n, synth.SOURCE_SEED))).cuda()
+for kk in (1, 8):
+    timed("nearestKSearch k=%d, %d queries (self)" % (kk, n), lambda: tree.nearestKSearch(cloud, kk))
+    print("   kernel ms %.2f" % tree.lastKernelMs())
+    timed("nearestKSearch k=%d, %d queries (stand-off cloud)" % (kk, n), lambda: tree.nearestKSearch(src, kk))
+    print("   kernel ms %.2f" % tree.lastKernelMs())
 q = cloud[:1_000_000]
 timed("radiusSearch 1M queries r=0.002", lambda: tree.radiusSearch(q, 0.002))
 ne = pcl_amd.NormalEstimation(ctx); ne.setInputCloud(cloud); ne.setSearchMethod(tree); ne.setRadiusSearch(0.002); ne.setViewPoint(0, 0, 10)
