@@ -29,11 +29,17 @@ constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
 // =================================================================================================
 // Queries are Morton-ordered float4 (w = original query index, NO_INDEX bits for non-finite
 // queries).  Results are written at the ORIGINAL query position: out[(orig*k) + c].
+// No search here bounds leaves by discs: the box-only LDS layout (WaveLdsBoxT), for k = 1 with three KB of staging (NN1Min
+// stages no original indices), and four waves per SIMD up to k = 8.  10M self-queries, k = 1: 1.80 -> 1.53 ms, from a
+// stand-off 4.74 -> 4.20 ms; k = 8: 3.48 -> 3.41 and 6.40 -> 6.29 ms.
+#define KNN_MINW(K) ((K) <= 8 ? 4 : 1)
 template <int K>
-__global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const float4* __restrict__ q,
+using KnnWaveLds = WaveLdsBoxT<(K == 1 ? 3072 : LEAF_BATCH * LEAF_FLOATS * 4)>;
+template <int K>
+__global__ __launch_bounds__(BLOCK, KNN_MINW(K)) void knn_reg_kernel(IndexView ix, const float4* __restrict__ q,
                                                         uint32_t nq, int k, int32_t* __restrict__ out_idx,
                                                         float* __restrict__ out_d2, unsigned long long* gstats) {
-  __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
+  __shared__ KnnWaveLds<K> wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
   load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(IndexView ix, const floa
 __global__ __launch_bounds__(BLOCK) void knn_heap_kernel(IndexView ix, const float4* __restrict__ q,
                                                          uint32_t nq, int k, int32_t* __restrict__ out_idx,
                                                          float* __restrict__ out_d2, uint64_t* heap, unsigned long long* gstats) {
-  __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
+  __shared__ KnnWaveLds<64> wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
   load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
