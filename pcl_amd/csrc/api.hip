@@ -438,6 +438,8 @@ static pclhip_status ctx_create_impl(int device, void* stream, bool adopt, pclhi
     const size_t quarter = size_t(prop.totalGlobalMem) / 4;
     if (ctx->cache_limit > quarter) ctx->cache_limit = quarter;
   }
+  PCLHIP_CHECK_HIP(ctx, hipMalloc(&ctx->sched_ctr, pclhip::SCHED_CTR_BYTES));
+  PCLHIP_CHECK_HIP(ctx, hipMemset(ctx->sched_ctr, 0, pclhip::SCHED_CTR_BYTES));
   preload_code_objects(ctx);
   *out = ctx;
   return PCLHIP_OK;
@@ -459,6 +461,7 @@ void pclhip_ctx_destroy(pclhip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) dev_free(ctx, ctx->scratch);
   if (ctx->stats) (void)hipFree(ctx->stats);
+  if (ctx->sched_ctr) (void)hipFree(ctx->sched_ctr);
   if (ctx->staging) (void)hipFree(ctx->staging);
   dev_cache_release(ctx);
   for (auto& b : ctx->pinned_cache) (void)hipHostFree(b.first);

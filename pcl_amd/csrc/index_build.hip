@@ -1270,5 +1270,6 @@ pclhip::IndexView pclhip_index::view() const {
   v.top = top;
   v.n = n;
   v.n_pad = n_pad;
+  v.sched_ctr = ctx->sched_ctr;
   return v;
 }

@@ -32,6 +32,8 @@ namespace pclhip {
 
 constexpr int LEAF = 16;        // points per leaf (candidates broadcast through SGPRs)
 constexpr int FANOUT = 64;      // children per internal node = one per lane of a wavefront
+constexpr int SCHED_CTR_STRIDE = 32;                       // uint32 between the counters of two XCDs (128 bytes)
+constexpr size_t SCHED_CTR_BYTES = 8 * SCHED_CTR_STRIDE * 4;  // GroupFeed's counters of a context
 constexpr int MAX_LEVELS = 6;   // levels 1..5: 16 * 64^5 points, far beyond the int32 indices of the API (2^31 points: 134M leaves ->
                                 // 2.1M, 32768, 512, 8 boxes).  Every entry costs the kernels four scalar registers.
 constexpr int WAVE = 64;
@@ -67,6 +69,7 @@ struct IndexView {
   int top;                      // highest level (count[top] <= FANOUT)
   uint32_t n;                   // finite points
   uint32_t n_pad;
+  uint32_t* sched_ctr;          // the context's group counters, one per XCD, 128 bytes apart (traverse.hpp: GroupFeed)
 };
 
 // Axis-aligned region [lo, hi) of the rank that owns a query (target sharding, dist.hip): a source point
@@ -136,6 +139,8 @@ struct pclhip_ctx {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   unsigned long long* stats = nullptr;  // 8 work counters (device), non-null when enabled
+  uint32_t* sched_ctr = nullptr;        // 8 group counters (device), 128 bytes apart: the dynamic tail of GroupFeed
+  std::mutex feed_mutex;                // keeps "zero the counters, launch" one step of the stream (PCLHIP_LAUNCH_FED)
   void* staging = nullptr;  // device staging for host inputs
   size_t staging_bytes = 0;
   // Device allocations of indices, registrations and temporaries are recycled through the context
@@ -361,6 +366,15 @@ pclhip_status icp_align_device(pclhip_icp* icp, const pclhip_icp_params* params,
 bool icp_is_sharded(const pclhip_icp* icp);
 // under sharding only per-pair filters (the Distance rejector) are allowed: PCLHIP_ERR_STATE otherwise
 pclhip_status sharded_filters_ok(pclhip_icp* icp);
+
+// Kernels that take part of their groups from the context's counters (traverse.hpp: GroupFeed) are launched through
+// this: the counters are zeroed in stream order first, and no other thread's launch gets between the two.
+#define PCLHIP_LAUNCH_FED(ctx, ...)                                                                \
+  do {                                                                                             \
+    std::lock_guard<std::mutex> pclhip_feed_lock((ctx)->feed_mutex);                               \
+    (void)hipMemsetAsync((ctx)->sched_ctr, 0, pclhip::SCHED_CTR_BYTES, (ctx)->stream);             \
+    hipLaunchKernelGGL(__VA_ARGS__);                                                               \
+  } while (0)
 
 // ---- kernels launched from api.cpp ----------------------------------------------------------
 // timed = false: no events, no wait (k <= 32): the launch is queued and the call returns

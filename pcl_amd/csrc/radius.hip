@@ -57,22 +57,25 @@ struct RadiusFill {
 // BYPOS: counts / offsets are indexed by the query's position in `q` (self-queries of the index in kd
 // order) instead of by the original index stored in q[i].w; [q_begin, q_end) restricts the launch to a
 // chunk of queries whose segments start at offsets[i] - base.
+// (box-only LDS layout -- a radius query never bounds leaves by discs --: 36 KB per block, a fourth block per CU)
 template <bool FILL, bool BYPOS = false>
-__global__ __launch_bounds__(BLOCK) void radius_kernel(IndexView ix, const float4* __restrict__ q, uint32_t nq, float r2,
+__global__ __launch_bounds__(BLOCK, 4) void radius_kernel(IndexView ix, const float4* __restrict__ q, uint32_t nq, float r2,
                                                        uint32_t* __restrict__ counts,
                                                        const unsigned long long* __restrict__ offsets,
                                                        uint64_t* __restrict__ keys, uint32_t q_begin = 0,
                                                        unsigned long long base = 0) {
-  __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
+  __shared__ WaveLdsBoxT<LEAF_BATCH * LEAF_FLOATS * 4> wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
   load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t ngroups = (nq - q_begin + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups);
   TraverseStats ts;
-  for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
+  GroupFeed feed(sched, ix.sched_ctr);
+  for (uint32_t gl = feed.first(sched); gl != GroupFeed::END; gl = feed.advance()) {
     const uint32_t g = sched.global(gl);
     if (g >= ngroups) break;
+    feed.ahead(gl);
     const uint32_t i = q_begin + g * WAVE + lane;
     float4 p = make_float4(0, 0, 0, 0);
     const bool real = i < nq;
@@ -219,7 +222,7 @@ extern "C" pclhip_status pclhip_radius_search(pclhip_index* ix, const void* quer
   PCLHIP_CHECK_HIP(ctx, g.alloc(&wide, size_t(n + 1) * 8));
   PCLHIP_CHECK_HIP(ctx, g.alloc(&full_off, size_t(n + 1) * 8));
   PCLHIP_CHECK_HIP(ctx, g.alloc(&out_off, size_t(n + 1) * 8));
-  hipLaunchKernelGGL(radius_kernel<false>, dim3(grid), dim3(BLOCK), 0, s, v, qs, n, r2, counts,
+  PCLHIP_LAUNCH_FED(ctx, radius_kernel<false>, dim3(grid), dim3(BLOCK), 0, s, v, qs, n, r2, counts,
                      (const unsigned long long*)nullptr, (uint64_t*)nullptr);
   // exclusive scans of the full counts (segment starts) and of the clamped counts (output CSR)
   launch_exclusive_scan_u64(s, counts, n, 0u, wide, full_off);
@@ -237,7 +240,7 @@ extern "C" pclhip_status pclhip_radius_search(pclhip_index* ix, const void* quer
   }
   uint64_t* k0 = nullptr;
   PCLHIP_CHECK_HIP(ctx, g.alloc(&k0, size_t(full_total) * 8));
-  hipLaunchKernelGGL(radius_kernel<true>, dim3(grid), dim3(BLOCK), 0, s, v, qs, n, r2, counts, full_off, k0);
+  PCLHIP_LAUNCH_FED(ctx, radius_kernel<true>, dim3(grid), dim3(BLOCK), 0, s, v, qs, n, r2, counts, full_off, k0);
   uint32_t* long_list = nullptr;
   PCLHIP_CHECK_HIP(ctx, g.alloc(&long_list, size_t(n + 1) * 4));  // [n]: the counter
   launch_segmented_sort_u64(s, ctx->num_cus, k0, full_off, 0ull, 0u, n, long_list, long_list + n);
@@ -309,7 +312,7 @@ static pclhip_status normals_radius_impl(pclhip_index* ix, const float4* queries
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   (void)hipEventRecord(e0, s);
-  hipLaunchKernelGGL((radius_kernel<false, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, v, q, n, r2, counts,
+  PCLHIP_LAUNCH_FED(ctx, (radius_kernel<false, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, v, q, n, r2, counts,
                      (const unsigned long long*)nullptr, (uint64_t*)nullptr, 0u, 0ull);
   launch_exclusive_scan_u64(s, counts, n, 0u, wide, off);
   std::vector<unsigned long long> h_off(size_t(n) + 1);
@@ -334,7 +337,7 @@ static pclhip_status normals_radius_impl(pclhip_index* ix, const float4* queries
     const uint32_t a = cuts[c], b = cuts[c + 1];
     const unsigned long long base = h_off[a], nkeys = h_off[b] - h_off[a];
     if (nkeys > 0) {
-      hipLaunchKernelGGL((radius_kernel<true, true>), dim3(grid_for(b - a)), dim3(BLOCK), 0, s, v, q, b, r2, counts, off,
+      PCLHIP_LAUNCH_FED(ctx, (radius_kernel<true, true>), dim3(grid_for(b - a)), dim3(BLOCK), 0, s, v, q, b, r2, counts, off,
                          k0, a, base);
       // the chunk's segments start at off[a .. b] - base
       launch_segmented_sort_u64(s, ctx->num_cus, k0, off, base, a, b, long_list, long_list + n);

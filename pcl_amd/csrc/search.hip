@@ -46,9 +46,11 @@ __global__ __launch_bounds__(BLOCK, KNN_MINW(K)) void knn_reg_kernel(IndexView i
   const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups);
   TraverseStats ts;
-  for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
+  GroupFeed feed(sched, ix.sched_ctr);
+  for (uint32_t gl = feed.first(sched); gl != GroupFeed::END; gl = feed.advance()) {
     const uint32_t g = sched.global(gl);
     if (g >= ngroups) break;
+    feed.ahead(gl);
     const uint32_t i = g * WAVE + lane;
     float4 p = make_float4(0, 0, 0, 0);
     bool valid = i < nq;
@@ -113,9 +115,11 @@ __global__ __launch_bounds__(BLOCK) void knn_heap_kernel(IndexView ix, const flo
   const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups);
   TraverseStats ts;
-  for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
+  GroupFeed feed(sched, ix.sched_ctr);
+  for (uint32_t gl = feed.first(sched); gl != GroupFeed::END; gl = feed.advance()) {
     const uint32_t g = sched.global(gl);
     if (g >= ngroups) break;
+    feed.ahead(gl);
     const uint32_t i = g * WAVE + lane;
     float4 p = make_float4(0, 0, 0, 0);
     bool valid = i < nq;
@@ -202,22 +206,22 @@ pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, 
   } timer{ix, e0, e1, s};
   if (k == 1) {
     const int grid = resident_blocks(ctx, knn_reg_kernel<1>, ngroups);
-    hipLaunchKernelGGL(knn_reg_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2, ctx->stats);
+    PCLHIP_LAUNCH_FED(ctx, knn_reg_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2, ctx->stats);
   } else if (k <= 8) {
     const int grid = resident_blocks(ctx, knn_reg_kernel<8>, ngroups);
-    hipLaunchKernelGGL(knn_reg_kernel<8>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2, ctx->stats);
+    PCLHIP_LAUNCH_FED(ctx, knn_reg_kernel<8>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2, ctx->stats);
   } else if (k <= 16) {
     const int grid = resident_blocks(ctx, knn_reg_kernel<16>, ngroups);
-    hipLaunchKernelGGL(knn_reg_kernel<16>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2, ctx->stats);
+    PCLHIP_LAUNCH_FED(ctx, knn_reg_kernel<16>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2, ctx->stats);
   } else if (k <= 32) {
     const int grid = resident_blocks(ctx, knn_reg_kernel<32>, ngroups);
-    hipLaunchKernelGGL(knn_reg_kernel<32>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2, ctx->stats);
+    PCLHIP_LAUNCH_FED(ctx, knn_reg_kernel<32>, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2, ctx->stats);
   } else {
     const size_t bytes = size_t(nq) * size_t(k) * sizeof(uint64_t);
     uint64_t* heap = nullptr;
     PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &heap, bytes));
     const int grid = resident_blocks(ctx, knn_heap_kernel, ngroups);
-    hipLaunchKernelGGL(knn_heap_kernel, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2,
+    PCLHIP_LAUNCH_FED(ctx, knn_heap_kernel, dim3(grid), dim3(BLOCK), 0, s, v, q_sorted, nq, k, out_idx, out_d2,
                        heap, ctx->stats);
     hipError_t e = hipStreamSynchronize(s);
     (void)dev_free(ctx, heap);
@@ -250,9 +254,11 @@ __global__ __launch_bounds__(BLOCK, (K == 8 && PCLHIP_NRM_WAVES >= 4) ? 4 : 1) v
   const GroupSchedule sched(ngroups);
   TraverseStats ts;
   const float qnan = __builtin_nanf("");
-  for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
+  GroupFeed feed(sched, ix.sched_ctr);
+  for (uint32_t gl = feed.first(sched); gl != GroupFeed::END; gl = feed.advance()) {
     const uint32_t g = sched.global(gl);
     if (g >= ngroups) break;
+    feed.ahead(gl);
     const uint32_t i = g * WAVE + lane;
     const bool valid = i < ix.n;
     float4 p = make_float4(0, 0, 0, 0);
@@ -537,13 +543,13 @@ pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_
   (void)hipEventRecord(e0, s);
   if (ix->n > 0) {
     if (k <= 8) {
-      hipLaunchKernelGGL(normals_kernel<8>, dim3(resident_blocks(ctx, normals_kernel<8>, ngroups)), dim3(BLOCK), 0, s, v, k, vp[0],
+      PCLHIP_LAUNCH_FED(ctx, normals_kernel<8>, dim3(resident_blocks(ctx, normals_kernel<8>, ngroups)), dim3(BLOCK), 0, s, v, k, vp[0],
                          vp[1], vp[2], ix->nrm, d_nan, ctx->stats);
     } else if (k <= 16) {
-      hipLaunchKernelGGL(normals_kernel<16>, dim3(resident_blocks(ctx, normals_kernel<16>, ngroups)), dim3(BLOCK), 0, s, v, k, vp[0],
+      PCLHIP_LAUNCH_FED(ctx, normals_kernel<16>, dim3(resident_blocks(ctx, normals_kernel<16>, ngroups)), dim3(BLOCK), 0, s, v, k, vp[0],
                          vp[1], vp[2], ix->nrm, d_nan, ctx->stats);
     } else if (k <= 32) {
-      hipLaunchKernelGGL(normals_kernel<32>, dim3(resident_blocks(ctx, normals_kernel<32>, ngroups)), dim3(BLOCK), 0, s, v, k, vp[0],
+      PCLHIP_LAUNCH_FED(ctx, normals_kernel<32>, dim3(resident_blocks(ctx, normals_kernel<32>, ngroups)), dim3(BLOCK), 0, s, v, k, vp[0],
                          vp[1], vp[2], ix->nrm, d_nan, ctx->stats);
     } else {  // k > 32: materialise the k-NN lists (heap kernel), then fit the planes
       float4* q = nullptr;
@@ -674,9 +680,11 @@ __global__ __launch_bounds__(BLOCK) void gicp_cov_kernel(IndexView ix, int k, do
   const uint32_t ngroups = (ix.n + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups);
   TraverseStats ts;
-  for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
+  GroupFeed feed(sched, ix.sched_ctr);
+  for (uint32_t gl = feed.first(sched); gl != GroupFeed::END; gl = feed.advance()) {
     const uint32_t g = sched.global(gl);
     if (g >= ngroups) break;
+    feed.ahead(gl);
     const uint32_t i = g * WAVE + lane;
     const bool valid = i < ix.n;
     float4 p = make_float4(0, 0, 0, 0);
@@ -728,7 +736,7 @@ pclhip_status launch_gicp_covariances(pclhip_index* ix, int k, double eps, doubl
   if (ix->n == 0) return PCLHIP_OK;
   const IndexView v = ix->view();
   const uint32_t ngroups = (ix->n + WAVE - 1) / WAVE;
-  hipLaunchKernelGGL(gicp_cov_kernel, dim3(resident_blocks(ctx, gicp_cov_kernel, ngroups)), dim3(BLOCK), 0, ctx->stream, v, k,
+  PCLHIP_LAUNCH_FED(ctx, gicp_cov_kernel, dim3(resident_blocks(ctx, gicp_cov_kernel, ngroups)), dim3(BLOCK), 0, ctx->stream, v, k,
                      eps, cov_sorted, ctx->stats);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   return PCLHIP_OK;
@@ -776,6 +784,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_iterate_kernel(IndexView ix, 
   double sum_d2 = 0.0;
   uint32_t cnt = 0, skipped = 0;
 
+  // fixed shares (no GroupFeed): the sums of a block must not depend on which wave was through first
   for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
     const uint32_t g = sched.global(gl);
     if (g >= ngroups) break;
@@ -938,6 +947,14 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
   // in flight while the current group is searched
   uint32_t gl = sched.first();
   uint32_t g = (gl < sched.end()) ? sched.global(gl) : ngroups;
+  // the group after the one in flight is known one group ahead (its loads are issued under the current search); what
+  // follows it is asked for at the same moment and arrives by the end of the search (GroupFeed)
+  GroupFeed feed(sched, ix.sched_ctr);
+  uint32_t gl_next = GroupFeed::END;
+  if (gl < sched.end() && !feed.static_next(gl, gl_next)) {
+    feed.request();
+    gl_next = feed.resolve();
+  }
   float4 p_n[Q], t_n[Q];
   uint32_t sp_n[Q];
 #pragma unroll
@@ -976,8 +993,13 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
       in_range[q] = (g * GROUP + q * WAVE + lane) < ns;
     }
     // next group: issue its points + seed positions now ...
-    gl += sched.step();
-    const uint32_t g2 = (gl < sched.end()) ? sched.global(gl) : ngroups;
+    const uint32_t g2 = (gl_next != GroupFeed::END) ? sched.global(gl_next) : ngroups;
+    uint32_t gl_after = GroupFeed::END;
+    bool asked = false;
+    if (gl_next != GroupFeed::END && !feed.static_next(gl_next, gl_after)) {
+      feed.request();
+      asked = true;
+    }
     bool next_ok[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -1053,6 +1075,7 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
       }
     }
     g = g2;
+    gl_next = asked ? feed.resolve() : gl_after;
     ICP_LAP(7);
   }
 #undef ICP_LAP
@@ -1229,9 +1252,11 @@ __global__ __launch_bounds__(BLOCK, 4) void recip_search_kernel(IndexView sx, co
   const uint32_t ngroups = (n + WAVE - 1) / WAVE;
   const GroupSchedule sched(ngroups);
   TraverseStats ts;
-  for (uint32_t gl = sched.first(); gl < sched.end(); gl += sched.step()) {
+  GroupFeed feed(sched, sx.sched_ctr);
+  for (uint32_t gl = feed.first(sched); gl != GroupFeed::END; gl = feed.advance()) {
     const uint32_t g = sched.global(gl);
     if (g >= ngroups) break;
+    feed.ahead(gl);
     const uint32_t i = g * WAVE + lane;
     bool valid = i < n && keep[i] != 0;
     float4 p = make_float4(0, 0, 0, 0);
@@ -1282,7 +1307,7 @@ pclhip_status launch_recip_search(pclhip_index* src_ix, const float4* tgt_pts, c
   if (n == 0) return PCLHIP_OK;
   const uint32_t ngroups = (n + WAVE - 1) / WAVE;
   const int grid = resident_blocks(ctx, recip_search_kernel, ngroups);
-  hipLaunchKernelGGL(recip_search_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, src_ix->view(), tgt_pts, match_pos,
+  PCLHIP_LAUNCH_FED(ctx, recip_search_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, src_ix->view(), tgt_pts, match_pos,
                      pos_of_slot, cur, n, max_d2, use_max ? 1 : 0, keep, ctx->stats);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   return PCLHIP_OK;
@@ -1732,7 +1757,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     (void)hipEventRecord(device_loop ? ev[0] : icp->ev0, s);
     if (standoff && device_loop) {
       const int gd = resident_blocks(ctx, icp_search_dual_kernel, ngroups);
-      hipLaunchKernelGGL(icp_search_dual_kernel, dim3(gd), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl,
+      PCLHIP_LAUNCH_FED(ctx, icp_search_dual_kernel, dim3(gd), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl,
                          icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
     } else if (cold) {
       const int gc = resident_blocks(ctx, icp_cold_search_kernel, ngroups);
@@ -1740,7 +1765,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
                          ctl, icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2,
                          ctx->stats);
     } else {
-      hipLaunchKernelGGL(ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl, icp->region,
+      PCLHIP_LAUNCH_FED(ctx, ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl, icp->region,
                          order, bound, kflags, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
     }
     (void)hipEventRecord(device_loop ? ev[1] : icp->ev_mid, s);
@@ -1870,7 +1895,7 @@ pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double ma
   // transformPointCloud(cloud, out, Matrix4) is Transformer::se3 (transforms.hpp:109-123): order 1
   // target sharding: this rank scores the source points whose position under T lies in its region (every point has
   // exactly one owner), against its slab + halo index; the (sum, count) pairs are summed over the ranks below
-  hipLaunchKernelGGL((icp_search_kernel<4, 1, true>), dim3(gs), dim3(BLOCK), 0, s, v, cur, static_cast<const float4*>(cur), n,
+  PCLHIP_LAUNCH_FED(ctx, (icp_search_kernel<4, 1, true>), dim3(gs), dim3(BLOCK), 0, s, v, cur, static_cast<const float4*>(cur), n,
                      M, static_cast<const IcpControl*>(nullptr), icp->region, 1, __builtin_inff(), 0, pos, id, d2,
                      ctx->stats);
   hipLaunchKernelGGL(fitness_partial_kernel, dim3(gr), dim3(BLOCK), 0, s, d2, n, max_range, part);
