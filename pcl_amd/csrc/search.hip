@@ -23,6 +23,9 @@ namespace pclhip {
 
 constexpr int BLOCK = 256;
 constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+#ifndef PCLHIP_COLD_RUN
+#define PCLHIP_COLD_RUN 4  // groups per run of the stand-off search (icp_cold_search_body)
+#endif
 
 // =================================================================================================
 // batched exact k-NN
@@ -1082,8 +1085,8 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
   flush_stats(ts, gstats);
 }
 
-// The launch WITHOUT seeds (first iteration of an alignment), for indices that carry leaf discs: every wave owns a
-// run of consecutive -- spatially adjacent -- groups and seeds each from its predecessor's matches (standoff.hpp:
+// The launch WITHOUT seeds (first iteration of an alignment), for indices that carry leaf discs: a wave works through
+// runs of consecutive -- spatially adjacent -- groups and seeds each from its predecessor's matches (standoff.hpp:
 // collect / cull / evaluate); whatever that path gives up on goes through traverse() with the bounds reached so
 // far.  Same outputs as the seeded search, bit for bit.
 __device__ __forceinline__ void icp_cold_search_body(const IndexView& ix, float4* __restrict__ cur,
@@ -1106,24 +1109,39 @@ __device__ __forceinline__ void icp_cold_search_body(const IndexView& ix, float4
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   const uint32_t ngroups = (ns + WAVE - 1) / WAVE;
-  const GroupSchedule sched(ngroups, true);
   TraverseStats ts;
   PrevGroup prev;
   prev.init();
-  uint32_t gl = sched.first();
+  // Runs of COLD_RUN consecutive -- spatially adjacent -- groups of the XCD's window, handed out IN ORDER by the XCD's
+  // counter (a wave's first run comes without asking; IndexView::sched_ctr, zeroed by PCLHIP_LAUNCH_FED): the waves of an
+  // XCD work on one front that marches over the kd order, and whoever is through first takes the next run.  Inside a run
+  // a group borrows its predecessor's match as its seed; a run starts without one (one lane's exact neighbour).  Until
+  // round 3's last day every wave owned ONE run of ~38 groups (fixed shares: the launch ended with its slowest wave, and
+  // the 4096 resident waves touched 4096 scattered neighbourhoods -- 2.3 GB fetched per launch): 2.58 -> 2.06 ms at 10M
+  // points with runs of 4 (2.27 with 2: too many starts; 2.32 with 8: too coarse a tail).
+  const GroupSchedule sched(ngroups);  // the XCD's window and this wave's slot in it
+  constexpr uint32_t RUN = PCLHIP_COLD_RUN;
+  const uint32_t nruns = (sched.groups_per_xcd + RUN - 1u) / RUN;
+  uint32_t* const run_ctr = ix.sched_ctr + (blockIdx.x % (gridDim.x < 8u ? gridDim.x : 8u)) * uint32_t(SCHED_CTR_STRIDE);
+  for (uint32_t run = sched.slot_wave; run < nruns;) {
+  uint32_t ticket = 0;
+  if (lane == 0) ticket = atomicAdd(run_ctr, 1u);  // the run after this one: asked for now, read when this one is done
+  prev.forget();
+  uint32_t gl = run * RUN;
+  const uint32_t run_end = (gl + RUN) < sched.groups_per_xcd ? (gl + RUN) : sched.groups_per_xcd;
   float4 p_n = make_float4(0, 0, 0, 0);
   {
-    const uint32_t g0 = (gl < sched.end()) ? sched.global(gl) : ngroups;
+    const uint32_t g0 = (gl < run_end) ? sched.global(gl) : ngroups;
     if (g0 < ngroups && g0 * WAVE + lane < ns) p_n = in[g0 * WAVE + lane];
   }
-  for (; gl < sched.end(); ++gl) {
+  for (; gl < run_end; ++gl) {
     const uint32_t g = sched.global(gl);
     if (g >= ngroups) break;
     float4 p = p_n;
     const uint32_t i = g * WAVE + lane;
     const bool in_range = i < ns;
     {  // the next group's points are in flight while this one is searched
-      const uint32_t g2 = (gl + 1u < sched.end()) ? sched.global(gl + 1u) : ngroups;
+      const uint32_t g2 = (gl + 1u < run_end) ? sched.global(gl + 1u) : ngroups;
       p_n = make_float4(0, 0, 0, 0);
       if (g2 < ngroups && g2 * WAVE + lane < ns) p_n = in[g2 * WAVE + lane];
     }
@@ -1182,6 +1200,8 @@ __device__ __forceinline__ void icp_cold_search_body(const IndexView& ix, float4
     (void)so_t0;
     if (!done) ++ts.c[4];
 #endif
+  }
+  run = sched.waves_per_xcd + uniform_u32(ticket);
   }
   flush_stats(ts, gstats);
 }
@@ -1734,11 +1754,10 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
       const char* e = getenv("PCLHIP_SO_THICKNESS");
       return e ? float(atof(e)) : 0.2f;
     }();
-    // ... and where the target index stays cache-resident under the chunked schedule: every wave works in a region of its
-    // own (that is what lets a group borrow its predecessor's match), so the 4096 resident waves touch 4096 scattered
-    // neighbourhoods at a time instead of one window per XCD.  Measured on the bench surface: 2.7 against 3.2 ms for
-    // the seeded search at 10M points (0.56 GB of index), 7.2 against 5.4 ms at 15M (0.84 GB) with the same lists per
-    // group -- beyond the gate below launches without seeds keep the interleaved schedule and traverse().
+    // ... and a gate on the index size that dates from the schedule in which every wave owned ONE long run of groups (4096
+    // scattered neighbourhoods at a time: 2.7 against 3.2 ms for the seeded search at 10M points, 0.56 GB of index, but 7.2
+    // against 5.4 ms at 15M, 0.84 GB).  The front-ordered runs of icp_cold_search_body keep an XCD's waves on adjacent
+    // groups, which is what the gate was about; it stays until a 15M-point run has been measured with them.
     static const size_t so_max_bytes = [] {
       const char* e = getenv("PCLHIP_SO_MAX_MB");
       return size_t(e ? strtoull(e, nullptr, 10) : 640ull) << 20;
@@ -1761,7 +1780,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
                          icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
     } else if (cold) {
       const int gc = resident_blocks(ctx, icp_cold_search_kernel, ngroups);
-      hipLaunchKernelGGL(icp_cold_search_kernel, dim3(gc), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M,
+      PCLHIP_LAUNCH_FED(ctx, icp_cold_search_kernel, dim3(gc), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M,
                          ctl, icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2,
                          ctx->stats);
     } else {

@@ -254,6 +254,11 @@ struct PrevGroup {
     skip = 0;
     attempted = false;
   }
+  // the wave jumps to another part of the cloud: its earlier matches are no seeds there (the back-off state stays)
+  __device__ __forceinline__ void forget() {
+    pos = hpos = NO_INDEX;
+    count = 0;
+  }
   __device__ __forceinline__ bool skip_now() {  // wave-uniform
     attempted = skip == 0;
     if (skip == 0) return false;

@@ -1376,13 +1376,11 @@ __device__ __forceinline__ void flush_stats(const TraverseStats& ts, unsigned lo
   }
 }
 
-// XCD-aware mapping of (block, wave, iteration) -> query group: blocks that share an XCD (and its
-// L2) work on one contiguous window of kd-ordered groups at a time.  Strided (default): the waves of an XCD
-// interleave over the window.  Chunked: every wave owns a run of CONSECUTIVE groups of the window -- spatial
-// neighbours in kd order, which is what lets a group borrow its predecessor's match as a seed (standoff.hpp).
+// XCD-aware mapping of (block, wave, iteration) -> query group: blocks that share an XCD (and its L2) work on one
+// contiguous window of kd-ordered groups at a time; the waves of an XCD interleave over the window.
 struct GroupSchedule {
-  uint32_t groups_per_xcd, xcd_first, slot_wave, waves_per_xcd, first_, step_, end_;
-  __device__ __forceinline__ GroupSchedule(uint32_t ngroups, bool chunked = false) {
+  uint32_t groups_per_xcd, xcd_first, slot_wave, waves_per_xcd;
+  __device__ __forceinline__ GroupSchedule(uint32_t ngroups) {
     const uint32_t nxcd = gridDim.x < 8u ? gridDim.x : 8u;  // partitions = XCDs that own a block
     const uint32_t xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
     const uint32_t slots = (gridDim.x + nxcd - 1 - xcd) / nxcd;  // blocks on this XCD
@@ -1391,20 +1389,10 @@ struct GroupSchedule {
     xcd_first = xcd * groups_per_xcd;
     slot_wave = slot * waves_per_block + threadIdx.x / WAVE;
     waves_per_xcd = slots * waves_per_block;
-    if (chunked) {
-      const uint32_t chunk = (groups_per_xcd + waves_per_xcd - 1) / waves_per_xcd;
-      first_ = slot_wave * chunk;
-      step_ = 1u;
-      end_ = (first_ + chunk) < groups_per_xcd ? (first_ + chunk) : groups_per_xcd;
-    } else {
-      first_ = slot_wave;
-      step_ = waves_per_xcd;
-      end_ = groups_per_xcd;
-    }
   }
-  __device__ __forceinline__ uint32_t first() const { return first_; }
-  __device__ __forceinline__ uint32_t step() const { return step_; }
-  __device__ __forceinline__ uint32_t end() const { return end_; }  // local groups [first, end) in steps of step()
+  __device__ __forceinline__ uint32_t first() const { return slot_wave; }
+  __device__ __forceinline__ uint32_t step() const { return waves_per_xcd; }
+  __device__ __forceinline__ uint32_t end() const { return groups_per_xcd; }  // local groups [first, end) in steps of step()
   // local group index g (0 <= g < groups_per_xcd) -> global group
   __device__ __forceinline__ uint32_t global(uint32_t g) const { return xcd_first + g; }
 };
