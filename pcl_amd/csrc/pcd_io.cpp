@@ -562,6 +562,13 @@ bool decode_body(std::string_view bytes, const Header& h, Body& body, std::strin
       err = "truncated binary_compressed body";
       return false;
     }
+    // An LZF stream grows by at most 88x (a 3-byte back reference yields up to 264 bytes): a size word beyond that is the
+    // decompressor's "does not match" failure, known before 4 GB are allocated and cleared for a 500-byte file (the
+    // reference resizes first, :576-580; same outcome for every file it accepts)
+    if (uint64_t(usize) > uint64_t(csize) * 88u) {
+      err = "Size of decompressed lzf data does not match value stored in PCD header";
+      return false;
+    }
     body.storage.resize(usize);
     const size_t got = usize ? lzf_decompress(file + h.data_offset + 8, csize, body.storage.data(), usize) : 0;
     if (got != usize) {

@@ -166,6 +166,20 @@ def test_reader_rejects_hostile_headers(api, tmp_path):
     p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 300000000\nHEIGHT 1\nPOINTS 300000000\nDATA ascii\n0 0 0\n")
     with pytest.raises(api.PclHipError, match="shorter"):
         api.loadPCDFile(str(p))
+    # binary_compressed: a size word the stream cannot produce (LZF grows by at most 88x) is rejected before anything of
+    # that size is allocated -- 4 GB cleared for a 200-byte file took 10-50 s (found by tests/cpp/fuzz_host_io.cpp)
+    import struct
+    import time
+    good = tmp_path / "good.pcd"
+    api.savePCDFile(str(good), np.ones((8, 4), np.float32), "binary_compressed")
+    raw = good.read_bytes()
+    at = raw.index(b"DATA binary_compressed\n") + len(b"DATA binary_compressed\n")
+    for usize in (0xFFFFFFFF, 0x7FFFFFFF, 1 << 20):
+        p.write_bytes(raw[:at + 4] + struct.pack("<I", usize) + raw[at + 8:])
+        t0 = time.perf_counter()
+        with pytest.raises(api.PclHipError, match="decompressed lzf"):
+            api.loadPCDFile(str(p))
+        assert time.perf_counter() - t0 < 0.5
 
 
 def test_organized_write_viewpoint_and_field_reader(api, tmp_path):
