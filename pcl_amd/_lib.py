@@ -195,6 +195,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # tests/wavesim builds the same sources for the host (a lane-accurate emulation of the wavefront, used by the CPU test
+    # tier to check kernels against the oracle).  It is test infrastructure: the product never runs on it.
+    if b"wavesim" in (lib.pclhip_version() or b"") and os.environ.get("PCLHIP_ALLOW_WAVESIM") != "1":
+        raise PclHipUnavailable("%s is the CPU emulation of the test tier (tests/wavesim), not the HIP library; only "
+                                "tests/test_wavesim.py loads it (PCLHIP_ALLOW_WAVESIM=1).  There is no CPU fallback." % LIB_PATH)
     _lib = lib
     return lib
 

@@ -390,7 +390,11 @@ pclhip_status pclhip::sharded_filters_ok(pclhip_icp* icp) {
 
 extern "C" {
 
+#ifdef PCLHIP_WAVESIM  // the CPU emulation of the test tier (tests/wavesim) says what it is: pcl_amd/_lib.py refuses it unless asked
+const char* pclhip_version(void) { return "pclhip 0.1 (wavesim: CPU emulation, test infrastructure)"; }
+#else
 const char* pclhip_version(void) { return "pclhip 0.1 (gfx950)"; }
+#endif
 
 const char* pclhip_last_error(const pclhip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
 

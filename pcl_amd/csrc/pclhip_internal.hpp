@@ -367,6 +367,13 @@ bool icp_is_sharded(const pclhip_icp* icp);
 // under sharding only per-pair filters (the Distance rejector) are allowed: PCLHIP_ERR_STATE otherwise
 pclhip_status sharded_filters_ok(pclhip_icp* icp);
 
+// A divergent branch that holds cross-lane operations (ballots among the lanes that took it) is marked with this for the
+// CPU emulation of the wavefront in the test tier (tests/wavesim/wavesim.hpp, which defines it); on the device the
+// execution mask does the same and the marker is nothing.
+#ifndef PCLHIP_LANE_MASKED_REGION
+#define PCLHIP_LANE_MASKED_REGION (void)0
+#endif
+
 // Kernels that take part of their groups from the context's counters (traverse.hpp: GroupFeed) are launched through
 // this: the counters are zeroed in stream order first, and no other thread's launch gets between the two.
 #define PCLHIP_LAUNCH_FED(ctx, ...)                                                                \

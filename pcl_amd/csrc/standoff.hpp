@@ -575,7 +575,7 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
       }
       __builtin_amdgcn_wave_barrier();
       so_stage8(ix, wl.buf, idu[lane & 7]);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PCLHIP_WAIT_VMCNT0();
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (uint32_t k = 0; k < 2; ++k) {
@@ -662,7 +662,7 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
           m16 |= ((need0 ? 1u : 0u) | (need1 ? 2u : 0u)) << b;
         }
         SO_LAP(6);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PCLHIP_WAIT_VMCNT0();
         while (__builtin_amdgcn_ballot_w64(m16 != 0) != 0) {
           uint32_t slot = 0, id = NO_INDEX;
           if (m16 != 0) {
@@ -707,7 +707,7 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
         if (__builtin_amdgcn_ballot_w64(m16 != 0) == 0) continue;
         const uint32_t cn = (ucnt - c0) < uint32_t(LEAF_BATCH) ? (ucnt - c0) : uint32_t(LEAF_BATCH);
         so_stage(ix, wl.buf, sub < cn ? idu[c0 + sub] : NO_INDEX);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PCLHIP_WAIT_VMCNT0();
         while (__builtin_amdgcn_ballot_w64(m16 != 0) != 0) {
           uint32_t slot = 0, id = NO_INDEX;
           if (m16 != 0) {

@@ -170,6 +170,32 @@ __device__ __forceinline__ bool row_reach_alive(const RowReach& rr, float ngx, f
 // update_dpp builtin costs a copy, a v_mov_dpp, a canonicalising v_max and the min).  A DPP read of a
 // VGPR written by the previous VALU instruction needs two wait states: s_nop 1 in the single-value
 // chains, independent work in between in the 7-wide version.  Inputs are never NaN.
+#ifdef PCLHIP_WAVESIM  // tests/wavesim (CPU emulation of the wavefront, test tier only): the same reductions as shuffles
+__device__ __forceinline__ float wave_min_f(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ void wave_min3_max4(float& a0, float& a1, float& a2, float& b0, float& b1, float& b2,
+                                               float& b3) {
+  a0 = wave_min_f(a0); a1 = wave_min_f(a1); a2 = wave_min_f(a2);
+  b0 = wave_max_f(b0); b1 = wave_max_f(b1); b2 = wave_max_f(b2); b3 = wave_max_f(b3);
+}
+__device__ __forceinline__ void row_max3_f(float& a, float& b, float& c) {
+  for (int o = 8; o > 0; o >>= 1) {
+    a = fmaxf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); c = fmaxf(c, __shfl_xor(c, o));
+  }
+}
+__device__ __forceinline__ void row_min3_f(float& a, float& b, float& c) {
+  for (int o = 8; o > 0; o >>= 1) {
+    a = fminf(a, __shfl_xor(a, o)); b = fminf(b, __shfl_xor(b, o)); c = fminf(c, __shfl_xor(c, o));
+  }
+}
+#define PCLHIP_WAIT_VMCNT0() (void)0  // global_load_lds is immediate there
+#else
 #define PCLHIP_DPP_STEPS(OP)                                                                 \
   "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"          \
   "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"          \
@@ -234,6 +260,8 @@ __device__ __forceinline__ void row_min3_f(float& a, float& b, float& c) {
 }
 #undef PCLHIP_ROW_REDUCE3
 #undef PCLHIP_ROW_STEP3
+#define PCLHIP_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -535,6 +563,7 @@ struct TopKReg {
   __device__ __forceinline__ void leaf_lane(const float* buf, uint32_t slot, uint32_t leaf_id, const float* qx,
                                             const float* qy, const float* qz) {
     if (leaf_id != NO_INDEX) {
+      PCLHIP_LANE_MASKED_REGION;  // the ballots below run among the lanes that have a leaf
       const float4* s = reinterpret_cast<const float4*>(buf) + slot;  // chunk c at s[c * 16]
       const uint32_t base = leaf_id * LEAF;
       const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
@@ -1172,7 +1201,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
               if (__builtin_amdgcn_ballot_w64(m16 != 0) == 0) continue;
               const uint32_t cn = (n_alive - c0) < uint32_t(LEAF_BATCH) ? (n_alive - c0) : uint32_t(LEAF_BATCH);
               stage(c0, cn);
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              PCLHIP_WAIT_VMCNT0();
               while (__builtin_amdgcn_ballot_w64(m16 != 0) != 0) {
                 uint32_t slot = 0, id = NO_INDEX;
                 if (m16 != 0) {
@@ -1209,7 +1238,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
               bool need = valid[0] && !(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w));
               if (__builtin_amdgcn_ballot_w64(need && pid != NO_INDEX) != 0) {
                 if (!landed) {
-                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                  PCLHIP_WAIT_VMCNT0();
                   landed = true;
                 }
                 const float w0 = pol.worst(0);
@@ -1226,7 +1255,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
             }
             if (__builtin_amdgcn_ballot_w64(pid != NO_INDEX) != 0) {
               if (!landed) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PCLHIP_WAIT_VMCNT0();
                 landed = true;
               }
               const float w0 = pol.worst(0);
@@ -1255,7 +1284,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
             if (!valid[0]) mask = 0;
             while (__builtin_amdgcn_ballot_w64(mask != 0) != 0) {
               if (!landed) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PCLHIP_WAIT_VMCNT0();
                 landed = true;
               }
               uint32_t slot = 0, id = NO_INDEX;
@@ -1270,7 +1299,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
             }
           }
           // the next batch overwrites wl.buf: make sure this batch's DMA is not still landing
-          if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (!landed) PCLHIP_WAIT_VMCNT0();
         }
         {
           const float after = pol.worst(0);
@@ -1320,7 +1349,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
           if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
           ++ts.c[2];
           if (!landed) {  // first use of this batch: the DMA must have landed (it ran under the tests)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PCLHIP_WAIT_VMCNT0();
             landed = true;
           }
           const float before = lane_worst(pol, valid);
@@ -1330,7 +1359,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
           if (__builtin_amdgcn_ballot_w64(after < before) != 0) T = wave_max_f(after);
         }
         // the next batch overwrites wl.buf: make sure this batch's DMA is not still landing
-        if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!landed) PCLHIP_WAIT_VMCNT0();
       }
       }  // wave-uniform leaf evaluation
     } else {

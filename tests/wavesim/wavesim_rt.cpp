@@ -1,0 +1,451 @@
+// wavesim_rt.cpp -- the runtime half of tests/wavesim (TEST INFRASTRUCTURE, see wavesim.hpp): fibers and the
+// rendezvous of cross-lane operations, a pool of OS threads that runs the workgroups of a launch, and the few dozen HIP
+// runtime entry points the host side of libpclhip calls, implemented over plain host memory ("device" allocations are
+// malloc'ed blocks remembered in a table so that hipPointerGetAttributes can tell them from user memory; streams are
+// immediate; events are timestamps).
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace wavesim {
+
+struct Idx3 {
+  unsigned x, y, z;
+};
+struct LaneCtx {
+  Idx3 tid, bid, bdim, gdim;
+};
+thread_local LaneCtx* cur = nullptr;
+
+namespace {
+
+extern "C" void wavesim_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl wavesim_switch
+.type wavesim_switch,@function
+wavesim_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size wavesim_switch,.-wavesim_switch
+)");
+
+enum State { READY, WAIT_WAVE, WAIT_BLOCK, DONE };
+constexpr size_t STACK_BYTES = 256 << 10;
+constexpr unsigned MAX_LANES = 1024;
+
+struct Wave {
+  uint64_t val[64];  // operands of the lanes of the last release (read by each of them right after it resumes)
+};
+struct Lane {
+  LaneCtx ctx;
+  void* sp = nullptr;
+  State state = DONE;
+  const char* site = nullptr;
+  uint64_t pending = 0;  // operand of the cross-lane operation the lane waits at
+  uint64_t live = 0;     // lanes that took part in the lane's last cross-lane operation
+  int depth = 0;         // nesting of lane-masked regions (PCLHIP_LANE_MASKED_REGION) the lane is inside of
+  Wave* wave = nullptr;
+};
+
+struct Worker {  // per OS thread
+  char* stacks = nullptr;
+  std::vector<Lane> lanes;
+  std::vector<Wave> waves;
+  void* sched_sp = nullptr;
+  Lane* running = nullptr;
+  const std::function<void()>* body = nullptr;
+};
+thread_local Worker* tw = nullptr;
+
+[[noreturn]] void die(const char* what, const char* a = "", const char* b = "") {
+  std::fprintf(stderr, "wavesim: %s %s %s\n", what, a ? a : "(null)", b ? b : "(null)");
+  std::fflush(stderr);
+  std::abort();
+}
+
+void yield_to_scheduler() {
+  Worker* w = tw;
+  Lane* me = w->running;
+  wavesim_switch(&me->sp, w->sched_sp);
+}
+
+extern "C" void wavesim_fiber_entry() {
+  Worker* w = tw;
+  Lane* me = w->running;
+  (*w->body)();
+  me->state = DONE;
+  yield_to_scheduler();
+  die("a finished fiber was resumed");
+}
+
+void resume(Worker* w, Lane* l) {
+  w->running = l;
+  cur = &l->ctx;
+  wavesim_switch(&w->sched_sp, l->sp);
+  w->running = nullptr;
+}
+
+void run_block(Worker* w, dim3 grid, dim3 block, unsigned bx, const std::function<void()>& body) {
+  const unsigned nthreads = block.x * block.y * block.z;
+  if (nthreads > MAX_LANES) die("block too large");
+  if (block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1) die("only 1-D launches are emulated");
+  if (!w->stacks) {
+    w->stacks = static_cast<char*>(mmap(nullptr, size_t(MAX_LANES) * STACK_BYTES, PROT_READ | PROT_WRITE,
+                                        MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
+    if (w->stacks == MAP_FAILED) die("cannot map fiber stacks");
+    w->lanes.resize(MAX_LANES);
+    w->waves.resize(MAX_LANES / 64);
+  }
+  w->body = &body;
+  const unsigned nwaves = (nthreads + 63) / 64;
+  for (unsigned t = 0; t < nthreads; ++t) {
+    Lane& l = w->lanes[t];
+    l.ctx.tid = {t, 0, 0};
+    l.ctx.bid = {bx, 0, 0};
+    l.ctx.bdim = {block.x, 1, 1};
+    l.ctx.gdim = {grid.x, 1, 1};
+    l.state = READY;
+    l.site = nullptr;
+    l.depth = 0;
+    l.wave = &w->waves[t / 64];
+    // initial frame: six callee-saved registers, the entry point, a null return address (see wavesim_switch)
+    uintptr_t top = reinterpret_cast<uintptr_t>(w->stacks + size_t(t + 1) * STACK_BYTES) & ~uintptr_t(15);
+    void** f = reinterpret_cast<void**>(top - 64);
+    for (int i = 0; i < 6; ++i) f[i] = nullptr;
+    f[6] = reinterpret_cast<void*>(&wavesim_fiber_entry);
+    f[7] = nullptr;
+    l.sp = f;
+  }
+  unsigned done = 0;
+  while (done < nthreads) {
+    bool progress = false;
+    for (unsigned wv = 0; wv < nwaves; ++wv) {
+      const unsigned t0 = wv * 64, t1 = std::min(nthreads, t0 + 64);
+      for (;;) {
+        bool ran = false;
+        for (unsigned t = t0; t < t1; ++t) {
+          Lane& l = w->lanes[t];
+          if (l.state != READY) continue;
+          resume(w, &l);
+          ran = true;
+          if (l.state == DONE) ++done;
+        }
+        if (ran) progress = true;
+        // every lane of the wave is now waiting or done.  Lanes inside a lane-masked region (a divergent branch that
+        // holds cross-lane operations, annotated in the sources) go first, as a partial wavefront -- the others wait at
+        // the point where the branch rejoins, which is what the hardware's execution mask does.
+        int depth = -1;
+        for (unsigned t = t0; t < t1; ++t)
+          if (w->lanes[t].state == WAIT_WAVE) depth = std::max(depth, w->lanes[t].depth);
+        if (depth < 0) break;  // the wave is done or at a workgroup barrier
+        const char* site = nullptr;
+        uint64_t group = 0;
+        for (unsigned t = t0; t < t1; ++t) {
+          const Lane& l = w->lanes[t];
+          if (l.state == DONE || l.depth != depth) continue;
+          if (l.state == WAIT_BLOCK) die("lanes of one wavefront are at a cross-lane operation and at __syncthreads:", site, l.site);
+          if (site && site != l.site && std::strcmp(site, l.site) != 0)
+            die("lanes of one wavefront are at different cross-lane operations (a divergent region that needs "
+                "PCLHIP_LANE_MASKED_REGION?):", site, l.site);
+          site = l.site;
+          group |= 1ull << (t - t0);
+        }
+        for (unsigned t = t0; t < t1; ++t)
+          if ((group >> (t - t0)) & 1u) {
+            Lane& l = w->lanes[t];
+            w->waves[wv].val[t - t0] = l.pending;
+            l.live = group;
+            l.state = READY;
+          }
+        progress = true;
+      }
+    }
+    if (done == nthreads) break;
+    // all live lanes wait at the workgroup barrier
+    bool all_block = true;
+    for (unsigned t = 0; t < nthreads; ++t)
+      if (w->lanes[t].state != DONE && w->lanes[t].state != WAIT_BLOCK) all_block = false;
+    if (all_block) {
+      for (unsigned t = 0; t < nthreads; ++t)
+        if (w->lanes[t].state == WAIT_BLOCK) w->lanes[t].state = READY;
+      progress = true;
+    }
+    if (!progress) die("deadlock inside a workgroup");
+  }
+  cur = nullptr;
+}
+
+// ---- pool --------------------------------------------------------------------------------------------------------------
+struct Pool {
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> threads;
+  // the job
+  uint64_t generation = 0;
+  dim3 grid, block;
+  const std::function<void()>* body = nullptr;
+  std::atomic<unsigned> next{0};
+  unsigned active = 0;
+  bool quit = false;
+
+  unsigned size() {
+    if (const char* e = std::getenv("WAVESIM_THREADS")) return std::max(1, std::atoi(e));
+    return std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  }
+  void worker_main() {
+    Worker me;
+    tw = &me;
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_work.wait(lk, [&] { return quit || generation != seen; });
+        if (quit) return;
+        seen = generation;
+      }
+      for (;;) {
+        const unsigned b = next.fetch_add(1);
+        if (b >= grid.x) break;
+        run_block(&me, grid, block, b, *body);
+      }
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (--active == 0) cv_done.notify_all();
+      }
+    }
+  }
+  void run(dim3 g, dim3 b, const std::function<void()>& f) {
+    std::unique_lock<std::mutex> lk(m);
+    if (threads.empty()) {
+      const unsigned n = size();
+      for (unsigned i = 0; i < n; ++i) threads.emplace_back([this] { worker_main(); });
+    }
+    grid = g;
+    block = b;
+    body = &f;
+    next.store(0);
+    active = unsigned(threads.size());
+    ++generation;
+    cv_work.notify_all();
+    cv_done.wait(lk, [&] { return active == 0; });
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      quit = true;
+    }
+    cv_work.notify_all();
+    for (auto& t : threads) t.join();
+  }
+};
+Pool& pool() {
+  static Pool* p = new Pool;  // leaked on purpose: worker threads may outlive static destruction order otherwise
+  return *p;
+}
+std::mutex launch_mutex;  // one launch at a time (streams are immediate)
+
+}  // namespace
+
+const uint64_t* exchange(uint64_t v, const char* site, uint64_t* live_mask) {
+  Worker* w = tw;
+  Lane* me = w->running;
+  me->pending = v;
+  me->site = site;
+  me->state = WAIT_WAVE;
+  yield_to_scheduler();
+  *live_mask = me->live;
+  return me->wave->val;
+}
+
+void masked_region_enter() { ++tw->running->depth; }
+void masked_region_leave() { --tw->running->depth; }
+
+void block_barrier(const char* site) {
+  Worker* w = tw;
+  Lane* me = w->running;
+  me->site = site;
+  me->state = WAIT_BLOCK;
+  yield_to_scheduler();
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+  if (grid.x == 0 || block.x == 0) return;
+  std::lock_guard<std::mutex> lk(launch_mutex);
+  pool().run(grid, block, body);
+}
+
+}  // namespace wavesim
+
+// ======================================================================================================================
+// HIP runtime entry points (host memory, immediate streams)
+// ======================================================================================================================
+namespace {
+std::mutex alloc_mutex;
+std::map<uintptr_t, size_t> device_blocks;  // start -> bytes
+thread_local hipError_t last_error = hipSuccess;
+struct FakeEvent {
+  std::chrono::steady_clock::time_point t;
+};
+int fake_stream_storage;
+}  // namespace
+
+extern "C" {
+
+hipError_t hipMalloc(void** p, size_t bytes) {
+  void* q = nullptr;
+  if (posix_memalign(&q, 256, bytes ? bytes : 256) != 0) return hipErrorOutOfMemory;
+  std::memset(q, 0xCD, bytes < (size_t(1) << 20) ? bytes : (size_t(1) << 20));  // fresh device memory is not zero
+  std::lock_guard<std::mutex> lk(alloc_mutex);
+  device_blocks[reinterpret_cast<uintptr_t>(q)] = bytes ? bytes : 256;
+  *p = q;
+  return hipSuccess;
+}
+hipError_t hipFree(void* p) {
+  if (!p) return hipSuccess;
+  std::lock_guard<std::mutex> lk(alloc_mutex);
+  device_blocks.erase(reinterpret_cast<uintptr_t>(p));
+  std::free(p);
+  return hipSuccess;
+}
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
+  *p = std::calloc(1, bytes ? bytes : 16);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipHostFree(void* p) {
+  std::free(p);
+  return hipSuccess;
+}
+hipError_t hipMemGetInfo(size_t* f, size_t* t) {
+  *f = size_t(8) << 30;
+  *t = size_t(16) << 30;
+  return hipSuccess;
+}
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* attr, const void* p) {
+  std::lock_guard<std::mutex> lk(alloc_mutex);
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  auto it = device_blocks.upper_bound(a);
+  if (it != device_blocks.begin()) {
+    --it;
+    if (a < it->first + it->second) {
+      std::memset(attr, 0, sizeof *attr);
+      attr->type = hipMemoryTypeDevice;
+      attr->devicePointer = const_cast<void*>(p);
+      return hipSuccess;
+    }
+  }
+  last_error = hipErrorInvalidValue;
+  return hipErrorInvalidValue;
+}
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
+  if (n) std::memmove(d, s, n);
+  return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+  if (n) std::memmove(d, s, n);
+  return hipSuccess;
+}
+hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind,
+                            hipStream_t) {
+  for (size_t r = 0; r < height; ++r)
+    std::memmove(static_cast<char*>(d) + r * dpitch, static_cast<const char*>(s) + r * spitch, width);
+  return hipSuccess;
+}
+hipError_t hipMemset(void* d, int v, size_t n) {
+  if (n) std::memset(d, v, n);
+  return hipSuccess;
+}
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
+  if (n) std::memset(d, v, n);
+  return hipSuccess;
+}
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+  *s = reinterpret_cast<hipStream_t>(&fake_stream_storage);
+  return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
+hipError_t hipGetDevice(int* d) {
+  *d = 0;
+  return hipSuccess;
+}
+hipError_t hipGetDeviceCount(int* n) {
+  *n = 1;
+  return hipSuccess;
+}
+hipError_t hipGetLastError() {
+  const hipError_t e = last_error;
+  last_error = hipSuccess;
+  return e;
+}
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "wavesim: HIP error"; }
+hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_t* prop, int) {
+  std::memset(prop, 0, sizeof *prop);
+  std::snprintf(prop->name, sizeof prop->name, "wavesim (CPU emulation of a wavefront machine)");
+  std::snprintf(prop->gcnArchName, sizeof prop->gcnArchName, "gfx950:wavesim");
+  prop->multiProcessorCount = []() {
+    const char* e = std::getenv("WAVESIM_CUS");
+    return e ? std::max(1, std::atoi(e)) : 16;
+  }();
+  prop->warpSize = 64;
+  prop->totalGlobalMem = size_t(16) << 30;
+  prop->sharedMemPerBlock = 64 << 10;
+  prop->maxThreadsPerBlock = 1024;
+  return hipSuccess;
+}
+hipError_t hipEventCreate(hipEvent_t* e) {
+  *e = reinterpret_cast<hipEvent_t>(new FakeEvent{std::chrono::steady_clock::now()});
+  return hipSuccess;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+hipError_t hipEventDestroy(hipEvent_t e) {
+  delete reinterpret_cast<FakeEvent*>(e);
+  return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+  reinterpret_cast<FakeEvent*>(e)->t = std::chrono::steady_clock::now();
+  return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(reinterpret_cast<FakeEvent*>(b)->t - reinterpret_cast<FakeEvent*>(a)->t).count();
+  return hipSuccess;
+}
+hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) {
+  *n = 2;
+  return hipSuccess;
+}
+hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) {
+  std::memset(a, 0, sizeof *a);
+  a->maxThreadsPerBlock = 1024;
+  return hipSuccess;
+}
+
+}  // extern "C"
