@@ -48,9 +48,26 @@ struct RcclApi {
   std::string why;
 };
 
+#ifdef PCLHIP_WAVESIM  // the CPU emulation of the test tier brings a stand-in (tests/wavesim/wavesim_rt.cpp: a sum in rank order
+extern "C" {           // through shared memory between the ranks' processes) so that N > 1 runs of THIS code can be tested there
+int wavesim_ncclGetUniqueId(NcclUniqueId*);
+int wavesim_ncclCommInitRank(NcclComm*, int, NcclUniqueId, int);
+int wavesim_ncclCommDestroy(NcclComm);
+int wavesim_ncclAllReduce(const void*, void*, size_t, int, int, NcclComm, hipStream_t);
+}
+#endif
+
 RcclApi& rccl() {
   static RcclApi api = [] {
     RcclApi a;
+#ifdef PCLHIP_WAVESIM
+    a.GetUniqueId = wavesim_ncclGetUniqueId;
+    a.CommInitRank = wavesim_ncclCommInitRank;
+    a.CommDestroy = wavesim_ncclCommDestroy;
+    a.AllReduce = wavesim_ncclAllReduce;
+    a.ok = true;
+    return a;
+#endif
     void* h = nullptr;
     if (dlsym(RTLD_DEFAULT, "ncclCommInitRank") == nullptr) {
       const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};

@@ -9,12 +9,19 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def link_args():
+    """-L/-l/-rpath of the library the run is about: pcl_amd/libpclhip.so, or the build PCLHIP_LIB names (an A/B variant;
+    tests/test_wavesim.py: the emulation of the CPU tier)."""
+    lib = os.environ.get("PCLHIP_LIB") or os.path.join(ROOT, "pcl_amd", "libpclhip.so")
+    d = os.path.dirname(os.path.abspath(lib))
+    return ["-L" + d, "-l:" + os.path.basename(lib), "-Wl,-rpath," + d]
+
+
 def build_cpp_test(tmp_path):
     exe = str(tmp_path / "test_pcl_compat")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "test_pcl_compat.cpp"), "-o", exe,
-                           "-L" + os.path.join(ROOT, "pcl_amd"), "-lpclhip",
-                           "-Wl,-rpath," + os.path.join(ROOT, "pcl_amd")])
+                           *link_args()])
     return exe
 
 
@@ -41,8 +48,7 @@ def build_c_example(tmp_path):
     exe = str(tmp_path / "icp_pcd")
     subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "examples", "icp_pcd.c"), "-o", exe,
-                           "-L" + os.path.join(ROOT, "pcl_amd"), "-lpclhip",
-                           "-Wl,-rpath," + os.path.join(ROOT, "pcl_amd"), "-lm"])
+                           *link_args(), "-lm"])
     return exe
 
 
@@ -84,8 +90,7 @@ def build_plugin_test(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(ROOT, "tests", "cpp", "pcl_mock"),
                            os.path.join(ROOT, "tests", "cpp", "test_pcl_plugin.cpp"), "-o", exe,
-                           "-L" + os.path.join(ROOT, "pcl_amd"), "-lpclhip",
-                           "-Wl,-rpath," + os.path.join(ROOT, "pcl_amd")])
+                           *link_args()])
     return exe
 
 

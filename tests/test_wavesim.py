@@ -67,14 +67,64 @@ SLOW = ("not sharded_target_on_device and not run_steps_is_align_repeated and no
 
 
 def test_gpu_parity_tests_run_on_the_emulation(wavesim_lib):
-    """test_gpu_parity / test_gpu_loop / test_gpu_dist / test_gpu_fuzz, the same functions the GPU tier runs, against the
+    """test_gpu_parity / test_gpu_loop / test_gpu_dist / test_gpu_fuzz / test_gpu_cpp_adapters (the C++ binding through PCL's
+    virtuals on the mock, the compat mirror, the plain-C example), the same functions the GPU tier runs, against the
     oracle: k-NN (register and heap kernels, ties, NaNs, subsets, representations), normals (k and radius, search
     surfaces), seeded and stand-off ICP searches bit for bit, the device-driven loop with rejector chains and reciprocal
     correspondences, estimators, radius search, VoxelGrid, GICP covariances, slab regions, fuzz slices and the degenerate
     inputs of the disc bounds."""
     keyword = NOT_HERE if os.environ.get("WAVESIM_FULL") == "1" else NOT_HERE + " and " + SLOW
     out = run_gpu_tests_on_the_emulation(
-        wavesim_lib, ["test_gpu_parity.py", "test_gpu_loop.py", "test_gpu_dist.py", "test_gpu_fuzz.py"], keyword)
+        wavesim_lib, ["test_gpu_parity.py", "test_gpu_loop.py", "test_gpu_dist.py", "test_gpu_fuzz.py",
+                      "test_gpu_cpp_adapters.py"], keyword)
     last = [ln for ln in out.splitlines() if " passed" in ln][-1]
     print(last)
     assert int(last.split(" passed")[0].split()[-1]) >= 90, last
+
+
+@pytest.mark.parametrize("mode,world", [("target", 2), ("source", 2), ("target", 3)])
+def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, world):
+    """An N > 1 execution of the library's own multi-GPU code, which the one-GPU box of a round cannot give: `world`
+    PROCESSES, each with its own (emulated) device, a native communicator created from one shared id (pclhip_comm_*; the
+    collective underneath is the emulation's stand-in -- a sum in rank order through shared memory -- not RCCL), the
+    device-driven loop all-reducing the record of every iteration between its reduction and its solve, regions masking
+    the source per rank ("target") or the source cut into slabs ("source").  Checked: every rank ends with the SAME 4x4
+    bit for bit (same all-reduced record, same solve), it is the single-process alignment's up to the summation order,
+    the iteration counts agree, and what the ranks served adds up to the all-reduced count."""
+    import numpy as np
+    n = 60_000
+    work = str(tmp_path)
+    env = dict(os.environ, PCLHIP_LIB=wavesim_lib, PCLHIP_ALLOW_WAVESIM="1", WAVESIM_THREADS="8")
+    worker = os.path.join(WS, "two_rank_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, mode, str(r), str(world), work, str(n)], env=env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    ranks = [np.load(os.path.join(work, "rank%d.npz" % r)) for r in range(world)]
+    # single-process reference on the same emulation (no communicator, no region)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "import pcl_amd; from pcl_amd import synth\n"
+            "tgt, src, _ = synth.icp_pair(%d); ctx = pcl_amd.Context(0)\n"
+            "tree = pcl_amd.KdTree(ctx); tree.setInputCloud(tgt)\n"
+            "ne = pcl_amd.NormalEstimation(ctx); ne.setInputCloud(tgt); ne.setSearchMethod(tree); ne.setKSearch(8)\n"
+            "ne.setViewPoint(0, 0, 10); ne.compute(want_output=False)\n"
+            "icp = pcl_amd.IterativeClosestPointWithNormals(ctx); icp.setSearchMethodTarget(tree, True); icp.setInputSource(src)\n"
+            "icp.setMaximumIterations(20); icp.setMaxCorrespondenceDistance(0.1); icp.setTransformationEpsilon(1e-10); icp.align()\n"
+            "np.savez(%r, T=icp.getFinalTransformation(), iterations=icp.nr_iterations_, fitness=icp.getFitnessScore(0.01),\n"
+            "         fitness_points=icp.fitness_points)\n" % (ROOT, n, os.path.join(work, "single.npz")))
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    one = np.load(os.path.join(work, "single.npz"))
+    for r_ in ranks[1:]:
+        assert np.array_equal(r_["T"], ranks[0]["T"]) and int(r_["iterations"]) == int(ranks[0]["iterations"])
+        assert np.array_equal(r_["counts"], ranks[0]["counts"])            # all-reduced: the same on every rank
+    assert int(ranks[0]["iterations"]) == int(one["iterations"]) and bool(ranks[0]["converged"])
+    assert np.abs(ranks[0]["T"].astype(np.float64) - one["T"].astype(np.float64)).max() < 2e-6
+    assert all(int(r_["served"]) > 0 for r_ in ranks)                       # every rank had work
+    assert sum(int(r_["served"]) for r_ in ranks) in set(int(c) for c in ranks[0]["counts"])
+    assert int(ranks[0]["counts"][0]) == n
+    if mode == "target":
+        assert all(int(r_["index_points"]) < n for r_ in ranks)             # a slab + halo, not the cloud
+        # getFitnessScore under sharding: the owned points' (sum, count) all-reduced -> the single-index score
+        assert all(int(r_["fitness_points"]) == int(one["fitness_points"]) for r_ in ranks)
+        assert all(abs(float(r_["fitness"]) - float(one["fitness"])) <= 1e-9 * float(one["fitness"]) for r_ in ranks)

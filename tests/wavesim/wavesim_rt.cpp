@@ -449,3 +449,102 @@ hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) {
 }
 
 }  // extern "C"
+
+// ======================================================================================================================
+// A stand-in for the collective library (icp_loop.hip binds these four under PCLHIP_WAVESIM instead of dlopen'ing RCCL):
+// the ranks are PROCESSES on this host, the communicator is a POSIX shared-memory block named by the unique id, an
+// all-reduce is "write my operand, barrier, add the ranks' operands in rank order, barrier".  It lets the N > 1 logic
+// of the library itself -- communicator set-up from a shared id, the stream-ordered all-reduce between the reduction and
+// the solve of every iteration, region masks with real peer processes -- run in the CPU tier.  It says nothing about
+// RCCL or xGMI.
+// ======================================================================================================================
+#include <fcntl.h>
+#include <sched.h>
+#include <unistd.h>
+
+namespace {
+constexpr int NCCL_MAX_RANKS = 16, NCCL_MAX_COUNT = 256;
+struct ShmComm {
+  std::atomic<uint32_t> arrived;
+  std::atomic<uint32_t> generation;
+  double slots[NCCL_MAX_RANKS][NCCL_MAX_COUNT];
+};
+struct FakeComm {
+  ShmComm* shm = nullptr;
+  int rank = 0, nranks = 1;
+  char name[64];
+};
+struct FakeUniqueId {
+  char internal[128];
+};
+bool shm_barrier(FakeComm* c) {
+  ShmComm* s = c->shm;
+  const uint32_t gen = s->generation.load(std::memory_order_acquire);
+  if (s->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == uint32_t(c->nranks)) {
+    s->arrived.store(0, std::memory_order_relaxed);
+    s->generation.fetch_add(1, std::memory_order_acq_rel);
+    return true;
+  }
+  for (uint64_t spins = 0; s->generation.load(std::memory_order_acquire) == gen; ++spins) {
+    if (spins > 2000) usleep(50); else sched_yield();
+    if (spins > 2400000) return false;  // ~2 minutes: a peer died
+  }
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
+__attribute__((visibility("default"))) int wavesim_ncclGetUniqueId(FakeUniqueId* id) {
+  std::memset(id, 0, sizeof *id);
+  static std::atomic<unsigned> serial{0};
+  std::snprintf(id->internal, sizeof id->internal, "/wavesim-nccl-%d-%u-%llx", int(getpid()), serial.fetch_add(1),
+                (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+  return 0;
+}
+__attribute__((visibility("default"))) int wavesim_ncclCommInitRank(void** comm, int nranks, FakeUniqueId id, int rank) {
+  if (nranks < 1 || nranks > NCCL_MAX_RANKS || rank < 0 || rank >= nranks) return 4;
+  id.internal[63] = 0;
+  const int fd = shm_open(id.internal, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) return 2;
+  if (ftruncate(fd, sizeof(ShmComm)) != 0) {
+    close(fd);
+    return 2;
+  }
+  void* p = mmap(nullptr, sizeof(ShmComm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return 2;
+  FakeComm* c = new FakeComm;
+  c->shm = static_cast<ShmComm*>(p);  // a fresh object is all zeros: counters start at 0
+  c->rank = rank;
+  c->nranks = nranks;
+  std::snprintf(c->name, sizeof c->name, "%s", id.internal);
+  if (!shm_barrier(c)) return 3;  // like ncclCommInitRank: returns when every rank has joined
+  *comm = c;
+  return 0;
+}
+__attribute__((visibility("default"))) int wavesim_ncclCommDestroy(void* comm) {
+  FakeComm* c = static_cast<FakeComm*>(comm);
+  if (!c) return 0;
+  if (c->rank == 0) shm_unlink(c->name);
+  munmap(c->shm, sizeof(ShmComm));
+  delete c;
+  return 0;
+}
+__attribute__((visibility("default"))) int wavesim_ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op,
+                                                                 void* comm, hipStream_t) {
+  FakeComm* c = static_cast<FakeComm*>(comm);
+  if (!c || dtype != 8 || op != 0 || count > size_t(NCCL_MAX_COUNT)) return 4;  // ncclFloat64, ncclSum
+  std::memcpy(c->shm->slots[c->rank], send, count * sizeof(double));
+  if (!shm_barrier(c)) return 3;
+  double* out = static_cast<double*>(recv);
+  for (size_t i = 0; i < count; ++i) {
+    double s = 0.0;
+    for (int r = 0; r < c->nranks; ++r) s += c->shm->slots[r][i];
+    out[i] = s;
+  }
+  if (!shm_barrier(c)) return 3;  // nobody overwrites its slot before everybody has read it
+  return 0;
+}
+
+}  // extern "C"
