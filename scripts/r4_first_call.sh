@@ -1,0 +1,31 @@
+#!/bin/bash
+# The first GPU-box call of round 4: everything round 3's last commit could not get because
+# the round's GPU budget ended with its bench A/B.  Usage (through gpurun, ~12 GPU-minutes):
+#   GRAFT_COMMIT=$(git rev-parse --short HEAD) bash scripts/r4_first_call.sh
+#   -> gpurun_out/r4first/ (+ gpurun_out/prof_r4first/); copy what is to be judged into profiles/ as r04_*.
+set -u
+export GRAFT_COMMIT=${GRAFT_COMMIT:-unknown}
+OUT=gpurun_out/r4first
+mkdir -p $OUT
+# 1. the short evidence run: -m gpu tests, trace + FETCH/WRITE passes of the driver's command (the cold launch's fetch
+#    volume under the front-ordered runs: 2.3 GB with one long run per wave), all bench lines, k-NN timings
+EVIDENCE_SHORT=1 bash scripts/final_evidence.sh r4first > $OUT/evidence.log 2>&1; tail -3 $OUT/evidence.log
+# 2. the gate on the index size of the stand-off search (PCLHIP_SO_MAX_MB, default 640 = between 10M and 15M points) dates
+#    from the old schedule: cold launch at 12M / 15M / 20M points with the gate as it is and lifted
+for n in 12000000 15000000 20000000; do
+  for mb in 640 100000; do
+    echo "== n $n PCLHIP_SO_MAX_MB $mb" >> $OUT/gate.log
+    PCLHIP_SO_MAX_MB=$mb timeout 300 python scratch/big_cold_probe.py $n >> $OUT/gate.log 2>&1
+  done
+done
+cat $OUT/gate.log
+# 3. the same correspondence check the CPU emulation ran at 3M points (profiles/r03_wavesim_icp_check_3M.txt), on the
+#    device at 3M and 10M: the emulation's answer and the hardware's must be the same lines
+for n in 3000000 10000000; do timeout 600 python scratch/wavesim_icp_check.py $n > $OUT/icp_check_$n.log 2>&1; tail -4 $OUT/icp_check_$n.log; done
+# 4. run length of the stand-off schedule (PCLHIP_COLD_RUN, compile time): variants built beforehand with
+#    scripts/build_variant.sh run3 -DPCLHIP_COLD_RUN=3 etc. are measured if present
+for v in run3 run6; do
+  L=pcl_amd/variants/libpclhip_$v.so
+  [ -f $L ] && { echo "== $v" >> $OUT/run_ab.log; PCLHIP_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-host-align >> $OUT/run_ab.log 2>&1; }
+done
+[ -f $OUT/run_ab.log ] && cat $OUT/run_ab.log
