@@ -973,6 +973,9 @@ static void icp_free_source(pclhip_icp* icp) {
   icp->src_records_host = nullptr;
   icp->src_records_stride = 0;
   icp->src_records_n = 0;
+  if (icp->own_block) (void)dev_free(icp->ctx, icp->own_block);
+  icp->own_block = nullptr;
+  icp->own_groups = 0;
   if (icp->src_sorted0) (void)dev_free(icp->ctx, icp->src_sorted0);
   if (icp->src_cur) (void)dev_free(icp->ctx, icp->src_cur);
   if (icp->src_nrm_sorted0) (void)dev_free(icp->ctx, icp->src_nrm_sorted0);

@@ -98,6 +98,27 @@ struct IcpControl {
   cf::CriteriaState st;
 };
 
+// Served groups under target sharding (search.hip: icp_own_* kernels).  A rank holds the whole source but serves only the
+// points whose current position lies in its region; the source is kd-ordered, so whole 64-point groups lie outside.  In
+// the device-driven loop every iteration first lists the groups whose (transformed) box touches the region, and the search
+// and accumulation kernels walk that list: a rank touches ~ n / G source points per iteration instead of n.  A group that
+// was skipped for some iterations is brought up to date on the fly from the transforms it missed (hist), in the order
+// and arithmetic the working cloud would have seen -- bit for bit what the full pass computes.
+constexpr int OWN_HIST_CAP = 128;
+struct OwnedState {
+  uint32_t epoch;     // launch index inside the running alignment (0 = the launch that starts it)
+  uint32_t overflow;  // more launches than OWN_HIST_CAP: every group is served from here on
+  uint32_t pad[2];
+  float hist[OWN_HIST_CAP][12];  // hist[e] = the transform launch e applies to the working cloud
+};
+struct OwnedGroups {  // kernel argument
+  const uint32_t* list;      // served groups of this launch, ascending
+  const uint32_t* count;     // their number
+  uint32_t* stamp;           // per group: transforms applied to its working copy so far (0: none, read the pristine
+                             // cloud); bit 31: its match entries are known to be empty
+  const OwnedState* state;
+};
+
 // Device-resident state of one pass of the rejector chain (rejectors.hip): counts, ranks and thresholds never visit the
 // host between the kernels of a chain.
 struct RejState {
@@ -250,6 +271,17 @@ struct pclhip_icp {
   std::vector<hipEvent_t> step_events;      // 4 per ring slot: start, after search, after accumulate, after solve
   pclhip_comm* comm = nullptr;              // native RCCL all-reduce of the record (dist.hip); not owned
   pclhip::RegionBox region = {{0, 0, 0}, {0, 0, 0}, 0};  // target sharding: the source points this rank serves
+  // served-group lists of the device-driven loop under target sharding (one device block, made on first use)
+  void* own_block = nullptr;
+  uint32_t own_groups = 0;
+  float4* own_gbox = nullptr;            // [2 * groups] box of every 64-point group of the pristine source
+  uint32_t* own_stamp = nullptr;         // [groups]
+  uint32_t* own_flags = nullptr;         // [groups] 1: served in this launch
+  uint32_t* own_prefix = nullptr;        // [groups] exclusive scan of the flags
+  uint32_t* own_list = nullptr;          // [groups]
+  uint32_t* own_tot = nullptr;           // [4] tot[0] = served groups
+  uint2* own_partial = nullptr;          // scan scratch
+  pclhip::OwnedState* own_state = nullptr;
 };
 
 namespace pclhip {

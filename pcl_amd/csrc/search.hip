@@ -15,6 +15,7 @@
 #include "traverse.hpp"
 #include "standoff.hpp"
 #include "normals_math.hpp"
+#include "device_scan.hpp"
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -923,13 +924,29 @@ __device__ __forceinline__ bool in_region(const RegionBox& r, float x, float y, 
 // no policy of the ICP search kernels stages the w chunks: 3 KB of staging per wave (see WaveLdsT)
 typedef WaveLdsT<3072> IcpWaveLds;
 
-template <int Q, bool SPARSE>
+// OWNED (target sharding in the device-driven loop, pclhip_internal.hpp: OwnedGroups): the groups come from the launch's list
+// of served groups, and a group whose working copy missed some launches is brought up to date first.
+struct NoOwnedGroups {};
+// the working copy of point p after the launches [from, to) it missed: the very operations those launches would have applied
+__device__ __forceinline__ void own_replay(const OwnedState* st, uint32_t from, uint32_t to, int order, float4& p) {
+  for (uint32_t e = from; e < to; ++e) {
+    const float* m = st->hist[e];
+    const float x = xform_row(m[0], m[1], m[2], m[3], p.x, p.y, p.z, order);
+    const float y = xform_row(m[4], m[5], m[6], m[7], p.x, p.y, p.z, order);
+    const float z = xform_row(m[8], m[9], m[10], m[11], p.x, p.y, p.z, order);
+    p.x = x; p.y = y; p.z = z;
+  }
+}
+
+template <int Q, bool SPARSE, bool OWNED = false, class OG = NoOwnedGroups>
 __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __restrict__ cur,
                                                 const float4* __restrict__ src0, uint32_t ns, Mat34 T,
                                                 const IcpControl* __restrict__ ctl, const RegionBox& region, int order,
                                                 float bound, int flags, uint32_t* __restrict__ match_pos,
                                                 uint32_t* __restrict__ match, float* __restrict__ match_d2,
-                                                unsigned long long* gstats, IcpWaveLds* wl_s, Box* topbox_s) {
+                                                unsigned long long* gstats, IcpWaveLds* wl_s, Box* topbox_s,
+                                                const OG& og = OG()) {
+  static_assert(!OWNED || Q == 1, "served-group lists are per 64-point group");
   bool restart = false;
   if (ctl != nullptr) {
     if (ctl->stop != 0) return;  // the alignment ended before this (speculatively queued) launch
@@ -943,7 +960,16 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   constexpr uint32_t GROUP = WAVE * Q;  // queries per wavefront: Q per lane
-  const uint32_t ngroups = (ns + GROUP - 1) / GROUP;
+  uint32_t ngroups = (ns + GROUP - 1) / GROUP;
+  uint32_t epoch = 0;
+  if constexpr (OWNED) {
+    ngroups = og.count[0];  // slots of the served list; gid() maps a slot to its group
+    epoch = og.state->epoch;
+  }
+  const auto gid = [&](uint32_t slot) -> uint32_t {
+    if constexpr (OWNED) return slot < ngroups ? og.list[slot] : 0u;
+    else return slot;
+  };
   const GroupSchedule sched(ngroups);
   TraverseStats ts;
   // software pipeline: the next group's points, seed positions and seed target points are already
@@ -960,14 +986,16 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
   }
   float4 p_n[Q], t_n[Q];
   uint32_t sp_n[Q];
+  uint32_t gid_n = gid(g), st_n = 0;  // the group behind slot g; how many launches its working copy has seen
+  if constexpr (OWNED) st_n = (g < ngroups && !restart) ? (og.stamp[gid_n] & 0x7FFFFFFFu) : 0u;
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     p_n[q] = make_float4(0, 0, 0, 0);
     t_n[q] = make_float4(0, 0, 0, 0);
     sp_n[q] = NO_INDEX;
-    const uint32_t i = g * GROUP + q * WAVE + lane;
+    const uint32_t i = gid_n * GROUP + q * WAVE + lane;
     if (g < ngroups && i < ns) {
-      p_n[q] = in[i];
+      p_n[q] = (OWNED && st_n == 0u) ? src0[i] : in[i];
       sp_n[q] = restart ? NO_INDEX : match_pos[i];
       if (sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
     }
@@ -988,15 +1016,18 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
     uint32_t seed_pos[Q];
     bool in_range[Q], valid[Q];
     float qx[Q], qy[Q], qz[Q];
+    const uint32_t gcur = gid_n, st_cur = st_n;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       p[q] = p_n[q];
       t0[q] = t_n[q];
       seed_pos[q] = sp_n[q];
-      in_range[q] = (g * GROUP + q * WAVE + lane) < ns;
+      in_range[q] = (gcur * GROUP + q * WAVE + lane) < ns;
     }
     // next group: issue its points + seed positions now ...
     const uint32_t g2 = (gl_next != GroupFeed::END) ? sched.global(gl_next) : ngroups;
+    gid_n = gid(g2);
+    if constexpr (OWNED) st_n = (g2 < ngroups && !restart) ? (og.stamp[gid_n] & 0x7FFFFFFFu) : 0u;
     uint32_t gl_after = GroupFeed::END;
     bool asked = false;
     if (gl_next != GroupFeed::END && !feed.static_next(gl_next, gl_after)) {
@@ -1006,12 +1037,12 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
     bool next_ok[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      const uint32_t i2 = g2 * GROUP + q * WAVE + lane;
+      const uint32_t i2 = gid_n * GROUP + q * WAVE + lane;
       next_ok[q] = g2 < ngroups && i2 < ns;
       p_n[q] = make_float4(0, 0, 0, 0);
       sp_n[q] = NO_INDEX;
       if (next_ok[q]) {
-        p_n[q] = in[i2];
+        p_n[q] = (OWNED && st_n == 0u) ? src0[i2] : in[i2];
         sp_n[q] = restart ? NO_INDEX : match_pos[i2];
       }
     }
@@ -1021,20 +1052,22 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
     for (int q = 0; q < Q; ++q) {
       valid[q] = in_range[q] && isfinite(p[q].x) && isfinite(p[q].y) && isfinite(p[q].z);
       if (valid[q]) {
+        if constexpr (OWNED) own_replay(og.state, st_cur, restart ? 0u : epoch, order, p[q]);  // the launches it was not served in
         const float x = xform_row(T.m[0], T.m[1], T.m[2], T.m[3], p[q].x, p[q].y, p[q].z, order);
         const float y = xform_row(T.m[4], T.m[5], T.m[6], T.m[7], p[q].x, p[q].y, p[q].z, order);
         const float z = xform_row(T.m[8], T.m[9], T.m[10], T.m[11], p[q].x, p[q].y, p[q].z, order);
         p[q].x = x; p[q].y = y; p[q].z = z;
-        cur[g * GROUP + q * WAVE + lane] = p[q];
+        cur[gcur * GROUP + q * WAVE + lane] = p[q];
         // target sharding: every rank moves the whole source, but serves only the points inside its region
         if (region.on) valid[q] = in_region(region, x, y, z);
         if (valid[q] && seed_pos[q] != NO_INDEX)
           fast.seed(q, l2_simple(x, y, z, t0[q].x, t0[q].y, t0[q].z), seed_pos[q]);
-      } else if (in_range[q] && restart) {
-        cur[g * GROUP + q * WAVE + lane] = p[q];  // non-finite points travel unchanged (icp.hpp:97-98)
+      } else if (in_range[q] && (restart || (OWNED && st_cur == 0u))) {
+        cur[gcur * GROUP + q * WAVE + lane] = p[q];  // non-finite points travel unchanged (icp.hpp:97-98)
       }
       qx[q] = p[q].x; qy[q] = p[q].y; qz[q] = p[q].z;
     }
+
     // hint for the descent: the leaf of one lane's seed (any lane: the containment test inside traverse()
     // decides whether the shortcut is valid for the whole wave)
     uint32_t start_leaf = NO_INDEX;
@@ -1071,11 +1104,16 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
       const uint32_t mid = key_index(pol.key);
       const bool found = valid[q] && mid != NO_INDEX;
       if (in_range[q]) {
-        const uint32_t i = g * GROUP + q * WAVE + lane;
+        const uint32_t i = gcur * GROUP + q * WAVE + lane;
         match[i] = found ? mid : NO_INDEX;
         match_pos[i] = found ? pol.pos : NO_INDEX;
         match_d2[i] = found ? key_dist(pol.key) : __builtin_inff();
       }
+    }
+    if constexpr (OWNED) {
+      // this launch's transform is in the group's working copy, its match entries are in use.  (Stored down here, behind
+      // the traversal's cross-lane operations: every lane has read the old value by then in any execution order.)
+      if (lane == 0) og.stamp[gcur] = epoch + 1u;
     }
     g = g2;
     gl_next = asked ? feed.resolve() : gl_after;
@@ -1089,13 +1127,14 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
 // runs of consecutive -- spatially adjacent -- groups and seeds each from its predecessor's matches (standoff.hpp:
 // collect / cull / evaluate); whatever that path gives up on goes through traverse() with the bounds reached so
 // far.  Same outputs as the seeded search, bit for bit.
+template <bool OWNED = false, class OG = NoOwnedGroups>
 __device__ __forceinline__ void icp_cold_search_body(const IndexView& ix, float4* __restrict__ cur,
                                                      const float4* __restrict__ src0, uint32_t ns, Mat34 T,
                                                      const IcpControl* __restrict__ ctl, const RegionBox& region, int order,
                                                      float bound, int flags, float so_from,
                                                      uint32_t* __restrict__ match_pos, uint32_t* __restrict__ match,
                                                      float* __restrict__ match_d2, unsigned long long* gstats,
-                                                     IcpWaveLds* wl_s, Box* topbox_s) {
+                                                     IcpWaveLds* wl_s, Box* topbox_s, const OG& og = OG()) {
   bool restart = false;
   if (ctl != nullptr) {
     if (ctl->stop != 0) return;
@@ -1108,7 +1147,12 @@ __device__ __forceinline__ void icp_cold_search_body(const IndexView& ix, float4
   load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
-  const uint32_t ngroups = (ns + WAVE - 1) / WAVE;
+  uint32_t ngroups = (ns + WAVE - 1) / WAVE;
+  if constexpr (OWNED) ngroups = og.count[0];  // slots of the served list (this body only starts alignments: no replay)
+  const auto gid = [&](uint32_t slot) -> uint32_t {
+    if constexpr (OWNED) return slot < ngroups ? og.list[slot] : 0u;
+    else return slot;
+  };
   TraverseStats ts;
   PrevGroup prev;
   prev.init();
@@ -1132,18 +1176,21 @@ __device__ __forceinline__ void icp_cold_search_body(const IndexView& ix, float4
   float4 p_n = make_float4(0, 0, 0, 0);
   {
     const uint32_t g0 = (gl < run_end) ? sched.global(gl) : ngroups;
-    if (g0 < ngroups && g0 * WAVE + lane < ns) p_n = in[g0 * WAVE + lane];
+    if (g0 < ngroups && gid(g0) * WAVE + lane < ns) p_n = in[gid(g0) * WAVE + lane];
   }
   for (; gl < run_end; ++gl) {
     const uint32_t g = sched.global(gl);
     if (g >= ngroups) break;
     float4 p = p_n;
-    const uint32_t i = g * WAVE + lane;
+    const uint32_t i = gid(g) * WAVE + lane;
     const bool in_range = i < ns;
     {  // the next group's points are in flight while this one is searched
       const uint32_t g2 = (gl + 1u < run_end) ? sched.global(gl + 1u) : ngroups;
       p_n = make_float4(0, 0, 0, 0);
-      if (g2 < ngroups && g2 * WAVE + lane < ns) p_n = in[g2 * WAVE + lane];
+      if (g2 < ngroups && gid(g2) * WAVE + lane < ns) p_n = in[gid(g2) * WAVE + lane];
+    }
+    if constexpr (OWNED) {
+      if (lane == 0) og.stamp[gid(g)] = 1u;  // the alignment's first transform applied; match entries in use
     }
     NN1Min fast;
     fast.init(bound);
@@ -1250,6 +1297,119 @@ __global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_search_dual_kerne
   else
     icp_search_body<1, true>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
                              topbox_s);
+}
+
+// The same two bodies over the launch's list of SERVED groups (target sharding in the device-driven loop): `standoff`
+// says whether launches that start an alignment take the stand-off body (the index carries discs and passes the gates).
+__global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_search_owned_kernel(
+    IndexView ix, float4* __restrict__ cur, const float4* __restrict__ src0, uint32_t ns, Mat34 T,
+    const IcpControl* __restrict__ ctl, RegionBox region, int order, float bound, int flags, float so_from, int standoff,
+    uint32_t* __restrict__ match_pos, uint32_t* __restrict__ match, float* __restrict__ match_d2, unsigned long long* gstats,
+    OwnedGroups og) {
+  __shared__ IcpWaveLds wl_s[WAVES_PER_BLOCK];
+  __shared__ Box topbox_s[TOPCACHE_BOXES];
+  if (standoff != 0 && ctl->restart != 0)
+    icp_cold_search_body<true, OwnedGroups>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, so_from, match_pos, match,
+                                            match_d2, gstats, wl_s, topbox_s, og);
+  else
+    icp_search_body<1, true, true, OwnedGroups>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match,
+                                                match_d2, gstats, wl_s, topbox_s, og);
+}
+
+// ---- served groups (pclhip_internal.hpp: OwnedGroups) ----------------------------------------------------------------
+// box of every 64-point group of the pristine, kd-ordered source: one wavefront per group
+__global__ __launch_bounds__(BLOCK) void icp_group_box_kernel(const float4* __restrict__ src0, uint32_t ns,
+                                                              float4* __restrict__ gbox) {
+  const uint32_t g = blockIdx.x * WAVES_PER_BLOCK + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  const uint32_t ngroups = (ns + WAVE - 1) / WAVE;
+  if (g >= ngroups) return;  // wave-uniform
+  const float BIG = 3.402823466e+38f;
+  float lx = BIG, ly = BIG, lz = BIG, hx = -BIG, hy = -BIG, hz = -BIG, unused = 0.0f;
+  const uint32_t i = g * WAVE + lane;
+  if (i < ns) {
+    const float4 p = src0[i];
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+      lx = hx = p.x; ly = hy = p.y; lz = hz = p.z;
+    }
+  }
+  wave_min3_max4(lx, ly, lz, hx, hy, hz, unused);
+  if (lane == 0) {
+    gbox[2 * g] = make_float4(lx, ly, lz, 0.0f);      // lo > hi: no finite point, never served
+    gbox[2 * g + 1] = make_float4(hx, hy, hz, 0.0f);
+  }
+}
+
+// one thread: which launch of the alignment this is, and the transform it applies (read back by groups that skip it)
+__global__ void icp_own_epoch_kernel(const IcpControl* __restrict__ ctl, OwnedState* __restrict__ st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || ctl->stop != 0) return;
+  const bool restart = ctl->restart != 0;
+  const uint32_t e = restart ? 0u : st->epoch + 1u;
+  st->epoch = e;
+  if (restart) st->overflow = 0u;
+  if (e < uint32_t(OWN_HIST_CAP)) {
+    for (int i = 0; i < 12; ++i) st->hist[e][i] = ctl->T_apply[i];
+  } else {
+    st->overflow = 1u;  // no room to remember this launch: nobody may skip it (or any later one)
+  }
+}
+
+// One thread per group: is it served in this launch?  After the launch every point sits at M * (pristine point), M =
+// ctl->final_T (the guess for the launch that starts an alignment, Tk ... T1 guess later on); the group's box goes
+// through M in float and is widened by far more than the working copy -- moved step by step, in float -- can deviate
+// from that product (2e-4 of the coordinates' size against ~1e-7 per step).  A group that stops being served has its match
+// entries emptied once (the accumulation and the host never see stale pairs).
+__global__ __launch_bounds__(BLOCK) void icp_own_flag_kernel(const IcpControl* __restrict__ ctl,
+                                                             const OwnedState* __restrict__ st,
+                                                             const float4* __restrict__ gbox, RegionBox region,
+                                                             uint32_t ngroups, uint32_t ns, uint32_t* __restrict__ stamp,
+                                                             uint32_t* __restrict__ flags, uint32_t* __restrict__ match,
+                                                             uint32_t* __restrict__ match_pos, float* __restrict__ match_d2) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ngroups || ctl->stop != 0) return;
+  const bool restart = ctl->restart != 0;
+  uint32_t sv = restart ? 0u : stamp[g];
+  const float4 lo = gbox[2 * g], hi = gbox[2 * g + 1];
+  bool own = false;
+  if (lo.x <= hi.x) {
+    if (st->overflow != 0u) {
+      own = true;
+    } else {
+      const float* M = ctl->final_T;
+      const float BIG = 3.402823466e+38f;
+      float bl[3] = {BIG, BIG, BIG}, bh[3] = {-BIG, -BIG, -BIG}, mag = 0.0f;
+      for (int c = 0; c < 8; ++c) {
+        const float x = (c & 1) ? hi.x : lo.x, y = (c & 2) ? hi.y : lo.y, z = (c & 4) ? hi.z : lo.z;
+        for (int r = 0; r < 3; ++r) {
+          const float v = M[4 * r] * x + M[4 * r + 1] * y + M[4 * r + 2] * z + M[4 * r + 3];
+          bl[r] = fminf(bl[r], v);
+          bh[r] = fmaxf(bh[r], v);
+          mag = fmaxf(mag, fabsf(M[4 * r] * x) + fabsf(M[4 * r + 1] * y) + fabsf(M[4 * r + 2] * z) + fabsf(M[4 * r + 3]));
+        }
+      }
+      const float eps = 2e-4f * mag + 1e-30f;
+      own = true;
+      for (int r = 0; r < 3; ++r) own = own && (bh[r] + eps >= region.lo[r]) && (bl[r] - eps < region.hi[r]);
+      if (!(mag < BIG)) own = true;  // a transform that overflows: decide per point
+    }
+  }
+  flags[g] = own ? 1u : 0u;
+  if (!own && (sv >> 31) == 0u) {
+    for (uint32_t i = g * WAVE; i < ns && i < (g + 1u) * WAVE; ++i) {
+      match[i] = NO_INDEX;
+      match_pos[i] = NO_INDEX;
+      match_d2[i] = __builtin_inff();
+    }
+    sv |= 0x80000000u;
+  }
+  stamp[g] = sv;
+}
+
+__global__ __launch_bounds__(BLOCK) void icp_own_scatter_kernel(const uint32_t* __restrict__ flags,
+                                                                const uint32_t* __restrict__ prefix, uint32_t ngroups,
+                                                                uint32_t* __restrict__ list) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < ngroups && flags[g] != 0u) list[prefix[g]] = g;
 }
 
 // Reciprocal correspondences (registration/include/pcl/registration/impl/correspondence_estimation.hpp:247-270): the
@@ -1535,6 +1695,37 @@ __global__ __launch_bounds__(BLOCK) void icp_accumulate_kernel(IndexView ix, con
   pa.store_block(red_s, partials);
 }
 
+// The accumulation over the launch's SERVED groups (target sharding in the device-driven loop): slot s of the list's
+// 64 * count slots is point 64 * list[s / 64] + s % 64.  Same per-pair arithmetic, a fixed order of its own.
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void icp_accumulate_owned_kernel(IndexView ix, const float4* __restrict__ cur, uint32_t ns,
+                                                                     const uint32_t* __restrict__ match_pos,
+                                                                     const float* __restrict__ match_d2,
+                                                                     const uint8_t* __restrict__ keep,
+                                                                     const IcpControl* __restrict__ ctl, int enforce,
+                                                                     double* __restrict__ partials, OwnedGroups og) {
+  static_assert(MODE != PCLHIP_ICP_SYMMETRIC, "the symmetric objective moves the source normals of every point: full pass");
+  __shared__ double red_s[WAVES_PER_BLOCK][NS];
+  if (ctl->stop != 0) return;
+  PairAcc<MODE> pa;
+  pa.init();
+  const uint64_t slots = uint64_t(og.count[0]) * WAVE;
+  const float4 zero = make_float4(0, 0, 0, 0);
+  for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < slots; s += uint64_t(gridDim.x) * blockDim.x) {
+    const uint32_t i = og.list[s / WAVE] * WAVE + uint32_t(s % WAVE);
+    if (i >= ns) continue;
+    const uint32_t pos = match_pos[i];
+    if (pos == NO_INDEX) continue;
+    if (keep != nullptr && !keep[i]) continue;
+    const float4 p = cur[i];
+    const float4 t = ix.pts[pos];
+    float4 n = zero;
+    if constexpr (MODE != PCLHIP_ICP_POINT_TO_POINT) n = ix.nrm[pos];
+    pa.add(p, zero, t, n, match_d2[i], enforce != 0);
+  }
+  pa.store_block(red_s, partials);
+}
+
 // TransformationEstimation::estimateRigidTransformation(cloud_src, cloud_tgt) for n given pairs
 // (registration/include/pcl/registration/transformation_estimation.h:71-115): pair i = (src[i], tgt[i]).
 template <int MODE>
@@ -1704,12 +1895,59 @@ static int search_skip_flag() {
   return skip;
 }
 
+// PCLHIP_OWNED_GROUPS=0: under target sharding every rank walks the whole source again (the form the lists replaced; A/B
+// and the tests that compare the two)
+static bool owned_groups_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("PCLHIP_OWNED_GROUPS");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
+
 template <int MODE>
 static void launch_accumulate(pclhip_icp* icp, const IndexView& v, int ga, const uint8_t* keep, const Mat34& M,
                               const IcpControl* ctl, hipStream_t s) {
   hipLaunchKernelGGL(icp_accumulate_kernel<MODE>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, icp->match_pos,
                      icp->match_d2, keep, M, ctl, icp->src_nrm_cur, icp->src_nrm_sorted0,
                      icp->enforce_same_direction_normals ? 1 : 0, icp->partials);
+}
+
+// Served-group lists (OwnedGroups): the arrays of a registration, made on first use; the boxes of the source's groups
+static pclhip_status ensure_owned_groups(pclhip_icp* icp) {
+  pclhip_ctx* ctx = icp->ctx;
+  const uint32_t ngroups = (icp->n + WAVE - 1) / WAVE;
+  if (icp->own_block != nullptr && icp->own_groups == ngroups) return PCLHIP_OK;
+  if (icp->own_block) dev_free(ctx, icp->own_block);
+  icp->own_block = nullptr;
+  const size_t g = ngroups ? ngroups : 1;
+  const size_t nb = (g + SC_BLOCK - 1) / SC_BLOCK;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = off;
+    off += (bytes + 255) & ~size_t(255);
+    return at;
+  };
+  const size_t o_box = take(2 * g * sizeof(float4)), o_stamp = take(g * 4), o_flags = take(g * 4), o_prefix = take(g * 4),
+               o_list = take(g * 4), o_tot = take(16), o_part = take(nb * sizeof(uint2)), o_state = take(sizeof(OwnedState));
+  char* base = nullptr;
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &base, off));
+  icp->own_block = base;
+  icp->own_groups = ngroups;
+  icp->own_gbox = reinterpret_cast<float4*>(base + o_box);
+  icp->own_stamp = reinterpret_cast<uint32_t*>(base + o_stamp);
+  icp->own_flags = reinterpret_cast<uint32_t*>(base + o_flags);
+  icp->own_prefix = reinterpret_cast<uint32_t*>(base + o_prefix);
+  icp->own_list = reinterpret_cast<uint32_t*>(base + o_list);
+  icp->own_tot = reinterpret_cast<uint32_t*>(base + o_tot);
+  icp->own_partial = reinterpret_cast<uint2*>(base + o_part);
+  icp->own_state = reinterpret_cast<OwnedState*>(base + o_state);
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(base + o_stamp, 0, off - o_stamp, ctx->stream));
+  if (ngroups)
+    hipLaunchKernelGGL(icp_group_box_kernel, dim3((ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK), 0, ctx->stream,
+                       icp->src_sorted0, icp->n, icp->own_gbox);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  return PCLHIP_OK;
 }
 
 // One iteration.  ev == nullptr: the host-driven form (T by value, the caller reads the record back);
@@ -1773,8 +2011,31 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
       return e ? float(atof(e)) : 1.0f;
     }();
     const float so_from = so_factor * icp->target->leaf_diag2;
+    // target sharding in the device-driven loop: list the groups this rank serves in this launch, walk the list
+    const bool owned = device_loop && icp->region.on != 0 && mode != PCLHIP_ICP_SYMMETRIC && owned_groups_enabled();
+    OwnedGroups og = {nullptr, nullptr, nullptr, nullptr};
+    if (owned) {
+      pclhip_status st = ensure_owned_groups(icp);
+      if (st != PCLHIP_OK) return st;
+      og.list = icp->own_list;
+      og.count = icp->own_tot;
+      og.stamp = icp->own_stamp;
+      og.state = icp->own_state;
+    }
     (void)hipEventRecord(device_loop ? ev[0] : icp->ev0, s);
-    if (standoff && device_loop) {
+    if (owned) {
+      hipLaunchKernelGGL(icp_own_epoch_kernel, dim3(1), dim3(1), 0, s, ctl, icp->own_state);
+      hipLaunchKernelGGL(icp_own_flag_kernel, dim3((ngroups + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, ctl, icp->own_state,
+                         icp->own_gbox, icp->region, ngroups, icp->n, icp->own_stamp, icp->own_flags, icp->match,
+                         icp->match_pos, icp->match_d2);
+      launch_scan_u32(s, icp->own_flags, ngroups, icp->own_partial, icp->own_tot, icp->own_prefix);
+      hipLaunchKernelGGL(icp_own_scatter_kernel, dim3((ngroups + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, icp->own_flags,
+                         icp->own_prefix, ngroups, icp->own_list);
+      const int go = resident_blocks(ctx, icp_search_owned_kernel, ngroups);
+      PCLHIP_LAUNCH_FED(ctx, icp_search_owned_kernel, dim3(go), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M,
+                         ctl, icp->region, order, bound, kflags, so_from, standoff ? 1 : 0, icp->match_pos, icp->match,
+                         icp->match_d2, ctx->stats, og);
+    } else if (standoff && device_loop) {
       const int gd = resident_blocks(ctx, icp_search_dual_kernel, ngroups);
       PCLHIP_LAUNCH_FED(ctx, icp_search_dual_kernel, dim3(gd), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl,
                          icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
@@ -1807,7 +2068,15 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
       const int need = int((uint64_t(icp->n) + 1023u) / 1024u);
       if (ga > need) ga = need < 64 ? 64 : need;
     }
-    if (mode == PCLHIP_ICP_POINT_TO_PLANE)
+    if (owned && mode == PCLHIP_ICP_POINT_TO_PLANE)
+      hipLaunchKernelGGL(icp_accumulate_owned_kernel<PCLHIP_ICP_POINT_TO_PLANE>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur,
+                         icp->n, icp->match_pos, icp->match_d2, keep, ctl, icp->enforce_same_direction_normals ? 1 : 0,
+                         icp->partials, og);
+    else if (owned)
+      hipLaunchKernelGGL(icp_accumulate_owned_kernel<PCLHIP_ICP_POINT_TO_POINT>, dim3(ga), dim3(BLOCK), 0, s, v, icp->src_cur,
+                         icp->n, icp->match_pos, icp->match_d2, keep, ctl, icp->enforce_same_direction_normals ? 1 : 0,
+                         icp->partials, og);
+    else if (mode == PCLHIP_ICP_POINT_TO_PLANE)
       launch_accumulate<PCLHIP_ICP_POINT_TO_PLANE>(icp, v, ga, keep, M, ctl, s);
     else if (mode == PCLHIP_ICP_SYMMETRIC)
       launch_accumulate<PCLHIP_ICP_SYMMETRIC>(icp, v, ga, keep, M, ctl, s);
@@ -1991,6 +2260,7 @@ void preload_search_kernels(pclhip_ctx* ctx) {
   (void)resident_blocks(ctx, icp_search_kernel<4, 1, true>, 1);
   (void)resident_blocks(ctx, icp_cold_search_kernel, 1);
   (void)resident_blocks(ctx, icp_search_dual_kernel, 1);
+  (void)resident_blocks(ctx, icp_search_owned_kernel, 1);
   (void)resident_blocks(ctx, normals_kernel<8>, 1);
   (void)resident_blocks(ctx, knn_reg_kernel<1>, 1);
 }

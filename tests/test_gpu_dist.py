@@ -181,3 +181,36 @@ def test_sharded_bench_path_single_slab_runs_whole_alignments():
         res.append([(s["iteration"], s["state"], s["num_correspondences"], s["alignment_ended"]) for s in steps])
     assert res[0] == res[1]
     assert [r[0] for r in res[0][:3]] == [1, 2, 3] and res[0][0][2] == len(src)
+
+
+def test_served_group_lists_equal_the_full_pass(tmp_path):
+    # Under target sharding the device-driven loop walks only the 64-point groups of the source whose box touches the
+    # rank's region, and brings a group that was skipped for some launches up to date from the transforms it missed.
+    # The same run with PCLHIP_OWNED_GROUPS=0 walks the whole source every launch: the served correspondences must be the
+    # same lists -- query, match AND float distance, which only come out equal if every replayed position is the full
+    # pass's bit for bit --, the step records the same counts and iterations, the 4x4 equal up to the summation order.
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "owned_groups_worker.py")
+    outs = []
+    for owned in ("1", "0"):
+        out = str(tmp_path / ("owned%s.npz" % owned))
+        env = dict(os.environ, PCLHIP_OWNED_GROUPS=owned)
+        r = subprocess.run([sys.executable, worker, out, "150000"], env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        if k.endswith(("_q", "_m", "_q2", "_m2", "_its", "_counts", "_iterations")):
+            assert np.array_equal(a[k], b[k]), k
+        elif k.endswith(("_d", "_d2")):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+        elif k.endswith("_T"):
+            assert np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() < 2e-6, k
+        elif k.endswith("_mse"):
+            assert np.allclose(a[k], b[k], rtol=1e-9, atol=1e-18), k
+    # the scenario does what it is for: regions that serve a part of the cloud, and a cloud that moves through them
+    assert 0 < len(a["strip_plane_q"]) < 150000 // 4 and 0 < len(a["corner_plane_q"]) < 150000 // 4
+    assert len(a["all_plane_q"]) == 150000
+    assert a["strip_plane_counts"][0] != a["strip_plane_counts"][2] and a["corner_point_counts"][0] != a["corner_point_counts"][5]
