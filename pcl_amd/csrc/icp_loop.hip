@@ -388,6 +388,7 @@ pclhip_status icp_align_device(pclhip_icp* icp, const pclhip_icp_params* params,
     }
     return r.ended == 0;
   });
+  if (st == PCLHIP_OK) st = owned_groups_catch_up(icp, params->mode);  // target sharding: see search.hip, served groups
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (st != PCLHIP_OK) return st;
   res->gpu_ms = total_ms;
@@ -461,6 +462,7 @@ extern "C" pclhip_status pclhip_icp_run_steps(pclhip_icp* icp, const pclhip_icp_
     icp->last_search_ms = t.search_ms;
     return true;
   });
+  if (st == PCLHIP_OK) st = owned_groups_catch_up(icp, params->mode);
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return st;
 }

@@ -104,7 +104,10 @@ struct IcpControl {
 // and accumulation kernels walk that list: a rank touches ~ n / G source points per iteration instead of n.  A group that
 // was skipped for some iterations is brought up to date on the fly from the transforms it missed (hist), in the order
 // and arithmetic the working cloud would have seen -- bit for bit what the full pass computes.
-constexpr int OWN_HIST_CAP = 128;
+#ifndef PCLHIP_OWN_HIST_CAP
+#define PCLHIP_OWN_HIST_CAP 128  // (tests build with 3: alignments that outlast the history)
+#endif
+constexpr int OWN_HIST_CAP = PCLHIP_OWN_HIST_CAP;
 struct OwnedState {
   uint32_t epoch;     // launch index inside the running alignment (0 = the launch that starts it)
   uint32_t overflow;  // more launches than OWN_HIST_CAP: every group is served from here on
@@ -422,6 +425,9 @@ pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, 
 pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_t* nan_count);
 pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d2, bool use_max,
                                  int mode, hipEvent_t* step_events = nullptr);
+// target sharding, after a run of the device-driven loop: the working copies of the groups the last launches did not
+// serve are brought up to date (search.hip: served groups), stream-ordered
+pclhip_status owned_groups_catch_up(pclhip_icp* icp, int mode);
 // sums icp->sums_dev over the ranks on the context's stream (native RCCL communicator or the hook); no-op
 // for a single-GPU registration
 pclhip_status allreduce_record(pclhip_icp* icp);

@@ -1405,6 +1405,27 @@ __global__ __launch_bounds__(BLOCK) void icp_own_flag_kernel(const IcpControl* _
   stamp[g] = sv;
 }
 
+// When the loop hands control back to the host: every group's working copy through the last launch's transform, so that
+// whatever reads or moves the working cloud next (a host-driven pclhip_icp_iterate) finds what the full pass leaves.
+__global__ __launch_bounds__(BLOCK) void icp_own_catchup_kernel(float4* __restrict__ cur, const float4* __restrict__ src0,
+                                                                uint32_t ns, int order, uint32_t* __restrict__ stamp,
+                                                                const OwnedState* __restrict__ st) {
+  const uint32_t g = blockIdx.x * WAVES_PER_BLOCK + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  const uint32_t ngroups = (ns + WAVE - 1) / WAVE;
+  if (g >= ngroups || st->overflow != 0u) return;  // (after an overflow every group was served in every launch)
+  const uint32_t raw = stamp[g], have = raw & 0x7FFFFFFFu, want = st->epoch + 1u;
+  if (have >= want) return;
+  const uint32_t i = g * WAVE + lane;
+  if (i < ns) {
+    float4 p = have == 0u ? src0[i] : cur[i];
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) own_replay(st, have, want, order, p);
+    cur[i] = p;
+  }
+  __builtin_amdgcn_wave_barrier();  // every lane has read the stamp before lane 0 replaces it
+  if (lane == 0) stamp[g] = want | (raw & 0x80000000u);
+}
+
 __global__ __launch_bounds__(BLOCK) void icp_own_scatter_kernel(const uint32_t* __restrict__ flags,
                                                                 const uint32_t* __restrict__ prefix, uint32_t ngroups,
                                                                 uint32_t* __restrict__ list) {
@@ -1946,6 +1967,17 @@ static pclhip_status ensure_owned_groups(pclhip_icp* icp) {
   if (ngroups)
     hipLaunchKernelGGL(icp_group_box_kernel, dim3((ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK), 0, ctx->stream,
                        icp->src_sorted0, icp->n, icp->own_gbox);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  return PCLHIP_OK;
+}
+
+pclhip_status owned_groups_catch_up(pclhip_icp* icp, int mode) {
+  if (icp->own_block == nullptr || icp->region.on == 0 || icp->n == 0) return PCLHIP_OK;
+  pclhip_ctx* ctx = icp->ctx;
+  const uint32_t ngroups = (icp->n + WAVE - 1) / WAVE;
+  hipLaunchKernelGGL(icp_own_catchup_kernel, dim3((ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK), 0, ctx->stream,
+                     icp->src_cur, icp->src_sorted0, icp->n, mode == PCLHIP_ICP_POINT_TO_POINT ? 0 : 1, icp->own_stamp,
+                     icp->own_state);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   return PCLHIP_OK;
 }

@@ -43,6 +43,13 @@ for name, region in regions.items():
         res[key + "_T"] = icp.getFinalTransformation().copy()
         res[key + "_iterations"] = icp.nr_iterations_
         res[key + "_q"], res[key + "_m"], res[key + "_d"] = q, m, d
+        # a host-driven iteration on top of the finished alignment: it moves the WHOLE working cloud, also the groups the
+        # loop's last launches did not serve
+        nudge = np.eye(4, dtype=np.float32)
+        nudge[0, 3] = -0.03
+        icp.iterate(nudge, max_dist=0.1)
+        q, m, d = icp.fetchCorrespondences()
+        res[key + "_q3"], res[key + "_m3"], res[key + "_d3"] = q, m, d
         steps = icp.runSteps(15)   # whole alignments back to back (from the identity): restarts inside the queue
         res[key + "_counts"] = np.asarray([s["num_correspondences"] for s in steps], np.float64)
         res[key + "_mse"] = np.asarray([s["mse"] for s in steps], np.float64)

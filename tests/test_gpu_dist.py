@@ -202,9 +202,9 @@ def test_served_group_lists_equal_the_full_pass(tmp_path):
     a, b = outs
     assert sorted(a.files) == sorted(b.files)
     for k in a.files:
-        if k.endswith(("_q", "_m", "_q2", "_m2", "_its", "_counts", "_iterations")):
+        if k.endswith(("_q", "_m", "_q2", "_m2", "_q3", "_m3", "_its", "_counts", "_iterations")):
             assert np.array_equal(a[k], b[k]), k
-        elif k.endswith(("_d", "_d2")):
+        elif k.endswith(("_d", "_d2", "_d3")):
             assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
         elif k.endswith("_T"):
             assert np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() < 2e-6, k
