@@ -128,3 +128,43 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
         # getFitnessScore under sharding: the owned points' (sum, count) all-reduced -> the single-index score
         assert all(int(r_["fitness_points"]) == int(one["fitness_points"]) for r_ in ranks)
         assert all(abs(float(r_["fitness"]) - float(one["fitness"])) <= 1e-9 * float(one["fitness"]) for r_ in ranks)
+
+
+def test_served_groups_when_an_alignment_outlasts_the_history(tmp_path):
+    """The served-group lists of the sharded device loop remember the transforms of at most OWN_HIST_CAP launches (128);
+    past that every group is served in every launch.  A build with a cap of 3 runs 12-iteration alignments through that
+    path: served lists, matches, float distances and step records equal the full pass's (PCLHIP_OWNED_GROUPS=0)."""
+    import numpy as np
+    if not os.path.exists(CLANG) or shutil.which("make") is None:
+        pytest.skip("needs the ROCm clang++ and make")
+    build = tmp_path / "ws_cap3"
+    build.mkdir()
+    mk = open(os.path.join(WS, "Makefile")).read()
+    mk = mk.replace("SRC = ../../pcl_amd/csrc", "SRC = %s" % os.path.join(ROOT, "pcl_amd", "csrc"))
+    mk = mk.replace("-I../../include", "-I" + os.path.join(ROOT, "include")).replace("../../include/pclhip.h", os.path.join(ROOT, "include", "pclhip.h"))
+    (build / "Makefile").write_text(mk)
+    for f in ("wavesim.hpp", "wavesim_rt.cpp"):
+        shutil.copy(os.path.join(WS, f), str(build / f))
+    r = subprocess.run(["make", "-C", str(build), "-j", str(min(16, os.cpu_count() or 1)), "EXTRA=-DPCLHIP_OWN_HIST_CAP=3"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lib = str(build / "libpclhip_wavesim.so")
+    worker = os.path.join(ROOT, "tests", "owned_groups_worker.py")
+    outs = []
+    for owned in ("1", "0"):
+        out = str(tmp_path / ("owned%s.npz" % owned))
+        env = dict(os.environ, PCLHIP_LIB=lib, PCLHIP_ALLOW_WAVESIM="1", PCLHIP_OWNED_GROUPS=owned)
+        r = subprocess.run([sys.executable, worker, out, "60000"], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert int(a["strip_point_iterations"]) == 12          # four times the history
+    for k in a.files:
+        if k.endswith("_T"):
+            assert np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() < 2e-6, k
+        elif k.endswith("_mse"):
+            assert np.allclose(a[k], b[k], rtol=1e-9, atol=1e-18), k
+        elif a[k].dtype == np.float32:
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+        else:
+            assert np.array_equal(a[k], b[k]), k
