@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--points", type=int, default=0, help="override the config's points per cloud (per GPU)")
     ap.add_argument("--knn", type=int, default=8, help="k of NormalEstimation")
     ap.add_argument("--replicated", action="store_true", help="config 5: replicate the target instead of sharding it")
+    ap.add_argument("--virtual-world", type=int, default=0,
+                    help="config 5 on ONE GPU: play rank --virtual-rank of this many ranks (its kd slab + halo, its region "
+                         "mask, no collective): what one rank of a G-GPU job does per iteration, measurable without the node")
+    ap.add_argument("--virtual-rank", type=int, default=0)
     ap.add_argument("--rejectors", default="", help="comma list of median,trimmed,one_to_one,distance: the rejector chain "
                                                      "inside the device-driven loop (configs 2/3)")
     ap.add_argument("--reciprocal", action="store_true", help="reciprocal correspondences inside the device-driven loop")

@@ -6,6 +6,7 @@ ncclAllReduce of the 32-double record.  `--replicated` runs the comparison point
 indexed on every rank, the source cut into slabs.  Either way the job registers the same two clouds, so `value`
 (correspondences of the whole job per second) is comparable; the run is strong scaling in the number of GPUs.
 """
+import os
 import time
 
 import numpy as np
@@ -45,7 +46,12 @@ def run_config5(args, ctx, comm, rank, local_rank, world, fence):
     else:
         src_h = synth.apply_rigid(T_inv, synth.gaussian_surface(n, synth.SOURCE_SEED))
         t1 = time.perf_counter()
-        st = ShardedTarget(ctx, tgt_h, rank, world, max_dist, k_normals=args.knn, viewpoint=(0, 0, 10))
+        # --virtual-world G --virtual-rank r on one GPU: this process plays rank r of G (slab, halo and region of that
+        # rank; the record is not exchanged, so the alignment is the one of the points this rank serves -- what is
+        # measured is a rank's work per iteration, e.g. with and without the served-group lists, PCLHIP_OWNED_GROUPS=0)
+        vworld = args.virtual_world if (args.virtual_world > 1 and world == 1) else 0
+        st = ShardedTarget(ctx, tgt_h, args.virtual_rank if vworld else rank, vworld or world, max_dist, k_normals=args.knn,
+                           viewpoint=(0, 0, 10))
         tree, region = st.tree, st.region
         from pcl_amd.dist import select_region
         owned_points = int(len(select_region(tgt_h, st.region, 0.0)))
@@ -109,7 +115,10 @@ def run_config5(args, ctx, comm, rank, local_rank, world, fence):
                                "ICP, max_dist %.2f; %s" %
                                (n, args.knn, max_dist,
                                 "target replicated, source cut into %d slabs" % world if args.replicated else
-                                "target cut into %d kd slabs + halo, source replicated and routed by current position" % world),
+                                "target cut into %d kd slabs + halo, source replicated and routed by current position%s" %
+                                (getattr(args, "virtual_world", 0) if (getattr(args, "virtual_world", 0) > 1 and world == 1) else world,
+                                 "; ONE GPU playing rank %d of that job, no collective" % args.virtual_rank
+                                 if (getattr(args, "virtual_world", 0) > 1 and world == 1) else "")),
                    "target_points": n, "source_points": n,
                    "parallelism": ("source slabs x%d" if args.replicated else "target kd slabs + halo x%d") % world +
                                   ", ncclAllReduce of the 32-double record per iteration"},
@@ -121,6 +130,10 @@ def run_config5(args, ctx, comm, rank, local_rank, world, fence):
         "per_step": [{"iteration": s["iteration"], "search_ms": round(s["search_ms"], 4), "step_ms": round(s["step_ms"], 4),
                       "ended": s["alignment_ended"], "state": s["state"]} for s in steps],
         "setup": dict(setup, synth_gen_s=round(gen_s, 1)),
+        "virtual_rank": ({"world": args.virtual_world, "rank": args.virtual_rank,
+                          "served_groups_lists": os.environ.get("PCLHIP_OWNED_GROUPS", "1") != "0",
+                          "note": "value / ms_per_step are ONE rank's share of the job; not a multi-GPU measurement"}
+                         if (args.virtual_world > 1 and world == 1) else None),
         "self_check": {"rccl_nranks": world if comm is not None else 1, "native_communicator": comm is not None,
                        "served_sum_equals_allreduced_count": True, "allreduced_count_last_step": last_count,
                        "per_rank": gathered},

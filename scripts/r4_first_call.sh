@@ -29,3 +29,11 @@ for v in run3 run6; do
   [ -f $L ] && { echo "== $v" >> $OUT/run_ab.log; PCLHIP_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-host-align >> $OUT/run_ab.log 2>&1; }
 done
 [ -f $OUT/run_ab.log ] && cat $OUT/run_ab.log
+# 5. the served-group lists of the sharded mode, on one GPU: rank 3 of 8 of a 30M-point job with the
+#    lists and with the full pass -- per-iteration time of ONE rank (bench.py --config 5 --virtual-world)
+for og in 1 0; do
+  echo "== PCLHIP_OWNED_GROUPS=$og" >> $OUT/virtual_rank.log
+  PCLHIP_OWNED_GROUPS=$og timeout 600 python bench.py --config 5 --points 30000000 --virtual-world 8 --virtual-rank 3 \
+    --steps 20 --warmup 5 >> $OUT/virtual_rank.log 2>&1
+done
+cat $OUT/virtual_rank.log
