@@ -975,6 +975,9 @@ static void icp_free_source(pclhip_icp* icp) {
   icp->src_records_n = 0;
   if (icp->own_block) (void)dev_free(icp->ctx, icp->own_block);
   icp->own_block = nullptr;
+  if (icp->grec_block) (void)dev_free(icp->ctx, icp->grec_block);
+  icp->grec_block = nullptr;
+  icp->grec_groups = 0;
   icp->own_groups = 0;
   if (icp->src_sorted0) (void)dev_free(icp->ctx, icp->src_sorted0);
   if (icp->src_cur) (void)dev_free(icp->ctx, icp->src_cur);

@@ -285,6 +285,9 @@ struct pclhip_icp {
   uint32_t* own_tot = nullptr;           // [4] tot[0] = served groups
   uint2* own_partial = nullptr;          // scan scratch
   pclhip::OwnedState* own_state = nullptr;
+  // leaf lists of the source's groups kept across seeded iterations (search.hip, -DPCLHIP_GROUP_LISTS=1 builds only)
+  void* grec_block = nullptr;
+  uint32_t grec_groups = 0;
 };
 
 namespace pclhip {

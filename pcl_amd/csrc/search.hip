@@ -924,6 +924,21 @@ __device__ __forceinline__ bool in_region(const RegionBox& r, float x, float y, 
 // no policy of the ICP search kernels stages the w chunks: 3 KB of staging per wave (see WaveLdsT)
 typedef WaveLdsT<3072> IcpWaveLds;
 
+// -DPCLHIP_GROUP_LISTS=1: the seeded ICP search keeps every group's leaf list across iterations (traverse.hpp: GroupRec) and
+// searches from it while the group's motion allows.  Off by default: exact (tests run it on the CPU emulation), not yet timed.
+#ifndef PCLHIP_GROUP_LISTS
+#define PCLHIP_GROUP_LISTS 0
+#endif
+struct GroupRecArrays {
+  uint32_t* ids;  // [groups][GREC_CAP]
+  float4* hdr;    // [groups][2]
+};
+#if PCLHIP_GROUP_LISTS
+#define PCLHIP_GREC_ARG(x) , x
+#else
+#define PCLHIP_GREC_ARG(x)
+#endif
+
 // OWNED (target sharding in the device-driven loop, pclhip_internal.hpp: OwnedGroups): the groups come from the launch's list
 // of served groups, and a group whose working copy missed some launches is brought up to date first.
 struct NoOwnedGroups {};
@@ -945,8 +960,9 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
                                                 float bound, int flags, uint32_t* __restrict__ match_pos,
                                                 uint32_t* __restrict__ match, float* __restrict__ match_d2,
                                                 unsigned long long* gstats, IcpWaveLds* wl_s, Box* topbox_s,
-                                                const OG& og = OG()) {
+                                                const OG& og = OG(), GroupRecArrays ga = {nullptr, nullptr}) {
   static_assert(!OWNED || Q == 1, "served-group lists are per 64-point group");
+  static_assert(!PCLHIP_GROUP_LISTS || Q == 1, "leaf lists are kept per 64-query group");
   bool restart = false;
   if (ctl != nullptr) {
     if (ctl->stop != 0) return;  // the alignment ended before this (speculatively queued) launch
@@ -1075,6 +1091,21 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
     if ((flags & 2) && hm != 0) start_leaf = uint32_t(__builtin_amdgcn_readlane(int(seed_pos[0]), __builtin_ctzll(hm))) / LEAF;
     // no lane has a seed: the first iteration of an alignment, queries stand off the target -> disc bounds
     ICP_LAP(5);
+#if PCLHIP_GROUP_LISTS
+    if (ga.ids != nullptr) {
+      GroupRec gr;
+      gr.ids = ga.ids + size_t(gcur) * GREC_CAP;
+      gr.hdr = ga.hdr + 2 * size_t(gcur);
+      bool from_record = false;
+      if (!restart) from_record = traverse_recorded(ix, qx, qy, qz, valid, fast, wl_s[wave], ts, gr);
+      if (!from_record) {
+        traverse<NN1MinT<Q>, SPARSE, IcpWaveLds, GroupRec>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, start_leaf,
+                                                             hm == 0, &gr);
+        if (__builtin_amdgcn_ballot_w64(valid[0]) != 0)
+          gr.store(wave_max_f(valid[0] ? fast.worst(0) : 0.0f), __builtin_inff());
+      }
+    } else
+#endif
     traverse<NN1MinT<Q>, SPARSE>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, start_leaf, hm == 0);
     ICP_LAP(6);
     fast.resolve(ix, qx, qy, qz);
@@ -1265,11 +1296,20 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
                                                                  uint32_t* __restrict__ match_pos,
                                                                  uint32_t* __restrict__ match,
                                                                  float* __restrict__ match_d2,
-                                                                 unsigned long long* gstats) {
+                                                                 unsigned long long* gstats
+#if PCLHIP_GROUP_LISTS
+                                                                 , GroupRecArrays ga
+#endif
+                                                                 ) {
   __shared__ IcpWaveLds wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
+#if PCLHIP_GROUP_LISTS
+  icp_search_body<Q, SPARSE>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
+                             topbox_s, NoOwnedGroups(), ga);
+#else
   icp_search_body<Q, SPARSE>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
                              topbox_s);
+#endif
 }
 
 #ifndef PCLHIP_COLD_MINW
@@ -1288,15 +1328,24 @@ __global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_cold_search_kerne
 __global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_search_dual_kernel(
     IndexView ix, float4* __restrict__ cur, const float4* __restrict__ src0, uint32_t ns, Mat34 T,
     const IcpControl* __restrict__ ctl, RegionBox region, int order, float bound, int flags, float so_from,
-    uint32_t* __restrict__ match_pos, uint32_t* __restrict__ match, float* __restrict__ match_d2, unsigned long long* gstats) {
+    uint32_t* __restrict__ match_pos, uint32_t* __restrict__ match, float* __restrict__ match_d2, unsigned long long* gstats
+#if PCLHIP_GROUP_LISTS
+    , GroupRecArrays ga
+#endif
+    ) {
   __shared__ IcpWaveLds wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
   if (ctl->restart != 0)
     icp_cold_search_body(ix, cur, src0, ns, T, ctl, region, order, bound, flags, so_from, match_pos, match, match_d2, gstats,
                          wl_s, topbox_s);
   else
+#if PCLHIP_GROUP_LISTS
+    icp_search_body<1, true>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
+                             topbox_s, NoOwnedGroups(), ga);
+#else
     icp_search_body<1, true>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
                              topbox_s);
+#endif
 }
 
 // The same two bodies over the launch's list of SERVED groups (target sharding in the device-driven loop): `standoff`
@@ -2054,6 +2103,24 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
       og.stamp = icp->own_stamp;
       og.state = icp->own_state;
     }
+#if PCLHIP_GROUP_LISTS
+    GroupRecArrays grec = {nullptr, nullptr};
+    if (!owned) {  // (the served-group lists of the sharded mode keep the plain search)
+      if (icp->grec_block == nullptr || icp->grec_groups != ngroups) {
+        if (icp->grec_block) dev_free(ctx, icp->grec_block);
+        icp->grec_block = nullptr;
+        const size_t hdr_bytes = size_t(ngroups ? ngroups : 1) * 2 * sizeof(float4);
+        const size_t bytes = hdr_bytes + size_t(ngroups ? ngroups : 1) * GREC_CAP * sizeof(uint32_t);
+        char* base = nullptr;
+        PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &base, bytes));
+        PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(base, 0, bytes, s));  // count 0: no record yet
+        icp->grec_block = base;
+        icp->grec_groups = ngroups;
+      }
+      grec.hdr = reinterpret_cast<float4*>(icp->grec_block);
+      grec.ids = reinterpret_cast<uint32_t*>(static_cast<char*>(icp->grec_block) + size_t(ngroups ? ngroups : 1) * 2 * sizeof(float4));
+    }
+#endif
     (void)hipEventRecord(device_loop ? ev[0] : icp->ev0, s);
     if (owned) {
       hipLaunchKernelGGL(icp_own_epoch_kernel, dim3(1), dim3(1), 0, s, ctl, icp->own_state);
@@ -2070,7 +2137,8 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     } else if (standoff && device_loop) {
       const int gd = resident_blocks(ctx, icp_search_dual_kernel, ngroups);
       PCLHIP_LAUNCH_FED(ctx, icp_search_dual_kernel, dim3(gd), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl,
-                         icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+                         icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2,
+                         ctx->stats PCLHIP_GREC_ARG(grec));
     } else if (cold) {
       const int gc = resident_blocks(ctx, icp_cold_search_kernel, ngroups);
       PCLHIP_LAUNCH_FED(ctx, icp_cold_search_kernel, dim3(gc), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M,
@@ -2078,7 +2146,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
                          ctx->stats);
     } else {
       PCLHIP_LAUNCH_FED(ctx, ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl, icp->region,
-                         order, bound, kflags, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+                         order, bound, kflags, icp->match_pos, icp->match, icp->match_d2, ctx->stats PCLHIP_GREC_ARG(grec));
     }
     (void)hipEventRecord(device_loop ? ev[1] : icp->ev_mid, s);
     icp->mid_recorded = true;
@@ -2217,7 +2285,7 @@ pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double ma
   // exactly one owner), against its slab + halo index; the (sum, count) pairs are summed over the ranks below
   PCLHIP_LAUNCH_FED(ctx, (icp_search_kernel<4, 1, true>), dim3(gs), dim3(BLOCK), 0, s, v, cur, static_cast<const float4*>(cur), n,
                      M, static_cast<const IcpControl*>(nullptr), icp->region, 1, __builtin_inff(), 0, pos, id, d2,
-                     ctx->stats);
+                     ctx->stats PCLHIP_GREC_ARG((GroupRecArrays{nullptr, nullptr})));
   hipLaunchKernelGGL(fitness_partial_kernel, dim3(gr), dim3(BLOCK), 0, s, d2, n, max_range, part);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   std::vector<double> h(size_t(gr) * 2);

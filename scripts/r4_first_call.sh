@@ -37,3 +37,16 @@ for og in 1 0; do
     --steps 20 --warmup 5 >> $OUT/virtual_rank.log 2>&1
 done
 cat $OUT/virtual_rank.log
+# 6. group leaf lists across seeded iterations (-DPCLHIP_GROUP_LISTS=1, traverse.hpp: GroupRec; exact on the emulation, 100 %
+#    of the converged groups searched from their record, node scans 2.8 -> 0, rounds 4.2 -> 3.2 per group): build the
+#    variant BEFORE the call (scripts/build_variant.sh grec "-DPCLHIP_GROUP_LISTS=1"; also grec125 with
+#    "-DPCLHIP_GROUP_LISTS=1 -DPCLHIP_GREC_GROW=1.25f"), then A/B against the default and check it against the oracle
+for v in grec grec125; do
+  L=pcl_amd/variants/libpclhip_$v.so
+  [ -f $L ] || continue
+  echo "== $v" >> $OUT/grec_ab.log
+  PCLHIP_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-host-align >> $OUT/grec_ab.log 2>&1
+  PCLHIP_LIB=$L timeout 300 python tests/wavesim/group_lists_probe.py 2000000 2>&1 | tail -3 >> $OUT/grec_ab.log
+  PCLHIP_LIB=$L timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_loop.py tests/test_gpu_fuzz.py -m gpu -q -x 2>&1 | tail -2 >> $OUT/grec_ab.log
+done
+[ -f $OUT/grec_ab.log ] && cat $OUT/grec_ab.log

@@ -168,3 +168,39 @@ def test_served_groups_when_an_alignment_outlasts_the_history(tmp_path):
             assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
         else:
             assert np.array_equal(a[k], b[k]), k
+
+
+def test_group_leaf_lists_variant_is_exact_and_used(tmp_path):
+    """-DPCLHIP_GROUP_LISTS=1 (off by default until it has been timed on the GPU): the seeded ICP search keeps every group's
+    leaf list across iterations and searches from it while the group's motion allows (traverse.hpp: GroupRec).  A build of
+    the emulation with it: eight iterations bit for bit the oracle's, converged iterations searched from the records with
+    no node scan at all, and the ICP parity tests of the GPU tier on that build."""
+    if not os.path.exists(CLANG) or shutil.which("make") is None:
+        pytest.skip("needs the ROCm clang++ and make")
+    build = tmp_path / "ws_grec"
+    build.mkdir()
+    mk = open(os.path.join(WS, "Makefile")).read()
+    mk = mk.replace("SRC = ../../pcl_amd/csrc", "SRC = %s" % os.path.join(ROOT, "pcl_amd", "csrc"))
+    mk = mk.replace("-I../../include", "-I" + os.path.join(ROOT, "include")).replace("../../include/pclhip.h", os.path.join(ROOT, "include", "pclhip.h"))
+    (build / "Makefile").write_text(mk)
+    for f in ("wavesim.hpp", "wavesim_rt.cpp"):
+        shutil.copy(os.path.join(WS, f), str(build / f))
+    r = subprocess.run(["make", "-C", str(build), "-j", str(min(16, os.cpu_count() or 1)), "EXTRA=-DPCLHIP_GROUP_LISTS=1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lib = str(build / "libpclhip_wavesim.so")
+    env = dict(os.environ, PCLHIP_LIB=lib, PCLHIP_ALLOW_WAVESIM="1")
+    r = subprocess.run([sys.executable, os.path.join(WS, "group_lists_probe.py"), "200000"], env=env, capture_output=True,
+                       text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    last = [ln for ln in r.stdout.splitlines() if ln.startswith("GROUP_LISTS")][-1]
+    vals = dict(kv.split("=") for kv in last.split()[1:])
+    print(r.stdout[-1200:])
+    assert int(vals["mismatches"]) == 0
+    assert float(vals["from_record"]) > 0.9 and float(vals["nodes"]) < 0.3
+    files, keyword = ["test_gpu_fuzz.py"], NOT_HERE      # unseeded + seeded correspondences of random / degenerate clouds
+    if os.environ.get("WAVESIM_FULL") == "1":             # every ICP-related parity test of the GPU tier (~45 s more)
+        files = ["test_gpu_parity.py", "test_gpu_loop.py", "test_gpu_fuzz.py"]
+        keyword = "(icp or rejector or reciprocal or fuzz or fitness) and " + NOT_HERE + " and " + SLOW
+    out = run_gpu_tests_on_the_emulation(lib, files, keyword)
+    print([ln for ln in out.splitlines() if " passed" in ln][-1])
