@@ -196,7 +196,7 @@ def test_served_group_lists_equal_the_full_pass(tmp_path):
     for owned in ("1", "0"):
         out = str(tmp_path / ("owned%s.npz" % owned))
         env = dict(os.environ, PCLHIP_OWNED_GROUPS=owned)
-        r = subprocess.run([sys.executable, worker, out, "150000"], env=env, capture_output=True, text=True, timeout=1200)
+        r = subprocess.run([sys.executable, worker, out, "90000"], env=env, capture_output=True, text=True, timeout=1200)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(np.load(out))
     a, b = outs
@@ -211,6 +211,6 @@ def test_served_group_lists_equal_the_full_pass(tmp_path):
         elif k.endswith("_mse"):
             assert np.allclose(a[k], b[k], rtol=1e-9, atol=1e-18), k
     # the scenario does what it is for: regions that serve a part of the cloud, and a cloud that moves through them
-    assert 0 < len(a["strip_plane_q"]) < 150000 // 4 and 0 < len(a["corner_plane_q"]) < 150000 // 4
-    assert len(a["all_plane_q"]) == 150000
+    assert 0 < len(a["strip_plane_q"]) < 90000 // 4 and 0 < len(a["corner_plane_q"]) < 90000 // 4
+    assert len(a["all_plane_q"]) == 90000
     assert a["strip_plane_counts"][0] != a["strip_plane_counts"][2] and a["corner_point_counts"][0] != a["corner_point_counts"][5]

@@ -41,6 +41,26 @@ def wavesim_lib():
     return lib
 
 
+@pytest.fixture(scope="module")
+def variant_lib(tmp_path_factory):
+    """ONE more build of the emulation for the tests of compile-time variants: the served-group history capped at 3
+    (-DPCLHIP_OWN_HIST_CAP=3) and the group leaf lists (-DPCLHIP_GROUP_LISTS=1; they stay out of the sharded search, so the
+    two do not meet)."""
+    if not os.path.exists(CLANG) or shutil.which("make") is None:
+        pytest.skip("needs the ROCm clang++ and make")
+    build = tmp_path_factory.mktemp("ws_variant")
+    mk = open(os.path.join(WS, "Makefile")).read()
+    mk = mk.replace("SRC = ../../pcl_amd/csrc", "SRC = %s" % os.path.join(ROOT, "pcl_amd", "csrc"))
+    mk = mk.replace("-I../../include", "-I" + os.path.join(ROOT, "include")).replace("../../include/pclhip.h", os.path.join(ROOT, "include", "pclhip.h"))
+    (build / "Makefile").write_text(mk)
+    for f in ("wavesim.hpp", "wavesim_rt.cpp"):
+        shutil.copy(os.path.join(WS, f), str(build / f))
+    r = subprocess.run(["make", "-C", str(build), "-j", str(min(16, os.cpu_count() or 1)),
+                        "EXTRA=-DPCLHIP_OWN_HIST_CAP=3 -DPCLHIP_GROUP_LISTS=1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return str(build / "libpclhip_wavesim.so")
+
+
 def run_gpu_tests_on_the_emulation(lib, files, keyword, timeout=1500):
     env = dict(os.environ, PCLHIP_LIB=lib, PCLHIP_ALLOW_WAVESIM="1")
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k", keyword] + \
@@ -130,25 +150,12 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
         assert all(abs(float(r_["fitness"]) - float(one["fitness"])) <= 1e-9 * float(one["fitness"]) for r_ in ranks)
 
 
-def test_served_groups_when_an_alignment_outlasts_the_history(tmp_path):
+def test_served_groups_when_an_alignment_outlasts_the_history(variant_lib, tmp_path):
     """The served-group lists of the sharded device loop remember the transforms of at most OWN_HIST_CAP launches (128);
     past that every group is served in every launch.  A build with a cap of 3 runs 12-iteration alignments through that
     path: served lists, matches, float distances and step records equal the full pass's (PCLHIP_OWNED_GROUPS=0)."""
     import numpy as np
-    if not os.path.exists(CLANG) or shutil.which("make") is None:
-        pytest.skip("needs the ROCm clang++ and make")
-    build = tmp_path / "ws_cap3"
-    build.mkdir()
-    mk = open(os.path.join(WS, "Makefile")).read()
-    mk = mk.replace("SRC = ../../pcl_amd/csrc", "SRC = %s" % os.path.join(ROOT, "pcl_amd", "csrc"))
-    mk = mk.replace("-I../../include", "-I" + os.path.join(ROOT, "include")).replace("../../include/pclhip.h", os.path.join(ROOT, "include", "pclhip.h"))
-    (build / "Makefile").write_text(mk)
-    for f in ("wavesim.hpp", "wavesim_rt.cpp"):
-        shutil.copy(os.path.join(WS, f), str(build / f))
-    r = subprocess.run(["make", "-C", str(build), "-j", str(min(16, os.cpu_count() or 1)), "EXTRA=-DPCLHIP_OWN_HIST_CAP=3"],
-                       capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lib = str(build / "libpclhip_wavesim.so")
+    lib = variant_lib
     worker = os.path.join(ROOT, "tests", "owned_groups_worker.py")
     outs = []
     for owned in ("1", "0"):
@@ -170,25 +177,12 @@ def test_served_groups_when_an_alignment_outlasts_the_history(tmp_path):
             assert np.array_equal(a[k], b[k]), k
 
 
-def test_group_leaf_lists_variant_is_exact_and_used(tmp_path):
+def test_group_leaf_lists_variant_is_exact_and_used(variant_lib):
     """-DPCLHIP_GROUP_LISTS=1 (off by default until it has been timed on the GPU): the seeded ICP search keeps every group's
     leaf list across iterations and searches from it while the group's motion allows (traverse.hpp: GroupRec).  A build of
     the emulation with it: eight iterations bit for bit the oracle's, converged iterations searched from the records with
-    no node scan at all, and the ICP parity tests of the GPU tier on that build."""
-    if not os.path.exists(CLANG) or shutil.which("make") is None:
-        pytest.skip("needs the ROCm clang++ and make")
-    build = tmp_path / "ws_grec"
-    build.mkdir()
-    mk = open(os.path.join(WS, "Makefile")).read()
-    mk = mk.replace("SRC = ../../pcl_amd/csrc", "SRC = %s" % os.path.join(ROOT, "pcl_amd", "csrc"))
-    mk = mk.replace("-I../../include", "-I" + os.path.join(ROOT, "include")).replace("../../include/pclhip.h", os.path.join(ROOT, "include", "pclhip.h"))
-    (build / "Makefile").write_text(mk)
-    for f in ("wavesim.hpp", "wavesim_rt.cpp"):
-        shutil.copy(os.path.join(WS, f), str(build / f))
-    r = subprocess.run(["make", "-C", str(build), "-j", str(min(16, os.cpu_count() or 1)), "EXTRA=-DPCLHIP_GROUP_LISTS=1"],
-                       capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lib = str(build / "libpclhip_wavesim.so")
+    no node scan at all, and the fuzz slices of the GPU tier (all ICP parity tests with WAVESIM_FULL=1) on that build."""
+    lib = variant_lib
     env = dict(os.environ, PCLHIP_LIB=lib, PCLHIP_ALLOW_WAVESIM="1")
     r = subprocess.run([sys.executable, os.path.join(WS, "group_lists_probe.py"), "200000"], env=env, capture_output=True,
                        text=True, timeout=900, cwd=ROOT)
