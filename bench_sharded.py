@@ -131,7 +131,7 @@ def run_config5(args, ctx, comm, rank, local_rank, world, fence):
                       "ended": s["alignment_ended"], "state": s["state"]} for s in steps],
         "setup": dict(setup, synth_gen_s=round(gen_s, 1)),
         "virtual_rank": ({"world": args.virtual_world, "rank": args.virtual_rank,
-                          "served_groups_lists": os.environ.get("PCLHIP_OWNED_GROUPS", "1") != "0",
+                          "served_groups_lists": os.environ.get("PCLHIP_OWNED_GROUPS", "0") == "1",
                           "note": "value / ms_per_step are ONE rank's share of the job; not a multi-GPU measurement"}
                          if (args.virtual_world > 1 and world == 1) else None),
         "self_check": {"rccl_nranks": world if comm is not None else 1, "native_communicator": comm is not None,

@@ -383,9 +383,11 @@ PCLHIP_API pclhip_status pclhip_select_region(const void* points, size_t stride_
 /* the slab whose region holds the point (x >= lo && x < hi per axis), -1 for non-finite points */
 PCLHIP_API int pclhip_region_owner(const float* regions, int n_slabs, const float xyz[3]);
 /* restrict the registration to the source points whose current position lies in `region`; NULL: all points.  Inside
- * pclhip_icp_align / pclhip_icp_run_steps the rank then WALKS only the 64-point groups of its (kd-ordered) source copy
+ * pclhip_icp_align / pclhip_icp_run_steps the rank can WALK only the 64-point groups of its (kd-ordered) source copy
  * whose box touches the region -- about n / n_slabs points per iteration, not n; groups that come into reach later are
- * brought up to date from the transforms they missed, bit for bit (PCLHIP_OWNED_GROUPS=0: the full pass, for A/B) */
+ * brought up to date from the transforms they missed, bit for bit.  Opt-in (environment PCLHIP_OWNED_GROUPS=1) until its
+ * first run on hardware: written and checked on the CPU emulation of the test tier after round 3's GPU budget was spent;
+ * the default walks the whole source copy and masks per point */
 PCLHIP_API pclhip_status pclhip_icp_set_region(pclhip_icp* icp, const float region[6]);
 /* Largest squared distance to the k-th nearest neighbour (the point itself counts as the first, as in
  * pclhip_normals) over the indexed points inside `box` (lo.xyz, hi.xyz; NULL: all).  With a halo index this

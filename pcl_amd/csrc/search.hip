@@ -1965,12 +1965,14 @@ static int search_skip_flag() {
   return skip;
 }
 
-// PCLHIP_OWNED_GROUPS=0: under target sharding every rank walks the whole source again (the form the lists replaced; A/B
-// and the tests that compare the two)
+// PCLHIP_OWNED_GROUPS=1: under target sharding the device-driven loop walks the served groups only (below).  Written at the
+// end of round 3 with the round's GPU budget spent: exact on the CPU emulation of the test tier (tests/wavesim), never yet
+// run on hardware -- so it is opt-in until round 4's first GPU call has run its test there (scripts/r4_first_call.sh); the
+// default is the full pass every hardware test has seen.
 static bool owned_groups_enabled() {
   static const bool on = [] {
     const char* e = getenv("PCLHIP_OWNED_GROUPS");
-    return !(e && atoi(e) == 0);
+    return e && atoi(e) == 1;
   }();
   return on;
 }

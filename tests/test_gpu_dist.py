@@ -191,6 +191,10 @@ def test_served_group_lists_equal_the_full_pass(tmp_path):
     # pass's bit for bit --, the step records the same counts and iterations, the 4x4 equal up to the summation order.
     import subprocess
     import sys
+    if os.environ.get("PCLHIP_ALLOW_WAVESIM") != "1" and os.environ.get("PCLHIP_HW_VALIDATE") != "1":
+        pytest.skip("the served-group lists (PCLHIP_OWNED_GROUPS=1, opt-in) were written with round 3's GPU budget spent: this "
+                    "test runs on the CPU emulation (tests/test_wavesim.py); its first hardware run is round 4's first GPU "
+                    "call (PCLHIP_HW_VALIDATE=1, scripts/r4_first_call.sh)")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "owned_groups_worker.py")
     outs = []
     for owned in ("1", "0"):

@@ -114,7 +114,8 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
     import numpy as np
     n = 60_000
     work = str(tmp_path)
-    env = dict(os.environ, PCLHIP_LIB=wavesim_lib, PCLHIP_ALLOW_WAVESIM="1", WAVESIM_THREADS="8")
+    env = dict(os.environ, PCLHIP_LIB=wavesim_lib, PCLHIP_ALLOW_WAVESIM="1", WAVESIM_THREADS="8",
+               PCLHIP_OWNED_GROUPS="1")   # target mode: the ranks walk their served groups (opt-in until hardware has run it)
     worker = os.path.join(WS, "two_rank_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, mode, str(r), str(world), work, str(n)], env=env, cwd=ROOT,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
