@@ -1085,6 +1085,8 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
     // extent, e.g. the first ICP iterations): ascending distance to the group box, so the bounds
     // collapse after the first few leaves and everything farther is cut off at once.  Tight bounds
     // (seeded steady state): plain index order, no ranking work.
+    // (the factor counted on the emulation at 1M points, second launch of an alignment, per group: 4 -> 21.7 per-lane tests
+    // and 10.7 rounds, 8 -> 20.1 / 9.5, 16 -> 19.3 / 9.0, 64 -> 18.9 / 9.0, 1024 -> 18.9 / 9.0 but 7.2 rounds once converged)
     const bool ordered = T * 16.0f > gdiag2;
     // Leaves of a loose search are bounded by their discs (see point_disc_lb) once the queries stand off
     // farther than a few leaf sizes: closer in, a disc excludes nothing a box does not and costs twice the test.
