@@ -65,8 +65,20 @@ def knn_icp_round(ctx, orc, rng, sizes=(1, 2, 15, 16, 17, 63, 64, 65, 1000, 4096
         moved = icp.transformCloud(qry, T)
         oq2, om2, od2 = otree.correspondences(moved, max_dist=md if md is not None else big)
         ok2 = np.array_equal(q2, oq2) and np.array_equal(m2, om2) and np.array_equal(d2, od2)
-        msg += "  icp cold %s seeded %s" % ("ok" if ok1 else "MISMATCH", "ok" if ok2 else "MISMATCH")
-        ok = ok and ok1 and ok2
+        # three more iterations with shrinking motions, as a converging alignment makes them (builds that keep the groups'
+        # leaf lists across iterations -- traverse.hpp: GroupRec -- search from their records here)
+        ok3 = True
+        for step in (1e-4, 1e-5, 0.0):
+            T = np.eye(4, dtype=np.float32)
+            T[:3, 3] = (rng.normal(size=3) * step * scale).astype(np.float32)
+            icp.iterate(T, max_dist=md)
+            q3, m3, d3 = icp.fetchCorrespondences()
+            moved = icp.transformCloud(moved, T)
+            oq3, om3, od3 = otree.correspondences(moved, max_dist=md if md is not None else big)
+            ok3 = ok3 and np.array_equal(q3, oq3) and np.array_equal(m3, om3) and np.array_equal(d3, od3)
+        msg += "  icp cold %s seeded %s converging %s" % ("ok" if ok1 else "MISMATCH", "ok" if ok2 else "MISMATCH",
+                                                        "ok" if ok3 else "MISMATCH")
+        ok = ok and ok1 and ok2 and ok3
     return ok, msg
 
 
