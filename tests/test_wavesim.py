@@ -83,7 +83,8 @@ def test_product_loader_refuses_the_emulation(wavesim_lib):
 
 # left to the GPU tier (or to WAVESIM_FULL=1) only because of their run time on the emulation: 10-20 s each
 SLOW = ("not sharded_target_on_device and not run_steps_is_align_repeated and not device_loop_matches_host_loop_twin "
-        "and not sharded_bench_path and not radius_chunked_large and not 300001")
+        "and not sharded_bench_path and not radius_chunked_large and not 300001 and not 65553 and not surface_200k "
+        "and not random_global_transforms and not fused_single_kernel and not cpp_adapters_bunny and not c_example_registers")
 
 
 def test_gpu_parity_tests_run_on_the_emulation(wavesim_lib):
