@@ -1493,19 +1493,38 @@ __device__ __forceinline__ bool traverse_recorded(const IndexView& ix, const flo
   const uint64_t mask = __builtin_amdgcn_ballot_w64(alive);  // (also: every lane has read its id before any is rewritten)
   const uint32_t n_alive = uint32_t(__builtin_popcountll(mask));
   const uint32_t rank = uint32_t(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
+#ifndef PCLHIP_GREC_PACKED
+#define PCLHIP_GREC_PACKED 1  // per-lane box tests of the recorded list two leaves at a time on packed math (0: one at a time)
+#endif
+  float* const ids_f = wl.radii();  // ids of the ranked leaves (the radii of disc lists are not in use here)
   if (alive) {
     gr.ids[rank] = id;  // the next record: the part of this one that is still within reach
-    wl.list[LS * rank] = make_float4(lx, ly, lz, __uint_as_float(id));
-    wl.list[LS * rank + 1] = make_float4(hx, hy, hz, lbG);
+    if constexpr (PCLHIP_GREC_PACKED != 0 && LS == 3) {
+      // pair p = rank / 2 holds leaves 2p, 2p + 1 side by side: (lxA lxB lyA lyB) (lzA lzB hxA hxB) (hyA hyB hzA hzB)
+      float* const w = reinterpret_cast<float*>(&wl.list[3u * (rank >> 1)]) + (rank & 1u);
+      w[0] = lx; w[2] = ly; w[4] = lz; w[6] = hx; w[8] = hy; w[10] = hz;
+      if ((n_alive & 1u) != 0u && rank + 1u == n_alive) {  // an odd list: the missing half of the last pair excludes itself
+        const float far = 3.0e38f;
+        w[1] = far; w[3] = far; w[5] = far; w[7] = far; w[9] = far; w[11] = far;
+      }
+      ids_f[rank] = __uint_as_float(id);
+    } else {
+      wl.list[LS * rank] = make_float4(lx, ly, lz, __uint_as_float(id));
+      wl.list[LS * rank + 1] = make_float4(hx, hy, hz, lbG);
+    }
   }
   __builtin_amdgcn_wave_barrier();
+  const auto id_at = [&](uint32_t r) -> uint32_t {
+    if constexpr (PCLHIP_GREC_PACKED != 0 && LS == 3) return __float_as_uint(ids_f[r]);
+    else return __float_as_uint(wl.list[LS * r].w);
+  };
   const float before = valid[0] ? pol.worst(0) : 0.0f;
   for (uint32_t b0 = 0; b0 < n_alive; b0 += LEAF_BATCH) {
     const uint32_t nb = (n_alive - b0) < uint32_t(LEAF_BATCH) ? (n_alive - b0) : uint32_t(LEAF_BATCH);
     {  // LDS-DMA of the batch's candidate blocks, transposed (as traverse() stages them)
       const uint32_t slot = uint32_t(lane) & 15u;
       uint32_t leaf_id = 0;
-      if (slot < nb) leaf_id = __float_as_uint(wl.list[LS * (b0 + slot)].w);
+      if (slot < nb) leaf_id = id_at(b0 + slot);
 #pragma unroll
       for (int i = 0; i < NCHUNK / 4; ++i) {
         if (slot < nb) {
@@ -1517,10 +1536,30 @@ __device__ __forceinline__ bool traverse_recorded(const IndexView& ix, const flo
     }
     ts.c[1] += nb;
     uint32_t m16 = 0;
-    for (uint32_t t = 0; t < nb; ++t) {
-      const float4 ea = wl.list[LS * (b0 + t)], eb = wl.list[LS * (b0 + t) + 1];  // broadcast reads
-      const float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
-      m16 |= ((!(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w))) ? 1u : 0u) << t;
+    if constexpr (PCLHIP_GREC_PACKED != 0 && LS == 3) {
+      // two leaves per step: the operations of point_box_lb component by component on v_pk_add / v_pk_mul (same values)
+      const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]}, zero2 = {0.0f, 0.0f};
+      for (uint32_t t = 0; t < nb; t += 2u) {
+        const uint32_t pr = (b0 + t) >> 1;
+        const float4 e0 = wl.list[3u * pr], e1 = wl.list[3u * pr + 1u], e2 = wl.list[3u * pr + 2u];  // broadcast reads
+        const v2f lx2 = {e0.x, e0.y}, ly2 = {e0.z, e0.w}, lz2 = {e1.x, e1.y};
+        const v2f hx2 = {e1.z, e1.w}, hy2 = {e2.x, e2.y}, hz2 = {e2.z, e2.w};
+        const v2f gx = __builtin_elementwise_max(__builtin_elementwise_max(lx2 - qx2, qx2 - hx2), zero2);
+        const v2f gy = __builtin_elementwise_max(__builtin_elementwise_max(ly2 - qy2, qy2 - hy2), zero2);
+        const v2f gz = __builtin_elementwise_max(__builtin_elementwise_max(lz2 - qz2, qz2 - hz2), zero2);
+        v2f r = gx * gx;
+        r = r + gy * gy;
+        r = r + gz * gz;
+        const float w = pol.worst(0);
+        m16 |= ((!(r.x > w) && pol_wants(pol, id_at(b0 + t))) ? 1u : 0u) << t;
+        if (t + 1u < nb) m16 |= ((!(r.y > w) && pol_wants(pol, id_at(b0 + t + 1u))) ? 1u : 0u) << (t + 1u);
+      }
+    } else {
+      for (uint32_t t = 0; t < nb; ++t) {
+        const float4 ea = wl.list[LS * (b0 + t)], eb = wl.list[LS * (b0 + t) + 1];  // broadcast reads
+        const float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
+        m16 |= ((!(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w))) ? 1u : 0u) << t;
+      }
     }
     if (!valid[0]) m16 = 0;
     PCLHIP_WAIT_VMCNT0();
@@ -1528,7 +1567,7 @@ __device__ __forceinline__ bool traverse_recorded(const IndexView& ix, const flo
       uint32_t slot = 0, lid = NO_INDEX;
       if (m16 != 0) {
         slot = uint32_t(__builtin_ctz(m16));
-        lid = __float_as_uint(wl.list[LS * (b0 + slot)].w);
+        lid = id_at(b0 + slot);
         m16 &= m16 - 1u;
       }
       ++ts.c[2];
