@@ -22,7 +22,8 @@ cat $OUT/gate.log
 # 3. the same correspondence check the CPU emulation ran at 3M points (profiles/r03_wavesim_icp_check_3M.txt), on the
 #    device at 3M and 10M: the emulation's answer and the hardware's must be the same lines
 for n in 3000000 10000000; do timeout 600 python scratch/wavesim_icp_check.py $n > $OUT/icp_check_$n.log 2>&1; tail -4 $OUT/icp_check_$n.log; done
-# 4. the stand-off schedule and its run starts (compile time).  Build the variants BEFORE the call, in the CPU container:
+# 4. the stand-off schedule and its run starts (compile time).  Build the variants BEFORE the call, in the CPU container
+#    (scripts/r4_build_variants.sh builds all of these and the ones of section 6):
 #      scripts/build_variant.sh run3 "-DPCLHIP_COLD_RUN=3";  scripts/build_variant.sh run6 "-DPCLHIP_COLD_RUN=6"
 #      scripts/build_variant.sh greedy "-DPCLHIP_SO_GREEDY_SEED=1"
 #      scripts/build_variant.sh greedy_r2 "-DPCLHIP_SO_GREEDY_SEED=1 -DPCLHIP_COLD_RUN=2"
@@ -31,7 +32,7 @@ for n in 3000000 10000000; do timeout 600 python scratch/wavesim_icp_check.py $n
 #    lane's exact neighbour; on the emulation -- profiles/r03_wavesim_cold_seed_counters.txt -- that seed is BETTER than the
 #    predecessor's match: runs of 1 do 12 % fewer evaluation rounds and lane-cull steps than the default's runs of 4, with
 #    no one-lane searches at all, and every group is then independent of its neighbours: the schedule can be fully dynamic)
-for v in run3 run6 greedy greedy_r2 greedy_r1; do
+for v in run3 run6 greedy greedy_r2 greedy_r1 greedy_r1_grec; do
   L=pcl_amd/variants/libpclhip_$v.so
   [ -f $L ] && { echo "== $v" >> $OUT/run_ab.log; PCLHIP_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-host-align >> $OUT/run_ab.log 2>&1; }
 done
