@@ -200,3 +200,34 @@ def test_group_leaf_lists_variant_is_exact_and_used(variant_lib):
         keyword = "(icp or rejector or reciprocal or fuzz or fitness) and " + NOT_HERE + " and " + SLOW
     out = run_gpu_tests_on_the_emulation(lib, files, keyword)
     print([ln for ln in out.splitlines() if " passed" in ln][-1])
+
+
+@pytest.mark.skipif(os.environ.get("WAVESIM_SANITIZE") != "1",
+                    reason="WAVESIM_SANITIZE=1: ~2 min of build + ~6 min of tests (profiles/r03_wavesim_sanitizers.txt is a run of it)")
+def test_kernels_and_host_api_under_asan_ubsan(tmp_path):
+    """The emulation built with -fsanitize=address,undefined (kernels, host API, emulation runtime) under the GPU tier's
+    parity tests: a memory checker for the kernels' LDS / global accesses and the library's host code."""
+    build = tmp_path / "ws_asan"
+    build.mkdir()
+    mk = open(os.path.join(WS, "Makefile")).read()
+    mk = mk.replace("SRC = ../../pcl_amd/csrc", "SRC = %s" % os.path.join(ROOT, "pcl_amd", "csrc"))
+    mk = mk.replace("-I../../include", "-I" + os.path.join(ROOT, "include")).replace("../../include/pclhip.h", os.path.join(ROOT, "include", "pclhip.h"))
+    mk = mk.replace("$(CXX) -shared -fPIC -o $@", "$(CXX) -shared -shared-libasan -fsanitize=address,undefined -fPIC -o $@")
+    mk = mk.replace("$(CXX) -std=c++17 -O2 -g -fPIC -fvisibility=hidden -D__HIP_PLATFORM_AMD__",
+                    "$(CXX) -std=c++17 -O1 -g -fPIC -fvisibility=hidden -fsanitize=address,undefined -D__HIP_PLATFORM_AMD__")
+    (build / "Makefile").write_text(mk)
+    for f in ("wavesim.hpp", "wavesim_rt.cpp"):
+        shutil.copy(os.path.join(WS, f), str(build / f))
+    r = subprocess.run(["make", "-C", str(build), "-j", str(min(16, os.cpu_count() or 1)),
+                        "EXTRA=-fsanitize=address,undefined -fno-omit-frame-pointer"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rt = subprocess.run([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    env = dict(os.environ, PCLHIP_LIB=str(build / "libpclhip_wavesim.so"), PCLHIP_ALLOW_WAVESIM="1", LD_PRELOAD=rt,
+               ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=0")
+    cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k", NOT_HERE + " and not cpp_adapters and not c_example",
+           os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_loop.py"),
+           os.path.join(ROOT, "tests", "test_gpu_dist.py"), os.path.join(ROOT, "tests", "test_gpu_fuzz.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=3000)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
