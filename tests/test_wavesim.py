@@ -94,6 +94,8 @@ def test_gpu_parity_tests_run_on_the_emulation(wavesim_lib):
     surfaces), seeded and stand-off ICP searches bit for bit, the device-driven loop with rejector chains and reciprocal
     correspondences, estimators, radius search, VoxelGrid, GICP covariances, slab regions, fuzz slices and the degenerate
     inputs of the disc bounds."""
+    if (os.cpu_count() or 1) < 4 and os.environ.get("WAVESIM_FULL") != "1":
+        pytest.skip("fewer than 4 cores: the emulation would take many minutes here (WAVESIM_FULL=1 runs it anyway)")
     keyword = NOT_HERE if os.environ.get("WAVESIM_FULL") == "1" else NOT_HERE + " and " + SLOW
     out = run_gpu_tests_on_the_emulation(
         wavesim_lib, ["test_gpu_parity.py", "test_gpu_loop.py", "test_gpu_dist.py", "test_gpu_fuzz.py",
