@@ -2362,7 +2362,6 @@ void preload_search_kernels(pclhip_ctx* ctx) {
   (void)resident_blocks(ctx, icp_search_kernel<4, 1, true>, 1);
   (void)resident_blocks(ctx, icp_cold_search_kernel, 1);
   (void)resident_blocks(ctx, icp_search_dual_kernel, 1);
-  (void)resident_blocks(ctx, icp_search_owned_kernel, 1);
   (void)resident_blocks(ctx, normals_kernel<8>, 1);
   (void)resident_blocks(ctx, knn_reg_kernel<1>, 1);
 }
