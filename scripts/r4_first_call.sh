@@ -1,6 +1,6 @@
 #!/bin/bash
 # The first GPU-box call of round 4: everything round 3's last commit could not get because
-# the round's GPU budget ended with its bench A/B.  Usage (through gpurun, ~12 GPU-minutes):
+# the round's GPU budget ended with its bench A/B.  Usage (through gpurun --timeout 2400; ~25 GPU-minutes, sections can be commented out):
 #   GRAFT_COMMIT=$(git rev-parse --short HEAD) bash scripts/r4_first_call.sh
 #   -> gpurun_out/r4first/ (+ gpurun_out/prof_r4first/); copy what is to be judged into profiles/ as r04_*.
 set -u
