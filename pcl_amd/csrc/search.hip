@@ -1099,10 +1099,20 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
       bool from_record = false;
       if (!restart) from_record = traverse_recorded(ix, qx, qy, qz, valid, fast, wl_s[wave], ts, gr);
       if (!from_record) {
+#ifndef PCLHIP_GREC_DEFER
+#define PCLHIP_GREC_DEFER 1  // tight searches collect their lists during the walk and evaluate them as one afterwards
+#endif
+        gr.defer = PCLHIP_GREC_DEFER != 0;
         traverse<NN1MinT<Q>, SPARSE, IcpWaveLds, GroupRec>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, start_leaf,
                                                              hm == 0, &gr);
-        if (__builtin_amdgcn_ballot_w64(valid[0]) != 0)
-          gr.store(wave_max_f(valid[0] ? fast.worst(0) : 0.0f), __builtin_inff());
+        if (__builtin_amdgcn_ballot_w64(valid[0]) != 0) {
+          const float Tnow = wave_max_f(valid[0] ? fast.worst(0) : 0.0f);
+          if (gr.ndeferred != 0u)  // the leaves the walk only wrote down: tested and evaluated as ONE list (and the record closed)
+            grec_evaluate(ix, qx, qy, qz, valid, fast, wl_s[wave], ts, gr, gr.ndeferred, gr.lo[0], gr.lo[1], gr.lo[2], gr.hi[0],
+                          gr.hi[1], gr.hi[2], Tnow, __builtin_inff(), gr.ok && gr.count == gr.ndeferred);
+          else
+            gr.store(Tnow, __builtin_inff());
+        }
       }
     } else
 #endif

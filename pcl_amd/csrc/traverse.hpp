@@ -957,6 +957,11 @@ struct GroupRec {
   // what a recording traversal leaves behind
   uint32_t count = 0;
   bool ok = false;
+  // PCLHIP_GREC_DEFER: a tight search (bounds from good seeds, lists in index order) does not test and evaluate every node's
+  // list on the spot -- the walk only writes the listed leaves down, and grec_evaluate() takes all of them as ONE list
+  // afterwards (fewer, fuller evaluation rounds; the radii of such a search hardly move while it runs)
+  bool defer = false;
+  uint32_t ndeferred = 0;  // ids[0, ndeferred) were written down without being evaluated
   float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   // close the record of a finished search: T = the final wave radius (squared), keep = a bound the reach may not exceed
   __device__ __forceinline__ void store(float T, float keep) {
@@ -1126,6 +1131,10 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         if (ordered || gr->count + n_alive > GREC_CAP) gr->ok = false;
         if (gr->ok && alive) gr->ids[gr->count + rank] = first + uint32_t(lane);
         gr->count += n_alive;
+        if (gr->defer && gr->ok && !use_disc) {  // (ok: a tight list that fitted)
+          gr->ndeferred = gr->count;
+          continue;
+        }
       }
       if (alive) {
         if (use_disc) {
@@ -1451,15 +1460,18 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
   }
 }
 
+template <class Policy, class WL>
+__device__ __forceinline__ void grec_evaluate(const IndexView& ix, const float* qx, const float* qy, const float* qz,
+                                              const bool* valid, Policy& pol, WL& wl, TraverseStats& ts, GroupRec& gr,
+                                              uint32_t count, float lx0, float ly0, float lz0, float hx0, float hy0, float hz0,
+                                              float T, float keep, bool record_ok);
+
 // The search of a group from its recorded leaf list (see GroupRec): false if the record does not cover this iteration
 // (the caller then runs traverse(), which records afresh).  One query per lane, lane-sparse evaluation, tight bounds.
 template <class Policy, class WL>
 __device__ __forceinline__ bool traverse_recorded(const IndexView& ix, const float* qx, const float* qy, const float* qz,
                                                   const bool* valid, Policy& pol, WL& wl, TraverseStats& ts, GroupRec& gr) {
   static_assert(Policy::QPL == 1 && lane_sparse_of<Policy>::value && !Policy::NEEDS_W, "1-NN policies of the ICP search");
-  constexpr int LS = WL::LIST_STRIDE;
-  constexpr int NCHUNK = 12;
-  const int lane = threadIdx.x & (WAVE - 1);
   if (__builtin_amdgcn_ballot_w64(valid[0]) == 0 || ix.n == 0) return true;  // nothing to search
   const float4 h0 = gr.hdr[0], h1 = gr.hdr[1];
   const uint32_t count = uniform_u32(__float_as_uint(h1.w));
@@ -1479,7 +1491,22 @@ __device__ __forceinline__ bool traverse_recorded(const IndexView& ix, const flo
   if (!(left > 0.0f) || !(left * left * 0.99999f > T)) return false;
   ++ts.c[4];
   ++ts.c[5];  // groups searched from their record
-  // ---- the recorded leaves as ONE list: boxes against the group's box, the survivors ranked in place ---------------------
+  grec_evaluate(ix, qx, qy, qz, valid, pol, wl, ts, gr, count, lx0, ly0, lz0, hx0, hy0, hz0, T, left, true);
+  return true;
+}
+
+// The leaves gr.ids[0, count) as ONE list: their boxes against the group's box (lx0 .. hz0) and the wave radius T, the
+// survivors ranked in place (they are the next record), per-lane tests, lane-sparse evaluation; then the record's header
+// (`keep`: a bound the recorded reach may not exceed).
+template <class Policy, class WL>
+__device__ __forceinline__ void grec_evaluate(const IndexView& ix, const float* qx, const float* qy, const float* qz,
+                                              const bool* valid, Policy& pol, WL& wl, TraverseStats& ts, GroupRec& gr,
+                                              uint32_t count, float lx0, float ly0, float lz0, float hx0, float hy0, float hz0,
+                                              float T, float keep, bool record_ok) {
+  constexpr int LS = WL::LIST_STRIDE;
+  constexpr int NCHUNK = 12;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const float left = keep;
   uint32_t id = NO_INDEX;
   float lx = 0, ly = 0, lz = 0, hx = 0, hy = 0, hz = 0;
   if (uint32_t(lane) < count) {
@@ -1581,9 +1608,8 @@ __device__ __forceinline__ bool traverse_recorded(const IndexView& ix, const flo
   gr.lo[0] = lx0; gr.lo[1] = ly0; gr.lo[2] = lz0;
   gr.hi[0] = hx0; gr.hi[1] = hy0; gr.hi[2] = hz0;
   gr.count = n_alive;
-  gr.ok = true;
+  gr.ok = record_ok;
   gr.store(Tend, left);
-  return true;
 }
 
 __device__ __forceinline__ void flush_stats(const TraverseStats& ts, unsigned long long* g) {
