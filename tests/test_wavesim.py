@@ -181,7 +181,7 @@ def test_served_groups_when_an_alignment_outlasts_the_history(variant_lib, tmp_p
             assert np.array_equal(a[k], b[k]), k
 
 
-def test_group_leaf_lists_variant_is_exact_and_used(variant_lib):
+def test_group_leaf_lists_variant_is_exact_and_used(variant_lib, wavesim_lib):
     """-DPCLHIP_GROUP_LISTS=1 (off by default until it has been timed on the GPU): the seeded ICP search keeps every group's
     leaf list across iterations and searches from it while the group's motion allows (traverse.hpp: GroupRec).  A build of
     the emulation with it: eight iterations bit for bit the oracle's, converged iterations searched from the records with
@@ -196,6 +196,16 @@ def test_group_leaf_lists_variant_is_exact_and_used(variant_lib):
     print(r.stdout[-1200:])
     assert int(vals["mismatches"]) == 0
     assert float(vals["from_record"]) > 0.9 and float(vals["nodes"]) < 0.3
+    # the device-driven loop with restarts inside the queue (records live across alignments): every step record of the
+    # variant build equals the default build's
+    lines = []
+    for use in (lib, os.path.join(WS, "libpclhip_wavesim.so")):
+        e2 = dict(os.environ, PCLHIP_LIB=use, PCLHIP_ALLOW_WAVESIM="1")
+        r2 = subprocess.run([sys.executable, os.path.join(WS, "loop_records.py"), "120000"], env=e2, capture_output=True, text=True,
+                            timeout=900, cwd=ROOT)
+        assert r2.returncode == 0, r2.stdout[-1500:] + r2.stderr[-1500:]
+        lines.append(r2.stdout.strip().splitlines()[-1])
+    assert lines[0] == lines[1] and len(lines[0]) > 500
     files, keyword = ["test_gpu_fuzz.py"], NOT_HERE      # unseeded + seeded correspondences of random / degenerate clouds
     if os.environ.get("WAVESIM_FULL") == "1":             # every ICP-related parity test of the GPU tier (~45 s more)
         files = ["test_gpu_parity.py", "test_gpu_loop.py", "test_gpu_fuzz.py"]
