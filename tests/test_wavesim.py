@@ -243,3 +243,11 @@ def test_kernels_and_host_api_under_asan_ubsan(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=3000)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+@pytest.mark.skipif(os.environ.get("WAVESIM_FULL") != "1", reason="WAVESIM_FULL=1 (about a minute)")
+def test_config2_at_its_full_size_on_the_emulation(wavesim_lib):
+    """BASELINE.json's config 2 at its own size (2^20-point clouds, 20 point-to-point iterations): every iteration's
+    correspondences bit for bit the oracle's and the SVD alignment within the 1e-5 contract -- the GPU tier's test, here."""
+    out = run_gpu_tests_on_the_emulation(wavesim_lib, ["test_gpu_fullsize.py"], "config2")
+    assert "1 passed" in out
