@@ -34,6 +34,13 @@ bool is_device_pointer(const void* p) {
   return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
+// Bytes from the first to the last one read of n records `stride` apart of which `elem` bytes each are read.  Callers hand
+// over pointers INTO their records (the normals of pcl::PointNormal: record + 16); copying n * stride from there would read
+// past the end of their array (found by the sanitizer run of the C++ binding on the emulation, tests/test_wavesim.py).
+static inline size_t strided_span(uint64_t n, size_t stride, size_t elem) {
+  return n == 0 ? 0 : size_t(n - 1) * stride + elem;
+}
+
 pclhip_status to_device(pclhip_ctx* ctx, const void* p, size_t bytes, const void** dev, void** owned) {
   *owned = nullptr;
   *dev = nullptr;
@@ -908,7 +915,7 @@ pclhip_status pclhip_index_set_normals(pclhip_index* ix, const void* normals, si
   DeviceGuard guard(ctx);
   const void* dn = nullptr;
   void* owned = nullptr;
-  pclhip_status st = to_device(ctx, normals, size_t(ix->n_orig) * stride, &dn, &owned);
+  pclhip_status st = to_device(ctx, normals, strided_span(ix->n_orig, stride, 12), &dn, &owned);  // (see strided_span)
   if (st != PCLHIP_OK) return st;
   guard.add(owned);
   if (!ix->nrm) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->nrm, size_t(ix->n_pad) * sizeof(float4)));
@@ -1105,7 +1112,7 @@ pclhip_status pclhip_icp_set_source_normals(pclhip_icp* icp, const void* normals
   DeviceGuard guard(ctx);
   const void* dn = nullptr;
   void* owned = nullptr;
-  pclhip_status st = to_device(ctx, normals, size_t(icp->n_orig) * stride, &dn, &owned);
+  pclhip_status st = to_device(ctx, normals, strided_span(icp->n_orig, stride, 12), &dn, &owned);  // (see strided_span)
   if (st != PCLHIP_OK) return st;
   guard.add(owned);
   const size_t cap = icp->n > 0 ? icp->n : 1;
@@ -1416,7 +1423,9 @@ static pclhip_status estimate_pairs_common(pclhip_ctx* ctx, int mode, const void
       PCLHIP_REQUIRE(ctx, strides[a] >= 12 && strides[a] % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
       const void* d = nullptr;
       void* owned = nullptr;
-      pclhip_status st = to_device(ctx, in[a], size_t(n) * strides[a], &d, &owned);
+      // exactly the bytes the kernel reads: three floats of every record.  The pointer may sit INSIDE the caller's records
+      // (the normals of a PointNormal array: base + 16, stride 48) -- n * stride from there runs 16 bytes past the array
+      pclhip_status st = to_device(ctx, in[a], strided_span(n, strides[a], 12), &d, &owned);
       if (st != PCLHIP_OK) return st;
       guard.add(owned);
       void* buf = nullptr;

@@ -243,6 +243,31 @@ def test_kernels_and_host_api_under_asan_ubsan(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=3000)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+    # the C++ host sides through the same build: the real-PCL binding on the mock and the compat mirror, with leak detection
+    import json
+    import numpy as np
+    from oracle import pcl_oracle as orc
+    z = np.load(os.path.join(ROOT, "tests", "golden", "bunny.npz"))
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+    np.savetxt(tmp_path / "bun0.txt", z["bun0"][:, :3], fmt="%.9g")
+    np.savetxt(tmp_path / "bun4.txt", z["bun4"][:, :3], fmt="%.9g")
+    np.savetxt(tmp_path / "corr.txt", np.asarray(g["correspondences_original"]), fmt="%d")
+    tgt = np.ones((len(z["bun4"]), 4), np.float32)
+    tgt[:, :3] = z["bun4"][:, :3]
+    np.savetxt(tmp_path / "bun4_normals.txt", orc.KdTree(tgt).normals(tgt, 10)[0][:, :3], fmt="%.9g")
+    common = [CLANG, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-shared-libasan", "-I" + os.path.join(ROOT, "include"),
+              "-L" + str(build), "-l:libpclhip_wavesim.so", "-Wl,-rpath," + str(build), "-Wl,-rpath," + os.path.dirname(rt)]
+    runs = [("test_pcl_plugin.cpp", ["-I" + os.path.join(ROOT, "tests", "cpp", "pcl_mock")], ["bun0.txt", "bun4.txt", "corr.txt", "bun4_normals.txt"]),
+            ("test_pcl_compat.cpp", [], ["bun0.txt", "bun4.txt", "corr.txt"])]
+    env2 = dict(os.environ, PCLHIP_ALLOW_WAVESIM="1", ASAN_OPTIONS="detect_leaks=1:detect_stack_use_after_return=0",
+                UBSAN_OPTIONS="print_stacktrace=1")
+    for src, extra, args in runs:
+        exe = str(tmp_path / src.replace(".cpp", "_asan"))
+        c = subprocess.run(common + extra + [os.path.join(ROOT, "tests", "cpp", src), "-o", exe], capture_output=True, text=True)
+        assert c.returncode == 0, c.stderr[-3000:]
+        r = subprocess.run([exe] + [str(tmp_path / a) for a in args], capture_output=True, text=True, env=env2, timeout=1800)
+        assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
 
 
 @pytest.mark.skipif(os.environ.get("WAVESIM_FULL") != "1", reason="WAVESIM_FULL=1 (about a minute)")
@@ -251,3 +276,14 @@ def test_config2_at_its_full_size_on_the_emulation(wavesim_lib):
     correspondences bit for bit the oracle's and the SVD alignment within the 1e-5 contract -- the GPU tier's test, here."""
     out = run_gpu_tests_on_the_emulation(wavesim_lib, ["test_gpu_fullsize.py"], "config2")
     assert "1 passed" in out
+
+
+def test_strided_inputs_are_read_to_their_last_byte_only(wavesim_lib):
+    """pclhip_estimate_rigid_transformation, pclhip_index_set_normals and pclhip_icp_set_source_normals take pointers INTO the
+    caller's records (normals at record + 16, stride 48): arrays that end at an inaccessible page must not fault (they did:
+    n * stride bytes were staged from the interior pointer, 16 past the array -- found by the sanitizer run of the C++
+    binding on the emulation)."""
+    env = dict(os.environ, PCLHIP_LIB=wavesim_lib, PCLHIP_ALLOW_WAVESIM="1")
+    r = subprocess.run([sys.executable, os.path.join(WS, "guard_page_probe.py")], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "GUARD_PAGE ok" in r.stdout, (r.returncode, r.stdout[-800:], r.stderr[-1500:])
