@@ -1532,10 +1532,10 @@ __global__ __launch_bounds__(BLOCK, 4) void recip_search_kernel(IndexView sx, co
     NN1Min fast;
     fast.init(__builtin_inff());
     if (valid && seed_pos != NO_INDEX) fast.seed(0, l2_simple(p.x, p.y, p.z, sp.x, sp.y, sp.z), seed_pos);
-    uint32_t start_leaf = NO_INDEX;
-    const uint64_t hm = __builtin_amdgcn_ballot_w64(valid && seed_pos != NO_INDEX);
-    if (hm != 0) start_leaf = uint32_t(__builtin_amdgcn_readlane(int(seed_pos), __builtin_ctzll(hm))) / LEAF;
-    traverse<NN1Min, true>(sx, qx, qy, qz, vv, fast, wl_s[wave], topbox_s, ts, start_leaf);
+    // The seed is a distance bound only: the source index is REFITTED to the moved cloud (refit_boxes), so after a
+    // rotation its nodes are no longer the cells of a kd partition and the start-level shortcut of traverse() (which
+    // needs disjoint cells) does not apply -- the descent starts at the root.
+    traverse<NN1Min, true>(sx, qx, qy, qz, vv, fast, wl_s[wave], topbox_s, ts);
     fast.resolve(sx, qx, qy, qz);
     NN1 pol;
     pol.soa = sx.soa;

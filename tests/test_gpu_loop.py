@@ -224,3 +224,31 @@ def test_native_communicator_single_rank(gpu):
             with pytest.raises(pcl_amd.PclHipError, match="Distance rejector"):
                 icp.align()
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+
+
+@pytest.mark.parametrize("deg", [5.0, 35.0])
+def test_reciprocal_correspondences_after_a_rotation(gpu, deg):
+    # the source index of the reciprocal test (impl/correspondence_estimation.hpp:247-270) is built in
+    # the source's input frame and only REFITTED once the cloud has moved; after a rotation its nodes are not kd cells any
+    # more, so a search of it must start at the root.  A guess of 5 / 35 degrees rotates the cloud before the first
+    # search: every iteration's pair count and the final transform must be the oracle's.
+    import pcl_amd
+    from oracle import pcl_oracle as orc
+    from oracle import rejectors as orej
+    tgt, src0, _ = pcl_amd.synth.icp_pair(40_000)
+    a = np.deg2rad(deg)
+    G = np.eye(4, dtype=np.float32)
+    G[:3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    Ginv = np.linalg.inv(G.astype(np.float64)).astype(np.float32)
+    src = orc.transform_cloud(Ginv, src0, order=0)          # so that the guess brings the cloud back near the target
+    icp = _make_icp(gpu, tgt, src, 0)
+    icp.setUseReciprocalCorrespondences(True)
+    icp.align(G)
+    moved = orc.transform_cloud(G, src, order=0)
+    ref = orej.icp_with_filters(orc, tgt, moved, 0, reciprocal=True, max_iterations=20,
+                                max_correspondence_distance=0.1, transformation_epsilon=1e-10)
+    assert icp.nr_iterations_ == ref["iterations"]
+    T_ref = ref["T"].astype(np.float64) @ G.astype(np.float64)
+    assert np.abs(icp.getFinalTransformation().astype(np.float64) - T_ref).max() < 2e-5
+    steps = icp.runSteps(ref["iterations"], guess=G)
+    assert [s["num_correspondences"] for s in steps] == [len(q) for q, _ in ref["per_iter"]][:len(steps)]
