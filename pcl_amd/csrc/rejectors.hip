@@ -31,54 +31,98 @@ __global__ void rej_distance_kernel(const float* __restrict__ d2, uint32_t n, fl
   if (i < n && keep[i] && !(d2[i] < max_d2)) keep[i] = 0;
 }
 
-// order-preserving key of a non-negative float, +inf (0xFFFFFFFF) for dropped slots
-__global__ void rej_dist_key_kernel(const float* __restrict__ d2, const uint8_t* __restrict__ keep, uint32_t n,
-                                    uint32_t* __restrict__ keys, unsigned int* __restrict__ count) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool k = false;
-  if (i < n) {
-    k = keep[i] != 0;
-    keys[i] = k ? __float_as_uint(d2[i]) : 0xFFFFFFFFu;
-  }
-  __shared__ unsigned int blk;
-  if (threadIdx.x == 0) blk = 0;
-  __syncthreads();
-  const unsigned long long b = __builtin_amdgcn_ballot_w64(k);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&blk, (unsigned int)__builtin_popcountll(b));
-  __syncthreads();
-  if (threadIdx.x == 0 && blk) atomicAdd(count, blk);
-}
-
-// ---- radix selection: the key of rank r among n unsigned keys ------------------------------------------------
-// MedianDistance and Trimmed only need ONE order statistic of the kept distances, not a sorted array: digit
-// passes of 11 bits from the top, each a histogram of the keys that match the prefix chosen so far (per-block
-// LDS histogram merged into a global one) followed by a one-workgroup scan that picks the bin holding the rank.
+// ---- radix selection: ONE order statistic of the kept distances, read where they lie --------------------------
+// MedianDistance and Trimmed need one order statistic each, not a sorted array.  The keys are never materialised:
+// every digit pass reads the distances (4 B) and the keep bytes (1 B) -- 50 MB at 10M pairs -- builds a per-block LDS
+// histogram of the kept distances that match the digits chosen so far and merges it into a global one; a one-workgroup
+// kernel then picks the bin that holds the rank.  The 32 distance bits take three passes (10 + 11 + 11 bits; the bits
+// of a non-negative float order like the float).  The FIRST pass also counts the kept pairs (the histogram's total), so
+// the rank -- which depends on that count -- is derived inside the first pick; the LAST pick writes the threshold.
+// Trimmed orders by (distance, original query index): when the distance holding the rank is shared by more pairs than
+// the rank takes, three more passes select on the query index (read from the source record only where the distance
+// equals the selected one); otherwise -- one pair at that distance, the usual case -- they return at once.
 struct RsState {
-  unsigned long long prefix;  // key bits decided so far (after the last pass: the key itself)
-  uint32_t rank;              // remaining rank inside the chosen bin
-  uint32_t pad;
+  uint32_t dkey;  // distance bits decided so far (after the three distance passes: the distance itself)
+  uint32_t ikey;  // query-index bits decided so far (Trimmed's tie passes)
+  uint32_t rank;  // remaining rank inside the chosen bin
+  uint32_t done;  // the selection is over (or there is nothing to select): later passes return at once
 };
 constexpr int RS_BINS = 2048;
+constexpr int RS_PASSES = 6;
 
-template <class K>
-__global__ __launch_bounds__(TB) void rs_hist_kernel(const K* __restrict__ keys, uint32_t n, const RsState* __restrict__ st,
-                                                     int shift, uint32_t* __restrict__ hist) {
+template <int PASS>
+__device__ __forceinline__ void rs_count(uint32_t* h, float d, bool kept, uint32_t dkey, uint32_t ikey, const float4* cur,
+                                         uint32_t i) {
+  if (!kept) return;
+  const uint32_t b = __float_as_uint(d);
+  if constexpr (PASS == 0) {
+    atomicAdd(&h[b >> 22], 1u);
+  } else if constexpr (PASS == 1) {
+    if ((b >> 22) == (dkey >> 22)) atomicAdd(&h[(b >> 11) & 2047u], 1u);
+  } else if constexpr (PASS == 2) {
+    if ((b >> 11) == (dkey >> 11)) atomicAdd(&h[b & 2047u], 1u);
+  } else {
+    if (b != dkey) return;
+    const uint32_t q = __float_as_uint(cur[i].w);
+    if constexpr (PASS == 3) {
+      atomicAdd(&h[q >> 22], 1u);
+    } else if constexpr (PASS == 4) {
+      if ((q >> 22) == (ikey >> 22)) atomicAdd(&h[(q >> 11) & 2047u], 1u);
+    } else {
+      if ((q >> 11) == (ikey >> 11)) atomicAdd(&h[q & 2047u], 1u);
+    }
+  }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(TB) void rs_hist_kernel(const float* __restrict__ d2, const uint8_t* __restrict__ keep,
+                                                     const float4* __restrict__ cur, uint32_t n,
+                                                     const RsState* __restrict__ st, uint32_t* __restrict__ hist) {
+  uint32_t dkey = 0, ikey = 0;
+  if constexpr (PASS > 0) {
+    if (st->done) return;
+    dkey = st->dkey;
+    ikey = st->ikey;
+  }
   __shared__ uint32_t h[RS_BINS];
   for (int i = threadIdx.x; i < RS_BINS; i += TB) h[i] = 0u;
   __syncthreads();
-  constexpr int BITS = int(sizeof(K)) * 8;
-  const int up = shift + 11;  // the bits above the digit must equal the prefix
-  const unsigned long long prefix = st->prefix;
-  for (uint32_t i = blockIdx.x * TB + threadIdx.x; i < n; i += gridDim.x * TB) {
-    const unsigned long long k = keys[i];
-    if (up >= BITS || (k >> up) == (prefix >> up)) atomicAdd(&h[uint32_t(k >> shift) & uint32_t(RS_BINS - 1)], 1u);
+  const uint32_t n4 = n / 4;  // four pairs per lane and step: one 16-byte and one 4-byte load
+  const float4* d4 = reinterpret_cast<const float4*>(d2);
+  const uint32_t* k4 = reinterpret_cast<const uint32_t*>(keep);
+  for (uint32_t j = blockIdx.x * TB + threadIdx.x; j < n4; j += gridDim.x * TB) {
+    const uint32_t k = k4[j];
+    if (k == 0u) continue;
+    const float4 d = d4[j];
+    rs_count<PASS>(h, d.x, (k & 0xFFu) != 0u, dkey, ikey, cur, 4 * j);
+    rs_count<PASS>(h, d.y, (k & 0xFF00u) != 0u, dkey, ikey, cur, 4 * j + 1);
+    rs_count<PASS>(h, d.z, (k & 0xFF0000u) != 0u, dkey, ikey, cur, 4 * j + 2);
+    rs_count<PASS>(h, d.w, (k & 0xFF000000u) != 0u, dkey, ikey, cur, 4 * j + 3);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {
+    const uint32_t i = 4 * n4 + threadIdx.x;
+    rs_count<PASS>(h, d2[i], keep[i] != 0, dkey, ikey, cur, i);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < RS_BINS; i += TB)
     if (h[i]) atomicAdd(hist + i, h[i]);
 }
 
-__global__ __launch_bounds__(256) void rs_pick_kernel(RsState* __restrict__ st, const uint32_t* __restrict__ hist, int shift) {
+// One workgroup: scan of the pass's histogram, the bin holding the rank, and what the pass's place in the chain asks for.
+//   MedianDistance: rank = count / 2 (nth_element at size/2, correspondence_rejection_median_distance.cpp:55-56),
+//                   threshold = median * factor in double (:64-66)
+//   Trimmed:        nv = max(floor(float(ratio) * float(count)), min_correspondences) (correspondence_rejection_trimmed.cpp
+//                   :47-50); nothing to do when nv >= count, everything dropped when nv == 0, else rank = nv - 1
+// The count of kept pairs, the rank it implies, the selected key and the threshold derived from it stay in device memory
+// (pclhip::RejState, one per registration; mirrored to pinned memory for the getters): the chain runs stream-ordered,
+// without the host in between -- it is part of the device-driven loop.
+template <int PASS>
+__global__ __launch_bounds__(256) void rs_pick_kernel(RejState* __restrict__ out, RsState* __restrict__ st,
+                                                      const uint32_t* __restrict__ hist, int kind, double param,
+                                                      unsigned int min_corr) {
+  if constexpr (PASS > 0) {
+    if (st->done) return;  // (uniform over the workgroup; nobody has written st yet)
+  }
   constexpr int PER = RS_BINS / 256;
   uint32_t c[PER], sum = 0;
 #pragma unroll
@@ -95,78 +139,104 @@ __global__ __launch_bounds__(256) void rs_pick_kernel(RsState* __restrict__ st, 
     scan[threadIdx.x] += v;
     __syncthreads();
   }
-  const uint32_t rank = st->rank;
+  uint32_t rank;
+  if constexpr (PASS == 0) {
+    const unsigned int cnt = scan[255];  // every kept pair is in exactly one bin of the first pass
+    int mode = 0;                        // 0 nothing to filter, 1 threshold at `rank`, 2 drop everything
+    rank = 0;
+    bool cut = false;
+    if (kind == PCLHIP_REJ_MEDIAN_DISTANCE) {
+      mode = cnt > 0 ? 1 : 0;
+      rank = cnt / 2;
+    } else {  // PCLHIP_REJ_TRIMMED
+      const float prod = __fmul_rn(float(param), float(cnt));
+      unsigned int nv = (unsigned int)floorf(prod);
+      if (nv < min_corr) nv = min_corr;
+      if (nv < cnt) {
+        mode = nv == 0 ? 2 : 1;
+        rank = nv == 0 ? 0 : nv - 1;
+        cut = true;
+      }
+    }
+    if (threadIdx.x == 0) {
+      out->count = cnt;
+      out->mode = mode;
+      if (cut) out->trimmed = 1;
+      st->dkey = 0;
+      st->ikey = 0;
+      st->rank = rank;
+      st->done = mode == 1 ? 0u : 1u;
+    }
+    if (mode != 1) return;
+  } else {
+    rank = st->rank;
+  }
   const uint32_t incl = scan[threadIdx.x], excl = incl - sum;
-  __syncthreads();  // every thread has read st->rank before one of them rewrites it
+  __syncthreads();  // every thread has read st before one of them rewrites it
   if (rank >= excl && rank < incl) {
     uint32_t cum = excl;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       if (rank >= cum && rank < cum + c[j]) {
-        st->prefix |= (unsigned long long)(threadIdx.x * PER + j) << shift;
-        st->rank = rank - cum;
+        const uint32_t bin = threadIdx.x * PER + j, left = rank - cum;
+        constexpr int SHIFT = (PASS % 3 == 0) ? 22 : (PASS % 3 == 1) ? 11 : 0;
+        if constexpr (PASS < 3) {
+          const uint32_t dkey = (PASS == 0 ? 0u : st->dkey) | (bin << SHIFT);
+          st->dkey = dkey;
+          st->rank = left;
+          if constexpr (PASS == 2) {
+            if (kind == PCLHIP_REJ_MEDIAN_DISTANCE) {
+              const double median = double(__uint_as_float(dkey));
+              out->key = dkey;
+              out->median = median;
+              out->threshold = median * param;
+              st->done = 1u;
+            } else if (left + 1u == c[j]) {  // the rank takes every pair at this distance: no tie to order
+              out->key = ((unsigned long long)dkey << 32) | 0xFFFFFFFFull;
+              st->done = 1u;
+            }
+          }
+        } else {
+          const uint32_t ikey = (PASS == 3 ? 0u : st->ikey) | (bin << SHIFT);
+          st->ikey = ikey;
+          st->rank = left;
+          if constexpr (PASS == 5) {
+            out->key = ((unsigned long long)st->dkey << 32) | ikey;
+            st->done = 1u;
+          }
+        }
       }
       cum += c[j];
     }
   }
 }
 
-// The chain runs stream-ordered, without the host in between (it is part of the device-driven loop): the count of kept
-// pairs, the rank it implies, the selected key and the threshold derived from it stay in device memory (pclhip::RejState,
-// one per registration; mirrored to pinned memory for the getters).
-//   MedianDistance: rank = count / 2 (nth_element at size/2, correspondence_rejection_median_distance.cpp:55-56),
-//                   threshold = median * factor in double (:64-66)
-//   Trimmed:        nv = max(floor(float(ratio) * float(count)), min_correspondences) (correspondence_rejection_trimmed.cpp
-//                   :47-50); nothing to do when nv >= count, everything dropped when nv == 0, else rank = nv - 1
-__global__ void rej_prepare_kernel(RejState* __restrict__ st, RsState* __restrict__ rs, const unsigned int* __restrict__ count,
-                                   int kind, double param, unsigned int min_corr) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const unsigned int cnt = *count;
-  unsigned int rank = 0;
-  int mode = 0;  // 0 nothing to filter, 1 threshold at `rank`, 2 drop everything
-  if (kind == PCLHIP_REJ_MEDIAN_DISTANCE) {
-    mode = cnt > 0 ? 1 : 0;
-    rank = cnt / 2;
-  } else {  // PCLHIP_REJ_TRIMMED
-    const float prod = __fmul_rn(float(param), float(cnt));
-    unsigned int nv = (unsigned int)floorf(prod);
-    if (nv < min_corr) nv = min_corr;
-    if (nv < cnt) {
-      mode = nv == 0 ? 2 : 1;
-      rank = nv == 0 ? 0 : nv - 1;
-      st->trimmed = 1;
-    }
-  }
-  st->count = cnt;
-  st->mode = mode;
-  rs->prefix = 0;
-  rs->rank = rank;
-  rs->pad = 0;
+// the order statistic a MedianDistance (three passes) or Trimmed (three + three tie passes) rejector asks for ->
+// RejState (count, mode, key, median, threshold), stream-ordered.  hist_dev: RS_PASSES histograms.
+template <int PASS>
+void radix_select_pass(pclhip_ctx* ctx, int grid, const float* d2, const uint8_t* keep, const float4* cur, uint32_t n,
+                       RejState* out, RsState* rs, uint32_t* hist_dev, int kind, double param, unsigned int min_corr) {
+  uint32_t* const h = hist_dev + size_t(PASS) * RS_BINS;
+  hipLaunchKernelGGL(rs_hist_kernel<PASS>, dim3(grid), dim3(TB), 0, ctx->stream, d2, keep, cur, n, rs, h);
+  hipLaunchKernelGGL(rs_pick_kernel<PASS>, dim3(1), dim3(256), 0, ctx->stream, out, rs, h, kind, param, min_corr);
 }
-
-// after the digit passes: the selected key, and what MedianDistance makes of it
-__global__ void rej_threshold_kernel(RejState* __restrict__ st, const RsState* __restrict__ rs, int kind, double param) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  st->key = rs->prefix;
-  if (kind == PCLHIP_REJ_MEDIAN_DISTANCE && st->mode == 1) {
-    const double median = double(__uint_as_float(uint32_t(rs->prefix)));
-    st->median = median;
-    st->threshold = median * param;
-  }
-}
-
-// key of the rank rs->rank (set by rej_prepare_kernel) -> rs->prefix, stream-ordered
-template <class K>
-void radix_select_queued(pclhip_ctx* ctx, const K* keys, uint32_t n, RsState* rs, uint32_t* hist_dev) {
-  hipStream_t s = ctx->stream;
-  constexpr int BITS = int(sizeof(K)) * 8;
-  int grid = int((n + TB - 1) / TB);
+hipError_t radix_select_queued(pclhip_ctx* ctx, const float* d2, const uint8_t* keep, const float4* cur, uint32_t n,
+                               RejState* out, RsState* rs, uint32_t* hist_dev, int kind, double param,
+                               unsigned int min_corr) {
+  int grid = int((n / 4 + TB - 1) / TB);
   if (grid > ctx->num_cus * 8) grid = ctx->num_cus * 8;
-  for (int shift = ((BITS - 1) / 11) * 11; shift >= 0; shift -= 11) {
-    (void)hipMemsetAsync(hist_dev, 0, RS_BINS * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(rs_hist_kernel<K>, dim3(grid), dim3(TB), 0, s, keys, n, rs, shift, hist_dev);
-    hipLaunchKernelGGL(rs_pick_kernel, dim3(1), dim3(256), 0, s, rs, hist_dev, shift);
+  if (grid < 1) grid = 1;
+  const hipError_t e = hipMemsetAsync(hist_dev, 0, size_t(RS_PASSES) * RS_BINS * sizeof(uint32_t), ctx->stream);
+  if (e != hipSuccess) return e;
+  radix_select_pass<0>(ctx, grid, d2, keep, cur, n, out, rs, hist_dev, kind, param, min_corr);
+  radix_select_pass<1>(ctx, grid, d2, keep, cur, n, out, rs, hist_dev, kind, param, min_corr);
+  radix_select_pass<2>(ctx, grid, d2, keep, cur, n, out, rs, hist_dev, kind, param, min_corr);
+  if (kind == PCLHIP_REJ_TRIMMED) {
+    radix_select_pass<3>(ctx, grid, d2, keep, cur, n, out, rs, hist_dev, kind, param, min_corr);
+    radix_select_pass<4>(ctx, grid, d2, keep, cur, n, out, rs, hist_dev, kind, param, min_corr);
+    radix_select_pass<5>(ctx, grid, d2, keep, cur, n, out, rs, hist_dev, kind, param, min_corr);
   }
+  return hipGetLastError();
 }
 
 // correspondence_rejection_median_distance.cpp:64-66: keep if double(d) <= median * factor
@@ -178,25 +248,6 @@ __global__ void rej_median_kernel(const float* __restrict__ d2, uint32_t n, cons
   if (i < n && keep[i] && !(double(d2[i]) <= thr)) keep[i] = 0;
 }
 
-// (distance, original query index) key; ~0 for dropped slots
-__global__ void rej_pair_key_kernel(const float4* __restrict__ cur, const float* __restrict__ d2,
-                                    const uint8_t* __restrict__ keep, uint32_t n, uint64_t* __restrict__ keys,
-                                    unsigned int* __restrict__ count) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool k = false;
-  if (i < n) {
-    k = keep[i] != 0;
-    keys[i] = k ? ((uint64_t(__float_as_uint(d2[i])) << 32) | __float_as_uint(cur[i].w)) : ~0ull;
-  }
-  __shared__ unsigned int blk;
-  if (threadIdx.x == 0) blk = 0;
-  __syncthreads();
-  const unsigned long long b = __builtin_amdgcn_ballot_w64(k);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&blk, (unsigned int)__builtin_popcountll(b));
-  __syncthreads();
-  if (threadIdx.x == 0 && blk) atomicAdd(count, blk);
-}
-
 // correspondence_rejection_trimmed.cpp:53-58: keep the n smallest (distance, query) keys
 __global__ void rej_trim_kernel(const float4* __restrict__ cur, const float* __restrict__ d2, uint32_t n,
                                 const RejState* __restrict__ st, uint8_t* __restrict__ keep) {
@@ -204,9 +255,10 @@ __global__ void rej_trim_kernel(const float4* __restrict__ cur, const float* __r
   const int mode = st->mode;
   if (mode == 0) return;  // nv >= count: the list passes unchanged
   const uint64_t thr_key = st->key;
+  const uint32_t thr_d = uint32_t(thr_key >> 32), thr_q = uint32_t(thr_key);
   if (i < n && keep[i]) {
-    const uint64_t k = (uint64_t(__float_as_uint(d2[i])) << 32) | __float_as_uint(cur[i].w);
-    if (mode == 2 || k > thr_key) keep[i] = 0;
+    const uint32_t b = __float_as_uint(d2[i]);  // the query index is read only where the distance alone does not decide
+    if (mode == 2 || b > thr_d || (b == thr_d && thr_q != 0xFFFFFFFFu && __float_as_uint(cur[i].w) > thr_q)) keep[i] = 0;
   }
 }
 
@@ -288,12 +340,10 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
   hipLaunchKernelGGL(rej_init_kernel, grid, block, 0, s, icp->match_pos, n, icp->keep);
   Guard g;  // stream-ordered temporaries: released to the context when this returns, re-used only by later work of the stream
   g.ctx = ctx;
-  unsigned int* d_cnt = nullptr;
   RsState* rs = nullptr;
   uint32_t* rs_hist = nullptr;
-  PCLHIP_CHECK_HIP(ctx, g.alloc(&d_cnt, sizeof(unsigned int)));
   PCLHIP_CHECK_HIP(ctx, g.alloc(&rs, sizeof(RsState)));
-  PCLHIP_CHECK_HIP(ctx, g.alloc(&rs_hist, RS_BINS * sizeof(uint32_t)));
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&rs_hist, size_t(RS_PASSES) * RS_BINS * sizeof(uint32_t)));
 
   if (icp->reciprocal) {
     // An index over the source: built ONCE per source cloud (from the pristine, kd-ordered copy; ids = original source
@@ -337,14 +387,8 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
         break;
       }
       case PCLHIP_REJ_MEDIAN_DISTANCE: {
-        uint32_t* k0 = nullptr;
-        PCLHIP_CHECK_HIP(ctx, g.alloc(&k0, size_t(n) * 4));
-        PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
-        // dropped slots carry the largest key, so rank count / 2 counts kept distances only
-        hipLaunchKernelGGL(rej_dist_key_kernel, grid, block, 0, s, icp->match_d2, icp->keep, n, k0, d_cnt);
-        hipLaunchKernelGGL(rej_prepare_kernel, dim3(1), dim3(1), 0, s, icp->rej_state, rs, d_cnt, int(r.kind), r.param, 0u);
-        radix_select_queued<uint32_t>(ctx, k0, n, rs, rs_hist);
-        hipLaunchKernelGGL(rej_threshold_kernel, dim3(1), dim3(1), 0, s, icp->rej_state, rs, int(r.kind), r.param);
+        PCLHIP_CHECK_HIP(ctx, radix_select_queued(ctx, icp->match_d2, icp->keep, icp->src_cur, n, icp->rej_state, rs, rs_hist,
+                                                  int(r.kind), r.param, 0u));
         hipLaunchKernelGGL(rej_median_kernel, grid, block, 0, s, icp->match_d2, n, icp->rej_state, icp->keep);
         break;
       }
@@ -362,14 +406,9 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
         break;
       }
       case PCLHIP_REJ_TRIMMED: {
-        uint64_t* k0 = nullptr;
-        PCLHIP_CHECK_HIP(ctx, g.alloc(&k0, size_t(n) * 8));
-        PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
-        hipLaunchKernelGGL(rej_pair_key_kernel, grid, block, 0, s, icp->src_cur, icp->match_d2, icp->keep, n, k0, d_cnt);
-        hipLaunchKernelGGL(rej_prepare_kernel, dim3(1), dim3(1), 0, s, icp->rej_state, rs, d_cnt, int(r.kind), r.param,
-                           r.min_correspondences);
-        radix_select_queued<uint64_t>(ctx, k0, n, rs, rs_hist);  // the nv-th smallest (distance, query) key
-        hipLaunchKernelGGL(rej_threshold_kernel, dim3(1), dim3(1), 0, s, icp->rej_state, rs, int(r.kind), r.param);
+        // the nv-th smallest (distance, query) key
+        PCLHIP_CHECK_HIP(ctx, radix_select_queued(ctx, icp->match_d2, icp->keep, icp->src_cur, n, icp->rej_state, rs, rs_hist,
+                                                  int(r.kind), r.param, r.min_correspondences));
         hipLaunchKernelGGL(rej_trim_kernel, grid, block, 0, s, icp->src_cur, icp->match_d2, n, icp->rej_state, icp->keep);
         trimmed_in_chain = true;  // the list comes back sorted by distance IF it was cut (RejState::trimmed says so)
         break;
@@ -388,6 +427,6 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
 
 void preload_rejector_kernels() {
   hipFuncAttributes a;
-  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(rs_pick_kernel));
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(rs_pick_kernel<0>));
 }
 }  // namespace pclhip

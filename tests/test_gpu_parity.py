@@ -791,6 +791,39 @@ def test_rejector_chain_and_reciprocal_vs_oracle_50k(gpu, orc):
         assert 0 < len(q) < 50_000
 
 
+@pytest.mark.parametrize("n_same", [0, 1, 700, 3000])
+def test_trimmed_and_median_on_tied_distances(gpu, orc, n_same):
+    # correspondence_rejection_trimmed.cpp:53-58 orders by distance; equal distances (here: source points that ARE target
+    # points, distance 0, and a lattice of equal offsets) are ordered by the query index -- the selection's tie passes
+    import pcl_amd
+    from oracle import rejectors as rej
+    rng = np.random.default_rng(5 + n_same)
+    tgt = np.ones((3000, 4), np.float32)
+    tgt[:, :3] = rng.integers(0, 64, (3000, 3)).astype(np.float32)       # lattice: many equal squared distances
+    src = tgt[rng.permutation(3000)].copy()
+    src[n_same:, :3] += rng.choice(np.array([0.0, 0.25, 0.5], np.float32), (3000 - n_same, 3))
+    for ratio in (0.1, 0.5, 0.9):
+        for kind in ("trimmed", "median"):
+            ce = pcl_amd.CorrespondenceEstimation(gpu)
+            ce.setInputSource(src)
+            ce.setInputTarget(tgt)
+            if kind == "trimmed":
+                r = pcl_amd.CorrespondenceRejectorTrimmed()
+                r.setOverlapRatio(ratio)
+            else:
+                r = pcl_amd.CorrespondenceRejectorMedianDistance()
+                r.setMedianFactor(2.0 * ratio)
+            q, m, d = ce.determineCorrespondences(rejectors=[r])
+            oq, om, od = orc.KdTree(tgt).correspondences(src)
+            if kind == "trimmed":
+                oq, om, od = rej.reject_trimmed(oq, om, od, ratio)
+            else:
+                oq, om, od, med = rej.reject_median_distance(oq, om, od, 2.0 * ratio)
+                assert r.getMedianDistance() == med
+            # Trimmed hands its list back ordered by distance; ties by query index on both sides
+            assert np.array_equal(q, oq) and np.array_equal(m, om) and np.array_equal(d, od), (kind, ratio)
+
+
 def test_icp_with_rejectors_vs_oracle(gpu, orc, bunny):
     # test/registration/test_registration.cpp:336-382 style: ICP + median + one-to-one rejectors
     import pcl_amd
