@@ -115,44 +115,104 @@ __global__ void radius_emit_kernel(const uint64_t* __restrict__ keys, const unsi
 }
 
 // NormalEstimation with setRadiusSearch (features/include/pcl/features/impl/normal_3d.hpp:48-95 through
-// Feature::compute, impl/feature.hpp:140-155): plane fit over ALL neighbours within the radius, in the
-// order radiusSearch returns them (ascending distance, ties by index).  One thread per query walks its
-// sorted segment; fewer than 3 neighbours -> NaN (normal_3d.h:308-322).
-// `q`: the queries (the index's own points for search surface == input); by_slot: the result goes to out[q[i].w] (queries
-// of another cloud, Feature::setSearchSurface) instead of out[i].
-__global__ __launch_bounds__(BLOCK) void normals_from_radius_kernel(IndexView ix, const uint32_t* __restrict__ rank,
-                                                                    const float4* __restrict__ q, int by_slot,
-                                                                    const uint64_t* __restrict__ keys,
-                                                                    const unsigned long long* __restrict__ offsets,
-                                                                    unsigned long long base, uint32_t q_begin,
-                                                                    uint32_t q_end, float vx, float vy, float vz,
-                                                                    float4* __restrict__ nrm_sorted,
-                                                                    unsigned long long* __restrict__ nan_count) {
-  const uint32_t i = q_begin + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= q_end) return;
-  const float4 p = q[i];
-  const unsigned long long b = offsets[i] - base, cnt = offsets[i + 1] - offsets[i];
-  const float qnan = __builtin_nanf("");
-  float4 out;
-  if (cnt < 3) {
-    out = make_float4(qnan, qnan, qnan, qnan);
-    atomicAdd(nan_count, 1ull);
-  } else {
-    Cov cv;
-    const float4 p0 = ix.pts[rank[uint32_t(keys[b])]];
-    cv.start(p0.x, p0.y, p0.z);
-    for (unsigned long long c = 0; c < cnt; ++c) {
-      const float4 pc = ix.pts[rank[uint32_t(keys[b + c])]];
-      cv.add(pc.x, pc.y, pc.z);
-    }
-    float cov[9];
-    cv.finish(int(cnt), cov);
-    float nx, ny, nz, curv;
-    solve_plane(cov, nx, ny, nz, curv);
-    flip_to_viewpoint(p.x, p.y, p.z, vx, vy, vz, nx, ny, nz);
-    out = make_float4(nx, ny, nz, curv);
+// Feature::compute, impl/feature.hpp:140-155): plane fit over ALL neighbours within the radius.  The covariance is
+// accumulated INSIDE the radius traversal -- no neighbour lists, no sort: computeMeanAndCovarianceMatrix
+// (common/include/pcl/common/impl/centroid.hpp:581-650) shifts by the first neighbour and sums float products in
+// ascending-distance order; here the shift is the query itself (the first neighbour of a self-query, coordinate for
+// coordinate) and the nine float products are summed in DOUBLE in traversal order, rounded to float once at the end --
+// a sum that does not depend on the order to within 2^-53 and sits inside the rounding of the reference's own float
+// sum (the plane fit's contract is |n . n_ref| >= 1 - 1e-5).  Fewer than 3 neighbours -> NaN
+// (normal_3d.h:308-322).
+struct RadiusCov {
+  static constexpr int QPL = 1;
+  float r2, kx, ky, kz;
+  double a[9];
+  uint32_t cnt;
+  __device__ __forceinline__ float worst(int) const { return r2; }
+  __device__ __forceinline__ void add(bool in, float px, float py, float pz) {
+    const float x = in ? __fsub_rn(px, kx) : 0.0f, y = in ? __fsub_rn(py, ky) : 0.0f, z = in ? __fsub_rn(pz, kz) : 0.0f;
+    a[0] += double(__fmul_rn(x, x));
+    a[1] += double(__fmul_rn(x, y));
+    a[2] += double(__fmul_rn(x, z));
+    a[3] += double(__fmul_rn(y, y));
+    a[4] += double(__fmul_rn(y, z));
+    a[5] += double(__fmul_rn(z, z));
+    a[6] += double(x);
+    a[7] += double(y);
+    a[8] += double(z);
+    cnt += in ? 1u : 0u;
   }
-  nrm_sorted[by_slot ? __float_as_uint(p.w) : i] = out;
+  __device__ __forceinline__ void leaf(const float* l, uint32_t, const float* qx, const float* qy, const float* qz) {
+    const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]};
+    const v2f* p = reinterpret_cast<const v2f*>(l);
+#pragma unroll 1  // (unrolled, the scheduler interleaves the eight pairs' double sums and spills 200 registers)
+    for (int j = 0; j < LEAF / 2; ++j) {
+      const v2f r = pair_dist(l, j, qx2, qy2, qz2);
+      const bool in0 = r.x < r2, in1 = r.y < r2;
+      if (__builtin_amdgcn_ballot_w64(in0 || in1) != 0) {  // wave-uniform: most pairs of a leaf are outside every lane's ball
+        const v2f px = p[j], py = p[LEAF / 2 + j], pz = p[LEAF + j];
+        add(in0, px.x, py.x, pz.x);
+        add(in1, px.y, py.y, pz.y);
+      }
+    }
+  }
+};
+
+// `q`: the queries in kd order (the index's own points for search surface == input); BYSLOT: the result goes to
+// out[q[i].w] (queries of another cloud, Feature::setSearchSurface) instead of out[i].
+template <bool BYSLOT>
+__global__ __launch_bounds__(BLOCK, 4) void normals_radius_kernel(IndexView ix, const float4* __restrict__ q, uint32_t nq,
+                                                                  float r2, float vx, float vy, float vz,
+                                                                  float4* __restrict__ nrm,
+                                                                  unsigned long long* __restrict__ nan_count) {
+  __shared__ WaveLdsBoxT<LEAF_BATCH * LEAF_FLOATS * 4> wl_s[WAVES_PER_BLOCK];
+  __shared__ Box topbox_s[TOPCACHE_BOXES];
+  load_top_cache(ix, topbox_s);
+  const int lane = threadIdx.x & (WAVE - 1);
+  const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
+  const GroupSchedule sched(ngroups);
+  TraverseStats ts;
+  GroupFeed feed(sched, ix.sched_ctr);
+  uint32_t nans = 0;
+  for (uint32_t gl = feed.first(sched); gl != GroupFeed::END; gl = feed.advance()) {
+    const uint32_t g = sched.global(gl);
+    if (g >= ngroups) break;
+    feed.ahead(gl);
+    const uint32_t i = g * WAVE + lane;
+    float4 p = make_float4(0, 0, 0, 0);
+    const bool real = i < nq;
+    if (real) p = q[i];
+    const bool vv[1] = {real && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)};
+    const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
+    RadiusCov pol;
+    pol.r2 = r2;
+    pol.kx = p.x;
+    pol.ky = p.y;
+    pol.kz = p.z;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) pol.a[t] = 0.0;
+    pol.cnt = 0;
+    traverse(ix, qx, qy, qz, vv, pol, wl_s[threadIdx.x / WAVE], topbox_s, ts);
+    if (!real) continue;
+    const float qnan = __builtin_nanf("");
+    float4 out = make_float4(qnan, qnan, qnan, qnan);
+    if (vv[0] && pol.cnt >= 3) {
+      Cov cv;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) cv.a[t] = float(pol.a[t]);
+      float cov[9];
+      cv.finish(int(pol.cnt), cov);
+      float nx, ny, nz, curv;
+      solve_plane(cov, nx, ny, nz, curv);
+      flip_to_viewpoint(p.x, p.y, p.z, vx, vy, vz, nx, ny, nz);
+      out = make_float4(nx, ny, nz, curv);
+    } else {
+      ++nans;
+    }
+    nrm[BYSLOT ? __float_as_uint(p.w) : i] = out;
+  }
+  const unsigned long long any = __builtin_amdgcn_ballot_w64(nans != 0);
+  if (any != 0 && nans != 0) atomicAdd(nan_count, (unsigned long long)nans);
 }
 
 
@@ -257,8 +317,7 @@ extern "C" pclhip_status pclhip_radius_search(pclhip_index* ix, const void* quer
   return PCLHIP_OK;
 }
 
-// NormalEstimation::setRadiusSearch path.  Neighbour lists are materialised chunk by chunk (at most
-// ~2^27 (distance, index) keys = 2 GB of sort buffers at a time), never for the whole cloud at once.
+// NormalEstimation::setRadiusSearch path: ONE traversal per query group, the covariance accumulated inside it.
 static pclhip_status normals_radius_impl(pclhip_index* ix, const float4* queries, uint32_t nq, double radius, const float vp[3],
                                          float4* out, uint64_t* nan_count);
 
@@ -294,57 +353,24 @@ static pclhip_status normals_radius_impl(pclhip_index* ix, const float4* queries
   }
   const float r2 = float(radius * radius);  // kdtree_flann.hpp:398
   const IndexView v = ix->view();
-  auto grid_for = [&](uint32_t nq) {
-    const uint32_t ngroups = (nq + WAVE - 1) / WAVE;
-    int grid = int((ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-    const int cap = ctx->num_cus * 4;
-    if (grid > cap) grid = cap;
-    return grid < 1 ? 1 : grid;
-  };
-  uint32_t* counts = nullptr;
-  unsigned long long *wide = nullptr, *off = nullptr, *d_nan = nullptr;
-  PCLHIP_CHECK_HIP(ctx, g.alloc(&counts, size_t(n) * 4));
-  PCLHIP_CHECK_HIP(ctx, g.alloc(&wide, size_t(n + 1) * 8));
-  PCLHIP_CHECK_HIP(ctx, g.alloc(&off, size_t(n + 1) * 8));
+  const uint32_t ngroups = (n + WAVE - 1) / WAVE;
+  int grid = int((ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+  const int cap = ctx->num_cus * 4;
+  if (grid > cap) grid = cap;
+  if (grid < 1) grid = 1;
+  unsigned long long* d_nan = nullptr;
   PCLHIP_CHECK_HIP(ctx, g.alloc(&d_nan, 8));
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_nan, 0, 8, s));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   (void)hipEventRecord(e0, s);
-  PCLHIP_LAUNCH_FED(ctx, (radius_kernel<false, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, v, q, n, r2, counts,
-                     (const unsigned long long*)nullptr, (uint64_t*)nullptr, 0u, 0ull);
-  launch_exclusive_scan_u64(s, counts, n, 0u, wide, off);
-  std::vector<unsigned long long> h_off(size_t(n) + 1);
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(h_off.data(), off, h_off.size() * 8, hipMemcpyDeviceToHost, s));
-  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-  // chunks of whole queries with at most KEY_BUDGET keys (a single query larger than that gets its own chunk)
-  const unsigned long long KEY_BUDGET = 1ull << 27;
-  unsigned long long max_keys = 0;
-  std::vector<uint32_t> cuts{0};
-  for (uint32_t a = 0; a < n;) {
-    uint32_t b = a + 1;
-    while (b < n && h_off[b + 1] - h_off[a] <= KEY_BUDGET) ++b;
-    if (h_off[b] - h_off[a] > max_keys) max_keys = h_off[b] - h_off[a];
-    cuts.push_back(b);
-    a = b;
-  }
-  uint64_t* k0 = nullptr;
-  PCLHIP_CHECK_HIP(ctx, g.alloc(&k0, size_t(max_keys) * 8));
-  uint32_t* long_list = nullptr;
-  PCLHIP_CHECK_HIP(ctx, g.alloc(&long_list, size_t(n + 1) * 4));  // [n]: the counter
-  for (size_t c = 0; c + 1 < cuts.size(); ++c) {
-    const uint32_t a = cuts[c], b = cuts[c + 1];
-    const unsigned long long base = h_off[a], nkeys = h_off[b] - h_off[a];
-    if (nkeys > 0) {
-      PCLHIP_LAUNCH_FED(ctx, (radius_kernel<true, true>), dim3(grid_for(b - a)), dim3(BLOCK), 0, s, v, q, b, r2, counts, off,
-                         k0, a, base);
-      // the chunk's segments start at off[a .. b] - base
-      launch_segmented_sort_u64(s, ctx->num_cus, k0, off, base, a, b, long_list, long_list + n);
-    }
-    hipLaunchKernelGGL(normals_from_radius_kernel, dim3((b - a + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, v, ix->rank, q, self ? 0 : 1, k0,
-                       off, base, a, b, vp[0], vp[1], vp[2], dst, d_nan);
-  }
+  if (self)
+    PCLHIP_LAUNCH_FED(ctx, normals_radius_kernel<false>, dim3(grid), dim3(BLOCK), 0, s, v, q, n, r2, vp[0], vp[1], vp[2], dst,
+                       d_nan);
+  else
+    PCLHIP_LAUNCH_FED(ctx, normals_radius_kernel<true>, dim3(grid), dim3(BLOCK), 0, s, v, q, n, r2, vp[0], vp[1], vp[2], dst,
+                       d_nan);
   (void)hipEventRecord(e1, s);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   unsigned long long h = 0;
