@@ -94,6 +94,7 @@ SIGNATURES = {
     "pclhip_ctx_destroy": (None, [_vp]),
     "pclhip_ctx_synchronize": (C.c_int, [_vp]),
     "pclhip_ctx_reserve": (C.c_int, [_vp, C.c_uint64]),
+    "pclhip_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "pclhip_ctx_stats": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64)]),
     "pclhip_index_build": (C.c_int, [_vp, _vp, _sz, _u64, _vp, _u64, C.POINTER(_vp)]),
     "pclhip_index_build_scaled": (C.c_int, [_vp, _vp, _sz, _u64, _vp, _u64, C.POINTER(C.c_float), C.POINTER(_vp)]),

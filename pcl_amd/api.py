@@ -69,6 +69,10 @@ class Context:
         """Reserve the context's device arena up front (pclhip_ctx_reserve); automatic for the first large cloud otherwise."""
         check(self.lib.pclhip_ctx_reserve(self.h, int(nbytes)), self.h)
 
+    def setOption(self, name, value):
+        """pclhip_ctx_set_option: "served_groups", "icp_lookahead", "cache_mb", "arena_mb" (none changes a result)."""
+        check(self.lib.pclhip_ctx_set_option(self.h, name.encode(), float(value)), self.h)
+
     def stats(self, enable=True):
         """Read (then re-arm or disable) the traversal work counters."""
         out = (C.c_uint64 * 8)()

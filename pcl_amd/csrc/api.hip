@@ -128,12 +128,12 @@ pclhip_status reserve_arena(pclhip_ctx* ctx, size_t bytes) {
 
 // Device bytes a registration pipeline holds per point of its largest cloud: the index (points, SoA copy, normals,
 // boxes, discs, rank: ~60), the build's and the source ordering's scratch (~100), the source arrays of a registration
-// (copies, matches, distances: ~50) and a VoxelGrid pass (~60) -- 288 with slack.  PCLHIP_ARENA_MB overrides (0: none).
+// (copies, matches, distances: ~50) and a VoxelGrid pass (~60) -- 288 with slack.  Option "arena_mb" overrides (0: none).
 void dev_reserve_for_points(pclhip_ctx* ctx, uint64_t points) {
   if (ctx == nullptr || ctx->arena_tried || ctx->arena != nullptr || points < 1000000ull) return;
   ctx->arena_tried = true;
   size_t want = size_t(points) * 288;
-  if (const char* e = getenv("PCLHIP_ARENA_MB")) want = size_t(strtoull(e, nullptr, 10)) << 20;
+  if (ctx->opt_arena_mb >= 0) want = size_t(ctx->opt_arena_mb) << 20;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 2) want = free_b / 2;
   if (want > 0) (void)reserve_arena(ctx, want);
@@ -362,13 +362,7 @@ float float_at_most(double v) {  // largest float <= v  (v >= 0)
 namespace pclhip {
 // The runtime loads a translation unit's code object at the first use of one of its kernels: that is a context's
 // business, not the first timed launch's (the driver's fresh box showed the first index build at 12x the steady one).
-// PCLHIP_PRELOAD=0 leaves it lazy.
 void preload_code_objects(pclhip_ctx* ctx) {
-  static const bool on = [] {
-    const char* e = getenv("PCLHIP_PRELOAD");
-    return !(e && atoi(e) == 0);
-  }();
-  if (!on) return;
   preload_search_kernels(ctx);
   preload_index_build_kernels();
   preload_voxelgrid_kernels();
@@ -444,7 +438,6 @@ static pclhip_status ctx_create_impl(int device, void* stream, bool adopt, pclhi
     PCLHIP_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->own_stream = true;
   }
-  if (const char* e = getenv("PCLHIP_CACHE_MB")) ctx->cache_limit = size_t(strtoull(e, nullptr, 10)) << 20;
   {  // never hold back more than a quarter of the device's memory
     const size_t quarter = size_t(prop.totalGlobalMem) / 4;
     if (ctx->cache_limit > quarter) ctx->cache_limit = quarter;
@@ -464,6 +457,28 @@ pclhip_status pclhip_ctx_reserve(pclhip_ctx* ctx, uint64_t bytes) {
   const pclhip_status st = pclhip::reserve_arena(ctx, size_t(bytes));
   if (st != PCLHIP_OK) pclhip::set_error(ctx, "could not reserve the arena (allocations fall back to hipMalloc)");
   return st;
+}
+
+pclhip_status pclhip_ctx_set_option(pclhip_ctx* ctx, const char* name, double value) {
+  if (!ctx || !name) return PCLHIP_ERR_INVALID;
+  if (!(value >= 0.0) || value > 1e9) {
+    pclhip::set_error(ctx, "option values are non-negative numbers");
+    return PCLHIP_ERR_INVALID;
+  }
+  if (!std::strcmp(name, "served_groups")) {
+    ctx->opt_served_groups = value != 0.0 ? 1 : 0;
+  } else if (!std::strcmp(name, "icp_lookahead")) {
+    ctx->opt_lookahead = int(value);
+  } else if (!std::strcmp(name, "cache_mb")) {
+    std::lock_guard<std::mutex> lock(ctx->cache_mutex);
+    ctx->cache_limit = size_t(value) << 20;
+  } else if (!std::strcmp(name, "arena_mb")) {
+    ctx->opt_arena_mb = (long long)value;
+  } else {
+    pclhip::set_error(ctx, "unknown option (served_groups, icp_lookahead, cache_mb, arena_mb)");
+    return PCLHIP_ERR_INVALID;
+  }
+  return PCLHIP_OK;
 }
 
 void pclhip_ctx_destroy(pclhip_ctx* ctx) {
@@ -982,9 +997,6 @@ static void icp_free_source(pclhip_icp* icp) {
   icp->src_records_n = 0;
   if (icp->own_block) (void)dev_free(icp->ctx, icp->own_block);
   icp->own_block = nullptr;
-  if (icp->grec_block) (void)dev_free(icp->ctx, icp->grec_block);
-  icp->grec_block = nullptr;
-  icp->grec_groups = 0;
   icp->own_groups = 0;
   if (icp->src_sorted0) (void)dev_free(icp->ctx, icp->src_sorted0);
   if (icp->src_cur) (void)dev_free(icp->ctx, icp->src_cur);
@@ -1242,152 +1254,32 @@ pclhip_status pclhip_icp_align(pclhip_icp* icp, const pclhip_icp_params* params,
                                pclhip_icp_result* res) {
   if (!icp || !params || !res) return PCLHIP_ERR_INVALID;
   pclhip_ctx* ctx = icp->ctx;
-  static const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   std::memset(res, 0, sizeof *res);
   // The loop runs on the device (icp_loop.hip): no read-back, host solve or reset copy between iterations; a
   // rejector chain and reciprocal correspondences are part of it (counts, ranks and thresholds stay in device memory; the
-  // source index of the reciprocal test is built once and refitted per iteration: rejectors.hip).  The host-driven loop
-  // below remains for A/B and for the twin test (PCLHIP_ICP_HOST_LOOP=1).
-  static const bool host_loop = [] {
-    const char* e = getenv("PCLHIP_ICP_HOST_LOOP");
-    return e && atoi(e) == 1;
-  }();
+  // source index of the reciprocal test is built once and refitted per iteration: rejectors.hip).  A host-driven loop
+  // is what a caller composes from pclhip_icp_iterate + pclhip_solve_transformation + pclhip_convergence_has_converged
+  // (tests/test_gpu_loop.py does, as the twin of this one).
   {
     const pclhip_status sf = sharded_filters_ok(icp);
     if (sf != PCLHIP_OK) return sf;
   }
-  if (!host_loop) {
-    if (params->mode != PCLHIP_ICP_POINT_TO_POINT && params->mode != PCLHIP_ICP_POINT_TO_PLANE &&
-        params->mode != PCLHIP_ICP_SYMMETRIC) {
-      set_error(ctx, "unknown ICP mode");
-      return PCLHIP_ERR_INVALID;
-    }
-    if (params->mode == PCLHIP_ICP_SYMMETRIC && icp->src_nrm_cur == nullptr) {
-      set_error(ctx, "the symmetric objective needs source normals (pclhip_icp_set_source_normals)");
-      return PCLHIP_ERR_STATE;
-    }
-    if (params->mode != PCLHIP_ICP_POINT_TO_POINT && !icp->target->has_normals) {
-      set_error(ctx, "point-to-plane ICP needs target normals (pclhip_normals / pclhip_index_set_normals)");
-      return PCLHIP_ERR_STATE;
-    }
-    PCLHIP_REQUIRE(ctx, icp->src_cur != nullptr, "no source cloud set");
-    PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    return icp_align_device(icp, params, guess, res);
+  if (params->mode != PCLHIP_ICP_POINT_TO_POINT && params->mode != PCLHIP_ICP_POINT_TO_PLANE &&
+      params->mode != PCLHIP_ICP_SYMMETRIC) {
+    set_error(ctx, "unknown ICP mode");
+    return PCLHIP_ERR_INVALID;
   }
-  pclhip_status st = pclhip_icp_reset(icp);
-  if (st != PCLHIP_OK) return st;
-  hipEvent_t t0, t1;
-  PCLHIP_CHECK_HIP(ctx, hipEventCreate(&t0));
-  PCLHIP_CHECK_HIP(ctx, hipEventCreate(&t1));
-  (void)hipEventRecord(t0, ctx->stream);
-
-  float final_T[16], Tk[16], T_apply[16];
-  std::memcpy(final_T, guess ? guess : I4, sizeof final_T);  // :123
-  std::memcpy(T_apply, guess ? guess : I4, sizeof T_apply);  // :126-131 applied by the first launch
-  std::memcpy(Tk, I4, sizeof Tk);
-  // :157-161 criteria setup (rotation threshold default 0.99999, default_convergence_criteria.h:298)
-  const int max_iterations = params->max_iterations;
-  const double mse_rel = params->euclidean_fitness_epsilon;
-  const double trans_thr = params->transformation_epsilon;
-  const double rot_thr = params->transformation_rotation_epsilon > 0 ? params->transformation_rotation_epsilon : 0.99999;
-  const double mse_abs = params->mse_threshold_absolute;
-  const int max_similar = params->max_iterations_similar_transforms;
-
-  int nr_iterations = 0;
-  bool converged = false;
-  double sums[PCLHIP_ICP_NSUMS];
-  double kernel_ms = 0;
-  enum { NOT_CONVERGED = 0, ITERATIONS, TRANSFORM, ABS_MSE, REL_MSE, NO_CORRESPONDENCES, FAILURE_AFTER_MAX_ITERATIONS };
-  do {
-    st = pclhip_icp_iterate(icp, T_apply, params->max_correspondence_distance, params->mode, sums);
-    if (st != PCLHIP_OK) break;
-    kernel_ms += icp->last_kernel_ms;
-    const double ncorr = sums[28];
-    res->num_correspondences = uint64_t(ncorr);
-    if (ncorr < double(params->min_number_correspondences)) {  // :204-213
-      icp->convergence_state = NO_CORRESPONDENCES;
-      converged = false;
-      break;
-    }
-    pclhip_solve_transformation(sums, params->mode, Tk);  // :216-217
-    std::memcpy(T_apply, Tk, sizeof T_apply);              // :220 (applied by the next launch)
-    mat4_mul_f32(Tk, final_T, final_T);                    // :223
-    ++nr_iterations;
-    const double mse = sums[27] / ncorr;  // calculateMSE, default_convergence_criteria.h:262-270
-    res->mse = mse;
-
-    // ---- hasConverged ----
-    if (icp->convergence_state != NOT_CONVERGED) {
-      icp->iterations_similar_transforms = 0;
-      icp->convergence_state = NOT_CONVERGED;
-    }
-    bool is_similar = false;
-    bool done = false;
-    if (nr_iterations >= max_iterations) {
-      if (!params->failure_after_max_iterations) {
-        icp->convergence_state = ITERATIONS;
-        converged = true;
-        done = true;
-      } else {
-        icp->convergence_state = FAILURE_AFTER_MAX_ITERATIONS;
-      }
-    }
-    if (!done) {
-      const double cos_angle = 0.5 * double(Tk[0] + Tk[5] + Tk[10] - 1);
-      const double translation_sqr = double(Tk[3] * Tk[3] + Tk[7] * Tk[7] + Tk[11] * Tk[11]);
-      if (cos_angle >= rot_thr && translation_sqr <= trans_thr) {
-        if (icp->iterations_similar_transforms >= max_similar) {
-          icp->convergence_state = TRANSFORM;
-          converged = true;
-          done = true;
-        }
-        is_similar = true;
-      }
-    }
-    if (!done) {
-      if (std::fabs(mse - icp->prev_mse) < mse_abs) {
-        if (icp->iterations_similar_transforms >= max_similar) {
-          icp->convergence_state = ABS_MSE;
-          converged = true;
-          done = true;
-        }
-        is_similar = true;
-      }
-    }
-    if (!done) {
-      if (std::fabs(mse - icp->prev_mse) / icp->prev_mse < mse_rel) {
-        if (icp->iterations_similar_transforms >= max_similar) {
-          icp->convergence_state = REL_MSE;
-          converged = true;
-          done = true;
-        }
-        is_similar = true;
-      }
-    }
-    if (!done) {
-      if (is_similar)
-        ++icp->iterations_similar_transforms;
-      else
-        icp->iterations_similar_transforms = 0;
-      icp->prev_mse = mse;
-      converged = false;
-    }
-  } while (icp->convergence_state == NOT_CONVERGED);
-  (void)hipEventRecord(t1, ctx->stream);
-  (void)hipStreamSynchronize(ctx->stream);
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, t0, t1);
-  (void)hipEventDestroy(t0);
-  (void)hipEventDestroy(t1);
-  if (st != PCLHIP_OK) return st;
-  std::memcpy(res->final_transformation, final_T, sizeof final_T);
-  std::memcpy(res->last_transformation, Tk, sizeof Tk);
-  res->nr_iterations = nr_iterations;
-  res->converged = converged ? 1 : 0;
-  res->convergence_state = icp->convergence_state;
-  res->gpu_ms = ms;
-  res->gpu_ms_search_kernel = kernel_ms;
-  return PCLHIP_OK;
+  if (params->mode == PCLHIP_ICP_SYMMETRIC && icp->src_nrm_cur == nullptr) {
+    set_error(ctx, "the symmetric objective needs source normals (pclhip_icp_set_source_normals)");
+    return PCLHIP_ERR_STATE;
+  }
+  if (params->mode != PCLHIP_ICP_POINT_TO_POINT && !icp->target->has_normals) {
+    set_error(ctx, "point-to-plane ICP needs target normals (pclhip_normals / pclhip_index_set_normals)");
+    return PCLHIP_ERR_STATE;
+  }
+  PCLHIP_REQUIRE(ctx, icp->src_cur != nullptr, "no source cloud set");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  return icp_align_device(icp, params, guess, res);
 }
 
 namespace {

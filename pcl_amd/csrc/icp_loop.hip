@@ -305,19 +305,10 @@ pclhip_status run_loop(pclhip_icp* icp, const pclhip_icp_params* p, int window, 
   long enq = 0, done = 0;
   bool feed = true;
   pclhip_status st = PCLHIP_OK;
-  static const bool debug = getenv("PCLHIP_LOOP_DEBUG") != nullptr;
-  double t_enq = 0, t_wait = 0;
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  struct Report {
-    const bool on; const double& a; const double& b; const long& n;
-    ~Report() { if (on) fprintf(stderr, "[pclhip loop] %ld steps: enqueue %.3f ms, waiting %.3f ms (host)\n", n, a, b); }
-  } report{debug, t_enq, t_wait, done};
   while (done < enq || (feed && (max_steps < 0 || enq < max_steps))) {
     while (feed && (max_steps < 0 || enq < max_steps) && enq - done < window) {
       hipEvent_t* ev = &icp->step_events[size_t(enq % icp->steps_capacity) * 4];
-      const double t0 = debug ? now() : 0;
       st = launch_icp_iterate(icp, nullptr, fmax2, use_max, p->mode, ev);
-      if (debug) t_enq += now() - t0;
       if (st != PCLHIP_OK) {
         (void)hipStreamSynchronize(ctx->stream);
         return st;
@@ -326,9 +317,7 @@ pclhip_status run_loop(pclhip_icp* icp, const pclhip_icp_params* p, int window, 
     }
     if (done == enq) break;
     hipEvent_t* ev = &icp->step_events[size_t(done % icp->steps_capacity) * 4];
-    const double tw = debug ? now() : 0;
     PCLHIP_CHECK_HIP(ctx, hipEventSynchronize(ev[3]));
-    if (debug) t_wait += now() - tw;
     const IcpStepRecord rec = icp->steps[done % icp->steps_capacity];
     StepTimes t;
     if (feed) {  // launches queued behind a finished alignment fell through: no record, no times
@@ -347,14 +336,8 @@ pclhip_status run_loop(pclhip_icp* icp, const pclhip_icp_params* p, int window, 
   return PCLHIP_OK;
 }
 
-int loop_window() {
-  static const int w = [] {
-    const char* e = getenv("PCLHIP_ICP_LOOKAHEAD");  // iterations queued ahead of the host's knowledge
-    const int v = e ? atoi(e) : 1;
-    return (v < 0 ? 0 : v) + 1;
-  }();
-  return w;
-}
+// iterations in flight: the one the host waits for + those queued ahead of its knowledge (option "icp_lookahead")
+int loop_window(const pclhip_ctx* ctx) { return (ctx->opt_lookahead < 0 ? 0 : ctx->opt_lookahead) + 1; }
 
 }  // namespace
 
@@ -369,7 +352,7 @@ pclhip_status icp_align_device(pclhip_icp* icp, const pclhip_icp_params* params,
   std::memcpy(res->final_transformation, guess ? guess : kIdentity, sizeof res->final_transformation);
   std::memcpy(res->last_transformation, kIdentity, sizeof res->last_transformation);
   double search_ms = 0, total_ms = 0;
-  st = run_loop(icp, params, loop_window(), -1, [&](const IcpStepRecord& r, const StepTimes& t) {
+  st = run_loop(icp, params, loop_window(icp->ctx), -1, [&](const IcpStepRecord& r, const StepTimes& t) {
     search_ms += t.kernels_ms;
     total_ms += t.step_ms;
     icp->last_kernel_ms = t.kernels_ms;

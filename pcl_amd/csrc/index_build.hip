@@ -1159,10 +1159,6 @@ pclhip_status build_boxes(pclhip_index* ix) {
         }
         ix->leaf_diag2 = float(sum / double(c));
         ix->disc_thickness = rs > 0.0 ? float(hs / rs) : 1.0f;
-        static const bool debug = getenv("PCLHIP_INDEX_DEBUG") != nullptr;
-        if (debug)
-          std::fprintf(stderr, "pclhip index: %u points, %u leaves, mean leaf diagonal^2 %.4g, disc thickness ratio %.4f\n",
-                       ix->n, c, double(ix->leaf_diag2), double(ix->disc_thickness));
       }
     } else {
       const uint64_t threads = uint64_t(c) * WAVE;
@@ -1248,16 +1244,8 @@ pclhip::IndexView pclhip_index::view() const {
   v.pts = pts;
   v.soa = soa;
   v.nrm = nrm;
-  static const bool use_discs = [] {  // A/B: PCLHIP_DISC=0 searches with the axis-aligned boxes only
-    const char* e = getenv("PCLHIP_DISC");
-    return !(e && atoi(e) == 0);
-  }();
-  v.disc = use_discs ? disc : nullptr;
-  static const float factor = [] {  // stand-off (squared, in leaf diagonals squared) from which discs replace boxes
-    const char* e = getenv("PCLHIP_DISC_FACTOR");
-    return e ? float(atof(e)) : 4.0f;
-  }();
-  v.disc_from = factor * leaf_diag2;
+  v.disc = disc;
+  v.disc_from = 4.0f * leaf_diag2;  // stand-off (squared, in leaf diagonals squared) from which discs replace boxes
   v.lv = lv_dev;
   for (int l = 0; l < pclhip::MAX_LEVELS; ++l) {
     v.box[l] = box[l];

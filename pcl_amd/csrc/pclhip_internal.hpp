@@ -175,6 +175,10 @@ struct pclhip_ctx {
   std::unordered_map<void*, size_t> live;         // blocks handed out
   size_t cached_bytes = 0;
   size_t cache_limit = size_t(16384) << 20;
+  // pclhip_ctx_set_option (none of them changes a result)
+  int opt_served_groups = 1;            // target sharding: the device-driven loop walks the served groups only
+  int opt_lookahead = 1;                // pclhip_icp_align: iterations queued ahead of the host's knowledge
+  long long opt_arena_mb = -1;          // automatic arena: -1 = 288 B per point of the first large cloud, 0 = none
   std::mutex cache_mutex;
   // Small pinned host blocks (control blocks, step rings, mirrored states of the registrations) are kept for the
   // context's lifetime: hipHostFree synchronises the device (170 us each, three per registration object).
@@ -285,9 +289,6 @@ struct pclhip_icp {
   uint32_t* own_tot = nullptr;           // [4] tot[0] = served groups
   uint2* own_partial = nullptr;          // scan scratch
   pclhip::OwnedState* own_state = nullptr;
-  // leaf lists of the source's groups kept across seeded iterations (search.hip, -DPCLHIP_GROUP_LISTS=1 builds only)
-  void* grec_block = nullptr;
-  uint32_t grec_groups = 0;
 };
 
 namespace pclhip {
@@ -383,6 +384,10 @@ pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stri
                             uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
                             uint32_t* rank_or_null, const float* scale = nullptr);
 pclhip_status build_boxes(pclhip_index* ix);
+// shard_dev.hip: partition / halo selection of a cloud in device memory (shard.cpp's results, bit for bit)
+pclhip_status partition_slabs_device(const void* points, size_t stride, uint64_t n, int n_slabs, float* regions);
+pclhip_status select_region_device(const void* points, size_t stride, uint64_t n, const float lo[3], const float hi[3],
+                                   int32_t* out_indices, uint64_t capacity, uint64_t* out_count);
 pclhip_status refit_boxes(pclhip_index* ix);  // the points of a built index moved: boxes again, stream-ordered
 int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns);
 pclhip_status launch_estimate_pairs(pclhip_ctx* ctx, int mode, const float4* src, const float4* src_nrm,

@@ -24,9 +24,7 @@ namespace pclhip {
 
 constexpr int BLOCK = 256;
 constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
-#ifndef PCLHIP_COLD_RUN
-#define PCLHIP_COLD_RUN 4  // groups per run of the stand-off search (icp_cold_search_body)
-#endif
+constexpr uint32_t COLD_RUN = 4;  // groups per run of the stand-off search (icp_cold_search_body)
 
 // =================================================================================================
 // batched exact k-NN
@@ -747,7 +745,7 @@ pclhip_status launch_gicp_covariances(pclhip_index* ix, int k, double eps, doubl
 }
 
 // =================================================================================================
-// fused ICP iteration
+// ICP iteration
 // =================================================================================================
 struct Mat34 {
   float m[12];  // rows 0..2 of the 4x4
@@ -764,155 +762,10 @@ __device__ __forceinline__ float xform_row(float r0, float r1, float r2, float r
 
 constexpr int NS = PCLHIP_ICP_NSUMS;
 
-template <int MODE, int MINW>
-__global__ __launch_bounds__(BLOCK, MINW) void icp_iterate_kernel(IndexView ix, float4* __restrict__ cur, uint32_t ns,
-                                                            Mat34 T, int order, float bound, int use_max,
-                                                            uint32_t* __restrict__ match_pos,
-                                                            uint32_t* __restrict__ match,
-                                                            float* __restrict__ match_d2,
-                                                            double* __restrict__ partials,
-                                                            unsigned long long* gstats) {
-  __shared__ WaveLds wl_s[WAVES_PER_BLOCK];
-  __shared__ Box topbox_s[TOPCACHE_BOXES];
-  load_top_cache(ix, topbox_s);
-  __shared__ double red_s[WAVES_PER_BLOCK][NS];
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int wave = threadIdx.x / WAVE;
-  const uint32_t ngroups = (ns + WAVE - 1) / WAVE;
-  const GroupSchedule sched(ngroups);
-  TraverseStats ts;
-  constexpr int NACC = (MODE == PCLHIP_ICP_POINT_TO_PLANE) ? 27 : 15;
-  double acc[NACC];
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-  double sum_d2 = 0.0;
-  uint32_t cnt = 0, skipped = 0;
-
-  // fixed shares (no GroupFeed): the sums of a block must not depend on which wave was through first
-  for (uint32_t gl = sched.first(); gl < sched.groups_per_xcd; gl += sched.step()) {
-    const uint32_t g = sched.global(gl);
-    if (g >= ngroups) break;
-    const uint32_t i = g * WAVE + lane;
-    bool valid = i < ns;
-    float4 p = make_float4(0, 0, 0, 0);
-    if (valid) p = cur[i];
-    const bool in_range = valid;
-    valid = valid && isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
-    if (valid) {  // cur <- T * cur (non-finite points are left untouched, icp.hpp:97-98)
-      const float x = xform_row(T.m[0], T.m[1], T.m[2], T.m[3], p.x, p.y, p.z, order);
-      const float y = xform_row(T.m[4], T.m[5], T.m[6], T.m[7], p.x, p.y, p.z, order);
-      const float z = xform_row(T.m[8], T.m[9], T.m[10], T.m[11], p.x, p.y, p.z, order);
-      p.x = x; p.y = y; p.z = z;
-      cur[i] = p;
-    }
-    // fast minimum-distance traversal, seeded with the previous iteration's match (a valid upper
-    // bound: the same target point, re-measured against the moved query)
-    NN1Min fast;
-    fast.init(bound);
-    const uint32_t seed_pos = in_range ? match_pos[i] : NO_INDEX;
-    if (valid && seed_pos != NO_INDEX) {
-      const float4 t0 = ix.pts[seed_pos];
-      fast.seed(0, l2_simple(p.x, p.y, p.z, t0.x, t0.y, t0.z), seed_pos);
-    }
-    const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
-    const bool vv[1] = {valid};
-    traverse<NN1Min, true>(ix, qx, qy, qz, vv, fast, wl_s[wave], topbox_s, ts);
-    fast.resolve(ix, qx, qy, qz);
-    NN1 pol;
-    pol.soa = ix.soa;
-    pol.key = KEY_NONE;
-    pol.pos = fast.bestpos[0];
-    if (fast.bestpos[0] != NO_INDEX) pol.key = make_key(fast.best[0], __float_as_uint(ix.pts[fast.bestpos[0]].w));
-    {
-      const bool redo[1] = {valid && (fast.tie[0] || (fast.bestpos[0] == NO_INDEX && !use_max))};
-      if (__builtin_amdgcn_ballot_w64(redo[0]) != 0) {  // exact (distance, index) policy for tie lanes
-        NN1 ex = pol;
-        traverse<NN1, true>(ix, qx, qy, qz, redo, ex, wl_s[wave], topbox_s, ts);
-        if (redo[0]) pol = ex;
-      }
-    }
-    const uint32_t mid = key_index(pol.key);
-    const bool found = valid && mid != NO_INDEX;
-    if (in_range) {
-      match[i] = found ? mid : NO_INDEX;
-      match_pos[i] = found ? pol.pos : NO_INDEX;
-      match_d2[i] = found ? key_dist(pol.key) : __builtin_inff();
-    }
-    if (found) {
-      ++cnt;
-      sum_d2 += double(key_dist(pol.key));
-      const float4 t = ix.pts[pol.pos];
-      if constexpr (MODE == PCLHIP_ICP_POINT_TO_PLANE) {
-        // impl/transformation_estimation_point_to_plane_lls.hpp:182-241
-        const float4 n = ix.nrm[pol.pos];
-        if (isfinite(n.x) && isfinite(n.y) && isfinite(n.z)) {
-          const float sx = p.x, sy = p.y, sz = p.z;
-          const float nx = n.x, ny = n.y, nz = n.z;
-          const double a = double(__fsub_rn(__fmul_rn(nz, sy), __fmul_rn(ny, sz)));
-          const double b = double(__fsub_rn(__fmul_rn(nx, sz), __fmul_rn(nz, sx)));
-          const double c = double(__fsub_rn(__fmul_rn(ny, sx), __fmul_rn(nx, sy)));
-          acc[0] += a * a;  acc[1] += a * b;  acc[2] += a * c;
-          acc[3] += a * double(nx); acc[4] += a * double(ny); acc[5] += a * double(nz);
-          acc[6] += b * b;  acc[7] += b * c;
-          acc[8] += b * double(nx); acc[9] += b * double(ny); acc[10] += b * double(nz);
-          acc[11] += c * c;
-          acc[12] += c * double(nx); acc[13] += c * double(ny); acc[14] += c * double(nz);
-          acc[15] += double(__fmul_rn(nx, nx)); acc[16] += double(__fmul_rn(nx, ny));
-          acc[17] += double(__fmul_rn(nx, nz)); acc[18] += double(__fmul_rn(ny, ny));
-          acc[19] += double(__fmul_rn(ny, nz)); acc[20] += double(__fmul_rn(nz, nz));
-          // :235  nx*dx + ny*dy + nz*dz - nx*sx - ny*sy - nz*sz, float, left to right
-          float df = __fmul_rn(nx, t.x);
-          df = __fadd_rn(df, __fmul_rn(ny, t.y));
-          df = __fadd_rn(df, __fmul_rn(nz, t.z));
-          df = __fsub_rn(df, __fmul_rn(nx, sx));
-          df = __fsub_rn(df, __fmul_rn(ny, sy));
-          df = __fsub_rn(df, __fmul_rn(nz, sz));
-          const double d = double(df);
-          acc[21] += a * d; acc[22] += b * d; acc[23] += c * d;
-          acc[24] += double(nx) * d; acc[25] += double(ny) * d; acc[26] += double(nz) * d;
-        } else {
-          ++skipped;
-        }
-      } else {
-        // raw sums for umeyama (common/include/pcl/common/impl/eigen.hpp:696-712)
-        const double sx = p.x, sy = p.y, sz = p.z, tx = t.x, ty = t.y, tz = t.z;
-        acc[0] += sx; acc[1] += sy; acc[2] += sz;
-        acc[3] += tx; acc[4] += ty; acc[5] += tz;
-        acc[6] += tx * sx; acc[7] += tx * sy; acc[8] += tx * sz;
-        acc[9] += ty * sx; acc[10] += ty * sy; acc[11] += ty * sz;
-        acc[12] += tz * sx; acc[13] += tz * sy; acc[14] += tz * sz;
-      }
-    }
-  }
-  flush_stats(ts, gstats);
-  // wave tree-reduce (shuffles), then fixed-order block reduce through LDS -> deterministic
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) {
-    const double s = wave_sum_d(acc[i]);
-    if (lane == 0) red_s[wave][i] = s;
-  }
-  {
-    const double s0 = wave_sum_d(sum_d2), s1 = wave_sum_d(double(cnt)), s2 = wave_sum_d(double(skipped));
-    if (lane == 0) {
-      for (int i = NACC; i < NS; ++i) red_s[wave][i] = 0.0;
-      red_s[wave][27] = s0;
-      red_s[wave][28] = s1;
-      red_s[wave][29] = s2;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < NS) {
-    double s = 0.0;
-#pragma unroll
-    for (int w = 0; w < WAVES_PER_BLOCK; ++w) s += red_s[w][threadIdx.x];
-    partials[size_t(blockIdx.x) * NS + threadIdx.x] = s;
-  }
-}
-
 // -------------------------------------------------------------------------------------------------
-// Two-kernel variant of the iteration (PCLHIP_ICP_FUSED=0): a search-only kernel without the 27 fp64
-// accumulators (fewer registers, room to software-pipeline the next group's loads) followed by a
-// streaming accumulate kernel.  Same results as the fused kernel up to fp64 summation order.
+// The iteration is two kernels: a search-only kernel without the 27 fp64 accumulators of the plane system (fewer
+// registers, room to software-pipeline the next group's loads) followed by a streaming accumulate kernel.  (Round 1's
+// single-kernel form was measured slower and left the library in round 4.)
 // With `ctl` (device-driven loop, icp_loop.hip) the transform, the "alignment starts here" flag and the stop
 // flag come from device memory, written by the icp_solve_kernel of the previous iteration: iterations are
 // queued back to back and the host never sits between them.  A starting alignment reads the pristine
@@ -923,21 +776,6 @@ __device__ __forceinline__ bool in_region(const RegionBox& r, float x, float y, 
 
 // no policy of the ICP search kernels stages the w chunks: 3 KB of staging per wave (see WaveLdsT)
 typedef WaveLdsT<3072> IcpWaveLds;
-
-// -DPCLHIP_GROUP_LISTS=1: the seeded ICP search keeps every group's leaf list across iterations (traverse.hpp: GroupRec) and
-// searches from it while the group's motion allows.  Off by default: exact (tests run it on the CPU emulation), not yet timed.
-#ifndef PCLHIP_GROUP_LISTS
-#define PCLHIP_GROUP_LISTS 0
-#endif
-struct GroupRecArrays {
-  uint32_t* ids;  // [groups][GREC_CAP]
-  float4* hdr;    // [groups][2]
-};
-#if PCLHIP_GROUP_LISTS
-#define PCLHIP_GREC_ARG(x) , x
-#else
-#define PCLHIP_GREC_ARG(x)
-#endif
 
 // OWNED (target sharding in the device-driven loop, pclhip_internal.hpp: OwnedGroups): the groups come from the launch's list
 // of served groups, and a group whose working copy missed some launches is brought up to date first.
@@ -960,9 +798,8 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
                                                 float bound, int flags, uint32_t* __restrict__ match_pos,
                                                 uint32_t* __restrict__ match, float* __restrict__ match_d2,
                                                 unsigned long long* gstats, IcpWaveLds* wl_s, Box* topbox_s,
-                                                const OG& og = OG(), GroupRecArrays ga = {nullptr, nullptr}) {
+                                                const OG& og = OG()) {
   static_assert(!OWNED || Q == 1, "served-group lists are per 64-point group");
-  static_assert(!PCLHIP_GROUP_LISTS || Q == 1, "leaf lists are kept per 64-query group");
   bool restart = false;
   if (ctl != nullptr) {
     if (ctl->stop != 0) return;  // the alignment ended before this (speculatively queued) launch
@@ -1091,31 +928,6 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
     if ((flags & 2) && hm != 0) start_leaf = uint32_t(__builtin_amdgcn_readlane(int(seed_pos[0]), __builtin_ctzll(hm))) / LEAF;
     // no lane has a seed: the first iteration of an alignment, queries stand off the target -> disc bounds
     ICP_LAP(5);
-#if PCLHIP_GROUP_LISTS
-    if (ga.ids != nullptr) {
-      GroupRec gr;
-      gr.ids = ga.ids + size_t(gcur) * GREC_CAP;
-      gr.hdr = ga.hdr + 2 * size_t(gcur);
-      bool from_record = false;
-      if (!restart) from_record = traverse_recorded(ix, qx, qy, qz, valid, fast, wl_s[wave], ts, gr);
-      if (!from_record) {
-#ifndef PCLHIP_GREC_DEFER
-#define PCLHIP_GREC_DEFER 1  // tight searches collect their lists during the walk and evaluate them as one afterwards
-#endif
-        gr.defer = PCLHIP_GREC_DEFER != 0;
-        traverse<NN1MinT<Q>, SPARSE, IcpWaveLds, GroupRec>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, start_leaf,
-                                                             hm == 0, &gr);
-        if (__builtin_amdgcn_ballot_w64(valid[0]) != 0) {
-          const float Tnow = wave_max_f(valid[0] ? fast.worst(0) : 0.0f);
-          if (gr.ndeferred != 0u)  // the leaves the walk only wrote down: tested and evaluated as ONE list (and the record closed)
-            grec_evaluate(ix, qx, qy, qz, valid, fast, wl_s[wave], ts, gr, gr.ndeferred, gr.lo[0], gr.lo[1], gr.lo[2], gr.hi[0],
-                          gr.hi[1], gr.hi[2], Tnow, __builtin_inff(), gr.ok && gr.count == gr.ndeferred);
-          else
-            gr.store(Tnow, __builtin_inff());
-        }
-      }
-    } else
-#endif
     traverse<NN1MinT<Q>, SPARSE>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, start_leaf, hm == 0);
     ICP_LAP(6);
     fast.resolve(ix, qx, qy, qz);
@@ -1205,7 +1017,7 @@ __device__ __forceinline__ void icp_cold_search_body(const IndexView& ix, float4
   // the 4096 resident waves touched 4096 scattered neighbourhoods -- 2.3 GB fetched per launch): 2.58 -> 2.06 ms at 10M
   // points with runs of 4 (2.27 with 2: too many starts; 2.32 with 8: too coarse a tail).
   const GroupSchedule sched(ngroups);  // the XCD's window and this wave's slot in it
-  constexpr uint32_t RUN = PCLHIP_COLD_RUN;
+  constexpr uint32_t RUN = COLD_RUN;
   const uint32_t nruns = (sched.groups_per_xcd + RUN - 1u) / RUN;
   uint32_t* const run_ctr = ix.sched_ctr + (blockIdx.x % (gridDim.x < 8u ? gridDim.x : 8u)) * uint32_t(SCHED_CTR_STRIDE);
   for (uint32_t run = sched.slot_wave; run < nruns;) {
@@ -1307,19 +1119,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
                                                                  uint32_t* __restrict__ match,
                                                                  float* __restrict__ match_d2,
                                                                  unsigned long long* gstats
-#if PCLHIP_GROUP_LISTS
-                                                                 , GroupRecArrays ga
-#endif
                                                                  ) {
   __shared__ IcpWaveLds wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
-#if PCLHIP_GROUP_LISTS
-  icp_search_body<Q, SPARSE>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
-                             topbox_s, NoOwnedGroups(), ga);
-#else
   icp_search_body<Q, SPARSE>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
                              topbox_s);
-#endif
 }
 
 #ifndef PCLHIP_COLD_MINW
@@ -1339,9 +1143,6 @@ __global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_search_dual_kerne
     IndexView ix, float4* __restrict__ cur, const float4* __restrict__ src0, uint32_t ns, Mat34 T,
     const IcpControl* __restrict__ ctl, RegionBox region, int order, float bound, int flags, float so_from,
     uint32_t* __restrict__ match_pos, uint32_t* __restrict__ match, float* __restrict__ match_d2, unsigned long long* gstats
-#if PCLHIP_GROUP_LISTS
-    , GroupRecArrays ga
-#endif
     ) {
   __shared__ IcpWaveLds wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
@@ -1349,13 +1150,8 @@ __global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_search_dual_kerne
     icp_cold_search_body(ix, cur, src0, ns, T, ctl, region, order, bound, flags, so_from, match_pos, match, match_d2, gstats,
                          wl_s, topbox_s);
   else
-#if PCLHIP_GROUP_LISTS
-    icp_search_body<1, true>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
-                             topbox_s, NoOwnedGroups(), ga);
-#else
     icp_search_body<1, true>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
                              topbox_s);
-#endif
 }
 
 // The same two bodies over the launch's list of SERVED groups (target sharding in the device-driven loop): `standoff`
@@ -1958,34 +1754,7 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(IcpControl* __restrict__ 
 }
 
 // flags of the search kernels: 1 a finite maximum distance is set, 2 seeded descents may start below the root
-// (search_skip_flag)
-static bool standoff_enabled() {  // A/B: PCLHIP_STANDOFF=0 keeps traverse() for launches without seeds
-  static const bool f = [] {
-    const char* e = getenv("PCLHIP_STANDOFF");
-    return !(e && atoi(e) == 0);
-  }();
-  return f;
-}
-
-static int search_skip_flag() {
-  static const int skip = [] {  // A/B: PCLHIP_ICP_SKIP=0 always descends from the root
-    const char* e = getenv("PCLHIP_ICP_SKIP");  // (the shortcut relies on the kd order: cells with disjoint interiors)
-    return (e && atoi(e) == 0) ? 0 : 2;
-  }();
-  return skip;
-}
-
-// PCLHIP_OWNED_GROUPS=1: under target sharding the device-driven loop walks the served groups only (below).  Written at the
-// end of round 3 with the round's GPU budget spent: exact on the CPU emulation of the test tier (tests/wavesim), never yet
-// run on hardware -- so it is opt-in until round 4's first GPU call has run its test there (scripts/r4_first_call.sh); the
-// default is the full pass every hardware test has seen.
-static bool owned_groups_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("PCLHIP_OWNED_GROUPS");
-    return e && atoi(e) == 1;
-  }();
-  return on;
-}
+constexpr int SEARCH_SKIP_FLAG = 2;  // seeded descents may start below the root (traverse(): start_leaf)
 
 template <int MODE>
 static void launch_accumulate(pclhip_icp* icp, const IndexView& v, int ga, const uint8_t* keep, const Mat34& M,
@@ -2062,16 +1831,9 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   // candidates must be <= max_d2 (a float): strict bound just above it; +inf when unbounded
   const float bound = use_max ? std::nextafterf(max_d2, __builtin_inff()) : __builtin_inff();
   const uint32_t ngroups = (icp->n + WAVE - 1) / WAVE;
-  // single-kernel variant (PCLHIP_ICP_FUSED=1): 27 (15) fp64 accumulators per lane -> 3 waves/SIMD
-  auto k_plane = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE, 3>;
-  auto k_point = icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT, 3>;
-  static const int unfused = [] {
-    const char* e = getenv("PCLHIP_ICP_FUSED");
-    return (e && atoi(e) == 1) ? 0 : 1;  // default: the two-kernel variant (measured faster)
-  }();
   const bool filters = icp->reciprocal || !icp->rejectors.empty();
   bool solved = false;
-  if (icp->n > 0 && (device_loop || unfused || filters || mode == PCLHIP_ICP_SYMMETRIC || icp->region.on)) {
+  if (icp->n > 0) {
     auto ks = icp_search_kernel<4, 1, true>;
     const int gs = resident_blocks(ctx, ks, ngroups);
     // launches without seeds go through the stand-off search when the index carries leaf discs: the host-driven loop
@@ -2081,31 +1843,21 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     // well above its noise: thickness ratio ~0.1 at the bench's 10M points).  Where the noise is of the order of the point
     // spacing (ratio 0.3 at 100M points of the same surface) every query needs tens of leaves whatever the bound, the
     // lists outgrow the LDS, and the seeded search is the faster one (measured: 76 against 108 ms at 100M).
-    static const float so_thick = [] {
-      const char* e = getenv("PCLHIP_SO_THICKNESS");
-      return e ? float(atof(e)) : 0.2f;
-    }();
-    // ... and a gate on the index size that dates from the schedule in which every wave owned ONE long run of groups (4096
-    // scattered neighbourhoods at a time: 2.7 against 3.2 ms for the seeded search at 10M points, 0.56 GB of index, but 7.2
-    // against 5.4 ms at 15M, 0.84 GB).  The front-ordered runs of icp_cold_search_body keep an XCD's waves on adjacent
-    // groups, which is what the gate was about; it stays until a 15M-point run has been measured with them.
-    static const size_t so_max_bytes = [] {
-      const char* e = getenv("PCLHIP_SO_MAX_MB");
-      return size_t(e ? strtoull(e, nullptr, 10) : 640ull) << 20;
-    }();
-    const bool standoff = standoff_enabled() && v.disc != nullptr && search_skip_flag() != 0 &&
-                          icp->target->disc_thickness < so_thick && size_t(icp->target->n_pad) * 56u <= so_max_bytes;
+    constexpr float SO_THICKNESS = 0.2f;
+    // ... and a gate on the index size.  Measured in round 4 with the front-ordered runs (cold launch, stand-off search
+    // against traverse(), ms): 12M points 3.5 / 3.6, 15M 4.7 / 4.5, 20M 8.0 / 7.2 -- beyond ~0.7 GB of index (points + leaf
+    // blocks + boxes, 56 B per point) the leaf blocks no longer stay in the 256 MB last-level cache under either body
+    // (both jump from 2.0 ms at 10M to 3.5 ms at 12M) and the stand-off search's longer lists cost more than they prune.
+    constexpr size_t SO_MAX_INDEX_BYTES = size_t(640) << 20;
+    const bool standoff = v.disc != nullptr && icp->target->disc_thickness < SO_THICKNESS &&
+                          size_t(icp->target->n_pad) * 56u <= SO_MAX_INDEX_BYTES;
     const bool cold = standoff && !device_loop && icp->seeds_cleared;
     icp->seeds_cleared = false;
-    const int kflags = (use_max ? 1 : 0) | search_skip_flag();
+    const int kflags = (use_max ? 1 : 0) | SEARCH_SKIP_FLAG;
     // wave radii (squared) up to so_from stay with traverse(): the groups that sit on the surface
-    static const float so_factor = [] {
-      const char* e = getenv("PCLHIP_SO_FACTOR");
-      return e ? float(atof(e)) : 1.0f;
-    }();
-    const float so_from = so_factor * icp->target->leaf_diag2;
+    const float so_from = icp->target->leaf_diag2;
     // target sharding in the device-driven loop: list the groups this rank serves in this launch, walk the list
-    const bool owned = device_loop && icp->region.on != 0 && mode != PCLHIP_ICP_SYMMETRIC && owned_groups_enabled();
+    const bool owned = device_loop && icp->region.on != 0 && mode != PCLHIP_ICP_SYMMETRIC && ctx->opt_served_groups != 0;
     OwnedGroups og = {nullptr, nullptr, nullptr, nullptr};
     if (owned) {
       pclhip_status st = ensure_owned_groups(icp);
@@ -2115,24 +1867,6 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
       og.stamp = icp->own_stamp;
       og.state = icp->own_state;
     }
-#if PCLHIP_GROUP_LISTS
-    GroupRecArrays grec = {nullptr, nullptr};
-    if (!owned) {  // (the served-group lists of the sharded mode keep the plain search)
-      if (icp->grec_block == nullptr || icp->grec_groups != ngroups) {
-        if (icp->grec_block) dev_free(ctx, icp->grec_block);
-        icp->grec_block = nullptr;
-        const size_t hdr_bytes = size_t(ngroups ? ngroups : 1) * 2 * sizeof(float4);
-        const size_t bytes = hdr_bytes + size_t(ngroups ? ngroups : 1) * GREC_CAP * sizeof(uint32_t);
-        char* base = nullptr;
-        PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &base, bytes));
-        PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(base, 0, bytes, s));  // count 0: no record yet
-        icp->grec_block = base;
-        icp->grec_groups = ngroups;
-      }
-      grec.hdr = reinterpret_cast<float4*>(icp->grec_block);
-      grec.ids = reinterpret_cast<uint32_t*>(static_cast<char*>(icp->grec_block) + size_t(ngroups ? ngroups : 1) * 2 * sizeof(float4));
-    }
-#endif
     (void)hipEventRecord(device_loop ? ev[0] : icp->ev0, s);
     if (owned) {
       hipLaunchKernelGGL(icp_own_epoch_kernel, dim3(1), dim3(1), 0, s, ctl, icp->own_state);
@@ -2150,7 +1884,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
       const int gd = resident_blocks(ctx, icp_search_dual_kernel, ngroups);
       PCLHIP_LAUNCH_FED(ctx, icp_search_dual_kernel, dim3(gd), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl,
                          icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2,
-                         ctx->stats PCLHIP_GREC_ARG(grec));
+                         ctx->stats);
     } else if (cold) {
       const int gc = resident_blocks(ctx, icp_cold_search_kernel, ngroups);
       PCLHIP_LAUNCH_FED(ctx, icp_cold_search_kernel, dim3(gc), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M,
@@ -2158,7 +1892,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
                          ctx->stats);
     } else {
       PCLHIP_LAUNCH_FED(ctx, ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl, icp->region,
-                         order, bound, kflags, icp->match_pos, icp->match, icp->match_d2, ctx->stats PCLHIP_GREC_ARG(grec));
+                         order, bound, kflags, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
     }
     (void)hipEventRecord(device_loop ? ev[1] : icp->ev_mid, s);
     icp->mid_recorded = true;
@@ -2168,11 +1902,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
       if (st != PCLHIP_OK) return st;
       keep = icp->keep;
     }
-    static const int acc_per_cu = [] {  // A/B: blocks of the streaming accumulate kernel per CU (rows the reduction reads)
-      const char* e = getenv("PCLHIP_ACC_BLOCKS_PER_CU");
-      const int v = e ? atoi(e) : 4;
-      return v >= 1 && v <= 8 ? v : 4;
-    }();
+    constexpr int acc_per_cu = 4;  // blocks of the streaming accumulate kernel per CU (rows the reduction reads)
     int ga = ctx->num_cus * acc_per_cu;
     if (ga > icp->grid_blocks) ga = icp->grid_blocks;
     {  // small clouds: no more blocks than give every thread ~4 points -- each block leaves a row of partial sums that the
@@ -2200,19 +1930,6 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     solved = device_loop && !icp_is_sharded(icp);  // no record to exchange: the reduction launch closes the iteration
     hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(FINALIZE_THREADS), 0, s, icp->partials, ga, icp->sums_dev, ctl,
                        solved ? icp->ctl : static_cast<IcpControl*>(nullptr), icp->steps);
-  } else if (icp->n > 0) {
-    int grid = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? resident_blocks(ctx, k_plane, ngroups)
-                                                   : resident_blocks(ctx, k_point, ngroups);
-    if (grid > icp->grid_blocks) grid = icp->grid_blocks;
-    icp->mid_recorded = false;
-    (void)hipEventRecord(icp->ev0, s);
-    auto kern = (mode == PCLHIP_ICP_POINT_TO_PLANE) ? k_plane : k_point;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), 0, s, v, icp->src_cur, icp->n, M, order, bound,
-                       use_max ? 1 : 0, icp->match_pos, icp->match, icp->match_d2, icp->partials, ctx->stats);
-    (void)hipEventRecord(icp->ev1, s);
-    hipLaunchKernelGGL(icp_finalize_kernel, dim3(1), dim3(FINALIZE_THREADS), 0, s, icp->partials, grid, icp->sums_dev,
-                       static_cast<const IcpControl*>(nullptr), static_cast<IcpControl*>(nullptr),
-                       static_cast<IcpStepRecord*>(nullptr));
   } else {
     if (device_loop) {
       (void)hipEventRecord(ev[0], s);
@@ -2297,7 +2014,7 @@ pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double ma
   // exactly one owner), against its slab + halo index; the (sum, count) pairs are summed over the ranks below
   PCLHIP_LAUNCH_FED(ctx, (icp_search_kernel<4, 1, true>), dim3(gs), dim3(BLOCK), 0, s, v, cur, static_cast<const float4*>(cur), n,
                      M, static_cast<const IcpControl*>(nullptr), icp->region, 1, __builtin_inff(), 0, pos, id, d2,
-                     ctx->stats PCLHIP_GREC_ARG((GroupRecArrays{nullptr, nullptr})));
+                     ctx->stats);
   hipLaunchKernelGGL(fitness_partial_kernel, dim3(gr), dim3(BLOCK), 0, s, d2, n, max_range, part);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   std::vector<double> h(size_t(gr) * 2);
@@ -2356,12 +2073,8 @@ pclhip_status launch_estimate_pairs(pclhip_ctx* ctx, int mode, const float4* src
 // upper bound of the persistent grid (sizes the partial-sum buffer)
 int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns) {
   const uint32_t ngroups = (ns + WAVE - 1) / WAVE;
-  int g = resident_blocks(ctx, icp_iterate_kernel<PCLHIP_ICP_POINT_TO_PLANE, 3>, ngroups);
-  const int gp = resident_blocks(ctx, icp_iterate_kernel<PCLHIP_ICP_POINT_TO_POINT, 3>, ngroups);
-  const int gsr = resident_blocks(ctx, icp_search_kernel<4, 1, true>, ngroups);
-  if (gp > g) g = gp;
-  if (gsr > g) g = gsr;
-  if (ctx->num_cus * 8 > g) g = ctx->num_cus * 8;  // the streaming accumulate kernel of the two-kernel variant
+  int g = resident_blocks(ctx, icp_search_kernel<4, 1, true>, ngroups);
+  if (ctx->num_cus * 8 > g) g = ctx->num_cus * 8;  // the streaming accumulate kernel
   return g;
 }
 

@@ -9,8 +9,9 @@
 // point has exactly one owner.  A query q in region R and a target point p with |q - p| <= d satisfy
 // p in R dilated by d per axis, which is the halo rule below.
 //
-// This is host code (order statistics + a filter over the cloud, once per target): it needs no GPU, which is
-// what lets the partition / halo / routing logic be tested in multi-process CPU runs.  The per-iteration side
+// This file is the host code for clouds in HOST memory (order statistics + a filter over the cloud, once per target):
+// it needs no GPU, which is what lets the partition / halo / routing logic be tested in multi-process CPU runs.
+// Clouds in DEVICE memory are partitioned and selected where they are (shard_dev.hip: same cuts, same lists).  The per-iteration side
 // lives in the search kernel (search.hip: RegionBox) and in the record all-reduce (icp_loop.hip).
 #include <algorithm>
 #include <cmath>
@@ -104,7 +105,7 @@ void bisect(const HostCloud& c, std::vector<uint32_t>& ids, size_t begin, size_t
       return va < vb || (va == vb && a < b);
     };
     std::nth_element(ids.begin() + long(begin), ids.begin() + long(k), ids.begin() + long(end), less);
-    cut = c.xyz[size_t(ids[k]) * 3 + axis];
+    cut = c.xyz[size_t(ids[k]) * 3 + axis] + 0.0f;  // (-0.0 -> +0.0: one spelling of the bound, host and device code)
     // left = strictly below the cut (ties go right, like the kernel's x >= lo && x < hi ownership test)
     k = size_t(std::partition(ids.begin() + long(begin), ids.begin() + long(end),
                               [&](uint32_t a) { return c.xyz[size_t(a) * 3 + axis] < cut; }) - ids.begin());
@@ -126,6 +127,7 @@ pclhip_status pclhip_partition_slabs(const void* points, size_t stride, uint64_t
     set_error(nullptr, "stride must be a multiple of 4 and >= 12 bytes, the cloud must fit int32 indices");
     return PCLHIP_ERR_INVALID;
   }
+  if (n > 0 && is_device_pointer(points)) return partition_slabs_device(points, stride, n, n_slabs, regions);  // shard_dev.hip
   HostCloud c;
   pclhip_status st = fetch_cloud(points, stride, n, c);
   if (st != PCLHIP_OK) return st;
@@ -153,9 +155,6 @@ pclhip_status pclhip_select_region(const void* points, size_t stride, uint64_t n
     set_error(nullptr, "stride must be a multiple of 4 and >= 12 bytes, the cloud must fit int32 indices");
     return PCLHIP_ERR_INVALID;
   }
-  HostCloud c;
-  pclhip_status st = fetch_cloud(points, stride, n, c);
-  if (st != PCLHIP_OK) return st;
   // dilated box, rounded outwards: a float d2 that passes the double test d2 <= max_dist^2 may belong to a point a
   // few ulp farther than max_dist; the relative slack covers that and the rounding of the bounds themselves
   float lo[3], hi[3];
@@ -166,6 +165,11 @@ pclhip_status pclhip_select_region(const void* points, size_t stride, uint64_t n
     if (!std::isfinite(region[d])) lo[d] = region[d];
     if (!std::isfinite(region[3 + d])) hi[d] = region[3 + d];
   }
+  if (n > 0 && is_device_pointer(points))  // shard_dev.hip: the cloud stays where it is
+    return select_region_device(points, stride, n, lo, hi, out_indices, capacity, out_count);
+  HostCloud c;
+  pclhip_status st = fetch_cloud(points, stride, n, c);
+  if (st != PCLHIP_OK) return st;
   const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   std::vector<std::vector<int32_t>> part(nt);
   std::vector<std::thread> th;

@@ -66,9 +66,6 @@ namespace pclhip {
 #define SO_COUNT(expr) (void)0
 #endif
 
-#ifndef PCLHIP_SO_GREEDY_SEED
-#define PCLHIP_SO_GREEDY_SEED 0  // A/B: 1 = the first group of a run takes its seed from one greedy walk down the hierarchy
-#endif
 #ifndef PCLHIP_SO_BATCHCULL
 #define PCLHIP_SO_BATCHCULL 1  // A/B: 0 culls all union slots of a segment before the first evaluation
 #endif
@@ -347,14 +344,13 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
       const uint64_t at = __builtin_amdgcn_ballot_w64((pok || hok) && d == m);
       if (at != 0) seed_pos = uint32_t(__builtin_amdgcn_readlane(int(cand), __builtin_ctzll(at)));
     }
-#if PCLHIP_SO_GREEDY_SEED
     if (seed_pos == NO_INDEX) {
       // No previous group (the first of a run) or none with a match.  Any target point near the group will do as a seed --
       // it only has to give every lane a radius, the search below is exact whatever it is -- so instead of one lane's exact
       // neighbour (an unseeded best-first search that the whole wave executes: ~2000 wave-instructions, a quarter of a
       // group's own search, for one group in four) the wave walks DOWN the hierarchy once, at every level into the child
       // whose box is nearest to the group's centre (4 scans without ranking at 10M points), and takes that leaf's point
-      // nearest to the centre.  A/B variant (-DPCLHIP_SO_GREEDY_SEED=1) until timed.
+      // nearest to the centre.  (Round 4, 10M points: cold launch 2.00 -> 1.80 ms.)
       uint32_t level = uint32_t(ix.top) + 1u, node = 0u;
       while (level > 1u) {
         const uint32_t cl = level - 1u, first = node * FANOUT;
@@ -390,7 +386,6 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
       const uint64_t at = __builtin_amdgcn_ballot_w64(lane < LEAF && d == m && d < INF);
       if (at != 0) seed_pos = node * LEAF + uint32_t(__builtin_ctzll(at));
     }
-#endif
     if (seed_pos == NO_INDEX) {
       // no previous group (first of the wave's chunk) or none with a match: the exact neighbour of ONE lane
       const uint64_t vm = __builtin_amdgcn_ballot_w64(valid);

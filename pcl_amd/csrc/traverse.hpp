@@ -931,55 +931,11 @@ __device__ __forceinline__ float lane_worst(const Policy& pol, const bool* valid
   return w;
 }
 
-// ---- a group's leaf list kept across seeded ICP iterations (search.hip compiles it in with
-// -DPCLHIP_GROUP_LISTS=1, off by default until it has been measured) ----------------------------------------------------
-// A seeded traversal re-derives, every iteration, the leaves within the wave radius of the group's box -- and in a
-// converged alignment finds the same ones.  With GroupRec the traversal prunes its GROUP-level tests (node and leaf boxes
-// against the group's box) with the radius grown by GREC_GROW and writes down the leaves that pass: by construction that
-// is every leaf within reach = GREC_GROW * sqrt(final wave radius) of the group's box Q.  The next iteration's group box
-// Q' sticks out of Q by e (a point of Q' has a point of Q within e), so every leaf NOT in the record is farther than
-// reach - e from Q'; if that exceeds the new wave radius, no lane can need such a leaf, and traverse_recorded() tests and
-// evaluates the recorded leaves directly -- no node walk.  Exact by the triangle inequality; a statement about the
-// (unchanged) target index only, so a record stays true across alignments.  Whenever the check fails, traverse() runs
-// and records afresh.
-struct NoGroupRec {
-  static constexpr bool on = false;
-};
-constexpr uint32_t GREC_CAP = 32;      // recorded leaves per group (a converged group lists ~13)
-#ifndef PCLHIP_GREC_GROW
-#define PCLHIP_GREC_GROW 1.1f
-#endif
-constexpr float GREC_GROW = PCLHIP_GREC_GROW;  // recorded reach over the wave radius: the slack the group may use up by moving
-struct GroupRec {
-  static constexpr bool on = true;
-  uint32_t* ids = nullptr;  // [GREC_CAP] of this group (global memory)
-  float4* hdr = nullptr;    // [2] (Q.lo, reach) (Q.hi, count as bits); count 0: no record
-  // what a recording traversal leaves behind
-  uint32_t count = 0;
-  bool ok = false;
-  // PCLHIP_GREC_DEFER: a tight search (bounds from good seeds, lists in index order) does not test and evaluate every node's
-  // list on the spot -- the walk only writes the listed leaves down, and grec_evaluate() takes all of them as ONE list
-  // afterwards (fewer, fuller evaluation rounds; the radii of such a search hardly move while it runs)
-  bool defer = false;
-  uint32_t ndeferred = 0;  // ids[0, ndeferred) were written down without being evaluated
-  float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-  // close the record of a finished search: T = the final wave radius (squared), keep = a bound the reach may not exceed
-  __device__ __forceinline__ void store(float T, float keep) {
-    const bool good = ok && count >= 1u && count <= GREC_CAP && T < 3.0e38f;
-    const float reach = fminf(GREC_GROW * __fsqrt_rn(T) * 0.999999f, keep);
-    if ((threadIdx.x & (WAVE - 1)) == 0) {
-      hdr[0] = make_float4(lo[0], lo[1], lo[2], reach);
-      hdr[1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(good && reach > 0.0f ? count : 0u));
-    }
-  }
-};
-
 // qx/qy/qz/valid: Policy::QPL queries per lane (the wave owns 64*QPL spatially compact queries).
-template <class Policy, bool SPARSE = false, class WL = WaveLds, class GR = NoGroupRec>
+template <class Policy, bool SPARSE = false, class WL = WaveLds>
 __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, const float* qy, const float* qz,
                                          const bool* valid, Policy& pol, WL& wl, const Box* topbox,
-                                         TraverseStats& ts, uint32_t start_leaf = NO_INDEX, bool allow_disc = false,
-                                         GR* gr = nullptr) {
+                                         TraverseStats& ts, uint32_t start_leaf = NO_INDEX, bool allow_disc = false) {
   constexpr int QPL = Policy::QPL;
   const int lane = threadIdx.x & (WAVE - 1);
   bool any_valid = false;
@@ -1002,13 +958,6 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
   wave_min3_max4(lx0, ly0, lz0, hx0, hy0, hz0, T);
   const float Qlx = lx0, Qly = ly0, Qlz = lz0, Qhx = hx0, Qhy = hy0, Qhz = hz0;
   const float gdiag2 = (Qhx - Qlx) * (Qhx - Qlx) + (Qhy - Qly) * (Qhy - Qly) + (Qhz - Qlz) * (Qhz - Qlz);
-  if constexpr (GR::on) {
-    gr->lo[0] = Qlx; gr->lo[1] = Qly; gr->lo[2] = Qlz;
-    gr->hi[0] = Qhx; gr->hi[1] = Qhy; gr->hi[2] = Qhz;
-    gr->count = 0;
-    gr->ok = true;
-  }
-  constexpr float GROW2 = GR::on ? GREC_GROW * GREC_GROW * 1.000001f : 1.0f;  // group-level tests of a recording search
   // Disc bounds pay where queries STAND OFF the indexed surface (the unseeded first iteration of a
   // registration): the caller says so.  Self-queries (normals) and seeded queries sit on or near the surface,
   // inside the discs of all the leaves around them, where a disc excludes nothing a box does not.
@@ -1029,7 +978,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
     const auto inside = [&](const Box& b) {
       const float d = fminf(fminf(fminf(Qlx - b.lo.x, b.hi.x - Qhx), fminf(Qly - b.lo.y, b.hi.y - Qhy)),
                             fminf(Qlz - b.lo.z, b.hi.z - Qhz));
-      return d > 0.0f && d * d * 0.999999f > (GR::on ? T * GROW2 : T);
+      return d > 0.0f && d * d * 0.999999f > T;
     };
     const bool has2 = ix.top >= 2, has3 = ix.top >= 3;
     Box b2 = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)}, b3 = b2;
@@ -1051,7 +1000,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
       __builtin_amdgcn_wave_barrier();
       const uint2 e = stack[sp];
       const uint32_t ex = uniform_u32(e.x), ey = uniform_u32(e.y);
-      if (__uint_as_float(ey) > (GR::on ? T * GROW2 : T)) continue;  // pruned since it was pushed
+      if (__uint_as_float(ey) > T) continue;  // pruned since it was pushed
       level = ex >> 28;
       node = ex & 0x0FFFFFFFu;
     }
@@ -1107,7 +1056,7 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         // cost 45 instructions per scan; the lanes' own disc tests below are what prunes)
       }
     }
-    const bool alive = has && !(lbG > (GR::on ? T * GROW2 : T));
+    const bool alive = has && !(lbG > T);
     const uint64_t mask = __builtin_amdgcn_ballot_w64(alive);
     if (mask == 0) continue;
     if (cl == 1u) {
@@ -1127,15 +1076,6 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
         lbG = __uint_as_float(key & ~63u);
       }
       const uint32_t n_alive = uint32_t(__builtin_popcountll(mask));
-      if constexpr (GR::on) {  // write the listed leaves down (lists of tight searches only: rank = position)
-        if (ordered || gr->count + n_alive > GREC_CAP) gr->ok = false;
-        if (gr->ok && alive) gr->ids[gr->count + rank] = first + uint32_t(lane);
-        gr->count += n_alive;
-        if (gr->defer && gr->ok && !use_disc) {  // (ok: a tight list that fitted)
-          gr->ndeferred = gr->count;
-          continue;
-        }
-      }
       if (alive) {
         if (use_disc) {
           wl.list[LS * rank] = make_float4(dcR.x, dcR.y, dcR.z, __uint_as_float(first + uint32_t(lane)));
@@ -1458,158 +1398,6 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
       have = true;
     }
   }
-}
-
-template <class Policy, class WL>
-__device__ __forceinline__ void grec_evaluate(const IndexView& ix, const float* qx, const float* qy, const float* qz,
-                                              const bool* valid, Policy& pol, WL& wl, TraverseStats& ts, GroupRec& gr,
-                                              uint32_t count, float lx0, float ly0, float lz0, float hx0, float hy0, float hz0,
-                                              float T, float keep, bool record_ok);
-
-// The search of a group from its recorded leaf list (see GroupRec): false if the record does not cover this iteration
-// (the caller then runs traverse(), which records afresh).  One query per lane, lane-sparse evaluation, tight bounds.
-template <class Policy, class WL>
-__device__ __forceinline__ bool traverse_recorded(const IndexView& ix, const float* qx, const float* qy, const float* qz,
-                                                  const bool* valid, Policy& pol, WL& wl, TraverseStats& ts, GroupRec& gr) {
-  static_assert(Policy::QPL == 1 && lane_sparse_of<Policy>::value && !Policy::NEEDS_W, "1-NN policies of the ICP search");
-  if (__builtin_amdgcn_ballot_w64(valid[0]) == 0 || ix.n == 0) return true;  // nothing to search
-  const float4 h0 = gr.hdr[0], h1 = gr.hdr[1];
-  const uint32_t count = uniform_u32(__float_as_uint(h1.w));
-  if (count == 0u || count > GREC_CAP) return false;
-  const float BIG = 3.402823466e+38f;
-  float lx0 = valid[0] ? qx[0] : BIG, ly0 = valid[0] ? qy[0] : BIG, lz0 = valid[0] ? qz[0] : BIG;
-  float hx0 = valid[0] ? qx[0] : -BIG, hy0 = valid[0] ? qy[0] : -BIG, hz0 = valid[0] ? qz[0] : -BIG;
-  float T = valid[0] ? pol.worst(0) : 0.0f;
-  wave_min3_max4(lx0, ly0, lz0, hx0, hy0, hz0, T);
-  if (!(T < BIG)) return false;  // a lane without a seed: no radius to check against
-  // how far this iteration's group box sticks out of the recorded one
-  const float ex = fmaxf(fmaxf(uniform_f32(h0.x) - lx0, hx0 - uniform_f32(h1.x)), 0.0f);
-  const float ey = fmaxf(fmaxf(uniform_f32(h0.y) - ly0, hy0 - uniform_f32(h1.y)), 0.0f);
-  const float ez = fmaxf(fmaxf(uniform_f32(h0.z) - lz0, hz0 - uniform_f32(h1.z)), 0.0f);
-  const float e = __fsqrt_rn((ex * ex + ey * ey) + ez * ez) * 1.000001f;
-  const float left = uniform_f32(h0.w) - e;                  // every leaf outside the record is farther than this from Q'
-  if (!(left > 0.0f) || !(left * left * 0.99999f > T)) return false;
-  ++ts.c[4];
-  ++ts.c[5];  // groups searched from their record
-  grec_evaluate(ix, qx, qy, qz, valid, pol, wl, ts, gr, count, lx0, ly0, lz0, hx0, hy0, hz0, T, left, true);
-  return true;
-}
-
-// The leaves gr.ids[0, count) as ONE list: their boxes against the group's box (lx0 .. hz0) and the wave radius T, the
-// survivors ranked in place (they are the next record), per-lane tests, lane-sparse evaluation; then the record's header
-// (`keep`: a bound the recorded reach may not exceed).
-template <class Policy, class WL>
-__device__ __forceinline__ void grec_evaluate(const IndexView& ix, const float* qx, const float* qy, const float* qz,
-                                              const bool* valid, Policy& pol, WL& wl, TraverseStats& ts, GroupRec& gr,
-                                              uint32_t count, float lx0, float ly0, float lz0, float hx0, float hy0, float hz0,
-                                              float T, float keep, bool record_ok) {
-  constexpr int LS = WL::LIST_STRIDE;
-  constexpr int NCHUNK = 12;
-  const int lane = threadIdx.x & (WAVE - 1);
-  const float left = keep;
-  uint32_t id = NO_INDEX;
-  float lx = 0, ly = 0, lz = 0, hx = 0, hy = 0, hz = 0;
-  if (uint32_t(lane) < count) {
-    id = gr.ids[lane];
-    const Box b = ix.box[1][id];
-    lx = b.lo.x; ly = b.lo.y; lz = b.lo.z;
-    hx = b.hi.x; hy = b.hi.y; hz = b.hi.z;
-  }
-  const float lbG = id != NO_INDEX ? box_box_lb(lx0, ly0, lz0, hx0, hy0, hz0, lx, ly, lz, hx, hy, hz) : __builtin_inff();
-  const bool alive = id != NO_INDEX && !(lbG > T * (GREC_GROW * GREC_GROW * 1.000001f));
-  const uint64_t mask = __builtin_amdgcn_ballot_w64(alive);  // (also: every lane has read its id before any is rewritten)
-  const uint32_t n_alive = uint32_t(__builtin_popcountll(mask));
-  const uint32_t rank = uint32_t(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
-#ifndef PCLHIP_GREC_PACKED
-#define PCLHIP_GREC_PACKED 1  // per-lane box tests of the recorded list two leaves at a time on packed math (0: one at a time)
-#endif
-  float* const ids_f = wl.radii();  // ids of the ranked leaves (the radii of disc lists are not in use here)
-  if (alive) {
-    gr.ids[rank] = id;  // the next record: the part of this one that is still within reach
-    if constexpr (PCLHIP_GREC_PACKED != 0 && LS == 3) {
-      // pair p = rank / 2 holds leaves 2p, 2p + 1 side by side: (lxA lxB lyA lyB) (lzA lzB hxA hxB) (hyA hyB hzA hzB)
-      float* const w = reinterpret_cast<float*>(&wl.list[3u * (rank >> 1)]) + (rank & 1u);
-      w[0] = lx; w[2] = ly; w[4] = lz; w[6] = hx; w[8] = hy; w[10] = hz;
-      if ((n_alive & 1u) != 0u && rank + 1u == n_alive) {  // an odd list: the missing half of the last pair excludes itself
-        const float far = 3.0e38f;
-        w[1] = far; w[3] = far; w[5] = far; w[7] = far; w[9] = far; w[11] = far;
-      }
-      ids_f[rank] = __uint_as_float(id);
-    } else {
-      wl.list[LS * rank] = make_float4(lx, ly, lz, __uint_as_float(id));
-      wl.list[LS * rank + 1] = make_float4(hx, hy, hz, lbG);
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  const auto id_at = [&](uint32_t r) -> uint32_t {
-    if constexpr (PCLHIP_GREC_PACKED != 0 && LS == 3) return __float_as_uint(ids_f[r]);
-    else return __float_as_uint(wl.list[LS * r].w);
-  };
-  const float before = valid[0] ? pol.worst(0) : 0.0f;
-  for (uint32_t b0 = 0; b0 < n_alive; b0 += LEAF_BATCH) {
-    const uint32_t nb = (n_alive - b0) < uint32_t(LEAF_BATCH) ? (n_alive - b0) : uint32_t(LEAF_BATCH);
-    {  // LDS-DMA of the batch's candidate blocks, transposed (as traverse() stages them)
-      const uint32_t slot = uint32_t(lane) & 15u;
-      uint32_t leaf_id = 0;
-      if (slot < nb) leaf_id = id_at(b0 + slot);
-#pragma unroll
-      for (int i = 0; i < NCHUNK / 4; ++i) {
-        if (slot < nb) {
-          const float* src = ix.soa + size_t(leaf_id) * LEAF_FLOATS + (i * 4 + (lane >> 4)) * 4;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(wl.buf + i * (WAVE * 4)), 16, 0, 0);
-        }
-      }
-    }
-    ts.c[1] += nb;
-    uint32_t m16 = 0;
-    if constexpr (PCLHIP_GREC_PACKED != 0 && LS == 3) {
-      // two leaves per step: the operations of point_box_lb component by component on v_pk_add / v_pk_mul (same values)
-      const v2f qx2 = {qx[0], qx[0]}, qy2 = {qy[0], qy[0]}, qz2 = {qz[0], qz[0]}, zero2 = {0.0f, 0.0f};
-      for (uint32_t t = 0; t < nb; t += 2u) {
-        const uint32_t pr = (b0 + t) >> 1;
-        const float4 e0 = wl.list[3u * pr], e1 = wl.list[3u * pr + 1u], e2 = wl.list[3u * pr + 2u];  // broadcast reads
-        const v2f lx2 = {e0.x, e0.y}, ly2 = {e0.z, e0.w}, lz2 = {e1.x, e1.y};
-        const v2f hx2 = {e1.z, e1.w}, hy2 = {e2.x, e2.y}, hz2 = {e2.z, e2.w};
-        const v2f gx = __builtin_elementwise_max(__builtin_elementwise_max(lx2 - qx2, qx2 - hx2), zero2);
-        const v2f gy = __builtin_elementwise_max(__builtin_elementwise_max(ly2 - qy2, qy2 - hy2), zero2);
-        const v2f gz = __builtin_elementwise_max(__builtin_elementwise_max(lz2 - qz2, qz2 - hz2), zero2);
-        v2f r = gx * gx;
-        r = r + gy * gy;
-        r = r + gz * gz;
-        const float w = pol.worst(0);
-        m16 |= ((!(r.x > w) && pol_wants(pol, id_at(b0 + t))) ? 1u : 0u) << t;
-        if (t + 1u < nb) m16 |= ((!(r.y > w) && pol_wants(pol, id_at(b0 + t + 1u))) ? 1u : 0u) << (t + 1u);
-      }
-    } else {
-      for (uint32_t t = 0; t < nb; ++t) {
-        const float4 ea = wl.list[LS * (b0 + t)], eb = wl.list[LS * (b0 + t) + 1];  // broadcast reads
-        const float lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
-        m16 |= ((!(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w))) ? 1u : 0u) << t;
-      }
-    }
-    if (!valid[0]) m16 = 0;
-    PCLHIP_WAIT_VMCNT0();
-    while (__builtin_amdgcn_ballot_w64(m16 != 0) != 0) {
-      uint32_t slot = 0, lid = NO_INDEX;
-      if (m16 != 0) {
-        slot = uint32_t(__builtin_ctz(m16));
-        lid = id_at(b0 + slot);
-        m16 &= m16 - 1u;
-      }
-      ++ts.c[2];
-      pol.leaf_lane(wl.buf, slot, lid, qx, qy, qz);
-    }
-    __builtin_amdgcn_wave_barrier();  // the next batch overwrites the staging area
-  }
-  (void)before;
-  // the record of this iteration: the same leaves, as far as they are still within reach of the new box
-  const float Tend = wave_max_f(valid[0] ? pol.worst(0) : 0.0f);
-  gr.lo[0] = lx0; gr.lo[1] = ly0; gr.lo[2] = lz0;
-  gr.hi[0] = hx0; gr.hi[1] = hy0; gr.hi[2] = hz0;
-  gr.count = n_alive;
-  gr.ok = record_ok;
-  gr.store(Tend, left);
 }
 
 __device__ __forceinline__ void flush_stats(const TraverseStats& ts, unsigned long long* g) {

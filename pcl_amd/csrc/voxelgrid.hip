@@ -326,67 +326,6 @@ __global__ __launch_bounds__(256) void vg_centroid_kernel(const void* pts, size_
   }
 }
 
-// The same for LONG runs (coarse leaves: hundreds of points per voxel): one wavefront per run gathers 64 points at
-// a time and every lane adds them up in index order from lane broadcasts -- the float sums stay sequential (and
-// bit-identical), the gathers do not.
-__global__ __launch_bounds__(256) void vg_centroid_wave_kernel(const void* pts, size_t stride, const uint32_t* vals,
-                                                               const uint32_t* run_start, const uint32_t* keep,
-                                                               const uint32_t* keep_scan, uint32_t nruns, void* out,
-                                                               size_t ostride, size_t noff, int all_data) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-  const bool with_n = noff != 0 && all_data;
-  for (uint32_t r = wave; r < nruns; r += nwaves) {
-    if (!keep[r]) continue;
-    const uint32_t b = run_start[r], e = run_start[r + 1];
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f, cv = 0.0f;
-    for (uint32_t c = b; c < e; c += 64u) {
-      const uint32_t m = (e - c) < 64u ? (e - c) : 64u;
-      float px = 0.0f, py = 0.0f, pz = 0.0f, qx = 0.0f, qy = 0.0f, qz = 0.0f, qc = 0.0f;
-      if (lane < m) {
-        const float* p = rec(pts, stride, vals[c + lane]);
-        px = p[0]; py = p[1]; pz = p[2];
-        if (with_n) {
-          const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + noff);
-          qx = q[0]; qy = q[1]; qz = q[2]; qc = q[4];
-        }
-      }
-      for (uint32_t j = 0; j < m; ++j) {  // j is wave-uniform: v_readlane broadcasts
-        sx = __fadd_rn(sx, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), int(j))));
-        sy = __fadd_rn(sy, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), int(j))));
-        sz = __fadd_rn(sz, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), int(j))));
-        if (with_n) {
-          nx = __fadd_rn(nx, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), int(j))));
-          ny = __fadd_rn(ny, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), int(j))));
-          nz = __fadd_rn(nz, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), int(j))));
-          cv = __fadd_rn(cv, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qc), int(j))));
-        }
-      }
-    }
-    if (lane == 0) {
-      const float cnt = float(e - b);
-      float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + size_t(keep_scan[r]) * ostride);
-      o[0] = __fdiv_rn(sx, cnt);
-      o[1] = __fdiv_rn(sy, cnt);
-      o[2] = __fdiv_rn(sz, cnt);
-      if (ostride >= 16) o[3] = 1.0f;
-      if (noff != 0) {
-        float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(o) + noff);
-        float a = 0.0f, bb = 0.0f, cc = 0.0f, k = 0.0f;
-        if (with_n) {
-          const float len = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
-          a = __fdiv_rn(nx, len);
-          bb = __fdiv_rn(ny, len);
-          cc = __fdiv_rn(nz, len);
-          k = __fdiv_rn(cv, cnt);
-        }
-        q[0] = a; q[1] = bb; q[2] = cc; q[3] = 0.0f;
-        q[4] = k; q[5] = 0.0f; q[6] = 0.0f; q[7] = 0.0f;
-      }
-    }
-  }
-}
-
 // Four runs per wavefront, one per row of 16 lanes: a row gathers 16 points of its run at a time and every lane of the
 // row adds them up in index order from row broadcasts (ds_bpermute) -- the same sequential float sums, a quarter of the
 // broadcast + add instructions per point of the wave-per-run form.
@@ -676,15 +615,7 @@ extern "C" pclhip_status pclhip_voxelgrid_ex2(pclhip_ctx* ctx, const void* point
   if (total > 0) {
     if (out_stride != 16 && (normals_offset == 0 || out_stride != normals_offset + 32))
       PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_out, 0, size_t(total) * out_stride, s));  // fields this filter does not fill
-    static const int centroid_form = [] {  // A/B: PCLHIP_VG_CENTROID=wave keeps the wavefront-per-run kernel for long runs
-      const char* e = getenv("PCLHIP_VG_CENTROID");
-      return (e && !strcmp(e, "wave")) ? 1 : 0;
-    }();
-    if (uint64_t(nv) > uint64_t(nruns) * 16 && centroid_form == 1) {  // long runs on average: a wavefront per run
-      const unsigned blocks = unsigned(std::min<uint64_t>((uint64_t(nruns) + 3) / 4, uint64_t(ctx->num_cus) * 16));
-      hipLaunchKernelGGL(vg_centroid_wave_kernel, dim3(blocks), dim3(256), 0, s, dp, stride, vals_sorted, run_start, keep,
-                         keep_scan, nruns, d_out, out_stride, normals_offset, downsample_all_data ? 1 : 0);
-    } else if (uint64_t(nv) > uint64_t(nruns) * 8) {  // runs of a row's size and more: a row of 16 lanes per run
+    if (uint64_t(nv) > uint64_t(nruns) * 8) {  // runs of a row's size and more: a row of 16 lanes per run
       const unsigned blocks = unsigned(std::min<uint64_t>((uint64_t(nruns) + 15) / 16, uint64_t(ctx->num_cus) * 16));
       hipLaunchKernelGGL(vg_centroid_row_kernel, dim3(blocks), dim3(256), 0, s, dp, stride, vals_sorted, run_start, keep,
                          keep_scan, nruns, d_out, out_stride, normals_offset, downsample_all_data ? 1 : 0);

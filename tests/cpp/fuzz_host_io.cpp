@@ -28,10 +28,15 @@
 #include "../../pcl_amd/csrc/pclhip_internal.hpp"
 #include "pclhip.h"
 
-// ---- the three symbols pcd_io.cpp / shard.cpp take from the rest of the library -------------------------------------
+// ---- the symbols pcd_io.cpp / shard.cpp take from the rest of the library (no pointer here is device memory, so the
+// device-side partition of shard_dev.hip is never reached) ------------------------------------------------------------
 namespace pclhip {
 bool is_device_pointer(const void*) { return false; }
 void set_error(pclhip_ctx*, const std::string&) {}
+pclhip_status partition_slabs_device(const void*, size_t, uint64_t, int, float*) { return PCLHIP_ERR_HIP; }
+pclhip_status select_region_device(const void*, size_t, uint64_t, const float*, const float*, int32_t*, uint64_t, uint64_t*) {
+  return PCLHIP_ERR_HIP;
+}
 }  // namespace pclhip
 extern "C" hipError_t hipMemcpy(void*, const void*, size_t, hipMemcpyKind) { return hipErrorNotSupported; }
 

@@ -1,5 +1,5 @@
 """One run of the served-group scenario of tests/test_gpu_dist.py::test_served_group_lists_equal_the_full_pass (a process
-of its own because PCLHIP_OWNED_GROUPS is read once per process).  argv: out.npz points"""
+of its own so that both runs start from a fresh context).  argv: out.npz points served_groups(0|1)"""
 import os
 import sys
 
@@ -15,6 +15,7 @@ tgt, src, _ = synth.icp_pair(n)
 guess = np.eye(4, dtype=np.float32)
 guess[0, 3] = 0.06
 ctx = pcl_amd.Context(0)
+ctx.setOption("served_groups", int(sys.argv[3]))   # 0: every launch walks the whole source (the reference of the test)
 tree = pcl_amd.KdTree(ctx)
 tree.setInputCloud(tgt)
 ne = pcl_amd.NormalEstimation(ctx)

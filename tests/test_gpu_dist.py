@@ -186,21 +186,17 @@ def test_sharded_bench_path_single_slab_runs_whole_alignments():
 def test_served_group_lists_equal_the_full_pass(tmp_path):
     # Under target sharding the device-driven loop walks only the 64-point groups of the source whose box touches the
     # rank's region, and brings a group that was skipped for some launches up to date from the transforms it missed.
-    # The same run with PCLHIP_OWNED_GROUPS=0 walks the whole source every launch: the served correspondences must be the
+    # The same run with the option "served_groups" = 0 walks the whole source every launch: the served correspondences must be the
     # same lists -- query, match AND float distance, which only come out equal if every replayed position is the full
     # pass's bit for bit --, the step records the same counts and iterations, the 4x4 equal up to the summation order.
     import subprocess
     import sys
-    if os.environ.get("PCLHIP_ALLOW_WAVESIM") != "1" and os.environ.get("PCLHIP_HW_VALIDATE") != "1":
-        pytest.skip("the served-group lists (PCLHIP_OWNED_GROUPS=1, opt-in) were written with round 3's GPU budget spent: this "
-                    "test runs on the CPU emulation (tests/test_wavesim.py); its first hardware run is round 4's first GPU "
-                    "call (PCLHIP_HW_VALIDATE=1, scripts/r4_first_call.sh)")
+    # (First hardware run: round 4's first GPU call, profiles/r04_first_call.txt; on by default since.)
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "owned_groups_worker.py")
     outs = []
     for owned in ("1", "0"):
         out = str(tmp_path / ("owned%s.npz" % owned))
-        env = dict(os.environ, PCLHIP_OWNED_GROUPS=owned)
-        r = subprocess.run([sys.executable, worker, out, "90000"], env=env, capture_output=True, text=True, timeout=1200)
+        r = subprocess.run([sys.executable, worker, out, "90000", owned], capture_output=True, text=True, timeout=1200)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(np.load(out))
     a, b = outs
@@ -218,3 +214,78 @@ def test_served_group_lists_equal_the_full_pass(tmp_path):
     assert 0 < len(a["strip_plane_q"]) < 90000 // 4 and 0 < len(a["corner_plane_q"]) < 90000 // 4
     assert len(a["all_plane_q"]) == 90000
     assert a["strip_plane_counts"][0] != a["strip_plane_counts"][2] and a["corner_point_counts"][0] != a["corner_point_counts"][5]
+
+
+class _DeviceCopy:
+    """a numpy array copied into device memory through the HIP runtime the library itself uses (the emulation's on the CPU
+    tier, libamdhip64 on the GPU box) -- no torch in between"""
+
+    def __init__(self, a):
+        import ctypes as C
+        from pcl_amd import _lib
+        lib = _lib.load()
+        self.rt = lib if hasattr(lib, "hipMalloc") and os.environ.get("PCLHIP_ALLOW_WAVESIM") == "1" else C.CDLL("libamdhip64.so")
+        self.a = np.ascontiguousarray(a)
+        self.ptr = C.c_void_p()
+        assert self.rt.hipMalloc(C.byref(self.ptr), C.c_size_t(max(self.a.nbytes, 16))) == 0
+        if self.a.nbytes:
+            assert self.rt.hipMemcpy(self.ptr, C.c_void_p(self.a.ctypes.data), C.c_size_t(self.a.nbytes), 1) == 0
+
+    def free(self):
+        self.rt.hipFree(self.ptr)
+
+
+@pytest.mark.parametrize("kind", ["surface", "lattice", "few", "nan", "line"])
+def test_device_partition_and_selection_equal_the_host_code(kind):
+    # shard_dev.hip (clouds in device memory: radix selection of the cuts, flag / scan / scatter of the halo) against
+    # shard.cpp (host clouds: nth_element, filter): the same regions bit for bit and the same ascending index lists
+    import ctypes as C
+    import pcl_amd
+    from pcl_amd import _lib, synth
+    pcl_amd.Context(0)
+    lib = _lib.load()
+    rng = np.random.default_rng(17)
+    if kind == "surface":
+        cloud = synth.gaussian_surface(200_003, synth.TARGET_SEED)
+    elif kind == "lattice":                      # many equal coordinates: ties at every cut, -0.0 next to +0.0
+        cloud = np.ones((50_000, 4), np.float32)
+        cloud[:, :3] = rng.integers(-3, 4, (50_000, 3)).astype(np.float32)
+        cloud[::7, 0] = -0.0
+    elif kind == "few":                          # fewer points than slabs
+        cloud = np.ones((5, 4), np.float32)
+        cloud[:, :3] = rng.normal(size=(5, 3)).astype(np.float32)
+    elif kind == "nan":
+        cloud = np.ones((30_000, 4), np.float32)
+        cloud[:, :3] = rng.normal(size=(30_000, 3)).astype(np.float32)
+        cloud[rng.integers(0, 30_000, 2_000), rng.integers(0, 3, 2_000)] = np.nan
+        cloud[100, 1] = np.inf
+    else:                                        # a line: two axes without extent
+        cloud = np.ones((20_000, 4), np.float32)
+        cloud[:, :3] = 0.25
+        cloud[:, 1] = rng.uniform(-5, 5, 20_000).astype(np.float32)
+    dev = _DeviceCopy(cloud)
+    try:
+        n, stride = len(cloud), 16
+        for slabs in (1, 2, 3, 5, 8):
+            host = np.zeros((slabs, 6), np.float32)
+            devr = np.zeros((slabs, 6), np.float32)
+            fp = C.POINTER(C.c_float)
+            _lib.check(lib.pclhip_partition_slabs(C.c_void_p(cloud.ctypes.data), stride, n, slabs, host.ctypes.data_as(fp)))
+            _lib.check(lib.pclhip_partition_slabs(dev.ptr, stride, n, slabs, devr.ctypes.data_as(fp)))
+            assert np.array_equal(host.view(np.uint32), devr.view(np.uint32)), (kind, slabs, host, devr)
+            for g in range(slabs):
+                for margin in (0.0, 0.07):
+                    lists = []
+                    for ptr in (C.c_void_p(cloud.ctypes.data), dev.ptr):
+                        cnt = C.c_uint64(0)
+                        reg = host[g].ctypes.data_as(fp)
+                        st = lib.pclhip_select_region(ptr, stride, n, reg, margin, None, 0, C.byref(cnt))
+                        assert st in (0, -5)
+                        out = np.empty(int(cnt.value), np.int32)
+                        if len(out):
+                            _lib.check(lib.pclhip_select_region(ptr, stride, n, reg, margin, C.c_void_p(out.ctypes.data),
+                                                                len(out), C.byref(cnt)))
+                        lists.append(out)
+                    assert np.array_equal(lists[0], lists[1]), (kind, slabs, g, margin)
+    finally:
+        dev.free()

@@ -72,58 +72,81 @@ def test_run_steps_is_align_repeated(gpu, mode):
     assert icp.nr_iterations_ == k2 and np.array_equal(icp.getFinalTransformation(), T2)
 
 
-def test_device_loop_matches_host_loop_twin(gpu, tmp_path):
-    # PCLHIP_ICP_HOST_LOOP=1 runs the same iterations with the read-back + host solve + host criteria of
-    # round 1 (still the path of rejectors / reciprocal correspondences).  The switch is read once per
-    # process, so the host twin runs in a subprocess.  Device and host libm may differ in the last ulp of a
-    # double sin/cos: the 4x4 agree to float rounding, iteration counts and states exactly.
+def _host_loop_align(icp, conv):
+    """IterativeClosestPoint::computeTransformation (impl/icp.hpp:113-268) driven from the HOST, composed from the C ABI's
+    pieces: pclhip_icp_iterate (search + accumulate, record read back) -> pclhip_solve_transformation ->
+    pclhip_convergence_has_converged.  The twin of the device-driven loop inside pclhip_icp_align (same kernels for the
+    search and the sums, the solve and the criteria on the host instead of in icp_finalize_kernel)."""
+    import ctypes as C
+    from pcl_amd import _lib
+    lib = _lib.load()
+    icp.reset()
+    final = np.eye(4, dtype=np.float32)
+    T_apply = np.eye(4, dtype=np.float32)
+    Tk = np.eye(4, dtype=np.float32)
+    it, converged = 0, False
+    while True:
+        sums = icp.iterate(T_apply)
+        ncorr = sums[28]
+        if ncorr < icp.p.min_number_correspondences:          # icp.hpp:204-213
+            conv.convergence_state = 5                          # NO_CORRESPONDENCES
+            break
+        Tk = icp.solve(sums)                                    # :216-217
+        T_apply = Tk                                            # :220 (applied by the next launch)
+        final = (Tk @ final).astype(np.float32)                 # :223 (float product, as the library's mat4_mul_f32)
+        it += 1
+        mse = sums[27] / ncorr
+        t = np.ascontiguousarray(Tk, np.float32).reshape(16)
+        converged = bool(lib.pclhip_convergence_has_converged(C.byref(icp.p), C.byref(conv), it,
+                                                              t.ctypes.data_as(C.POINTER(C.c_float)), float(mse)))
+        if converged or conv.convergence_state != 0:
+            break
+    return {"T": final, "it": it, "state": int(conv.convergence_state), "conv": converged, "last": Tk}
+
+
+def test_device_loop_matches_host_loop_twin(gpu):
+    # The device-driven loop against a host-driven one composed from pclhip_icp_iterate / pclhip_solve_transformation /
+    # pclhip_convergence_has_converged (round 1's loop, which left the library in round 4: it is what a caller with a foreign
+    # estimation plugged in writes).  Device and host libm may differ in the last ulp of a double sin/cos: the 4x4 agree to
+    # float rounding, iteration counts and states exactly.
+    import ctypes as C
     import pcl_amd
-    script = tmp_path / "twin.py"
-    script.write_text('''
-import json, sys
-import numpy as np
-sys.path.insert(0, %r)
-import pcl_amd
-from oracle import pcl_oracle as orc
-ctx = pcl_amd.Context(0)
-out = {}
-z = np.load(%r)
-def xyz1(a):
-    o = np.ones((len(a), 4), np.float32); o[:, :3] = a[:, :3]; return o
-cases = {"bunny": (xyz1(z["bun4"]), xyz1(z["bun0"]), 0, None, 0.05)}
-tgt, src, _ = pcl_amd.synth.icp_pair(60_000)
-cases["p2plane"] = (tgt, src, 1, orc.KdTree(tgt).normals(tgt, 8, viewpoint=(0, 0, 10))[0], 0.1)
-cases["p2point"] = (tgt, src, 0, None, 0.1)
-for name, (tgt, src, mode, nrm, md) in cases.items():
-    cls = pcl_amd.IterativeClosestPointWithNormals if mode == 1 else pcl_amd.IterativeClosestPoint
-    icp = cls(ctx)
-    icp.setInputTarget(tgt)
-    if nrm is not None:
-        icp.setTargetNormals(nrm)
-    icp.setInputSource(src)
-    icp.setMaximumIterations(25)
-    icp.setMaxCorrespondenceDistance(md)
-    icp.setTransformationEpsilon(1e-9)
-    res = []
-    for rep in range(2):   # twice: the criteria's MSE memory persists across align() calls
-        icp.align()
-        res.append({"T": icp.getFinalTransformation().tolist(), "it": icp.nr_iterations_, "state": icp.getConvergenceState(),
-                    "conv": icp.hasConverged(), "last": icp.getLastIncrementalTransformation().tolist()})
-    out[name] = res
-print("RESULT" + json.dumps(out))
-''' % (ROOT, os.path.join(ROOT, "tests", "golden", "bunny.npz")))
-    runs = {}
-    for host in ("0", "1"):
-        env = dict(os.environ, PCLHIP_ICP_HOST_LOOP=host)
-        p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-2000:]
-        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1]
-        runs[host] = json.loads(line[len("RESULT"):])
-    for name in runs["0"]:
-        for a, b in zip(runs["0"][name], runs["1"][name]):
-            assert a["it"] == b["it"] and a["state"] == b["state"] and a["conv"] == b["conv"], (name, a, b)
-            assert np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max() < 2e-6, name
-            assert np.abs(np.asarray(a["last"]) - np.asarray(b["last"])).max() < 2e-6, name
+    from pcl_amd import _lib
+    from oracle import pcl_oracle as orc
+    z = np.load(os.path.join(ROOT, "tests", "golden", "bunny.npz"))
+
+    def xyz1(a):
+        o = np.ones((len(a), 4), np.float32)
+        o[:, :3] = a[:, :3]
+        return o
+    states = ["NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE", "NO_CORRESPONDENCES", "FAILURE_AFTER_MAX_ITERATIONS"]
+    cases = {"bunny": (xyz1(z["bun4"]), xyz1(z["bun0"]), 0, None, 0.05)}
+    tgt, src, _ = pcl_amd.synth.icp_pair(60_000)
+    cases["p2plane"] = (tgt, src, 1, orc.KdTree(tgt).normals(tgt, 8, viewpoint=(0, 0, 10))[0], 0.1)
+    cases["p2point"] = (tgt, src, 0, None, 0.1)
+    for name, (tgt, src, mode, nrm, md) in cases.items():
+        def make():
+            cls = pcl_amd.IterativeClosestPointWithNormals if mode == 1 else pcl_amd.IterativeClosestPoint
+            icp = cls(gpu)
+            icp.setInputTarget(tgt)
+            if nrm is not None:
+                icp.setTargetNormals(nrm)
+            icp.setInputSource(src)
+            icp.setMaximumIterations(25)
+            icp.setMaxCorrespondenceDistance(md)
+            icp.setTransformationEpsilon(1e-9)
+            return icp
+        dev, host = make(), make()
+        host._ensure()
+        conv = _lib.ConvergenceState()
+        _lib.load().pclhip_convergence_init(C.byref(conv))
+        for rep in range(2):   # twice: the criteria's MSE memory persists across align() calls
+            dev.align()
+            b = _host_loop_align(host, conv)
+            assert dev.nr_iterations_ == b["it"] and dev.getConvergenceState() == states[b["state"]], (name, rep, b)
+            assert dev.hasConverged() == b["conv"], (name, rep)
+            assert np.abs(dev.getFinalTransformation() - b["T"]).max() < 2e-6, name
+            assert np.abs(dev.getLastIncrementalTransformation() - b["last"]).max() < 2e-6, name
 
 
 @pytest.fixture(scope="module")

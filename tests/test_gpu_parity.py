@@ -1197,47 +1197,6 @@ def test_icp_lattice_ties_with_seeds_bit_exact(gpu, orc):
         assert np.array_equal(q, oq) and np.array_equal(m, om) and np.array_equal(d, od), it
 
 
-def test_fused_single_kernel_variant_matches_default(gpu, tmp_path):
-    # PCLHIP_ICP_FUSED=1 selects the single-kernel iteration (search + accumulation in one launch); it must
-    # produce the same correspondences and, up to fp64 summation order, the same records.  The switch is read
-    # once per process, so the variant runs in a subprocess.
-    import subprocess
-    import sys
-    import os
-    script = tmp_path / "fused.py"
-    script.write_text('''
-import sys, numpy as np
-sys.path.insert(0, %r)
-import pcl_amd
-tgt, src, _ = pcl_amd.synth.icp_pair(60000)
-ctx = pcl_amd.Context(0)
-tree = pcl_amd.KdTree(ctx); tree.setInputCloud(tgt)
-ne = pcl_amd.NormalEstimation(ctx); ne.setInputCloud(tgt); ne.setSearchMethod(tree); ne.setKSearch(8); ne.setViewPoint(0, 0, 10)
-ne.compute(want_output=False)
-out = {}
-for name, cls in (("plane", pcl_amd.IterativeClosestPointWithNormals), ("point", pcl_amd.IterativeClosestPoint)):
-    icp = cls(ctx); icp.setSearchMethodTarget(tree); icp.setInputSource(src); icp.reset()
-    T = np.eye(4, dtype=np.float32)
-    for it in range(4):
-        sums = icp.iterate(T, max_dist=0.1); T = icp.solve(sums)
-        q, m, d = icp.fetchCorrespondences()
-        out["%%s_m%%d" %% (name, it)] = m; out["%%s_d%%d" %% (name, it)] = d; out["%%s_s%%d" %% (name, it)] = sums
-np.savez(sys.argv[1], **out)
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    res = {}
-    for fused in ("0", "1"):
-        env = dict(os.environ, PCLHIP_ICP_FUSED=fused)
-        path = str(tmp_path / ("r%s.npz" % fused))
-        subprocess.run([sys.executable, str(script), path], check=True, env=env, timeout=300)
-        res[fused] = np.load(path)
-    for key in res["0"].files:
-        a, b = res["0"][key], res["1"][key]
-        if "_s" in key:
-            assert np.allclose(a, b, rtol=1e-9, atol=1e-12), key   # fp64 sums, different partial-sum grouping
-        else:
-            assert np.array_equal(a, b), key
-
-
 # ------------------------------------------------------------------------------------------------
 # mirrors of the reference's own end-to-end registration tests (property checks, no oracle)
 # ------------------------------------------------------------------------------------------------

@@ -43,9 +43,8 @@ def wavesim_lib():
 
 @pytest.fixture(scope="module")
 def variant_lib(tmp_path_factory):
-    """ONE more build of the emulation for the tests of compile-time variants: the served-group history capped at 3
-    (-DPCLHIP_OWN_HIST_CAP=3) and the group leaf lists (-DPCLHIP_GROUP_LISTS=1; they stay out of the sharded search, so the
-    two do not meet)."""
+    """ONE more build of the emulation for the test of a build parameter: the served-group history capped at 3
+    (-DPCLHIP_OWN_HIST_CAP=3)."""
     if not os.path.exists(CLANG) or shutil.which("make") is None:
         pytest.skip("needs the ROCm clang++ and make")
     build = tmp_path_factory.mktemp("ws_variant")
@@ -56,7 +55,7 @@ def variant_lib(tmp_path_factory):
     for f in ("wavesim.hpp", "wavesim_rt.cpp"):
         shutil.copy(os.path.join(WS, f), str(build / f))
     r = subprocess.run(["make", "-C", str(build), "-j", str(min(16, os.cpu_count() or 1)),
-                        "EXTRA=-DPCLHIP_OWN_HIST_CAP=3 -DPCLHIP_GROUP_LISTS=1"], capture_output=True, text=True)
+                        "EXTRA=-DPCLHIP_OWN_HIST_CAP=3"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     return str(build / "libpclhip_wavesim.so")
 
@@ -117,8 +116,7 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
     import numpy as np
     n = 60_000
     work = str(tmp_path)
-    env = dict(os.environ, PCLHIP_LIB=wavesim_lib, PCLHIP_ALLOW_WAVESIM="1", WAVESIM_THREADS="8",
-               PCLHIP_OWNED_GROUPS="1")   # target mode: the ranks walk their served groups (opt-in until hardware has run it)
+    env = dict(os.environ, PCLHIP_LIB=wavesim_lib, PCLHIP_ALLOW_WAVESIM="1", WAVESIM_THREADS="8")  # (target mode: the ranks walk their served groups)
     worker = os.path.join(WS, "two_rank_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, mode, str(r), str(world), work, str(n)], env=env, cwd=ROOT,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -157,15 +155,15 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
 def test_served_groups_when_an_alignment_outlasts_the_history(variant_lib, tmp_path):
     """The served-group lists of the sharded device loop remember the transforms of at most OWN_HIST_CAP launches (128);
     past that every group is served in every launch.  A build with a cap of 3 runs 12-iteration alignments through that
-    path: served lists, matches, float distances and step records equal the full pass's (PCLHIP_OWNED_GROUPS=0)."""
+    path: served lists, matches, float distances and step records equal the full pass's (option "served_groups" 0)."""
     import numpy as np
     lib = variant_lib
     worker = os.path.join(ROOT, "tests", "owned_groups_worker.py")
     outs = []
     for owned in ("1", "0"):
         out = str(tmp_path / ("owned%s.npz" % owned))
-        env = dict(os.environ, PCLHIP_LIB=lib, PCLHIP_ALLOW_WAVESIM="1", PCLHIP_OWNED_GROUPS=owned)
-        r = subprocess.run([sys.executable, worker, out, "60000"], env=env, capture_output=True, text=True, timeout=900)
+        env = dict(os.environ, PCLHIP_LIB=lib, PCLHIP_ALLOW_WAVESIM="1")
+        r = subprocess.run([sys.executable, worker, out, "60000", owned], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(np.load(out))
     a, b = outs
@@ -181,31 +179,9 @@ def test_served_groups_when_an_alignment_outlasts_the_history(variant_lib, tmp_p
             assert np.array_equal(a[k], b[k]), k
 
 
-def test_group_leaf_lists_variant_is_exact_and_used(variant_lib, wavesim_lib):
-    """-DPCLHIP_GROUP_LISTS=1 (off by default until it has been timed on the GPU): the seeded ICP search keeps every group's
-    leaf list across iterations and searches from it while the group's motion allows (traverse.hpp: GroupRec).  A build of
-    the emulation with it: eight iterations bit for bit the oracle's, converged iterations searched from the records with
-    no node scan at all, and the fuzz slices of the GPU tier (all ICP parity tests with WAVESIM_FULL=1) on that build."""
-    lib = variant_lib
-    env = dict(os.environ, PCLHIP_LIB=lib, PCLHIP_ALLOW_WAVESIM="1")
-    r = subprocess.run([sys.executable, os.path.join(WS, "group_lists_probe.py"), "200000"], env=env, capture_output=True,
-                       text=True, timeout=900, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    last = [ln for ln in r.stdout.splitlines() if ln.startswith("GROUP_LISTS")][-1]
-    vals = dict(kv.split("=") for kv in last.split()[1:])
-    print(r.stdout[-1200:])
-    assert int(vals["mismatches"]) == 0
-    assert float(vals["from_record"]) > 0.9 and float(vals["nodes"]) < 0.3
-    # the device-driven loop with restarts inside the queue (records live across alignments): every step record of the
-    # variant build equals the default build's
-    lines = []
-    for use in (lib, os.path.join(WS, "libpclhip_wavesim.so")):
-        e2 = dict(os.environ, PCLHIP_LIB=use, PCLHIP_ALLOW_WAVESIM="1")
-        r2 = subprocess.run([sys.executable, os.path.join(WS, "loop_records.py"), "120000"], env=e2, capture_output=True, text=True,
-                            timeout=900, cwd=ROOT)
-        assert r2.returncode == 0, r2.stdout[-1500:] + r2.stderr[-1500:]
-        lines.append(r2.stdout.strip().splitlines()[-1])
-    assert lines[0] == lines[1] and len(lines[0]) > 500
+def test_fuzz_slices_of_the_gpu_tier(wavesim_lib):
+    """The bounded fuzz slices of the GPU tier (all ICP parity tests with WAVESIM_FULL=1) on the emulation."""
+    lib = wavesim_lib
     files, keyword = ["test_gpu_fuzz.py"], NOT_HERE      # unseeded + seeded correspondences of random / degenerate clouds
     if os.environ.get("WAVESIM_FULL") == "1":             # every ICP-related parity test of the GPU tier (~45 s more)
         files = ["test_gpu_parity.py", "test_gpu_loop.py", "test_gpu_fuzz.py"]
