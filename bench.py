@@ -57,12 +57,23 @@ def parse():
                     help="config 5 on ONE GPU: play rank --virtual-rank of this many ranks (its kd slab + halo, its region "
                          "mask, no collective): what one rank of a G-GPU job does per iteration, measurable without the node")
     ap.add_argument("--virtual-rank", type=int, default=0)
+    ap.add_argument("--full-pass", action="store_true",
+                    help="config 5: every launch walks the whole source (option served_groups = 0) instead of the served groups")
     ap.add_argument("--rejectors", default="", help="comma list of median,trimmed,one_to_one,distance: the rejector chain "
                                                      "inside the device-driven loop (configs 2/3)")
     ap.add_argument("--reciprocal", action="store_true", help="reciprocal correspondences inside the device-driven loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-align", action="store_true", help="skip the host-boundary timing (examples/bench_pcl_align.cpp)")
     return ap.parse_args()
+
+
+def kernel_sources_sha():
+    """sha256 over the sources of the search kernel (scripts/make_pmc_traffic.py stamps the counter passes with it)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("search.hip", "traverse.hpp", "standoff.hpp", "pclhip_internal.hpp"):
+        h.update(open(os.path.join(ROOT, "pcl_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def git_head():
@@ -210,16 +221,21 @@ def main():
                 "iteration_alg_bytes_per_corr": B_ALG_ITER[mode]}
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if cfg == 3 and os.path.exists(traffic_file):
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes of this very command
-        # (scripts/profile_gpu.sh regenerates the file and stamps the commit it measured)
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes of this very command (scripts/profile_gpu.sh
+        # regenerates the file and stamps the commit and the hash of the search kernel's sources it measured); a file
+        # that was measured on other kernel sources than the ones in this tree is NOT reported
         try:
             tj = json.load(open(traffic_file))
-            roofline["traffic"] = tj.get("icp_search_bytes_per_launch")
+            fresh = tj.get("kernel_sources_sha") == kernel_sources_sha()
+            roofline["traffic"] = tj.get("icp_search_bytes_per_launch") if fresh else None
             roofline["traffic_source"] = {"file": "profiles/pmc_traffic.json", "commit": tj.get("commit"),
                                           "date": tj.get("date"), "command": tj.get("command"),
-                                          "note": "NOT measured in this run: FETCH_SIZE / WRITE_SIZE need their own "
-                                                  "rocprofv3 --pmc passes; this is the per-launch average of those passes "
-                                                  "of the same command at the commit named here"}
+                                          "kernel_sources_match": fresh,
+                                          "note": ("NOT measured in this run: FETCH_SIZE / WRITE_SIZE need their own "
+                                                   "rocprofv3 --pmc passes; this is the per-launch average of those passes "
+                                                   "of the same command at the commit named here, whose search kernel "
+                                                   "sources are the ones of this tree") if fresh else
+                                                  "the counter passes on file are of other kernel sources: traffic not reported"}
         except Exception:
             pass
 

@@ -24,15 +24,19 @@ def run_config5(args, ctx, comm, rank, local_rank, world, fence):
 
     n = args.points or 100_000_000
     max_dist = 0.1
+    # The clouds are generated where they are used -- in device memory (pcl_amd.synth.gaussian_surface_device: the same
+    # counter-based stream) -- and cut there too (pclhip_partition_slabs / pclhip_select_region on a device cloud:
+    # shard_dev.hip): no rank holds the whole target on the host.
+    dev = torch.device("cuda", torch.cuda.current_device())
     t0 = time.perf_counter()
-    tgt_h = synth.gaussian_surface(n, synth.TARGET_SEED)
+    tgt = synth.gaussian_surface_device(n, synth.TARGET_SEED, device=dev)
+    torch.cuda.synchronize()
     gen_s = time.perf_counter() - t0
     T_inv = np.linalg.inv(synth.ground_truth_transform())
     setup = {}
     if args.replicated:
         start, count = shard_range(n, rank, world)
-        src_h = synth.apply_rigid(T_inv, synth.gaussian_surface(count, synth.SOURCE_SEED, start=start))
-        tgt = torch.from_numpy(tgt_h).cuda()
+        src = synth.apply_rigid_device(T_inv, synth.gaussian_surface_device(count, synth.SOURCE_SEED, start=start, device=dev))
         tree = pcl_amd.KdTree(ctx)
         tree.setInputCloud(tgt)
         ne = pcl_amd.NormalEstimation(ctx)
@@ -44,23 +48,25 @@ def run_config5(args, ctx, comm, rank, local_rank, world, fence):
         region = None
         setup.update(index_points=tree.size(), index_build_ms=round(tree.build_ms(), 3), normals_kernel_ms=round(tree.lastKernelMs(), 3))
     else:
-        src_h = synth.apply_rigid(T_inv, synth.gaussian_surface(n, synth.SOURCE_SEED))
+        src = synth.apply_rigid_device(T_inv, synth.gaussian_surface_device(n, synth.SOURCE_SEED, device=dev))
+        torch.cuda.synchronize()
         t1 = time.perf_counter()
         # --virtual-world G --virtual-rank r on one GPU: this process plays rank r of G (slab, halo and region of that
         # rank; the record is not exchanged, so the alignment is the one of the points this rank serves -- what is
-        # measured is a rank's work per iteration, e.g. with and without the served-group lists, PCLHIP_OWNED_GROUPS=0)
+        # measured is a rank's work per iteration, e.g. with and without the served-group lists, --full-pass)
         vworld = args.virtual_world if (args.virtual_world > 1 and world == 1) else 0
-        st = ShardedTarget(ctx, tgt_h, args.virtual_rank if vworld else rank, vworld or world, max_dist, k_normals=args.knn,
+        if getattr(args, "full_pass", False):
+            ctx.setOption("served_groups", 0)
+        st = ShardedTarget(ctx, tgt, args.virtual_rank if vworld else rank, vworld or world, max_dist, k_normals=args.knn,
                            viewpoint=(0, 0, 10))
         tree, region = st.tree, st.region
         from pcl_amd.dist import select_region
-        owned_points = int(len(select_region(tgt_h, st.region, 0.0)))
+        owned_points = int(len(select_region(tgt, st.region, 0.0)))
         setup.update(index_points=tree.size(), owned_points=owned_points, halo_margin=round(st.margin, 5),
                      kth_neighbour_distance=round(st.kth, 6),
                      normals_exact=bool(st.normals_exact), index_build_ms=round(tree.build_ms(), 3),
                      shard_setup_s=round(time.perf_counter() - t1, 2))
-    del tgt_h
-    src = torch.from_numpy(src_h).cuda()
+    del tgt
     icp = pcl_amd.IterativeClosestPointWithNormals(ctx)
     icp.setSearchMethodTarget(tree, True)
     icp.setInputSource(src)
@@ -131,7 +137,7 @@ def run_config5(args, ctx, comm, rank, local_rank, world, fence):
                       "ended": s["alignment_ended"], "state": s["state"]} for s in steps],
         "setup": dict(setup, synth_gen_s=round(gen_s, 1)),
         "virtual_rank": ({"world": args.virtual_world, "rank": args.virtual_rank,
-                          "served_groups_lists": os.environ.get("PCLHIP_OWNED_GROUPS", "0") == "1",
+                          "served_groups_lists": not getattr(args, "full_pass", False),
                           "note": "value / ms_per_step are ONE rank's share of the job; not a multi-GPU measurement"}
                          if (args.virtual_world > 1 and world == 1) else None),
         "self_check": {"rccl_nranks": world if comm is not None else 1, "native_communicator": comm is not None,

@@ -90,3 +90,66 @@ def icp_pair(n, start=0, n_target=None, target_start=0):
     T = ground_truth_transform()
     src = apply_rigid(np.linalg.inv(T), src)
     return tgt, src, T
+
+
+# ---- the same stream generated where it is used: in device memory (bench.py --config 5: no rank materialises the
+# 100M-point target on the host).  Same counter-based RNG bit for bit (int64 arithmetic wraps like uint64); the heights
+# go through the device's exp / log / cos in double, so a z may differ from gaussian_surface()'s in its last float bit --
+# the parity tests therefore keep the numpy generator, this one feeds measurements only.
+def _lsr(z, k):
+    return (z >> k) & ((1 << (64 - k)) - 1)
+
+
+def _i64(v):
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _splitmix64_t(x):
+    x = x + _i64(0x9E3779B97F4A7C15)
+    z = (x ^ _lsr(x, 30)) * _i64(0xBF58476D1CE4E5B9)
+    z = (z ^ _lsr(z, 27)) * _i64(0x94D049BB133111EB)
+    return z ^ _lsr(z, 31)
+
+
+def _u01_t(seed, i, c):
+    import torch
+    h = _splitmix64_t(_i64(int(seed)) ^ _splitmix64_t(4 * i + c))
+    return _lsr(h, 40).to(torch.float32) * (2.0 ** -24)
+
+
+def gaussian_surface_device(n, seed=TARGET_SEED, start=0, noise=1e-4, device="cuda", chunk=1 << 24):
+    """gaussian_surface() as an (n, 4) float32 torch tensor generated on `device`."""
+    import math
+    import torch
+    out = torch.empty((n, 4), dtype=torch.float32, device=device)
+    for b in range(0, n, chunk):
+        e = min(n, b + chunk)
+        i = torch.arange(start + b, start + e, dtype=torch.int64, device=device)
+        x = 2.0 * _u01_t(seed, i, 0) - 1.0
+        y = 2.0 * _u01_t(seed, i, 1) - 1.0
+        u1 = _u01_t(seed, i, 2).double() + 2.0 ** -25
+        u2 = _u01_t(seed, i, 3).double()
+        g = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * math.pi * u2)
+        xd, yd = x.double(), y.double()
+        z = torch.zeros_like(xd)
+        for cx, cy, s, a in _BUMPS:
+            z += float(a) * torch.exp(-((xd - float(cx)) ** 2 + (yd - float(cy)) ** 2) / (2.0 * float(s) * float(s)))
+        out[b:e, 0] = x
+        out[b:e, 1] = y
+        out[b:e, 2] = (z + noise * g).float()
+        out[b:e, 3] = 1.0
+    return out
+
+
+def apply_rigid_device(T, pts):
+    """apply_rigid() on a device tensor (float64 application, float32 result, w = 1)."""
+    import torch
+    Tt = torch.as_tensor(np.asarray(T, np.float64), device=pts.device)
+    out = torch.empty((pts.shape[0], 4), dtype=torch.float32, device=pts.device)
+    step = 1 << 24
+    for b in range(0, pts.shape[0], step):
+        p = pts[b:b + step, :3].double()
+        out[b:b + step, :3] = (p @ Tt[:3, :3].T + Tt[:3, 3]).float()
+    out[:, 3] = 1.0
+    return out

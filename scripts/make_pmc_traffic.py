@@ -15,6 +15,18 @@ import os
 import sys
 
 d, commit, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def kernel_sources_sha():
+    """sha256 over the sources of the search kernel (bench.py computes the same and drops a stale file's figures)"""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pcl_amd", "csrc")
+    h = hashlib.sha256()
+    for f in ("search.hip", "traverse.hpp", "standoff.hpp", "pclhip_internal.hpp"):
+        h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
     acc = collections.defaultdict(float)
@@ -31,7 +43,7 @@ for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
             "icp_accumulate" if "icp_accumulate_kernel" in k else "normals" if "normals_kernel" in k else None
         if short:
             per[short][counter].append(v)
-out = {"commit": commit, "date": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "command": cmd,
+out = {"commit": commit, "kernel_sources_sha": kernel_sources_sha(), "date": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "command": cmd,
        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), scripts/profile_gpu.sh",
        "correction": "KB -> bytes; gfx950: FETCH_SIZE doubled (64 B tallied per 128-B request), WRITE_SIZE as reported"}
 for short, c in per.items():
