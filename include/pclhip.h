@@ -449,7 +449,11 @@ PCLHIP_API pclhip_status pclhip_transform_cloud(pclhip_ctx* ctx, const float T[1
 /* The same for the SOURCE cloud of a registration: when `in` is the host buffer pclhip_icp_set_source[_indexed] was
  * given (same address, stride and count), the records staged on the device then are used and nothing is uploaded
  * again -- the moved cloud IterativeClosestPoint::computeTransformation hands back (impl/icp.hpp:264-267:
- * output = *input_, then transformCloud) costs one download.  Any other `in` behaves like pclhip_transform_cloud. */
+ * output = *input_, then transformCloud) costs one download.  Any other `in` behaves like pclhip_transform_cloud.
+ * CONTRACT: the staged records are the cloud as it was when pclhip_icp_set_source[_indexed] was called -- like the
+ * registration's own copy of the points.  A caller that edits the buffer in place (or reuses the address for another
+ * cloud) must call pclhip_icp_set_source[_indexed] again before aligning or transforming, exactly as it must for the
+ * alignment itself to see the change; the copy is dropped there and is never kept beyond 1/8 of the device's memory. */
 PCLHIP_API pclhip_status pclhip_icp_transform_source(pclhip_icp* icp, const float T[16], int order,
                                                      const void* in, void* out, size_t stride_bytes,
                                                      uint64_t n, size_t normals_offset_bytes);

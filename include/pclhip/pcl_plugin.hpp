@@ -447,8 +447,13 @@ class RegistrationHIP : public Base {
       source_uploaded_ = nullptr;
       target_normals_of_ = nullptr;
     }
-    if (kind != SVD && tree->normalsFrom() == static_cast<const void*>(this->target_.get()))
-      target_normals_of_ = this->target_.get();  // KdTreeHIP::setInputCloud attached them from its own upload
+    // KdTreeHIP::setInputCloud attaches a PointNormal cloud's normals from its own upload.  They are the cloud's normals
+    // of THAT moment: trusted only when Registration::initCompute built the tree itself (registration.hpp:73-101 rebuilds
+    // inside align() unless force_no_recompute_).  A tree the user built beforehand (setSearchMethodTarget(tree, true))
+    // may predate the normals -- NormalEstimation writing into the same cloud afterwards --, so its first alignment
+    // uploads them, as PCL's CPU path would read them now.
+    if (kind != SVD && !this->force_no_recompute_ && tree->normalsFrom() == static_cast<const void*>(this->target_.get()))
+      target_normals_of_ = this->target_.get();
     if (kind != SVD && target_normals_of_ != this->target_.get()) {  // pcl::PointNormal: normals at +16
       const char* base = reinterpret_cast<const char*>(this->target_->points.data());
       if (pclhip_index_set_normals(tree->handle(), base + 16, sizeof(PointTarget)) != PCLHIP_OK) return;

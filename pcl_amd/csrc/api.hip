@@ -130,8 +130,12 @@ pclhip_status reserve_arena(pclhip_ctx* ctx, size_t bytes) {
 // boxes, discs, rank: ~60), the build's and the source ordering's scratch (~100), the source arrays of a registration
 // (copies, matches, distances: ~50) and a VoxelGrid pass (~60) -- 288 with slack.  Option "arena_mb" overrides (0: none).
 void dev_reserve_for_points(pclhip_ctx* ctx, uint64_t points) {
-  if (ctx == nullptr || ctx->arena_tried || ctx->arena != nullptr || points < 1000000ull) return;
-  ctx->arena_tried = true;
+  if (ctx == nullptr || points < 1000000ull) return;
+  {
+    std::lock_guard<std::mutex> lock(ctx->cache_mutex);  // (two threads of one context may bring their first clouds at once)
+    if (ctx->arena_tried || ctx->arena != nullptr) return;
+    ctx->arena_tried = true;
+  }
   size_t want = size_t(points) * 288;
   if (ctx->opt_arena_mb >= 0) want = size_t(ctx->opt_arena_mb) << 20;
   size_t free_b = 0, total_b = 0;
@@ -195,6 +199,25 @@ hipError_t dev_malloc(pclhip_ctx* ctx, void** p, size_t bytes) {
     (void)hipGetLastError();
     dev_cache_release(ctx);
     e = hipMalloc(p, bytes);
+  }
+  if (e != hipSuccess) {  // still: an arena nobody holds a block of goes back to the device too (another context or
+    (void)hipGetLastError();  // process on this GPU, or one allocation larger than what the arena left free)
+    char* idle = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(ctx->cache_mutex);
+      if (ctx->arena != nullptr && ctx->arena_free.size() == 1 && ctx->arena_free.begin()->first == 0 &&
+          ctx->arena_free.begin()->second == ctx->arena_bytes) {
+        idle = ctx->arena;
+        ctx->arena = nullptr;
+        ctx->arena_bytes = 0;
+        ctx->arena_free.clear();
+      }
+    }
+    if (idle != nullptr) {
+      (void)hipStreamSynchronize(ctx->stream);  // blocks handed back to the arena may still be read by queued work
+      (void)hipFree(idle);
+      e = hipMalloc(p, bytes);
+    }
   }
   if (e == hipSuccess) {
     std::lock_guard<std::mutex> lock(ctx->cache_mutex);
@@ -1061,11 +1084,17 @@ pclhip_status pclhip_icp_set_source_indexed(pclhip_icp* icp, const void* points,
   if (st != PCLHIP_OK) return st;
   if (owned != nullptr) {
     // a host cloud: its staged copy stays with the registration, so that the moved cloud an alignment hands back
-    // (pclhip_icp_transform_source) does not upload the same records again
-    icp->src_records = owned;
-    icp->src_records_host = points;
-    icp->src_records_stride = stride;
-    icp->src_records_n = n;
+    // (pclhip_icp_transform_source) does not upload the same records again.  The copy is the cloud AS IT WAS AT THIS CALL
+    // (pclhip.h says so); it is not kept when it would hold more than an eighth of the device's memory.
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && size_t(n) * stride <= total_b / 8) {
+      icp->src_records = owned;
+      icp->src_records_host = points;
+      icp->src_records_stride = stride;
+      icp->src_records_n = n;
+    } else {
+      guard.add(owned);
+    }
   }
   const void* dsel = nullptr;
   if (indices) {  // PCLBase::setIndices / setIndicesSource: only these points take part

@@ -281,6 +281,31 @@ int main(int argc, char** argv) {
       for (int c = 0; c < 3; ++c) EXPECT(std::fabs(T(r, c) - T_point[4 * r + c]) < 1e-1);
     }
     EXPECT(!reg->getUseSymmetricObjective());
+    // a search tree built BEFORE the cloud had its normals, handed over with force_no_recompute -- the
+    // alignment must use the normals the cloud has NOW (as PCL's CPU path would read them), not the ones the tree's own
+    // upload happened to see
+    pcl::PointCloud<pcl::PointNormal>::Ptr late(new pcl::PointCloud<pcl::PointNormal>(*tn));
+    for (auto& p : late->points) { p.normal_x = 1.0f; p.normal_y = 0.0f; p.normal_z = 0.0f; }   // placeholders
+    auto early_tree = std::make_shared<KdTreeHIP<pcl::PointNormal>>(dev);
+    EXPECT(early_tree->setInputCloud(late));
+    for (std::size_t i = 0; i < late->size(); ++i) {                                             // the real ones arrive
+      (*late)[i].normal_x = (*tn)[i].normal_x; (*late)[i].normal_y = (*tn)[i].normal_y; (*late)[i].normal_z = (*tn)[i].normal_z;
+    }
+    IterativeClosestPointWithNormalsHIP<pcl::PointNormal, pcl::PointNormal> reg2(dev);
+    reg2.setInputSource(sn);
+    reg2.setInputTarget(late);
+    reg2.setSearchMethodTarget(early_tree, true);
+    reg2.setMaximumIterations(50);
+    reg2.setTransformationEpsilon(1e-8);
+    reg2.setMaxCorrespondenceDistance(0.05);
+    pcl::PointCloud<pcl::PointNormal> out2;
+    reg2.align(out2);
+    EXPECT(reg2.deferredReason().empty() && reg2.hasConverged());
+    const auto T2 = reg2.getFinalTransformation();
+    bool same_pose = true;
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) same_pose = same_pose && T2(r, c) == T(r, c);
+    EXPECT(same_pose);
   }
 
   {  // 7. NormalEstimationHIP through pcl::Feature::compute (feature.hpp:195-229 -> the overridden computeFeature)
