@@ -335,9 +335,14 @@ class CorrespondenceEstimationHIP : public pcl::registration::CorrespondenceEsti
 };
 
 // ---- the whole loop on the device ------------------------------------------------------------------------
-// Shared body of the two ICP subclasses.  `Base` is pcl::IterativeClosestPoint<S,T,float> or
-// pcl::IterativeClosestPointWithNormals<S,T,float>.
-template <typename Base, typename PointSource, typename PointTarget>
+// Shared body of the two ICP subclasses.  `Base` is pcl::IterativeClosestPoint<S,T,Scalar> or
+// pcl::IterativeClosestPointWithNormals<S,T,Scalar>.  Scalar (registration.h:56, icp.h:97,339: float by default, double
+// for callers that keep their poses in double) is the type of the 4x4 matrices at the boundary: the points are float
+// either way and the reference moves them with the matrix cast to float (impl/icp.hpp:54-55); the device computes what it
+// computes for float -- float products, fp64 sums, fp64 solve -- and a double instantiation receives those matrices
+// widened.  PCL's own double instantiation keeps final = T_k * final in double: the two agree to float rounding of the
+// 4x4 (the 1e-5 Frobenius contract of SURVEY.md section 8), not bit for bit.
+template <typename Base, typename PointSource, typename PointTarget, typename Scalar = float>
 class RegistrationHIP : public Base {
  public:
   using PointCloudSource = pcl::PointCloud<PointSource>;
@@ -367,18 +372,18 @@ class RegistrationHIP : public Base {
 
   static void to_rows(const Matrix4& M, float* T) {
     for (int r = 0; r < 4; ++r)
-      for (int c = 0; c < 4; ++c) T[4 * r + c] = M(r, c);
+      for (int c = 0; c < 4; ++c) T[4 * r + c] = float(M(r, c));
   }
   static void from_rows(const float* T, Matrix4& M) {
     for (int r = 0; r < 4; ++r)
-      for (int c = 0; c < 4; ++c) M(r, c) = T[4 * r + c];
+      for (int c = 0; c < 4; ++c) M(r, c) = Scalar(T[4 * r + c]);
   }
   Kind estimatorKind() const {
     using namespace pcl::registration;
     const auto* te = this->transformation_estimation_.get();
-    if (dynamic_cast<const TransformationEstimationSymmetricPointToPlaneLLS<PointSource, PointTarget, float>*>(te)) return SYM;
-    if (dynamic_cast<const TransformationEstimationPointToPlaneLLS<PointSource, PointTarget, float>*>(te)) return LLS;
-    if (dynamic_cast<const TransformationEstimationSVD<PointSource, PointTarget, float>*>(te)) return SVD;
+    if (dynamic_cast<const TransformationEstimationSymmetricPointToPlaneLLS<PointSource, PointTarget, Scalar>*>(te)) return SYM;
+    if (dynamic_cast<const TransformationEstimationPointToPlaneLLS<PointSource, PointTarget, Scalar>*>(te)) return LLS;
+    if (dynamic_cast<const TransformationEstimationSVD<PointSource, PointTarget, Scalar>*>(te)) return SVD;
     return FOREIGN;
   }
   // the rejectors the device chain knows, recognised by class name (registration.h:518-547)
@@ -418,8 +423,8 @@ class RegistrationHIP : public Base {
     const Kind kind = estimatorKind();
     std::vector<pclhip_rejector> rej;
     const auto* ce = this->correspondence_estimation_.get();
-    const bool own_ce = ce == nullptr || dynamic_cast<const CorrespondenceEstimationHIP<PointSource, PointTarget, float>*>(ce) ||
-                        dynamic_cast<const CorrespondenceEstimation<PointSource, PointTarget, float>*>(ce);
+    const bool own_ce = ce == nullptr || dynamic_cast<const CorrespondenceEstimationHIP<PointSource, PointTarget, Scalar>*>(ce) ||
+                        dynamic_cast<const CorrespondenceEstimation<PointSource, PointTarget, Scalar>*>(ce);
     if (!record_layout<PointSource>().xyz_at_0 || !record_layout<PointTarget>().xyz_at_0)
       deferred_ = "a point type without (x, y, z) floats at offset 0";
     else if (tree == nullptr || tree->handle() == nullptr) deferred_ = "the target search method is not a KdTreeHIP";
@@ -501,7 +506,7 @@ class RegistrationHIP : public Base {
     from_rows(r.last_transformation, this->transformation_);
     this->nr_iterations_ = r.nr_iterations;
     this->converged_ = r.converged != 0;
-    using Criteria = DefaultConvergenceCriteria<float>;
+    using Criteria = DefaultConvergenceCriteria<Scalar>;
     this->convergence_criteria_->setConvergenceState(static_cast<typename Criteria::ConvergenceState>(r.convergence_state));
     // impl/icp.hpp:264-267: the whole input cloud, moved by the final transformation.  (pcl::Registration::align hands
     // computeTransformation a copy of the input already -- registration.hpp:190-205 -- so the records are only copied
@@ -531,27 +536,27 @@ class RegistrationHIP : public Base {
   Timings timings_;
 };
 
-template <typename PointSource, typename PointTarget>
+template <typename PointSource, typename PointTarget, typename Scalar = float>
 class IterativeClosestPointHIP
-    : public RegistrationHIP<pcl::IterativeClosestPoint<PointSource, PointTarget, float>, PointSource, PointTarget> {
+    : public RegistrationHIP<pcl::IterativeClosestPoint<PointSource, PointTarget, Scalar>, PointSource, PointTarget, Scalar> {
  public:
-  using Ptr = std::shared_ptr<IterativeClosestPointHIP<PointSource, PointTarget>>;
+  using Ptr = std::shared_ptr<IterativeClosestPointHIP<PointSource, PointTarget, Scalar>>;
   explicit IterativeClosestPointHIP(Device::Ptr dev = Device::instance()) {
     this->reg_name_ = "IterativeClosestPointHIP";
     this->setSearchMethodTarget(std::make_shared<KdTreeHIP<PointTarget>>(dev));
-    this->setCorrespondenceEstimation(std::make_shared<CorrespondenceEstimationHIP<PointSource, PointTarget, float>>());
+    this->setCorrespondenceEstimation(std::make_shared<CorrespondenceEstimationHIP<PointSource, PointTarget, Scalar>>());
   }
 };
 
-template <typename PointSource, typename PointTarget>
+template <typename PointSource, typename PointTarget, typename Scalar = float>
 class IterativeClosestPointWithNormalsHIP
-    : public RegistrationHIP<pcl::IterativeClosestPointWithNormals<PointSource, PointTarget, float>, PointSource, PointTarget> {
+    : public RegistrationHIP<pcl::IterativeClosestPointWithNormals<PointSource, PointTarget, Scalar>, PointSource, PointTarget, Scalar> {
  public:
-  using Ptr = std::shared_ptr<IterativeClosestPointWithNormalsHIP<PointSource, PointTarget>>;
+  using Ptr = std::shared_ptr<IterativeClosestPointWithNormalsHIP<PointSource, PointTarget, Scalar>>;
   explicit IterativeClosestPointWithNormalsHIP(Device::Ptr dev = Device::instance()) {
     this->reg_name_ = "IterativeClosestPointWithNormalsHIP";
     this->setSearchMethodTarget(std::make_shared<KdTreeHIP<PointTarget>>(dev));
-    this->setCorrespondenceEstimation(std::make_shared<CorrespondenceEstimationHIP<PointSource, PointTarget, float>>());
+    this->setCorrespondenceEstimation(std::make_shared<CorrespondenceEstimationHIP<PointSource, PointTarget, Scalar>>());
   }
  protected:
   bool enforceSameDirectionNormals() const override { return this->getEnforceSameDirectionNormals(); }
@@ -699,9 +704,9 @@ class VoxelGridHIP : public pcl::VoxelGrid<PointT> {
 // ---- transformation estimators on explicit pairs ---------------------------------------------------------
 // MODE: PCLHIP_ICP_POINT_TO_POINT (TransformationEstimationSVD), PCLHIP_ICP_POINT_TO_PLANE (...PointToPlaneLLS),
 // PCLHIP_ICP_SYMMETRIC (...SymmetricPointToPlaneLLS); normals are the point types' own fields at +16.
-template <typename PointSource, typename PointTarget, int MODE>
-class TransformationEstimationHIP : public pcl::registration::TransformationEstimation<PointSource, PointTarget, float> {
-  using Base = pcl::registration::TransformationEstimation<PointSource, PointTarget, float>;
+template <typename PointSource, typename PointTarget, int MODE, typename Scalar = float>
+class TransformationEstimationHIP : public pcl::registration::TransformationEstimation<PointSource, PointTarget, Scalar> {
+  using Base = pcl::registration::TransformationEstimation<PointSource, PointTarget, Scalar>;
  public:
   using Matrix4 = typename Base::Matrix4;
   explicit TransformationEstimationHIP(Device::Ptr dev = Device::instance()) : dev_(std::move(dev)) {}
@@ -756,15 +761,17 @@ class TransformationEstimationHIP : public pcl::registration::TransformationEsti
                                              sizeof(PointTarget), n, enforce_ ? 1 : 0, m, nullptr) != PCLHIP_OK)
       return;
     for (int r = 0; r < 4; ++r)
-      for (int c = 0; c < 4; ++c) T(r, c) = m[4 * r + c];
+      for (int c = 0; c < 4; ++c) T(r, c) = Scalar(m[4 * r + c]);
   }
   Device::Ptr dev_;
   bool enforce_ = true;
 };
-template <typename S, typename T> using TransformationEstimationSVDHIP = TransformationEstimationHIP<S, T, PCLHIP_ICP_POINT_TO_POINT>;
-template <typename S, typename T> using TransformationEstimationPointToPlaneLLSHIP = TransformationEstimationHIP<S, T, PCLHIP_ICP_POINT_TO_PLANE>;
-template <typename S, typename T>
-using TransformationEstimationSymmetricPointToPlaneLLSHIP = TransformationEstimationHIP<S, T, PCLHIP_ICP_SYMMETRIC>;
+template <typename S, typename T, typename Scalar = float>
+using TransformationEstimationSVDHIP = TransformationEstimationHIP<S, T, PCLHIP_ICP_POINT_TO_POINT, Scalar>;
+template <typename S, typename T, typename Scalar = float>
+using TransformationEstimationPointToPlaneLLSHIP = TransformationEstimationHIP<S, T, PCLHIP_ICP_POINT_TO_PLANE, Scalar>;
+template <typename S, typename T, typename Scalar = float>
+using TransformationEstimationSymmetricPointToPlaneLLSHIP = TransformationEstimationHIP<S, T, PCLHIP_ICP_SYMMETRIC, Scalar>;
 
 }  // namespace plugin
 }  // namespace pclhip

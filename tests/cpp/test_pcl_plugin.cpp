@@ -308,6 +308,50 @@ int main(int argc, char** argv) {
     EXPECT(same_pose);
   }
 
+  {  // 6b. Scalar = double (registration.h:56, icp.h:97,339): the same registration with the poses kept in double
+    auto tn = load_xyz<pcl::PointNormal>(argv[2]);
+    auto sn = load_xyz<pcl::PointNormal>(argv[1]);
+    std::ifstream fn(argv[4]);
+    for (auto& p : tn->points) fn >> p.normal_x >> p.normal_y >> p.normal_z;
+    IterativeClosestPointWithNormalsHIP<pcl::PointNormal, pcl::PointNormal, float> regf(dev);
+    IterativeClosestPointWithNormalsHIP<pcl::PointNormal, pcl::PointNormal, double> regd(dev);
+    pcl::Registration<pcl::PointNormal, pcl::PointNormal, double>& base_d = regd;  // what a double pipeline holds
+    pcl::PointCloud<pcl::PointNormal> outf, outd;
+    regf.setInputSource(sn); regf.setInputTarget(tn); regf.setMaximumIterations(50);
+    regf.setTransformationEpsilon(1e-8); regf.setMaxCorrespondenceDistance(0.05);
+    base_d.setInputSource(sn); base_d.setInputTarget(tn); base_d.setMaximumIterations(50);
+    base_d.setTransformationEpsilon(1e-8); base_d.setMaxCorrespondenceDistance(0.05);
+    regf.align(outf);
+    Eigen::Matrix<double, 4, 4> guess = Eigen::Matrix<double, 4, 4>::Identity();
+    base_d.align(outd, guess);
+    EXPECT(regd.deferredReason().empty() && base_d.hasConverged() && regd.iterations() == regf.iterations());
+    const Eigen::Matrix<double, 4, 4> Td = base_d.getFinalTransformation();
+    const Eigen::Matrix4f Tf = regf.getFinalTransformation();
+    bool same = true;
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) same = same && Td(r, c) == double(Tf(r, c));
+    EXPECT(same);
+    EXPECT(outd.size() == outf.size() && outd[7].x == outf[7].x && outd[7].normal_z == outf[7].normal_z);
+    // the estimators and the point-to-point registration instantiate for double too
+    TransformationEstimationPointToPlaneLLSHIP<pcl::PointNormal, pcl::PointNormal, double> ted(dev);
+    TransformationEstimationPointToPlaneLLSHIP<pcl::PointNormal, pcl::PointNormal, float> tef(dev);
+    Eigen::Matrix<double, 4, 4> Ed = Eigen::Matrix<double, 4, 4>::Identity();
+    Eigen::Matrix4f Ef = Eigen::Matrix4f::Identity();
+    pcl::PointCloud<pcl::PointNormal> head_s, head_t;
+    for (std::size_t i = 0; i < 300; ++i) { head_s.push_back((*tn)[i]); head_t.push_back((*tn)[i]); head_s[i].x += 0.001f; }
+    ted.estimateRigidTransformation(head_s, head_t, Ed);
+    tef.estimateRigidTransformation(head_s, head_t, Ef);
+    EXPECT(Ed(0, 3) == double(Ef(0, 3)) && std::fabs(Ed(0, 3) + 0.001) < 1e-4);
+    IterativeClosestPointHIP<pcl::PointXYZ, pcl::PointXYZ, double> regp(dev);
+    auto sx = load_xyz<pcl::PointXYZ>(argv[1]);
+    auto tx = load_xyz<pcl::PointXYZ>(argv[2]);
+    regp.setInputSource(sx); regp.setInputTarget(tx); regp.setMaximumIterations(50); regp.setMaxCorrespondenceDistance(0.05);
+    pcl::PointCloud<pcl::PointXYZ> outp;
+    regp.align(outp);
+    EXPECT(regp.deferredReason().empty() && regp.hasConverged());
+    for (int r = 0; r < 3; ++r) EXPECT(std::fabs(regp.getFinalTransformation()(r, 3) - double(T_point[4 * r + 3])) < 1e-3);
+  }
+
   {  // 7. NormalEstimationHIP through pcl::Feature::compute (feature.hpp:195-229 -> the overridden computeFeature)
     auto tgt = load_xyz<pcl::PointXYZ>(argv[2]);
     auto src = load_xyz<pcl::PointXYZ>(argv[1]);
