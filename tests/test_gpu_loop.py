@@ -275,3 +275,30 @@ def test_reciprocal_correspondences_after_a_rotation(gpu, deg):
     assert np.abs(icp.getFinalTransformation().astype(np.float64) - T_ref).max() < 2e-5
     steps = icp.runSteps(ref["iterations"], guess=G)
     assert [s["num_correspondences"] for s in steps] == [len(q) for q, _ in ref["per_iter"]][:len(steps)]
+
+
+def test_device_driven_loop_correspondences_iteration_by_iteration(gpu, orc):
+    # the full-size check of tests/test_gpu_fullsize.py (device-driven loop, every iteration's correspondences against
+    # the oracle, the oracle's cloud moved by the device's own incremental transforms) at a size the CPU tier runs too
+    import pcl_amd
+    tgt, src, _ = pcl_amd.synth.icp_pair(150_000)
+    otree = orc.KdTree(tgt)
+    normals = otree.normals(tgt, 8, viewpoint=(0, 0, 10))[0]
+    gpu.setOption("icp_lookahead", 0)
+    try:
+        cur = src.copy()
+        full = None
+        for K in range(1, 12):
+            icp = _make_icp(gpu, tgt, src, 1, normals)   # a fresh object: the criteria keep their memory across align() calls
+            icp.setMaximumIterations(K)
+            icp.align()
+            if icp.nr_iterations_ < K:
+                full = icp.nr_iterations_
+                break
+            oq, om, od = otree.correspondences(cur, 0.1)
+            q, m, d = icp.fetchCorrespondences()
+            assert np.array_equal(q, oq) and np.array_equal(m, om) and np.array_equal(d.view(np.uint32), od.view(np.uint32)), K
+            cur = orc.transform_cloud(icp.getLastIncrementalTransformation(), cur, order=1)
+        assert full is not None and full >= 3
+    finally:
+        gpu.setOption("icp_lookahead", 1)
