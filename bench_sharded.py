@@ -65,7 +65,7 @@ def run_config5(args, ctx, comm, rank, local_rank, world, fence):
         setup.update(index_points=tree.size(), owned_points=owned_points, halo_margin=round(st.margin, 5),
                      kth_neighbour_distance=round(st.kth, 6),
                      normals_exact=bool(st.normals_exact), index_build_ms=round(tree.build_ms(), 3),
-                     shard_setup_s=round(time.perf_counter() - t1, 2))
+                     shard_setup_s=round(time.perf_counter() - t1, 2), shard_setup_stages_s=st.timings)
     del tgt
     icp = pcl_amd.IterativeClosestPointWithNormals(ctx)
     icp.setSearchMethodTarget(tree, True)

@@ -117,6 +117,11 @@ PCLHIP_API void pclhip_index_destroy(pclhip_index* index);
 PCLHIP_API uint64_t pclhip_index_size(const pclhip_index* index);
 /* milliseconds of GPU time spent in the last build (bbox + kd ordering by radix-sort rounds + gather + boxes) */
 PCLHIP_API double pclhip_index_build_ms(const pclhip_index* index);
+/* The order the index keeps its points in: out[j] = original index of the point at position j (pclhip_index_size entries,
+ * host or device memory).  Consecutive positions are spatial neighbours -- every aligned run of 16 * 4^k positions is one
+ * cell of a kd partition -- so a caller can lay per-point attributes out the same way.  (KdTreeFLANN keeps the
+ * corresponding permutation private: kdtree_flann.h `index_mapping_`; tests use this to check the cells.) */
+PCLHIP_API pclhip_status pclhip_index_order(pclhip_index* index, int32_t* out);
 
 /* Exact k nearest neighbours of nq query points.
  * Replaces pcl::KdTreeFLANN<PointT>::nearestKSearch (kdtree_flann.hpp:234-274) and the batch

@@ -240,6 +240,13 @@ class KdTree:
     def build_ms(self):
         return float(self.lib.pclhip_index_build_ms(self.h))
 
+    def order(self):
+        """pclhip_index_order: original index of the point at every position of the index's kd order (int32 array)."""
+        out = np.empty(self.size(), np.int32)
+        if len(out):
+            check(self.lib.pclhip_index_order(self.h, C.c_void_p(out.ctypes.data)), self.ctx.h)
+        return out
+
     def lastKernelMs(self):
         return float(self.lib.pclhip_index_last_kernel_ms(self.h))
 

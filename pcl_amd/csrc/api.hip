@@ -677,6 +677,33 @@ void pclhip_index_destroy(pclhip_index* ix) {
 uint64_t pclhip_index_size(const pclhip_index* ix) { return ix ? ix->n : 0; }
 double pclhip_index_build_ms(const pclhip_index* ix) { return ix ? ix->build_ms : 0.0; }
 
+namespace {
+__global__ void index_order_kernel(const float4* __restrict__ pts, uint32_t n, int32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = int32_t(__float_as_uint(pts[i].w));
+}
+}  // namespace
+
+pclhip_status pclhip_index_order(pclhip_index* ix, int32_t* out) {
+  if (!ix) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = ix->ctx;
+  if (ix->n == 0) return PCLHIP_OK;
+  PCLHIP_REQUIRE(ctx, out != nullptr, "null buffer");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx);
+  int32_t* d = out;
+  const bool dev = is_device_pointer(out);
+  if (!dev) {
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &d, size_t(ix->n) * sizeof(int32_t)));
+    guard.add(d);
+  }
+  hipLaunchKernelGGL(index_order_kernel, dim3((ix->n + 255) / 256), dim3(256), 0, ctx->stream, ix->pts, ix->n, d);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  if (!dev) PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, d, size_t(ix->n) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLHIP_OK;
+}
+
 pclhip_status pclhip_knn(pclhip_index* ix, const void* queries, size_t stride, uint64_t nq, int k, int32_t* out_idx,
                          float* out_d2) {
   if (!ix) return PCLHIP_ERR_INVALID;

@@ -366,17 +366,34 @@ __global__ __launch_bounds__(256) void kd_cell_split_kernel(const float4* __rest
 // ---- bottom kd rounds in one workgroup ------------------------------------------------------------
 // Segments of <= 4096 points are ordered entirely inside LDS: the rounds that cut a 4096-point segment into
 // four 1024-point slabs, those into 256-point slabs, those into 64-point cells, and the two binary cuts of a
-// cell (see above) run back to back in one launch instead of three radix sorts of the whole cloud plus the
-// cell-split kernel.  Per level: bounding box of every sub-segment -> widest axis -> bitonic sort of
-// (orderable coordinate, position) pairs inside the sub-segment.  The points stay where they are (x, y, z
-// planes in LDS); a 16-bit permutation moves.  Keys are exact float orders, so cells keep disjoint interiors.
+// cell (see above) run back to back in one launch.  The points stay where they are (x, y, z planes in LDS); a 16-bit
+// permutation moves.  Per level: bounding box of every sub-segment -> widest axis -> keys = exact unsigned order of
+// the coordinate along it, then
+//   * the three four-way levels (sub-segments of 4096 / 1024 / 256 points) only need every sub-segment CUT at its
+//     quartile order statistics -- the order inside a slab is irrelevant, the next level re-orders it along another
+//     axis.  So they do what the top rounds do across the grid (kp_* below), inside LDS: the three quartile keys by
+//     radix selection (7-bit digits from the top of the key range of the sub-segment: per-sub-segment histograms with
+//     packed 16-bit counters, after the first pass only the keys inside the three selected bins count), every point
+//     classified against them (< s1, = s1, between, ..., > s3: seven classes, monotone in the key), and the permutation
+//     rearranged by (class, previous position) with a prefix sum over the threads -- deterministic; the positional slab
+//     boundaries fall inside the "= s_k" classes, so ties at a splitter are split by count.  (Until round 4 these
+//     levels were full bitonic sorts of (key, position) pairs: 169 of the kernel's 205 compare-exchange stages,
+//     0.83 ms at 10M points.)
+//   * the two binary levels (64 and 32 points) stay bitonic sorts inside one wavefront: shuffles only.
+// Keys are exact float orders, so cells keep disjoint interiors.
 constexpr int KDB_N = 4096;
 constexpr int KDB_THREADS = 1024;
+constexpr int KDB_WAVES = KDB_THREADS / WAVE;
+constexpr int KDB_MAXSUB = KDB_N / 256;  // sub-segments of the smallest four-way level
 struct KdBlockLds {
   float x[KDB_N], y[KDB_N], z[KDB_N];
-  uint32_t key[KDB_N];
   uint16_t perm[KDB_N];
-  float wbox[KDB_THREADS / WAVE][6];
+  float wbox[KDB_WAVES][6];
+  uint32_t hist[KDB_MAXSUB][3][64];   // 128 bins of 16 bits per (sub-segment, splitter): 12 KB -- with the 56 KB of points
+                                      // and permutation two blocks still fit a CU's LDS (256 bins: one block, measured)
+  uint32_t sel_prefix[KDB_MAXSUB][3], sel_rank[KDB_MAXSUB][3], sel_digit[KDB_MAXSUB][3];
+  uint32_t max_bits;                  // widest key range among the block's sub-segments at this level
+  uint32_t wscan[KDB_WAVES][4];       // per-wave class totals: seven 16-bit fields
 };
 
 __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __restrict__ in, uint32_t n,
@@ -441,9 +458,158 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
     float best = ex;
     if (ey > best) { best = ey; a = 1; }
     if (ez > best) { a = 2; }
+    uint32_t kk[4], pp[4];
+    if (nsub >= 256u) {
+      // ---- four-way level: quartile selection + partition (block-uniform branch) ---------------------------------
+      const uint32_t sub = t / group;
+      const bool empty = !(lo[0] <= hi[0]);  // a sub-segment of padding only
+      const uint32_t kmin = orderable(a == 0 ? lo[0] : (a == 1 ? lo[1] : lo[2]));
+      const uint32_t W = empty ? 0u : orderable(a == 0 ? hi[0] : (a == 1 ? hi[1] : hi[2])) - kmin;
+      const uint32_t PAD = W + 1u;  // above every real key (finite coordinates: W < 2^32 - 1)
+      const int nb = 32 - __builtin_clz(PAD);  // bits of the key range, >= 1
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t p = 4u * t + uint32_t(e);
+        const float c = a == 0 ? s.x[idx[e]] : (a == 1 ? s.y[idx[e]] : s.z[idx[e]]);
+        kk[e] = p < cnt ? orderable(c) - kmin : PAD;
+        pp[e] = idx[e];
+      }
+      const uint32_t tin = t - sub * group;  // thread inside its sub-segment
+      if (tin < 3u) {
+        s.sel_prefix[sub][tin] = 0u;
+        s.sel_rank[sub][tin] = (tin + 1u) * group;  // position (k + 1) * nsub / 4 of the sorted order
+      }
+      if (t == 0u) s.max_bits = 0u;
+      __syncthreads();
+      if (tin == 0u) atomicMax(&s.max_bits, uint32_t(nb));
+      __syncthreads();
+      const int npass = int(s.max_bits + 6u) / 7;
+      for (int pass = 0; pass < npass; ++pass) {
+        const int hi_b = nb - 7 * pass;  // this pass decides bits [lo_b, hi_b) of the sub-segment's keys
+        const bool active = hi_b > 0;
+        const int lo_b = hi_b > 7 ? hi_b - 7 : 0;
+        const uint32_t dmask = active ? ((1u << (hi_b - lo_b)) - 1u) : 0u;
+        for (uint32_t i = t; i < uint32_t(KDB_MAXSUB * 3 * 64); i += KDB_THREADS) (&s.hist[0][0][0])[i] = 0u;
+        __syncthreads();
+        if (active) {
+          const uint32_t p0 = s.sel_prefix[sub][0], p1 = s.sel_prefix[sub][1], p2 = s.sel_prefix[sub][2];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t K = kk[e], dg = (K >> lo_b) & dmask, add = 1u << (16u * (dg & 1u));
+            if (pass == 0) {  // no bits decided yet: one histogram serves the three splitters
+              atomicAdd(&s.hist[sub][0][dg >> 1], add);
+            } else {          // (hi_b <= 25 here)
+              const uint32_t top = K >> hi_b;
+              if (top == (p0 >> hi_b)) atomicAdd(&s.hist[sub][0][dg >> 1], add);
+              if (top == (p1 >> hi_b)) atomicAdd(&s.hist[sub][1][dg >> 1], add);
+              if (top == (p2 >> hi_b)) atomicAdd(&s.hist[sub][2][dg >> 1], add);
+            }
+          }
+        }
+        __syncthreads();
+        // one wavefront per (sub-segment, splitter): the bin that holds the rank
+        const uint32_t nsubseg = uint32_t(KDB_N) / nsub;
+        for (uint32_t pr = wave; pr < nsubseg * 3u; pr += uint32_t(KDB_WAVES)) {
+          const uint32_t sb = pr / 3u, k = pr - sb * 3u;
+          // (a sub-segment whose key range is exhausted adds nothing to the histograms: marked by rank 0xFFFFFFFF)
+          const uint32_t rank = s.sel_rank[sb][k];
+          if (rank == 0xFFFFFFFFu) continue;
+          const uint32_t* h = s.hist[sb][pass == 0 ? 0 : k];
+          const uint32_t wv = h[lane];  // bins 2 * lane, 2 * lane + 1
+          const uint32_t c0 = wv & 0xFFFFu, c1 = wv >> 16;
+          const uint32_t sum = c0 + c1;
+          uint32_t incl = sum;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (int(lane) >= o) incl += v;
+          }
+          const uint32_t total = __shfl(incl, 63);
+          if (total == 0u) {  // this sub-segment took no part in the pass (its key range is exhausted)
+            if (lane == 0) s.sel_rank[sb][k] = 0xFFFFFFFFu;
+            continue;
+          }
+          const uint32_t excl = incl - sum;
+          if (rank >= excl && rank < incl) {
+            const bool second = rank >= excl + c0;
+            const uint32_t dg = 2u * lane + (second ? 1u : 0u), left = rank - excl - (second ? c0 : 0u);
+            s.sel_digit[sb][k] = dg;  // folded into the prefix below, by a thread that knows the sub-segment's shift
+            s.sel_rank[sb][k] = left;
+          }
+        }
+        __syncthreads();
+        // the threads of a sub-segment know its shift: the first three fold the chosen digits into the prefixes
+        if (active && tin < 3u) s.sel_prefix[sub][tin] |= s.sel_digit[sub][tin] << lo_b;
+      }
+      __syncthreads();
+      const uint32_t s1 = s.sel_prefix[sub][0], s2 = s.sel_prefix[sub][1], s3 = s.sel_prefix[sub][2];
+      // classes, monotone in the key; layout by (class, previous position)
+      uint32_t cls[4], w0 = 0u, w1 = 0u, w2 = 0u, w3 = 0u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t K = kk[e];
+        const uint32_t c = (K >= s1 ? 1u : 0u) + (K > s1 ? 1u : 0u) + (K >= s2 ? 1u : 0u) + (K > s2 ? 1u : 0u) +
+                           (K >= s3 ? 1u : 0u) + (K > s3 ? 1u : 0u);
+        cls[e] = c;
+        const uint32_t add = 1u << (16u * (c & 1u));
+        w0 += (c >> 1) == 0u ? add : 0u;
+        w1 += (c >> 1) == 1u ? add : 0u;
+        w2 += (c >> 1) == 2u ? add : 0u;
+        w3 += (c >> 1) == 3u ? add : 0u;
+      }
+      uint32_t i0 = w0, i1 = w1, i2 = w2, i3 = w3;  // inclusive scan over the wavefront (inside one sub-segment)
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v0 = __shfl_up(i0, o), v1 = __shfl_up(i1, o), v2 = __shfl_up(i2, o), v3 = __shfl_up(i3, o);
+        if (int(lane) >= o) { i0 += v0; i1 += v1; i2 += v2; i3 += v3; }
+      }
+      if (lane == 63u) { s.wscan[wave][0] = i0; s.wscan[wave][1] = i1; s.wscan[wave][2] = i2; s.wscan[wave][3] = i3; }
+      __syncthreads();
+      const uint32_t wpg = group / 64u, wfirst = (wave / wpg) * wpg;
+      uint32_t b0 = 0u, b1 = 0u, b2 = 0u, b3 = 0u, t0 = 0u, t1 = 0u, t2 = 0u, t3 = 0u;  // waves before this one / all
+      for (uint32_t w = wfirst; w < wfirst + wpg; ++w) {
+        const uint32_t a0 = s.wscan[w][0], a1 = s.wscan[w][1], a2 = s.wscan[w][2], a3 = s.wscan[w][3];
+        if (w < wave) { b0 += a0; b1 += a1; b2 += a2; b3 += a3; }
+        t0 += a0; t1 += a1; t2 += a2; t3 += a3;
+      }
+      // exclusive prefix of this thread per class, class bases
+      const uint32_t x0 = b0 + i0 - w0, x1 = b1 + i1 - w1, x2 = b2 + i2 - w2, x3 = b3 + i3 - w3;
+      uint32_t cbase[7];
+      {
+        const uint32_t tot[7] = {t0 & 0xFFFFu, t0 >> 16, t1 & 0xFFFFu, t1 >> 16, t2 & 0xFFFFu, t2 >> 16, t3 & 0xFFFFu};
+        uint32_t acc = 0u;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+          cbase[c] = acc;
+          acc += tot[c];
+        }
+      }
+      uint32_t seen0 = 0u, seen1 = 0u, seen2 = 0u, seen3 = 0u;  // own earlier elements per class (packed like w*)
+      uint32_t dest[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t c = cls[e], hsel = c >> 1, sh = 16u * (c & 1u);
+        const uint32_t xw = hsel == 0u ? x0 : (hsel == 1u ? x1 : (hsel == 2u ? x2 : x3));
+        const uint32_t sw = hsel == 0u ? seen0 : (hsel == 1u ? seen1 : (hsel == 2u ? seen2 : seen3));
+        uint32_t cb = cbase[0];
+#pragma unroll
+        for (int q = 1; q < 7; ++q) cb = c == uint32_t(q) ? cbase[q] : cb;
+        dest[e] = sub * nsub + cb + ((xw >> sh) & 0xFFFFu) + ((sw >> sh) & 0xFFFFu);
+        const uint32_t add = 1u << sh;
+        seen0 += hsel == 0u ? add : 0u;
+        seen1 += hsel == 1u ? add : 0u;
+        seen2 += hsel == 2u ? add : 0u;
+        seen3 += hsel == 3u ? add : 0u;
+      }
+      __syncthreads();  // every reader of perm (this level's idx[]) is done
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s.perm[dest[e]] = uint16_t(pp[e]);
+      __syncthreads();
+      continue;
+    }
+    // ---- binary levels (64 and 32 points): bitonic sort inside a wavefront --------------------------------------
     // (b) keys: the coordinate along that axis in unsigned order; padding sorts last.  The thread's four
     // (key, position) pairs live in registers from here on.
-    uint32_t kk[4], pp[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const uint32_t p = 4u * t + uint32_t(e);
@@ -452,26 +618,11 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
       pp[e] = idx[e];
     }
     // (c) bitonic sort of (key, position) inside every sub-segment, ascending.  Element i = 4t + e meets i ^ j:
-    // inside the thread for j < 4, across lanes (shuffle) for j < 256, through LDS above that -- 13 of the 205
-    // stages of a 4096-point block need a workgroup barrier.
+    // inside the thread for j < 4, across lanes (shuffle) above that (nsub <= 64: j <= 32).
     for (uint32_t k = 2; k <= nsub; k <<= 1) {
       for (uint32_t j = k >> 1; j > 0; j >>= 1) {
         uint32_t ok[4], op[4];
-        if (j >= 256u) {
-          __syncthreads();  // earlier readers of key / perm are done
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            s.key[4u * t + uint32_t(e)] = kk[e];
-            s.perm[4u * t + uint32_t(e)] = uint16_t(pp[e]);
-          }
-          __syncthreads();
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t ip = (4u * t + uint32_t(e)) ^ j;
-            ok[e] = s.key[ip];
-            op[e] = s.perm[ip];
-          }
-        } else if (j >= 4u) {
+        if (j >= 4u) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             ok[e] = __shfl_xor(kk[e], int(j >> 2));
@@ -499,7 +650,7 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
         }
       }
     }
-    __syncthreads();  // readers of perm (this level's idx[], the LDS stages) are done
+    __syncthreads();  // readers of perm (this level's idx[]) are done
 #pragma unroll
     for (int e = 0; e < 4; ++e) s.perm[4u * t + uint32_t(e)] = uint16_t(pp[e]);
     __syncthreads();

@@ -128,19 +128,33 @@ class ShardedTarget:
     def __init__(self, ctx, target, rank, world, max_correspondence_distance, k_normals=0, viewpoint=(0.0, 0.0, 0.0),
                  normals_margin=None, regions=None):
         from . import api
+        import time
+        tm = self.timings = {}   # seconds per stage of the setup (bench.py --config 5 reports them)
+
+        def lap(name, t0):
+            ctx.synchronize()
+            tm[name] = round(time.perf_counter() - t0, 4)
+        t0 = time.perf_counter()
         self.regions = partition_slabs(target, world) if regions is None else np.asarray(regions, np.float32).reshape(world, 6)
+        lap("partition", t0)
         self.region = self.regions[rank].copy()
         md = float(max_correspondence_distance)
         self.tree = api.KdTree(ctx)
         extra = 0.0 if k_normals <= 0 else (normals_margin if normals_margin is not None else None)
         if extra is None:  # measure the neighbourhood size on the bare slab first
+            t0 = time.perf_counter()
             probe = api.KdTree(ctx)
             probe.setInputCloud(target, select_region(target, self.region, 0.0))
             extra = 4.0 * probe.kthDistanceMax(k_normals)
             probe._free()
+            lap("probe", t0)
         self.margin = md + float(extra)
+        t0 = time.perf_counter()
         self.indices = select_region(target, self.region, self.margin)
+        lap("select", t0)
+        t0 = time.perf_counter()
         self.tree.setInputCloud(target, self.indices)
+        lap("index", t0)
         self.normals_exact = None
         if k_normals > 0:
             ne = api.NormalEstimation(ctx)
@@ -149,10 +163,14 @@ class ShardedTarget:
             ne.setKSearch(k_normals)
             ne.setViewPoint(*viewpoint)
             ne.tree = self.tree
+            t0 = time.perf_counter()
             self._compute_normals(ne)
+            lap("normals", t0)
+            t0 = time.perf_counter()
             # every target point a query of this region can be matched to lies within md of the region
             box = np.concatenate([self.region[:3] - np.float32(md * 1.00002), self.region[3:] + np.float32(md * 1.00002)])
             self.kth = self.tree.kthDistanceMax(k_normals, box)
+            lap("halo_check", t0)
             self.normals_exact = self.kth <= extra
             if not self.normals_exact:
                 raise RuntimeError("halo too thin for exact normals: k-th neighbour at %.3g, margin beyond max_dist %.3g"

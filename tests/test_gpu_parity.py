@@ -1469,3 +1469,77 @@ def test_registration_options_through_the_criteria_object(gpu, bunny):
     assert a.removeCorrespondenceRejector(0) and not a.removeCorrespondenceRejector(5)
     assert a.getCorrespondenceRejectors() == [r2]
     assert a.getMaximumIterations() == 3 and a.getClassName() == "IterativeClosestPoint"
+
+
+# ------------------------------------------------------------------------------------------------
+# the kd order itself (index_build.hip): what the start-level shortcut of the seeded searches relies on
+# ------------------------------------------------------------------------------------------------
+def _check_kd_cells(cloud, order):
+    """Every aligned run of 16 * 4^k positions is one cell of a kd partition: the four quarters of a run are separated,
+    in order, along ONE axis (max of a quarter <= min of the next); a 64-run is two binary cuts (halves along one axis,
+    each half's 16-runs along one axis)."""
+    n = len(order)
+    assert sorted(order.tolist()) == sorted(set(order.tolist())) and len(order) == n
+    pts = cloud[order, :3].astype(np.float64)
+    n_pad = -(-n // 16) * 16
+    run = 16
+    # min / max of every 16-run (pads of the last leaf ignored)
+    big = np.full((n_pad, 3), np.nan)
+    big[:n] = pts
+    lo = np.nanmin(big.reshape(-1, 16, 3), axis=1)
+    hi = np.nanmax(big.reshape(-1, 16, 3), axis=1)
+
+    def separated(lo_a, hi_a, lo_b, hi_b):  # some axis on which all of a lies at or below all of b
+        return np.any(hi_a <= lo_b, axis=-1)
+    level = 0
+    while len(lo) > 1:
+        fan = 2 if level < 2 else 4            # 16 -> 32 -> 64 by binary cuts, then four slabs per round
+        m = len(lo) // fan * fan
+        if m == 0:
+            break
+        L, H = lo[:m].reshape(-1, fan, 3), hi[:m].reshape(-1, fan, 3)
+        ok = np.ones(len(L), bool)
+        if fan == 2:
+            ok &= separated(L[:, 0], H[:, 0], L[:, 1], H[:, 1])
+        else:                                   # the same axis for the three cuts of a round
+            ax_ok = np.ones((len(L), 3), bool)
+            for j in range(3):
+                ax_ok &= H[:, j] <= L[:, j + 1]
+            ok &= np.any(ax_ok, axis=1)
+        assert ok.all(), ("kd cells overlap at runs of %d positions" % (run * fan), int((~ok).sum()), len(ok))
+        # the tail (an incomplete group of runs) is merged as it is
+        tail_lo = [np.nanmin(lo[m:], axis=0)] if m < len(lo) else []
+        tail_hi = [np.nanmax(hi[m:], axis=0)] if m < len(hi) else []
+        lo = np.concatenate([np.nanmin(L, axis=1)] + ([np.asarray(tail_lo)] if tail_lo else []))
+        hi = np.concatenate([np.nanmax(H, axis=1)] + ([np.asarray(tail_hi)] if tail_hi else []))
+        run *= fan
+        level += 1
+
+
+@pytest.mark.parametrize("kind,n", [("surface", 70_001), ("surface", 300_000), ("uniform", 20_000), ("lattice", 30_000),
+                                    ("tiny", 37), ("plane", 50_000),
+                                    # the one-workgroup rounds with every top level and partly filled blocks
+                                    ("uniform", 200), ("lattice", 700), ("uniform", 3000), ("lattice", 4096), ("uniform", 4097),
+                                    ("lattice", 5000), ("surface", 16_385), ("lattice", 66_000)])
+def test_kd_order_cells_are_a_kd_partition(gpu, kind, n):
+    from pcl_amd import synth
+    rng = np.random.default_rng(n)
+    if kind == "surface":
+        cloud = synth.gaussian_surface(n, synth.TARGET_SEED)
+    elif kind == "uniform":
+        cloud = np.ones((n, 4), np.float32)
+        cloud[:, :3] = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    elif kind == "lattice":                     # heavy ties at every cut
+        cloud = np.ones((n, 4), np.float32)
+        cloud[:, :3] = rng.integers(0, 12, (n, 3)).astype(np.float32)
+    elif kind == "plane":                       # one axis without extent
+        cloud = np.ones((n, 4), np.float32)
+        cloud[:, :2] = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+        cloud[:, 2] = 0.5
+    else:
+        cloud = np.ones((n, 4), np.float32)
+        cloud[:, :3] = rng.normal(size=(n, 3)).astype(np.float32)
+    tree = build_tree(gpu, cloud)
+    order = tree.order()
+    assert len(order) == n
+    _check_kd_cells(cloud, order)
