@@ -1,14 +1,15 @@
 #!/bin/bash
-# A/B builds: scripts/build_variant.sh <name> "<extra hipcc flags>" -> pcl_amd/variants/libpclhip_<name>.so
-# (only search.hip is recompiled with the flags; the other objects come from the default build).  Use with
-# PCLHIP_LIB=pcl_amd/variants/libpclhip_<name>.so.
+# A/B builds: scripts/build_variant.sh <name> "<extra hipcc flags>" [source.hip] -> pcl_amd/variants/libpclhip_<name>.so
+# (only that source -- search.hip by default -- is recompiled with the flags; the other objects come from the default
+# build).  Use with PCLHIP_LIB=pcl_amd/variants/libpclhip_<name>.so (scripts/ab_variants.sh runs the bench over them).
 set -e
-name=$1; flags=$2
+name=$1; flags=$2; src=${3:-search.hip}
+obj=${src%.*}
 cd "$(dirname "$0")/../pcl_amd/csrc"
 make -j8 >/dev/null
 mkdir -p ../variants
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-result \
-  -I../../include $flags -c search.hip -o ../variants/search_$name.o
-objs=$(ls *.o | grep -v '^search.o$')
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libpclhip_$name.so ../variants/search_$name.o $objs -ldl
+  -I../../include $flags -c $src -o ../variants/${obj}_$name.o
+objs=$(ls *.o | grep -v "^$obj.o$")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libpclhip_$name.so ../variants/${obj}_$name.o $objs -ldl
 echo built pcl_amd/variants/libpclhip_$name.so
