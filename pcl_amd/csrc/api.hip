@@ -662,7 +662,7 @@ void pclhip_index_destroy(pclhip_index* ix) {
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
   }
-  if (ix->pts) (void)dev_free(ix->ctx, ix->pts);
+  if (ix->pts && !ix->pts_borrowed) (void)dev_free(ix->ctx, ix->pts);
   if (ix->soa) (void)dev_free(ix->ctx, ix->soa);
   if (ix->nrm) (void)dev_free(ix->ctx, ix->nrm);
   if (ix->disc) (void)dev_free(ix->ctx, ix->disc);
@@ -1036,10 +1036,6 @@ pclhip_status pclhip_icp_create(pclhip_index* target, pclhip_icp** out) {
 static void icp_free_source(pclhip_icp* icp) {
   if (icp->src_index) pclhip_index_destroy(icp->src_index);
   icp->src_index = nullptr;
-  if (icp->src_slot_of_orig) (void)dev_free(icp->ctx, icp->src_slot_of_orig);
-  icp->src_slot_of_orig = nullptr;
-  if (icp->src_pos_of_slot) (void)dev_free(icp->ctx, icp->src_pos_of_slot);
-  icp->src_pos_of_slot = nullptr;
   if (icp->src_records) (void)dev_free(icp->ctx, icp->src_records);
   icp->src_records = nullptr;
   icp->src_records_host = nullptr;
@@ -1164,6 +1160,7 @@ pclhip_status pclhip_icp_set_source_indexed(pclhip_icp* icp, const void* points,
                      hi, true, nullptr, nullptr);
   if (st != PCLHIP_OK) return st;
   (void)hipEventRecord(e1, ctx->stream);
+  icp->n_finite = nf;
   st = pclhip_icp_reset(icp);
   float ms = 0;
   if (st == PCLHIP_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) icp->source_order_ms = ms;

@@ -71,10 +71,11 @@ __global__ __launch_bounds__(256) void leaf_box_kernel(const float4* pts, uint32
 }
 
 // per-leaf structure-of-arrays copy: x[16] y[16] z[16] w[16] (w = original index bits), 256 B
-__global__ __launch_bounds__(256) void leaf_soa_kernel(const float4* pts, uint32_t n_pad, float* soa) {
+__global__ __launch_bounds__(256) void leaf_soa_kernel(const float4* pts, uint32_t n, uint32_t n_pad, float* soa) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pad) return;
-  const float4 p = pts[i];
+  // pad slots of the last leaf: +FLT_MAX sentinels with index 0xFFFFFFFF (the points array itself may end at n)
+  const float4 p = i < n ? pts[i] : make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(0xFFFFFFFFu));
   float* l = soa + size_t(i / LEAF) * (4 * LEAF) + (i % LEAF);
   l[0] = p.x;
   l[LEAF] = p.y;
@@ -1263,7 +1264,29 @@ pclhip_status build_index_from_float4(pclhip_ctx* ctx, const float4* dev_pts_wit
   return PCLHIP_OK;
 }
 
-pclhip_status build_boxes(pclhip_index* ix) {
+// An index over points that ARE in kd order already -- the working copy of a registration's source cloud, ordered by
+// spatial_order() when the source was set: nothing is sorted or copied, the index BORROWS the array (w = original index,
+// the finite points in front) and only carries boxes and the leaf blocks of it.  refit_boxes() follows the cloud.
+pclhip_status build_index_over(pclhip_ctx* ctx, float4* pts_in_kd_order, uint32_t n_finite, uint32_t n_orig, pclhip_index** out) {
+  *out = nullptr;
+  pclhip_index* ix = new pclhip_index();
+  ix->ctx = ctx;
+  ix->n_orig = n_orig;
+  ix->pts = pts_in_kd_order;
+  ix->pts_borrowed = true;
+  ix->n = n_finite;
+  ix->n_pad = ((n_finite + LEAF - 1) / LEAF) * LEAF;
+  if (ix->n_pad == 0) ix->n_pad = LEAF;
+  const pclhip_status st = build_boxes(ix, false);
+  if (st != PCLHIP_OK) {
+    pclhip_index_destroy(ix);
+    return st;
+  }
+  *out = ix;
+  return PCLHIP_OK;
+}
+
+pclhip_status build_boxes(pclhip_index* ix, bool with_discs) {
   pclhip_ctx* ctx = ix->ctx;
   hipStream_t s = ctx->stream;
   for (int l = 0; l < MAX_LEVELS; ++l) {
@@ -1288,9 +1311,10 @@ pclhip_status build_boxes(pclhip_index* ix) {
       if (ix->soa) (void)dev_free(ctx, ix->soa);
       ix->soa = nullptr;
       PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->soa, size_t(c) * 4 * LEAF * sizeof(float)));
-      hipLaunchKernelGGL(leaf_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, threads, ix->soa);
+      hipLaunchKernelGGL(leaf_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, threads, ix->soa);
       if (ix->disc) (void)dev_free(ctx, ix->disc);
       ix->disc = nullptr;
+      if (with_discs) {
       PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->disc, size_t(c) * 2 * sizeof(float4)));
       hipLaunchKernelGGL(leaf_disc_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c, ix->disc);
       {  // mean squared leaf diagonal: from what stand-off on the discs pay (traverse.hpp)
@@ -1313,6 +1337,7 @@ pclhip_status build_boxes(pclhip_index* ix) {
         ix->leaf_diag2 = float(sum / double(c));
         ix->disc_thickness = rs > 0.0 ? float(hs / rs) : 1.0f;
       }
+      }  // with_discs
     } else {
       const uint64_t threads = uint64_t(c) * WAVE;
       hipLaunchKernelGGL(node_box_kernel, dim3(unsigned((threads + 255) / 256)), dim3(256), 0, s, ix->box[l - 1],
@@ -1372,7 +1397,7 @@ pclhip_status refit_boxes(pclhip_index* ix) {
   const uint32_t c1 = ix->count[1];
   const uint32_t threads = c1 * LEAF;
   hipLaunchKernelGGL(leaf_box_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c1, ix->box[1]);
-  hipLaunchKernelGGL(leaf_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, threads, ix->soa);
+  hipLaunchKernelGGL(leaf_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, threads, ix->soa);
   for (int l = 2; l <= ix->top; ++l) {
     const uint64_t th = uint64_t(ix->count[l]) * WAVE;
     hipLaunchKernelGGL(node_box_kernel, dim3(unsigned((th + 255) / 256)), dim3(256), 0, s, ix->box[l - 1], ix->count[l - 1],

@@ -198,6 +198,7 @@ struct pclhip_index {
   uint32_t n = 0;       // finite, selected points
   uint32_t n_pad = 0;
   float4* pts = nullptr;
+  bool pts_borrowed = false;  // pts belongs to somebody else (build_index_over): not freed with the index
   float* soa = nullptr;
   float4* nrm = nullptr;
   float4* disc = nullptr;
@@ -226,6 +227,7 @@ struct pclhip_icp {
   pclhip_index* target = nullptr;
   uint64_t n_orig = 0;       // source records
   uint32_t n = 0;            // source points (all records; non-finite ones are flagged invalid)
+  uint32_t n_finite = 0;     // ... of which finite: the front of the kd-ordered arrays
   // the staged device copy of a HOST source cloud's records (all fields), kept for pclhip_icp_transform_source
   void* src_records = nullptr;
   const void* src_records_host = nullptr;
@@ -261,12 +263,9 @@ struct pclhip_icp {
   uint8_t* keep = nullptr;        // per sorted source slot: correspondence survives the chain
   double last_median = 0;
   int fetch_order = 0;            // 0 by query, 1 by (match, distance), 2 by distance
-  // reciprocal correspondences: an index over the SOURCE, built once per source cloud and refitted to the moved cloud
-  // every iteration (rejectors.hip); src_slot_of_orig: original source index -> slot of src_cur; src_pos_of_slot: slot
-  // of src_cur -> position of that point inside the source index (the seed of the reciprocal search)
+  // reciprocal correspondences: an index over the SOURCE that borrows src_cur as its point array (the working copy is in
+  // kd order already) and is refitted to the moved cloud every iteration (rejectors.hip)
   pclhip_index* src_index = nullptr;
-  uint32_t* src_slot_of_orig = nullptr;
-  uint32_t* src_pos_of_slot = nullptr;
   bool trim_pending = false;      // a Trimmed rejector ran: fetch_order becomes 2 if rej_state_host->trimmed says it cut
   pclhip::RejState* rej_state = nullptr;       // device
   pclhip::RejState* rej_state_host = nullptr;  // pinned mirror, valid after a stream synchronisation
@@ -383,7 +382,8 @@ pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stri
                             const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
                             uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
                             uint32_t* rank_or_null, const float* scale = nullptr);
-pclhip_status build_boxes(pclhip_index* ix);
+pclhip_status build_boxes(pclhip_index* ix, bool with_discs = true);
+pclhip_status build_index_over(pclhip_ctx* ctx, float4* pts_in_kd_order, uint32_t n_finite, uint32_t n_orig, pclhip_index** out);
 // shard_dev.hip: partition / halo selection of a cloud in device memory (shard.cpp's results, bit for bit)
 pclhip_status partition_slabs_device(const void* points, size_t stride, uint64_t n, int n_slabs, float* regions);
 pclhip_status select_region_device(const void* points, size_t stride, uint64_t n, const float lo[3], const float hi[3],
@@ -440,10 +440,10 @@ pclhip_status owned_groups_catch_up(pclhip_icp* icp, int mode);
 // for a single-GPU registration
 pclhip_status allreduce_record(pclhip_icp* icp);
 // The reciprocal test as one seeded search (search.hip): slot i asks the SOURCE index for the nearest neighbour of its
-// matched target point, seeded by source point i itself (position pos_of_slot[i]), and drops the pair unless that is
+// matched target point, seeded by source point i itself (the index's positions are the source's slots), and drops the pair unless that is
 // the answer (impl/correspondence_estimation.hpp:247-270).  Stream-ordered, no wait.
 pclhip_status launch_recip_search(pclhip_index* src_ix, const float4* tgt_pts, const uint32_t* match_pos,
-                                  const uint32_t* pos_of_slot, const float4* cur, uint32_t n, float max_d2, bool use_max,
+                                  const float4* cur, uint32_t n, float max_d2, bool use_max,
                                   uint8_t* keep);
 // rejectors.hip: reciprocal filter + rejector chain on icp->keep (stream-ordered, may synchronise)
 pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool use_max);

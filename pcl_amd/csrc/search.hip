@@ -1296,7 +1296,6 @@ __global__ __launch_bounds__(BLOCK) void icp_own_scatter_kernel(const uint32_t* 
 // matches of 64 neighbouring source points.  Exact (distance, index) order as everywhere: distance ties go through NN1.
 __global__ __launch_bounds__(BLOCK, 4) void recip_search_kernel(IndexView sx, const float4* __restrict__ tgt_pts,
                                                                 const uint32_t* __restrict__ match_pos,
-                                                                const uint32_t* __restrict__ pos_of_slot,
                                                                 const float4* __restrict__ cur, uint32_t n, float max_d2,
                                                                 int use_max, uint8_t* __restrict__ keep,
                                                                 unsigned long long* gstats) {
@@ -1320,8 +1319,10 @@ __global__ __launch_bounds__(BLOCK, 4) void recip_search_kernel(IndexView sx, co
     float4 sp = make_float4(0, 0, 0, 0);
     if (valid) {
       p = tgt_pts[match_pos[i]];
-      seed_pos = pos_of_slot[i];
-      if (seed_pos != NO_INDEX) sp = sx.pts[seed_pos];
+      if (i < sx.n) {  // the index's positions ARE the slots (it borrows the working copy): the pair's own source point
+        seed_pos = i;
+        sp = sx.pts[seed_pos];
+      }
     }
     const float qx[1] = {p.x}, qy[1] = {p.y}, qz[1] = {p.z};
     const bool vv[1] = {valid};
@@ -1357,14 +1358,13 @@ __global__ __launch_bounds__(BLOCK, 4) void recip_search_kernel(IndexView sx, co
 }
 
 pclhip_status launch_recip_search(pclhip_index* src_ix, const float4* tgt_pts, const uint32_t* match_pos,
-                                  const uint32_t* pos_of_slot, const float4* cur, uint32_t n, float max_d2, bool use_max,
-                                  uint8_t* keep) {
+                                  const float4* cur, uint32_t n, float max_d2, bool use_max, uint8_t* keep) {
   pclhip_ctx* ctx = src_ix->ctx;
   if (n == 0) return PCLHIP_OK;
   const uint32_t ngroups = (n + WAVE - 1) / WAVE;
   const int grid = resident_blocks(ctx, recip_search_kernel, ngroups);
   PCLHIP_LAUNCH_FED(ctx, recip_search_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, src_ix->view(), tgt_pts, match_pos,
-                     pos_of_slot, cur, n, max_d2, use_max ? 1 : 0, keep, ctx->stats);
+                     cur, n, max_d2, use_max ? 1 : 0, keep, ctx->stats);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   return PCLHIP_OK;
 }
