@@ -283,7 +283,7 @@ struct pclhip_icp {
   float4* own_gbox = nullptr;            // [2 * groups] box of every 64-point group of the pristine source
   uint32_t* own_stamp = nullptr;         // [groups]
   uint32_t* own_flags = nullptr;         // [groups] 1: served in this launch
-  uint32_t* own_prefix = nullptr;        // [groups] exclusive scan of the flags
+  uint32_t* own_prefix = nullptr;        // [groups / 256 used] served groups per block of the flag kernel
   uint32_t* own_list = nullptr;          // [groups]
   uint32_t* own_tot = nullptr;           // [4] tot[0] = served groups
   uint2* own_partial = nullptr;          // scan scratch

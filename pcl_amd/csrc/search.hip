@@ -1195,18 +1195,19 @@ __global__ __launch_bounds__(BLOCK) void icp_group_box_kernel(const float4* __re
   }
 }
 
-// one thread: which launch of the alignment this is, and the transform it applies (read back by groups that skip it)
-__global__ void icp_own_epoch_kernel(const IcpControl* __restrict__ ctl, OwnedState* __restrict__ st) {
-  if (threadIdx.x != 0 || blockIdx.x != 0 || ctl->stop != 0) return;
+// The launch's place in the history of the running alignment, derived from the state the LAST launch left (every thread
+// that needs it computes it the same way; icp_own_list_kernel writes it down for the search kernel afterwards).
+struct OwnEpoch {
+  uint32_t e;
+  bool overflow;
+};
+__device__ __forceinline__ OwnEpoch own_epoch(const IcpControl* __restrict__ ctl, const OwnedState* __restrict__ st) {
   const bool restart = ctl->restart != 0;
-  const uint32_t e = restart ? 0u : st->epoch + 1u;
-  st->epoch = e;
-  if (restart) st->overflow = 0u;
-  if (e < uint32_t(OWN_HIST_CAP)) {
-    for (int i = 0; i < 12; ++i) st->hist[e][i] = ctl->T_apply[i];
-  } else {
-    st->overflow = 1u;  // no room to remember this launch: nobody may skip it (or any later one)
-  }
+  OwnEpoch o;
+  o.e = restart ? 0u : st->epoch + 1u;
+  // no room to remember this launch: nobody may skip it (or any later one)
+  o.overflow = (!restart && st->overflow != 0u) || o.e >= uint32_t(OWN_HIST_CAP);
+  return o;
 }
 
 // One thread per group: is it served in this launch?  After the launch every point sits at M * (pristine point), M =
@@ -1218,16 +1219,23 @@ __global__ __launch_bounds__(BLOCK) void icp_own_flag_kernel(const IcpControl* _
                                                              const OwnedState* __restrict__ st,
                                                              const float4* __restrict__ gbox, RegionBox region,
                                                              uint32_t ngroups, uint32_t ns, uint32_t* __restrict__ stamp,
-                                                             uint32_t* __restrict__ flags, uint32_t* __restrict__ match,
+                                                             uint32_t* __restrict__ flags, uint32_t* __restrict__ block_count,
+                                                             uint32_t* __restrict__ match,
                                                              uint32_t* __restrict__ match_pos, float* __restrict__ match_d2) {
+  if (ctl->stop != 0) return;
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= ngroups || ctl->stop != 0) return;
+  const bool live = g < ngroups;
   const bool restart = ctl->restart != 0;
-  uint32_t sv = restart ? 0u : stamp[g];
-  const float4 lo = gbox[2 * g], hi = gbox[2 * g + 1];
+  const bool overflow = own_epoch(ctl, st).overflow;
+  uint32_t sv = (restart || !live) ? 0u : stamp[g];
+  float4 lo = make_float4(1.0f, 0.0f, 0.0f, 0.0f), hi = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (live) {
+    lo = gbox[2 * g];
+    hi = gbox[2 * g + 1];
+  }
   bool own = false;
   if (lo.x <= hi.x) {
-    if (st->overflow != 0u) {
+    if (overflow) {
       own = true;
     } else {
       const float* M = ctl->final_T;
@@ -1248,16 +1256,29 @@ __global__ __launch_bounds__(BLOCK) void icp_own_flag_kernel(const IcpControl* _
       if (!(mag < BIG)) own = true;  // a transform that overflows: decide per point
     }
   }
-  flags[g] = own ? 1u : 0u;
-  if (!own && (sv >> 31) == 0u) {
-    for (uint32_t i = g * WAVE; i < ns && i < (g + 1u) * WAVE; ++i) {
-      match[i] = NO_INDEX;
-      match_pos[i] = NO_INDEX;
-      match_d2[i] = __builtin_inff();
+  own = own && live;
+  if (live) {
+    flags[g] = own ? 1u : 0u;
+    if (!own && (sv >> 31) == 0u) {
+      for (uint32_t i = g * WAVE; i < ns && i < (g + 1u) * WAVE; ++i) {
+        match[i] = NO_INDEX;
+        match_pos[i] = NO_INDEX;
+        match_d2[i] = __builtin_inff();
+      }
+      sv |= 0x80000000u;
     }
-    sv |= 0x80000000u;
+    stamp[g] = sv;
   }
-  stamp[g] = sv;
+  // served groups of this block of BLOCK groups (icp_own_list_kernel turns the counts into list positions)
+  __shared__ uint32_t wcnt[WAVES_PER_BLOCK];
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(own);
+  if ((threadIdx.x & (WAVE - 1)) == 0) wcnt[threadIdx.x / WAVE] = uint32_t(__builtin_popcountll(b));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t c = 0;
+    for (int w = 0; w < WAVES_PER_BLOCK; ++w) c += wcnt[w];
+    block_count[blockIdx.x] = c;
+  }
 }
 
 // When the loop hands control back to the host: every group's working copy through the last launch's transform, so that
@@ -1281,11 +1302,62 @@ __global__ __launch_bounds__(BLOCK) void icp_own_catchup_kernel(float4* __restri
   if (lane == 0) stamp[g] = want | (raw & 0x80000000u);
 }
 
-__global__ __launch_bounds__(BLOCK) void icp_own_scatter_kernel(const uint32_t* __restrict__ flags,
-                                                                const uint32_t* __restrict__ prefix, uint32_t ngroups,
-                                                                uint32_t* __restrict__ list) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < ngroups && flags[g] != 0u) list[prefix[g]] = g;
+// The ascending list of the served groups, its length, and the launch's entry in the history -- one launch after the flags
+// (until round 4: a one-thread kernel for the history, three scan launches and a scatter).  A workgroup owns OWN_CHUNK
+// consecutive groups: its first list position is the sum of the flag kernel's block counts before it (a few thousand
+// values at most), inside the chunk every thread owns 16 consecutive flags and a prefix sum over the threads orders them.
+constexpr uint32_t OWN_CHUNK = 16u * BLOCK;
+__global__ __launch_bounds__(BLOCK) void icp_own_list_kernel(const IcpControl* __restrict__ ctl, OwnedState* __restrict__ st,
+                                                             const uint32_t* __restrict__ flags,
+                                                             const uint32_t* __restrict__ block_count, uint32_t ngroups,
+                                                             uint32_t* __restrict__ list, uint32_t* __restrict__ tot) {
+  if (ctl->stop != 0) return;
+  __shared__ uint32_t red[WAVES_PER_BLOCK];
+  const uint32_t t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
+  const uint32_t n_counts = (ngroups + BLOCK - 1) / BLOCK;
+  uint32_t before = 0;
+  {
+    uint32_t lim = blockIdx.x * (OWN_CHUNK / BLOCK);
+    if (lim > n_counts) lim = n_counts;
+    for (uint32_t i = t; i < lim; i += BLOCK) before += block_count[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    if (lane == 0) red[wave] = before;
+    __syncthreads();
+    before = 0;
+    for (int w = 0; w < WAVES_PER_BLOCK; ++w) before += red[w];
+    __syncthreads();
+  }
+  const uint32_t g0 = blockIdx.x * OWN_CHUNK + 16u * t;
+  uint32_t bits = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < 16u; ++j)
+    if (g0 + j < ngroups && flags[g0 + j] != 0u) bits |= 1u << j;
+  const uint32_t cnt = uint32_t(__builtin_popcount(bits));
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    const uint32_t v = __shfl_up(incl, o);
+    if (int(lane) >= o) incl += v;
+  }
+  if (lane == WAVE - 1) red[wave] = incl;
+  __syncthreads();
+  uint32_t waves_before = 0;
+  for (uint32_t w = 0; w < wave; ++w) waves_before += red[w];
+  uint32_t pos = before + waves_before + incl - cnt;
+  for (uint32_t m = bits; m != 0u; m &= m - 1u) list[pos++] = g0 + uint32_t(__builtin_ctz(m));
+  if (blockIdx.x == gridDim.x - 1) {
+    if (t == BLOCK - 1) tot[0] = pos;  // the last thread of the last chunk ends the list
+    if (t == 0) {                      // nobody reads the state in this launch: the history moves on here
+      const bool restart = ctl->restart != 0;
+      const OwnEpoch oe = own_epoch(ctl, st);
+      st->epoch = oe.e;
+      st->overflow = oe.overflow ? 1u : 0u;
+      if (oe.e < uint32_t(OWN_HIST_CAP))
+        for (int i = 0; i < 12; ++i) st->hist[oe.e][i] = ctl->T_apply[i];
+      (void)restart;
+    }
+  }
 }
 
 // Reciprocal correspondences (registration/include/pcl/registration/impl/correspondence_estimation.hpp:247-270): the
@@ -1869,13 +1941,11 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     }
     (void)hipEventRecord(device_loop ? ev[0] : icp->ev0, s);
     if (owned) {
-      hipLaunchKernelGGL(icp_own_epoch_kernel, dim3(1), dim3(1), 0, s, ctl, icp->own_state);
       hipLaunchKernelGGL(icp_own_flag_kernel, dim3((ngroups + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, ctl, icp->own_state,
-                         icp->own_gbox, icp->region, ngroups, icp->n, icp->own_stamp, icp->own_flags, icp->match,
+                         icp->own_gbox, icp->region, ngroups, icp->n, icp->own_stamp, icp->own_flags, icp->own_prefix, icp->match,
                          icp->match_pos, icp->match_d2);
-      launch_scan_u32(s, icp->own_flags, ngroups, icp->own_partial, icp->own_tot, icp->own_prefix);
-      hipLaunchKernelGGL(icp_own_scatter_kernel, dim3((ngroups + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, icp->own_flags,
-                         icp->own_prefix, ngroups, icp->own_list);
+      hipLaunchKernelGGL(icp_own_list_kernel, dim3((ngroups + OWN_CHUNK - 1) / OWN_CHUNK), dim3(BLOCK), 0, s, ctl, icp->own_state,
+                         icp->own_flags, icp->own_prefix, ngroups, icp->own_list, icp->own_tot);
       const int go = resident_blocks(ctx, icp_search_owned_kernel, ngroups);
       PCLHIP_LAUNCH_FED(ctx, icp_search_owned_kernel, dim3(go), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M,
                          ctl, icp->region, order, bound, kflags, so_from, standoff ? 1 : 0, icp->match_pos, icp->match,

@@ -38,8 +38,15 @@ def xyz1(a):
 # ------------------------------------------------------------------------------------------------
 # bounded fuzz slices (fixed seeds; clouds of at most 70k points so that a slice stays within seconds)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("seed", [11, 12])
+def _gpu_only_seed(seed, first_two):
+    # the CPU tier runs two slices of each kind on the emulation; the GPU tier runs ten
+    if seed not in first_two and os.environ.get("PCLHIP_ALLOW_WAVESIM") == "1":
+        pytest.skip("eight more seeds on the GPU only (the emulation runs the first two)")
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18, 19, 20])
 def test_fuzz_knn_and_icp_correspondences_slice(gpu, orc, seed):
+    _gpu_only_seed(seed, (11, 12))
     rng = np.random.default_rng(seed)
     log = []
     for it in range(6):
@@ -48,8 +55,9 @@ def test_fuzz_knn_and_icp_correspondences_slice(gpu, orc, seed):
         assert ok, "\n".join(log)
 
 
-@pytest.mark.parametrize("seed", [21, 22])
+@pytest.mark.parametrize("seed", [21, 22, 23, 24, 25, 26, 27, 28, 29, 30])
 def test_fuzz_voxelgrid_and_surface_normals_slice(gpu, orc, seed):
+    _gpu_only_seed(seed, (21, 22))
     rng = np.random.default_rng(seed)
     log = []
     for it in range(5):
