@@ -266,7 +266,10 @@ PCLHIP_API pclhip_status pclhip_icp_reset(pclhip_icp* icp);
  *   MEDIAN_DISTANCE  registration/src/correspondence_rejection_median_distance.cpp:43-69 param = factor
  *   ONE_TO_ONE       registration/src/correspondence_rejection_one_to_one.cpp:43-66
  *   TRIMMED          registration/src/correspondence_rejection_trimmed.cpp:43-60        param = overlap ratio
- * Exact ties, whose order the reference leaves to an unstable sort, go to the lower query index. */
+ * Exact ties, whose order the reference leaves to an unstable sort, go to the lower query index.
+ * Multi-GPU (pclhip_icp_set_comm / _set_allreduce): DISTANCE is per pair; MEDIAN_DISTANCE and TRIMMED cut at the one
+ * cloud-global order statistic (the histograms of their selection are all-reduced: the hook / communicator sees buffers
+ * of 2048 doubles besides the 32-double record); ONE_TO_ONE is refused (its conflicts span ranks). */
 enum { PCLHIP_REJ_DISTANCE = 0, PCLHIP_REJ_MEDIAN_DISTANCE = 1, PCLHIP_REJ_ONE_TO_ONE = 2, PCLHIP_REJ_TRIMMED = 3 };
 typedef struct {
   int kind;
@@ -279,7 +282,9 @@ PCLHIP_API pclhip_status pclhip_icp_set_rejectors(pclhip_icp* icp, const pclhip_
 PCLHIP_API double pclhip_icp_last_median_distance(const pclhip_icp* icp);
 /* use_reciprocal_correspondence_ (registration.h / impl/correspondence_estimation.hpp:220-311): keep
  * (i, m) only if the nearest source point of target[m] is i again (the reference rebuilds the source tree per iteration;
- * here the source index is built once, refitted to the moved cloud and searched from its root: same answers). */
+ * here the source index is built once, refitted to the moved cloud and searched from its root: same answers).
+ * Multi-GPU: supported when the TARGET is sharded (pclhip_icp_set_region: every rank holds the whole source), refused
+ * when the source is cut into slabs. */
 PCLHIP_API pclhip_status pclhip_icp_set_reciprocal(pclhip_icp* icp, int enable);
 
 /* One iteration on the device-resident working source cloud (a search kernel and a streaming

@@ -398,14 +398,20 @@ void preload_code_objects(pclhip_ctx* ctx) {
 pclhip_status pclhip::sharded_filters_ok(pclhip_icp* icp) {
   pclhip_ctx* ctx = icp->ctx;
   if (icp_is_sharded(icp)) {
-    // With the source sharded over ranks, MedianDistance / Trimmed thresholds, OneToOne conflicts and the
-    // reciprocal test would be evaluated per slab, which is not what a single-GPU (or the reference's) run
-    // computes.  Only per-pair filters (Distance) commute with the sharding.
-    bool global_filter = icp->reciprocal;
-    for (const pclhip_rejector& r : icp->rejectors) global_filter = global_filter || r.kind != PCLHIP_REJ_DISTANCE;
-    if (global_filter) {
-      set_error(ctx, "multi-GPU (all-reduce) iterations support only the Distance rejector: MedianDistance, Trimmed, "
-                     "OneToOne and reciprocal correspondences need cloud-global decisions");
+    // Per-pair filters (Distance) commute with the sharding; MedianDistance / Trimmed take ONE cloud-global order
+    // statistic, which the ranks find together (the histograms of the selection are all-reduced, rejectors.hip).  The
+    // reciprocal test needs the whole moved source on the rank: fine when the TARGET is sharded (a region is set: the
+    // source is replicated; the served-group lists stand aside), not when the source is cut into slabs.  OneToOne
+    // resolves conflicts between pairs that different ranks serve (a target point in two halos): not supported.
+    for (const pclhip_rejector& r : icp->rejectors) {
+      if (r.kind == PCLHIP_REJ_ONE_TO_ONE) {
+        set_error(ctx, "multi-GPU (all-reduce) iterations do not support the OneToOne rejector: its conflicts span ranks");
+        return PCLHIP_ERR_STATE;
+      }
+    }
+    if (icp->reciprocal && icp->region.on == 0) {
+      set_error(ctx, "reciprocal correspondences need the whole source on every rank: shard the target (pclhip_icp_set_region), "
+                     "not the source");
       return PCLHIP_ERR_STATE;
     }
   }

@@ -194,11 +194,13 @@ pclhip_status pclhip_icp_set_comm(pclhip_icp* icp, pclhip_comm* comm) {
 
 namespace pclhip {
 
-pclhip_status allreduce_record(pclhip_icp* icp) {
+// sum of `count` doubles in device memory over the ranks, on the context's stream (the native communicator or the
+// caller's hook; nothing to do for a registration on one GPU)
+pclhip_status allreduce_doubles(pclhip_icp* icp, double* device_buf, int count) {
   pclhip_ctx* ctx = icp->ctx;
-  if (icp->comm != nullptr) return pclhip_comm_allreduce_sum_f64(icp->comm, icp->sums_dev, PCLHIP_ICP_NSUMS);
+  if (icp->comm != nullptr) return pclhip_comm_allreduce_sum_f64(icp->comm, device_buf, count);
   if (icp->allreduce != nullptr) {
-    const int rc = icp->allreduce(icp->allreduce_user, icp->sums_dev, PCLHIP_ICP_NSUMS, ctx->stream);
+    const int rc = icp->allreduce(icp->allreduce_user, device_buf, count, ctx->stream);
     if (rc != 0) {
       set_error(ctx, "all-reduce hook failed");
       return PCLHIP_ERR_STATE;
@@ -206,6 +208,8 @@ pclhip_status allreduce_record(pclhip_icp* icp) {
   }
   return PCLHIP_OK;
 }
+
+pclhip_status allreduce_record(pclhip_icp* icp) { return allreduce_doubles(icp, icp->sums_dev, PCLHIP_ICP_NSUMS); }
 
 bool icp_is_sharded(const pclhip_icp* icp) { return icp->comm != nullptr || icp->allreduce != nullptr; }
 

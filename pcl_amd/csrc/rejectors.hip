@@ -211,32 +211,62 @@ __global__ __launch_bounds__(256) void rs_pick_kernel(RejState* __restrict__ out
   }
 }
 
+// Multi-GPU: every rank histograms the pairs IT serves; the histograms are summed over the ranks between the histogram
+// and the pick kernel (as doubles: the all-reduce of the record is the one collective the library has), so every rank
+// picks the same bin from the same global counts -- the count of kept pairs, the rank, the threshold and the `done` flag
+// are the single-GPU run's on every rank.  The host queues the same passes whatever `done` says, so the collectives match.
+__global__ void rs_hist_to_f64_kernel(const uint32_t* __restrict__ h, double* __restrict__ d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < RS_BINS) d[i] = double(h[i]);
+}
+__global__ void rs_hist_from_f64_kernel(const double* __restrict__ d, uint32_t* __restrict__ h) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < RS_BINS) h[i] = uint32_t(d[i]);  // exact: counts of at most 2^31 pairs
+}
+
 // the order statistic a MedianDistance (three passes) or Trimmed (three + three tie passes) rejector asks for ->
 // RejState (count, mode, key, median, threshold), stream-ordered.  hist_dev: RS_PASSES histograms.
 template <int PASS>
-void radix_select_pass(pclhip_ctx* ctx, int grid, const float* d2, const uint8_t* keep, const float4* cur, uint32_t n,
-                       RejState* out, RsState* rs, uint32_t* hist_dev, int kind, double param, unsigned int min_corr) {
+pclhip_status radix_select_pass(pclhip_icp* icp, int grid, const float* d2, const uint8_t* keep, const float4* cur, uint32_t n,
+                                RejState* out, RsState* rs, uint32_t* hist_dev, double* hist_f64, int kind, double param,
+                                unsigned int min_corr) {
+  pclhip_ctx* ctx = icp->ctx;
   uint32_t* const h = hist_dev + size_t(PASS) * RS_BINS;
   hipLaunchKernelGGL(rs_hist_kernel<PASS>, dim3(grid), dim3(TB), 0, ctx->stream, d2, keep, cur, n, rs, h);
+  if (hist_f64 != nullptr) {
+    hipLaunchKernelGGL(rs_hist_to_f64_kernel, dim3(RS_BINS / 256), dim3(256), 0, ctx->stream, h, hist_f64);
+    const pclhip_status st = allreduce_doubles(icp, hist_f64, RS_BINS);
+    if (st != PCLHIP_OK) return st;
+    hipLaunchKernelGGL(rs_hist_from_f64_kernel, dim3(RS_BINS / 256), dim3(256), 0, ctx->stream, hist_f64, h);
+  }
   hipLaunchKernelGGL(rs_pick_kernel<PASS>, dim3(1), dim3(256), 0, ctx->stream, out, rs, h, kind, param, min_corr);
+  return PCLHIP_OK;
 }
-hipError_t radix_select_queued(pclhip_ctx* ctx, const float* d2, const uint8_t* keep, const float4* cur, uint32_t n,
-                               RejState* out, RsState* rs, uint32_t* hist_dev, int kind, double param,
-                               unsigned int min_corr) {
+pclhip_status radix_select_queued(pclhip_icp* icp, const float* d2, const uint8_t* keep, const float4* cur, uint32_t n,
+                                  RejState* out, RsState* rs, uint32_t* hist_dev, double* hist_f64, int kind, double param,
+                                  unsigned int min_corr) {
+  pclhip_ctx* ctx = icp->ctx;
   int grid = int((n / 4 + TB - 1) / TB);
   if (grid > ctx->num_cus * 8) grid = ctx->num_cus * 8;
   if (grid < 1) grid = 1;
-  const hipError_t e = hipMemsetAsync(hist_dev, 0, size_t(RS_PASSES) * RS_BINS * sizeof(uint32_t), ctx->stream);
-  if (e != hipSuccess) return e;
-  radix_select_pass<0>(ctx, grid, d2, keep, cur, n, out, rs, hist_dev, kind, param, min_corr);
-  radix_select_pass<1>(ctx, grid, d2, keep, cur, n, out, rs, hist_dev, kind, param, min_corr);
-  radix_select_pass<2>(ctx, grid, d2, keep, cur, n, out, rs, hist_dev, kind, param, min_corr);
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(hist_dev, 0, size_t(RS_PASSES) * RS_BINS * sizeof(uint32_t), ctx->stream));
+#define RS_PASS(P)                                                                                                    \
+  do {                                                                                                                \
+    const pclhip_status st_ = radix_select_pass<P>(icp, grid, d2, keep, cur, n, out, rs, hist_dev, hist_f64, kind, param, \
+                                                   min_corr);                                                         \
+    if (st_ != PCLHIP_OK) return st_;                                                                                 \
+  } while (0)
+  RS_PASS(0);
+  RS_PASS(1);
+  RS_PASS(2);
   if (kind == PCLHIP_REJ_TRIMMED) {
-    radix_select_pass<3>(ctx, grid, d2, keep, cur, n, out, rs, hist_dev, kind, param, min_corr);
-    radix_select_pass<4>(ctx, grid, d2, keep, cur, n, out, rs, hist_dev, kind, param, min_corr);
-    radix_select_pass<5>(ctx, grid, d2, keep, cur, n, out, rs, hist_dev, kind, param, min_corr);
+    RS_PASS(3);
+    RS_PASS(4);
+    RS_PASS(5);
   }
-  return hipGetLastError();
+#undef RS_PASS
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  return PCLHIP_OK;
 }
 
 // correspondence_rejection_median_distance.cpp:64-66: keep if double(d) <= median * factor
@@ -323,6 +353,8 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
   uint32_t* rs_hist = nullptr;
   PCLHIP_CHECK_HIP(ctx, g.alloc(&rs, sizeof(RsState)));
   PCLHIP_CHECK_HIP(ctx, g.alloc(&rs_hist, size_t(RS_PASSES) * RS_BINS * sizeof(uint32_t)));
+  double* rs_hist_f64 = nullptr;  // multi-GPU: the histogram of a pass as doubles, summed over the ranks
+  if (icp_is_sharded(icp)) PCLHIP_CHECK_HIP(ctx, g.alloc(&rs_hist_f64, RS_BINS * sizeof(double)));
 
   if (icp->reciprocal) {
     // An index over the source, in the order the source already has: the registration's kd-ordered working copy IS the
@@ -354,8 +386,11 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
         break;
       }
       case PCLHIP_REJ_MEDIAN_DISTANCE: {
-        PCLHIP_CHECK_HIP(ctx, radix_select_queued(ctx, icp->match_d2, icp->keep, icp->src_cur, n, icp->rej_state, rs, rs_hist,
-                                                  int(r.kind), r.param, 0u));
+        {
+          const pclhip_status sr = radix_select_queued(icp, icp->match_d2, icp->keep, icp->src_cur, n, icp->rej_state, rs,
+                                                       rs_hist, rs_hist_f64, int(r.kind), r.param, 0u);
+          if (sr != PCLHIP_OK) return sr;
+        }
         hipLaunchKernelGGL(rej_median_kernel, grid, block, 0, s, icp->match_d2, n, icp->rej_state, icp->keep);
         break;
       }
@@ -374,8 +409,11 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
       }
       case PCLHIP_REJ_TRIMMED: {
         // the nv-th smallest (distance, query) key
-        PCLHIP_CHECK_HIP(ctx, radix_select_queued(ctx, icp->match_d2, icp->keep, icp->src_cur, n, icp->rej_state, rs, rs_hist,
-                                                  int(r.kind), r.param, r.min_correspondences));
+        {
+          const pclhip_status sr = radix_select_queued(icp, icp->match_d2, icp->keep, icp->src_cur, n, icp->rej_state, rs,
+                                                       rs_hist, rs_hist_f64, int(r.kind), r.param, r.min_correspondences);
+          if (sr != PCLHIP_OK) return sr;
+        }
         hipLaunchKernelGGL(rej_trim_kernel, grid, block, 0, s, icp->src_cur, icp->match_d2, n, icp->rej_state, icp->keep);
         trimmed_in_chain = true;  // the list comes back sorted by distance IF it was cut (RejState::trimmed says so)
         break;

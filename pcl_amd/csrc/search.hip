@@ -1929,7 +1929,9 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     // wave radii (squared) up to so_from stay with traverse(): the groups that sit on the surface
     const float so_from = icp->target->leaf_diag2;
     // target sharding in the device-driven loop: list the groups this rank serves in this launch, walk the list
-    const bool owned = device_loop && icp->region.on != 0 && mode != PCLHIP_ICP_SYMMETRIC && ctx->opt_served_groups != 0;
+    // (the reciprocal test searches the whole moved source: every group's working copy has to be current)
+    const bool owned = device_loop && icp->region.on != 0 && mode != PCLHIP_ICP_SYMMETRIC && ctx->opt_served_groups != 0 &&
+                       !icp->reciprocal;
     OwnedGroups og = {nullptr, nullptr, nullptr, nullptr};
     if (owned) {
       pclhip_status st = ensure_owned_groups(icp);

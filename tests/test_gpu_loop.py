@@ -241,11 +241,44 @@ def test_native_communicator_single_rank(gpu):
             icp.setCommunicator(comm)
         icp.align()
         res.append((icp.getFinalTransformation().copy(), icp.nr_iterations_))
-        if use:  # cloud-global rejectors are refused under sharding (they would be evaluated per slab)
-            rej = pcl_amd.CorrespondenceRejectorTrimmed()
-            icp.addCorrespondenceRejector(rej)
-            with pytest.raises(pcl_amd.PclHipError, match="Distance rejector"):
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    # MedianDistance / Trimmed under a communicator: the histograms of their selection are all-reduced (here over one rank:
+    # the collective runs, the numbers are the unsharded chain's); OneToOne and -- without a region: the source would be
+    # sharded -- reciprocal correspondences are refused
+    res = []
+    for use in (False, True):
+        icp = _make_icp(gpu, tgt, src, 1, nrm)
+        a = pcl_amd.CorrespondenceRejectorMedianDistance()
+        a.setMedianFactor(1.5)
+        b = pcl_amd.CorrespondenceRejectorTrimmed()
+        b.setOverlapRatio(0.8)
+        d = pcl_amd.CorrespondenceRejectorDistance()
+        d.setMaximumDistance(0.05)
+        for r in (a, b, d):
+            icp.addCorrespondenceRejector(r)
+        if use:
+            icp.setCommunicator(comm)
+        icp.align()
+        res.append((icp.getFinalTransformation().copy(), icp.nr_iterations_, len(icp.fetchCorrespondences()[0])))
+        if use:
+            assert np.array_equal(res[0][0], res[1][0]) and res[0][1:] == res[1][1:]
+            icp.addCorrespondenceRejector(pcl_amd.CorrespondenceRejectorOneToOne())
+            with pytest.raises(pcl_amd.PclHipError, match="OneToOne"):
                 icp.align()
+            icp2 = _make_icp(gpu, tgt, src, 1, nrm)
+            icp2.setCommunicator(comm)
+            icp2.setUseReciprocalCorrespondences(True)
+            with pytest.raises(pcl_amd.PclHipError, match="whole source"):
+                icp2.align()
+            inf = np.inf
+            icp2.setRegion([-inf] * 3 + [inf] * 3)       # the target sharded (here: one slab owning everything)
+            icp2.align()
+            one = _make_icp(gpu, tgt, src, 1, nrm)
+            one.setUseReciprocalCorrespondences(True)
+            one.align()
+            assert icp2.nr_iterations_ == one.nr_iterations_
+            assert np.array_equal(icp2.getFinalTransformation(), one.getFinalTransformation())
+    assert 0 < res[0][2] < len(src)
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
 
 

@@ -104,7 +104,8 @@ def test_gpu_parity_tests_run_on_the_emulation(wavesim_lib):
     assert int(last.split(" passed")[0].split()[-1]) >= 90, last
 
 
-@pytest.mark.parametrize("mode,world", [("target", 2), ("source", 2), ("target", 3)])
+@pytest.mark.parametrize("mode,world", [("target", 2), ("source", 2), ("target", 3), ("target+rej", 2), ("source+rej", 2),
+                                        ("target+recip", 2)])
 def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, world):
     """An N > 1 execution of the library's own multi-GPU code, which the one-GPU box of a round cannot give: `world`
     PROCESSES, each with its own (emulated) device, a native communicator created from one shared id (pclhip_comm_*; the
@@ -112,18 +113,31 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
     device-driven loop all-reducing the record of every iteration between its reduction and its solve, regions masking
     the source per rank ("target") or the source cut into slabs ("source").  Checked: every rank ends with the SAME 4x4
     bit for bit (same all-reduced record, same solve), it is the single-process alignment's up to the summation order,
-    the iteration counts agree, and what the ranks served adds up to the all-reduced count."""
+    the iteration counts agree, and what the ranks served adds up to the all-reduced count.  "+rej": a MedianDistance +
+    Trimmed + Distance chain inside the loop -- the histograms of the two selections are all-reduced, so every rank cuts at
+    the single-GPU run's thresholds; "+recip": reciprocal correspondences with the target sharded (the whole source on every
+    rank, the served-group lists standing aside)."""
     import numpy as np
     n = 60_000
+    mode, _, extra = mode.partition("+")
+    full_mode = mode + ("+" + extra if extra else "")
     work = str(tmp_path)
     env = dict(os.environ, PCLHIP_LIB=wavesim_lib, PCLHIP_ALLOW_WAVESIM="1", WAVESIM_THREADS="8")  # (target mode: the ranks walk their served groups)
     worker = os.path.join(WS, "two_rank_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, mode, str(r), str(world), work, str(n)], env=env, cwd=ROOT,
+    procs = [subprocess.Popen([sys.executable, worker, full_mode, str(r), str(world), work, str(n)], env=env, cwd=ROOT,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
     ranks = [np.load(os.path.join(work, "rank%d.npz" % r)) for r in range(world)]
     # single-process reference on the same emulation (no communicator, no region)
+    extra_lines = ""
+    if extra == "rej":
+        extra_lines = ("a = pcl_amd.CorrespondenceRejectorMedianDistance(); a.setMedianFactor(1.5)\n"
+                       "b = pcl_amd.CorrespondenceRejectorTrimmed(); b.setOverlapRatio(0.8)\n"
+                       "d = pcl_amd.CorrespondenceRejectorDistance(); d.setMaximumDistance(0.05)\n"
+                       "[icp.addCorrespondenceRejector(r) for r in (a, b, d)]\n")
+    if extra == "recip":
+        extra_lines = "icp.setUseReciprocalCorrespondences(True)\n"
     code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
             "import pcl_amd; from pcl_amd import synth\n"
             "tgt, src, _ = synth.icp_pair(%d); ctx = pcl_amd.Context(0)\n"
@@ -131,9 +145,11 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
             "ne = pcl_amd.NormalEstimation(ctx); ne.setInputCloud(tgt); ne.setSearchMethod(tree); ne.setKSearch(8)\n"
             "ne.setViewPoint(0, 0, 10); ne.compute(want_output=False)\n"
             "icp = pcl_amd.IterativeClosestPointWithNormals(ctx); icp.setSearchMethodTarget(tree, True); icp.setInputSource(src)\n"
-            "icp.setMaximumIterations(20); icp.setMaxCorrespondenceDistance(0.1); icp.setTransformationEpsilon(1e-10); icp.align()\n"
+            "icp.setMaximumIterations(20); icp.setMaxCorrespondenceDistance(0.1); icp.setTransformationEpsilon(1e-10)\n"
+            "%s"
+            "icp.align()\n"
             "np.savez(%r, T=icp.getFinalTransformation(), iterations=icp.nr_iterations_, fitness=icp.getFitnessScore(0.01),\n"
-            "         fitness_points=icp.fitness_points)\n" % (ROOT, n, os.path.join(work, "single.npz")))
+            "         fitness_points=icp.fitness_points)\n" % (ROOT, n, extra_lines, os.path.join(work, "single.npz")))
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     one = np.load(os.path.join(work, "single.npz"))
@@ -144,7 +160,10 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
     assert np.abs(ranks[0]["T"].astype(np.float64) - one["T"].astype(np.float64)).max() < 2e-6
     assert all(int(r_["served"]) > 0 for r_ in ranks)                       # every rank had work
     assert sum(int(r_["served"]) for r_ in ranks) in set(int(c) for c in ranks[0]["counts"])
-    assert int(ranks[0]["counts"][0]) == n
+    if not extra:
+        assert int(ranks[0]["counts"][0]) == n
+    else:
+        assert 0 < int(ranks[0]["counts"][0]) < n                          # the chain / the reciprocal test dropped pairs
     if mode == "target":
         assert all(int(r_["index_points"]) < n for r_ in ranks)             # a slab + halo, not the cloud
         # getFitnessScore under sharding: the owned points' (sum, count) all-reduced -> the single-index score

@@ -22,6 +22,7 @@ from pcl_amd import synth  # noqa: E402
 from pcl_amd.dist import ShardedTarget, shard_range  # noqa: E402
 
 mode, rank, world, work = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+mode, _, extra = mode.partition("+")   # "+rej": MedianDistance + Trimmed + Distance chain; "+recip": reciprocal correspondences
 n = int(sys.argv[5]) if len(sys.argv) > 5 else 60_000
 uid_path = os.path.join(work, "uid.bin")
 if rank == 0:
@@ -64,6 +65,17 @@ icp.setTransformationEpsilon(1e-10)
 icp.setCommunicator(comm)
 if region is not None:
     icp.setRegion(region)
+if extra == "rej":
+    a = pcl_amd.CorrespondenceRejectorMedianDistance()
+    a.setMedianFactor(1.5)
+    b = pcl_amd.CorrespondenceRejectorTrimmed()
+    b.setOverlapRatio(0.8)
+    d = pcl_amd.CorrespondenceRejectorDistance()
+    d.setMaximumDistance(0.05)
+    for r in (a, b, d):
+        icp.addCorrespondenceRejector(r)
+if extra == "recip":
+    icp.setUseReciprocalCorrespondences(True)
 icp.align()
 T = icp.getFinalTransformation().copy()
 iters = icp.nr_iterations_

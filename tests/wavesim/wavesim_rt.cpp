@@ -463,7 +463,7 @@ hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) {
 #include <unistd.h>
 
 namespace {
-constexpr int NCCL_MAX_RANKS = 16, NCCL_MAX_COUNT = 256;
+constexpr int NCCL_MAX_RANKS = 16, NCCL_MAX_COUNT = 2048;  // (the 2048-bin histograms of the rejectors' selections)
 struct ShmComm {
   std::atomic<uint32_t> arrived;
   std::atomic<uint32_t> generation;
