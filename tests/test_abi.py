@@ -177,3 +177,17 @@ def test_convergence_criteria_twin_matches_the_oracle():
                 assert st.prev_mse == oc.correspondences_prev_mse
                 if st.convergence_state != 0:
                     break
+
+
+def test_library_sources_read_no_environment_variable():
+    # eighteen getenv switches (among them round 1's fused kernel and the host loop) -> none; the tuning
+    # knobs that remain go through pclhip_ctx_set_option
+    import glob
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pcl_amd", "csrc")
+    hits = []
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.cpp")) + glob.glob(os.path.join(root, "*.hpp"))):
+        for i, line in enumerate(open(f), 1):
+            if "getenv" in line:
+                hits.append("%s:%d" % (os.path.basename(f), i))
+    assert hits == [], hits

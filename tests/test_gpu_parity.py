@@ -1543,3 +1543,16 @@ def test_kd_order_cells_are_a_kd_partition(gpu, kind, n):
     order = tree.order()
     assert len(order) == n
     _check_kd_cells(cloud, order)
+
+
+def test_context_options(gpu):
+    # pclhip_ctx_set_option: the library's four tuning knobs (it reads no environment variable); unknown names and
+    # negative values are refused, none of them changes a result (the served-groups / lookahead tests rely on that)
+    import pcl_amd
+    for name, value in (("served_groups", 0), ("served_groups", 1), ("icp_lookahead", 3), ("icp_lookahead", 1),
+                        ("cache_mb", 1024), ("cache_mb", 16384)):
+        gpu.setOption(name, value)
+    with pytest.raises(pcl_amd.PclHipError, match="unknown option"):
+        gpu.setOption("standoff", 0)
+    with pytest.raises(pcl_amd.PclHipError, match="non-negative"):
+        gpu.setOption("cache_mb", -1)
