@@ -157,6 +157,16 @@ PCLHIP_API pclhip_status pclhip_radius_search(pclhip_index* index, const void* q
  * The normals are also retained inside the index for point-to-plane ICP.  out_nan_count optional. */
 PCLHIP_API pclhip_status pclhip_normals(pclhip_index* index, int k, const float viewpoint[3],
                                         void* out, size_t out_stride_bytes, uint64_t* out_nan_count);
+/* The same normals (k >= 1 and radius 0, or k 0 and radius > 0) written as WHOLE output records, the way
+ * Feature::compute leaves a PointCloud<pcl::Normal> (impl/feature.hpp:195-229: the cloud is resized -- value-initialised
+ * records -- and computeFeature fills normal[0..2] and curvature, normal_3d.hpp:60-66): every record_bytes record is
+ * zeroed, the normal goes to normal_offset, the curvature to curvature_offset (pcl::Normal: 32 / 0 / 16).  A host `out`
+ * costs one linear copy instead of 16-byte rows into a staging array plus the caller's unpacking loop: a repeated
+ * NormalEstimation::compute of 10M points through the binding 87 -> 7.6 ms, a first one 185 -> 94 ms (of which 60 are
+ * PCL's own resize of the output cloud; scratch/boundary_probe.cpp). */
+PCLHIP_API pclhip_status pclhip_normals_records(pclhip_index* index, int k, double radius, const float viewpoint[3],
+                                                void* out, size_t record_bytes, size_t normal_offset,
+                                                size_t curvature_offset, uint64_t* out_nan_count);
 /* Same with setRadiusSearch(radius) (Feature::compute, features/include/pcl/features/impl/feature.hpp:140-155):
  * the plane is fitted to ALL indexed points with squared distance < float(radius^2), taken in the
  * order radiusSearch returns them (ascending distance); fewer than 3 neighbours -> NaN. */

@@ -588,11 +588,25 @@ class NormalEstimationHIP : public pcl::NormalEstimation<PointInT, PointOutT> {
     }
     deferred_.clear();
     const std::size_t m = this->indices_->size();
-    std::vector<float> tmp(m * 4);
     std::uint64_t nan = 0;
     const float vp[3] = {this->vpx_, this->vpy_, this->vpz_};
     const bool all = this->fake_indices_;
     pclhip_status st;
+    if constexpr (std::is_same<PointOutT, pcl::Normal>::value) {
+      // every point of the cloud itself, into pcl::Normal records: the device hands back whole records (zeros, the normal at
+      // +0, the curvature at +16 -- what Feature::compute's resize + computeFeature leave), one linear copy straight into
+      // the output cloud instead of a 160 MB staging vector (fresh pages on every call) and a 10M-iteration unpacking loop
+      if (this->fake_surface_ && all && output.size() == m && m == this->input_->size()) {
+        st = pclhip_normals_records(dev_tree->handle(), this->k_, this->k_ != 0 ? 0.0 : this->search_radius_, vp,
+                                    output.points.data(), sizeof(pcl::Normal), 0, 16, &nan);
+        if (st == PCLHIP_OK) {
+          if (nan != 0) output.is_dense = false;
+          return;
+        }
+      }
+    }
+    std::vector<float>& tmp = staging_;  // kept between calls: a fresh 160 MB vector costs 40 ms of page faults every time
+    tmp.resize(m * 4);
     if (this->fake_surface_ && all) {  // surface == input, every point: the fused kernel, normals kept in the index
       st = (this->k_ != 0) ? pclhip_normals(dev_tree->handle(), this->k_, vp, tmp.data(), 16, &nan)
                            : pclhip_normals_radius(dev_tree->handle(), this->search_radius_, vp, tmp.data(), 16, &nan);
@@ -614,6 +628,7 @@ class NormalEstimationHIP : public pcl::NormalEstimation<PointInT, PointOutT> {
   }
  private:
   std::string deferred_;
+  std::vector<float> staging_;
 };
 
 // ---- VoxelGrid ----------------------------------------------------------------------------------------

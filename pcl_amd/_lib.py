@@ -108,6 +108,7 @@ SIGNATURES = {
     "pclhip_radius_search": (C.c_int, [_vp, _vp, _sz, _u64, C.c_double, C.c_uint32, C.POINTER(_u64), _vp, _vp, _u64,
                                        C.POINTER(_u64)]),
     "pclhip_normals": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), _vp, _sz, C.POINTER(_u64)]),
+    "pclhip_normals_records": (C.c_int, [_vp, C.c_int, C.c_double, C.POINTER(C.c_float), _vp, _sz, _sz, _sz, C.POINTER(_u64)]),
     "pclhip_normals_radius": (C.c_int, [_vp, C.c_double, C.POINTER(C.c_float), _vp, _sz, C.POINTER(_u64)]),
     "pclhip_normals_at": (C.c_int, [_vp, _vp, _sz, _u64, _vp, _u64, C.c_int, C.c_double, C.POINTER(C.c_float), _vp, _sz,
                                     C.POINTER(_u64)]),

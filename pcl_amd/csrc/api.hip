@@ -295,6 +295,23 @@ __global__ void scatter_normals_kernel(const float4* __restrict__ nrm_sorted, co
   out[i] = (r == NO_INDEX) ? make_float4(qn, qn, qn, qn) : nrm_sorted[r];
 }
 
+// whole output records (pcl::Normal and the like: the reference value-initialises them before it writes the normal):
+// zeros, the normal at normal_off, the curvature at curvature_off; NaN for dropped points
+__global__ void normal_records_kernel(const float4* __restrict__ nrm_sorted, const uint32_t* __restrict__ rank, uint64_t n_orig,
+                                      char* __restrict__ out, uint32_t record_bytes, uint32_t normal_off,
+                                      uint32_t curvature_off) {
+  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  if (i >= n_orig) return;
+  const uint32_t r = rank[i];
+  const float qn = __builtin_nanf("");
+  const float4 v = (r == NO_INDEX) ? make_float4(qn, qn, qn, qn) : nrm_sorted[r];
+  float* rec = reinterpret_cast<float*>(out + i * record_bytes);
+  for (uint32_t w = 0; w < record_bytes / 4; ++w) rec[w] = 0.0f;
+  float* n = reinterpret_cast<float*>(out + i * record_bytes + normal_off);
+  n[0] = v.x; n[1] = v.y; n[2] = v.z;
+  *reinterpret_cast<float*>(out + i * record_bytes + curvature_off) = v.w;
+}
+
 __global__ void gather_normals_kernel(const void* normals, size_t stride, const float4* __restrict__ pts_sorted,
                                       uint32_t n, uint32_t n_pad, float4* __restrict__ nrm_sorted) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -784,6 +801,35 @@ static pclhip_status normals_common(pclhip_index* ix, int k, double radius, cons
     st = copy_out_strided(ctx, out, out_stride, dense, sizeof(float4), ix->n_orig);
     if (st != PCLHIP_OK) return st;
   }
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_normals_records(pclhip_index* ix, int k, double radius, const float viewpoint[3], void* out,
+                                     size_t record_bytes, size_t normal_offset, size_t curvature_offset,
+                                     uint64_t* out_nan_count) {
+  if (!ix) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = ix->ctx;
+  PCLHIP_REQUIRE(ctx, out != nullptr, "null buffer");
+  PCLHIP_REQUIRE(ctx, record_bytes % 4 == 0 && record_bytes >= 16 && record_bytes <= 256 && normal_offset % 4 == 0 &&
+                          curvature_offset % 4 == 0 && normal_offset + 12 <= record_bytes && curvature_offset + 4 <= record_bytes &&
+                          (curvature_offset + 4 <= normal_offset || curvature_offset >= normal_offset + 12),
+                  "record layout: 4-byte aligned normal (12 bytes) and curvature (4 bytes) inside a record of 16..256 bytes");
+  // the normals themselves (kept in the index), no output yet
+  const pclhip_status st = normals_common(ix, k, radius, viewpoint, nullptr, 0, out_nan_count);
+  if (st != PCLHIP_OK || ix->n_orig == 0) return st;
+  const size_t bytes = size_t(ix->n_orig) * record_bytes;
+  DeviceGuard guard(ctx);
+  char* d = static_cast<char*>(out);
+  const bool dev = is_device_pointer(out);
+  if (!dev) {
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &d, bytes));
+    guard.add(d);
+  }
+  hipLaunchKernelGGL(normal_records_kernel, dim3(unsigned((ix->n_orig + 255) / 256)), dim3(256), 0, ctx->stream, ix->nrm, ix->rank,
+                     uint64_t(ix->n_orig), d, uint32_t(record_bytes), uint32_t(normal_offset), uint32_t(curvature_offset));
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  if (!dev) PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, ctx->stream));  // ONE linear copy
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PCLHIP_OK;
 }
 

@@ -1556,3 +1556,32 @@ def test_context_options(gpu):
         gpu.setOption("standoff", 0)
     with pytest.raises(pcl_amd.PclHipError, match="non-negative"):
         gpu.setOption("cache_mb", -1)
+
+
+def test_normals_as_whole_records(gpu, bunny):
+    # pclhip_normals_records: the normals of pclhip_normals laid out as whole output records (pcl::Normal: 32 bytes, normal
+    # at +0, curvature at +16; other layouts alike), everything else zero, NaN for dropped points
+    import ctypes as C
+    from pcl_amd import _lib
+    lib = _lib.load()
+    cloud = xyz1(bunny["bun0"]).copy()
+    cloud[5, 0] = np.nan
+    tree = build_tree(gpu, cloud)
+    n = len(cloud)
+    vp = (C.c_float * 3)(0, 0, 10)
+    ref = np.zeros((n, 4), np.float32)
+    nan = C.c_uint64(0)
+    _lib.check(lib.pclhip_normals(tree.h, 8, vp, C.c_void_p(ref.ctypes.data), 16, C.byref(nan)), gpu.h)
+    for rec, noff, coff in ((32, 0, 16), (48, 16, 32), (16, 4, 0)):
+        out = np.full((n, rec // 4), 7.0, np.float32)
+        nan2 = C.c_uint64(0)
+        _lib.check(lib.pclhip_normals_records(tree.h, 8, 0.0, vp, C.c_void_p(out.ctypes.data), rec, noff, coff, C.byref(nan2)), gpu.h)
+        assert nan2.value == nan.value == 1
+        got = np.concatenate([out[:, noff // 4:noff // 4 + 3], out[:, coff // 4:coff // 4 + 1]], axis=1)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))          # NaN rows included, bit for bit
+        rest = np.ones(rec // 4, bool)
+        rest[noff // 4:noff // 4 + 3] = False
+        rest[coff // 4] = False
+        assert np.all(out[:, rest] == 0.0)
+    with pytest.raises(_lib.PclHipError):
+        _lib.check(lib.pclhip_normals_records(tree.h, 8, 0.0, vp, C.c_void_p(out.ctypes.data), 32, 8, 16, C.byref(nan)), gpu.h)
