@@ -441,6 +441,16 @@ PCLHIP_API pclhip_status pclhip_icp_fitness_score(pclhip_icp* icp, const float T
 PCLHIP_API pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_query,
                                                           int32_t* index_match, float* distance,
                                                           uint64_t* out_n);
+/* The same list as an array of pcl::Correspondence records -- { int32 index_query; int32 index_match; float distance },
+ * 12 bytes (correspondence.h:60-71) --, compacted on the device and handed over in ONE copy: what
+ * CorrespondenceEstimation::determineCorrespondences leaves in its std::vector (impl/correspondence_estimation.hpp
+ * :160-216: resized to the number of queries, filled, shrunk to the valid ones).  Query order only: refused (ERR_STATE)
+ * when a ONE_TO_ONE or TRIMMED rejector re-orders the list.  `capacity` records at `out` (host or device); *out_n receives
+ * the count, PCLHIP_ERR_OVERFLOW if it exceeds the capacity.  10M pairs through the binding
+ * (CorrespondenceEstimationHIP::determineCorrespondences on host clouds): 102 -> 13.6 ms repeated, 138 -> 66 ms the first
+ * time (scratch/boundary_probe.cpp). */
+PCLHIP_API pclhip_status pclhip_icp_fetch_correspondence_records(pclhip_icp* icp, void* out, uint64_t capacity,
+                                                                 uint64_t* out_n);
 
 /* TransformationEstimation::estimateRigidTransformation(cloud_src, cloud_tgt, T)
  * (registration/include/pcl/registration/transformation_estimation.h:71-115) for n explicit pairs

@@ -307,6 +307,19 @@ class CorrespondenceEstimationHIP : public pcl::registration::CorrespondenceEsti
         pclhip_icp_set_reciprocal(icp_, reciprocal ? 1 : 0) == PCLHIP_OK &&
         pclhip_icp_iterate(icp_, I, md, PCLHIP_ICP_POINT_TO_POINT, sums) == PCLHIP_OK) {
       const std::size_t n = this->input_->size();
+      if (!subset && sizeof(pcl::Correspondence) == 12) {
+        // the whole cloud, ascending by index_query (the order of the reference's loop over all points): the device
+        // compacts the kept pairs into pcl::Correspondence records and the vector receives them in one copy -- sized for
+        // every query first, shrunk to the valid ones afterwards, as impl/correspondence_estimation.hpp:160-216 does
+        out.resize(n);
+        std::uint64_t cnt = 0;
+        if (pclhip_icp_fetch_correspondence_records(icp_, out.data(), n, &cnt) == PCLHIP_OK) {
+          out.resize(std::size_t(cnt));
+          this->deinitCompute();
+          return;
+        }
+        out.clear();
+      }
       pcl::Indices q(n), m(n);
       std::vector<float> d(n);
       std::uint64_t cnt = 0;

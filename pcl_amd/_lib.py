@@ -154,6 +154,7 @@ SIGNATURES = {
     "pclhip_index_kth_distance_max": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "pclhip_icp_fitness_score": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_double, C.POINTER(C.c_double),
                                            C.POINTER(_u64)]),
+    "pclhip_icp_fetch_correspondence_records": (C.c_int, [_vp, _vp, _u64, C.POINTER(_u64)]),
     "pclhip_icp_fetch_correspondences": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_u64)]),
     "pclhip_estimate_rigid_transformation": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _u64,
                                                        C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "pclhip_internal.hpp"
+#include "device_scan.hpp"
 
 using namespace pclhip;
 
@@ -387,6 +388,21 @@ __global__ void scatter_matches_kernel(const float4* __restrict__ cur, const uin
   const bool kept = m != NO_INDEX && (keep == nullptr || keep[i]);
   out_m[oq] = kept ? int32_t(m) : -1;
   out_d[oq] = d2[i];
+}
+
+// pcl::Correspondence records (index_query, index_match, distance: 12 bytes) of the kept pairs, ascending by query
+__global__ void match_flag_kernel(const int32_t* __restrict__ m, uint64_t no, uint32_t* __restrict__ flag) {
+  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  if (i < no) flag[i] = m[i] >= 0 ? 1u : 0u;
+}
+struct CorrRecord {
+  int32_t q, m;
+  float d;
+};
+__global__ void match_emit_kernel(const int32_t* __restrict__ m, const float* __restrict__ d, const uint32_t* __restrict__ pos,
+                                  uint64_t no, CorrRecord* __restrict__ out) {
+  const uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+  if (i < no && m[i] >= 0) out[pos[i]] = CorrRecord{int32_t(i), m[i], d[i]};
 }
 
 float float_at_most(double v) {  // largest float <= v  (v >= 0)
@@ -1478,6 +1494,67 @@ pclhip_status pclhip_icp_fitness_score(pclhip_icp* icp, const float T[16], doubl
   pclhip_status st = launch_fitness_score(icp, T, max_range, score, &n_used);
   if (nr) *nr = n_used;
   return st;
+}
+
+pclhip_status pclhip_icp_fetch_correspondence_records(pclhip_icp* icp, void* out, uint64_t capacity, uint64_t* out_n) {
+  if (!icp || !out_n) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = icp->ctx;
+  *out_n = 0;
+  if (icp->n == 0) return PCLHIP_OK;
+  const bool filtered = icp->reciprocal || !icp->rejectors.empty();
+  for (const pclhip_rejector& r : icp->rejectors) {
+    if (r.kind == PCLHIP_REJ_ONE_TO_ONE || r.kind == PCLHIP_REJ_TRIMMED) {
+      set_error(ctx, "correspondence records come in query order: OneToOne / Trimmed re-order the list (pclhip_icp_fetch_correspondences)");
+      return PCLHIP_ERR_STATE;
+    }
+  }
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx);
+  const size_t no = size_t(icp->n_orig);  // dense arrays over the ORIGINAL source records (a subset leaves gaps)
+  int32_t* dm = nullptr;
+  float* dd = nullptr;
+  uint32_t *flag = nullptr, *pos = nullptr, *tot = nullptr;
+  uint2* partial = nullptr;
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &dm, no * sizeof(int32_t)));
+  guard.add(dm);
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &dd, no * sizeof(float)));
+  guard.add(dd);
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &flag, no * sizeof(uint32_t)));
+  guard.add(flag);
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &pos, no * sizeof(uint32_t)));
+  guard.add(pos);
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &partial, ((no + SC_BLOCK - 1) / SC_BLOCK) * sizeof(uint2)));
+  guard.add(partial);
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &tot, 4 * sizeof(uint32_t)));
+  guard.add(tot);
+  hipStream_t s = ctx->stream;
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(dm, 0xFF, no * sizeof(int32_t), s));
+  PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(tot, 0, 4 * sizeof(uint32_t), s));
+  hipLaunchKernelGGL(scatter_matches_kernel, dim3((icp->n + 255) / 256), dim3(256), 0, s, icp->src_cur, icp->match, icp->match_d2,
+                     filtered ? icp->keep : nullptr, icp->n, dm, dd);
+  const unsigned blocks = unsigned((no + 255) / 256);
+  hipLaunchKernelGGL(match_flag_kernel, dim3(blocks), dim3(256), 0, s, dm, uint64_t(no), flag);
+  launch_scan_u32(s, flag, no, partial, tot, pos);
+  uint32_t total = 0;
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&total, tot, sizeof total, hipMemcpyDeviceToHost, s));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  *out_n = total;
+  if (total == 0) return PCLHIP_OK;
+  if (!out || capacity < total) {
+    set_error(ctx, "correspondence records: output capacity too small (out_n holds the required number)");
+    return PCLHIP_ERR_OVERFLOW;
+  }
+  CorrRecord* drec = static_cast<CorrRecord*>(out);
+  const bool dev = is_device_pointer(out);
+  if (!dev) {
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &drec, size_t(total) * sizeof(CorrRecord)));
+    guard.add(drec);
+  }
+  hipLaunchKernelGGL(match_emit_kernel, dim3(blocks), dim3(256), 0, s, dm, dd, pos, uint64_t(no), drec);
+  PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  if (!dev) PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, drec, size_t(total) * sizeof(CorrRecord), hipMemcpyDeviceToHost, s));
+  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  return PCLHIP_OK;
 }
 
 pclhip_status pclhip_icp_fetch_correspondences(pclhip_icp* icp, int32_t* index_query, int32_t* index_match,

@@ -56,5 +56,21 @@ int main(int argc, char** argv) {
     if (std::memcmp(normals[i].normal, pn[i].normal, 12) != 0 || std::memcmp(&normals[i].curvature, &pn[i].curvature, 4) != 0) ++bad;
   std::printf("generic path (PointNormal output) first %.1f ms | again %.1f ms | records that differ from the pcl::Normal path: %zu of %zu\n",
               ms(t9, t10), ms(t10, t11), bad, n);
+  // CorrespondenceEstimationHIP::determineCorrespondences: 10M pcl::Correspondence structs back on the host
+  {
+    pcl::PointCloud<pcl::PointXYZ>::Ptr src(new pcl::PointCloud<pcl::PointXYZ>(*cloud));
+    for (auto& p : src->points) { p.x += 0.001f; p.z += 0.002f; }
+    CorrespondenceEstimationHIP<pcl::PointXYZ, pcl::PointXYZ> ce;
+    ce.setSearchMethodTarget(std::make_shared<KdTreeHIP<pcl::PointXYZ>>(dev));
+    ce.setInputTarget(cloud);
+    ce.setInputSource(src);
+    pcl::Correspondences corr;
+    auto c0 = Clock::now();
+    ce.determineCorrespondences(corr, 0.1);
+    auto c1 = Clock::now();
+    ce.determineCorrespondences(corr, 0.1);
+    auto c2 = Clock::now();
+    std::printf("determineCorrespondences first %.1f ms | again %.1f ms | %zu pairs\n", ms(c0, c1), ms(c1, c2), corr.size());
+  }
   return bad == 0 ? 0 : 1;
 }

@@ -1585,3 +1585,40 @@ def test_normals_as_whole_records(gpu, bunny):
         assert np.all(out[:, rest] == 0.0)
     with pytest.raises(_lib.PclHipError):
         _lib.check(lib.pclhip_normals_records(tree.h, 8, 0.0, vp, C.c_void_p(out.ctypes.data), 32, 8, 16, C.byref(nan)), gpu.h)
+
+
+def test_correspondences_as_records(gpu, orc, bunny):
+    # pclhip_icp_fetch_correspondence_records: the kept pairs as 12-byte pcl::Correspondence records, compacted on the
+    # device, in query order -- the same list pclhip_icp_fetch_correspondences assembles on the host
+    import ctypes as C
+    import pcl_amd
+    from pcl_amd import _lib
+    lib = _lib.load()
+    src, tgt = xyz1(bunny["bun0"]).copy(), xyz1(bunny["bun4"])
+    src[3, 1] = np.nan                                   # a query without a match: a gap in the dense arrays
+    rec_t = np.dtype([("q", np.int32), ("m", np.int32), ("d", np.float32)])
+    for chain in ((), ("median",), ("distance", "median")):
+        icp = pcl_amd.IterativeClosestPoint(gpu)
+        icp.setInputTarget(tgt)
+        icp.setInputSource(src)
+        for name in chain:
+            r = pcl_amd.CorrespondenceRejectorMedianDistance() if name == "median" else pcl_amd.CorrespondenceRejectorDistance()
+            if name == "median":
+                r.setMedianFactor(1.2)
+            else:
+                r.setMaximumDistance(0.02)
+            icp.addCorrespondenceRejector(r)
+        icp.iterate(max_dist=0.05)
+        q, m, d = icp.fetchCorrespondences()
+        out = np.zeros(len(src), rec_t)
+        cnt = C.c_uint64(0)
+        _lib.check(lib.pclhip_icp_fetch_correspondence_records(icp.h, C.c_void_p(out.ctypes.data), len(out), C.byref(cnt)), gpu.h)
+        assert cnt.value == len(q) and 0 < len(q) < len(src)
+        got = out[:cnt.value]
+        assert np.array_equal(got["q"], q) and np.array_equal(got["m"], m) and np.array_equal(got["d"].view(np.uint32), d.view(np.uint32))
+        small = np.zeros(3, rec_t)                           # too small: the count comes back with ERR_OVERFLOW
+        st = lib.pclhip_icp_fetch_correspondence_records(icp.h, C.c_void_p(small.ctypes.data), 3, C.byref(cnt))
+        assert st == -5 and cnt.value == len(q)
+    icp.addCorrespondenceRejector(pcl_amd.CorrespondenceRejectorOneToOne())   # re-orders the list: refused here
+    icp.iterate(max_dist=0.05)
+    assert lib.pclhip_icp_fetch_correspondence_records(icp.h, C.c_void_p(out.ctypes.data), len(out), C.byref(cnt)) != 0
