@@ -510,13 +510,12 @@ class NormalEstimation : public PCLBase<PointInT> {
     }
     output.resize(input->size());
     std::uint64_t nan = 0;
-    std::vector<float> tmp(input->size() * 4);
-    const pclhip_status st = (k_ >= 1) ? pclhip_normals(dev->handle(), k_, vp_, tmp.data(), 16, &nan)
-                                       : pclhip_normals_radius(dev->handle(), radius_, vp_, tmp.data(), 16, &nan);
-    if (st != PCLHIP_OK) { output.points.clear(); return; }
-    for (std::size_t i = 0; i < output.size(); ++i) {
-      output[i].normal_x = tmp[4 * i]; output[i].normal_y = tmp[4 * i + 1]; output[i].normal_z = tmp[4 * i + 2];
-      output[i].curvature = tmp[4 * i + 3];
+    static_assert(sizeof(Normal) == 32, "pcl::Normal: normal at +0, curvature at +16");
+    // the output type of this class is pcl::Normal: whole records in one copy (pclhip_normals_records)
+    if (pclhip_normals_records(dev->handle(), k_ >= 1 ? k_ : 0, k_ >= 1 ? 0.0 : radius_, vp_, output.points.data(), sizeof(Normal),
+                               0, 16, &nan) != PCLHIP_OK) {
+      output.points.clear();
+      return;
     }
     output.is_dense = (nan == 0);  // normal_3d.hpp:56,63
   }
@@ -769,9 +768,17 @@ class CorrespondenceEstimation : public CorrespondenceEstimationBase<PointSource
         pclhip_icp_set_reciprocal(icp_, reciprocal ? 1 : 0) == PCLHIP_OK &&
         pclhip_icp_iterate(icp_, I, md, PCLHIP_ICP_POINT_TO_POINT, sums) == PCLHIP_OK) {
       const std::size_t n = this->input_->size();
+      std::uint64_t cnt = 0;
+      if (!subset && sizeof(Correspondence) == 12) {  // the records compacted on the device, one copy
+        out.resize(n);
+        if (pclhip_icp_fetch_correspondence_records(icp_, out.data(), n, &cnt) == PCLHIP_OK) {
+          out.resize(std::size_t(cnt));
+          return;
+        }
+        out.clear();
+      }
       Indices q(n), m(n);
       std::vector<float> d(n);
-      std::uint64_t cnt = 0;
       if (pclhip_icp_fetch_correspondences(icp_, q.data(), m.data(), d.data(), &cnt) == PCLHIP_OK) {
         out.resize(std::size_t(cnt));
         for (std::uint64_t i = 0; i < cnt; ++i) out[std::size_t(i)] = Correspondence(q[std::size_t(i)], m[std::size_t(i)], d[std::size_t(i)]);
