@@ -247,7 +247,9 @@ pclhip_status radix_select_queued(pclhip_icp* icp, const float* d2, const uint8_
                                   unsigned int min_corr) {
   pclhip_ctx* ctx = icp->ctx;
   int grid = int((n / 4 + TB - 1) / TB);
-  if (grid > ctx->num_cus * 8) grid = ctx->num_cus * 8;
+  // (every block merges up to 2048 bins into the global histogram: 8 / 4 / 2 / 1 blocks per CU measured at 10M pairs --
+  // 1.278 / 1.236 / 1.236 / 1.291 ms per step with a median + trimmed chain)
+  if (grid > ctx->num_cus * 4) grid = ctx->num_cus * 4;
   if (grid < 1) grid = 1;
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(hist_dev, 0, size_t(RS_PASSES) * RS_BINS * sizeof(uint32_t), ctx->stream));
 #define RS_PASS(P)                                                                                                    \
