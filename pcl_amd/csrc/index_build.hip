@@ -46,13 +46,25 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // one 16-lane group per leaf
-__global__ __launch_bounds__(256) void leaf_box_kernel(const float4* pts, uint32_t n, uint32_t nleaf, Box* box) {
+// One 16-lane group per leaf, one pass over the points: the leaf's box, and its structure-of-arrays copy
+// x[16] y[16] z[16] w[16] (w = original index bits, 256 B).  Pad slots of the last leaf get +FLT_MAX sentinels with index
+// 0xFFFFFFFF in the copy (the points array itself may end at n) and do not count for the box.
+__global__ __launch_bounds__(256) void leaf_box_soa_kernel(const float4* __restrict__ pts, uint32_t n, uint32_t nleaf,
+                                                           Box* __restrict__ box, float* __restrict__ soa) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t leaf = i / LEAF;
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  float4 p = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(0xFFFFFFFFu));
   if (i < n) {
-    const float4 p = pts[i];
+    p = pts[i];
     lo[0] = hi[0] = p.x; lo[1] = hi[1] = p.y; lo[2] = hi[2] = p.z;
+  }
+  if (leaf < nleaf) {
+    float* l = soa + size_t(leaf) * (4 * LEAF) + (i % LEAF);
+    l[0] = p.x;
+    l[LEAF] = p.y;
+    l[2 * LEAF] = p.z;
+    l[3 * LEAF] = p.w;
   }
 #pragma unroll
   for (int o = LEAF / 2; o > 0; o >>= 1) {
@@ -68,19 +80,6 @@ __global__ __launch_bounds__(256) void leaf_box_kernel(const float4* pts, uint32
     b.hi = make_float4(hi[0], hi[1], hi[2], 0.0f);
     box[leaf] = b;
   }
-}
-
-// per-leaf structure-of-arrays copy: x[16] y[16] z[16] w[16] (w = original index bits), 256 B
-__global__ __launch_bounds__(256) void leaf_soa_kernel(const float4* pts, uint32_t n, uint32_t n_pad, float* soa) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_pad) return;
-  // pad slots of the last leaf: +FLT_MAX sentinels with index 0xFFFFFFFF (the points array itself may end at n)
-  const float4 p = i < n ? pts[i] : make_float4(FLT_MAX, FLT_MAX, FLT_MAX, __uint_as_float(0xFFFFFFFFu));
-  float* l = soa + size_t(i / LEAF) * (4 * LEAF) + (i % LEAF);
-  l[0] = p.x;
-  l[LEAF] = p.y;
-  l[2 * LEAF] = p.z;
-  l[3 * LEAF] = p.w;
 }
 
 // One thread per leaf: the bounded cylinder ("disc") of its points (traverse.hpp: point_disc_lb) -- centre c
@@ -307,63 +306,6 @@ __device__ __forceinline__ uint32_t orderable(float f) {
 
 
 
-// ---- last kd round in a wavefront -----------------------------------------------------------------
-// The rounds above cut every segment into four slabs along its widest axis.  Done once more at the bottom
-// that would leave 16-point leaves shaped 8 x 2 point spacings on a surface; two binary cuts (widest axis of
-// the 64-point cell, then the widest axis of each half) give 4 x 4 patches instead: smaller boxes, smaller
-// discs, and no radix sort of the whole cloud for this round -- one wavefront orders one cell with a bitonic
-// network over its lanes.  Cells stay cells of a kd partition (disjoint interiors), which is all the search needs.
-template <int N>
-__device__ __forceinline__ float4 wave_sort_widest(float4 p, bool valid, uint32_t lane) {
-  float lo[3] = {valid ? p.x : FLT_MAX, valid ? p.y : FLT_MAX, valid ? p.z : FLT_MAX};
-  float hi[3] = {valid ? p.x : -FLT_MAX, valid ? p.y : -FLT_MAX, valid ? p.z : -FLT_MAX};
-#pragma unroll
-  for (int o = N / 2; o > 0; o >>= 1) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
-      hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
-    }
-  }
-  const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-  int a = 0;
-  float best = ex;
-  if (ey > best) { best = ey; a = 1; }
-  if (ez > best) { a = 2; }
-  const float c = a == 0 ? p.x : (a == 1 ? p.y : p.z);
-  // (coordinate, lane) keys: equal coordinates keep their order; lanes without a point sort last
-  unsigned long long key = valid ? ((static_cast<unsigned long long>(orderable(c)) << 8) | lane) : ~0ull;
-  const uint32_t il = lane & (N - 1);
-#pragma unroll
-  for (int k = 2; k <= N; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const unsigned long long other = __shfl_xor(key, j);
-      const bool up = (il & k) == 0, lower = (il & j) == 0;
-      const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
-      key = (lower == up) ? mn : mx;
-    }
-  }
-  const int src = int(key & 63ull);
-  float4 r;
-  r.x = __shfl(p.x, src); r.y = __shfl(p.y, src); r.z = __shfl(p.z, src); r.w = __shfl(p.w, src);
-  return r;
-}
-
-__global__ __launch_bounds__(256) void kd_cell_split_kernel(const float4* __restrict__ in, uint32_t n,
-                                                            float4* __restrict__ out) {
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t base = wave * WAVE;
-  if (base >= n) return;
-  const uint32_t m = (n - base) < uint32_t(WAVE) ? (n - base) : uint32_t(WAVE);
-  float4 p = make_float4(0, 0, 0, 0);
-  if (lane < m) p = in[base + lane];
-  p = wave_sort_widest<64>(p, lane < m, lane);   // the cell's points come out first, ordered along its widest axis
-  p = wave_sort_widest<32>(p, lane < m, lane);   // each half along ITS widest axis
-  if (lane < m) out[base + lane] = p;
-}
-
 // ---- bottom kd rounds in one workgroup ------------------------------------------------------------
 // Segments of <= 4096 points are ordered entirely inside LDS: the rounds that cut a 4096-point segment into
 // four 1024-point slabs, those into 256-point slabs, those into 64-point cells, and the two binary cuts of a
@@ -401,7 +343,7 @@ struct KdBlockLds {
 
 __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __restrict__ in, uint32_t n,
                                                                float4* __restrict__ out, uint32_t top_nsub,
-                                                               uint32_t bottom_nsub) {
+                                                               uint32_t bottom_nsub, uint32_t* __restrict__ rank) {
   __shared__ KdBlockLds s;
   const uint32_t t = threadIdx.x;
   const uint32_t lane = t & 63u, wave = t >> 6;
@@ -659,7 +601,12 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
     __syncthreads();
     if (nsub == 32u) break;  // (guards the unsigned loop condition when bottom_nsub is 32)
   }
-  for (uint32_t p = t; p < cnt; p += KDB_THREADS) out[base + p] = in[base + s.perm[p]];
+  // the last level: `out` is the caller's array, and the position of every original index goes with it
+  for (uint32_t p = t; p < cnt; p += KDB_THREADS) {
+    const float4 v = in[base + s.perm[p]];
+    out[base + p] = v;
+    if (rank) rank[__float_as_uint(v.w)] = base + p;
+  }
 }
 
 // ---- top kd rounds by selection + partition ----------------------------------------------------------
@@ -703,28 +650,45 @@ __device__ __forceinline__ void kp_digits(uint32_t nbits, int pass, uint32_t& sh
   else { shift = 0u; width = sh2; up_shift = sh2; }
 }
 
-// one wavefront per segment: reduce its chunk boxes, pick the widest axis, publish the key range
-__global__ __launch_bounds__(256) void kp_param_kernel(const Box* __restrict__ chunk_box, uint32_t nchunks,
+// one workgroup per segment: reduce its boxes, pick the widest axis, publish the key range.
+// from_parent == 0: the segment's own chunk boxes (kd_load_box_kernel / kd_chunk_box_kernel), chunks_per_seg of them;
+// from_parent != 0: the boxes the previous round's scatter left per (block of the parent segment, child slab):
+//                   boxes[(block) * 4 + child], chunks_per_seg = blocks of the PARENT segment
+__global__ __launch_bounds__(256) void kp_param_kernel(const Box* __restrict__ boxes, uint32_t nchunks,
                                                        uint32_t chunks_per_seg, uint32_t nseg, uint32_t n, uint64_t seg_size,
-                                                       SegParam* __restrict__ sp, SelState* __restrict__ sel) {
-  const uint32_t sgm = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-  const uint32_t lane = threadIdx.x & 63;
-  if (sgm >= nseg) return;
+                                                       SegParam* __restrict__ sp, SelState* __restrict__ sel, int from_parent) {
+  const uint32_t sgm = blockIdx.x;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  const uint64_t b = uint64_t(sgm) * chunks_per_seg;
+  const uint64_t owner = from_parent ? uint64_t(sgm >> 2) : uint64_t(sgm);
+  const uint64_t b = owner * chunks_per_seg;
   uint64_t e = b + chunks_per_seg;
   if (e > nchunks) e = nchunks;
-  for (uint64_t i = b + lane; i < e; i += WAVE) {
-    const Box bx = chunk_box[i];
+  for (uint64_t i = b + threadIdx.x; i < e; i += 256) {
+    const Box bx = from_parent ? boxes[i * 4 + (sgm & 3u)] : boxes[i];
     lo[0] = fminf(lo[0], bx.lo.x); lo[1] = fminf(lo[1], bx.lo.y); lo[2] = fminf(lo[2], bx.lo.z);
     hi[0] = fmaxf(hi[0], bx.hi.x); hi[1] = fmaxf(hi[1], bx.hi.y); hi[2] = fmaxf(hi[2], bx.hi.z);
   }
+  __shared__ float red[4][6];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     lo[d] = wave_min(lo[d]);
     hi[d] = wave_max(hi[d]);
   }
   if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      red[wave][d] = lo[d];
+      red[wave][3 + d] = hi[d];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = fminf(fminf(red[0][d], red[1][d]), fminf(red[2][d], red[3][d]));
+      hi[d] = fmaxf(fmaxf(red[0][3 + d], red[1][3 + d]), fmaxf(red[2][3 + d], red[3][3 + d]));
+    }
     const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
     uint32_t a = 0;
     float best = ex;
@@ -856,33 +820,51 @@ __device__ __forceinline__ uint32_t kp_class(uint32_t v, const SelState* st) {
   return 6u;
 }
 
-// class counts per block: counts[block * 8 + class]
+// class counts per block: counts[block * 8 + class].  A lane counts its sixteen keys in 16-bit fields of two 64-bit
+// words (classes 0-3, classes 4-6; a block holds 4096 keys, so a field never overflows), the fields are summed over the
+// wavefront with six exchanges per word -- not sixteen rows of seven ballots, which made this pass over 4 bytes per
+// point cost 30 us at 10M points.
 __global__ __launch_bounds__(KP_THREADS) void kp_count_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                               uint32_t blocks_per_seg, const SelState* __restrict__ sel,
                                                               uint32_t* __restrict__ counts) {
-  __shared__ uint32_t c[8];
-  if (threadIdx.x < 8) c[threadIdx.x] = 0u;
+  __shared__ unsigned long long part[KP_THREADS / WAVE][2];
   const uint32_t sgm = blockIdx.x / blocks_per_seg;
   SelState st[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) st[k] = sel[sgm * 3 + k];
-  __syncthreads();
   const uint32_t base = blockIdx.x * uint32_t(KP_BLOCK);
-  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  unsigned long long a = 0ull, b = 0ull;
+#pragma unroll
   for (int e = 0; e < KP_ROWS; ++e) {
     const uint32_t i = base + uint32_t(e) * KP_THREADS + threadIdx.x;
-    const uint32_t cl = i < n ? kp_class(keys[i], st) : 7u;
-#pragma unroll
-    for (uint32_t k = 0; k < 7; ++k) {
-      const unsigned long long b = __builtin_amdgcn_ballot_w64(cl == k);
-      if (lane == 0 && b) atomicAdd(&c[k], uint32_t(__builtin_popcountll(b)));
+    if (i < n) {
+      const uint32_t cl = kp_class(keys[i], st);
+      a += cl < 4u ? 1ull << (16u * cl) : 0ull;
+      b += cl >= 4u ? 1ull << (16u * (cl - 4u)) : 0ull;
     }
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+  }
+  if (lane == 0) {
+    part[wave][0] = a;
+    part[wave][1] = b;
+  }
   __syncthreads();
-  if (threadIdx.x < 8) counts[blockIdx.x * 8 + threadIdx.x] = c[threadIdx.x];
+  if (threadIdx.x < 8) {
+    const uint32_t k = threadIdx.x;
+    unsigned long long w = 0ull;
+#pragma unroll
+    for (int v = 0; v < KP_THREADS / WAVE; ++v) w += part[v][k >> 2];
+    counts[blockIdx.x * 8 + k] = k < 7u ? uint32_t((w >> (16u * (k & 3u))) & 0xFFFFull) : 0u;
+  }
 }
 
-// one workgroup per segment: counts -> destination of the first point of every (block, class)
+// one workgroup per segment: counts -> destination of the first point of every (block, class); the seven classes are
+// scanned together (one pass over the counts, one ladder of barriers)
 __global__ __launch_bounds__(256) void kp_scan_kernel(const uint32_t* __restrict__ counts, uint32_t nblocks,
                                                       uint32_t blocks_per_seg, uint64_t seg_size,
                                                       uint32_t* __restrict__ offsets) {
@@ -890,35 +872,56 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(const uint32_t* __restrict
   const uint32_t b0 = sgm * blocks_per_seg;
   const uint32_t nb = (nblocks - b0) < blocks_per_seg ? (nblocks - b0) : blocks_per_seg;
   const uint32_t per = (nb + 255u) / 256u;
-  const uint32_t mine0 = threadIdx.x * per, mine1 = (mine0 + per) < nb ? (mine0 + per) : nb;
-  __shared__ uint32_t scan[256];
-  uint32_t class_base = uint32_t(uint64_t(sgm) * seg_size);
-  for (uint32_t k = 0; k < 7; ++k) {
-    uint32_t sum = 0;
-    for (uint32_t b = mine0; b < mine1; ++b) sum += counts[(b0 + b) * 8 + k];
-    __syncthreads();   // the previous class's scan[] is no longer read
-    scan[threadIdx.x] = sum;
+  const uint32_t mine0 = threadIdx.x * per < nb ? threadIdx.x * per : nb;
+  const uint32_t mine1 = (mine0 + per) < nb ? (mine0 + per) : nb;
+  __shared__ uint32_t scan[7][256];
+  const uint4* c4 = reinterpret_cast<const uint4*>(counts);
+  uint32_t sum[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  for (uint32_t b = mine0; b < mine1; ++b) {
+    const uint4 lo = c4[size_t(b0 + b) * 2], hi = c4[size_t(b0 + b) * 2 + 1];
+    sum[0] += lo.x; sum[1] += lo.y; sum[2] += lo.z; sum[3] += lo.w;
+    sum[4] += hi.x; sum[5] += hi.y; sum[6] += hi.z;
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) scan[k][threadIdx.x] = sum[k];
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {   // inclusive Hillis-Steele scans, all classes per step
+    uint32_t v[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = threadIdx.x >= uint32_t(o) ? scan[k][threadIdx.x - o] : 0u;
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-      const uint32_t v = threadIdx.x >= uint32_t(o) ? scan[threadIdx.x - o] : 0u;
-      __syncthreads();
-      scan[threadIdx.x] += v;
-      __syncthreads();
-    }
-    uint32_t run = class_base + scan[threadIdx.x] - sum;
-    for (uint32_t b = mine0; b < mine1; ++b) {
-      offsets[(b0 + b) * 8 + k] = run;
-      run += counts[(b0 + b) * 8 + k];
-    }
-    class_base += scan[255];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) scan[k][threadIdx.x] += v[k];
+    __syncthreads();
+  }
+  uint32_t run[7];
+  uint32_t class_base = uint32_t(uint64_t(sgm) * seg_size);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    run[k] = class_base + scan[k][threadIdx.x] - sum[k];
+    class_base += scan[k][255];
+  }
+  uint4* o4 = reinterpret_cast<uint4*>(offsets);
+  for (uint32_t b = mine0; b < mine1; ++b) {
+    const uint4 lo = c4[size_t(b0 + b) * 2], hi = c4[size_t(b0 + b) * 2 + 1];
+    o4[size_t(b0 + b) * 2] = make_uint4(run[0], run[1], run[2], run[3]);
+    o4[size_t(b0 + b) * 2 + 1] = make_uint4(run[4], run[5], run[6], 0u);
+    run[0] += lo.x; run[1] += lo.y; run[2] += lo.z; run[3] += lo.w;
+    run[4] += hi.x; run[5] += hi.y; run[6] += hi.z;
   }
 }
 
+// BOXES: the next round is another partition round and wants the bounding box of every slab this round creates; the
+// points pass through here anyway, so every block leaves the boxes of its points per destination slab
+// (slab_box[block * 4 + slab]; kp_param_kernel folds them over the blocks of the segment) instead of a separate pass
+// over the cloud (kd_chunk_box_kernel, 45 us per round at 10M points).
+template <bool BOXES>
 __global__ __launch_bounds__(KP_THREADS) void kp_scatter_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ keys,
                                                                 uint32_t n, uint32_t blocks_per_seg,
                                                                 const SelState* __restrict__ sel,
                                                                 const uint32_t* __restrict__ offsets,
-                                                                float4* __restrict__ out) {
+                                                                float4* __restrict__ out, uint32_t slab_shift,
+                                                                Box* __restrict__ slab_box) {
   constexpr int WAVES = KP_THREADS / WAVE;       // 4
   constexpr int CELLS = KP_ROWS * WAVES;         // 64 (row, wave) cells in position order
   __shared__ uint32_t cell[CELLS][8];
@@ -959,11 +962,61 @@ __global__ __launch_bounds__(KP_THREADS) void kp_scatter_kernel(const float4* __
     }
   }
   __syncthreads();
+  float lo[4][3], hi[4][3];
+  if (BOXES) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        lo[c][d] = FLT_MAX;
+        hi[c][d] = -FLT_MAX;
+      }
+  }
+  const uint32_t seg_first = sgm * blocks_per_seg * uint32_t(KP_BLOCK);
 #pragma unroll
   for (int e = 0; e < KP_ROWS; ++e) {
     if (cls[e] < 7u) {
       const uint32_t i = base + uint32_t(e) * KP_THREADS + threadIdx.x;
-      out[boff[cls[e]] + cell[e * WAVES + int(wave)][cls[e]] + rnk[e]] = in[i];
+      const uint32_t dst = boff[cls[e]] + cell[e * WAVES + int(wave)][cls[e]] + rnk[e];
+      const float4 q = in[i];
+      out[dst] = q;
+      if (BOXES) {
+        const uint32_t slab = (dst - seg_first) >> slab_shift;
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+          const bool mine = slab == c;
+          lo[c][0] = fminf(lo[c][0], mine ? q.x : FLT_MAX); hi[c][0] = fmaxf(hi[c][0], mine ? q.x : -FLT_MAX);
+          lo[c][1] = fminf(lo[c][1], mine ? q.y : FLT_MAX); hi[c][1] = fmaxf(hi[c][1], mine ? q.y : -FLT_MAX);
+          lo[c][2] = fminf(lo[c][2], mine ? q.z : FLT_MAX); hi[c][2] = fmaxf(hi[c][2], mine ? q.z : -FLT_MAX);
+        }
+      }
+    }
+  }
+  if (BOXES) {
+    __shared__ float red[WAVES][4][6];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float l = wave_min(lo[c][d]), h = wave_max(hi[c][d]);
+        if (lane == 0) {
+          red[wave][c][d] = l;
+          red[wave][c][3 + d] = h;
+        }
+      }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      const uint32_t c = threadIdx.x;
+      float l[3], h[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        l[d] = fminf(fminf(red[0][c][d], red[1][c][d]), fminf(red[2][c][d], red[3][c][d]));
+        h[d] = fmaxf(fmaxf(red[0][c][3 + d], red[1][c][3 + d]), fmaxf(red[2][c][3 + d], red[3][c][3 + d]));
+      }
+      Box bx;
+      bx.lo = make_float4(l[0], l[1], l[2], 0.0f);
+      bx.hi = make_float4(h[0], h[1], h[2], 0.0f);
+      slab_box[size_t(blockIdx.x) * 4 + c] = bx;
     }
   }
 }
@@ -995,24 +1048,6 @@ __global__ __launch_bounds__(256) void kd_compact_kernel(const uint32_t* __restr
   vals[pos] = rec;
 }
 
-// the common case needs no compaction at all: count the finite selected records first (read-only pass)
-__global__ __launch_bounds__(256) void kd_count_kernel(const void* pts, size_t stride, const int32_t* sel, uint64_t m,
-                                                       unsigned int* n_finite, Scale3 sc) {
-  unsigned int mine = 0;
-  for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < m; i += uint64_t(gridDim.x) * blockDim.x) {
-    const uint64_t rec = sel ? uint64_t(sel[i]) : i;
-    const float* p = record(pts, stride, rec);
-    const bool fin = (sc.x == 0.0f || isfinite(p[0])) && (sc.y == 0.0f || isfinite(p[1])) && (sc.z == 0.0f || isfinite(p[2]));
-    mine += fin ? 1u : 0u;
-  }
-  __shared__ unsigned int blk;
-  if (threadIdx.x == 0) blk = 0;
-  __syncthreads();
-  if (mine) atomicAdd(&blk, mine);
-  __syncthreads();
-  if (threadIdx.x == 0 && blk) atomicAdd(n_finite, blk);
-}
-
 // vals == nullptr: record j of the selection (or of the cloud) goes to slot j
 __global__ __launch_bounds__(256) void kd_load_kernel(const void* pts, size_t stride, const uint32_t* vals, const int32_t* sel,
                                                       uint64_t m, float4* out, int ids_from_w, Scale3 sc, int scaled) {
@@ -1030,10 +1065,106 @@ __global__ __launch_bounds__(256) void kd_load_kernel(const void* pts, size_t st
   out[j] = make_float4(x, y, z, ids_from_w ? p[3] : __uint_as_float(rec));
 }
 
+// The common case in one pass: record j of the selection (or of the cloud) -> slot j, the number of finite records, and
+// the bounding box of every block of KP_BLOCK slots (the chunk boxes of round 0 and of the first partition round).  If a
+// record turns out not to be finite the count says so and the caller takes the compaction path; boxes and slots of this
+// pass are then overwritten.
+__global__ __launch_bounds__(KP_THREADS) void kd_load_box_kernel(const void* pts, size_t stride, const int32_t* sel, uint64_t m,
+                                                                 float4* __restrict__ out, int ids_from_w, Scale3 sc, int scaled,
+                                                                 unsigned int* n_finite, Box* __restrict__ chunk_box) {
+  const uint64_t base = uint64_t(blockIdx.x) * KP_BLOCK;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  unsigned int mine = 0;
+#pragma unroll 4
+  for (int e = 0; e < KP_ROWS; ++e) {
+    const uint64_t j = base + uint64_t(e) * KP_THREADS + threadIdx.x;
+    if (j < m) {
+      const uint32_t rec = sel ? uint32_t(sel[j]) : uint32_t(j);
+      const float* p = record(pts, stride, rec);
+      float x = p[0], y = p[1], z = p[2];
+      const bool fin = (sc.x == 0.0f || isfinite(x)) && (sc.y == 0.0f || isfinite(y)) && (sc.z == 0.0f || isfinite(z));
+      mine += fin ? 1u : 0u;
+      if (scaled) {  // as kd_load_kernel
+        x = sc.x == 0.0f ? 0.0f : __fmul_rn(x, sc.x);
+        y = sc.y == 0.0f ? 0.0f : __fmul_rn(y, sc.y);
+        z = sc.z == 0.0f ? 0.0f : __fmul_rn(z, sc.z);
+      }
+      out[j] = make_float4(x, y, z, ids_from_w ? p[3] : __uint_as_float(rec));
+      lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+      hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+    }
+  }
+  __shared__ float red[KP_THREADS / WAVE][6];
+  __shared__ unsigned int blk;
+  if (threadIdx.x == 0) blk = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = wave_min(lo[d]);
+    hi[d] = wave_max(hi[d]);
+  }
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      red[wave][d] = lo[d];
+      red[wave][3 + d] = hi[d];
+    }
+  }
+  if (mine) atomicAdd(&blk, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Box bx;
+    bx.lo = make_float4(fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0])),
+                        fminf(fminf(red[0][1], red[1][1]), fminf(red[2][1], red[3][1])),
+                        fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2])), 0.0f);
+    bx.hi = make_float4(fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3])),
+                        fmaxf(fmaxf(red[0][4], red[1][4]), fmaxf(red[2][4], red[3][4])),
+                        fmaxf(fmaxf(red[0][5], red[1][5]), fmaxf(red[2][5], red[3][5])), 0.0f);
+    chunk_box[blockIdx.x] = bx;
+    if (blk) atomicAdd(n_finite, blk);
+  }
+}
+
+// one workgroup: the box of all chunk boxes (the bounding box the caller gets)
+__global__ __launch_bounds__(256) void kd_fold_box_kernel(const Box* __restrict__ boxes, uint32_t count, Box* __restrict__ out) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (uint32_t i = threadIdx.x; i < count; i += 256) {
+    const Box bx = boxes[i];
+    lo[0] = fminf(lo[0], bx.lo.x); lo[1] = fminf(lo[1], bx.lo.y); lo[2] = fminf(lo[2], bx.lo.z);
+    hi[0] = fmaxf(hi[0], bx.hi.x); hi[1] = fmaxf(hi[1], bx.hi.y); hi[2] = fmaxf(hi[2], bx.hi.z);
+  }
+  __shared__ float red[4][6];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = wave_min(lo[d]);
+    hi[d] = wave_max(hi[d]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      red[wave][d] = lo[d];
+      red[wave][3 + d] = hi[d];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Box bx;
+    bx.lo = make_float4(fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0])),
+                        fminf(fminf(red[0][1], red[1][1]), fminf(red[2][1], red[3][1])),
+                        fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2])), 0.0f);
+    bx.hi = make_float4(fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3])),
+                        fmaxf(fmaxf(red[0][4], red[1][4]), fmaxf(red[2][4], red[3][4])),
+                        fmaxf(fmaxf(red[0][5], red[1][5]), fmaxf(red[2][5], red[3][5])), 0.0f);
+    *out = bx;
+  }
+}
+
 __global__ __launch_bounds__(256) void kd_finish_kernel(const float4* __restrict__ in, uint64_t live, uint32_t nf,
                                                         float4* __restrict__ out, uint32_t out_cap,
-                                                        uint32_t* __restrict__ rank) {
-  const uint64_t j = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+                                                        uint32_t* __restrict__ rank, uint32_t first) {
+  const uint64_t j = uint64_t(first) + blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
   if (j >= out_cap) return;
   if (j < live) {
     const float4 p = in[j];
@@ -1060,7 +1191,7 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
   if (m == 0) {
     if (out_capacity)
       hipLaunchKernelGGL(kd_finish_kernel, dim3((out_capacity + 255) / 256), dim3(256), 0, s, (const float4*)nullptr,
-                         uint64_t(0), 0u, out_sorted, out_capacity, (uint32_t*)nullptr);
+                         uint64_t(0), 0u, out_sorted, out_capacity, (uint32_t*)nullptr, 0u);
     PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
     return PCLHIP_OK;
   }
@@ -1073,13 +1204,12 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
   // second key buffer of the sorting variants; the partition rounds keep their three digit histograms per segment
   // here (segments hold >= 16384 points)
   const size_t hist_room = (size_t(m) / 16384 + 1) * 3 * 3 * KP_BINS * sizeof(uint32_t);
-  const size_t off_v0 = off_k1 + align(std::max<size_t>(m * sizeof(uint64_t), hist_room));
-  const size_t off_v1 = off_v0 + align(m * sizeof(uint32_t));
+  const size_t off_v1 = off_k1 + align(std::max<size_t>(m * sizeof(uint64_t), hist_room));
   const size_t off_pa = off_v1 + align(m * sizeof(uint32_t));
   const size_t off_pb = off_pa + align(m * sizeof(float4));
   const size_t off_cb = off_pb + align(m * sizeof(float4));
-  const size_t off_ax = off_cb + align(size_t(max_chunks) * sizeof(Box));
-  const size_t off_cn = off_ax + align(size_t(max_chunks));
+  const size_t off_bb = off_cb + align(size_t(max_chunks) * sizeof(Box));
+  const size_t off_cn = off_bb + align(sizeof(Box));
   const size_t off_tmp = off_cn + align(sizeof(unsigned int));
   const size_t total = off_tmp + align(temp_bytes);
   pclhip_status st = ensure_scratch(ctx, total);
@@ -1087,29 +1217,30 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
   char* base = static_cast<char*>(ctx->scratch);
   uint64_t* k0 = reinterpret_cast<uint64_t*>(base + off_k0);
   uint64_t* k1 = reinterpret_cast<uint64_t*>(base + off_k1);
-  uint32_t* v0 = reinterpret_cast<uint32_t*>(base + off_v0);
   uint32_t* v1 = reinterpret_cast<uint32_t*>(base + off_v1);
   float4* pa = reinterpret_cast<float4*>(base + off_pa);
   float4* pb = reinterpret_cast<float4*>(base + off_pb);
   Box* cb = reinterpret_cast<Box*>(base + off_cb);
+  Box* bb = reinterpret_cast<Box*>(base + off_bb);
   unsigned int* cn = reinterpret_cast<unsigned int*>(base + off_cn);
   void* tmp = base + off_tmp;
 
-  // --- compaction: finite records first (stable 1-bit sort of (flag, record)) ---
+  // --- load: record j -> slot j, counting the finite ones and boxing every KP_BLOCK slots on the way; only a cloud
+  //     with non-finite records pays the stable compaction (finite records first, the others behind them) ---
   uint32_t* f0 = reinterpret_cast<uint32_t*>(k0);
   uint32_t* f1 = reinterpret_cast<uint32_t*>(k1);
   unsigned int hn = 0;
+  const uint32_t load_chunks = uint32_t((m + KP_BLOCK - 1) / KP_BLOCK);
+  std::vector<Box> hb(1);
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(cn, 0, sizeof(unsigned int), s));
-  {
-    const unsigned grid = unsigned(std::min<uint64_t>((m + 255) / 256, uint64_t(ctx->num_cus) * 16));
-    hipLaunchKernelGGL(kd_count_kernel, dim3(grid), dim3(256), 0, s, dev_points, stride, dev_sel, m, cn, sc);
-  }
+  hipLaunchKernelGGL(kd_load_box_kernel, dim3(load_chunks), dim3(KP_THREADS), 0, s, dev_points, stride, dev_sel, m, pa,
+                     ids_from_w ? 1 : 0, sc, scaled, cn, cb);
+  hipLaunchKernelGGL(kd_fold_box_kernel, dim3(1), dim3(256), 0, s, cb, load_chunks, bb);
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&hn, cn, sizeof hn, hipMemcpyDeviceToHost, s));
+  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(hb.data(), bb, sizeof(Box), hipMemcpyDeviceToHost, s));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-  if (uint64_t(hn) == m) {  // every record is finite: slot j <- record j, no compaction sort
-    hipLaunchKernelGGL(kd_load_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, s, dev_points, stride,
-                       (const uint32_t*)nullptr, dev_sel, m, pa, ids_from_w ? 1 : 0, sc, scaled);
-  } else {  // stable compaction: flags -> exclusive scan (device_scan.hpp) -> scatter of the record numbers
+  bool boxes_of_load = uint64_t(hn) == m;   // cb holds the boxes of pa's KP_BLOCK chunks, hb[0] the box of them all
+  if (!boxes_of_load) {  // stable compaction: flags -> exclusive scan (device_scan.hpp) -> scatter of the record numbers
     uint32_t* flags = f0;
     uint32_t* before = f1;
     uint2* sc_part = reinterpret_cast<uint2*>(tmp);
@@ -1127,6 +1258,7 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
   // --- kd rounds over the finite prefix ---
   float4* cur = pa;
   float4* nxt = pb;
+  bool placed = false;   // kd_block_kernel has written out_sorted[0, nf) and the ranks
   if (nf > 0) {
     const uint64_t nleaf = (uint64_t(nf) + LEAF - 1) / LEAF;
     int R = 0;
@@ -1135,6 +1267,19 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
       cap *= 4;
       ++R;
     }
+    auto fold = [&](const std::vector<Box>& boxes) {
+      float l[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, h[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+      for (const Box& b : boxes) {
+        l[0] = std::fmin(l[0], b.lo.x); l[1] = std::fmin(l[1], b.lo.y); l[2] = std::fmin(l[2], b.lo.z);
+        h[0] = std::fmax(h[0], b.hi.x); h[1] = std::fmax(h[1], b.hi.y); h[2] = std::fmax(h[2], b.hi.z);
+      }
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = l[d];
+        hi[d] = h[d];
+      }
+    };
+    bool slab_boxes = false;            // cb holds the previous scatter's boxes per (block, slab)
+    uint32_t parent_blocks = 0;         // ... of segments of this many blocks
     // round 0 (no sort) only measures the bounding box of everything for the caller
     for (int r = 0; r <= R; ++r) {
       // segment being split this round (r = 0: one segment covering all points, bbox only)
@@ -1145,41 +1290,25 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
       const uint32_t nchunks = uint32_t((uint64_t(nf) + chunk - 1) / chunk);
       const uint32_t chunks_per_seg = uint32_t(seg_size / chunk);
       const uint32_t nseg = uint32_t((uint64_t(nf) + seg_size - 1) / seg_size);
-      if (r > 0 && seg_size <= uint64_t(KDB_N)) {  // the remaining rounds fit one workgroup's LDS
+      if (r > 0 && seg_size <= uint64_t(KDB_N)) {  // the remaining rounds fit one workgroup's LDS: the last launch
         hipLaunchKernelGGL(kd_block_kernel, dim3(unsigned((uint64_t(nf) + KDB_N - 1) / KDB_N)), dim3(KDB_THREADS), 0, s, cur, nf,
-                           nxt, uint32_t(seg_size), 32u);
-        if (keep_nonfinite_at_end && m > nf)
-          PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(nxt + nf, cur + nf, (m - nf) * sizeof(float4), hipMemcpyDeviceToDevice, s));
-        float4* t = cur;
-        cur = nxt;
-        nxt = t;
+                           out_sorted, uint32_t(seg_size), 32u, rank_or_null);
+        placed = true;
         break;
       }
-      if (r == R && r > 0) {  // 64-point cells: two binary cuts inside one wavefront each
-        hipLaunchKernelGGL(kd_cell_split_kernel, dim3(unsigned((uint64_t(nf) + 255) / 256)), dim3(256), 0, s, cur, nf, nxt);
-        if (keep_nonfinite_at_end && m > nf)
-          PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(nxt + nf, cur + nf, (m - nf) * sizeof(float4), hipMemcpyDeviceToDevice, s));
-        float4* t = cur;
-        cur = nxt;
-        nxt = t;
-        continue;
-      }
-      hipLaunchKernelGGL(kd_chunk_box_kernel, dim3(unsigned((uint64_t(nchunks) * WAVE + 255) / 256)), dim3(256), 0, s, cur,
-                         nf, chunk, nchunks, cb);
       if (r == 0) {
-        // nseg == 1: reduce on the host (tiny)
-        std::vector<Box> hb(nchunks);
+        if (boxes_of_load) {
+          fold(hb);
+          continue;
+        }
+        hipLaunchKernelGGL(kd_chunk_box_kernel, dim3(unsigned((uint64_t(nchunks) * WAVE + 255) / 256)), dim3(256), 0, s, cur,
+                           nf, chunk, nchunks, cb);
+        hb.resize(nchunks);   // nseg == 1: reduce on the host (tiny)
         PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(hb.data(), cb, size_t(nchunks) * sizeof(Box), hipMemcpyDeviceToHost, s));
         PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-        float l[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, h[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (const Box& b : hb) {
-          l[0] = std::fmin(l[0], b.lo.x); l[1] = std::fmin(l[1], b.lo.y); l[2] = std::fmin(l[2], b.lo.z);
-          h[0] = std::fmax(h[0], b.hi.x); h[1] = std::fmax(h[1], b.hi.y); h[2] = std::fmax(h[2], b.hi.z);
-        }
-        for (int d = 0; d < 3; ++d) {
-          lo[d] = l[d];
-          hi[d] = h[d];
-        }
+        fold(hb);
+        // the same boxes serve the first partition round when its chunks are these
+        boxes_of_load = chunk == uint32_t(KP_BLOCK);
         continue;
       }
       if (chunk == uint32_t(KP_BLOCK) && seg_size % KP_BLOCK == 0) {
@@ -1187,13 +1316,23 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
         const uint32_t nblocks = nchunks, blocks_per_seg = chunks_per_seg;
         uint32_t* keys = reinterpret_cast<uint32_t*>(k0);
         uint32_t* hist = reinterpret_cast<uint32_t*>(k1);
-        uint32_t* counts = v0;
-        uint32_t* offsets = v0 + size_t(nblocks) * 8;
         SegParam* sp = reinterpret_cast<SegParam*>(v1);
         SelState* sel = reinterpret_cast<SelState*>(sp + nseg);
         const size_t hist_bytes = size_t(nseg) * 3 * KP_BINS * sizeof(uint32_t);
-        hipLaunchKernelGGL(kp_param_kernel, dim3(unsigned((uint64_t(nseg) * WAVE + 255) / 256)), dim3(256), 0, s, cb, nchunks,
-                           chunks_per_seg, nseg, nf, seg_size, sp, sel);
+        // class counts per block and the destinations scanned from them: 2 x 8 words per block in the key buffer's
+        // upper half (keys are 4 bytes per point, the buffer holds 8)
+        uint32_t* counts = reinterpret_cast<uint32_t*>(k0) + ((size_t(m) + 3) & ~size_t(3));   // 16-byte aligned
+        uint32_t* offsets = counts + size_t(nblocks) * 8;
+        if (slab_boxes) {
+          hipLaunchKernelGGL(kp_param_kernel, dim3(nseg), dim3(256), 0, s, cb, nblocks, parent_blocks, nseg, nf, seg_size, sp, sel,
+                             1);
+        } else {
+          if (!(r == 1 && boxes_of_load))
+            hipLaunchKernelGGL(kd_chunk_box_kernel, dim3(unsigned((uint64_t(nchunks) * WAVE + 255) / 256)), dim3(256), 0, s, cur,
+                               nf, chunk, nchunks, cb);
+          hipLaunchKernelGGL(kp_param_kernel, dim3(nseg), dim3(256), 0, s, cb, nchunks, chunks_per_seg, nseg, nf, seg_size, sp,
+                             sel, 0);
+        }
         PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(hist, 0, 3 * hist_bytes, s));   // one table per digit pass
         uint32_t* hist2 = hist + hist_bytes / sizeof(uint32_t);
         uint32_t* hist3 = hist2 + hist_bytes / sizeof(uint32_t);
@@ -1205,8 +1344,19 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
         hipLaunchKernelGGL(kp_select_kernel<3>, dim3(nseg * 3), dim3(256), 0, s, sp, sel, hist3);
         hipLaunchKernelGGL(kp_count_kernel, dim3(nblocks), dim3(KP_THREADS), 0, s, keys, nf, blocks_per_seg, sel, counts);
         hipLaunchKernelGGL(kp_scan_kernel, dim3(nseg), dim3(256), 0, s, counts, nblocks, blocks_per_seg, seg_size, offsets);
-        hipLaunchKernelGGL(kp_scatter_kernel, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sel, offsets,
-                           nxt);
+        // the slabs this round creates are the next round's segments: box them here unless kd_block_kernel comes next
+        const bool next_is_partition = seg_size / 4 > uint64_t(KDB_N);
+        uint32_t slab_shift = 0;
+        while ((uint64_t(1) << slab_shift) < seg_size / 4) ++slab_shift;
+        if (next_is_partition)
+          hipLaunchKernelGGL(kp_scatter_kernel<true>, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sel,
+                             offsets, nxt, slab_shift, cb);
+        else
+          hipLaunchKernelGGL(kp_scatter_kernel<false>, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sel,
+                             offsets, nxt, slab_shift, cb);
+
+        slab_boxes = next_is_partition;
+        parent_blocks = blocks_per_seg;
         if (keep_nonfinite_at_end && m > nf)
           PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(nxt + nf, cur + nf, (m - nf) * sizeof(float4), hipMemcpyDeviceToDevice, s));
         float4* t = cur;
@@ -1220,9 +1370,13 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
       return PCLHIP_ERR_STATE;
     }
   }
+  // what kd_block_kernel did not place: the non-finite records behind the finite ones (if kept) and the sentinels of
+  // the capacity -- or everything, for a cloud of at most one leaf, which has no round at all
   const uint64_t live = keep_nonfinite_at_end ? m : nf;
-  hipLaunchKernelGGL(kd_finish_kernel, dim3((out_capacity + 255) / 256), dim3(256), 0, s, cur, live, nf, out_sorted,
-                     out_capacity, rank_or_null);
+  const uint32_t first = placed ? nf : 0u;
+  if (out_capacity > first)
+    hipLaunchKernelGGL(kd_finish_kernel, dim3((out_capacity - first + 255) / 256), dim3(256), 0, s, cur, live, nf, out_sorted,
+                       out_capacity, rank_or_null, first);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
   return PCLHIP_OK;
@@ -1307,11 +1461,11 @@ pclhip_status build_boxes(pclhip_index* ix, bool with_discs) {
     PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->box[l], size_t(c) * sizeof(Box)));
     if (l == 1) {
       const uint32_t threads = c * LEAF;
-      hipLaunchKernelGGL(leaf_box_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c, ix->box[1]);
       if (ix->soa) (void)dev_free(ctx, ix->soa);
       ix->soa = nullptr;
       PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->soa, size_t(c) * 4 * LEAF * sizeof(float)));
-      hipLaunchKernelGGL(leaf_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, threads, ix->soa);
+      hipLaunchKernelGGL(leaf_box_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c, ix->box[1],
+                         ix->soa);
       if (ix->disc) (void)dev_free(ctx, ix->disc);
       ix->disc = nullptr;
       if (with_discs) {
@@ -1396,8 +1550,8 @@ pclhip_status refit_boxes(pclhip_index* ix) {
   }
   const uint32_t c1 = ix->count[1];
   const uint32_t threads = c1 * LEAF;
-  hipLaunchKernelGGL(leaf_box_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c1, ix->box[1]);
-  hipLaunchKernelGGL(leaf_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, threads, ix->soa);
+  hipLaunchKernelGGL(leaf_box_soa_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c1, ix->box[1],
+                     ix->soa);
   for (int l = 2; l <= ix->top; ++l) {
     const uint64_t th = uint64_t(ix->count[l]) * WAVE;
     hipLaunchKernelGGL(node_box_kernel, dim3(unsigned((th + 255) / 256)), dim3(256), 0, s, ix->box[l - 1], ix->count[l - 1],
@@ -1412,7 +1566,7 @@ pclhip_status refit_boxes(pclhip_index* ix) {
 
 void preload_index_build_kernels() {
   hipFuncAttributes a;
-  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(leaf_box_kernel));
+  (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(leaf_box_soa_kernel));
 }
 
 }  // namespace pclhip

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <sched.h>
 #include <cstring>
 #include <functional>
 
@@ -148,6 +149,11 @@ inline void global_load_lds(const void* g, void* lds_base, unsigned size, unsign
 #define __builtin_amdgcn_alignbit(hi, lo, sh) \
   uint32_t(((uint64_t(uint32_t(hi)) << 32) | uint64_t(uint32_t(lo))) >> ((sh) & 31))
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)
+// a polling lane gives its OS thread away (the workgroup it waits for may share the core)
+#define __builtin_amdgcn_s_sleep(n) ::sched_yield()
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4   // clang's value; the host build of __hip_atomic_* ignores the scope
+#endif
 #define __builtin_amdgcn_fmed3f(a, b, c) ::wavesim_fmed3(a, b, c)
 inline float wavesim_fmed3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 
