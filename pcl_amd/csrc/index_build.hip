@@ -1126,8 +1126,18 @@ __global__ __launch_bounds__(KP_THREADS) void kd_load_box_kernel(const void* pts
   }
 }
 
-// one workgroup: the box of all chunk boxes (the bounding box the caller gets)
-__global__ __launch_bounds__(256) void kd_fold_box_kernel(const Box* __restrict__ boxes, uint32_t count, Box* __restrict__ out) {
+// what the host waits for after the load pass, written straight into pinned host memory (no copy commands between the
+// load and the first round: the stream's idle time there is host latency)
+struct LoadResult {
+  Box box;
+  unsigned int n_finite;
+  unsigned int pad[7];
+};
+
+// one workgroup: the box of all chunk boxes (the bounding box the caller gets) and the finite count, for the host
+__global__ __launch_bounds__(256) void kd_fold_box_kernel(const Box* __restrict__ boxes, uint32_t count,
+                                                          const unsigned int* __restrict__ n_finite,
+                                                          LoadResult* __restrict__ out) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (uint32_t i = threadIdx.x; i < count; i += 256) {
@@ -1157,7 +1167,8 @@ __global__ __launch_bounds__(256) void kd_fold_box_kernel(const Box* __restrict_
     bx.hi = make_float4(fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3])),
                         fmaxf(fmaxf(red[0][4], red[1][4]), fmaxf(red[2][4], red[3][4])),
                         fmaxf(fmaxf(red[0][5], red[1][5]), fmaxf(red[2][5], red[3][5])), 0.0f);
-    *out = bx;
+    out->box = bx;
+    out->n_finite = *n_finite;
   }
 }
 
@@ -1208,8 +1219,7 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
   const size_t off_pa = off_v1 + align(m * sizeof(uint32_t));
   const size_t off_pb = off_pa + align(m * sizeof(float4));
   const size_t off_cb = off_pb + align(m * sizeof(float4));
-  const size_t off_bb = off_cb + align(size_t(max_chunks) * sizeof(Box));
-  const size_t off_cn = off_bb + align(sizeof(Box));
+  const size_t off_cn = off_cb + align(size_t(max_chunks) * sizeof(Box));
   const size_t off_tmp = off_cn + align(sizeof(unsigned int));
   const size_t total = off_tmp + align(temp_bytes);
   pclhip_status st = ensure_scratch(ctx, total);
@@ -1221,7 +1231,6 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
   float4* pa = reinterpret_cast<float4*>(base + off_pa);
   float4* pb = reinterpret_cast<float4*>(base + off_pb);
   Box* cb = reinterpret_cast<Box*>(base + off_cb);
-  Box* bb = reinterpret_cast<Box*>(base + off_bb);
   unsigned int* cn = reinterpret_cast<unsigned int*>(base + off_cn);
   void* tmp = base + off_tmp;
 
@@ -1235,10 +1244,18 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(cn, 0, sizeof(unsigned int), s));
   hipLaunchKernelGGL(kd_load_box_kernel, dim3(load_chunks), dim3(KP_THREADS), 0, s, dev_points, stride, dev_sel, m, pa,
                      ids_from_w ? 1 : 0, sc, scaled, cn, cb);
-  hipLaunchKernelGGL(kd_fold_box_kernel, dim3(1), dim3(256), 0, s, cb, load_chunks, bb);
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&hn, cn, sizeof hn, hipMemcpyDeviceToHost, s));
-  PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(hb.data(), bb, sizeof(Box), hipMemcpyDeviceToHost, s));
-  PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
+  {
+    LoadResult* res = nullptr;
+    PCLHIP_CHECK_HIP(ctx, pinned_malloc(ctx, &res, sizeof(LoadResult)));
+    hipLaunchKernelGGL(kd_fold_box_kernel, dim3(1), dim3(256), 0, s, cb, load_chunks, cn, res);
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) {
+      hn = res->n_finite;
+      hb[0] = res->box;
+    }
+    pinned_free(ctx, res, sizeof(LoadResult));
+    PCLHIP_CHECK_HIP(ctx, e);
+  }
   bool boxes_of_load = uint64_t(hn) == m;   // cb holds the boxes of pa's KP_BLOCK chunks, hb[0] the box of them all
   if (!boxes_of_load) {  // stable compaction: flags -> exclusive scan (device_scan.hpp) -> scatter of the record numbers
     uint32_t* flags = f0;
@@ -1443,6 +1460,15 @@ pclhip_status build_index_over(pclhip_ctx* ctx, float4* pts_in_kd_order, uint32_
 pclhip_status build_boxes(pclhip_index* ix, bool with_discs) {
   pclhip_ctx* ctx = ix->ctx;
   hipStream_t s = ctx->stream;
+  constexpr int DIAG_NB = 64;
+  double* diag_part = nullptr;   // pinned; released at the final wait
+  uint32_t diag_leaves = 0;
+  struct PinnedGuard {
+    pclhip_ctx* ctx;
+    double** p;
+    size_t bytes;
+    ~PinnedGuard() { if (*p) pinned_free(ctx, *p, bytes); }
+  } diag_guard{ctx, &diag_part, 3 * DIAG_NB * sizeof(double)};
   for (int l = 0; l < MAX_LEVELS; ++l) {
     if (ix->box[l]) (void)dev_free(ctx, ix->box[l]);
     ix->box[l] = nullptr;
@@ -1471,26 +1497,14 @@ pclhip_status build_boxes(pclhip_index* ix, bool with_discs) {
       if (with_discs) {
       PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->disc, size_t(c) * 2 * sizeof(float4)));
       hipLaunchKernelGGL(leaf_disc_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ix->pts, ix->n, c, ix->disc);
-      {  // mean squared leaf diagonal: from what stand-off on the discs pay (traverse.hpp)
-        constexpr int NB = 64;
-        double* part = nullptr;
-        PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &part, 3 * NB * sizeof(double)));
-        hipLaunchKernelGGL(leaf_diag_kernel, dim3(NB), dim3(256), 0, s, ix->box[1], ix->disc, c, part);
-        double h[3 * NB];
-        const hipError_t e1 = hipMemcpyAsync(h, part, sizeof h, hipMemcpyDeviceToHost, s);
-        const hipError_t e2 = hipStreamSynchronize(s);
-        (void)dev_free(ctx, part);
-        PCLHIP_CHECK_HIP(ctx, e1);
-        PCLHIP_CHECK_HIP(ctx, e2);
-        double sum = 0.0, hs = 0.0, rs = 0.0;
-        for (int i = 0; i < NB; ++i) {
-          sum += h[i];
-          hs += h[NB + i];
-          rs += h[2 * NB + i];
-        }
-        ix->leaf_diag2 = float(sum / double(c));
-        ix->disc_thickness = rs > 0.0 ? float(hs / rs) : 1.0f;
+      // mean squared leaf diagonal: from what stand-off on the discs pay (traverse.hpp).  The partial sums land in
+      // pinned host memory and are read at this function's final wait, so the stream does not idle here.
+      if (pinned_malloc(ctx, &diag_part, 3 * DIAG_NB * sizeof(double)) != hipSuccess) {
+        set_error(ctx, "hipHostMalloc failed for the leaf statistics");
+        return PCLHIP_ERR_HIP;
       }
+      diag_leaves = c;
+      hipLaunchKernelGGL(leaf_diag_kernel, dim3(DIAG_NB), dim3(256), 0, s, ix->box[1], ix->disc, c, diag_part);
       }  // with_discs
     } else {
       const uint64_t threads = uint64_t(c) * WAVE;
@@ -1533,6 +1547,16 @@ pclhip_status build_boxes(pclhip_index* ix, bool with_discs) {
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(ix->lv_dev, h, sizeof h, hipMemcpyHostToDevice, s));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));  // h is a stack buffer
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+  if (diag_part) {
+    double sum = 0.0, hs = 0.0, rs = 0.0;
+    for (int i = 0; i < DIAG_NB; ++i) {
+      sum += diag_part[i];
+      hs += diag_part[DIAG_NB + i];
+      rs += diag_part[2 * DIAG_NB + i];
+    }
+    ix->leaf_diag2 = float(sum / double(diag_leaves));
+    ix->disc_thickness = rs > 0.0 ? float(hs / rs) : 1.0f;
+  }
   return PCLHIP_OK;
 }
 
