@@ -717,48 +717,82 @@ __global__ __launch_bounds__(256) void kp_param_kernel(const Box* __restrict__ b
 }
 
 // digit histograms of one pass.  PASS 1 also materialises the keys (4 bytes per point for the later passes).
+// `copies` (a power of two): the blocks of a segment merge into this many copies of its tables (block % copies), which the
+// selection adds up -- with one or four segments every block of the grid would otherwise add to the same few hundred
+// populated bins (float keys crowd into the bins of the outer binades), and same-address atomics serialise at the memory
+// side: hist<1> 64 us instead of 42 in the first two rounds at 10M points.
+// Passes 2 and 3 only count keys that share the digits already decided, normally a few per block: such a block adds them
+// to the global tables directly and never touches its LDS tables (zeroing and sweeping 24 KB cost more than the 16 KB
+// of keys it reads); blocks with many candidates (skewed or tied keys) take the LDS path.
+constexpr uint32_t KP_SPARSE_MAX = 128;
 template <int PASS>
 __global__ __launch_bounds__(KP_THREADS) void kp_hist_kernel(const float4* __restrict__ pts, uint32_t* __restrict__ keys,
                                                              uint32_t n, uint32_t blocks_per_seg,
                                                              const SegParam* __restrict__ sp, const SelState* __restrict__ sel,
-                                                             uint32_t* __restrict__ hist) {
+                                                             uint32_t* __restrict__ hist, uint32_t copies) {
   constexpr int NH = PASS == 1 ? 1 : 3;
   __shared__ uint32_t h[NH][KP_BINS];
+  __shared__ uint32_t candidates;
   const uint32_t sgm = blockIdx.x / blocks_per_seg;
   const SegParam p = sp[sgm];
   uint32_t shift, width, up;
   kp_digits(p.nbits, PASS, shift, width, up);
   if (PASS > 1 && width == 0u) return;   // nothing left to decide for this segment (wave-uniform)
-  for (int i = threadIdx.x; i < NH * KP_BINS; i += KP_THREADS) (&h[0][0])[i] = 0u;
-  SelState st[3];
-  if (PASS > 1) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) st[k] = sel[sgm * 3 + k];
-  }
-  __syncthreads();
+  uint32_t* g = hist + (size_t(sgm) * copies + (blockIdx.x & (copies - 1u))) * 3 * KP_BINS;
   const uint32_t base = blockIdx.x * uint32_t(KP_BLOCK);
   const uint32_t mask = width >= 32u ? 0xFFFFFFFFu : ((1u << width) - 1u);
+  if (PASS == 1) {
+    for (int i = threadIdx.x; i < NH * KP_BINS; i += KP_THREADS) (&h[0][0])[i] = 0u;
+    __syncthreads();
 #pragma unroll 4
-  for (int e = 0; e < KP_ROWS; ++e) {
-    const uint32_t i = base + uint32_t(e) * KP_THREADS + threadIdx.x;
-    if (i < n) {
-      uint32_t v;
-      if (PASS == 1) {
+    for (int e = 0; e < KP_ROWS; ++e) {
+      const uint32_t i = base + uint32_t(e) * KP_THREADS + threadIdx.x;
+      if (i < n) {
         const float4 q = pts[i];
         const float c = p.axis == 0u ? q.x : (p.axis == 1u ? q.y : q.z);
-        v = orderable(c) - p.klo;
+        const uint32_t v = orderable(c) - p.klo;
         keys[i] = v;
         atomicAdd(&h[0][(v >> shift) & mask], 1u);
-      } else {
-        v = keys[i];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (st[k].has && (v >> up) == (st[k].val >> up)) atomicAdd(&h[k][(v >> shift) & mask], 1u);
       }
     }
+  } else {
+    SelState st[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st[k] = sel[sgm * 3 + k];
+    if (threadIdx.x == 0) candidates = 0u;
+    uint32_t v[KP_ROWS];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int e = 0; e < KP_ROWS; ++e) {
+      const uint32_t i = base + uint32_t(e) * KP_THREADS + threadIdx.x;
+      v[e] = i < n ? keys[i] : 0u;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) mine += (i < n && st[k].has && (v[e] >> up) == (st[k].val >> up)) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(&candidates, mine);
+    __syncthreads();
+    const bool sparse = candidates <= KP_SPARSE_MAX;   // block-uniform
+    if (!sparse) {
+      for (int i = threadIdx.x; i < NH * KP_BINS; i += KP_THREADS) (&h[0][0])[i] = 0u;
+      __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < KP_ROWS; ++e) {
+      const uint32_t i = base + uint32_t(e) * KP_THREADS + threadIdx.x;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (i < n && st[k].has && (v[e] >> up) == (st[k].val >> up)) {
+          const uint32_t b = (v[e] >> shift) & mask;
+          if (sparse) atomicAdd(g + k * KP_BINS + b, 1u);
+          else atomicAdd(&h[k][b], 1u);
+        }
+    }
+    if (sparse) return;
   }
   __syncthreads();
-  uint32_t* g = hist + size_t(sgm) * 3 * KP_BINS;
   const uint32_t nb = 1u << width;
   for (uint32_t i = threadIdx.x; i < uint32_t(NH) * nb; i += KP_THREADS) {
     const uint32_t k = i / nb, b = i - k * nb;
@@ -770,21 +804,24 @@ __global__ __launch_bounds__(KP_THREADS) void kp_hist_kernel(const float4* __res
 // one workgroup per (segment, splitter): find the bin that holds the wanted rank, descend into it
 template <int PASS>
 __global__ __launch_bounds__(256) void kp_select_kernel(const SegParam* __restrict__ sp, SelState* __restrict__ sel,
-                                                        const uint32_t* __restrict__ hist) {
+                                                        const uint32_t* __restrict__ hist, uint32_t copies) {
   const uint32_t sgm = blockIdx.x / 3, k = blockIdx.x % 3;
   const SegParam p = sp[sgm];
   uint32_t shift, width, up;
   kp_digits(p.nbits, PASS, shift, width, up);
   SelState st = sel[sgm * 3 + k];
   if (!st.has || width == 0u) return;
-  const uint32_t* H = hist + (size_t(sgm) * 3 + (PASS == 1 ? 0u : k)) * KP_BINS;
   constexpr int PER = KP_BINS / 256;  // 8 bins per thread
   uint32_t c[PER], sum = 0;
 #pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    c[j] = H[threadIdx.x * PER + j];
-    sum += c[j];
+  for (int j = 0; j < PER; ++j) c[j] = 0u;
+  for (uint32_t cp = 0; cp < copies; ++cp) {
+    const uint32_t* H = hist + ((size_t(sgm) * copies + cp) * 3 + (PASS == 1 ? 0u : k)) * KP_BINS;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) c[j] += H[threadIdx.x * PER + j];
   }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) sum += c[j];
   __shared__ uint32_t scan[256];
   scan[threadIdx.x] = sum;
   __syncthreads();
@@ -1214,7 +1251,7 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
   const size_t off_k1 = off_k0 + align(m * sizeof(uint64_t));
   // second key buffer of the sorting variants; the partition rounds keep their three digit histograms per segment
   // here (segments hold >= 16384 points)
-  const size_t hist_room = (size_t(m) / 16384 + 1) * 3 * 3 * KP_BINS * sizeof(uint32_t);
+  const size_t hist_room = std::max<size_t>(size_t(m) / 16384 + 1, 64) * 3 * 3 * KP_BINS * sizeof(uint32_t);
   const size_t off_v1 = off_k1 + align(std::max<size_t>(m * sizeof(uint64_t), hist_room));
   const size_t off_pa = off_v1 + align(m * sizeof(uint32_t));
   const size_t off_pb = off_pa + align(m * sizeof(float4));
@@ -1335,7 +1372,9 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
         uint32_t* hist = reinterpret_cast<uint32_t*>(k1);
         SegParam* sp = reinterpret_cast<SegParam*>(v1);
         SelState* sel = reinterpret_cast<SelState*>(sp + nseg);
-        const size_t hist_bytes = size_t(nseg) * 3 * KP_BINS * sizeof(uint32_t);
+        // copies of a segment's tables (see kp_hist_kernel): nseg * copies <= 64
+        const uint32_t copies = nseg <= 4u ? 16u : (nseg <= 16u ? 4u : 1u);
+        const size_t hist_bytes = size_t(nseg) * copies * 3 * KP_BINS * sizeof(uint32_t);
         // class counts per block and the destinations scanned from them: 2 x 8 words per block in the key buffer's
         // upper half (keys are 4 bytes per point, the buffer holds 8)
         uint32_t* counts = reinterpret_cast<uint32_t*>(k0) + ((size_t(m) + 3) & ~size_t(3));   // 16-byte aligned
@@ -1353,12 +1392,15 @@ pclhip_status kd_order(pclhip_ctx* ctx, const void* dev_points, size_t stride, u
         PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(hist, 0, 3 * hist_bytes, s));   // one table per digit pass
         uint32_t* hist2 = hist + hist_bytes / sizeof(uint32_t);
         uint32_t* hist3 = hist2 + hist_bytes / sizeof(uint32_t);
-        hipLaunchKernelGGL(kp_hist_kernel<1>, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sp, sel, hist);
-        hipLaunchKernelGGL(kp_select_kernel<1>, dim3(nseg * 3), dim3(256), 0, s, sp, sel, hist);
-        hipLaunchKernelGGL(kp_hist_kernel<2>, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sp, sel, hist2);
-        hipLaunchKernelGGL(kp_select_kernel<2>, dim3(nseg * 3), dim3(256), 0, s, sp, sel, hist2);
-        hipLaunchKernelGGL(kp_hist_kernel<3>, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sp, sel, hist3);
-        hipLaunchKernelGGL(kp_select_kernel<3>, dim3(nseg * 3), dim3(256), 0, s, sp, sel, hist3);
+        hipLaunchKernelGGL(kp_hist_kernel<1>, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sp, sel, hist,
+                           copies);
+        hipLaunchKernelGGL(kp_select_kernel<1>, dim3(nseg * 3), dim3(256), 0, s, sp, sel, hist, copies);
+        hipLaunchKernelGGL(kp_hist_kernel<2>, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sp, sel, hist2,
+                           copies);
+        hipLaunchKernelGGL(kp_select_kernel<2>, dim3(nseg * 3), dim3(256), 0, s, sp, sel, hist2, copies);
+        hipLaunchKernelGGL(kp_hist_kernel<3>, dim3(nblocks), dim3(KP_THREADS), 0, s, cur, keys, nf, blocks_per_seg, sp, sel, hist3,
+                           copies);
+        hipLaunchKernelGGL(kp_select_kernel<3>, dim3(nseg * 3), dim3(256), 0, s, sp, sel, hist3, copies);
         hipLaunchKernelGGL(kp_count_kernel, dim3(nblocks), dim3(KP_THREADS), 0, s, keys, nf, blocks_per_seg, sel, counts);
         hipLaunchKernelGGL(kp_scan_kernel, dim3(nseg), dim3(256), 0, s, counts, nblocks, blocks_per_seg, seg_size, offsets);
         // the slabs this round creates are the next round's segments: box them here unless kd_block_kernel comes next
