@@ -3,7 +3,7 @@
 TAG=$1; L=${2:-pcl_amd/libpclhip.so}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-PCLHIP_LIB=$L timeout 300 rocprofv3 --kernel-trace -d $OUT/prof -o trace --output-format csv -- python scratch/build_only.py > $OUT/run.log 2>&1
+PCLHIP_LIB=$L timeout 300 rocprofv3 --kernel-trace -d $OUT/prof -o trace --output-format csv -- python scratch/build_only.py ${N:-10000000} > $OUT/run.log 2>&1
 grep "^build" $OUT/run.log
 f=$(find $OUT/prof -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY' | tee $OUT/dispatches.txt
