@@ -68,10 +68,11 @@ def parse():
 
 
 def kernel_sources_sha():
-    """sha256 over the sources of the search kernel (scripts/make_pmc_traffic.py stamps the counter passes with it)"""
+    """sha256 over the sources of the search kernel and of the index build that shapes the tree it walks (scripts/make_pmc_traffic.py
+    stamps the counter passes with it)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("search.hip", "traverse.hpp", "standoff.hpp", "pclhip_internal.hpp"):
+    for f in ("search.hip", "traverse.hpp", "standoff.hpp", "pclhip_internal.hpp", "index_build.hip"):
         h.update(open(os.path.join(ROOT, "pcl_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -307,29 +307,34 @@ __device__ __forceinline__ uint32_t orderable(float f) {
 
 
 // ---- bottom kd rounds in one workgroup ------------------------------------------------------------
-// Segments of <= 4096 points are ordered entirely inside LDS: the rounds that cut a 4096-point segment into
-// four 1024-point slabs, those into 256-point slabs, those into 64-point cells, and the two binary cuts of a
-// cell (see above) run back to back in one launch.  The points stay where they are (x, y, z planes in LDS); a 16-bit
-// permutation moves.  Per level: bounding box of every sub-segment -> widest axis -> keys = exact unsigned order of
-// the coordinate along it, then
-//   * the three four-way levels (sub-segments of 4096 / 1024 / 256 points) only need every sub-segment CUT at its
-//     quartile order statistics -- the order inside a slab is irrelevant, the next level re-orders it along another
-//     axis.  So they do what the top rounds do across the grid (kp_* below), inside LDS: the three quartile keys by
-//     radix selection (7-bit digits from the top of the key range of the sub-segment: per-sub-segment histograms with
-//     packed 16-bit counters, after the first pass only the keys inside the three selected bins count), every point
-//     classified against them (< s1, = s1, between, ..., > s3: seven classes, monotone in the key), and the permutation
-//     rearranged by (class, previous position) with a prefix sum over the threads -- deterministic; the positional slab
-//     boundaries fall inside the "= s_k" classes, so ties at a splitter are split by count.  (Until round 4 these
-//     levels were full bitonic sorts of (key, position) pairs: 169 of the kernel's 205 compare-exchange stages,
-//     0.83 ms at 10M points.)
-//   * the two binary levels (64 and 32 points) stay bitonic sorts inside one wavefront: shuffles only.  (Cutting them
-//     short after the stage that separates the halves -- 27 stages instead of 36 -- changed nothing measurable: what a
-//     level costs is its gathers through the permutation and its barriers, 0.29 ms for these two.)
+// Segments of <= 4096 points are ordered entirely inside LDS: the rounds that cut a 4096-point segment into four
+// 1024-point slabs and those into 256-point slabs, then four BINARY cuts (256 -> 128 -> 64 -> 32 -> 16, each along the
+// widest axis of the piece it cuts) run back to back in one launch.  The points stay where they are (x, y, z planes in
+// LDS); a 16-bit permutation moves.  Per level: bounding box of every sub-segment -> widest axis -> keys = exact
+// unsigned order of the coordinate along it, then
+//   * the two four-way levels (sub-segments of 4096 / 1024 points) only need every sub-segment CUT at its quartile
+//     order statistics -- the order inside a slab is irrelevant, the next level re-orders it along another axis.  So
+//     they do what the top rounds do across the grid (kp_* below), inside LDS: the three quartile keys by radix
+//     selection (7-bit digits from the top of the key range of the sub-segment: per-sub-segment histograms with packed
+//     16-bit counters, after the first pass only the keys inside the three selected bins count), every point classified
+//     against them (< s1, = s1, between, ..., > s3: seven classes, monotone in the key), and the permutation rearranged
+//     by (class, previous position) with a prefix sum over the threads -- deterministic; the positional slab boundaries
+//     fall inside the "= s_k" classes, so ties at a splitter are split by count.  (Until round 4 these levels were full
+//     bitonic sorts of (key, position) pairs.)
+//   * the four binary levels (256, 128, 64 and 32 points) are bitonic sorts inside one wavefront (a thread holds four
+//     consecutive positions, so a wavefront holds a whole 256-point sub-segment): shuffles only.
+// Why binary below 1024: four slabs along ONE axis make a square cell into four 4:1 strips.  Until the end of round 4 the
+// 256-point level was such a cut, so a 64-point cell -- one wavefront of queries, and the run the stand-off search seeds --
+// was a 16 x 4 strip of point spacings on a surface; two binary cuts make it an 8 x 8 patch (and the 16-point leaves
+// 4 x 4 as before).  A strip's neighbourhood is a third longer than a square's: every search launch got 6-18 % faster
+// (`ms_per_step` 1.088 -> 0.991 at 10M points, cold launch 1.83 -> 1.50 ms, same call and box) for 0.13 ms more in this
+// kernel (the 256- and 128-point sorts: 64 more compare-exchange stages).
 // Keys are exact float orders, so cells keep disjoint interiors.
 constexpr int KDB_N = 4096;
 constexpr int KDB_THREADS = 1024;
 constexpr int KDB_WAVES = KDB_THREADS / WAVE;
-constexpr int KDB_MAXSUB = KDB_N / 256;  // sub-segments of the smallest four-way level
+constexpr int KDB_FOURWAY_FROM = 1024;   // sub-segments of this size and above are cut four ways, smaller ones in two
+constexpr int KDB_MAXSUB = KDB_N / KDB_FOURWAY_FROM;  // sub-segments of the smallest four-way level
 struct KdBlockLds {
   float x[KDB_N], y[KDB_N], z[KDB_N];
   uint16_t perm[KDB_N];
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
     s.perm[p] = uint16_t(p);
   }
   __syncthreads();
-  for (uint32_t nsub = top_nsub; nsub >= bottom_nsub; nsub = (nsub > 64u) ? nsub / 4u : nsub / 2u) {
+  for (uint32_t nsub = top_nsub; nsub >= bottom_nsub; nsub = (nsub >= uint32_t(KDB_FOURWAY_FROM)) ? nsub / 4u : nsub / 2u) {
     // (a) bounding box of the sub-segment this thread's four positions belong to
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     uint32_t idx[4];
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
     if (ey > best) { best = ey; a = 1; }
     if (ez > best) { a = 2; }
     uint32_t kk[4], pp[4];
-    if (nsub >= 256u) {
+    if (nsub >= uint32_t(KDB_FOURWAY_FROM)) {
       // ---- four-way level: quartile selection + partition (block-uniform branch) ---------------------------------
       const uint32_t sub = t / group;
       const bool empty = !(lo[0] <= hi[0]);  // a sub-segment of padding only
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
       __syncthreads();
       continue;
     }
-    // ---- binary levels (64 and 32 points): bitonic sort inside a wavefront --------------------------------------
+    // ---- binary levels (256 ... 32 points): bitonic sort inside a wavefront -------------------------------------
     // (b) keys: the coordinate along that axis in unsigned order; padding sorts last.  The thread's four
     // (key, position) pairs live in registers from here on.
 #pragma unroll
@@ -563,7 +568,7 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
       pp[e] = idx[e];
     }
     // (c) bitonic sort of (key, position) inside every sub-segment, ascending.  Element i = 4t + e meets i ^ j:
-    // inside the thread for j < 4, across lanes (shuffle) above that (nsub <= 64: j <= 32).
+    // inside the thread for j < 4, across lanes (shuffle) above that (nsub <= 256: j <= 128, 32 lanes away).
     for (uint32_t k = 2; k <= nsub; k <<= 1) {
       for (uint32_t j = k >> 1; j > 0; j >>= 1) {
         uint32_t ok[4], op[4];

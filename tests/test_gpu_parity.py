@@ -1475,9 +1475,9 @@ def test_registration_options_through_the_criteria_object(gpu, bunny):
 # the kd order itself (index_build.hip): what the start-level shortcut of the seeded searches relies on
 # ------------------------------------------------------------------------------------------------
 def _check_kd_cells(cloud, order):
-    """Every aligned run of 16 * 4^k positions is one cell of a kd partition: the four quarters of a run are separated,
-    in order, along ONE axis (max of a quarter <= min of the next); a 64-run is two binary cuts (halves along one axis,
-    each half's 16-runs along one axis)."""
+    """Every aligned run of 16 * 2^k positions up to 256, and of 256 * 4^k above, is one cell of a kd partition: a run of
+    at most 256 positions is cut in two along one axis (max of the first half <= min of the second), a larger one into four
+    quarters separated, in order, along ONE axis (max of a quarter <= min of the next)."""
     n = len(order)
     assert sorted(order.tolist()) == sorted(set(order.tolist())) and len(order) == n
     pts = cloud[order, :3].astype(np.float64)
@@ -1493,7 +1493,7 @@ def _check_kd_cells(cloud, order):
         return np.any(hi_a <= lo_b, axis=-1)
     level = 0
     while len(lo) > 1:
-        fan = 2 if level < 2 else 4            # 16 -> 32 -> 64 by binary cuts, then four slabs per round
+        fan = 2 if level < 4 else 4            # 16 -> 32 -> 64 -> 128 -> 256 by binary cuts, then four slabs per round
         m = len(lo) // fan * fan
         if m == 0:
             break
