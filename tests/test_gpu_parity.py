@@ -1545,6 +1545,26 @@ def test_kd_order_cells_are_a_kd_partition(gpu, kind, n):
     _check_kd_cells(cloud, order)
 
 
+def test_kd_cells_of_64_points_are_patches_not_strips(gpu):
+    # what a wavefront of queries pays for is the neighbourhood of its 64 points: the block kernel of the index build cuts
+    # a 256-point cell in two, twice, so that a 64-point cell of a surface is an 8 x 8 patch of point spacings; four slabs
+    # along one axis (the schedule until the end of round 4) made it a 16 x 4 strip and every search launch 6-18 % slower
+    # (profiles/r04_seed_experiments_ab.txt).  Exactness does not depend on this; the headline does.
+    rng = np.random.default_rng(64)
+    for n in (50_000, 200_000):                 # both parities of the number of four-way rounds above the block kernel
+        cloud = np.ones((n, 4), np.float32)
+        cloud[:, :2] = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+        cloud[:, 2] = 0.5
+        order = build_tree(gpu, cloud).order()
+        pts = cloud[order, :2].astype(np.float64)
+        for run, limit in ((64, 2.0), (16, 2.0)):
+            m = n // run * run
+            cells = pts[:m].reshape(-1, run, 2)
+            ext = cells.max(axis=1) - cells.min(axis=1)
+            aspect = ext.max(axis=1) / np.maximum(ext.min(axis=1), 1e-12)
+            assert np.median(aspect) < limit, (n, run, float(np.median(aspect)))
+
+
 def test_context_options(gpu):
     # pclhip_ctx_set_option: the library's four tuning knobs (it reads no environment variable); unknown names and
     # negative values are refused, none of them changes a result (the served-groups / lookahead tests rely on that)
