@@ -122,6 +122,16 @@ PCLHIP_API double pclhip_index_build_ms(const pclhip_index* index);
  * cell of a kd partition -- so a caller can lay per-point attributes out the same way.  (KdTreeFLANN keeps the
  * corresponding permutation private: kdtree_flann.h `index_mapping_`; tests use this to check the cells.) */
 PCLHIP_API pclhip_status pclhip_index_order(pclhip_index* index, int32_t* out);
+/* The structure the per-lane search of the seeded ICP launches walks (round 5): the kd order seen as a 4-ary tree over
+ * the 16-point leaves.  Level q has ceil(leaves / 4^q) nodes; node i covers positions [16 i 4^q, 16 (i+1) 4^q) of
+ * pclhip_index_order.  For one level: boxes[6 i ..] = tight AABB (lo xyz, hi xyz) of node i, cells[6 i ..] = its CELL --
+ * an axis-aligned region, +-inf where unbounded, whose INTERIOR holds no point of any other node (what lets a search
+ * stop inside the node; an inverted cell, lo > hi, marks a node whose siblings the build could not separate).
+ * *count receives the number of nodes of the level, *top_level the root's level; buffers (host memory, `capacity` nodes
+ * each, either may be NULL) are filled when capacity suffices.  No counterpart in PCL (FLANN keeps its tree private);
+ * tests check the cells against the points with it.  PCLHIP_ERR_STATE for an index without the structure. */
+PCLHIP_API pclhip_status pclhip_index_cells(pclhip_index* index, int level, float* boxes, float* cells, uint64_t capacity,
+                                            uint64_t* count, int* top_level);
 
 /* Exact k nearest neighbours of nq query points.
  * Replaces pcl::KdTreeFLANN<PointT>::nearestKSearch (kdtree_flann.hpp:234-274) and the batch

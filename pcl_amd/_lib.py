@@ -104,6 +104,7 @@ SIGNATURES = {
     "pclhip_index_size": (_u64, [_vp]),
     "pclhip_index_build_ms": (C.c_double, [_vp]),
     "pclhip_index_order": (C.c_int, [_vp, _vp]),
+    "pclhip_index_cells": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "pclhip_knn": (C.c_int, [_vp, _vp, _sz, _u64, C.c_int, _vp, _vp]),
     "pclhip_radius_search": (C.c_int, [_vp, _vp, _sz, _u64, C.c_double, C.c_uint32, C.POINTER(_u64), _vp, _vp, _u64,
                                        C.POINTER(_u64)]),

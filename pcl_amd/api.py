@@ -70,7 +70,8 @@ class Context:
         check(self.lib.pclhip_ctx_reserve(self.h, int(nbytes)), self.h)
 
     def setOption(self, name, value):
-        """pclhip_ctx_set_option: "served_groups", "icp_lookahead", "cache_mb", "arena_mb" (none changes a result)."""
+        """pclhip_ctx_set_option: "served_groups", "icp_lookahead", "cache_mb", "arena_mb", "lane_search", "lane_max_up",
+        "lane_far" (none changes a result)."""
         check(self.lib.pclhip_ctx_set_option(self.h, name.encode(), float(value)), self.h)
 
     def stats(self, enable=True):
@@ -79,6 +80,13 @@ class Context:
         check(self.lib.pclhip_ctx_stats(self.h, int(enable), out), self.h)
         names = ("nodes", "leaves_group", "leaves_allpairs", "pushes", "groups", "so_done", "so_list", "so_union")
         return {n: int(out[i]) for i, n in enumerate(names)}
+
+    def counters(self, enable=True):
+        """The same eight counters as a plain list (the per-lane search kernels of lane.hip count in them too: 0 queries,
+        1 done with their own leaf, 2 done in the first pass, 3 greedy descents, 4 finished by the second pass)."""
+        out = (C.c_uint64 * 8)()
+        check(self.lib.pclhip_ctx_stats(self.h, int(enable), out), self.h)
+        return [int(v) for v in out]
 
     def close(self):
         if getattr(self, "h", None):
@@ -246,6 +254,16 @@ class KdTree:
         if len(out):
             check(self.lib.pclhip_index_order(self.h, C.c_void_p(out.ctypes.data)), self.ctx.h)
         return out
+
+    def cells(self, level):
+        """pclhip_index_cells: (boxes [n,6], cells [n,6], top level) of one quad level of the per-lane search structure."""
+        cnt, top = C.c_uint64(0), C.c_int(0)
+        check(self.lib.pclhip_index_cells(self.h, int(level), None, None, 0, C.byref(cnt), C.byref(top)), self.ctx.h)
+        boxes = np.empty((cnt.value, 6), np.float32)
+        cells = np.empty((cnt.value, 6), np.float32)
+        check(self.lib.pclhip_index_cells(self.h, int(level), C.c_void_p(boxes.ctypes.data), C.c_void_p(cells.ctypes.data),
+                                          cnt.value, C.byref(cnt), C.byref(top)), self.ctx.h)
+        return boxes, cells, top.value
 
     def lastKernelMs(self):
         return float(self.lib.pclhip_index_last_kernel_ms(self.h))

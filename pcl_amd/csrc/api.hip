@@ -424,6 +424,7 @@ void preload_code_objects(pclhip_ctx* ctx) {
   preload_voxelgrid_kernels();
   preload_rejector_kernels();
   preload_radius_kernels();
+  preload_lane_kernels();
   (void)hipGetLastError();
 }
 }  // namespace pclhip
@@ -530,14 +531,28 @@ pclhip_status pclhip_ctx_set_option(pclhip_ctx* ctx, const char* name, double va
   if (!std::strcmp(name, "served_groups")) {
     ctx->opt_served_groups = value != 0.0 ? 1 : 0;
   } else if (!std::strcmp(name, "icp_lookahead")) {
-    ctx->opt_lookahead = int(value);
+    ctx->opt_lookahead = value > 62.0 ? 62 : int(value);  // the step ring holds 64 records (icp_loop.hip)
   } else if (!std::strcmp(name, "cache_mb")) {
+    size_t limit = size_t(value) << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipSetDevice(ctx->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && limit > total_b / 4)
+      limit = total_b / 4;  // never hold back more than a quarter of the device's memory (as at creation)
     std::lock_guard<std::mutex> lock(ctx->cache_mutex);
-    ctx->cache_limit = size_t(value) << 20;
+    ctx->cache_limit = limit;
   } else if (!std::strcmp(name, "arena_mb")) {
+    if (ctx->arena_tried) {
+      pclhip::set_error(ctx, "arena_mb: the context's arena exists already (set it before the first large cloud)");
+      return PCLHIP_ERR_STATE;
+    }
     ctx->opt_arena_mb = (long long)value;
+  } else if (!std::strcmp(name, "lane_search")) {
+    ctx->opt_lane_search = value != 0.0 ? 1 : 0;
+  } else if (!std::strcmp(name, "lane_max_up")) {
+    ctx->opt_lane_max_up = value > 15.0 ? 15 : int(value);
+  } else if (!std::strcmp(name, "lane_far")) {
+    ctx->opt_lane_far = float(value);
   } else {
-    pclhip::set_error(ctx, "unknown option (served_groups, icp_lookahead, cache_mb, arena_mb)");
+    pclhip::set_error(ctx, "unknown option (served_groups, icp_lookahead, cache_mb, arena_mb, lane_search, lane_max_up, lane_far)");
     return PCLHIP_ERR_INVALID;
   }
   return PCLHIP_OK;
@@ -708,6 +723,9 @@ void pclhip_index_destroy(pclhip_index* ix) {
   if (ix->rank) (void)dev_free(ix->ctx, ix->rank);
   if (ix->lv_dev) (void)dev_free(ix->ctx, ix->lv_dev);
   if (ix->topcache) (void)dev_free(ix->ctx, ix->topcache);
+  if (ix->qbox) ix->box[1] = nullptr;  // the leaf boxes are the front of qbox
+  if (ix->qbox) (void)dev_free(ix->ctx, ix->qbox);
+  if (ix->qcell) (void)dev_free(ix->ctx, ix->qcell);
   for (int l = 0; l < MAX_LEVELS; ++l)
     if (ix->box[l]) (void)dev_free(ix->ctx, ix->box[l]);
   delete ix;
@@ -740,6 +758,45 @@ pclhip_status pclhip_index_order(pclhip_index* ix, int32_t* out) {
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   if (!dev) PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, d, size_t(ix->n) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLHIP_OK;
+}
+
+pclhip_status pclhip_index_cells(pclhip_index* ix, int level, float* boxes, float* cells, uint64_t capacity, uint64_t* count,
+                                 int* top_level) {
+  if (!ix) return PCLHIP_ERR_INVALID;
+  pclhip_ctx* ctx = ix->ctx;
+  if (ix->qcell == nullptr) {
+    set_error(ctx, "this index carries no per-lane search structure");
+    return PCLHIP_ERR_STATE;
+  }
+  PCLHIP_REQUIRE(ctx, level >= 0 && level <= ix->qtop, "level out of range");
+  PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t nleaf = ix->count[1];
+  size_t off = 0;
+  for (int q = 0; q < level; ++q) off += lane_tree_count(nleaf, q);
+  const uint64_t c = lane_tree_count(nleaf, level);
+  if (count) *count = c;
+  if (top_level) *top_level = ix->qtop;
+  if (capacity < c || (boxes == nullptr && cells == nullptr)) return PCLHIP_OK;
+  std::vector<Box> tmp(c);
+  for (int pass = 0; pass < 2; ++pass) {
+    float* out = pass == 0 ? boxes : cells;
+    if (out == nullptr) continue;
+    if (pass == 1 && level == ix->qtop) {  // the root's cell is all of space (never stored, never read)
+      for (int d = 0; d < 3; ++d) {
+        out[d] = -INFINITY;
+        out[3 + d] = INFINITY;
+      }
+      continue;
+    }
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(tmp.data(), (pass == 0 ? ix->qbox : ix->qcell) + off, c * sizeof(Box),
+                                         hipMemcpyDeviceToHost, ctx->stream));
+    PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint64_t i = 0; i < c; ++i) {
+      out[6 * i + 0] = tmp[i].lo.x; out[6 * i + 1] = tmp[i].lo.y; out[6 * i + 2] = tmp[i].lo.z;
+      out[6 * i + 3] = tmp[i].hi.x; out[6 * i + 4] = tmp[i].hi.y; out[6 * i + 5] = tmp[i].hi.z;
+    }
+  }
   return PCLHIP_OK;
 }
 
@@ -1112,6 +1169,9 @@ static void icp_free_source(pclhip_icp* icp) {
   if (icp->own_block) (void)dev_free(icp->ctx, icp->own_block);
   icp->own_block = nullptr;
   icp->own_groups = 0;
+  if (icp->lane_block) (void)dev_free(icp->ctx, icp->lane_block);
+  icp->lane_block = nullptr;
+  icp->lane_cap = 0;
   if (icp->src_sorted0) (void)dev_free(icp->ctx, icp->src_sorted0);
   if (icp->src_cur) (void)dev_free(icp->ctx, icp->src_cur);
   if (icp->src_nrm_sorted0) (void)dev_free(icp->ctx, icp->src_nrm_sorted0);

@@ -264,6 +264,128 @@ __global__ __launch_bounds__(256) void node_box_kernel(const Box* child, uint32_
   }
 }
 
+
+// ---- the per-lane search structure (pclhip_internal.hpp: LaneTree) ------------------------------------------------
+// boxes of one quad level from the level below: one thread per parent, four consecutive children
+__global__ __launch_bounds__(256) void quad_box_kernel(const Box* __restrict__ child, uint32_t nchild, Box* __restrict__ parent,
+                                                       uint32_t nparent) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nparent) return;
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+#pragma unroll
+  for (uint32_t c = 0; c < 4u; ++c) {
+    if (4u * i + c < nchild) {
+      const Box b = child[4u * i + c];
+      lo[0] = fminf(lo[0], b.lo.x); lo[1] = fminf(lo[1], b.lo.y); lo[2] = fminf(lo[2], b.lo.z);
+      hi[0] = fmaxf(hi[0], b.hi.x); hi[1] = fmaxf(hi[1], b.hi.y); hi[2] = fmaxf(hi[2], b.hi.z);
+    }
+  }
+  Box b;
+  b.lo = make_float4(lo[0], lo[1], lo[2], 0.0f);
+  b.hi = make_float4(hi[0], hi[1], hi[2], 0.0f);
+  parent[i] = b;
+}
+
+struct B3 {
+  float lo[3], hi[3];
+};
+__device__ __forceinline__ bool b3_empty(const B3& b) { return !(b.lo[0] <= b.hi[0]); }
+__device__ __forceinline__ B3 b3_union(const B3& a, const B3& b) {
+  B3 r;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    r.lo[d] = fminf(a.lo[d], b.lo[d]);
+    r.hi[d] = fmaxf(a.hi[d], b.hi[d]);
+  }
+  return r;
+}
+// X lies in front of Y in the kd order.  Both non-empty: an axis along which every point of X is <= every point of Y
+// (the widest gap if several do) puts a face into both cells: X ends where Y's points begin, Y begins where X's points
+// end -- each face is set by the OTHER side's extreme, so that "strictly inside my cell" means "strictly in front of
+// every point of the other side".  No such axis (the order is not the kd partition this structure assumes): both
+// cells are inverted and contain nothing, which sends every query of the two subtrees up to the parent.
+__device__ __forceinline__ void cell_split(const B3& X, const B3& Y, B3& cx, B3& cy) {
+  if (b3_empty(X) || b3_empty(Y)) return;
+  int axis = -1;
+  float gap = -1.0f;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float g = Y.lo[d] - X.hi[d];
+    if (X.hi[d] <= Y.lo[d] && g > gap) {
+      gap = g;
+      axis = d;
+    }
+  }
+  if (axis < 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      cx.lo[d] = cy.lo[d] = INFINITY;
+      cx.hi[d] = cy.hi[d] = -INFINITY;
+    }
+    return;
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (d == axis) {
+      cx.hi[d] = fminf(cx.hi[d], Y.lo[d]);
+      cy.lo[d] = fmaxf(cy.lo[d], X.hi[d]);
+    }
+  }
+}
+// cells of one quad level from the cells of the level above and the boxes of the level itself: one thread per PARENT.
+// The four children are two halves of two (a four-way cut along one axis is the same thing seen as binary cuts).
+__global__ __launch_bounds__(256) void quad_cell_kernel(const Box* __restrict__ pcell, uint32_t nparent, int parent_is_root,
+                                                        const Box* __restrict__ cbox, uint32_t nchild,
+                                                        Box* __restrict__ ccell) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nparent) return;
+  B3 pc;
+  if (parent_is_root) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      pc.lo[d] = -INFINITY;
+      pc.hi[d] = INFINITY;
+    }
+  } else {
+    const Box b = pcell[i];
+    pc.lo[0] = b.lo.x; pc.lo[1] = b.lo.y; pc.lo[2] = b.lo.z;
+    pc.hi[0] = b.hi.x; pc.hi[1] = b.hi.y; pc.hi[2] = b.hi.z;
+  }
+  B3 cb[4], cc[4];
+#pragma unroll
+  for (uint32_t c = 0; c < 4u; ++c) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      cb[c].lo[d] = FLT_MAX;
+      cb[c].hi[d] = -FLT_MAX;
+    }
+    if (4u * i + c < nchild) {
+      const Box b = cbox[4u * i + c];
+      cb[c].lo[0] = b.lo.x; cb[c].lo[1] = b.lo.y; cb[c].lo[2] = b.lo.z;
+      cb[c].hi[0] = b.hi.x; cb[c].hi[1] = b.hi.y; cb[c].hi[2] = b.hi.z;
+    }
+    cc[c] = pc;
+  }
+  {
+    const B3 A = b3_union(cb[0], cb[1]), Bh = b3_union(cb[2], cb[3]);
+    B3 ca = pc, cbh = pc;
+    cell_split(A, Bh, ca, cbh);
+    cc[0] = cc[1] = ca;
+    cc[2] = cc[3] = cbh;
+  }
+  cell_split(cb[0], cb[1], cc[0], cc[1]);
+  cell_split(cb[2], cb[3], cc[2], cc[3]);
+#pragma unroll
+  for (uint32_t c = 0; c < 4u; ++c) {
+    if (4u * i + c < nchild) {
+      Box b;
+      b.lo = make_float4(cc[c].lo[0], cc[c].lo[1], cc[c].lo[2], 0.0f);
+      b.hi = make_float4(cc[c].hi[0], cc[c].hi[1], cc[c].hi[2], 0.0f);
+      ccell[4u * i + c] = b;
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -1516,14 +1638,31 @@ pclhip_status build_boxes(pclhip_index* ix, bool with_discs) {
     size_t bytes;
     ~PinnedGuard() { if (*p) pinned_free(ctx, *p, bytes); }
   } diag_guard{ctx, &diag_part, 3 * DIAG_NB * sizeof(double)};
+  if (ix->qbox) ix->box[1] = nullptr;  // box[1] was the front of qbox
   for (int l = 0; l < MAX_LEVELS; ++l) {
     if (ix->box[l]) (void)dev_free(ctx, ix->box[l]);
     ix->box[l] = nullptr;
     ix->count[l] = 0;
   }
+  if (ix->qbox) (void)dev_free(ctx, ix->qbox);
+  if (ix->qcell) (void)dev_free(ctx, ix->qcell);
+  ix->qbox = ix->qcell = nullptr;
+  ix->qtop = 0;
   ix->count[0] = ix->n;
   uint32_t c = (ix->n + LEAF - 1) / LEAF;
   if (c == 0) c = 1;  // an empty index still has one (empty) leaf so kernels stay uniform
+  // the per-lane search structure of a kd index (LaneTree): every quad level in one array, the leaf boxes in front
+  const bool lane_tree = with_discs;
+  size_t qnodes = 0;
+  if (lane_tree) {
+    int q = 0;
+    for (;; ++q) {
+      const uint32_t cq = lane_tree_count(c, q);
+      qnodes += cq;
+      if (cq == 1) break;
+    }
+    ix->qtop = q;
+  }
   int l = 1;
   for (;;) {
     if (l >= MAX_LEVELS) {
@@ -1531,7 +1670,13 @@ pclhip_status build_boxes(pclhip_index* ix, bool with_discs) {
       return PCLHIP_ERR_INVALID;
     }
     ix->count[l] = c;
-    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->box[l], size_t(c) * sizeof(Box)));
+    if (l == 1 && lane_tree) {
+      PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->qbox, qnodes * sizeof(Box)));
+      PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->qcell, qnodes * sizeof(Box)));
+      ix->box[1] = ix->qbox;
+    } else {
+      PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &ix->box[l], size_t(c) * sizeof(Box)));
+    }
     if (l == 1) {
       const uint32_t threads = c * LEAF;
       if (ix->soa) (void)dev_free(ctx, ix->soa);
@@ -1563,6 +1708,23 @@ pclhip_status build_boxes(pclhip_index* ix, bool with_discs) {
     ++l;
   }
   ix->top = l;
+  if (lane_tree) {  // quad levels bottom-up (boxes), then top-down (cells): ~2 x 13 small launches at 10M points
+    const uint32_t nleaf = ix->count[1];
+    size_t off = 0;
+    for (int q = 1; q <= ix->qtop; ++q) {
+      const uint32_t cc = lane_tree_count(nleaf, q - 1), cp = lane_tree_count(nleaf, q);
+      hipLaunchKernelGGL(quad_box_kernel, dim3((cp + 255) / 256), dim3(256), 0, s, ix->qbox + off, cc, ix->qbox + off + cc, cp);
+      off += cc;
+    }
+    // off = offset of the top level now
+    for (int q = ix->qtop; q >= 1; --q) {
+      const uint32_t cc = lane_tree_count(nleaf, q - 1), cp = lane_tree_count(nleaf, q);
+      const size_t coff = off - cc;
+      hipLaunchKernelGGL(quad_cell_kernel, dim3((cp + 255) / 256), dim3(256), 0, s, ix->qcell + off, cp, q == ix->qtop ? 1 : 0,
+                         ix->qbox + coff, cc, ix->qcell + coff);
+      off = coff;
+    }
+  }
   // contiguous copy of the top levels (as many whole levels as fit TOPCACHE_BOXES, never the leaves)
   {
     uint32_t total = 0;
@@ -1641,6 +1803,15 @@ void preload_index_build_kernels() {
 }
 
 }  // namespace pclhip
+
+pclhip::LaneTree pclhip_index::lane_tree() const {
+  pclhip::LaneTree t;
+  t.qbox = qbox;
+  t.qcell = qcell;
+  t.nleaf = count[1];
+  t.top = qtop;
+  return t;
+}
 
 pclhip::IndexView pclhip_index::view() const {
   pclhip::IndexView v;

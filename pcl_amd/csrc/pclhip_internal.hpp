@@ -72,6 +72,26 @@ struct IndexView {
   uint32_t* sched_ctr;          // the context's group counters, one per XCD, 128 bytes apart (traverse.hpp: GroupFeed)
 };
 
+// The per-lane search structure (lane_search.hpp; round 5): the same kd order seen as an implicit 4-ary tree over the
+// leaves.  Level q holds cnt(q) = ceil(n_leaf / 4^q) nodes, node i of level q covers leaves [i 4^q, (i+1) 4^q); the
+// levels lie one after the other in both arrays (level 0 first), so the offset of level q+1 is that of level q plus
+// cnt(q) and a lane that moves one level at a time keeps it in a register.
+//   qbox   tight AABB of every node (level 0 = the leaf boxes: pclhip_index::box[1] IS the front of this array)
+//   qcell  a CELL of every node: an axis-aligned region (faces at +-inf where nothing bounds it) such that every point
+//          of the index that does NOT belong to the node lies outside its interior (index_build.hip: quad_cell_kernel,
+//          derived from the sibling boxes and checked while it is derived: a node whose siblings are not separated along
+//          an axis gets an inverted cell that contains nothing).  A ball strictly inside the cell of a node therefore
+//          holds no point of any other node: the search of that ball ends inside the node.
+struct LaneTree {
+  const Box* qbox;
+  const Box* qcell;
+  uint32_t nleaf;   // cnt(0)
+  int top;          // the root's level: cnt(top) == 1
+};
+__host__ __device__ inline uint32_t lane_tree_count(uint32_t nleaf, int q) {
+  return uint32_t((uint64_t(nleaf) + ((uint64_t(1) << (2 * q)) - 1u)) >> (2 * q));
+}
+
 // Axis-aligned region [lo, hi) of the rank that owns a query (target sharding, dist.hip): a source point
 // takes part in an iteration only while its CURRENT position lies inside.  Unbounded sides are +-inf.
 struct RegionBox {
@@ -179,6 +199,9 @@ struct pclhip_ctx {
   int opt_served_groups = 1;            // target sharding: the device-driven loop walks the served groups only
   int opt_lookahead = 1;                // pclhip_icp_align: iterations queued ahead of the host's knowledge
   long long opt_arena_mb = -1;          // automatic arena: -1 = 288 B per point of the first large cloud, 0 = none
+  int opt_lane_search = 1;              // seeded ICP launches one lane per query (lane.hip); 0 = the wave-cooperative body
+  int opt_lane_max_up = 2;              // ... quad levels the first pass climbs before it hands a query to the second
+  float opt_lane_far = 0.25f;           // ... a seed beyond this many mean leaf diagonals (squared) is replaced by a descent
   std::mutex cache_mutex;
   // Small pinned host blocks (control blocks, step rings, mirrored states of the registrations) are kept for the
   // context's lifetime: hipHostFree synchronises the device (170 us each, three per registration object).
@@ -206,6 +229,11 @@ struct pclhip_index {
   float disc_thickness = 1.0f;  // sum of the discs' half thicknesses / sum of their radii: how thin the leaves are
   uint32_t* rank = nullptr;
   pclhip::Box* box[pclhip::MAX_LEVELS] = {};
+  // per-lane search structure (LaneTree above): box[1] is the front of qbox when it exists
+  pclhip::Box* qbox = nullptr;
+  pclhip::Box* qcell = nullptr;
+  int qtop = 0;
+  pclhip::LaneTree lane_tree() const;
   pclhip::LevelInfo* lv_dev = nullptr;
   pclhip::Box* topcache = nullptr;
   uint32_t cache_off[pclhip::MAX_LEVELS] = {};
@@ -288,6 +316,13 @@ struct pclhip_icp {
   uint32_t* own_tot = nullptr;           // [4] tot[0] = served groups
   uint2* own_partial = nullptr;          // scan scratch
   pclhip::OwnedState* own_state = nullptr;
+  // per-lane seeded search (lane.hip): masks, block counts, the list of given-up queries and its length -- one device block
+  void* lane_block = nullptr;
+  uint32_t lane_cap = 0;
+  unsigned long long* lane_mask = nullptr;
+  uint32_t* lane_bcount = nullptr;
+  uint32_t* lane_queue = nullptr;
+  uint32_t* lane_tot = nullptr;
 };
 
 namespace pclhip {
@@ -315,6 +350,11 @@ void preload_index_build_kernels();
 void preload_voxelgrid_kernels();
 void preload_rejector_kernels();
 void preload_radius_kernels();
+void preload_lane_kernels();
+// lane.hip: the seeded search launches of an iteration, one lane per query (needs the target's LaneTree)
+bool lane_search_available(const pclhip_icp* icp);
+pclhip_status launch_lane_search(pclhip_icp* icp, const float T12[12], const pclhip::IcpControl* ctl, int order, float bound,
+                                 bool use_max);
 template <class T>
 inline hipError_t dev_malloc(pclhip_ctx* ctx, T** p, size_t bytes) {
   return dev_malloc(ctx, reinterpret_cast<void**>(p), bytes);
@@ -382,6 +422,8 @@ pclhip_status spatial_order(pclhip_ctx* ctx, const void* dev_points, size_t stri
                             const int32_t* dev_sel, uint64_t n_sel, float4* out_sorted, uint32_t out_capacity,
                             uint32_t* out_n_finite, float lo[3], float hi[3], bool keep_nonfinite_at_end,
                             uint32_t* rank_or_null, const float* scale = nullptr);
+// with_discs also says "a kd index of its own points" (not the borrowed, refitted index of the reciprocal test): only such
+// an index gets the per-lane search structure (cells need the kd partition)
 pclhip_status build_boxes(pclhip_index* ix, bool with_discs = true);
 pclhip_status build_index_over(pclhip_ctx* ctx, float4* pts_in_kd_order, uint32_t n_finite, uint32_t n_orig, pclhip_index** out);
 // shard_dev.hip: partition / halo selection of a cloud in device memory (shard.cpp's results, bit for bit)

@@ -16,6 +16,7 @@
 #include "standoff.hpp"
 #include "normals_math.hpp"
 #include "device_scan.hpp"
+#include "icp_xform.hpp"
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -747,18 +748,7 @@ pclhip_status launch_gicp_covariances(pclhip_index* ix, int k, double eps, doubl
 // =================================================================================================
 // ICP iteration
 // =================================================================================================
-struct Mat34 {
-  float m[12];  // rows 0..2 of the 4x4
-};
-
-// order 0: Eigen Matrix4f * Vector4f (registration/include/pcl/registration/impl/icp.hpp:49-111)
-// order 1: Transformer<float>::se3 (common/include/pcl/common/impl/transforms.hpp:117-123)
-__device__ __forceinline__ float xform_row(float r0, float r1, float r2, float r3, float x, float y, float z,
-                                           int order) {
-  if (order == 0)
-    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r0, x), __fmul_rn(r1, y)), __fmul_rn(r2, z)), __fmul_rn(r3, 1.0f));
-  return __fadd_rn(__fmul_rn(r0, x), __fadd_rn(__fmul_rn(r1, y), __fadd_rn(__fmul_rn(r2, z), r3)));
-}
+// Mat34, xform_row, in_region: icp_xform.hpp (shared with the per-lane search of lane.hip)
 
 constexpr int NS = PCLHIP_ICP_NSUMS;
 
@@ -770,9 +760,6 @@ constexpr int NS = PCLHIP_ICP_NSUMS;
 // flag come from device memory, written by the icp_solve_kernel of the previous iteration: iterations are
 // queued back to back and the host never sits between them.  A starting alignment reads the pristine
 // source `src0` instead of the working copy and has no seeds, so no reset copy is needed either.
-__device__ __forceinline__ bool in_region(const RegionBox& r, float x, float y, float z) {
-  return x >= r.lo[0] && x < r.hi[0] && y >= r.lo[1] && y < r.hi[1] && z >= r.lo[2] && z < r.hi[2];
-}
 
 // no policy of the ICP search kernels stages the w chunks: 3 KB of staging per wave (see WaveLdsT)
 typedef WaveLdsT<3072> IcpWaveLds;
@@ -804,6 +791,7 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
   if (ctl != nullptr) {
     if (ctl->stop != 0) return;  // the alignment ended before this (speculatively queued) launch
     restart = ctl->restart != 0;
+    if ((flags & 4) != 0 && !restart) return;  // SEARCH_RESTART_ONLY: the seeded launches are lane.hip's
 #pragma unroll
     for (int i = 0; i < 12; ++i) T.m[i] = ctl->T_apply[i];
   }
@@ -1149,6 +1137,8 @@ __global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_search_dual_kerne
   if (ctl->restart != 0)
     icp_cold_search_body(ix, cur, src0, ns, T, ctl, region, order, bound, flags, so_from, match_pos, match, match_d2, gstats,
                          wl_s, topbox_s);
+  else if ((flags & 4) != 0)
+    return;  // SEARCH_RESTART_ONLY
   else
     icp_search_body<1, true>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
                              topbox_s);
@@ -1827,6 +1817,8 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(IcpControl* __restrict__ 
 
 // flags of the search kernels: 1 a finite maximum distance is set, 2 seeded descents may start below the root
 constexpr int SEARCH_SKIP_FLAG = 2;  // seeded descents may start below the root (traverse(): start_leaf)
+constexpr int SEARCH_RESTART_ONLY = 4;  // device-driven loop with the per-lane search (lane.hip): this launch only serves the
+                                        // iteration that STARTS an alignment and falls through otherwise
 
 template <int MODE>
 static void launch_accumulate(pclhip_icp* icp, const IndexView& v, int ga, const uint8_t* keep, const Mat34& M,
@@ -1924,8 +1916,9 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     const bool standoff = v.disc != nullptr && icp->target->disc_thickness < SO_THICKNESS &&
                           size_t(icp->target->n_pad) * 56u <= SO_MAX_INDEX_BYTES;
     const bool cold = standoff && !device_loop && icp->seeds_cleared;
+    const bool host_restart = !device_loop && icp->seeds_cleared;
     icp->seeds_cleared = false;
-    const int kflags = (use_max ? 1 : 0) | SEARCH_SKIP_FLAG;
+    int kflags = (use_max ? 1 : 0) | SEARCH_SKIP_FLAG;
     // wave radii (squared) up to so_from stay with traverse(): the groups that sit on the surface
     const float so_from = icp->target->leaf_diag2;
     // target sharding in the device-driven loop: list the groups this rank serves in this launch, walk the list
@@ -1941,8 +1934,17 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
       og.stamp = icp->own_stamp;
       og.state = icp->own_state;
     }
+    // Seeded launches one lane per query (lane.hip) wherever the target carries the structure for it: in the device-driven
+    // loop the kernels of this file then only serve the launch that starts an alignment (SEARCH_RESTART_ONLY) and the
+    // lane kernels every other one -- each falls through in the other's case, the control block decides on the device;
+    // the host-driven loop knows which launch it is.
+    const bool lane = !owned && lane_search_available(icp);
+    const bool lane_now = lane && (device_loop || !host_restart);
+    if (lane && device_loop) kflags |= SEARCH_RESTART_ONLY;
     (void)hipEventRecord(device_loop ? ev[0] : icp->ev0, s);
-    if (owned) {
+    if (lane_now && !device_loop) {
+      // nothing of this file
+    } else if (owned) {
       hipLaunchKernelGGL(icp_own_flag_kernel, dim3((ngroups + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, ctl, icp->own_state,
                          icp->own_gbox, icp->region, ngroups, icp->n, icp->own_stamp, icp->own_flags, icp->own_prefix, icp->match,
                          icp->match_pos, icp->match_d2);
@@ -1965,6 +1967,10 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     } else {
       PCLHIP_LAUNCH_FED(ctx, ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl, icp->region,
                          order, bound, kflags, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+    }
+    if (lane_now) {
+      const pclhip_status lst = launch_lane_search(icp, M.m, ctl, order, bound, use_max);
+      if (lst != PCLHIP_OK) return lst;
     }
     (void)hipEventRecord(device_loop ? ev[1] : icp->ev_mid, s);
     icp->mid_recorded = true;

@@ -329,13 +329,23 @@ struct NN1 {
   const float* soa = nullptr;  // IndexView::soa
   __device__ __forceinline__ void leaf_lane(const float* buf, uint32_t slot, uint32_t leaf_id, const float* qx,
                                             const float* qy, const float* qz) {
+    leaf_at<16>(reinterpret_cast<const float4*>(buf) + slot, leaf_id, qx, qy, qz);  // chunk c at s[c * 16]
+  }
+  // the same straight from the index's SoA copy (chunk c at s[c]): the per-lane search (lane_search.hpp)
+  __device__ __forceinline__ void leaf_global(const float* soa_, uint32_t leaf_id, const float* qx, const float* qy,
+                                              const float* qz) {
+    leaf_at<1>(reinterpret_cast<const float4*>(soa_ + size_t(leaf_id != NO_INDEX ? leaf_id : 0u) * LEAF_FLOATS), leaf_id, qx, qy,
+               qz);
+  }
+  template <int STRIDE>
+  __device__ __forceinline__ void leaf_at(const float4* s, uint32_t leaf_id, const float* qx, const float* qy,
+                                          const float* qz) {
     if (leaf_id != NO_INDEX) {
-      const float4* s = reinterpret_cast<const float4*>(buf) + slot;  // chunk c at s[c * 16]
       const float4* wsrc = reinterpret_cast<const float4*>(soa + size_t(leaf_id) * LEAF_FLOATS + 3 * LEAF);
       const uint32_t base = leaf_id * LEAF;
 #pragma unroll
       for (int c4 = 0; c4 < LEAF / 4; ++c4) {
-        const float4 X = s[c4 * 16], Y = s[(4 + c4) * 16], Z = s[(8 + c4) * 16], W = wsrc[c4];
+        const float4 X = s[c4 * STRIDE], Y = s[(4 + c4) * STRIDE], Z = s[(8 + c4) * STRIDE], W = wsrc[c4];
         const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w},
                     ws[4] = {W.x, W.y, W.z, W.w};
 #pragma unroll
@@ -469,11 +479,14 @@ struct NN1MinT {
   }
   // after the traversal: find the winning slot inside the winning leaf (same arithmetic, same bits)
   __device__ __forceinline__ void resolve(const IndexView& ix, const float* qx, const float* qy, const float* qz) {
+    resolve(ix.soa, qx, qy, qz);
+  }
+  __device__ __forceinline__ void resolve(const float* __restrict__ soa, const float* qx, const float* qy, const float* qz) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       if (__builtin_amdgcn_ballot_w64(unres[q]) == 0) continue;
       if (unres[q]) {
-        const float4* s = reinterpret_cast<const float4*>(ix.soa + size_t(bestpos[q] / LEAF) * LEAF_FLOATS);
+        const float4* s = reinterpret_cast<const float4*>(soa + size_t(bestpos[q] / LEAF) * LEAF_FLOATS);
         uint32_t hit = 0;
         // the 16 distances on packed v_pk_* math, exactly as the evaluation computed them (scalar: +0.7 % per converged iteration)
         const v2f qx2 = {qx[q], qx[q]}, qy2 = {qy[q], qy[q]}, qz2 = {qz[q], qz[q]};

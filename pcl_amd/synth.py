@@ -153,3 +153,61 @@ def apply_rigid_device(T, pts):
         out[b:b + step, :3] = (p @ Tt[:3, :3].T + Tt[:3, 3]).float()
     out[:, 3] = 1.0
     return out
+
+
+# ---- cloud families beyond the bench's sheet (round 5): the geometry a search structure is NOT tuned on -----------------
+# Same counter-based RNG, so every family is reproducible and shardable.  `kind`:
+#   sheet     the Gaussian surface above (2.5-D)
+#   cube      uniform in [-1, 1]^3 (volumetric, like the random clouds of test/search/test_search.cpp:292-364)
+#   layers    two copies of the surface, the second lifted by three point spacings (a query between them has near
+#             neighbours on both: leaf boxes of the two layers interleave in z)
+#   clusters  half of the points spread over the surface, half packed into ten discs that cover 1 % of the area
+#             (density contrast 100x: leaves of very different size next to each other)
+FAMILIES = ("sheet", "cube", "layers", "clusters")
+_CLUSTER_CENTRES = np.array([(-.7, -.6), (-.2, .7), (.5, .5), (.8, -.3), (0., 0.), (-.5, .1), (.3, -.7), (.65, .85), (-.85, .8),
+                             (.1, .35)], np.float64)
+
+
+def family_cloud(kind, n, seed=TARGET_SEED, start=0, noise=1e-4):
+    """(n, 4) float32 cloud of family `kind` -- points [start, start+n) of the stream for `seed`."""
+    if kind == "sheet":
+        return gaussian_surface(n, seed, start, noise)
+    i = np.arange(start, start + n, dtype=np.uint64)
+    out = np.ones((n, 4), np.float32)
+    if kind == "cube":
+        for c in range(3):
+            out[:, c] = np.float32(2.0) * _u01(seed, i, c) - np.float32(1.0)
+        return out
+    base = gaussian_surface(n, seed, start, noise)
+    if kind == "layers":
+        gap = 3.0 * 2.0 / np.sqrt(max(n, 2) / 2.0)
+        upper = (i & np.uint64(1)).astype(bool)
+        base[upper, 2] += np.float32(gap)
+        return base
+    if kind == "clusters":
+        # every second point is re-drawn inside one of ten discs of radius r, 10 pi r^2 = 1 % of the 4 units of area
+        r = np.sqrt(0.04 / (10.0 * np.pi))
+        packed = (i & np.uint64(1)).astype(bool)
+        which = ((i >> np.uint64(1)) % np.uint64(10)).astype(np.int64)
+        u = _u01(seed ^ 0x5151, i, 0).astype(np.float64)
+        v = _u01(seed ^ 0x5151, i, 1).astype(np.float64)
+        rad = r * np.sqrt(u)
+        x = _CLUSTER_CENTRES[which, 0] + rad * np.cos(2.0 * np.pi * v)
+        y = _CLUSTER_CENTRES[which, 1] + rad * np.sin(2.0 * np.pi * v)
+        u1 = _u01(seed ^ 0x5151, i, 2).astype(np.float64) + 2.0 ** -25
+        u2 = _u01(seed ^ 0x5151, i, 3).astype(np.float64)
+        g = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+        z = surface_height(x, y) + noise * g
+        base[packed, 0] = x[packed].astype(np.float32)
+        base[packed, 1] = y[packed].astype(np.float32)
+        base[packed, 2] = z[packed].astype(np.float32)
+        return base
+    raise ValueError("unknown cloud family %r" % (kind,))
+
+
+def family_pair(kind, n, n_target=None):
+    """(target, source, T_gt) of family `kind`: the source is an independent resample moved by T_gt^-1 (icp_pair's recipe)."""
+    tgt = family_cloud(kind, n_target if n_target is not None else n, TARGET_SEED)
+    src = family_cloud(kind, n, SOURCE_SEED)
+    T = ground_truth_transform()
+    return tgt, apply_rigid(np.linalg.inv(T), src), T
