@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--rejectors", default="", help="comma list of median,trimmed,one_to_one,distance: the rejector chain "
                                                      "inside the device-driven loop (configs 2/3)")
     ap.add_argument("--reciprocal", action="store_true", help="reciprocal correspondences inside the device-driven loop")
+    ap.add_argument("--cloud", default="sheet", choices=["sheet", "cube", "layers", "clusters"],
+                    help="cloud family of configs 2/3 (pcl_amd/synth.py: family_cloud); the metric's config is the sheet")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="pclhip_ctx_set_option before anything is built (A/B runs: lane_search=0, lane_max_up=1, ...)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-align", action="store_true", help="skip the host-boundary timing (examples/bench_pcl_align.cpp)")
     return ap.parse_args()
@@ -110,6 +114,9 @@ def main():
     mode = 0 if cfg == 2 else 1
     n = args.points or {2: 1 << 20, 3: 10_000_000, 4: 10_000_000, 5: 100_000_000}[cfg]
     ctx = pcl_amd.Context(local_rank)      # its own stream; collectives are issued on it from C
+    for kv in args.opt:
+        name, _, value = kv.partition("=")
+        ctx.setOption(name, float(value))
 
     def fence():
         ctx.synchronize()
@@ -134,9 +141,9 @@ def main():
 
     # ---- synthetic clouds; target identical on every rank, source = this rank's slab
     t0 = time.perf_counter()
-    tgt_h = synth.gaussian_surface(n, synth.TARGET_SEED)
+    tgt_h = synth.family_cloud(args.cloud, n, synth.TARGET_SEED)
     src_h = synth.apply_rigid(np.linalg.inv(synth.ground_truth_transform()),
-                              synth.gaussian_surface(n, synth.SOURCE_SEED, start=rank * n))
+                              synth.family_cloud(args.cloud, n, synth.SOURCE_SEED, start=rank * n))
     gen_s = time.perf_counter() - t0
     tgt = torch.from_numpy(tgt_h).cuda()
     src = torch.from_numpy(src_h).cuda()
@@ -255,8 +262,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 search / f64 accumulate", "data": "synthetic",
-            "config": {"workload": "%s; %d-point synthetic Gaussian-surface source per GPU vs %d-point target, 1-NN "
-                                   "correspondences, max_dist 0.1" % (name, n, n),
+            "config": {"workload": "%s; %d-point synthetic %s source per GPU vs %d-point target, 1-NN "
+                                   "correspondences, max_dist 0.1" % (name, n, {"sheet": "Gaussian-surface"}.get(args.cloud, args.cloud), n),
+                       "cloud": args.cloud, "options": args.opt or None,
                        "baseline_metric": "ICP correspondences/sec/GPU + ms/iteration, 10M-pt cloud; HBM GB/s vs roofline "
                                           "(BASELINE.json; `value` is the whole-job aggregate, ms/iteration = ms_per_step, "
                                           "HBM GB/s = roofline.achieved)",

@@ -547,12 +547,16 @@ pclhip_status pclhip_ctx_set_option(pclhip_ctx* ctx, const char* name, double va
     ctx->opt_arena_mb = (long long)value;
   } else if (!std::strcmp(name, "lane_search")) {
     ctx->opt_lane_search = value != 0.0 ? 1 : 0;
+  } else if (!std::strcmp(name, "cell_start")) {
+    ctx->opt_cell_start = value != 0.0 ? 1 : 0;
+  } else if (!std::strcmp(name, "reseed")) {
+    ctx->opt_reseed = value != 0.0 ? 1 : 0;
   } else if (!std::strcmp(name, "lane_max_up")) {
     ctx->opt_lane_max_up = value > 15.0 ? 15 : int(value);
   } else if (!std::strcmp(name, "lane_far")) {
     ctx->opt_lane_far = float(value);
   } else {
-    pclhip::set_error(ctx, "unknown option (served_groups, icp_lookahead, cache_mb, arena_mb, lane_search, lane_max_up, lane_far)");
+    pclhip::set_error(ctx, "unknown option (served_groups, icp_lookahead, cache_mb, arena_mb, cell_start, reseed, lane_search, lane_max_up, lane_far)");
     return PCLHIP_ERR_INVALID;
   }
   return PCLHIP_OK;

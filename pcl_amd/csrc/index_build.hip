@@ -1833,5 +1833,14 @@ pclhip::IndexView pclhip_index::view() const {
   v.n = n;
   v.n_pad = n_pad;
   v.sched_ctr = ctx->sched_ctr;
+  v.cell2 = v.cell3 = nullptr;
+  if (qcell != nullptr && ctx->opt_cell_start != 0) {
+    size_t off = 0;
+    for (int q = 0; q <= qtop; ++q) {
+      if (q == 3 && q < qtop) v.cell2 = qcell + off;   // (the root's cell is never stored)
+      if (q == 6 && q < qtop) v.cell3 = qcell + off;
+      off += pclhip::lane_tree_count(count[1], q);
+    }
+  }
   return v;
 }

@@ -70,6 +70,11 @@ struct IndexView {
   uint32_t n;                   // finite points
   uint32_t n_pad;
   uint32_t* sched_ctr;          // the context's group counters, one per XCD, 128 bytes apart (traverse.hpp: GroupFeed)
+  // kd CELLS of the level-2 / level-3 nodes (LaneTree::qcell at quad levels 3 and 6; nullptr: none): a node's tight box
+  // lies inside its cell, so the start-level test of traverse() passes on the cell wherever it passed on the box -- and
+  // also where the box is thin (a flat piece of a surface: the box is as thick as the noise, the cell is unbounded)
+  const Box* cell2;
+  const Box* cell3;
 };
 
 // The per-lane search structure (lane_search.hpp; round 5): the same kd order seen as an implicit 4-ary tree over the
@@ -199,7 +204,10 @@ struct pclhip_ctx {
   int opt_served_groups = 1;            // target sharding: the device-driven loop walks the served groups only
   int opt_lookahead = 1;                // pclhip_icp_align: iterations queued ahead of the host's knowledge
   long long opt_arena_mb = -1;          // automatic arena: -1 = 288 B per point of the first large cloud, 0 = none
-  int opt_lane_search = 1;              // seeded ICP launches one lane per query (lane.hip); 0 = the wave-cooperative body
+  int opt_lane_search = 0;              // 1: seeded ICP launches one lane per query (lane.hip) -- exact, measured 2.5x SLOWER than the
+                                        // wave-cooperative body at 10M points (profiles/r05_lane_search_ab.txt): kept as a tested option
+  int opt_cell_start = 1;               // start-level test of the seeded descents on kd cells instead of tight boxes (A/B)
+  int opt_reseed = 1;                   // seeded search: one fresh seed for a group whose seeds are all far (A/B)
   int opt_lane_max_up = 2;              // ... quad levels the first pass climbs before it hands a query to the second
   float opt_lane_far = 0.25f;           // ... a seed beyond this many mean leaf diagonals (squared) is replaced by a descent
   std::mutex cache_mutex;

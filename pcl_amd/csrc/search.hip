@@ -914,6 +914,33 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
     uint32_t start_leaf = NO_INDEX;
     const uint64_t hm = __builtin_amdgcn_ballot_w64(valid[0] && seed_pos[0] != NO_INDEX);
     if ((flags & 2) && hm != 0) start_leaf = uint32_t(__builtin_amdgcn_readlane(int(seed_pos[0]), __builtin_ctzll(hm))) / LEAF;
+    // Every seed of the group is far from its query -- the second iteration of an alignment, whose first transform slid
+    // the queries tens of point spacings along the surface: one fresh seed for the group (a point next to its centre,
+    // found by one greedy walk of the wave) gives every lane a radius of a few spacings instead of tens.
+    if constexpr (Q == 1 && !OWNED) {
+      if ((flags & 8) != 0 && hm != 0 && ix.disc != nullptr) {  // SEARCH_RESEED
+        const float INF = __builtin_inff(), BIG = 3.402823466e+38f;
+        const float near = wave_min_f((valid[0] && seed_pos[0] != NO_INDEX) ? fast.best[0] : INF);
+        if (near > ix.disc_from) {
+          float lx = valid[0] ? qx[0] : BIG, ly = valid[0] ? qy[0] : BIG, lz = valid[0] ? qz[0] : BIG;
+          float hx = valid[0] ? qx[0] : -BIG, hy = valid[0] ? qy[0] : -BIG, hz = valid[0] ? qz[0] : -BIG, dummy = 0.0f;
+          wave_min3_max4(lx, ly, lz, hx, hy, hz, dummy);
+          const uint32_t gp = wave_greedy_point(ix, 0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz), topbox_s, ts);
+          if (gp != NO_INDEX) {
+            const float4 t = ix.pts[gp];  // wave-uniform address
+            if (valid[0]) {
+              const float d = l2_simple(qx[0], qy[0], qz[0], t.x, t.y, t.z);
+              if (d < fast.best[0]) {
+                fast.seed(0, d, gp);
+                seed_pos[0] = gp;   // (the winner's original index is read again below unless this seed wins: t0 is stale)
+                t0[0] = t;
+              }
+            }
+            if (flags & 2) start_leaf = gp / LEAF;
+          }
+        }
+      }
+    }
     // no lane has a seed: the first iteration of an alignment, queries stand off the target -> disc bounds
     ICP_LAP(5);
     traverse<NN1MinT<Q>, SPARSE>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, start_leaf, hm == 0);
@@ -1817,6 +1844,7 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(IcpControl* __restrict__ 
 
 // flags of the search kernels: 1 a finite maximum distance is set, 2 seeded descents may start below the root
 constexpr int SEARCH_SKIP_FLAG = 2;  // seeded descents may start below the root (traverse(): start_leaf)
+constexpr int SEARCH_RESEED = 8;  // a group whose seeds are all far gets one fresh seed from a greedy walk (icp_search_body)
 constexpr int SEARCH_RESTART_ONLY = 4;  // device-driven loop with the per-lane search (lane.hip): this launch only serves the
                                         // iteration that STARTS an alignment and falls through otherwise
 
@@ -1918,7 +1946,7 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     const bool cold = standoff && !device_loop && icp->seeds_cleared;
     const bool host_restart = !device_loop && icp->seeds_cleared;
     icp->seeds_cleared = false;
-    int kflags = (use_max ? 1 : 0) | SEARCH_SKIP_FLAG;
+    int kflags = (use_max ? 1 : 0) | SEARCH_SKIP_FLAG | (ctx->opt_reseed != 0 ? SEARCH_RESEED : 0);
     // wave radii (squared) up to so_from stay with traverse(): the groups that sit on the surface
     const float so_from = icp->target->leaf_diag2;
     // target sharding in the device-driven loop: list the groups this rank serves in this launch, walk the list

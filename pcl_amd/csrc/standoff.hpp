@@ -232,6 +232,53 @@ __device__ __forceinline__ void so_stage8(const IndexView& ix, float* dst, uint3
   }
 }
 
+// One target point near (Cx, Cy, Cz), found by the whole wave: DOWN the hierarchy once, at every level into the child whose
+// box is nearest (no ranking, no stack: 4 scans at 10M points), then the nearest of that leaf's 16 points.  Any point of the
+// index is a valid seed -- it only gives the lanes a radius, the search that follows is exact whatever it is.  Used by the
+// stand-off search for groups without a predecessor, and by the seeded search when every seed of a group is far away (the
+// second iteration of an alignment slides the queries tens of point spacings along the surface).  All 64 lanes call it.
+__device__ __forceinline__ uint32_t wave_greedy_point(const IndexView& ix, float Cx, float Cy, float Cz, const Box* topbox,
+                                                      TraverseStats& ts) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const float INF = __builtin_inff();
+  uint32_t seed_pos = NO_INDEX;
+  uint32_t level = uint32_t(ix.top) + 1u, node = 0u;
+  while (level > 1u) {
+    const uint32_t cl = level - 1u, first = node * FANOUT;
+    const Box* level_box = ix.box[1];
+    uint32_t total = ix.count[1], coff = 0;
+#pragma unroll
+    for (int l = 2; l < MAX_LEVELS; ++l) {
+      if (cl == uint32_t(l)) {
+        level_box = ix.box[l];
+        total = ix.count[l];
+        coff = ix.cache_off[l];
+      }
+    }
+    const uint32_t nchild = (total - first) < uint32_t(FANOUT) ? (total - first) : uint32_t(FANOUT);
+    const bool has = uint32_t(lane) < nchild;
+    float lb = INF;
+    if (has) {
+      const Box b = (int(cl) >= ix.cache_from) ? topbox[coff + first + lane] : level_box[first + lane];
+      lb = point_box_lb(Cx, Cy, Cz, b.lo.x, b.lo.y, b.lo.z, b.hi.x, b.hi.y, b.hi.z);
+    }
+    const float m = wave_min_f(lb);
+    const uint64_t at = __builtin_amdgcn_ballot_w64(has && lb == m);
+    node = first + uint32_t(at != 0 ? __builtin_ctzll(at) : 0);
+    level = cl;
+    SO_COUNT(++ts.c[0]);
+  }
+  float d = INF;
+  if (lane < LEAF) {
+    const float4 t = ix.pts[size_t(node) * LEAF + lane];
+    d = l2_simple(Cx, Cy, Cz, t.x, t.y, t.z);  // pad slots hold FLT_MAX sentinels: +inf
+  }
+  const float m = wave_min_f(d);
+  const uint64_t at = __builtin_amdgcn_ballot_w64(lane < LEAF && d == m && d < INF);
+  if (at != 0) seed_pos = node * LEAF + uint32_t(__builtin_ctzll(at));
+  return seed_pos;
+}
+
 // Where the seed comes from: the previous group of this wave (every lane's query as searched and its match), and a
 // history of one (query, match) pair of each of the wave's last 64 groups, one per lane -- consecutive groups of the
 // kd order are usually neighbours, but a quarter of the steps jump, and then an older group is the nearer one.
@@ -351,40 +398,7 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
       // group's own search, for one group in four) the wave walks DOWN the hierarchy once, at every level into the child
       // whose box is nearest to the group's centre (4 scans without ranking at 10M points), and takes that leaf's point
       // nearest to the centre.  (Round 4, 10M points: cold launch 2.00 -> 1.80 ms.)
-      uint32_t level = uint32_t(ix.top) + 1u, node = 0u;
-      while (level > 1u) {
-        const uint32_t cl = level - 1u, first = node * FANOUT;
-        const Box* level_box = ix.box[1];
-        uint32_t total = ix.count[1], coff = 0;
-#pragma unroll
-        for (int l = 2; l < MAX_LEVELS; ++l) {
-          if (cl == uint32_t(l)) {
-            level_box = ix.box[l];
-            total = ix.count[l];
-            coff = ix.cache_off[l];
-          }
-        }
-        const uint32_t nchild = (total - first) < uint32_t(FANOUT) ? (total - first) : uint32_t(FANOUT);
-        const bool has = uint32_t(lane) < nchild;
-        float lb = INF;
-        if (has) {
-          const Box b = (int(cl) >= ix.cache_from) ? topbox[coff + first + lane] : level_box[first + lane];
-          lb = point_box_lb(Cx, Cy, Cz, b.lo.x, b.lo.y, b.lo.z, b.hi.x, b.hi.y, b.hi.z);
-        }
-        const float m = wave_min_f(lb);
-        const uint64_t at = __builtin_amdgcn_ballot_w64(has && lb == m);
-        node = first + uint32_t(at != 0 ? __builtin_ctzll(at) : 0);
-        level = cl;
-        SO_COUNT(++ts.c[0]);
-      }
-      float d = INF;
-      if (lane < LEAF) {
-        const float4 t = ix.pts[size_t(node) * LEAF + lane];
-        d = l2_simple(Cx, Cy, Cz, t.x, t.y, t.z);  // pad slots hold FLT_MAX sentinels: +inf
-      }
-      const float m = wave_min_f(d);
-      const uint64_t at = __builtin_amdgcn_ballot_w64(lane < LEAF && d == m && d < INF);
-      if (at != 0) seed_pos = node * LEAF + uint32_t(__builtin_ctzll(at));
+      seed_pos = wave_greedy_point(ix, Cx, Cy, Cz, topbox, ts);
     }
     if (seed_pos == NO_INDEX) {
       // no previous group (first of the wave's chunk) or none with a match: the exact neighbour of ONE lane
@@ -441,8 +455,8 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
       };
       const bool has2 = ix.top >= 2, has3 = ix.top >= 3;
       Box b2 = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)}, b3 = b2;
-      if (has2) b2 = ix.box[2][seed_leaf_out >> 6];
-      if (has3) b3 = ix.box[3][seed_leaf_out >> 12];
+      if (has2) b2 = ix.cell2 != nullptr ? ix.cell2[seed_leaf_out >> 6] : ix.box[2][seed_leaf_out >> 6];
+      if (has3) b3 = ix.cell3 != nullptr ? ix.cell3[seed_leaf_out >> 12] : ix.box[3][seed_leaf_out >> 12];
       if (has2 && inside(b2)) {
         level = 2u;
         node0 = seed_leaf_out >> 6;

@@ -995,8 +995,9 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
     };
     const bool has2 = ix.top >= 2, has3 = ix.top >= 3;
     Box b2 = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)}, b3 = b2;
-    if (has2) b2 = ix.box[2][start_leaf >> 6];   // wave-uniform addresses: both loads are in flight together
-    if (has3) b3 = ix.box[3][start_leaf >> 12];
+    // (the node's kd cell where the index carries cells: the box lies inside it, see IndexView::cell2)
+    if (has2) b2 = ix.cell2 != nullptr ? ix.cell2[start_leaf >> 6] : ix.box[2][start_leaf >> 6];   // wave-uniform addresses: both loads are in flight together
+    if (has3) b3 = ix.cell3 != nullptr ? ix.cell3[start_leaf >> 12] : ix.box[3][start_leaf >> 12];
     if (has2 && inside(b2)) {
       level = 2u;
       node = start_leaf >> 6;

@@ -25,6 +25,17 @@ def gpu():
     return pcl_amd.Context(0)
 
 
+@pytest.fixture
+def lane(gpu):
+    """the per-lane search is an OPTION of the context (off by default since its first measurement: exact, but 2.5x slower
+    than the wave-cooperative body at 10M points -- profiles/r05_lane_search_ab.txt); these tests switch it on"""
+    gpu.setOption("lane_search", 1)
+    yield gpu
+    gpu.setOption("lane_search", 0)
+    gpu.setOption("lane_max_up", 2)
+    gpu.setOption("lane_far", 0.25)
+
+
 @pytest.fixture(scope="module")
 def orc():
     from oracle import pcl_oracle
@@ -137,7 +148,8 @@ STEPS = [np.eye(4, dtype=np.float32),                       # cold launch
 
 @pytest.mark.parametrize("kind,n", [("sheet", 30_000), ("cube", 20_000), ("layers", 30_000), ("clusters", 30_000), ("far", 8_000)])
 @pytest.mark.parametrize("max_up,far", [(2, 0.25), (0, 0.25), (15, 0.25), (1, 0.0), (2, 1e9)])
-def test_seeded_launches_equal_the_oracle(gpu, orc, kind, n, max_up, far):
+def test_seeded_launches_equal_the_oracle(lane, orc, kind, n, max_up, far):
+    gpu = lane
     tgt = make_cloud(kind, n, 1001)
     src = make_cloud(kind, n // 2 + 3, 2002)
     src[::97, 0] = np.nan                                     # non-finite queries travel unchanged and match nothing
@@ -152,7 +164,8 @@ def test_seeded_launches_equal_the_oracle(gpu, orc, kind, n, max_up, far):
 
 
 @pytest.mark.parametrize("max_up,far", [(2, 0.25), (0, 0.0), (15, 1e9)])
-def test_seeded_launches_on_a_lattice_full_of_ties(gpu, orc, max_up, far):
+def test_seeded_launches_on_a_lattice_full_of_ties(lane, orc, max_up, far):
+    gpu = lane
     # every query between lattice points has 2, 4 or 8 equidistant targets; the index order is unrelated to the position,
     # so "lowest index" is not "first visited".  Ties are the finishing pass's business: all of them have to get there.
     g = np.arange(14, dtype=np.float32)
@@ -172,7 +185,8 @@ def test_seeded_launches_on_a_lattice_full_of_ties(gpu, orc, max_up, far):
 
 
 @pytest.mark.parametrize("n_tgt", [1, 2, 15, 16, 17, 63, 65, 300])
-def test_seeded_launches_on_tiny_targets(gpu, orc, n_tgt):
+def test_seeded_launches_on_tiny_targets(lane, orc, n_tgt):
+    gpu = lane
     rng = np.random.default_rng(n_tgt)
     tgt = np.ones((n_tgt, 4), np.float32)
     tgt[:, :3] = rng.normal(size=(n_tgt, 3)).astype(np.float32)
@@ -200,12 +214,13 @@ def test_lane_search_equals_the_wave_cooperative_search_in_the_device_loop(gpu):
             icp.align()
             res.append((icp.nr_iterations_, icp.getFinalTransformation().copy(), icp.hasConverged()))
         finally:
-            gpu.setOption("lane_search", 1)
+            gpu.setOption("lane_search", 0)
     assert res[0][0] == res[1][0] and res[0][2] == res[1][2]
     assert np.array_equal(res[0][1], res[1][1])
 
 
-def test_lane_search_counters(gpu):
+def test_lane_search_counters(lane):
+    gpu = lane
     # pclhip_ctx_stats with the lane kernels: slot 0 = queries, 2 = done in the first pass, 4 = finished by the second;
     # on a converged sheet most queries are done by looking at one leaf (what the design rests on)
     import pcl_amd
