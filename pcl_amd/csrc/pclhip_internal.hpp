@@ -359,6 +359,7 @@ void preload_voxelgrid_kernels();
 void preload_rejector_kernels();
 void preload_radius_kernels();
 void preload_lane_kernels();
+bool search_built_with_verify_bounds();  // search.hip compiled with -DPCLHIP_VERIFY_BOUNDS (traverse.hpp)
 // lane.hip: the seeded search launches of an iteration, one lane per query (needs the target's LaneTree)
 bool lane_search_available(const pclhip_icp* icp);
 pclhip_status launch_lane_search(pclhip_icp* icp, const float T12[12], const pclhip::IcpControl* ctl, int order, float bound,
@@ -498,6 +499,8 @@ pclhip_status launch_recip_search(pclhip_index* src_ix, const float4* tgt_pts, c
                                   uint8_t* keep);
 // rejectors.hip: reciprocal filter + rejector chain on icp->keep (stream-ordered, may synchronise)
 pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool use_max);
+// the collectives of the chain's selection passes for a rank whose source share is empty (zero histograms, same order)
+pclhip_status apply_empty_shard_collectives(pclhip_icp* icp);
 // kd order of float4 records whose .w already holds the point's id (used for the reciprocal index)
 pclhip_status build_index_from_float4(pclhip_ctx* ctx, const float4* dev_pts_with_ids, uint32_t n, pclhip_index** out);
 

@@ -432,6 +432,32 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
   return PCLHIP_OK;
 }
 
+// A rank of a sharded registration whose source share is EMPTY (fewer source points than ranks: dist.shard_range gives
+// such ranks a count of 0) has nothing to filter, but its peers all-reduce one 2048-bin histogram per selection pass of
+// every MedianDistance (3 passes) and Trimmed (6) rejector between their histogram and pick kernels: the empty rank issues
+// the same collectives, in the same order, with zero histograms -- otherwise RCCL sees mismatched operations and hangs
+// (ADVICE r4, medium).  Stream-ordered; no-op for a single-GPU registration.
+pclhip_status apply_empty_shard_collectives(pclhip_icp* icp) {
+  if (!icp_is_sharded(icp)) return PCLHIP_OK;
+  pclhip_ctx* ctx = icp->ctx;
+  int passes = 0;
+  for (const pclhip_rejector& r : icp->rejectors) {
+    if (r.kind == PCLHIP_REJ_MEDIAN_DISTANCE) passes += 3;
+    if (r.kind == PCLHIP_REJ_TRIMMED) passes += 6;
+  }
+  if (passes == 0) return PCLHIP_OK;
+  Guard g;
+  g.ctx = ctx;
+  double* zeros = nullptr;
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&zeros, RS_BINS * sizeof(double)));
+  for (int p = 0; p < passes; ++p) {
+    PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(zeros, 0, RS_BINS * sizeof(double), ctx->stream));
+    const pclhip_status st = allreduce_doubles(icp, zeros, RS_BINS);
+    if (st != PCLHIP_OK) return st;
+  }
+  return PCLHIP_OK;
+}
+
 void preload_rejector_kernels() {
   hipFuncAttributes a;
   (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(rs_pick_kernel<0>));

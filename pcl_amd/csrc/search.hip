@@ -2041,6 +2041,10 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
       (void)hipEventRecord(ev[0], s);
       (void)hipEventRecord(ev[1], s);
     }
+    if (filters) {  // an empty source share still takes part in the collectives of the chain's selection passes
+      const pclhip_status es = apply_empty_shard_collectives(icp);
+      if (es != PCLHIP_OK) return es;
+    }
     PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(icp->sums_dev, 0, NS * sizeof(double), s));
     if (device_loop) (void)hipEventRecord(ev[2], s);
   }
@@ -2093,7 +2097,9 @@ pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double ma
   hipStream_t s = ctx->stream;
   *score = DBL_MAX;
   *nr = 0;
-  if (icp->n == 0) return PCLHIP_OK;
+  if (icp->n == 0 && !icp_is_sharded(icp)) return PCLHIP_OK;
+  double sum = 0.0, cnt = 0.0;
+  if (icp->n > 0) {
   const IndexView v = icp->target->view();
   Mat34 M;
   for (int i = 0; i < 12; ++i) M.m[i] = T[i];
@@ -2126,11 +2132,11 @@ pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double ma
   std::vector<double> h(size_t(gr) * 2);
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(h.data(), part, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
-  double sum = 0.0, cnt = 0.0;
   for (int b = 0; b < gr; ++b) {
     sum += h[size_t(b) * 2];
     cnt += h[size_t(b) * 2 + 1];
   }
+  }  // (a rank whose share of the source is empty scores nothing but still takes part in the sum below)
   if (icp_is_sharded(icp)) {  // source slabs or target regions: one score for the whole registration
     std::memset(icp->sums_host, 0, NS * sizeof(double));
     icp->sums_host[0] = sum;
@@ -2184,6 +2190,14 @@ int icp_grid_blocks(pclhip_ctx* ctx, uint32_t ns) {
   return g;
 }
 
+
+bool search_built_with_verify_bounds() {
+#ifdef PCLHIP_VERIFY_BOUNDS
+  return true;
+#else
+  return false;
+#endif
+}
 
 // every kernel of this translation unit lives in one code object: asking for the occupancy of the hot ones loads it and
 // fills resident_blocks()'s cache, so neither sits inside a first timed launch

@@ -568,6 +568,12 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
       const float4 cR = ix.disc[2 * size_t(id)], nh = ix.disc[2 * size_t(id) + 1];
       const bool al = e < n && (!(gq.rho < 1e30f) || so_reach_alive(gq, geo.ngx, geo.ngy, geo.ngz, cR, nh));
       const uint64_t bal = __builtin_amdgcn_ballot_w64(al);
+#ifdef PCLHIP_VERIFY_BOUNDS  // collected leaves the group-level reach filter dropped: every lane checks every one of them
+      for (uint64_t db = __builtin_amdgcn_ballot_w64(e < n && !al); db != 0; db &= db - 1ull) {
+        const uint32_t vid = uint32_t(__builtin_amdgcn_readlane(int(id), __builtin_ctzll(db)));
+        PCLHIP_VERIFY_CULL(ix.soa, vid, qx, qy, qz, pol.worst(0), valid, ts);
+      }
+#endif
       if (bal == 0) continue;
       const uint32_t cnt = uint32_t(__builtin_popcountll(bal));
       if (ms + cnt > SO_SURV_CAP) {
@@ -659,6 +665,13 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
           const uint32_t id = sid[b0 + ec];
           const bool al = e < m && geo.any && (!(rr.rho < 1e30f) || so_reach_alive(rr, geo.ngx, geo.ngy, geo.ngz, cR, nh));
           const uint64_t bal = __builtin_amdgcn_ballot_w64(al);
+#ifdef PCLHIP_VERIFY_BOUNDS  // (row, leaf) pairs the row-level reach filter dropped: the lanes of that row check the leaf
+          for (uint64_t db = __builtin_amdgcn_ballot_w64(e < m && geo.any && !al); db != 0; db &= db - 1ull) {
+            const uint32_t bit = uint32_t(__builtin_ctzll(db));
+            const uint32_t vid = uint32_t(__builtin_amdgcn_readlane(int(id), int(bit)));
+            PCLHIP_VERIFY_CULL(ix.soa, vid, qx, qy, qz, pol.worst(0), valid && (uint32_t(lane) >> 4) == (bit >> 4), ts);
+          }
+#endif
           __builtin_amdgcn_wave_barrier();  // the pass has read its 16 entries before slots <= them are rewritten
           if (bal == 0) continue;
           const uint32_t any16 = uint32_t((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull);
@@ -715,6 +728,8 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
           const uint2 ii = *reinterpret_cast<const uint2*>(idu + c0 + b);
           const bool need0 = (rbits & 1u) != 0 && !(lb.x > w) && ii.x != id1 && ii.x != id2;  // the row seeds are done
           const bool need1 = (rbits & 2u) != 0 && !(lb.y > w) && ii.y != id1 && ii.y != id2;
+          PCLHIP_VERIFY_CULL(ix.soa, ii.x, qx, qy, qz, w, (rbits & 1u) != 0 && lb.x > w, ts);
+          PCLHIP_VERIFY_CULL(ix.soa, ii.y, qx, qy, qz, w, (rbits & 2u) != 0 && lb.y > w, ts);
           m16 |= ((need0 ? 1u : 0u) | (need1 ? 2u : 0u)) << b;
         }
         SO_LAP(6);
@@ -748,6 +763,8 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
           const uint2 ii = *reinterpret_cast<const uint2*>(idu + b);
           const bool need0 = (rbits & 1u) != 0 && !(lb.x > w) && ii.x != id1 && ii.x != id2;  // the row seeds are done
           const bool need1 = (rbits & 2u) != 0 && !(lb.y > w) && ii.y != id1 && ii.y != id2;
+          PCLHIP_VERIFY_CULL(ix.soa, ii.x, qx, qy, qz, w, (rbits & 1u) != 0 && lb.x > w, ts);
+          PCLHIP_VERIFY_CULL(ix.soa, ii.y, qx, qy, qz, w, (rbits & 2u) != 0 && lb.y > w, ts);
           const uint32_t nb = ((need0 ? 1u : 0u) | (need1 ? 2u : 0u)) << (b & 31u);
           if (b < 32u) lm_lo |= nb;
           else lm_hi |= nb;
@@ -782,7 +799,7 @@ __device__ __forceinline__ bool standoff_search(const IndexView& ix, float qx, f
   }
   SO_WHY(7);
   ++ts.c[4];
-#if !defined(PCLHIP_SO_PROFILE) && !defined(PCLHIP_SO_REASONS)
+#if !defined(PCLHIP_SO_PROFILE) && !defined(PCLHIP_SO_REASONS) && !defined(PCLHIP_VERIFY_BOUNDS)
   ++ts.c[5];
   ts.c[6] += n;
   ts.c[7] += stat_union;

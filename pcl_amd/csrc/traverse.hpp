@@ -117,7 +117,11 @@ __device__ __forceinline__ float point_disc_lb(float qx, float qy, float qz, con
   const float b2 = fmaxf(__fmaf_rn(r2, 0.999999f, -(a_hi * a_hi) * 1.000003f), 0.0f);
   const float gt = fmaxf(__fmaf_rn(__fsqrt_rn(b2), 0.999999f, -cR.w), 0.0f);
   const float gn = fmaxf((a - e) - nh.w, 0.0f);
+#ifdef PCLHIP_VERIFY_MUTATE  // a deliberately WRONG bound: proves that the PCLHIP_VERIFY_BOUNDS build sees a broken claim
+  return __fmaf_rn(gt, gt, gn * gn) * PCLHIP_VERIFY_MUTATE;
+#else
   return __fmaf_rn(gt, gt, gn * gn) * DISC_SHRINK;
+#endif
 }
 // ---- row filter for disc leaves (pair mode of the loose path, see traverse()) -------------------------------
 // A lower bound for a whole GROUP of queries standing h off a sheet takes the smallest stand-off against the largest
@@ -910,6 +914,29 @@ struct TraverseStats {
   uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+// -DPCLHIP_VERIFY_BOUNDS (scripts/build_variant.sh verify "-DPCLHIP_VERIFY_BOUNDS"; tests/test_gpu_verify_bounds.py): the
+// two bounds that are NOT bit-monotone -- the per-lane disc bound (point_disc_lb / so_disc_lb2) and the reach filters
+// (row_reach_alive / so_reach_alive) -- are checked where they cull.  A cull claims "no point of this leaf is within the
+// lane's bound of this moment"; the lane computes the leaf's true minimum distance (l2_simple on its 16 points) and counts
+// the claim in slot 6 and a broken claim (minimum <= bound) in slot 7 of the work counters (per lane, summed by
+// flush_stats).  Nothing of this exists in the default build.
+#ifdef PCLHIP_VERIFY_BOUNDS
+__device__ __forceinline__ float l2_simple(float qx, float qy, float qz, float cx, float cy, float cz);
+static __device__ __noinline__ void verify_culled_leaf(const float* __restrict__ soa, uint32_t id, float qx, float qy, float qz, float worst,
+                                                bool active, TraverseStats& ts) {
+  if (active && id != NO_INDEX) {
+    const float* l = soa + size_t(id) * (4 * LEAF);
+    float m = __builtin_inff();
+    for (int c = 0; c < LEAF; ++c) m = fminf(m, l2_simple(qx, qy, qz, l[c], l[LEAF + c], l[2 * LEAF + c]));
+    ++ts.c[6];
+    if (m <= worst) ++ts.c[7];
+  }
+}
+#define PCLHIP_VERIFY_CULL(soa, id, qx, qy, qz, worst, active, ts) verify_culled_leaf(soa, id, qx, qy, qz, worst, active, ts)
+#else
+#define PCLHIP_VERIFY_CULL(soa, id, qx, qy, qz, worst, active, ts) (void)0
+#endif
+
 // does the policy offer the lane-sparse leaf evaluation?
 template <class P, class = void>
 struct lane_sparse_of { static constexpr bool value = false; };
@@ -1197,6 +1224,18 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
                                      row_reach_alive(rr, ngx, ngy, ngz, make_float4(ea.x, ea.y, ea.z, rad[e]), es));
               }
               const uint64_t bal = __builtin_amdgcn_ballot_w64(al);
+#ifdef PCLHIP_VERIFY_BOUNDS  // (row, entry) pairs the reach filter dropped: every lane of that row checks the entry's leaf
+              {
+                bool dropped = false;
+                if (e < n_alive) dropped = !al && !(wl.list[LS * e + 1].w > T);
+                for (uint64_t db = __builtin_amdgcn_ballot_w64(dropped); db != 0; db &= db - 1ull) {
+                  const uint32_t bit = uint32_t(__builtin_ctzll(db));
+                  const uint32_t vid = __float_as_uint(wl.list[LS * (e0 + (bit & 15u))].w);
+                  PCLHIP_VERIFY_CULL(ix.soa, vid, qx[0], qy[0], qz[0], pol.worst(0),
+                                     valid[0] && (uint32_t(lane) >> 4) == (bit >> 4) && pol_wants(pol, vid), ts);
+                }
+              }
+#endif
               rowmask |= ((bal >> rshift) & 0xFFFFull) << e0;
             }
             // (lane, leaf) pairs: every lane walks the entries alive for its row
@@ -1209,6 +1248,8 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
               const float4 ea = wl.list[LS * e], es = wl.list[LS * e + 2];
               const float lb = point_disc_lb(qx[0], qy[0], qz[0], make_float4(ea.x, ea.y, ea.z, rad[e]), es);
               const bool need = has && !(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w));
+              PCLHIP_VERIFY_CULL(ix.soa, __float_as_uint(ea.w), qx[0], qy[0], qz[0], pol.worst(0),
+                                 has && lb > pol.worst(0) && pol_wants(pol, __float_as_uint(ea.w)), ts);
               lanemask |= need ? (1ull << e) : 0ull;
             }
             // evaluation, 16 staged leaves at a time, every lane its own
@@ -1252,6 +1293,8 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
                 lb = point_box_lb(qx[0], qy[0], qz[0], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
               }
               bool need = valid[0] && !(lb > pol.worst(0)) && pol_wants(pol, __float_as_uint(ea.w));
+              PCLHIP_VERIFY_CULL(ix.soa, __float_as_uint(ea.w), qx[0], qy[0], qz[0], pol.worst(0),
+                                 use_disc && valid[0] && lb > pol.worst(0) && pol_wants(pol, __float_as_uint(ea.w)), ts);
               if (__builtin_amdgcn_ballot_w64(need && pid != NO_INDEX) != 0) {
                 if (!landed) {
                   PCLHIP_WAIT_VMCNT0();
@@ -1361,6 +1404,8 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
               lb = point_box_lb(qx[q], qy[q], qz[q], ea.x, ea.y, ea.z, eb.x, eb.y, eb.z);
             }
             need = need || (valid[q] && !(lb > pol.worst(q)));
+            PCLHIP_VERIFY_CULL(ix.soa, __float_as_uint(ea.w), qx[q], qy[q], qz[q], pol.worst(q),
+                               use_disc && valid[q] && lb > pol.worst(q), ts);
           }
           if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
           ++ts.c[2];
@@ -1414,7 +1459,17 @@ __device__ __forceinline__ void traverse(const IndexView& ix, const float* qx, c
   }
 }
 
-__device__ __forceinline__ void flush_stats(const TraverseStats& ts, unsigned long long* g) {
+__device__ __forceinline__ void flush_stats(const TraverseStats& ts_in, unsigned long long* g) {
+#ifdef PCLHIP_VERIFY_BOUNDS  // slots 6 / 7 were counted per lane (verify_culled_leaf)
+  TraverseStats ts = ts_in;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ts.c[6] += __shfl_xor(ts.c[6], o);
+    ts.c[7] += __shfl_xor(ts.c[7], o);
+  }
+#else
+  const TraverseStats& ts = ts_in;
+#endif
   if (g != nullptr && (threadIdx.x & (WAVE - 1)) == 0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) atomicAdd(g + i, (unsigned long long)ts.c[i]);

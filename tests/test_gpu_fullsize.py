@@ -325,3 +325,62 @@ def test_config3_device_driven_loop_correspondences_bit_exact_at_10m(gpu, orc, c
         assert full is not None and 3 <= full <= 5
     finally:
         gpu.setOption("icp_lookahead", 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# the same all-iteration check OFF the bench's geometry (VERDICT r4 #1b): a volume, two close layers, 100x density
+# contrast -- at sizes whose trees are as deep as the bench's, one of them with the other parity of four-way rounds
+# (2.5M points: 256-point cells are strips there).  pcl_amd/synth.py: family_cloud.  PCL's own search tests use
+# volumetric random clouds (test/search/test_search.cpp:292-364).
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,n,mode", [("cube", 10_000_000, 0), ("layers", 10_000_000, 1), ("clusters", 2_500_000, 0)])
+def test_families_correspondences_bit_exact_at_size(gpu, orc, kind, n, mode):
+    import torch
+    import pcl_amd
+    tgt, src, _ = pcl_amd.synth.family_pair(kind, n)
+    otree = orc.KdTree(tgt)
+    kw = dict(ICP_KW, max_iterations=6)
+    onrm = None
+    if mode == 1:
+        onrm, nan = otree.normals(tgt, 8, viewpoint=(0, 0, 10))
+        assert nan == 0
+    ref = orc.icp_align(otree, tgt, src, mode=mode, tgt_normals=onrm, record=True, acc_double=1, **kw)
+    assert ref["iterations"] >= 3
+    tgt_d = torch.from_numpy(tgt).cuda()
+    tree = pcl_amd.KdTree(gpu)
+    tree.setInputCloud(tgt_d)
+    # k = 8 on a quarter of the cloud (self-queries through the batched kernel)
+    q = np.ascontiguousarray(tgt[: n // 4])
+    gi, gd = tree.nearestKSearch(q, 8)
+    oi, od = otree.knn(q, 8)
+    assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    cls = pcl_amd.IterativeClosestPointWithNormals if mode == 1 else pcl_amd.IterativeClosestPoint
+    icp = cls(gpu)
+    icp.setSearchMethodTarget(tree, True)
+    if mode == 1:
+        icp.setTargetNormals(onrm)
+    icp.setInputSource(torch.from_numpy(src).cuda())
+    icp.reset()
+    T_prev = np.eye(4, dtype=np.float32)
+    cur = src.copy()
+    for it in range(ref["iterations"]):            # the cold launch and every seeded one, all n correspondences each
+        sums = icp.iterate(T_prev, max_dist=0.1)
+        cur = orc.transform_cloud(T_prev, cur, order=mode)
+        want = otree.correspondences(cur, 0.1)
+        assert_same_correspondences(icp.fetchCorrespondences(), want, "%s iteration %d" % (kind, it))
+        assert int(sums[28]) == len(want[0])
+        T_prev = ref["per_iter_T"][it]
+    # the device-driven loop on the same clouds: same iteration count and state, the 4x4 within the contract
+    icp2 = cls(gpu)
+    icp2.setSearchMethodTarget(tree, True)
+    if mode == 1:
+        icp2.setTargetNormals(onrm)
+    icp2.setInputSource(torch.from_numpy(src).cuda())
+    icp2.setMaximumIterations(kw["max_iterations"])
+    icp2.setMaxCorrespondenceDistance(0.1)
+    icp2.setTransformationEpsilon(1e-10)
+    icp2.align()
+    assert icp2.nr_iterations_ == ref["iterations"]
+    err = frob(icp2.getFinalTransformation(), ref["T"])
+    print("%s (%d points): %d iterations, |T_gpu - T_oracle|_F = %.3g" % (kind, n, ref["iterations"], err))
+    assert err < 1e-5

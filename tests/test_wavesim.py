@@ -43,8 +43,8 @@ def wavesim_lib():
 
 @pytest.fixture(scope="module")
 def variant_lib(tmp_path_factory):
-    """ONE more build of the emulation for the test of a build parameter: the served-group history capped at 3
-    (-DPCLHIP_OWN_HIST_CAP=3)."""
+    """ONE more build of the emulation for the tests of build parameters: the served-group history capped at 3
+    (-DPCLHIP_OWN_HIST_CAP=3) and the bounds checked where they cull (-DPCLHIP_VERIFY_BOUNDS, traverse.hpp)."""
     if not os.path.exists(CLANG) or shutil.which("make") is None:
         pytest.skip("needs the ROCm clang++ and make")
     build = tmp_path_factory.mktemp("ws_variant")
@@ -55,7 +55,7 @@ def variant_lib(tmp_path_factory):
     for f in ("wavesim.hpp", "wavesim_rt.cpp"):
         shutil.copy(os.path.join(WS, f), str(build / f))
     r = subprocess.run(["make", "-C", str(build), "-j", str(min(16, os.cpu_count() or 1)),
-                        "EXTRA=-DPCLHIP_OWN_HIST_CAP=3"], capture_output=True, text=True)
+                        "EXTRA=-DPCLHIP_OWN_HIST_CAP=3 -DPCLHIP_VERIFY_BOUNDS"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     return str(build / "libpclhip_wavesim.so")
 
@@ -105,7 +105,7 @@ def test_gpu_parity_tests_run_on_the_emulation(wavesim_lib):
 
 
 @pytest.mark.parametrize("mode,world", [("target", 2), ("source", 2), ("target", 3), ("target+rej", 2), ("source+rej", 2),
-                                        ("target+recip", 2)])
+                                        ("target+recip", 2), ("source+rej+empty", 3)])
 def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, world):
     """An N > 1 execution of the library's own multi-GPU code, which the one-GPU box of a round cannot give: `world`
     PROCESSES, each with its own (emulated) device, a native communicator created from one shared id (pclhip_comm_*; the
@@ -116,7 +116,8 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
     the iteration counts agree, and what the ranks served adds up to the all-reduced count.  "+rej": a MedianDistance +
     Trimmed + Distance chain inside the loop -- the histograms of the two selections are all-reduced, so every rank cuts at
     the single-GPU run's thresholds; "+recip": reciprocal correspondences with the target sharded (the whole source on every
-    rank, the served-group lists standing aside)."""
+    rank, the served-group lists standing aside); "+empty": the last rank's share of the source is EMPTY -- it has nothing to
+    filter but still issues the chain's histogram all-reduces, in step with its peers."""
     import numpy as np
     n = 60_000
     mode, _, extra = mode.partition("+")
@@ -131,12 +132,13 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
     ranks = [np.load(os.path.join(work, "rank%d.npz" % r)) for r in range(world)]
     # single-process reference on the same emulation (no communicator, no region)
     extra_lines = ""
-    if extra == "rej":
+    extras = set(extra.split("+")) if extra else set()
+    if "rej" in extras:
         extra_lines = ("a = pcl_amd.CorrespondenceRejectorMedianDistance(); a.setMedianFactor(1.5)\n"
                        "b = pcl_amd.CorrespondenceRejectorTrimmed(); b.setOverlapRatio(0.8)\n"
                        "d = pcl_amd.CorrespondenceRejectorDistance(); d.setMaximumDistance(0.05)\n"
                        "[icp.addCorrespondenceRejector(r) for r in (a, b, d)]\n")
-    if extra == "recip":
+    if "recip" in extras:
         extra_lines = "icp.setUseReciprocalCorrespondences(True)\n"
     code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
             "import pcl_amd; from pcl_amd import synth\n"
@@ -158,7 +160,10 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
         assert np.array_equal(r_["counts"], ranks[0]["counts"])            # all-reduced: the same on every rank
     assert int(ranks[0]["iterations"]) == int(one["iterations"]) and bool(ranks[0]["converged"])
     assert np.abs(ranks[0]["T"].astype(np.float64) - one["T"].astype(np.float64)).max() < 2e-6
-    assert all(int(r_["served"]) > 0 for r_ in ranks)                       # every rank had work
+    if "empty" in extras:
+        assert int(ranks[-1]["served"]) == 0 and all(int(r_["served"]) > 0 for r_ in ranks[:-1])
+    else:
+        assert all(int(r_["served"]) > 0 for r_ in ranks)                   # every rank had work
     assert sum(int(r_["served"]) for r_ in ranks) in set(int(c) for c in ranks[0]["counts"])
     if not extra:
         assert int(ranks[0]["counts"][0]) == n
@@ -282,3 +287,20 @@ def test_strided_inputs_are_read_to_their_last_byte_only(wavesim_lib):
     r = subprocess.run([sys.executable, os.path.join(WS, "guard_page_probe.py")], env=env, capture_output=True, text=True,
                        timeout=600, cwd=ROOT)
     assert r.returncode == 0 and "GUARD_PAGE ok" in r.stdout, (r.returncode, r.stdout[-800:], r.stderr[-1500:])
+
+
+def test_bounds_checked_where_they_cull_on_the_emulation(variant_lib):
+    """tests/test_gpu_verify_bounds.py's worker on the emulation's -DPCLHIP_VERIFY_BOUNDS build: every leaf a disc bound or a
+    reach filter drops has its true minimum distance evaluated by the lane it was dropped for; no claim may be broken, and
+    at these sizes the results are compared with the oracle as well."""
+    import json
+    env = dict(os.environ, PCLHIP_LIB=variant_lib, PCLHIP_ALLOW_WAVESIM="1")
+    fams = ["sheet", "cube", "collinear", "coincident", "far"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "verify_bounds_worker.py"), "30000"] + fams,
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(rows) == 5 * len(fams)
+    assert sum(x["checks"] for x in rows) > 1_000_000
+    assert all(x["violations"] == 0 for x in rows), [x for x in rows if x["violations"]]
+    assert all(x["matches_vs_oracle"] is True for x in rows)

@@ -23,6 +23,7 @@ from pcl_amd.dist import ShardedTarget, shard_range  # noqa: E402
 
 mode, rank, world, work = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 mode, _, extra = mode.partition("+")   # "+rej": MedianDistance + Trimmed + Distance chain; "+recip": reciprocal correspondences
+extras = set(extra.split("+")) if extra else set()   # "+empty" (source mode): the LAST rank's share of the source is empty
 n = int(sys.argv[5]) if len(sys.argv) > 5 else 60_000
 uid_path = os.path.join(work, "uid.bin")
 if rank == 0:
@@ -54,7 +55,10 @@ else:
     ne.setKSearch(8)
     ne.setViewPoint(0, 0, 10)
     ne.compute(want_output=False)
-    start, count = shard_range(n, rank, world)
+    if "empty" in extras:
+        start, count = shard_range(n, rank, world - 1) if rank < world - 1 else (0, 0)
+    else:
+        start, count = shard_range(n, rank, world)
     my_src = np.ascontiguousarray(src[start:start + count])
 icp = pcl_amd.IterativeClosestPointWithNormals(ctx)
 icp.setSearchMethodTarget(tree, True)
@@ -65,7 +69,7 @@ icp.setTransformationEpsilon(1e-10)
 icp.setCommunicator(comm)
 if region is not None:
     icp.setRegion(region)
-if extra == "rej":
+if "rej" in extras:
     a = pcl_amd.CorrespondenceRejectorMedianDistance()
     a.setMedianFactor(1.5)
     b = pcl_amd.CorrespondenceRejectorTrimmed()
@@ -74,7 +78,7 @@ if extra == "rej":
     d.setMaximumDistance(0.05)
     for r in (a, b, d):
         icp.addCorrespondenceRejector(r)
-if extra == "recip":
+if "recip" in extras:
     icp.setUseReciprocalCorrespondences(True)
 icp.align()
 T = icp.getFinalTransformation().copy()
