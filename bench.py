@@ -211,6 +211,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # a fresh frame: a NEW source cloud against the resident target -- its ordering, then one whole alignment (device times)
+    fresh = None
+    if world == 1 and not args.rejectors and not args.reciprocal:
+        icp_f = cls(ctx)
+        icp_f.setSearchMethodTarget(tree, True)
+        icp_f.setInputSource(src)
+        icp_f.setMaximumIterations(20)
+        icp_f.setMaxCorrespondenceDistance(0.1)
+        icp_f.setTransformationEpsilon(1e-10)
+        tf0 = time.perf_counter()
+        many = icp_f.runSteps(21)
+        ctx.synchronize()
+        one = []
+        for s_ in many:                       # the first whole alignment of the run
+            one.append(s_)
+            if s_["alignment_ended"]:
+                break
+        fresh = {"source_order_ms": round(icp_f.sourceOrderMs(), 3), "iterations": len(one),
+                 "alignment_device_ms": round(sum(s_["step_ms"] for s_ in one), 3),
+                 "fresh_frame_ms": round(icp_f.sourceOrderMs() + sum(s_["step_ms"] for s_ in one), 3),
+                 "wall_ms_of_21_steps": round((time.perf_counter() - tf0) * 1e3, 3)}
+        del icp_f
     ncorr = float(sum(s["num_correspondences"] for s in steps))   # already the all-reduced (global) count
     search_ms = sum(s["search_ms"] for s in steps)
     kernel_ms = sum(s["kernels_ms"] for s in steps)
@@ -221,7 +243,8 @@ def main():
     achieved = B_ALG_SEARCH * corr_per_launch_local / avg_kernel_s / 1e9
     roofline = {"bound": "hbm",
                 "kernel": "icp_search_dual_kernel (one launch per iteration: the stand-off body for the first iteration of an "
-                          "alignment, the seeded body after it; both are averaged here as the steps mix them)",
+                          "alignment, the seeded body after it -- with a greedy reseed where every seed of a group is far; both "
+                          "are averaged here as the steps mix them)",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": None, "alg_bytes_per_corr": B_ALG_SEARCH, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
@@ -236,6 +259,11 @@ def main():
             tj = json.load(open(traffic_file))
             fresh = tj.get("kernel_sources_sha") == kernel_sources_sha()
             roofline["traffic"] = tj.get("icp_search_bytes_per_launch") if fresh else None
+            if fresh and roofline["traffic"]:
+                # SURVEY.md 8(d)'s "measured": the counters' bytes over the launch's duration, beside the algorithmic figure
+                roofline["measured"] = round(roofline["traffic"] / avg_kernel_s / 1e9, 2)
+                roofline["measured_frac"] = round(roofline["traffic"] / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 5)
+                roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / (B_ALG_SEARCH * corr_per_launch_local), 3)
             roofline["traffic_source"] = {"file": "profiles/pmc_traffic.json", "commit": tj.get("commit"),
                                           "date": tj.get("date"), "command": tj.get("command"),
                                           "kernel_sources_match": fresh,
@@ -289,6 +317,8 @@ def main():
                       "iteration_roofline_frac": round(B_ALG_ITER[mode] * corr_per_launch_local /
                                                        (kernel_ms / max(args.steps, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                       "source_order_ms": round(source_order_ms, 3),
+                      # a new source against the resident target: ordering + one whole alignment (device times)
+                      "fresh_frame_ms": None if fresh is None else fresh["fresh_frame_ms"], "fresh_frame": fresh,
                       # pcl::Registration::align() from HOST pcl::PointClouds through the real-PCL binding (mock build)
                       "host_align_ms": None if not boundary or "align_first" not in boundary else
                       round(boundary["align_first"]["total_ms"], 3),
@@ -449,6 +479,9 @@ def cpu_pipeline(args, tgt, src):
     return {"value": round(2.0 * len(tgt_h) / (t2 - t0), 1), "unit": "input points/s", "cores": cores,
             "threads_used": cores, "host_hardware_threads": host_cpus()[0], "host_physical_cores": host_cpus()[1],
             "kind": "port",
+            "note": "a dependency-free RESTATEMENT of PCL's CPU path (oracle/pcl_oracle.c), not PCL + FLANN: a stated baseline, "
+                    "never a target -- its one-thread search costs several microseconds per query where FLANN-class trees take "
+                    "1-2, so the GPU / CPU ratio says nothing about kernel quality (roofline.frac does)",
             "sample": "the same two %d-point clouds, whole pipeline once: VoxelGrid %.2f s (1 thread, as in PCL), "
                       "kd-tree + k=%d normals + %d ICP iterations %.2f s (search on %d threads)" %
                       (len(tgt_h), t1 - t0, args.knn, r["iterations"], t2 - t1, cores)}
