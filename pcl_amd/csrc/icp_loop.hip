@@ -30,6 +30,21 @@ using namespace pclhip;
 // RCCL, bound at run time: libpclhip.so has no link-time dependency on it (single-GPU users need none), and a
 // process that already carries an RCCL (torch ships its own) keeps using that one instead of a second copy.
 // ---------------------------------------------------------------------------------------------------
+// RCCL's entry points as WEAK references: null unless the link unit this library ends up in (or a library already loaded
+// into the global scope) defines them -- then they are used directly; otherwise librccl is dlopen()ed below.  (The CPU
+// emulation of the test tier links a stand-in under these names: tests/wavesim/wavesim_rt.cpp -- a link-time hook, no
+// conditional compilation here.)  Declared with opaque signatures: only their addresses are taken.
+extern "C" {
+__attribute__((weak)) void ncclGetUniqueId();
+__attribute__((weak)) void ncclCommInitRank();
+__attribute__((weak)) void ncclCommDestroy();
+__attribute__((weak)) void ncclAllReduce();
+}
+static void (*const pclhip_weak_ncclGetUniqueId)() = &ncclGetUniqueId;
+static void (*const pclhip_weak_ncclCommInitRank)() = &ncclCommInitRank;
+static void (*const pclhip_weak_ncclCommDestroy)() = &ncclCommDestroy;
+static void (*const pclhip_weak_ncclAllReduce)() = &ncclAllReduce;
+
 namespace {
 
 struct NcclUniqueId {
@@ -48,26 +63,19 @@ struct RcclApi {
   std::string why;
 };
 
-#ifdef PCLHIP_WAVESIM  // the CPU emulation of the test tier brings a stand-in (tests/wavesim/wavesim_rt.cpp: a sum in rank order
-extern "C" {           // through shared memory between the ranks' processes) so that N > 1 runs of THIS code can be tested there
-int wavesim_ncclGetUniqueId(NcclUniqueId*);
-int wavesim_ncclCommInitRank(NcclComm*, int, NcclUniqueId, int);
-int wavesim_ncclCommDestroy(NcclComm);
-int wavesim_ncclAllReduce(const void*, void*, size_t, int, int, NcclComm, hipStream_t);
-}
-#endif
-
 RcclApi& rccl() {
   static RcclApi api = [] {
     RcclApi a;
-#ifdef PCLHIP_WAVESIM
-    a.GetUniqueId = wavesim_ncclGetUniqueId;
-    a.CommInitRank = wavesim_ncclCommInitRank;
-    a.CommDestroy = wavesim_ncclCommDestroy;
-    a.AllReduce = wavesim_ncclAllReduce;
-    a.ok = true;
-    return a;
-#endif
+    // linked in already (whatever this library is part of provides the entry points): use them as they are
+    if (pclhip_weak_ncclGetUniqueId != nullptr && pclhip_weak_ncclCommInitRank != nullptr &&
+        pclhip_weak_ncclCommDestroy != nullptr && pclhip_weak_ncclAllReduce != nullptr) {
+      a.GetUniqueId = reinterpret_cast<int (*)(NcclUniqueId*)>(pclhip_weak_ncclGetUniqueId);
+      a.CommInitRank = reinterpret_cast<int (*)(NcclComm*, int, NcclUniqueId, int)>(pclhip_weak_ncclCommInitRank);
+      a.CommDestroy = reinterpret_cast<int (*)(NcclComm)>(pclhip_weak_ncclCommDestroy);
+      a.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, NcclComm, hipStream_t)>(pclhip_weak_ncclAllReduce);
+      a.ok = true;
+      return a;
+    }
     void* h = nullptr;
     if (dlsym(RTLD_DEFAULT, "ncclCommInitRank") == nullptr) {
       const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};

@@ -495,14 +495,14 @@ bool shm_barrier(FakeComm* c) {
 
 extern "C" {
 
-__attribute__((visibility("default"))) int wavesim_ncclGetUniqueId(FakeUniqueId* id) {
+__attribute__((visibility("hidden"))) int ncclGetUniqueId(FakeUniqueId* id) {
   std::memset(id, 0, sizeof *id);
   static std::atomic<unsigned> serial{0};
   std::snprintf(id->internal, sizeof id->internal, "/wavesim-nccl-%d-%u-%llx", int(getpid()), serial.fetch_add(1),
                 (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
   return 0;
 }
-__attribute__((visibility("default"))) int wavesim_ncclCommInitRank(void** comm, int nranks, FakeUniqueId id, int rank) {
+__attribute__((visibility("hidden"))) int ncclCommInitRank(void** comm, int nranks, FakeUniqueId id, int rank) {
   if (nranks < 1 || nranks > NCCL_MAX_RANKS || rank < 0 || rank >= nranks) return 4;
   id.internal[63] = 0;
   const int fd = shm_open(id.internal, O_CREAT | O_RDWR, 0600);
@@ -523,7 +523,7 @@ __attribute__((visibility("default"))) int wavesim_ncclCommInitRank(void** comm,
   *comm = c;
   return 0;
 }
-__attribute__((visibility("default"))) int wavesim_ncclCommDestroy(void* comm) {
+__attribute__((visibility("hidden"))) int ncclCommDestroy(void* comm) {
   FakeComm* c = static_cast<FakeComm*>(comm);
   if (!c) return 0;
   if (c->rank == 0) shm_unlink(c->name);
@@ -531,7 +531,7 @@ __attribute__((visibility("default"))) int wavesim_ncclCommDestroy(void* comm) {
   delete c;
   return 0;
 }
-__attribute__((visibility("default"))) int wavesim_ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op,
+__attribute__((visibility("hidden"))) int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op,
                                                                  void* comm, hipStream_t) {
   FakeComm* c = static_cast<FakeComm*>(comm);
   if (!c || dtype != 8 || op != 0 || count > size_t(NCCL_MAX_COUNT)) return 4;  // ncclFloat64, ncclSum
