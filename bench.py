@@ -212,7 +212,7 @@ def main():
         elapsed = float(t.item())
 
     # a fresh frame: a NEW source cloud against the resident target -- its ordering, then one whole alignment (device times)
-    fresh = None
+    fresh_frame = None
     if world == 1 and not args.rejectors and not args.reciprocal:
         icp_f = cls(ctx)
         icp_f.setSearchMethodTarget(tree, True)
@@ -228,7 +228,7 @@ def main():
             one.append(s_)
             if s_["alignment_ended"]:
                 break
-        fresh = {"source_order_ms": round(icp_f.sourceOrderMs(), 3), "iterations": len(one),
+        fresh_frame = {"source_order_ms": round(icp_f.sourceOrderMs(), 3), "iterations": len(one),
                  "alignment_device_ms": round(sum(s_["step_ms"] for s_ in one), 3),
                  "fresh_frame_ms": round(icp_f.sourceOrderMs() + sum(s_["step_ms"] for s_ in one), 3),
                  "wall_ms_of_21_steps": round((time.perf_counter() - tf0) * 1e3, 3)}
@@ -318,7 +318,7 @@ def main():
                                                        (kernel_ms / max(args.steps, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                       "source_order_ms": round(source_order_ms, 3),
                       # a new source against the resident target: ordering + one whole alignment (device times)
-                      "fresh_frame_ms": None if fresh is None else fresh["fresh_frame_ms"], "fresh_frame": fresh,
+                      "fresh_frame_ms": None if fresh_frame is None else fresh_frame["fresh_frame_ms"], "fresh_frame": fresh_frame,
                       # pcl::Registration::align() from HOST pcl::PointClouds through the real-PCL binding (mock build)
                       "host_align_ms": None if not boundary or "align_first" not in boundary else
                       round(boundary["align_first"]["total_ms"], 3),
