@@ -189,7 +189,11 @@ PCLHIP_API pclhip_status pclhip_normals_radius(pclhip_index* index, double radiu
  * indices is NULL); its plane is fitted to the surface points the search returns, in that order, and the normal is
  * flipped towards the viewpoint as seen from the QUERY point.  Exactly one of k >= 1 / radius > 0.
  * out (host or device): nx,ny,nz,curvature at byte 0 of out_stride_bytes records, one per query; NaN where the query
- * is non-finite or has fewer than 3 neighbours.  Nothing is retained in the index. */
+ * is non-finite or has fewer than 3 neighbours.  Nothing is retained in the index.
+ * Radius mode accumulates the covariance inside the traversal, shifted by the QUERY point and summed in double in
+ * traversal order; the reference shifts by the first neighbour returned and sums in float in ascending-distance order
+ * (common/include/pcl/common/impl/centroid.hpp:581-650).  For self-queries the two shifts coincide; for a search surface
+ * that is not the input the results meet the 1e-5 contract on normals and curvature, not bit parity. */
 PCLHIP_API pclhip_status pclhip_normals_at(pclhip_index* surface, const void* queries, size_t stride_bytes, uint64_t n_queries,
                                            const int32_t* indices, uint64_t n_indices, int k, double radius,
                                            const float viewpoint[3], void* out, size_t out_stride_bytes,
@@ -289,7 +293,11 @@ PCLHIP_API pclhip_status pclhip_icp_reset(pclhip_icp* icp);
  * Exact ties, whose order the reference leaves to an unstable sort, go to the lower query index.
  * Multi-GPU (pclhip_icp_set_comm / _set_allreduce): DISTANCE is per pair; MEDIAN_DISTANCE and TRIMMED cut at the one
  * cloud-global order statistic (the histograms of their selection are all-reduced: the hook / communicator sees buffers
- * of 2048 doubles besides the 32-double record); ONE_TO_ONE is refused (its conflicts span ranks). */
+ * of 2048 doubles besides the 32-double record); ONE_TO_ONE is refused (its conflicts span ranks).  A rank whose share
+ * of the source is empty still issues those collectives (with zero histograms), in step with its peers.  With the SOURCE
+ * cut into slabs, TRIMMED breaks exact distance ties at the cut by the rank-LOCAL query index (every rank's indices
+ * restart at 0): the number of pairs kept is the single-GPU run's, which of several exactly tied pairs survive may not
+ * be. */
 enum { PCLHIP_REJ_DISTANCE = 0, PCLHIP_REJ_MEDIAN_DISTANCE = 1, PCLHIP_REJ_ONE_TO_ONE = 2, PCLHIP_REJ_TRIMMED = 3 };
 typedef struct {
   int kind;
@@ -409,7 +417,10 @@ PCLHIP_API pclhip_status pclhip_icp_set_comm(pclhip_icp* icp, pclhip_comm* comm)
  *   3. takes part in the per-iteration all-reduce of the record (pclhip_icp_set_comm); all ranks then apply the
  *      same transformation, so routing stays consistent without any other exchange.
  * Correspondences over all ranks are exactly those of a single index over the whole target.
- * Partitioning and selection are host code (no GPU needed); clouds may be host or device memory.
+ * Partitioning and selection are host code (no GPU needed); clouds may be host or device memory.  A cloud in DEVICE
+ * memory is cut on the device (same regions and lists, bit for bit; up to 254 slabs, more fall back to the host code):
+ * these two calls take no context, run on the null stream and first wait for everything queued on the device, so a
+ * cloud another stream is still producing is complete when they read it.
  * regions: n_slabs x 6 floats (lo.xyz, hi.xyz), +-inf on unbounded sides. */
 PCLHIP_API pclhip_status pclhip_partition_slabs(const void* points, size_t stride_bytes, uint64_t n, int n_slabs,
                                                 float* regions);

@@ -937,6 +937,8 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
               }
             }
             if (flags & 2) start_leaf = gp / LEAF;
+            // (measured and dropped: every lane also evaluating the whole 64-point block around that leaf -- the second
+            // launch of an alignment 0.895 -> 0.99 ms at 10M points, profiles/r05_lane_search_ab.txt: its cost is not its radii)
           }
         }
       }

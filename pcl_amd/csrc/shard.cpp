@@ -127,7 +127,8 @@ pclhip_status pclhip_partition_slabs(const void* points, size_t stride, uint64_t
     set_error(nullptr, "stride must be a multiple of 4 and >= 12 bytes, the cloud must fit int32 indices");
     return PCLHIP_ERR_INVALID;
   }
-  if (n > 0 && is_device_pointer(points)) return partition_slabs_device(points, stride, n, n_slabs, regions);  // shard_dev.hip
+  // shard_dev.hip (8-bit cell labels: up to 254 slabs; more go through the host code below, which fetches the cloud)
+  if (n > 0 && is_device_pointer(points) && n_slabs <= 254) return partition_slabs_device(points, stride, n, n_slabs, regions);
   HostCloud c;
   pclhip_status st = fetch_cloud(points, stride, n, c);
   if (st != PCLHIP_OK) return st;

@@ -223,6 +223,12 @@ struct Cell {
 // pclhip_partition_slabs for a cloud in device memory (same regions as shard.cpp's bisect(), bit for bit)
 pclhip_status partition_slabs_device(const void* points, size_t stride, uint64_t n, int n_slabs, float* regions) {
   const float inf = std::numeric_limits<float>::infinity();
+  // These setup calls take no context: they run on the null stream.  A cloud that another (non-blocking) stream is still
+  // writing is not ordered before them by the stream semantics, so everything queued on the device is waited for first.
+  if (hipDeviceSynchronize() != hipSuccess) {
+    set_error(nullptr, "device synchronisation failed before the partition");
+    return PCLHIP_ERR_HIP;
+  }
   if (n_slabs > 254) {
     set_error(nullptr, "at most 254 slabs");
     return PCLHIP_ERR_INVALID;
@@ -319,6 +325,10 @@ pclhip_status partition_slabs_device(const void* points, size_t stride, uint64_t
 // pclhip_select_region for a cloud in device memory: lo / hi are the dilated, outward-rounded bounds of shard.cpp
 pclhip_status select_region_device(const void* points, size_t stride, uint64_t n, const float lo[3], const float hi[3],
                                    int32_t* out_indices, uint64_t capacity, uint64_t* out_count) {
+  if (hipDeviceSynchronize() != hipSuccess) {  // see partition_slabs_device
+    set_error(nullptr, "device synchronisation failed before the selection");
+    return PCLHIP_ERR_HIP;
+  }
   *out_count = 0;
   if (n == 0) return PCLHIP_OK;
   const char* pts = static_cast<const char*>(points);
