@@ -74,14 +74,25 @@ PCLHIP_API pclhip_status pclhip_ctx_reserve(pclhip_ctx* ctx, uint64_t bytes);
  *                           serves (default 1; 0 = every launch walks the whole source -- the reference of the tests)
  *   "icp_lookahead"  n      pclhip_icp_align: iterations queued ahead of the host's knowledge (default 1)
  *   "cache_mb"       n      device blocks kept for reuse between calls, MiB (default 16384, at most a quarter of the device)
- *   "arena_mb"       n      size of the automatic arena (pclhip_ctx_reserve), MiB; 0 = none (default: 288 B per point)
+ *   "arena_mb"       n      size of the automatic arena (pclhip_ctx_reserve), MiB; 0 = none (default: 288 B per point);
+ *                           PCLHIP_ERR_STATE once the arena exists
+ *   "cell_start"     0 | 1  seeded descents test the kd CELL of the level-2 / level-3 node of a seed (pclhip_index_cells)
+ *                           instead of its tight box when they look for a start level (default 1)
+ *   "reseed"         0 | 1  a 64-query group whose seeds are all farther than two leaf diagonals gets one fresh seed from a
+ *                           greedy walk down the hierarchy (default 1)
+ *   "lane_search"    0 | 1  the seeded launches of an ICP iteration run one lane per query over the quad levels and their
+ *                           cells (lane.hip) instead of the wave-cooperative traversal (default 0: exact, measured 2.5x
+ *                           slower at 10M points); "lane_max_up" n (default 2) quad levels the first pass climbs,
+ *                           "lane_far" x (default 0.25) squared mean leaf diagonals beyond which a seed is replaced
  * No PCL counterpart (PCL's knobs are the setters of its classes, which the bindings map onto the calls below). */
 PCLHIP_API pclhip_status pclhip_ctx_set_option(pclhip_ctx* ctx, const char* name, double value);
 PCLHIP_API const char* pclhip_version(void);
 /* Optional traversal work counters (diagnostics): enable != 0 allocates/zeroes 8 device counters
  * that every search kernel of this context adds to; out (8 x uint64, may be NULL) receives the
  * current values: [0] interior nodes scanned, [1] leaves past the group test, [2] leaves past the
- * per-lane test (16-candidate all-pairs blocks), [3] stack pushes, [4] 64-query groups. */
+ * per-lane test (16-candidate all-pairs blocks), [3] stack pushes, [4] 64-query groups.  (With "lane_search" the lane
+ * kernels count in the same slots: [0] queries, [1] done with their own leaf, [2] done in the first pass, [3] greedy
+ * descents, [4] finished by the second pass.) */
 PCLHIP_API pclhip_status pclhip_ctx_stats(pclhip_ctx* ctx, int enable, uint64_t* out);
 
 /* ---- spatial index over the target cloud ------------------------------------------------------
