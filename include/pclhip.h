@@ -304,7 +304,10 @@ PCLHIP_API pclhip_status pclhip_icp_reset(pclhip_icp* icp);
  * Exact ties, whose order the reference leaves to an unstable sort, go to the lower query index.
  * Multi-GPU (pclhip_icp_set_comm / _set_allreduce): DISTANCE is per pair; MEDIAN_DISTANCE and TRIMMED cut at the one
  * cloud-global order statistic (the histograms of their selection are all-reduced: the hook / communicator sees buffers
- * of 2048 doubles besides the 32-double record); ONE_TO_ONE is refused (its conflicts span ranks).  A rank whose share
+ * of 2048 doubles besides the 32-double record); ONE_TO_ONE resolves its conflicts over the ranks by a minimum
+ * all-reduce of the per-target (distance, query) keys -- with the native communicator and a sharded TARGET
+ * (pclhip_icp_set_region: every rank holds the whole source, so query indices are global; 8 bytes per target point
+ * travel per iteration); with source slabs or an all-reduce hook it is refused.  A rank whose share
  * of the source is empty still issues those collectives (with zero histograms), in step with its peers.  With the SOURCE
  * cut into slabs, TRIMMED breaks exact distance ties at the cut by the rank-LOCAL query index (every rank's indices
  * restart at 0): the number of pairs kept is the single-GPU run's, which of several exactly tied pairs survive may not

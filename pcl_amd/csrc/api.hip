@@ -436,10 +436,14 @@ pclhip_status pclhip::sharded_filters_ok(pclhip_icp* icp) {
     // statistic, which the ranks find together (the histograms of the selection are all-reduced, rejectors.hip).  The
     // reciprocal test needs the whole moved source on the rank: fine when the TARGET is sharded (a region is set: the
     // source is replicated; the served-group lists stand aside), not when the source is cut into slabs.  OneToOne
-    // resolves conflicts between pairs that different ranks serve (a target point in two halos): not supported.
+    // resolves conflicts between pairs that different ranks serve (a target point in two halos): the per-target minimum
+    // keys are reduced over the ranks (ncclMin on 64-bit keys) -- with the native communicator and a sharded TARGET, where
+    // every rank holds the whole source and query indices are global; with source slabs the indices are rank-local.
     for (const pclhip_rejector& r : icp->rejectors) {
-      if (r.kind == PCLHIP_REJ_ONE_TO_ONE) {
-        set_error(ctx, "multi-GPU (all-reduce) iterations do not support the OneToOne rejector: its conflicts span ranks");
+      if (r.kind == PCLHIP_REJ_ONE_TO_ONE && (icp->comm == nullptr || icp->region.on == 0)) {
+        set_error(ctx, "the OneToOne rejector under multi-GPU iterations needs the native communicator (pclhip_icp_set_comm) "
+                       "and a sharded target (pclhip_icp_set_region): with source slabs or an all-reduce hook its conflicts "
+                       "cannot be resolved");
         return PCLHIP_ERR_STATE;
       }
     }

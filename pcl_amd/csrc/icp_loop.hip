@@ -219,6 +219,23 @@ pclhip_status allreduce_doubles(pclhip_icp* icp, double* device_buf, int count) 
 
 pclhip_status allreduce_record(pclhip_icp* icp) { return allreduce_doubles(icp, icp->sums_dev, PCLHIP_ICP_NSUMS); }
 
+// element-wise MINIMUM of 64-bit keys over the ranks (the OneToOne rejector under target sharding: per target point the
+// smallest (distance, query) key any rank holds).  Native communicator only: the caller's hook sums doubles.
+pclhip_status allreduce_min_u64(pclhip_icp* icp, unsigned long long* device_buf, size_t count) {
+  pclhip_ctx* ctx = icp->ctx;
+  if (icp->comm == nullptr) {
+    set_error(ctx, "a minimum over the ranks needs the native communicator (pclhip_icp_set_comm)");
+    return PCLHIP_ERR_STATE;
+  }
+  constexpr int kNcclUint64 = 5, kNcclMin = 3;  // ncclDataType_t::ncclUint64, ncclRedOp_t::ncclMin (rccl.h)
+  const int rc = rccl().AllReduce(device_buf, device_buf, count, kNcclUint64, kNcclMin, icp->comm->comm, ctx->stream);
+  if (rc != 0) {
+    set_error(ctx, "ncclAllReduce(min): " + nccl_error(rc));
+    return PCLHIP_ERR_HIP;
+  }
+  return PCLHIP_OK;
+}
+
 bool icp_is_sharded(const pclhip_icp* icp) { return icp->comm != nullptr || icp->allreduce != nullptr; }
 
 // ---------------------------------------------------------------------------------------------------

@@ -491,6 +491,7 @@ pclhip_status owned_groups_catch_up(pclhip_icp* icp, int mode);
 // for a single-GPU registration
 pclhip_status allreduce_record(pclhip_icp* icp);
 pclhip_status allreduce_doubles(pclhip_icp* icp, double* device_buf, int count);  // any buffer (rejector histograms)
+pclhip_status allreduce_min_u64(pclhip_icp* icp, unsigned long long* device_buf, size_t count);  // native communicator only
 // The reciprocal test as one seeded search (search.hip): slot i asks the SOURCE index for the nearest neighbour of its
 // matched target point, seeded by source point i itself (the index's positions are the source's slots), and drops the pair unless that is
 // the answer (impl/correspondence_estimation.hpp:247-270).  Stream-ordered, no wait.

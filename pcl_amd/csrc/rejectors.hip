@@ -403,6 +403,10 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
         PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(best, 0xFF, nt * 8, s));
         hipLaunchKernelGGL(rej_o2o_min_kernel, grid, block, 0, s, icp->src_cur, icp->match, icp->match_d2, icp->keep, n,
                            best);
+        if (icp_is_sharded(icp)) {  // target slabs: a target point of two halos may be matched on two ranks -- the global minimum wins
+          const pclhip_status sm = allreduce_min_u64(icp, best, nt);
+          if (sm != PCLHIP_OK) return sm;
+        }
         hipLaunchKernelGGL(rej_o2o_keep_kernel, grid, block, 0, s, icp->src_cur, icp->match, icp->match_d2, n, best,
                            icp->keep);
         icp->fetch_order = 1;

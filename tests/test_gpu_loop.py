@@ -243,8 +243,8 @@ def test_native_communicator_single_rank(gpu):
         res.append((icp.getFinalTransformation().copy(), icp.nr_iterations_))
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
     # MedianDistance / Trimmed under a communicator: the histograms of their selection are all-reduced (here over one rank:
-    # the collective runs, the numbers are the unsharded chain's); OneToOne and -- without a region: the source would be
-    # sharded -- reciprocal correspondences are refused
+    # the collective runs, the numbers are the unsharded chain's); OneToOne and reciprocal correspondences are refused
+    # without a region (the source would be the sharded side) and run with one
     res = []
     for use in (False, True):
         icp = _make_icp(gpu, tgt, src, 1, nrm)
@@ -263,8 +263,19 @@ def test_native_communicator_single_rank(gpu):
         if use:
             assert np.array_equal(res[0][0], res[1][0]) and res[0][1:] == res[1][1:]
             icp.addCorrespondenceRejector(pcl_amd.CorrespondenceRejectorOneToOne())
-            with pytest.raises(pcl_amd.PclHipError, match="OneToOne"):
+            with pytest.raises(pcl_amd.PclHipError, match="OneToOne"):   # no region: the SOURCE would be the sharded side
                 icp.align()
+            # with the target sharded (one slab owning everything) the per-target minimum keys go through ncclAllReduce
+            # (ncclUint64, ncclMin) -- over one rank the identity: the unsharded chain's result
+            icp.setRegion([-np.inf] * 3 + [np.inf] * 3)
+            icp.align()
+            ref = _make_icp(gpu, tgt, src, 1, nrm)
+            for r in (a, b, d, pcl_amd.CorrespondenceRejectorOneToOne()):
+                ref.addCorrespondenceRejector(r)
+            ref.align()
+            assert icp.nr_iterations_ == ref.nr_iterations_
+            assert np.array_equal(icp.getFinalTransformation(), ref.getFinalTransformation())
+            assert len(icp.fetchCorrespondences()[0]) == len(ref.fetchCorrespondences()[0])
             icp2 = _make_icp(gpu, tgt, src, 1, nrm)
             icp2.setCommunicator(comm)
             icp2.setUseReciprocalCorrespondences(True)

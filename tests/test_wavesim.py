@@ -105,7 +105,7 @@ def test_gpu_parity_tests_run_on_the_emulation(wavesim_lib):
 
 
 @pytest.mark.parametrize("mode,world", [("target", 2), ("source", 2), ("target", 3), ("target+rej", 2), ("source+rej", 2),
-                                        ("target+recip", 2), ("source+rej+empty", 3)])
+                                        ("target+recip", 2), ("source+rej+empty", 3), ("target+o2o", 2)])
 def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, world):
     """An N > 1 execution of the library's own multi-GPU code, which the one-GPU box of a round cannot give: `world`
     PROCESSES, each with its own (emulated) device, a native communicator created from one shared id (pclhip_comm_*; the
@@ -117,7 +117,9 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
     Trimmed + Distance chain inside the loop -- the histograms of the two selections are all-reduced, so every rank cuts at
     the single-GPU run's thresholds; "+recip": reciprocal correspondences with the target sharded (the whole source on every
     rank, the served-group lists standing aside); "+empty": the last rank's share of the source is EMPTY -- it has nothing to
-    filter but still issues the chain's histogram all-reduces, in step with its peers."""
+    filter but still issues the chain's histogram all-reduces, in step with its peers; "+o2o": the OneToOne
+    rejector with the target sharded -- a target point that lies in two halos can be matched on two ranks, the smallest
+    (distance, query) key over the ranks wins (a minimum all-reduce of the per-target keys), as on one GPU."""
     import numpy as np
     n = 60_000
     mode, _, extra = mode.partition("+")
@@ -140,6 +142,8 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
                        "[icp.addCorrespondenceRejector(r) for r in (a, b, d)]\n")
     if "recip" in extras:
         extra_lines = "icp.setUseReciprocalCorrespondences(True)\n"
+    if "o2o" in extras:
+        extra_lines = "icp.addCorrespondenceRejector(pcl_amd.CorrespondenceRejectorOneToOne())\n"
     code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
             "import pcl_amd; from pcl_amd import synth\n"
             "tgt, src, _ = synth.icp_pair(%d); ctx = pcl_amd.Context(0)\n"
@@ -150,8 +154,9 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
             "icp.setMaximumIterations(20); icp.setMaxCorrespondenceDistance(0.1); icp.setTransformationEpsilon(1e-10)\n"
             "%s"
             "icp.align()\n"
+            "kept = len(icp.fetchCorrespondences()[0])\n"
             "np.savez(%r, T=icp.getFinalTransformation(), iterations=icp.nr_iterations_, fitness=icp.getFitnessScore(0.01),\n"
-            "         fitness_points=icp.fitness_points)\n" % (ROOT, n, extra_lines, os.path.join(work, "single.npz")))
+            "         fitness_points=icp.fitness_points, kept_after_align=kept)\n" % (ROOT, n, extra_lines, os.path.join(work, "single.npz")))
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     one = np.load(os.path.join(work, "single.npz"))
@@ -165,6 +170,10 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
     else:
         assert all(int(r_["served"]) > 0 for r_ in ranks)                   # every rank had work
     assert sum(int(r_["served"]) for r_ in ranks) in set(int(c) for c in ranks[0]["counts"])
+    if mode == "target":
+        # what the ranks kept in the alignment's last iteration adds up to what the single process kept: under the rejector
+        # chains the cuts (medians, trim ranks, one-to-one winners) are the single-GPU run's, pair for pair
+        assert sum(int(r_["kept_after_align"]) for r_ in ranks) == int(one["kept_after_align"])
     if not extra:
         assert int(ranks[0]["counts"][0]) == n
     else:

@@ -78,11 +78,14 @@ if "rej" in extras:
     d.setMaximumDistance(0.05)
     for r in (a, b, d):
         icp.addCorrespondenceRejector(r)
+if "o2o" in extras:   # OneToOne under TARGET sharding: the per-target minimum keys are reduced over the ranks
+    icp.addCorrespondenceRejector(pcl_amd.CorrespondenceRejectorOneToOne())
 if "recip" in extras:
     icp.setUseReciprocalCorrespondences(True)
 icp.align()
 T = icp.getFinalTransformation().copy()
 iters = icp.nr_iterations_
+kept_after_align = len(icp.fetchCorrespondences()[0])   # the pairs of the last iteration that this rank serves and the chain kept
 # the measurement loop of bench.py on top: whole alignments queued back to back, records all-reduced
 steps = icp.runSteps(6)
 served = len(icp.fetchCorrespondences()[0])
@@ -90,4 +93,4 @@ fit = icp.getFitnessScore(0.01)
 np.savez(os.path.join(work, "rank%d.npz" % rank), T=T, iterations=iters, converged=icp.hasConverged(),
          counts=np.asarray([s["num_correspondences"] for s in steps], np.float64),
          step_iterations=np.asarray([s["iteration"] for s in steps]), served=served, index_points=tree.size(),
-         fitness=fit, fitness_points=icp.fitness_points)
+         fitness=fit, fitness_points=icp.fitness_points, kept_after_align=kept_after_align)

@@ -534,14 +534,34 @@ __attribute__((visibility("hidden"))) int ncclCommDestroy(void* comm) {
 __attribute__((visibility("hidden"))) int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op,
                                                                  void* comm, hipStream_t) {
   FakeComm* c = static_cast<FakeComm*>(comm);
-  if (!c || dtype != 8 || op != 0 || count > size_t(NCCL_MAX_COUNT)) return 4;  // ncclFloat64, ncclSum
-  std::memcpy(c->shm->slots[c->rank], send, count * sizeof(double));
-  if (!shm_barrier(c)) return 3;
-  double* out = static_cast<double*>(recv);
-  for (size_t i = 0; i < count; ++i) {
-    double s = 0.0;
-    for (int r = 0; r < c->nranks; ++r) s += c->shm->slots[r][i];
-    out[i] = s;
+  const bool sum_f64 = dtype == 8 && op == 0, min_u64 = dtype == 5 && op == 3;  // (ncclFloat64, ncclSum) / (ncclUint64, ncclMin)
+  if (!c || !(sum_f64 || min_u64)) return 4;
+  // any count: NCCL_MAX_COUNT 8-byte elements at a time (write my operand, barrier, combine in rank order, barrier)
+  for (size_t at = 0; at < count || (count == 0 && at == 0); at += NCCL_MAX_COUNT) {
+    const size_t m = count - at < size_t(NCCL_MAX_COUNT) ? count - at : size_t(NCCL_MAX_COUNT);
+    std::memcpy(c->shm->slots[c->rank], static_cast<const char*>(send) + at * 8, m * 8);
+    if (!shm_barrier(c)) return 3;
+    if (sum_f64) {
+      double* out = static_cast<double*>(recv) + at;
+      for (size_t i = 0; i < m; ++i) {
+        double s = 0.0;
+        for (int r = 0; r < c->nranks; ++r) s += c->shm->slots[r][i];
+        out[i] = s;
+      }
+    } else {
+      unsigned long long* out = static_cast<unsigned long long*>(recv) + at;
+      for (size_t i = 0; i < m; ++i) {
+        unsigned long long v = ~0ull;
+        for (int r = 0; r < c->nranks; ++r) {
+          unsigned long long x;
+          std::memcpy(&x, &c->shm->slots[r][i], 8);
+          v = x < v ? x : v;
+        }
+        out[i] = v;
+      }
+    }
+    if (count == 0) break;
+    if (at + NCCL_MAX_COUNT < count && !shm_barrier(c)) return 3;  // the next chunk overwrites the slots
   }
   if (!shm_barrier(c)) return 3;  // nobody overwrites its slot before everybody has read it
   return 0;
