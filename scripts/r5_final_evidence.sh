@@ -10,6 +10,7 @@ TAG=${1:-r5final}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export GRAFT_COMMIT=${GRAFT_COMMIT:-unknown}
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 ( time timeout 1500 python -m pytest tests -m gpu -q ) > $OUT/tests.log 2>&1; grep -E "passed|failed|real" $OUT/tests.log | tail -2
 bash scripts/profile_gpu.sh $TAG "trace sq1 sq2 fetch write" > $OUT/prof.log 2>&1
 cp gpurun_out/prof_$TAG/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
