@@ -98,10 +98,10 @@ def test_gpu_parity_tests_run_on_the_emulation(wavesim_lib):
     keyword = NOT_HERE if os.environ.get("WAVESIM_FULL") == "1" else NOT_HERE + " and " + SLOW
     out = run_gpu_tests_on_the_emulation(
         wavesim_lib, ["test_gpu_parity.py", "test_gpu_loop.py", "test_gpu_dist.py", "test_gpu_fuzz.py",
-                      "test_gpu_cpp_adapters.py"], keyword)
+                      "test_gpu_cpp_adapters.py", "test_gpu_lane.py"], keyword)
     last = [ln for ln in out.splitlines() if " passed" in ln][-1]
     print(last)
-    assert int(last.split(" passed")[0].split()[-1]) >= 90, last
+    assert int(last.split(" passed")[0].split()[-1]) >= 140, last
 
 
 @pytest.mark.parametrize("mode,world", [("target", 2), ("source", 2), ("target", 3), ("target+rej", 2), ("source+rej", 2),
@@ -248,7 +248,8 @@ def test_kernels_and_host_api_under_asan_ubsan(tmp_path):
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=0")
     cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k", NOT_HERE + " and not cpp_adapters and not c_example",
            os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_loop.py"),
-           os.path.join(ROOT, "tests", "test_gpu_dist.py"), os.path.join(ROOT, "tests", "test_gpu_fuzz.py")]
+           os.path.join(ROOT, "tests", "test_gpu_dist.py"), os.path.join(ROOT, "tests", "test_gpu_fuzz.py"),
+           os.path.join(ROOT, "tests", "test_gpu_lane.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=3000)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
