@@ -23,15 +23,8 @@ ICP_KW = dict(max_iterations=20, max_correspondence_distance=0.1, transformation
 
 @pytest.fixture(scope="module")
 def gpu():
-    # PCLHIP_TEST_OPTIONS="lane_search=1,..." (read by THIS test module, not by the library): the same full-size checks
-    # with context options set, e.g. the per-lane seeded search at 10M points (profiles/r05_lane_search_fullsize.txt)
-    import os
-    import pcl_amd
-    ctx = pcl_amd.Context(0)
-    for kv in [o for o in os.environ.get("PCLHIP_TEST_OPTIONS", "").split(",") if o]:
-        name, _, value = kv.partition("=")
-        ctx.setOption(name, float(value))
-    return ctx
+    from conftest import make_context      # PCLHIP_TEST_OPTIONS: tests/conftest.py
+    return make_context(0)
 
 
 @pytest.fixture(scope="module")

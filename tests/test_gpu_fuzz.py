@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def gpu():
     import pcl_amd
-    return pcl_amd.Context(0)
+    from conftest import make_context
+    return make_context(0)
 
 
 @pytest.fixture(scope="module")

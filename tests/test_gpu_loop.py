@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def gpu():
     import pcl_amd
-    return pcl_amd.Context(0)
+    from conftest import make_context
+    return make_context(0)
 
 
 def _make_icp(gpu, tgt, src, mode, normals=None):

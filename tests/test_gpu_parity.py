@@ -18,7 +18,8 @@ def xyz1(a):
 @pytest.fixture(scope="module")
 def gpu():
     import pcl_amd
-    return pcl_amd.Context(0)
+    from conftest import make_context
+    return make_context(0)
 
 
 @pytest.fixture(scope="module")
