@@ -237,3 +237,17 @@ def test_lane_search_counters(lane):
     assert c[2] + c[4] == c[0]                                    # every query is finished by exactly one of the passes
     assert c[1] > 0.4 * c[0] and c[2] > 0.7 * c[0], list(c)
     assert c[3] == 0                                              # no seed was far
+
+
+def test_index_cells_argument_checks(gpu):
+    import pcl_amd
+    cloud = make_cloud("cube", 5000, 3)
+    tree = pcl_amd.KdTree(gpu)
+    tree.setInputCloud(cloud)
+    boxes, cells, top = tree.cells(0)
+    counts = [len(tree.cells(q)[0]) for q in range(top + 1)]
+    assert top == 5 and counts == [313, 79, 20, 5, 2, 1]           # ceil(313 / 4^q): the levels lie one after the other
+    with pytest.raises(pcl_amd.PclHipError, match="level out of range"):
+        tree.cells(top + 1)
+    with pytest.raises(pcl_amd.PclHipError, match="level out of range"):
+        tree.cells(-1)
