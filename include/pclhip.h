@@ -15,8 +15,14 @@
  *    +16, common/include/pcl/impl/point_types.hpp:315-321,843-853).  Buffers may live in host OR
  *    device memory -- the library detects which (hipPointerGetAttributes) and stages host data.
  *  - index_t is int32 (common/include/pcl/types.h:110-133); "no neighbour" is -1, distance +inf.
- *  - a handle is not thread-safe; distinct contexts may be used concurrently.  All work of a
- *    context is issued on its HIP stream; entry points that return host results synchronise it.
+ *  - a handle is not thread-safe, with one exception: the QUERY entry points pclhip_knn and
+ *    pclhip_radius_search may be called concurrently on one index / context (PCL calls its `const`
+ *    search virtuals from OpenMP loops: registration/.../impl/correspondence_estimation.hpp:163-175,
+ *    features/.../impl/normal_3d_omp.hpp:76-81, search/.../impl/search.hpp:164-190); such callers are
+ *    served one after the other (a lock of the context), not in parallel.  Building, destroying or
+ *    aligning on the same context meanwhile is the caller's race.  Distinct contexts may be used
+ *    concurrently.  All work of a context is issued on its HIP stream; entry points that return host
+ *    results synchronise it.
  *  - results: k-NN indices/distances are bit-exact w.r.t. the CPU oracle (float L2_Simple
  *    ((dx*dx)+dy*dy)+dz*dz, ascending (distance, index), ties -> lower index).
  */
@@ -307,7 +313,11 @@ PCLHIP_API pclhip_status pclhip_icp_reset(pclhip_icp* icp);
  * of 2048 doubles besides the 32-double record); ONE_TO_ONE resolves its conflicts over the ranks by a minimum
  * all-reduce of the per-target (distance, query) keys -- with the native communicator and a sharded TARGET
  * (pclhip_icp_set_region: every rank holds the whole source, so query indices are global; 8 bytes per target point
- * travel per iteration); with source slabs or an all-reduce hook it is refused.  A rank whose share
+ * travel per iteration); with source slabs or an all-reduce hook it is refused.  PRECONDITION of that mode: the keys are
+ * indexed by the ORIGINAL target index, so every rank must have built its index over the same WHOLE cloud plus its own
+ * subset list (pclhip_index_build(points, ..., indices = pclhip_select_region(...)), as pcl_amd.dist.ShardedTarget does) --
+ * not over a cloud that holds only its slab; the first iteration checks that all ranks report the same cloud size and
+ * returns PCLHIP_ERR_STATE on every rank otherwise.  A rank whose share
  * of the source is empty still issues those collectives (with zero histograms), in step with its peers.  With the SOURCE
  * cut into slabs, TRIMMED breaks exact distance ties at the cut by the rank-LOCAL query index (every rank's indices
  * restart at 0): the number of pairs kept is the single-GPU run's, which of several exactly tied pairs survive may not

@@ -179,7 +179,11 @@ class KdTreeHIP : public pcl::search::KdTree<PointT> {
   void setEpsilon(float eps) override { eps_ = eps; }  // the search is exact: an error bound is trivially met
   float getEpsilon() const override { return eps_; }
 
-  // kdtree/include/pcl/kdtree/impl/kdtree_flann.hpp:234-274 (one launch per call: API parity, not the fast path)
+  // kdtree/include/pcl/kdtree/impl/kdtree_flann.hpp:234-274 (one launch per call: API parity, not the fast path).
+  // The `const` per-point searches may be called from several threads at once, as PCL's OpenMP loops do
+  // (registration/.../impl/correspondence_estimation.hpp:163-175 with setNumberOfThreads, features/.../normal_3d_omp.hpp
+  // :76-81, search/.../impl/search.hpp:164-190): pclhip_knn / pclhip_radius_search serialise on the context (pclhip.h),
+  // and nothing of this object is written by them.
   int nearestKSearch(const PointT& p, int k, pcl::Indices& k_indices, std::vector<float>& k_sqr_distances) const override {
     k_indices.clear();
     k_sqr_distances.clear();
@@ -244,6 +248,40 @@ class KdTreeHIP : public pcl::search::KdTree<PointT> {
       return 0;
     }
     return int(total);
+  }
+  // the batch overload (search.h:349-355; the default, impl/search.hpp:164-190, is an OpenMP loop over the per-point
+  // virtual): ONE pclhip_radius_search for the whole cloud, the lists handed out from its CSR result
+  void radiusSearch(const pcl::PointCloud<PointT>& cloud, const pcl::Indices& indices, double radius,
+                    std::vector<pcl::Indices>& k_indices, std::vector<std::vector<float>>& k_sqr_distances,
+                    unsigned int max_nn = 0) const override {
+    k_indices.clear();
+    k_sqr_distances.clear();
+    if (!index_ || unsupported_) return;
+    std::vector<PointT> gathered;
+    const PointT* q = cloud.points.data();
+    std::size_t nq = cloud.size();
+    if (!indices.empty()) {
+      gathered.reserve(indices.size());
+      for (pcl::index_t i : indices) gathered.push_back(cloud[size_t(i)]);
+      q = gathered.data();
+      nq = gathered.size();
+    }
+    k_indices.assign(nq, pcl::Indices());
+    k_sqr_distances.assign(nq, std::vector<float>());
+    if (nq == 0) return;
+    std::vector<std::uint64_t> off(nq + 1, 0);
+    std::uint64_t total = 0;
+    const pclhip_status st = pclhip_radius_search(index_, q, sizeof(PointT), nq, radius, max_nn, off.data(), nullptr, nullptr, 0, &total);
+    if ((st != PCLHIP_OK && st != PCLHIP_ERR_OVERFLOW) || total == 0) return;
+    pcl::Indices flat_i(size_t(total), 0);
+    std::vector<float> flat_d(size_t(total), 0.0f);
+    if (pclhip_radius_search(index_, q, sizeof(PointT), nq, radius, max_nn, off.data(), flat_i.data(), flat_d.data(), total,
+                             &total) != PCLHIP_OK)
+      return;
+    for (std::size_t i = 0; i < nq; ++i) {
+      k_indices[i].assign(flat_i.begin() + long(off[i]), flat_i.begin() + long(off[i + 1]));
+      k_sqr_distances[i].assign(flat_d.begin() + long(off[i]), flat_d.begin() + long(off[i + 1]));
+    }
   }
   pclhip_index* handle() const { return index_; }
   std::uint64_t generation() const { return generation_; }  // bumped by every setInputCloud
@@ -369,13 +407,20 @@ class RegistrationHIP : public Base {
   struct Timings { double upload_ms = 0, loop_ms = 0, output_ms = 0; };
   const Timings& lastTimings() const { return timings_; }
   int iterations() const { return this->nr_iterations_; }  // of the last align() (PCL keeps nr_iterations_ protected)
-  // Registration::getFitnessScore (impl/registration.hpp:132-168) on the device (after an align())
-  double getFitnessScore(double max_range = std::numeric_limits<double>::max()) override {
-    if (!icp_) return Base::getFitnessScore(max_range);
+  // Registration::getFitnessScore (registration.h:450-452, impl/registration.hpp:132-168) on the device, after an align().
+  // The reference's is NOT virtual: this one HIDES it -- called on the HIP class it scores on the device in one launch; a
+  // caller holding a pcl::Registration* gets PCL's own loop, which reaches the same index point by point through
+  // KdTreeHIP::nearestKSearch (same value, one launch per point).  The device holds the source as the last align()
+  // uploaded it -- the whole cloud, or the user's index subset --: when the reference would score the other set
+  // (use_indices, :141-144), PCL's loop runs.
+  double getFitnessScore(double max_range = std::numeric_limits<double>::max(), bool use_indices = false) {
+    const bool subset = this->indices_ && this->input_ && this->indices_->size() != this->input_->size();
+    if (!icp_ || source_uploaded_ != this->input_.get() || (subset && use_indices != source_subset_) || (!subset && source_subset_))
+      return Base::getFitnessScore(max_range, use_indices);
     float T[16];
     to_rows(this->final_transformation_, T);
     double score = std::numeric_limits<double>::max();
-    pclhip_icp_fitness_score(icp_, T, max_range, &score, nullptr);
+    if (pclhip_icp_fitness_score(icp_, T, max_range, &score, nullptr) != PCLHIP_OK) return Base::getFitnessScore(max_range, use_indices);
     return score;
   }
 

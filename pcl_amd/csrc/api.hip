@@ -814,16 +814,60 @@ pclhip_status pclhip_index_cells(pclhip_index* ix, int level, float* boxes, floa
   return PCLHIP_OK;
 }
 
+// The per-point calls of PCL's search virtuals (Search::nearestKSearch(point, k, ...), one query at a time --
+// impl/correspondence_estimation.hpp:163-175): at most one wavefront of host queries with host results goes through ONE
+// pinned block -- the queries are written into it in the index's space, the kernel reads them and writes its rows there,
+// one launch and one wait; no staging copy, no ordering pass (a single group needs none), no device allocation.
+constexpr uint64_t KNN_FEW_QUERIES = 64;
+constexpr int KNN_FEW_K = 32;
+static pclhip_status knn_few(pclhip_index* ix, const void* queries, size_t stride, uint32_t nq, int k, int32_t* out_idx,
+                             float* out_d2) {
+  pclhip_ctx* ctx = ix->ctx;
+  constexpr size_t Q_BYTES = KNN_FEW_QUERIES * sizeof(float4), ROW = KNN_FEW_QUERIES * size_t(KNN_FEW_K);
+  constexpr size_t BYTES = Q_BYTES + ROW * (sizeof(int32_t) + sizeof(float));  // one size: the pinned cache always hits
+  void* blk = nullptr;
+  PCLHIP_CHECK_HIP(ctx, pinned_malloc(ctx, &blk, BYTES));
+  float4* q = static_cast<float4*>(blk);
+  int32_t* ri = reinterpret_cast<int32_t*>(static_cast<char*>(blk) + Q_BYTES);
+  float* rd = reinterpret_cast<float*>(ri + ROW);
+  for (uint32_t i = 0; i < nq; ++i) {
+    const float* p = reinterpret_cast<const float*>(static_cast<const char*>(queries) + size_t(i) * stride);
+    float x = p[0], y = p[1], z = p[2];
+    if (ix->scaled) {  // the index's (rescaled) space, as kd_load_kernel maps the records
+      x = ix->scale[0] == 0.0f ? 0.0f : x * ix->scale[0];
+      y = ix->scale[1] == 0.0f ? 0.0f : y * ix->scale[1];
+      z = ix->scale[2] == 0.0f ? 0.0f : z * ix->scale[2];
+    }
+    float w;
+    std::memcpy(&w, &i, sizeof(w));
+    q[i] = make_float4(x, y, z, w);
+  }
+  pclhip_status st = launch_knn(ix, q, nq, k, ri, rd);
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (st == PCLHIP_OK && e == hipSuccess) {
+    std::memcpy(out_idx, ri, size_t(nq) * size_t(k) * sizeof(int32_t));
+    std::memcpy(out_d2, rd, size_t(nq) * size_t(k) * sizeof(float));
+  }
+  pinned_free(ctx, blk, BYTES);
+  if (st != PCLHIP_OK) return st;
+  PCLHIP_CHECK_HIP(ctx, e);
+  return PCLHIP_OK;
+}
+
 pclhip_status pclhip_knn(pclhip_index* ix, const void* queries, size_t stride, uint64_t nq, int k, int32_t* out_idx,
                          float* out_d2) {
   if (!ix) return PCLHIP_ERR_INVALID;
   pclhip_ctx* ctx = ix->ctx;
+  std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mutex);  // safe under concurrent callers (pclhip.h)
   PCLHIP_REQUIRE(ctx, k >= 1, "k must be >= 1");
   PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
   PCLHIP_REQUIRE(ctx, nq < 0x7FFFFFFFull, "too many queries");
   if (nq == 0) return PCLHIP_OK;
   PCLHIP_REQUIRE(ctx, queries && out_idx && out_d2, "null buffer");
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  if (nq <= KNN_FEW_QUERIES && k <= KNN_FEW_K && !is_device_pointer(queries) && !is_device_pointer(out_idx) &&
+      !is_device_pointer(out_d2))
+    return knn_few(ix, queries, stride, uint32_t(nq), k, out_idx, out_d2);
   DeviceGuard guard(ctx);
   const void* dq = nullptr;
   void* owned = nullptr;

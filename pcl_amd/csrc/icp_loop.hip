@@ -23,6 +23,7 @@
 #include <cstring>
 
 #include "pclhip_internal.hpp"
+#include "rccl_abi.hpp"  // the by-value constants of RCCL's ABI; checked against <rccl/rccl.h> by rccl_abi_check.cpp
 
 using namespace pclhip;
 
@@ -39,19 +40,20 @@ __attribute__((weak)) void ncclGetUniqueId();
 __attribute__((weak)) void ncclCommInitRank();
 __attribute__((weak)) void ncclCommDestroy();
 __attribute__((weak)) void ncclAllReduce();
+__attribute__((weak)) void ncclGetVersion();
 }
 static void (*const pclhip_weak_ncclGetUniqueId)() = &ncclGetUniqueId;
 static void (*const pclhip_weak_ncclCommInitRank)() = &ncclCommInitRank;
 static void (*const pclhip_weak_ncclCommDestroy)() = &ncclCommDestroy;
 static void (*const pclhip_weak_ncclAllReduce)() = &ncclAllReduce;
+static void (*const pclhip_weak_ncclGetVersion)() = &ncclGetVersion;
 
 namespace {
 
 struct NcclUniqueId {
-  char internal[128];  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+  char internal[rccl_abi::kUniqueIdBytes];  // ncclUniqueId
 };
 typedef void* NcclComm;
-enum { kNcclFloat64 = 8, kNcclSum = 0 };  // ncclDataType_t::ncclFloat64 / ncclDouble, ncclRedOp_t::ncclSum
 
 struct RcclApi {
   int (*GetUniqueId)(NcclUniqueId*) = nullptr;
@@ -59,9 +61,36 @@ struct RcclApi {
   int (*CommDestroy)(NcclComm) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
   bool ok = false;
   std::string why;
 };
+
+// The constants of rccl_abi.hpp belong to NCCL/RCCL major version 2: whatever library the entry points resolved to (this
+// process may carry another build than the ROCm this was compiled with) must say it is one.  A library without
+// ncclGetVersion is accepted only when it was LINKED in (the stand-in of the test tier's emulation).
+void check_rccl_version(RcclApi& a, bool linked_in) {
+  if (!a.ok) return;
+  if (a.GetVersion == nullptr) {
+    if (!linked_in) {
+      a.ok = false;
+      a.why = "the RCCL library has no ncclGetVersion: its ABI cannot be checked";
+    }
+    return;
+  }
+  int v = 0;
+  if (a.GetVersion(&v) != rccl_abi::kSuccess) {
+    a.ok = false;
+    a.why = "ncclGetVersion failed";
+    return;
+  }
+  const int major = v >= 10000 ? v / 10000 : v / 1000;  // NCCL_VERSION: major * 10000 + ... since 2.9, major * 1000 + ... before
+  if (major != rccl_abi::kMajor) {
+    a.ok = false;
+    a.why = "RCCL version " + std::to_string(v) + " is not major version " + std::to_string(rccl_abi::kMajor) +
+            ": the enum values this library passes were not checked against it";
+  }
+}
 
 RcclApi& rccl() {
   static RcclApi api = [] {
@@ -73,7 +102,9 @@ RcclApi& rccl() {
       a.CommInitRank = reinterpret_cast<int (*)(NcclComm*, int, NcclUniqueId, int)>(pclhip_weak_ncclCommInitRank);
       a.CommDestroy = reinterpret_cast<int (*)(NcclComm)>(pclhip_weak_ncclCommDestroy);
       a.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, NcclComm, hipStream_t)>(pclhip_weak_ncclAllReduce);
+      if (pclhip_weak_ncclGetVersion != nullptr) a.GetVersion = reinterpret_cast<int (*)(int*)>(pclhip_weak_ncclGetVersion);
       a.ok = true;
+      check_rccl_version(a, true);
       return a;
     }
     void* h = nullptr;
@@ -98,8 +129,10 @@ RcclApi& rccl() {
     a.AllReduce =
         reinterpret_cast<int (*)(const void*, void*, size_t, int, int, NcclComm, hipStream_t)>(sym("ncclAllReduce"));
     a.GetErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
+    a.GetVersion = reinterpret_cast<int (*)(int*)>(sym("ncclGetVersion"));
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
     if (!a.ok) a.why = "the RCCL library lacks a required symbol";
+    check_rccl_version(a, false);
     return a;
   }();
   return api;
@@ -133,7 +166,7 @@ pclhip_status pclhip_comm_get_unique_id(unsigned char id[PCLHIP_COMM_ID_BYTES]) 
     set_error(nullptr, "ncclGetUniqueId: " + nccl_error(rc));
     return PCLHIP_ERR_HIP;
   }
-  static_assert(sizeof(NcclUniqueId) == PCLHIP_COMM_ID_BYTES, "id size");
+  static_assert(sizeof(NcclUniqueId) == PCLHIP_COMM_ID_BYTES && rccl_abi::kUniqueIdBytes == PCLHIP_COMM_ID_BYTES, "id size");
   std::memcpy(id, &u, sizeof u);
   return PCLHIP_OK;
 }
@@ -183,7 +216,7 @@ pclhip_status pclhip_comm_allreduce_sum_f64(pclhip_comm* comm, double* device_bu
   if (!comm || !device_buf || count < 0) return PCLHIP_ERR_INVALID;
   pclhip_ctx* ctx = comm->ctx;
   PCLHIP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-  const int rc = rccl().AllReduce(device_buf, device_buf, size_t(count), kNcclFloat64, kNcclSum, comm->comm, ctx->stream);
+  const int rc = rccl().AllReduce(device_buf, device_buf, size_t(count), rccl_abi::kFloat64, rccl_abi::kSum, comm->comm, ctx->stream);
   if (rc != 0) {
     set_error(ctx, "ncclAllReduce: " + nccl_error(rc));
     return PCLHIP_ERR_HIP;
@@ -227,12 +260,41 @@ pclhip_status allreduce_min_u64(pclhip_icp* icp, unsigned long long* device_buf,
     set_error(ctx, "a minimum over the ranks needs the native communicator (pclhip_icp_set_comm)");
     return PCLHIP_ERR_STATE;
   }
-  constexpr int kNcclUint64 = 5, kNcclMin = 3;  // ncclDataType_t::ncclUint64, ncclRedOp_t::ncclMin (rccl.h)
-  const int rc = rccl().AllReduce(device_buf, device_buf, count, kNcclUint64, kNcclMin, icp->comm->comm, ctx->stream);
+  const int rc = rccl().AllReduce(device_buf, device_buf, count, rccl_abi::kUint64, rccl_abi::kMin, icp->comm->comm, ctx->stream);
   if (rc != 0) {
     set_error(ctx, "ncclAllReduce(min): " + nccl_error(rc));
     return PCLHIP_ERR_HIP;
   }
+  return PCLHIP_OK;
+}
+
+// OneToOne under target sharding indexes its per-target keys by the ORIGINAL index of the whole target cloud: every rank
+// must have indexed that same cloud (through its own subset list).  min and max of n_orig over the ranks in one collective
+// (min of {n, ~n}); a mismatch is an error on every rank, before the big all-reduce could hang or corrupt.  Once per
+// (registration, communicator).
+pclhip_status check_same_target_size(pclhip_icp* icp) {
+  pclhip_ctx* ctx = icp->ctx;
+  if (icp->comm == nullptr || icp->target_size_checked_for == icp->comm) return PCLHIP_OK;
+  unsigned long long* d = nullptr;
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &d, 16));
+  const unsigned long long n = icp->target->n_orig;
+  unsigned long long h[2] = {n, ~n};
+  pclhip_status st = PCLHIP_OK;
+  hipError_t e = hipMemcpyAsync(d, h, 16, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // h lives on this stack
+  if (e == hipSuccess) st = allreduce_min_u64(icp, d, 2);
+  if (e == hipSuccess && st == PCLHIP_OK) e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && st == PCLHIP_OK) e = hipStreamSynchronize(ctx->stream);
+  (void)dev_free(ctx, d);
+  if (st != PCLHIP_OK) return st;
+  PCLHIP_CHECK_HIP(ctx, e);
+  if (h[0] != n || ~h[1] != n) {
+    set_error(ctx, "OneToOne under target sharding: the ranks indexed target clouds of different sizes (" +
+                       std::to_string(h[0]) + " .. " + std::to_string(~h[1]) +
+                       " points): every rank must build its index over the WHOLE cloud plus its subset list");
+    return PCLHIP_ERR_STATE;
+  }
+  icp->target_size_checked_for = icp->comm;
   return PCLHIP_OK;
 }
 

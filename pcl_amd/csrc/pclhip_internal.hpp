@@ -211,6 +211,10 @@ struct pclhip_ctx {
   int opt_lane_max_up = 2;              // ... quad levels the first pass climbs before it hands a query to the second
   float opt_lane_far = 0.25f;           // ... a seed beyond this many mean leaf diagonals (squared) is replaced by a descent
   std::mutex cache_mutex;
+  // The QUERY entry points (pclhip_knn, pclhip_radius_search -- what PCL's `const` search virtuals call from OpenMP loops,
+  // registration/include/pcl/registration/impl/correspondence_estimation.hpp:163-175, features/.../normal_3d_omp.hpp:76-81)
+  // take this lock for their whole duration: concurrent callers on one context are served one after the other.
+  std::recursive_mutex api_mutex;
   // Small pinned host blocks (control blocks, step rings, mirrored states of the registrations) are kept for the
   // context's lifetime: hipHostFree synchronises the device (170 us each, three per registration object).
   std::vector<std::pair<void*, size_t>> pinned_cache;  // free blocks (pointer, bytes)
@@ -312,6 +316,7 @@ struct pclhip_icp {
   int steps_capacity = 0;
   std::vector<hipEvent_t> step_events;      // 4 per ring slot: start, after search, after accumulate, after solve
   pclhip_comm* comm = nullptr;              // native RCCL all-reduce of the record (dist.hip); not owned
+  const pclhip_comm* target_size_checked_for = nullptr;  // check_same_target_size passed with this communicator
   pclhip::RegionBox region = {{0, 0, 0}, {0, 0, 0}, 0};  // target sharding: the source points this rank serves
   // served-group lists of the device-driven loop under target sharding (one device block, made on first use)
   void* own_block = nullptr;
@@ -492,6 +497,7 @@ pclhip_status owned_groups_catch_up(pclhip_icp* icp, int mode);
 pclhip_status allreduce_record(pclhip_icp* icp);
 pclhip_status allreduce_doubles(pclhip_icp* icp, double* device_buf, int count);  // any buffer (rejector histograms)
 pclhip_status allreduce_min_u64(pclhip_icp* icp, unsigned long long* device_buf, size_t count);  // native communicator only
+pclhip_status check_same_target_size(pclhip_icp* icp);  // OneToOne under target sharding: same n_orig on every rank
 // The reciprocal test as one seeded search (search.hip): slot i asks the SOURCE index for the nearest neighbour of its
 // matched target point, seeded by source point i itself (the index's positions are the source's slots), and drops the pair unless that is
 // the answer (impl/correspondence_estimation.hpp:247-270).  Stream-ordered, no wait.

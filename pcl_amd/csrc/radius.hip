@@ -245,6 +245,7 @@ extern "C" pclhip_status pclhip_radius_search(pclhip_index* ix, const void* quer
                                               float* out_d2, uint64_t capacity, uint64_t* out_total) {
   if (!ix || !out_offsets || !out_total) return PCLHIP_ERR_INVALID;
   pclhip_ctx* ctx = ix->ctx;
+  std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mutex);  // safe under concurrent callers (pclhip.h)
   *out_total = 0;
   PCLHIP_REQUIRE(ctx, stride >= 12 && stride % 4 == 0, "stride must be a multiple of 4 and >= 12 bytes");
   PCLHIP_REQUIRE(ctx, nq < 0x7FFFFFFFull, "too many queries");

@@ -49,6 +49,13 @@ struct RsState {
 };
 constexpr int RS_BINS = 2048;
 constexpr int RS_PASSES = 6;
+// selection passes (= histogram all-reduces of a sharded run) per rejector kind: the distance's three digits for the
+// median, three more over the query index for Trimmed's ties.  ONE place: radix_select_queued runs them, a rank with an
+// empty share issues as many zero histograms (apply_empty_shard_collectives).
+constexpr int RS_PASSES_MEDIAN = 3, RS_PASSES_TRIMMED = 6;
+constexpr int rs_passes_of(int kind) {
+  return kind == PCLHIP_REJ_TRIMMED ? RS_PASSES_TRIMMED : kind == PCLHIP_REJ_MEDIAN_DISTANCE ? RS_PASSES_MEDIAN : 0;
+}
 
 template <int PASS>
 __device__ __forceinline__ void rs_count(uint32_t* h, float d, bool kept, uint32_t dkey, uint32_t ikey, const float4* cur,
@@ -258,10 +265,13 @@ pclhip_status radix_select_queued(pclhip_icp* icp, const float* d2, const uint8_
                                                    min_corr);                                                         \
     if (st_ != PCLHIP_OK) return st_;                                                                                 \
   } while (0)
+  // (the number of passes -- and with it the number of collectives of a sharded run -- is rs_passes_of(kind): the ranks
+  // with an empty share issue exactly that many, apply_empty_shard_collectives)
   RS_PASS(0);
   RS_PASS(1);
   RS_PASS(2);
-  if (kind == PCLHIP_REJ_TRIMMED) {
+  static_assert(RS_PASSES_MEDIAN == 3 && RS_PASSES_TRIMMED == 6 && RS_PASSES_TRIMMED <= RS_PASSES, "pass schedule");
+  if (rs_passes_of(kind) == RS_PASSES_TRIMMED) {
     RS_PASS(3);
     RS_PASS(4);
     RS_PASS(5);
@@ -404,6 +414,10 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
         hipLaunchKernelGGL(rej_o2o_min_kernel, grid, block, 0, s, icp->src_cur, icp->match, icp->match_d2, icp->keep, n,
                            best);
         if (icp_is_sharded(icp)) {  // target slabs: a target point of two halos may be matched on two ranks -- the global minimum wins
+          // best[] is indexed by the GLOBAL target index: every rank must have built its index over the same whole cloud
+          // plus its own subset list (pclhip.h, pclhip_icp_set_region) -- checked once per registration, not assumed
+          const pclhip_status sc = check_same_target_size(icp);
+          if (sc != PCLHIP_OK) return sc;
           const pclhip_status sm = allreduce_min_u64(icp, best, nt);
           if (sm != PCLHIP_OK) return sm;
         }
@@ -446,8 +460,14 @@ pclhip_status apply_empty_shard_collectives(pclhip_icp* icp) {
   pclhip_ctx* ctx = icp->ctx;
   int passes = 0;
   for (const pclhip_rejector& r : icp->rejectors) {
-    if (r.kind == PCLHIP_REJ_MEDIAN_DISTANCE) passes += 3;
-    if (r.kind == PCLHIP_REJ_TRIMMED) passes += 6;
+    passes += rs_passes_of(r.kind);
+    // the only other collective of the chain is OneToOne's minimum, which sharded_filters_ok admits with a sharded TARGET
+    // only -- where every rank holds the whole source, so no rank's share is empty.  Were that ever relaxed, this rank
+    // would have to issue that collective too: refuse instead of hanging RCCL.
+    if (r.kind == PCLHIP_REJ_ONE_TO_ONE) {
+      set_error(ctx, "OneToOne on a rank with an empty source share: its collective is not issued here");
+      return PCLHIP_ERR_STATE;
+    }
   }
   if (passes == 0) return PCLHIP_OK;
   Guard g;

@@ -5,11 +5,12 @@
 set -e
 name=$1; flags=$2; src=${3:-search.hip}
 obj=${src%.*}
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}; ARCH=${ARCH:-gfx950}   # the same overrides the main Makefile honours
 cd "$(dirname "$0")/../pcl_amd/csrc"
-make -j8 >/dev/null
+make -j8 HIPCC="$HIPCC" ARCH="$ARCH" >/dev/null
 mkdir -p ../variants
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-result \
+$HIPCC -O3 -std=c++17 -fPIC --offload-arch=$ARCH -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-result \
   -I../../include $flags -c $src -o ../variants/${obj}_$name.o
 objs=$(ls *.o | grep -v "^$obj.o$")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libpclhip_$name.so ../variants/${obj}_$name.o $objs -ldl
+$HIPCC --offload-arch=$ARCH -shared -fPIC -o ../variants/libpclhip_$name.so ../variants/${obj}_$name.o $objs -ldl
 echo built pcl_amd/variants/libpclhip_$name.so

@@ -6,6 +6,7 @@
 // The forwarding headers next to this file give it PCL's include paths (<pcl/search/kdtree.h> ...).
 #pragma once
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -16,6 +17,9 @@
 #include <memory>
 #include <string>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace Eigen {  // just enough of Eigen::Matrix for Matrix4f / Vector4f / Quaternionf members
 template <typename S, int R, int C>
@@ -569,28 +573,56 @@ class CorrespondenceEstimationBase : public PCLBase<PointSource> {
   bool input_fields_updated_ = false;
 };
 
-// PCL's own estimator: ONE nearestKSearch per source point through the virtual search interface
-// (impl/correspondence_estimation.hpp:145-218) -- the call pattern a search backend alone is subject to
+// PCL's own estimator: ONE nearestKSearch per source point through the virtual search interface, from an OpenMP loop
+// with setNumberOfThreads(n) threads (correspondence_estimation.h:144-155, impl/correspondence_estimation.hpp:145-218)
+// -- the call pattern a search backend alone is subject to, concurrency included
 template <typename PointSource, typename PointTarget, typename Scalar = float>
 class CorrespondenceEstimation : public CorrespondenceEstimationBase<PointSource, PointTarget, Scalar> {
   using Base = CorrespondenceEstimationBase<PointSource, PointTarget, Scalar>;
  public:
   using Ptr = shared_ptr<CorrespondenceEstimation<PointSource, PointTarget, Scalar>>;
   CorrespondenceEstimation() { this->corr_name_ = "CorrespondenceEstimation"; }
+  void setNumberOfThreads(unsigned int nr_threads) {  // correspondence_estimation.h:144-155
+#ifdef _OPENMP
+    num_threads_ = nr_threads != 0 ? nr_threads : static_cast<unsigned int>(omp_get_num_procs());
+#else
+    (void)nr_threads;
+    num_threads_ = 1;
+#endif
+  }
   void determineCorrespondences(pcl::Correspondences& correspondences,
                                 double max_distance = std::numeric_limits<double>::max()) override {
     correspondences.clear();
     if (!this->initCompute()) return;
     const double max_dist_sqr = max_distance * max_distance;
-    pcl::Indices index(1);
-    std::vector<float> distance(1);
-    for (index_t idx : *this->indices_) {
-      const PointSource& p = (*this->input_)[idx];
+    std::vector<pcl::Correspondences> per_thread(num_threads_);
+    const auto& indices = *this->indices_;
+    const auto& input = *this->input_;
+    const auto& tree = *this->tree_;
+    const int n = static_cast<int>(indices.size());
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(num_threads_)
+#endif
+    for (int i = 0; i < n; ++i) {
+      pcl::Indices index(1);            // firstprivate(index, distance) in the reference
+      std::vector<float> distance(1);
+      const index_t idx = indices[std::size_t(i)];
+      const PointSource& p = input[idx];
       if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
-      if (this->tree_->nearestKSearchT(p, 1, index, distance) == 0) continue;
+      if (tree.nearestKSearchT(p, 1, index, distance) == 0) continue;
       if (distance[0] > max_dist_sqr) continue;
-      correspondences.emplace_back(idx, index[0], distance[0]);
+#ifdef _OPENMP
+      const int t = omp_get_thread_num();
+#else
+      const int t = 0;
+#endif
+      per_thread[std::size_t(t)].emplace_back(idx, index[0], distance[0]);
     }
+    // :191-214: the per-thread lists merged, ordered by index_query
+    for (const auto& c : per_thread) correspondences.insert(correspondences.end(), c.begin(), c.end());
+    if (num_threads_ > 1)
+      std::stable_sort(correspondences.begin(), correspondences.end(),
+                       [](const pcl::Correspondence& a, const pcl::Correspondence& b) { return a.index_query < b.index_query; });
     this->deinitCompute();
   }
   void determineReciprocalCorrespondences(pcl::Correspondences&, double = std::numeric_limits<double>::max()) override {
@@ -599,6 +631,8 @@ class CorrespondenceEstimation : public CorrespondenceEstimationBase<PointSource
   typename Base::Ptr clone() const override {
     return typename Base::Ptr(new CorrespondenceEstimation<PointSource, PointTarget, Scalar>(*this));
   }
+ protected:
+  unsigned int num_threads_{1};  // correspondence_estimation.h:383
 };
 
 }  // namespace registration
@@ -676,9 +710,32 @@ class Registration : public PCLBase<PointSource> {
   void setPointRepresentation(const PointRepresentationConstPtr& point_representation) {
     point_representation_ = point_representation;
   }
-  // impl/registration.hpp:132-168 calls tree_->nearestKSearch per point; subclasses of the binding override it
-  virtual double getFitnessScore(double /*max_range*/ = std::numeric_limits<double>::max()) {
-    mock_no_cpu_path("Registration::getFitnessScore");
+  // registration.h:450-452 -- NOT virtual in the reference: a subclass can only hide it.  impl/registration.hpp:132-168:
+  // the moved source through tree_->nearestKSearchT point by point (the one CPU loop the mock carries: it is how a
+  // caller holding a pcl::Registration* reaches the search backend)
+  inline double getFitnessScore(double max_range = std::numeric_limits<double>::max(), bool use_indices = false) {
+    double fitness_score = 0.0;
+    const bool subset = use_indices && indices_ && indices_->size() != input_->size();
+    const std::size_t n = subset ? indices_->size() : input_->size();
+    pcl::Indices nn_indices(1);
+    std::vector<float> nn_dists(1);
+    int nr = 0;
+    const Matrix4& T = final_transformation_;
+    for (std::size_t i = 0; i < n; ++i) {
+      const PointSource& s = (*input_)[subset ? std::size_t((*indices_)[i]) : i];
+      PointSource p = s;  // transformPointCloud: float, rotation rows then the translation (common/.../impl/transforms.hpp)
+      p.x = float(T(0, 0) * s.x + T(0, 1) * s.y + T(0, 2) * s.z + T(0, 3));
+      p.y = float(T(1, 0) * s.x + T(1, 1) * s.y + T(1, 2) * s.z + T(1, 3));
+      p.z = float(T(2, 0) * s.x + T(2, 1) * s.y + T(2, 2) * s.z + T(2, 3));
+      if (!input_->is_dense && !(std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z))) continue;
+      tree_->nearestKSearchT(p, 1, nn_indices, nn_dists);
+      if (nn_dists[0] <= max_range) {
+        fitness_score += nn_dists[0];
+        nr++;
+      }
+    }
+    if (nr > 0) return fitness_score / nr;
+    return std::numeric_limits<double>::max();
   }
   bool hasConverged() const { return converged_; }
   void align(PointCloudSource& output) { align(output, Matrix4::Identity()); }

@@ -8,10 +8,13 @@
 // Goldens: test/registration/test_registration_api.cpp:83-104 (397 bunny correspondences),
 // test/registration/test_registration.cpp:236-270 (ICP 4x4 @1e-3), test/kdtree/test_kdtree.cpp:226-289.
 // Inputs are written by tests/test_gpu_cpp_adapters.py from tests/golden/.
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <memory>
+#include <thread>
 
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
@@ -176,6 +179,64 @@ int main(int argc, char** argv) {
            corr.front().index_match == gold[396]);
   }
 
+  {  // 3b. the `const` search virtuals under CONCURRENT callers, as PCL itself calls them: the stock per-point estimator
+     //     with setNumberOfThreads(8) (impl/correspondence_estimation.hpp:163-175), NormalEstimationOMP's loop
+     //     (features/.../impl/normal_3d_omp.hpp:76-81) and the default batch radiusSearch (search/.../impl/search.hpp:164-190)
+     //     all run nearestKSearch / radiusSearch of ONE tree from several threads
+    auto tree = std::make_shared<KdTreeHIP<pcl::PointXYZ>>(dev);
+    pcl::registration::CorrespondenceEstimation<pcl::PointXYZ, pcl::PointXYZ, float> stock;
+    stock.setNumberOfThreads(8);
+    stock.setSearchMethodTarget(tree);
+    stock.setInputSource(source);
+    stock.setInputTarget(target);
+    for (int round = 0; round < 3; ++round) {
+      pcl::Correspondences par;
+      stock.determineCorrespondences(par);
+      EXPECT(par.size() == 397);
+      bool same = par.size() == gold.size();
+      for (std::size_t i = 0; same && i < par.size(); ++i) same = par[i].index_query == int(i) && par[i].index_match == gold[i];
+      EXPECT(same);  // the 397 golden pairs (test_registration_api_data.h:3-402), whatever the interleaving
+    }
+    // plain threads (no OpenMP needed): k-NN and radius searches of the same tree mixed, every answer equal to the
+    // serial one
+    const pcl::search::Search<pcl::PointXYZ>& search = *tree;
+    std::vector<pcl::Indices> want_k(source->size()), want_r(source->size());
+    std::vector<std::vector<float>> want_kd(source->size()), want_rd(source->size());
+    for (std::size_t i = 0; i < source->size(); ++i) {
+      search.nearestKSearch((*source)[i], 4, want_k[i], want_kd[i]);
+      search.radiusSearch((*source)[i], 0.01, want_r[i], want_rd[i]);
+    }
+    std::atomic<int> bad{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < 8; ++t)
+      pool.emplace_back([&, t] {
+        pcl::Indices idx;
+        std::vector<float> d2;
+        for (std::size_t i = std::size_t(t); i < source->size(); i += 8) {
+          if (search.nearestKSearch((*source)[i], 4, idx, d2) != 4 || idx != want_k[i] || d2 != want_kd[i]) ++bad;
+          if (search.radiusSearch((*source)[i], 0.01, idx, d2) != int(want_r[i].size()) || idx != want_r[i] || d2 != want_rd[i]) ++bad;
+        }
+      });
+    for (auto& th : pool) th.join();
+    EXPECT(bad.load() == 0);
+    // the batch radiusSearch virtual (search.h:349-355) is ONE call here; same lists as the per-point virtual
+    std::vector<pcl::Indices> br;
+    std::vector<std::vector<float>> brd;
+    search.radiusSearch(*source, pcl::Indices(), 0.01, br, brd);
+    EXPECT(br.size() == source->size());
+    bool lists = br.size() == source->size();
+    for (std::size_t i = 0; lists && i < br.size(); ++i) lists = br[i] == want_r[i] && brd[i] == want_rd[i];
+    EXPECT(lists);
+    pcl::Indices pick{5, 17, 396, 17};
+    search.radiusSearch(*source, pick, 0.01, br, brd, 3);  // an index list, max_nn = 3
+    EXPECT(br.size() == 4);
+    for (std::size_t j = 0; j < br.size() && j < pick.size(); ++j) {
+      const auto& full = want_r[std::size_t(pick[j])];
+      const std::size_t m = full.size() < 3 ? full.size() : 3;
+      EXPECT(br[j].size() == m && std::equal(br[j].begin(), br[j].end(), full.begin()));
+    }
+  }
+
   // test/registration/test_registration.cpp:251-269 (tests/golden/golden.json: icp_bunny)
   const double G[16] = {0.8806, 0.036481287, -0.4724, 0.03453, -0.02354, 0.9992, 0.03326, -0.001519,
                         0.4732, -0.01817, 0.8808, 0.04116, 0, 0, 0, 1};
@@ -203,6 +264,11 @@ int main(int argc, char** argv) {
     const float x = T(0, 0) * p.x + T(0, 1) * p.y + T(0, 2) * p.z + T(0, 3);
     EXPECT(std::fabs(out[5].x - x) < 1e-5f);
     EXPECT(reg->getFitnessScore() < 0.001);  // test_registration.cpp:301-302
+    // registration.h:450-452 is not virtual: through pcl::Registration* that was PCL's own loop over the HIP search
+    // backend (one nearestKSearch per point); on the HIP class it is one launch -- the same score
+    const double via_base = reg->getFitnessScore(), on_device = hip->getFitnessScore();
+    EXPECT(std::fabs(via_base - on_device) <= 1e-4 * via_base);
+    EXPECT(std::fabs(reg->getFitnessScore(1e-5) - hip->getFitnessScore(1e-5)) <= 1e-4 * via_base);  // max_range as given
     auto* icp = dynamic_cast<pcl::IterativeClosestPoint<pcl::PointXYZ, pcl::PointXYZ, float>*>(reg.get());
     EXPECT(icp->getConvergeCriteria()->getConvergenceState() !=
            pcl::registration::DefaultConvergenceCriteria<float>::CONVERGENCE_CRITERIA_NOT_CONVERGED);
@@ -226,6 +292,10 @@ int main(int argc, char** argv) {
     const auto T3 = reg->getFinalTransformation();
     for (int r = 0; r < 3; ++r) EXPECT(std::fabs(T3(r, 3) - G[4 * r + 3]) < 1e-2);  // half the points: the same pose, roughly
     EXPECT(reg->getFitnessScore() < 0.001);
+    // use_indices (impl/registration.hpp:141-144): the device holds the subset the alignment ran on -> scores it there;
+    // the whole cloud is then PCL's loop; both equal what the base computes
+    EXPECT(std::fabs(hip->getFitnessScore(1e30, true) - reg->getFitnessScore(1e30, true)) <= 1e-4 * reg->getFitnessScore(1e30, true));
+    EXPECT(hip->getFitnessScore(1e30, false) == reg->getFitnessScore(1e30, false));
     // another list of the SAME size (PCLBase::setIndices does not flag the source as updated): the device must not keep
     // the old subset -- twenty points near one end of the scan cannot give the pose of the whole scan
     pcl::IndicesPtr other(new pcl::Indices);

@@ -87,7 +87,8 @@ def test_c_example_registers_the_bunny_pair(tmp_path, bunny, golden):
 # ---- the real-PCL binding (include/pclhip/pcl_plugin.hpp) against the PCL mock -------------------------
 def build_plugin_test(tmp_path):
     exe = str(tmp_path / "test_pcl_plugin")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+    # -fopenmp: the mock's stock CorrespondenceEstimation runs PCL's own OpenMP loop over the search backend
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-fopenmp", "-pthread", "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(ROOT, "tests", "cpp", "pcl_mock"),
                            os.path.join(ROOT, "tests", "cpp", "test_pcl_plugin.cpp"), "-o", exe,
                            *link_args()])

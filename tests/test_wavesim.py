@@ -288,6 +288,41 @@ def test_config2_at_its_full_size_on_the_emulation(wavesim_lib):
     assert "1 passed" in out
 
 
+def test_const_search_virtuals_from_eight_threads_under_tsan(wavesim_lib, tmp_path):
+    """PCL calls the `const` search virtuals of ONE tree from OpenMP threads (impl/correspondence_estimation.hpp
+    :163-175 with setNumberOfThreads, normal_3d_omp.hpp:76-81, impl/search.hpp:164-190).  tests/cpp/test_pcl_plugin.cpp section
+    3b does that to a KdTreeHIP -- the mock's stock per-point CorrespondenceEstimation with 8 threads (397 golden pairs)
+    and 8 plain threads mixing k-NN and radius searches -- here with the test and the binding (pcl_plugin.hpp) compiled
+    -fsanitize=thread over the emulation.  (The OpenMP loop itself runs in the GPU tier and in the plain run of this
+    file on the emulation; under TSan the test is built without -fopenmp, whose runtime is not instrumented, so the
+    plain-thread half carries the concurrency.)  The library is not instrumented: its part of the contract -- the query
+    entry points serialise on the context -- shows as equal results under every interleaving."""
+    import json
+    import numpy as np
+    from oracle import pcl_oracle as orc
+    z = np.load(os.path.join(ROOT, "tests", "golden", "bunny.npz"))
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+    np.savetxt(tmp_path / "bun0.txt", z["bun0"][:, :3], fmt="%.9g")
+    np.savetxt(tmp_path / "bun4.txt", z["bun4"][:, :3], fmt="%.9g")
+    np.savetxt(tmp_path / "corr.txt", np.asarray(g["correspondences_original"]), fmt="%d")
+    tgt = np.ones((len(z["bun4"]), 4), np.float32)
+    tgt[:, :3] = z["bun4"][:, :3]
+    np.savetxt(tmp_path / "bun4_normals.txt", orc.KdTree(tgt).normals(tgt, 10)[0][:, :3], fmt="%.9g")
+    exe = str(tmp_path / "test_pcl_plugin_tsan")
+    d = os.path.dirname(os.path.abspath(wavesim_lib))
+    c = subprocess.run([CLANG, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "tests", "cpp", "pcl_mock"), os.path.join(ROOT, "tests", "cpp", "test_pcl_plugin.cpp"),
+                        "-o", exe, "-L" + d, "-l:" + os.path.basename(wavesim_lib), "-Wl,-rpath," + d], capture_output=True, text=True)
+    if c.returncode != 0 and "tsan" in c.stderr.lower():
+        pytest.skip("no ThreadSanitizer runtime for this clang")
+    assert c.returncode == 0, c.stderr[-3000:]
+    env = dict(os.environ, PCLHIP_ALLOW_WAVESIM="1", TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0")
+    r = subprocess.run([exe] + [str(tmp_path / a) for a in ("bun0.txt", "bun4.txt", "corr.txt", "bun4_normals.txt")],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
 def test_strided_inputs_are_read_to_their_last_byte_only(wavesim_lib):
     """pclhip_estimate_rigid_transformation, pclhip_index_set_normals and pclhip_icp_set_source_normals take pointers INTO the
     caller's records (normals at record + 16, stride 48): arrays that end at an inaccessible page must not fault (they did:
