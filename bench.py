@@ -96,19 +96,14 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-
     import pcl_amd
     from pcl_amd import synth
+    from pcl_amd.dist import init_ranks, make_fence, max_over_ranks, native_communicator, timed_steps
+
+    # rendezvous, the native communicator and the fences: pcl_amd/dist.py -- the same functions the 2- and 3-process CPU
+    # tests run (tests/wavesim/two_rank_worker.py over gloo and the emulation), so this control flow is not new to N > 1
+    rank, local_rank, world = init_ranks("nccl")
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     cfg = args.config
     mode = 0 if cfg == 2 else 1
@@ -117,21 +112,8 @@ def main():
     for kv in args.opt:
         name, _, value = kv.partition("=")
         ctx.setOption(name, float(value))
-
-    def fence():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    comm = None
-    if world > 1:  # native RCCL communicator: rank 0's id travels over the torch process group once
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(pcl_amd.Communicator.unique_id()), dtype=torch.uint8).cuda()
-        dist.broadcast(uid, 0)
-        comm = pcl_amd.Communicator(ctx, rank, world, bytes(uid.cpu().numpy().tobytes()))
+    fence = make_fence(ctx, world)
+    comm = native_communicator(ctx, rank, world)   # rank 0's id travels over the torch process group once
 
     if cfg == 5:
         from bench_sharded import run_config5     # target slab + halo sharding (pcl_amd/dist.py)
@@ -199,17 +181,7 @@ def main():
         icp.setUseReciprocalCorrespondences(True)
     source_order_ms = icp.sourceOrderMs()
 
-    if args.warmup > 0:
-        icp.runSteps(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    steps = icp.runSteps(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    steps, elapsed = timed_steps(icp, args.steps, args.warmup, fence, world)
 
     # a fresh frame: a NEW source cloud against the resident target -- its ordering, then one whole alignment (device times)
     fresh_frame = None
@@ -383,11 +355,8 @@ def run_pipeline(args, ctx, comm, tgt, src, n, rank, world, fence, gen_s):
     for _ in range(args.steps):
         step()
     fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from pcl_amd.dist import max_over_ranks
+    elapsed = max_over_ranks(time.perf_counter() - t0, world)
     if rank != 0:
         return None
     from pcl_amd import synth
@@ -487,13 +456,60 @@ def cpu_pipeline(args, tgt, src):
                       (len(tgt_h), t1 - t0, args.knn, r["iterations"], t2 - t1, cores)}
 
 
+def morton_order(pts):
+    """Permutation that puts a cloud into Morton order of its bounding box (21 bits per axis): spatially ordered queries, the
+    order a scan or any spatial pre-sort gives a source cloud.  numpy, host; not timed."""
+    import numpy as np
+    p = np.asarray(pts[:, :3], np.float64)
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    q = ((p - lo) / np.maximum(hi - lo, 1e-30) * ((1 << 21) - 1)).astype(np.uint64)
+
+    def spread(v):
+        v = v & np.uint64(0x1FFFFF)
+        v = (v | (v << np.uint64(32))) & np.uint64(0x1F00000000FFFF)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x1F0000FF0000FF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x100F00F00F00F00F)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x10C30C30C30C30C3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return v
+    return np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)) | (spread(q[:, 2]) << np.uint64(2)), kind="stable")
+
+
+def interleave_memory(on):
+    """set_mempolicy(MPOL_INTERLEAVE over all NUMA nodes) for the pages this process touches from now on (the oracle's
+    tree is built by one thread: first-touch would put all of it on that thread's node, and 256 threads would then query
+    one node's memory).  Raw syscall (no libnuma needed); returns whether it took effect."""
+    try:
+        import ctypes
+        nodes = [int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()]
+        if len(nodes) < 2:
+            return False
+        libc = ctypes.CDLL(None, use_errno=True)
+        maxnode = max(nodes) + 2
+        mask = (ctypes.c_ulong * ((maxnode + 63) // 64))()
+        if on:
+            for nd in nodes:
+                mask[nd // 64] |= 1 << (nd % 64)
+        SYS_set_mempolicy, MPOL_DEFAULT, MPOL_INTERLEAVE = 238, 0, 3   # x86_64
+        rc = libc.syscall(SYS_set_mempolicy, MPOL_INTERLEAVE if on else MPOL_DEFAULT, mask if on else None,
+                          maxnode if on else 0)
+        return rc == 0
+    except Exception:
+        return False
+
+
 def cpu_baseline(args, mode, n, tgt, src):
     """The oracle (restated PCL KdTree + ICP, OpenMP over source points as in correspondence_estimation.hpp
-    :163-191, estimation serial as in PCL) on the SAME clouds as the GPU line, timed on this box's host cores:
-    T = all cores for 3 iterations, and T = 1 for one iteration on a bounded slice of the source (the
-    per-query cost is what matters; the full cloud single-threaded would take ~15 s per iteration)."""
+    :163-191, estimation serial as in PCL) on the SAME clouds as the GPU line, timed on this box's host cores at
+    T = 1 (bounded slice), T = physical cores and T = hardware threads.  The CPU gets the conditions a careful user would
+    give it: the source in a spatial (Morton) order, so that a thread's contiguous share of the loop stays inside one part of
+    the tree, and the tree's pages interleaved over the NUMA nodes; the figure with the source in its given (random) order
+    is reported next to it."""
+    import numpy as np
     from oracle import pcl_oracle as orc
+    hw_threads, phys = host_cpus()
     cores = orc.default_threads()
+    interleaved = interleave_memory(True)
     t0 = time.perf_counter()
     tree = orc.KdTree(tgt)
     build_s = time.perf_counter() - t0
@@ -503,34 +519,54 @@ def cpu_baseline(args, mode, n, tgt, src):
         t0 = time.perf_counter()
         nrm, _ = tree.normals(tgt, args.knn, viewpoint=(0, 0, 10), nthreads=cores)
         normals_s = time.perf_counter() - t0
+    src_sorted = np.ascontiguousarray(src[morton_order(src)])
+    if interleaved:
+        interleave_memory(False)
     kw = dict(mode=mode, tgt_normals=nrm, max_correspondence_distance=0.1, transformation_epsilon=0.0)
-    # one thread first, on a bounded slice: its per-query cost also sizes the all-threads sample so that the baseline stays
+    # one thread first, on a bounded slice: its per-query cost also sizes the all-threads samples so that the baseline stays
     # within ~30 s of CPU wall time on a host with few cores (on the 128-core boxes seen so far the sample is the whole cloud)
     m1 = min(n, 1_000_000)
-    r1 = orc.icp_align(tree, tgt, src[:m1], max_iterations=1, nthreads=1, **kw)
+    r1 = orc.icp_align(tree, tgt, src_sorted[:m1], max_iterations=1, nthreads=1, **kw)
     per_iter1 = r1["seconds_total"] / max(r1["iterations"], 1)
-    est_full_iter = per_iter1 / m1 * n / max(cores * 0.08, 1.0)   # the port reaches ~8 % of linear scaling at 256 threads
-    n_all = n if est_full_iter * 3 <= 30.0 else max(m1, int(n * 30.0 / (est_full_iter * 3)))
-    src_all = src if n_all == n else src[:n_all]
-    r = orc.icp_align(tree, tgt, src_all, max_iterations=3, nthreads=cores, **kw)
-    it = max(r["iterations"], 1)
-    per_iter = r["seconds_total"] / it
+    est_full_iter = per_iter1 / m1 * n / max(cores * 0.25, 1.0)
+    n_all = n if est_full_iter * 3 <= 20.0 else max(m1, int(n * 20.0 / (est_full_iter * 3)))
+
+    def run(cloud, threads, iters):
+        r_ = orc.icp_align(tree, tgt, cloud if n_all == n else cloud[:n_all], max_iterations=iters, nthreads=threads, **kw)
+        it_ = max(r_["iterations"], 1)
+        return r_, it_, r_["seconds_total"] / it_
+
+    r, it, per_iter = run(src_sorted, cores, 3)
     n_sample = n_all
-    return {"value": round(r["num_correspondences"] / per_iter, 1), "unit": "correspondences/s", "cores": cores,
-            "threads_used": cores, "host_hardware_threads": host_cpus()[0], "host_physical_cores": host_cpus()[1],
-            "kind": "port",
-            "sample": "the bench's own %d-point target and %s%d-point source, %d ICP iterations on %d threads "
-                      "(search %.3f s + serial estimate/transform %.3f s per iteration); 1 thread: one iteration over "
-                      "the first %d source points against the full target; kd-tree build %.2f s single-thread (as in "
-                      "FLANN)%s" %
-                      (n, "" if n_sample == n else "the first %d points of its " % n_sample, n, it, cores, r["seconds_search"] / it, (r["seconds_total"] - r["seconds_search"]) / it, m1,
-                       build_s, "" if normals_s is None else ", k=%d normals %.2f s on %d threads" % (args.knn, normals_s, cores)),
-            "ms_per_iteration": round(per_iter * 1e3, 2),
-            "search_ms_per_iteration": round(r["seconds_search"] / it * 1e3, 2),
-            "serial_ms_per_iteration": round((r["seconds_total"] - r["seconds_search"]) / it * 1e3, 2),
-            "single_thread": {"value": round(r1["num_correspondences"] / per_iter1, 1), "unit": "correspondences/s",
-                              "cores": 1, "us_per_query": round(r1["seconds_search"] / m1 * 1e6, 3),
-                              "sample_points": m1}}
+    out = {"value": round(r["num_correspondences"] / per_iter, 1), "unit": "correspondences/s", "cores": cores,
+           "threads_used": cores, "host_hardware_threads": hw_threads, "host_physical_cores": phys,
+           "kind": "port",
+           "sample": "the bench's own %d-point target and %s%d-point source in Morton order, %d ICP iterations on %d threads "
+                     "(search %.3f s + serial estimate/transform %.3f s per iteration); 1 thread: one iteration over "
+                     "the first %d source points against the full target; kd-tree build %.2f s single-thread (as in "
+                     "FLANN)%s; tree pages %s" %
+                     (n, "" if n_sample == n else "the first %d points of its " % n_sample, n, it, cores, r["seconds_search"] / it,
+                      (r["seconds_total"] - r["seconds_search"]) / it, m1, build_s,
+                      "" if normals_s is None else ", k=%d normals %.2f s on %d threads" % (args.knn, normals_s, cores),
+                      "interleaved over the NUMA nodes" if interleaved else "first-touch (one NUMA node, or the policy call was refused)"),
+           "ms_per_iteration": round(per_iter * 1e3, 2),
+           "search_ms_per_iteration": round(r["seconds_search"] / it * 1e3, 2),
+           "serial_ms_per_iteration": round((r["seconds_total"] - r["seconds_search"]) / it * 1e3, 2),
+           "single_thread": {"value": round(r1["num_correspondences"] / per_iter1, 1), "unit": "correspondences/s",
+                             "cores": 1, "us_per_query": round(r1["seconds_search"] / m1 * 1e6, 3),
+                             "sample_points": m1}}
+    one = r1["seconds_search"] / m1
+    out["search_speedup_over_one_thread"] = round(one / (r["seconds_search"] / it / n_sample), 1)
+    if phys and phys < cores:   # one thread per physical core
+        rp, itp, per_p = run(src_sorted, phys, 2)
+        out["physical_cores"] = {"value": round(rp["num_correspondences"] / per_p, 1), "unit": "correspondences/s", "cores": phys,
+                                 "search_ms_per_iteration": round(rp["seconds_search"] / itp * 1e3, 2),
+                                 "search_speedup_over_one_thread": round(one / (rp["seconds_search"] / itp / n_sample), 1)}
+    ru, itu, per_u = run(src, cores, 2)   # the source as the bench generated it: random order
+    out["unsorted_source"] = {"value": round(ru["num_correspondences"] / per_u, 1), "unit": "correspondences/s", "cores": cores,
+                              "search_ms_per_iteration": round(ru["seconds_search"] / itu * 1e3, 2),
+                              "search_speedup_over_one_thread": round(one / (ru["seconds_search"] / itu / n_sample), 1)}
+    return out
 
 
 def finish(out, rank, world):

@@ -248,7 +248,13 @@ int orc_kdtree_knn(const orc_kdtree* t, const float* qry, int64_t nq, int qs, in
                    int32_t* out_idx, float* out_d2, int nthreads) {
   int keff = (k < t->n) ? k : (int)t->n;
   if (nthreads < 1) nthreads = 1;
-#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 256)
+  /* The reference's loop over the source points (impl/correspondence_estimation.hpp:163-191) is a plain `omp parallel
+   * for`: static, contiguous shares.  Contiguous runs matter when the queries are spatially ordered (a thread then stays
+   * inside one part of the tree); chunks of ~1/16 of a thread's share keep that and still balance uneven queries. */
+  int64_t chunk = nq / ((int64_t)nthreads * 16);
+  if (chunk < 64) chunk = 64;
+  if (chunk > 16384) chunk = 16384;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, chunk)
   for (int64_t i = 0; i < nq; ++i) {
     knn_set s = {keff, 0, out_d2 + i * k, out_idx + i * k};
     const float* q = qry + i * qs;

@@ -85,8 +85,8 @@ __global__ __launch_bounds__(LBLOCK, PCLHIP_LANE_MINW) void icp_lane_resolve_ker
     const uint32_t home = far ? lane_greedy_leaf(lt, p.x, p.y, p.z) : sp / LEAF;
     fast.leaf_global(soa, home, qx, qy, qz);
     if (gstats != nullptr) {  // (counted apart: how many are done with their own leaf)
-      const Box c = lt.qcell[home];
-      at_leaf = lt.top == 0 || ball_inside_cell(c, p.x, p.y, p.z, fast.best[0]);
+      // (a one-leaf index stores no cell: the root's is all of space and is never written -- do not read it)
+      at_leaf = lt.top == 0 || ball_inside_cell(lt.qcell[home], p.x, p.y, p.z, fast.best[0]);
     }
     gave_up = !lane_search(lt, soa, p.x, p.y, p.z, fast, home, max_up);
   }

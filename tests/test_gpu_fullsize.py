@@ -384,3 +384,21 @@ def test_families_correspondences_bit_exact_at_size(gpu, orc, kind, n, mode):
     err = frob(icp2.getFinalTransformation(), ref["T"])
     print("%s (%d points): %d iterations, |T_gpu - T_oracle|_F = %.3g" % (kind, n, ref["iterations"], err))
     assert err < 1e-5
+    if mode == 0:
+        # a-5 (TransformationEstimationSVD): the device sums umeyama's moments in fp64, the reference in float.  At 2^20
+        # points the 1e-5 contract also holds against the oracle's reference-ORDER float sums (config 2 above); at these
+        # sizes it cannot hold against ANY double-sum implementation, this one included: the float-sum variant of the
+        # oracle itself ends 5e-5 (10M cube) / 6e-5 (2.5M clusters) away from its own double-sum variant after the same six
+        # iterations (measured, CPU, round 6) -- summation noise of 10^7 float terms, not the search (the correspondences
+        # above are bit-equal in every iteration).  The oracle's float variant adds sequentially; Eigen's redux behind
+        # umeyama adds packet-wise, which is the more accurate order, so this is the pessimistic end of what real PCL
+        # would show.  Pinned here: the device stays within the contract of the double-sum oracle (above), and its
+        # distance to the float-order oracle IS that variant's own noise (triangle inequality, not a new tolerance).
+        ref_f = orc.icp_align(otree, tgt, src, mode=0, acc_double=0, **kw)
+        gap = frob(ref_f["T"], ref["T"])
+        to_float_order = frob(icp2.getFinalTransformation(), ref_f["T"])
+        print("%s (%d points): float-sum vs double-sum oracle gap = %.3g ; |T_gpu - T_oracle(float order)|_F = %.3g"
+              % (kind, n, gap, to_float_order))
+        assert ref_f["iterations"] == ref["iterations"]
+        assert abs(to_float_order - gap) < 1e-5          # the device sits on the double-sum side of that gap
+        assert gap < 5e-4                                # ... which stays float noise, two orders below the pose itself

@@ -125,7 +125,12 @@ def test_n_ranks_through_the_native_communicator(wavesim_lib, tmp_path, mode, wo
     mode, _, extra = mode.partition("+")
     full_mode = mode + ("+" + extra if extra else "")
     work = str(tmp_path)
-    env = dict(os.environ, PCLHIP_LIB=wavesim_lib, PCLHIP_ALLOW_WAVESIM="1", WAVESIM_THREADS="8")  # (target mode: the ranks walk their served groups)
+    import socket
+    with socket.socket() as sk:   # a free port for the ranks' torch.distributed (gloo) rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PCLHIP_LIB=wavesim_lib, PCLHIP_ALLOW_WAVESIM="1", WAVESIM_THREADS="8",  # (target mode: the ranks walk their served groups)
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     worker = os.path.join(WS, "two_rank_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, full_mode, str(r), str(world), work, str(n)], env=env, cwd=ROOT,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]

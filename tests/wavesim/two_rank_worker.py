@@ -5,14 +5,12 @@ of these as processes; never used outside the tests).  argv: mode rank world wor
                  rank serving the source points whose current position lies in its region (bench.py --config 5)
   mode "source"  the whole target indexed on every rank, the source cut into contiguous slabs (bench.py --gpus N)
 
-Either way the ranks share a native communicator (pclhip_comm_*: the id travels through a file here, through
-torch.distributed in bench.py) and the device-driven loop all-reduces the 32-double record of every iteration between
+Either way the ranks share a native communicator (pclhip_comm_*), brought up by the very functions bench.py uses
+(pcl_amd/dist.py: init_ranks / native_communicator / make_fence / timed_steps; the torch group is gloo here, nccl there) and the device-driven loop all-reduces the 32-double record of every iteration between
 its reduction and its solve kernel.  Every rank writes what it saw to workdir/rank<r>.npz.
 """
 import os
 import sys
-import time
-
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,21 +23,14 @@ mode, rank, world, work = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.a
 mode, _, extra = mode.partition("+")   # "+rej": MedianDistance + Trimmed + Distance chain; "+recip": reciprocal correspondences
 extras = set(extra.split("+")) if extra else set()   # "+empty" (source mode): the LAST rank's share of the source is empty
 n = int(sys.argv[5]) if len(sys.argv) > 5 else 60_000
-uid_path = os.path.join(work, "uid.bin")
-if rank == 0:
-    uid = pcl_amd.Communicator.unique_id()
-    with open(uid_path + ".tmp", "wb") as f:
-        f.write(bytes(uid))
-    os.rename(uid_path + ".tmp", uid_path)
-else:
-    t0 = time.time()
-    while not os.path.exists(uid_path):
-        if time.time() - t0 > 120:
-            raise SystemExit("rank 0 never published the communicator id")
-        time.sleep(0.05)
-    uid = open(uid_path, "rb").read()
+# the bring-up of bench.py, function for function (pcl_amd/dist.py): rendezvous from the launcher's environment (gloo here, nccl
+# there), rank 0's communicator id broadcast over the torch group, the native communicator next to torch's, the fences
+os.environ["RANK"], os.environ["LOCAL_RANK"], os.environ["WORLD_SIZE"] = str(rank), "0", str(world)
+from pcl_amd.dist import init_ranks, make_fence, native_communicator, timed_steps  # noqa: E402
+rank, _, world = init_ranks("gloo")
 ctx = pcl_amd.Context(0)
-comm = pcl_amd.Communicator(ctx, rank, world, bytes(uid))
+fence = make_fence(ctx, world)
+comm = native_communicator(ctx, rank, world)
 tgt, src, _ = synth.icp_pair(n)
 region = None
 if mode == "target":
@@ -87,10 +78,14 @@ T = icp.getFinalTransformation().copy()
 iters = icp.nr_iterations_
 kept_after_align = len(icp.fetchCorrespondences()[0])   # the pairs of the last iteration that this rank serves and the chain kept
 # the measurement loop of bench.py on top: whole alignments queued back to back, records all-reduced
-steps = icp.runSteps(6)
+steps, elapsed = timed_steps(icp, 6, 0, fence, world)   # warm-up 0: the records below are those of the first six steps
+assert elapsed > 0.0
 served = len(icp.fetchCorrespondences()[0])
 fit = icp.getFitnessScore(0.01)
 np.savez(os.path.join(work, "rank%d.npz" % rank), T=T, iterations=iters, converged=icp.hasConverged(),
          counts=np.asarray([s["num_correspondences"] for s in steps], np.float64),
          step_iterations=np.asarray([s["iteration"] for s in steps]), served=served, index_points=tree.size(),
          fitness=fit, fitness_points=icp.fitness_points, kept_after_align=kept_after_align)
+import torch.distributed as dist  # noqa: E402
+dist.barrier()
+dist.destroy_process_group()
