@@ -268,13 +268,18 @@ int orc_kdtree_knn(const orc_kdtree* t, const float* qry, int64_t nq, int qs, in
 }
 
 /* ------------------------------------------------------------------------------------------ */
-int64_t orc_correspondences(const orc_kdtree* t, const float* src, int64_t ns, int ss,
-                            double max_dist, int32_t* out_q, int32_t* out_m, float* out_d2,
-                            int nthreads) {
+/* nn / dd: scratch of ns entries each, or NULL (allocated here).  A caller that runs many iterations brings its own: fresh
+ * pages first touched inside the parallel loop are page faults under every thread at once (the whole process shares one
+ * address-space lock), which at 256 threads costs more than the search. */
+static int64_t correspondences_with(const orc_kdtree* t, const float* src, int64_t ns, int ss, double max_dist,
+                                    int32_t* out_q, int32_t* out_m, float* out_d2, int nthreads, int32_t* nn,
+                                    float* dd) {
   /* correspondence_estimation.hpp:161 */
   const double max_dist_sqr = max_dist * max_dist;
-  int32_t* nn = (int32_t*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
-  float* dd = (float*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(float));
+  int32_t* own_nn = NULL;
+  float* own_dd = NULL;
+  if (nn == NULL) nn = own_nn = (int32_t*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
+  if (dd == NULL) dd = own_dd = (float*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(float));
   orc_kdtree_knn(t, src, ns, ss, 1, nn, dd, nthreads);
   int64_t c = 0;
   for (int64_t i = 0; i < ns; ++i) {
@@ -285,9 +290,15 @@ int64_t orc_correspondences(const orc_kdtree* t, const float* src, int64_t ns, i
     out_d2[c] = dd[i];
     ++c;
   }
-  free(nn);
-  free(dd);
+  free(own_nn);
+  free(own_dd);
   return c;
+}
+
+int64_t orc_correspondences(const orc_kdtree* t, const float* src, int64_t ns, int ss,
+                            double max_dist, int32_t* out_q, int32_t* out_m, float* out_d2,
+                            int nthreads) {
+  return correspondences_with(t, src, ns, ss, max_dist, out_q, out_m, out_d2, nthreads, NULL, NULL);
 }
 
 /* Registration::getFitnessScore, registration/include/pcl/registration/impl/registration.hpp:132-168.
@@ -799,6 +810,11 @@ int orc_icp_align(const orc_kdtree* tgt_tree, const float* tgt, int ts, const fl
   int32_t* cq = (int32_t*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
   int32_t* cm = (int32_t*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
   float* cd = (float*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(float));
+  /* scratch of the search, touched once here (see correspondences_with) */
+  int32_t* s_nn = (int32_t*)calloc((size_t)(ns > 0 ? ns : 1), sizeof(int32_t));
+  float* s_dd = (float*)calloc((size_t)(ns > 0 ? ns : 1), sizeof(float));
+  if (s_nn) memset(s_nn, 0xFF, (size_t)(ns > 0 ? ns : 1) * sizeof(int32_t));
+  if (s_dd) memset(s_dd, 0, (size_t)(ns > 0 ? ns : 1) * sizeof(float));
   orc_kdtree* src_tree = NULL;
   /* :157-161 */
   conv->max_iterations = p->max_iterations;
@@ -816,8 +832,8 @@ int orc_icp_align(const orc_kdtree* tgt_tree, const float* tgt, int ts, const fl
                                           p->max_correspondence_distance, cq, cm, cd, p->nthreads);
       orc_kdtree_free(src_tree);
     } else {
-      nc = orc_correspondences(tgt_tree, cur, ns, 4, p->max_correspondence_distance, cq, cm, cd,
-                               p->nthreads);
+      nc = correspondences_with(tgt_tree, cur, ns, 4, p->max_correspondence_distance, cq, cm, cd, p->nthreads, s_nn,
+                                s_dd);
     }
     r->seconds_search += now_s() - ts0;
     if (per_iter_match) {
@@ -854,6 +870,8 @@ int orc_icp_align(const orc_kdtree* tgt_tree, const float* tgt, int ts, const fl
   free(cq);
   free(cm);
   free(cd);
+  free(s_nn);
+  free(s_dd);
   return 0;
 }
 

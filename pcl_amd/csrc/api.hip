@@ -561,6 +561,10 @@ pclhip_status pclhip_ctx_set_option(pclhip_ctx* ctx, const char* name, double va
     ctx->opt_cell_start = value != 0.0 ? 1 : 0;
   } else if (!std::strcmp(name, "reseed")) {
     ctx->opt_reseed = value != 0.0 ? 1 : 0;
+  } else if (!std::strcmp(name, "standoff_thickness")) {
+    ctx->opt_standoff_thickness = float(value);
+  } else if (!std::strcmp(name, "standoff_max_mb")) {
+    ctx->opt_standoff_max_mb = value < 0.0 ? 0 : int(value);
   } else if (!std::strcmp(name, "lane_max_up")) {
     ctx->opt_lane_max_up = value > 15.0 ? 15 : int(value);
   } else if (!std::strcmp(name, "lane_far")) {

@@ -267,10 +267,8 @@ __global__ __launch_bounds__(256) void node_box_kernel(const Box* child, uint32_
 
 // ---- the per-lane search structure (pclhip_internal.hpp: LaneTree) ------------------------------------------------
 // boxes of one quad level from the level below: one thread per parent, four consecutive children
-__global__ __launch_bounds__(256) void quad_box_kernel(const Box* __restrict__ child, uint32_t nchild, Box* __restrict__ parent,
-                                                       uint32_t nparent) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nparent) return;
+__device__ __forceinline__ void quad_box_node(const Box* __restrict__ child, uint32_t nchild, Box* __restrict__ parent,
+                                              uint32_t i) {
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
 #pragma unroll
   for (uint32_t c = 0; c < 4u; ++c) {
@@ -284,6 +282,11 @@ __global__ __launch_bounds__(256) void quad_box_kernel(const Box* __restrict__ c
   b.lo = make_float4(lo[0], lo[1], lo[2], 0.0f);
   b.hi = make_float4(hi[0], hi[1], hi[2], 0.0f);
   parent[i] = b;
+}
+__global__ __launch_bounds__(256) void quad_box_kernel(const Box* __restrict__ child, uint32_t nchild, Box* __restrict__ parent,
+                                                       uint32_t nparent) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nparent) quad_box_node(child, nchild, parent, i);
 }
 
 struct B3 {
@@ -334,11 +337,8 @@ __device__ __forceinline__ void cell_split(const B3& X, const B3& Y, B3& cx, B3&
 }
 // cells of one quad level from the cells of the level above and the boxes of the level itself: one thread per PARENT.
 // The four children are two halves of two (a four-way cut along one axis is the same thing seen as binary cuts).
-__global__ __launch_bounds__(256) void quad_cell_kernel(const Box* __restrict__ pcell, uint32_t nparent, int parent_is_root,
-                                                        const Box* __restrict__ cbox, uint32_t nchild,
-                                                        Box* __restrict__ ccell) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nparent) return;
+__device__ __forceinline__ void quad_cell_node(const Box* __restrict__ pcell, int parent_is_root, const Box* __restrict__ cbox,
+                                               uint32_t nchild, Box* __restrict__ ccell, uint32_t i) {
   B3 pc;
   if (parent_is_root) {
 #pragma unroll
@@ -383,6 +383,42 @@ __global__ __launch_bounds__(256) void quad_cell_kernel(const Box* __restrict__ 
       b.hi = make_float4(cc[c].hi[0], cc[c].hi[1], cc[c].hi[2], 0.0f);
       ccell[4u * i + c] = b;
     }
+  }
+}
+__global__ __launch_bounds__(256) void quad_cell_kernel(const Box* __restrict__ pcell, uint32_t nparent, int parent_is_root,
+                                                        const Box* __restrict__ cbox, uint32_t nchild,
+                                                        Box* __restrict__ ccell) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nparent) quad_cell_node(pcell, parent_is_root, cbox, nchild, ccell, i);
+}
+// The SMALL quad levels in one launch (a 10M-point index has eleven levels; from the fifth up they hold 2,442, 611, 153, ...
+// nodes: seven box launches and seven cell launches of a few microseconds of work and ~5 us of launch each).  One workgroup:
+// boxes of the levels [q_from, q_top] bottom-up, then the cells of the levels [q_from - 1, q_top - 1] top-down, a barrier
+// between levels (the levels' arrays are global memory written and read by this one workgroup).  qbox / qcell: the
+// arrays of all levels, level q at offset off(q) = sum of the counts below it.
+__global__ __launch_bounds__(1024) void quad_top_kernel(Box* __restrict__ qbox, Box* __restrict__ qcell, uint32_t nleaf, int q_from,
+                                                        int q_top) {
+  const auto count = [&](int q) { return lane_tree_count(nleaf, q); };
+  size_t off = 0;
+  for (int q = 0; q < q_from - 1; ++q) off += count(q);
+  // off = offset of level q_from - 1 (the children of the first level built here)
+  size_t o = off;
+  for (int q = q_from; q <= q_top; ++q) {
+    const uint32_t cc = count(q - 1), cp = count(q);
+    for (uint32_t i = threadIdx.x; i < cp; i += blockDim.x) quad_box_node(qbox + o, cc, qbox + o + cc, i);
+    o += cc;
+    __threadfence();
+    __syncthreads();
+  }
+  // o = offset of level q_top
+  for (int q = q_top; q >= q_from; --q) {
+    const uint32_t cc = count(q - 1), cp = count(q);
+    const size_t coff = o - cc;
+    for (uint32_t i = threadIdx.x; i < cp; i += blockDim.x)
+      quad_cell_node(qcell + o, q == q_top ? 1 : 0, qbox + coff, cc, qcell + coff, i);
+    o = coff;
+    __threadfence();
+    __syncthreads();
   }
 }
 
@@ -452,6 +488,15 @@ __device__ __forceinline__ uint32_t orderable(float f) {
 // (`ms_per_step` 1.088 -> 0.991 at 10M points, cold launch 1.83 -> 1.50 ms, same call and box) for 0.13 ms more in this
 // kernel (the 256- and 128-point sorts: 64 more compare-exchange stages).
 // Keys are exact float orders, so cells keep disjoint interiors.
+#ifndef PCLHIP_KDB_MINW
+#define PCLHIP_KDB_MINW 8     // waves per SIMD the register budget admits: 8 = 64 VGPRs = TWO 16-wave workgroups per CU.  The
+                              // kernel waits on LDS round trips (shuffles, gathers through the permutation), not on VALU
+                              // issue: 917 -> 801 us with the packed keys, -> 584 us with the second workgroup resident
+                              // (10M points, round 6; 6 VGPRs spill on the cold 64-bit path)
+#endif
+#ifndef PCLHIP_KDB_PACKED
+#define PCLHIP_KDB_PACKED 1   // A/B: 0 = the (key, position) 64-bit compare-exchange in every binary level
+#endif
 constexpr int KDB_N = 4096;
 constexpr int KDB_THREADS = 1024;
 constexpr int KDB_WAVES = KDB_THREADS / WAVE;
@@ -468,7 +513,20 @@ struct KdBlockLds {
   uint32_t wscan[KDB_WAVES][4];       // per-wave class totals: seven 16-bit fields
 };
 
-__global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __restrict__ in, uint32_t n,
+#ifdef PCLHIP_KDB_TICKS  // timing probe (scratch/kdb_ticks.py): clock64 ticks of thread 0 per phase, summed over the blocks
+__device__ unsigned long long g_kdb_ticks[8];
+#define KDB_LAP(i)                                            \
+  do {                                                        \
+    if (threadIdx.x == 0) {                                   \
+      const unsigned long long kdb_now = clock64();           \
+      kdb_acc[i] += kdb_now - kdb_t;                          \
+      kdb_t = kdb_now;                                        \
+    }                                                         \
+  } while (0)
+#else
+#define KDB_LAP(i) (void)0
+#endif
+__global__ __launch_bounds__(KDB_THREADS, PCLHIP_KDB_MINW) void kd_block_kernel(const float4* __restrict__ in, uint32_t n,
                                                                float4* __restrict__ out, uint32_t top_nsub,
                                                                uint32_t bottom_nsub, uint32_t* __restrict__ rank) {
   __shared__ KdBlockLds s;
@@ -477,6 +535,9 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
   const uint32_t base = blockIdx.x * uint32_t(KDB_N);
   if (base >= n) return;
   const uint32_t cnt = (n - base) < uint32_t(KDB_N) ? (n - base) : uint32_t(KDB_N);
+#ifdef PCLHIP_KDB_TICKS
+  unsigned long long kdb_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kdb_t = clock64();
+#endif
   for (uint32_t p = t; p < uint32_t(KDB_N); p += KDB_THREADS) {
     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (p < cnt) v = in[base + p];
@@ -484,7 +545,12 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
     s.perm[p] = uint16_t(p);
   }
   __syncthreads();
+  KDB_LAP(0);   // load
   for (uint32_t nsub = top_nsub; nsub >= bottom_nsub; nsub = (nsub >= uint32_t(KDB_FOURWAY_FROM)) ? nsub / 4u : nsub / 2u) {
+#ifdef PCLHIP_KDB_PROBE  // timing probes only (scratch/): 1 = skip the four-way levels, 2 = skip the binary levels, 3 = both
+    if ((PCLHIP_KDB_PROBE & 1) && nsub >= uint32_t(KDB_FOURWAY_FROM)) continue;
+    if ((PCLHIP_KDB_PROBE & 2) && nsub < uint32_t(KDB_FOURWAY_FROM)) break;
+#endif
     // (a) bounding box of the sub-segment this thread's four positions belong to
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     uint32_t idx[4];
@@ -531,6 +597,7 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
     if (ey > best) { best = ey; a = 1; }
     if (ez > best) { a = 2; }
     uint32_t kk[4], pp[4];
+    KDB_LAP(1);   // boxes + axis (all levels)
     if (nsub >= uint32_t(KDB_FOURWAY_FROM)) {
       // ---- four-way level: quartile selection + partition (block-uniform branch) ---------------------------------
       const uint32_t sub = t / group;
@@ -556,6 +623,10 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
       if (tin == 0u) atomicMax(&s.max_bits, uint32_t(nb));
       __syncthreads();
       const int npass = int(s.max_bits + 6u) / 7;
+      KDB_LAP(2);   // four-way: keys + setup
+#ifdef PCLHIP_KDB_TICKS
+      if (threadIdx.x == 0) kdb_acc[7] += (unsigned long long)npass;
+#endif
       for (int pass = 0; pass < npass; ++pass) {
         const int hi_b = nb - 7 * pass;  // this pass decides bits [lo_b, hi_b) of the sub-segment's keys
         const bool active = hi_b > 0;
@@ -614,6 +685,7 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
         if (active && tin < 3u) s.sel_prefix[sub][tin] |= s.sel_digit[sub][tin] << lo_b;
       }
       __syncthreads();
+      KDB_LAP(3);   // four-way: selection passes
       const uint32_t s1 = s.sel_prefix[sub][0], s2 = s.sel_prefix[sub][1], s3 = s.sel_prefix[sub][2];
       // classes, monotone in the key; layout by (class, previous position)
       uint32_t cls[4], w0 = 0u, w1 = 0u, w2 = 0u, w3 = 0u;
@@ -677,64 +749,144 @@ __global__ __launch_bounds__(KDB_THREADS) void kd_block_kernel(const float4* __r
 #pragma unroll
       for (int e = 0; e < 4; ++e) s.perm[dest[e]] = uint16_t(pp[e]);
       __syncthreads();
+      KDB_LAP(4);   // four-way: classify + scan + permute
       continue;
     }
     // ---- binary levels (256 ... 32 points): bitonic sort inside a wavefront -------------------------------------
-    // (b) keys: the coordinate along that axis in unsigned order; padding sorts last.  The thread's four
-    // (key, position) pairs live in registers from here on.
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint32_t p = 4u * t + uint32_t(e);
-      const float c = a == 0 ? s.x[idx[e]] : (a == 1 ? s.y[idx[e]] : s.z[idx[e]]);
-      kk[e] = p < cnt ? orderable(c) : 0xFFFFFFFFu;
-      pp[e] = idx[e];
-    }
-    // (c) bitonic sort of (key, position) inside every sub-segment, ascending.  Element i = 4t + e meets i ^ j:
-    // inside the thread for j < 4, across lanes (shuffle) above that (nsub <= 256: j <= 128, 32 lanes away).
-    for (uint32_t k = 2; k <= nsub; k <<= 1) {
-      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        uint32_t ok[4], op[4];
-        if (j >= 4u) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            ok[e] = __shfl_xor(kk[e], int(j >> 2));
-            op[e] = __shfl_xor(pp[e], int(j >> 2));
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            ok[e] = j == 1u ? kk[e ^ 1] : kk[e ^ 2];
-            op[e] = j == 1u ? pp[e ^ 1] : pp[e ^ 2];
-          }
-        }
-        // the lower slot of an ascending pair keeps the smaller (key, position); for j, k >= 4 the direction is the
-        // same for the thread's four elements (i = 4t + e)
-        const uint32_t i0 = 4u * t;
+    // A wavefront holds a whole 256-point sub-segment (a thread four consecutive positions), so these levels touch no
+    // other wavefront's slice of the permutation: wave barriers order their LDS traffic, no workgroup barrier.
+    // PACKED form (round 6): the key of an element is its coordinate's unsigned order RELATIVE to the sub-segment's
+    // minimum -- 24 bits or fewer for any cell that does not straddle zero or a dozen binades -- with the element's
+    // position inside the sub-segment in the low 8 bits: ONE 32-bit word that is unique, orders by (coordinate, current
+    // position), and tells where the winner of a slot came from.  A compare-exchange is then one shuffle, a min and a
+    // max instead of two shuffles and a 64-bit compare with two selects (the 100 stages of these four levels were
+    // 43 % of this kernel's cycles, VALU-issue-bound at 4 waves per SIMD: scratch/kdb_ticks.py).  The payload (the
+    // index into the coordinate planes) is fetched once per level from the permutation slot the low bits name.
+    // A wavefront with a wider sub-segment takes the (key, position) 64-bit form below.
+    const uint32_t lp0 = (4u * t) & (nsub - 1u);   // position of the thread's first element inside its sub-segment
+    const uint32_t segbase = (4u * t) & ~(nsub - 1u);
+    bool packed = false;
+#if PCLHIP_KDB_PACKED
+    {
+      const bool empty = !(lo[0] <= hi[0]);
+      const uint32_t kmin = empty ? 0u : orderable(a == 0 ? lo[0] : (a == 1 ? lo[1] : lo[2]));
+      const uint32_t W = empty ? 0u : orderable(a == 0 ? hi[0] : (a == 1 ? hi[1] : hi[2])) - kmin;
+      packed = __builtin_amdgcn_ballot_w64(W >= 0x00FFFFFEu) == 0ull;   // wave-uniform: every sub-segment of the wave fits
+      if (packed) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const uint32_t i = i0 + uint32_t(e);
-          const bool lower = (i & j) == 0u, up = ((i & (nsub - 1u)) & k) == 0u;
-          const unsigned long long own = ((unsigned long long)kk[e] << 32) | pp[e];
-          const unsigned long long oth = ((unsigned long long)ok[e] << 32) | op[e];
-          const bool keep_own = (lower == up) == (own < oth);
-          kk[e] = keep_own ? kk[e] : ok[e];
-          pp[e] = keep_own ? pp[e] : op[e];
+          const uint32_t p = 4u * t + uint32_t(e);
+          const float c = a == 0 ? s.x[idx[e]] : (a == 1 ? s.y[idx[e]] : s.z[idx[e]]);
+          // padding sorts last: above every real key (relative keys stay below 0xFFFFFE)
+          kk[e] = (p < cnt ? ((orderable(c) - kmin) << 8) : 0xFFFFFF00u) | (lp0 + uint32_t(e));
+        }
+        for (uint32_t k = 2; k <= nsub; k <<= 1) {
+          const bool up = (((4u * t) & (nsub - 1u)) & k) == 0u;   // k >= 4: the same for the thread's four elements
+          for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 4u) {
+              const bool take_min = (((4u * t) & j) == 0u) == up;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const uint32_t o = __shfl_xor(kk[e], int(j >> 2));
+                kk[e] = take_min ? (kk[e] < o ? kk[e] : o) : (kk[e] > o ? kk[e] : o);
+              }
+            } else {
+              uint32_t o[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = j == 1u ? kk[e ^ 1] : kk[e ^ 2];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const uint32_t i = 4u * t + uint32_t(e);
+                const bool lower = (i & j) == 0u, upe = ((i & (nsub - 1u)) & k) == 0u;   // k == 2: differs inside the thread
+                kk[e] = (lower == upe) ? (kk[e] < o[e] ? kk[e] : o[e]) : (kk[e] > o[e] ? kk[e] : o[e]);
+              }
+            }
+          }
+        }
+        // slot 4t + e now holds the element that stood at position (kk & 255) of the sub-segment: its payload
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pp[e] = s.perm[segbase + (kk[e] & 0xFFu)];
+      }
+    }
+#endif
+    if (!packed) {
+      // (b) keys: the coordinate along that axis in unsigned order; padding sorts last.  The thread's four
+      // (key, position) pairs live in registers from here on.
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t p = 4u * t + uint32_t(e);
+        const float c = a == 0 ? s.x[idx[e]] : (a == 1 ? s.y[idx[e]] : s.z[idx[e]]);
+        kk[e] = p < cnt ? orderable(c) : 0xFFFFFFFFu;
+        pp[e] = idx[e];
+      }
+      // (c) bitonic sort of (key, position) inside every sub-segment, ascending.  Element i = 4t + e meets i ^ j:
+      // inside the thread for j < 4, across lanes (shuffle) above that (nsub <= 256: j <= 128, 32 lanes away).
+      for (uint32_t k = 2; k <= nsub; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+          uint32_t ok[4], op[4];
+          if (j >= 4u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              ok[e] = __shfl_xor(kk[e], int(j >> 2));
+              op[e] = __shfl_xor(pp[e], int(j >> 2));
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              ok[e] = j == 1u ? kk[e ^ 1] : kk[e ^ 2];
+              op[e] = j == 1u ? pp[e ^ 1] : pp[e ^ 2];
+            }
+          }
+          // the lower slot of an ascending pair keeps the smaller (key, position); for j, k >= 4 the direction is the
+          // same for the thread's four elements (i = 4t + e)
+          const uint32_t i0 = 4u * t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t i = i0 + uint32_t(e);
+            const bool lower = (i & j) == 0u, up = ((i & (nsub - 1u)) & k) == 0u;
+            const unsigned long long own = ((unsigned long long)kk[e] << 32) | pp[e];
+            const unsigned long long oth = ((unsigned long long)ok[e] << 32) | op[e];
+            const bool keep_own = (lower == up) == (own < oth);
+            kk[e] = keep_own ? kk[e] : ok[e];
+            pp[e] = keep_own ? pp[e] : op[e];
+          }
         }
       }
     }
-    __syncthreads();  // readers of perm (this level's idx[]) are done
+    __builtin_amdgcn_wave_barrier();  // the wave's readers of perm (this level's idx[], the payload fetch) are done
 #pragma unroll
     for (int e = 0; e < 4; ++e) s.perm[4u * t + uint32_t(e)] = uint16_t(pp[e]);
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();  // ... and the next level reads what the wave just wrote (LDS is in order per wave)
+    KDB_LAP(5);   // binary levels: keys + bitonic sort + permutation
     if (nsub == 32u) break;  // (guards the unsigned loop condition when bottom_nsub is 32)
   }
+  __syncthreads();  // the binary levels ran wave by wave: the output pass below reads every wave's slice
   // the last level: `out` is the caller's array, and the position of every original index goes with it
   for (uint32_t p = t; p < cnt; p += KDB_THREADS) {
     const float4 v = in[base + s.perm[p]];
     out[base + p] = v;
     if (rank) rank[__float_as_uint(v.w)] = base + p;
   }
+#ifdef PCLHIP_KDB_TICKS
+  __syncthreads();
+  KDB_LAP(6);   // output gather + rank scatter
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_kdb_ticks[i], kdb_acc[i]);
+#endif
 }
+#ifdef PCLHIP_KDB_TICKS
+}  // namespace
+}  // namespace pclhip
+extern "C" __attribute__((visibility("default"))) void pclhip_debug_kdb_ticks(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pclhip::g_kdb_ticks), 8 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(pclhip::g_kdb_ticks), z, sizeof z);
+  }
+}
+namespace pclhip {
+namespace {
+#endif
 
 // ---- top kd rounds by selection + partition ----------------------------------------------------------
 // A round only has to cut every segment into four slabs at its quartile ORDER STATISTICS; the order inside a
@@ -1711,13 +1863,24 @@ pclhip_status build_boxes(pclhip_index* ix, bool with_discs) {
   if (lane_tree) {  // quad levels bottom-up (boxes), then top-down (cells): ~2 x 13 small launches at 10M points
     const uint32_t nleaf = ix->count[1];
     size_t off = 0;
-    for (int q = 1; q <= ix->qtop; ++q) {
+    // the large levels one launch each; the levels of at most QUAD_TOP_NODES nodes together in one workgroup
+    // (quad_top_kernel: boxes up, cells down) -- 20 launches become 8 at 10M points
+    constexpr uint32_t QUAD_TOP_NODES = 4096;
+    int q_small = ix->qtop + 1;   // first level built by the fused kernel
+    for (int q = 1; q <= ix->qtop; ++q)
+      if (lane_tree_count(nleaf, q) <= QUAD_TOP_NODES) {
+        q_small = q;
+        break;
+      }
+    for (int q = 1; q < q_small; ++q) {
       const uint32_t cc = lane_tree_count(nleaf, q - 1), cp = lane_tree_count(nleaf, q);
       hipLaunchKernelGGL(quad_box_kernel, dim3((cp + 255) / 256), dim3(256), 0, s, ix->qbox + off, cc, ix->qbox + off + cc, cp);
       off += cc;
     }
-    // off = offset of the top level now
-    for (int q = ix->qtop; q >= 1; --q) {
+    // off = offset of level q_small - 1 now
+    if (q_small <= ix->qtop)
+      hipLaunchKernelGGL(quad_top_kernel, dim3(1), dim3(1024), 0, s, ix->qbox, ix->qcell, nleaf, q_small, ix->qtop);
+    for (int q = q_small - 1; q >= 1; --q) {
       const uint32_t cc = lane_tree_count(nleaf, q - 1), cp = lane_tree_count(nleaf, q);
       const size_t coff = off - cc;
       hipLaunchKernelGGL(quad_cell_kernel, dim3((cp + 255) / 256), dim3(256), 0, s, ix->qcell + off, cp, q == ix->qtop ? 1 : 0,

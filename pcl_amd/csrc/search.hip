@@ -1937,12 +1937,12 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     // well above its noise: thickness ratio ~0.1 at the bench's 10M points).  Where the noise is of the order of the point
     // spacing (ratio 0.3 at 100M points of the same surface) every query needs tens of leaves whatever the bound, the
     // lists outgrow the LDS, and the seeded search is the faster one (measured: 76 against 108 ms at 100M).
-    constexpr float SO_THICKNESS = 0.2f;
+    const float SO_THICKNESS = ctx->opt_standoff_thickness;   // 0.2 (option "standoff_thickness": A/B on other geometries)
     // ... and a gate on the index size.  Measured in round 4 with the front-ordered runs (cold launch, stand-off search
     // against traverse(), ms): 12M points 3.5 / 3.6, 15M 4.7 / 4.5, 20M 8.0 / 7.2 -- beyond ~0.7 GB of index (points + leaf
     // blocks + boxes, 56 B per point) the leaf blocks no longer stay in the 256 MB last-level cache under either body
     // (both jump from 2.0 ms at 10M to 3.5 ms at 12M) and the stand-off search's longer lists cost more than they prune.
-    constexpr size_t SO_MAX_INDEX_BYTES = size_t(640) << 20;
+    const size_t SO_MAX_INDEX_BYTES = size_t(ctx->opt_standoff_max_mb) << 20;   // 640 MB (option "standoff_max_mb")
     const bool standoff = v.disc != nullptr && icp->target->disc_thickness < SO_THICKNESS &&
                           size_t(icp->target->n_pad) * 56u <= SO_MAX_INDEX_BYTES;
     const bool cold = standoff && !device_loop && icp->seeds_cleared;

@@ -72,7 +72,8 @@ def test_two_ranks_of_eight_at_100m_equal_the_oracle(job):
             # the rank with the largest halo: the launch that starts the alignment and two seeded ones; rank 0: one seeded
             # launch after the cold one (the oracle's pass over a rank's 12.5M served points of a 100M-point target is
             # what this module's time goes into: four passes instead of six keep the GPU tier inside its budget)
-            for K in ((1, 2, 3) if r == ranks[-1] or len(ranks) == 1 else (2,)):
+            checked = (1, 2, 3) if r == ranks[-1] or len(ranks) == 1 else (2,)
+            for K in (1, 2, 3)[:max(checked)]:
                 icp = pcl_amd.IterativeClosestPointWithNormals(ctx)     # fresh: the criteria keep their memory across align() calls
                 icp.setSearchMethodTarget(st.tree, True)
                 icp.setInputSource(src)
@@ -82,8 +83,9 @@ def test_two_ranks_of_eight_at_100m_equal_the_oracle(job):
                 icp.setMaximumIterations(K)
                 icp.align()                                              # device-driven loop, served-group lists on
                 assert icp.nr_iterations_ == K
-                total += assert_rank_matches_oracle(icp.fetchCorrespondences(), cur, st.region, otree,
-                                                    "rank %d of %d, launch %d" % (r, WORLD, K))
+                if K in checked:
+                    total += assert_rank_matches_oracle(icp.fetchCorrespondences(), cur, st.region, otree,
+                                                        "rank %d of %d, launch %d" % (r, WORLD, K))
                 cur = orc.transform_cloud(icp.getLastIncrementalTransformation(), cur, order=1)
                 del icp
             print("config 5 at size: rank %d of %d (slab + halo %d points, halo %d): %d correspondences equal "
