@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="pclhip_ctx_set_option before anything is built (A/B runs: lane_search=0, lane_max_up=1, ...)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-families", action="store_true",
+                    help="skip the `families` sub-record (the same measurement on the cube / layers / clusters clouds)")
     ap.add_argument("--no-host-align", action="store_true", help="skip the host-boundary timing (examples/bench_pcl_align.cpp)")
     return ap.parse_args()
 
@@ -247,6 +249,44 @@ def main():
         except Exception:
             pass
 
+    # ---- the same measurement OFF the metric's geometry: a volume, two close layers, 100x density contrast
+    # (pcl_amd/synth.py: family_cloud; PCL's own search tests use volumetric random clouds, test/search/test_search.cpp
+    # :292-364).  Not part of `value`: a sub-record, so that the driver's line shows how far the headline generalises.
+    families = None
+    if (cfg == 3 and world == 1 and args.cloud == "sheet" and not args.no_families and not args.rejectors and not args.reciprocal
+            and not args.points):
+        families = {}
+        sheet_ms = elapsed / max(args.steps, 1) * 1e3
+        sheet_first = float(np.mean([s_["search_ms"] for s_ in steps if s_["iteration"] == 1] or [0.0]))
+        for kind in ("cube", "layers", "clusters"):
+            f_tgt = torch.from_numpy(synth.family_cloud(kind, n, synth.TARGET_SEED)).cuda()
+            f_src = torch.from_numpy(synth.apply_rigid(np.linalg.inv(synth.ground_truth_transform()),
+                                                       synth.family_cloud(kind, n, synth.SOURCE_SEED))).cuda()
+            f_tree = pcl_amd.KdTree(ctx)
+            f_tree.setInputCloud(f_tgt)
+            f_ne = pcl_amd.NormalEstimation(ctx)
+            f_ne.setInputCloud(f_tgt)
+            f_ne.setSearchMethod(f_tree)
+            f_ne.setKSearch(args.knn)
+            f_ne.setViewPoint(0, 0, 10)
+            f_ne.compute(want_output=False)
+            f_icp = cls(ctx)
+            f_icp.setSearchMethodTarget(f_tree, True)
+            f_icp.setInputSource(f_src)
+            f_icp.setMaximumIterations(20)
+            f_icp.setMaxCorrespondenceDistance(0.1)
+            f_icp.setTransformationEpsilon(1e-10)
+            f_steps, f_elapsed = timed_steps(f_icp, args.steps, args.warmup, fence, world)
+            f_ms = f_elapsed / max(args.steps, 1) * 1e3
+            f_first = float(np.mean([s_["search_ms"] for s_ in f_steps if s_["iteration"] == 1] or [0.0]))
+            its = [s_["iteration"] for s_ in f_steps if s_["alignment_ended"]]
+            families[kind] = {"ms_per_step": round(f_ms, 4), "over_sheet": round(f_ms / sheet_ms, 3),
+                              "first_launch_search_ms": round(f_first, 4),
+                              "first_launch_over_sheet": round(f_first / sheet_first, 2) if sheet_first > 0 else None,
+                              "iterations_per_alignment": its[0] if its else None,
+                              "value": round(float(sum(s_["num_correspondences"] for s_ in f_steps)) / f_elapsed, 1)}
+            del f_icp, f_ne, f_tree, f_tgt, f_src
+
     out = None
     if rank == 0:
         cpu = None
@@ -274,7 +314,7 @@ def main():
                                "kernels queued back to back",
                        "parallelism": "source slab sharded x%d, target replicated%s" %
                                       (world, ", ncclAllReduce of the 32-double record per iteration" if world > 1 else "")},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "families": families,
             "per_step": [{"iteration": s["iteration"], "search_ms": round(s["search_ms"], 4),
                           "step_ms": round(s["step_ms"], 4), "ended": s["alignment_ended"], "state": s["state"]} for s in steps],
             "setup": {"index_build_ms": round(build_ms, 3), "index_build_first_ms": round(build_first_ms, 3),
@@ -431,6 +471,25 @@ def host_cpus():
     return threads, (len(cores) or None)
 
 
+def cpu_quota():
+    """CPU time this container may use, in cores (cgroup v2 cpu.max, v1 cfs quota), or None when unlimited / unknown.  A GPU box
+    shows every hardware thread of its host to a container that may only run on a few cores' worth of time: threads
+    beyond the quota are throttled, not run."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(per)
+        return None
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_pipeline(args, tgt, src):
     """config 4 on the host cores: the oracle's VoxelGrid (single thread, as in PCL) + kd-tree + normals + ICP."""
     from oracle import pcl_oracle as orc
@@ -508,7 +567,13 @@ def cpu_baseline(args, mode, n, tgt, src):
     import numpy as np
     from oracle import pcl_oracle as orc
     hw_threads, phys = host_cpus()
+    quota = cpu_quota()
+    # threads of the headline figure: every hardware thread -- unless the container's CPU quota is smaller, in which case more
+    # threads than the quota only add throttling (measured on a 256-thread host with a 16-core quota: 256 threads reach
+    # 11x one thread, the quota's worth of threads is what the box can give)
     cores = orc.default_threads()
+    if quota is not None and quota < cores:
+        cores = max(1, int(round(quota)))
     interleaved = interleave_memory(True)
     t0 = time.perf_counter()
     tree = orc.KdTree(tgt)
@@ -540,6 +605,7 @@ def cpu_baseline(args, mode, n, tgt, src):
     n_sample = n_all
     out = {"value": round(r["num_correspondences"] / per_iter, 1), "unit": "correspondences/s", "cores": cores,
            "threads_used": cores, "host_hardware_threads": hw_threads, "host_physical_cores": phys,
+           "container_cpu_quota_cores": quota,
            "kind": "port",
            "sample": "the bench's own %d-point target and %s%d-point source in Morton order, %d ICP iterations on %d threads "
                      "(search %.3f s + serial estimate/transform %.3f s per iteration); 1 thread: one iteration over "
@@ -557,6 +623,11 @@ def cpu_baseline(args, mode, n, tgt, src):
                              "sample_points": m1}}
     one = r1["seconds_search"] / m1
     out["search_speedup_over_one_thread"] = round(one / (r["seconds_search"] / it / n_sample), 1)
+    if quota is not None and quota < hw_threads:   # every hardware thread all the same: what oversubscribing the quota gives
+        ra, ita, per_a = run(src_sorted, hw_threads, 2)
+        out["all_hardware_threads"] = {"value": round(ra["num_correspondences"] / per_a, 1), "unit": "correspondences/s",
+                                       "cores": hw_threads, "search_ms_per_iteration": round(ra["seconds_search"] / ita * 1e3, 2),
+                                       "search_speedup_over_one_thread": round(one / (ra["seconds_search"] / ita / n_sample), 1)}
     if phys and phys < cores:   # one thread per physical core
         rp, itp, per_p = run(src_sorted, phys, 2)
         out["physical_cores"] = {"value": round(rp["num_correspondences"] / per_p, 1), "unit": "correspondences/s", "cores": phys,

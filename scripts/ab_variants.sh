@@ -3,7 +3,7 @@
 #   -> gpurun_out/<tag>/ab.log + one summary line per build (ms/step, search ms per iteration of an alignment)
 set -u
 TAG=$1; VARS=$2; shift; shift
-ARGS=${@:-"--no-cpu-baseline --no-host-align"}
+ARGS=${@:-"--no-cpu-baseline --no-host-align --no-families"}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 for v in default $VARS; do
   L=pcl_amd/libpclhip.so; [ $v != default ] && L=pcl_amd/variants/libpclhip_$v.so

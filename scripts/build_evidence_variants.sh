@@ -9,3 +9,4 @@ bash scripts/build_variant.sh nrmprof "-DPCLHIP_NRM_PROFILE"
 bash scripts/build_variant.sh icpprof "-DPCLHIP_ICP_PROFILE"
 bash scripts/build_variant.sh lanes "-DPCLHIP_STATS_LANES"
 bash scripts/build_variant.sh rec1 "-DPCLHIP_REC_CAP=1"
+bash scripts/build_variant.sh kdbticks "-DPCLHIP_KDB_TICKS" index_build.hip

@@ -7,7 +7,7 @@ set -u
 TAG=${1:-r1}; PASSES=${2:-"trace sq1 sq2 fetch write tcc"}; shift; shift
 # default: the driver's own command (bench.py with no flags = --steps 20 --warmup 5), less the CPU baseline, so that the
 # summary's average launch duration is the bench line's roofline.avg_kernel_ms (4 alignments x 5 iterations timed)
-ARGS=${@:-"--steps 20 --warmup 5 --no-cpu-baseline --no-host-align"}
+ARGS=${@:-"--steps 20 --warmup 5 --no-cpu-baseline --no-host-align --no-families"}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -5,7 +5,7 @@ TAG=$1; REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tm
 for v in $2; do
   L=$REPO/pcl_amd/libpclhip.so; [ $v != default ] && L=$REPO/pcl_amd/variants/libpclhip_$v.so
   rm -rf /tmp/rp_$v
-  PCLHIP_LIB=$L timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/rp_$v -o t --output-format csv -- python $REPO/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-host-align > $OUT/$v.log 2>&1
+  PCLHIP_LIB=$L timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/rp_$v -o t --output-format csv -- python $REPO/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-host-align --no-families > $OUT/$v.log 2>&1
   f=$(find /tmp/rp_$v -name "*kernel_stats.csv" | head -1)
   echo "== $v"
   cp "$f" $OUT/${v}_kernel_stats.csv
