@@ -88,7 +88,9 @@ PCLHIP_API pclhip_status pclhip_ctx_reserve(pclhip_ctx* ctx, uint64_t bytes);
  *                           greedy walk down the hierarchy (default 1)
  *   "lane_search"    0 | 1  the seeded launches of an ICP iteration run one lane per query over the quad levels and their
  *                           cells (lane.hip) instead of the wave-cooperative traversal (default 0: exact, measured 2.5x
- *                           slower at 10M points); "lane_max_up" n (default 2) quad levels the first pass climbs,
+ *                           slower at 10M points -- and in the device-driven loop every iteration then queues the
+ *                           fall-through search kernel plus three lane kernels, launch overhead that figure does not
+ *                           separate out); "lane_max_up" n (default 2) quad levels the first pass climbs,
  *                           "lane_far" x (default 0.25) squared mean leaf diagonals beyond which a seed is replaced
  *   "standoff_thickness" x, "standoff_max_mb" n   which indices the launch that starts an alignment searches by the stand-off
  *                           body (leaf discs): leaves thinner than x against their width (default 0.2) and an index of at

@@ -547,10 +547,6 @@ __global__ __launch_bounds__(KDB_THREADS, PCLHIP_KDB_MINW) void kd_block_kernel(
   __syncthreads();
   KDB_LAP(0);   // load
   for (uint32_t nsub = top_nsub; nsub >= bottom_nsub; nsub = (nsub >= uint32_t(KDB_FOURWAY_FROM)) ? nsub / 4u : nsub / 2u) {
-#ifdef PCLHIP_KDB_PROBE  // timing probes only (scratch/): 1 = skip the four-way levels, 2 = skip the binary levels, 3 = both
-    if ((PCLHIP_KDB_PROBE & 1) && nsub >= uint32_t(KDB_FOURWAY_FROM)) continue;
-    if ((PCLHIP_KDB_PROBE & 2) && nsub < uint32_t(KDB_FOURWAY_FROM)) break;
-#endif
     // (a) bounding box of the sub-segment this thread's four positions belong to
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     uint32_t idx[4];
