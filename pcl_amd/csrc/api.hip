@@ -458,17 +458,15 @@ pclhip_status pclhip::sharded_filters_ok(pclhip_icp* icp) {
 
 extern "C" {
 
-#ifdef PCLHIP_WAVESIM  // the CPU emulation of the test tier (tests/wavesim) says what it is: pcl_amd/_lib.py refuses it unless asked
-const char* pclhip_version(void) {
-  return pclhip::search_built_with_verify_bounds() ? "pclhip 0.1 (wavesim: CPU emulation, test infrastructure; verify-bounds build)"
-                                                   : "pclhip 0.1 (wavesim: CPU emulation, test infrastructure)";
-}
-#else
+// The CPU emulation of the test tier (tests/wavesim) says what it is -- pcl_amd/_lib.py refuses it unless asked --: its runtime
+// DEFINES this function, the product does not (a weak reference, null here): a link-time hook, no conditional compilation.
+__attribute__((weak)) const char* pclhip_emulation_banner(int verify_bounds);
 const char* pclhip_version(void) {
   // (search.hip says whether it was compiled with -DPCLHIP_VERIFY_BOUNDS: scripts/build_variant.sh rebuilds that unit only)
-  return pclhip::search_built_with_verify_bounds() ? "pclhip 0.1 (gfx950, verify-bounds build: test infrastructure)" : "pclhip 0.1 (gfx950)";
+  const bool vb = pclhip::search_built_with_verify_bounds();
+  if (&pclhip_emulation_banner != nullptr) return pclhip_emulation_banner(vb ? 1 : 0);
+  return vb ? "pclhip 0.1 (gfx950, verify-bounds build: test infrastructure)" : "pclhip 0.1 (gfx950)";
 }
-#endif
 
 const char* pclhip_last_error(const pclhip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
 

@@ -10,7 +10,7 @@ cd "$(dirname "$0")/../pcl_amd/csrc"
 make -j8 HIPCC="$HIPCC" ARCH="$ARCH" >/dev/null
 mkdir -p ../variants
 $HIPCC -O3 -std=c++17 -fPIC --offload-arch=$ARCH -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-result \
-  -I../../include $flags -c $src -o ../variants/${obj}_$name.o
+  -I../../include -I. $flags -c $src -o ../variants/${obj}_$name.o
 objs=$(ls *.o | grep -v "^$obj.o$")
 $HIPCC --offload-arch=$ARCH -shared -fPIC -o ../variants/libpclhip_$name.so ../variants/${obj}_$name.o $objs -ldl
 echo built pcl_amd/variants/libpclhip_$name.so

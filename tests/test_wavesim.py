@@ -52,7 +52,7 @@ def variant_lib(tmp_path_factory):
     mk = mk.replace("SRC = ../../pcl_amd/csrc", "SRC = %s" % os.path.join(ROOT, "pcl_amd", "csrc"))
     mk = mk.replace("-I../../include", "-I" + os.path.join(ROOT, "include")).replace("../../include/pclhip.h", os.path.join(ROOT, "include", "pclhip.h"))
     (build / "Makefile").write_text(mk)
-    for f in ("wavesim.hpp", "wavesim_rt.cpp"):
+    for f in ("wavesim.hpp", "wavesim_rt.cpp", "pclhip_wave_reduce.hpp"):
         shutil.copy(os.path.join(WS, f), str(build / f))
     r = subprocess.run(["make", "-C", str(build), "-j", str(min(16, os.cpu_count() or 1)),
                         "EXTRA=-DPCLHIP_OWN_HIST_CAP=3 -DPCLHIP_VERIFY_BOUNDS"], capture_output=True, text=True)
@@ -242,7 +242,7 @@ def test_kernels_and_host_api_under_asan_ubsan(tmp_path):
     mk = mk.replace("$(CXX) -std=c++17 -O2 -g -fPIC -fvisibility=hidden -D__HIP_PLATFORM_AMD__",
                     "$(CXX) -std=c++17 -O1 -g -fPIC -fvisibility=hidden -fsanitize=address,undefined -D__HIP_PLATFORM_AMD__")
     (build / "Makefile").write_text(mk)
-    for f in ("wavesim.hpp", "wavesim_rt.cpp"):
+    for f in ("wavesim.hpp", "wavesim_rt.cpp", "pclhip_wave_reduce.hpp"):
         shutil.copy(os.path.join(WS, f), str(build / f))
     r = subprocess.run(["make", "-C", str(build), "-j", str(min(16, os.cpu_count() or 1)),
                         "EXTRA=-fsanitize=address,undefined -fno-omit-frame-pointer"], capture_output=True, text=True)

@@ -568,3 +568,9 @@ __attribute__((visibility("hidden"))) int ncclAllReduce(const void* send, void* 
 }
 
 }  // extern "C"
+
+// what pclhip_version() of a library linked with this runtime says (api.hip holds a weak reference to this function)
+extern "C" __attribute__((visibility("default"))) const char* pclhip_emulation_banner(int verify_bounds) {
+  return verify_bounds ? "pclhip 0.1 (wavesim: CPU emulation, test infrastructure; verify-bounds build)"
+                       : "pclhip 0.1 (wavesim: CPU emulation, test infrastructure)";
+}
