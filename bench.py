@@ -78,7 +78,7 @@ def kernel_sources_sha():
     stamps the counter passes with it)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("search.hip", "traverse.hpp", "standoff.hpp", "pclhip_internal.hpp", "index_build.hip"):
+    for f in ("search.hip", "traverse.hpp", "pclhip_wave_reduce.hpp", "standoff.hpp", "pclhip_internal.hpp", "index_build.hip"):
         h.update(open(os.path.join(ROOT, "pcl_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -22,7 +22,7 @@ def kernel_sources_sha():
     import hashlib
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pcl_amd", "csrc")
     h = hashlib.sha256()
-    for f in ("search.hip", "traverse.hpp", "standoff.hpp", "pclhip_internal.hpp", "index_build.hip"):
+    for f in ("search.hip", "traverse.hpp", "pclhip_wave_reduce.hpp", "standoff.hpp", "pclhip_internal.hpp", "index_build.hip"):
         h.update(open(os.path.join(root, f), "rb").read())
     return h.hexdigest()[:16]
 
