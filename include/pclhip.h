@@ -14,6 +14,9 @@
  *    at byte 0 of each record (pcl::PointXYZ = 16 B, pcl::PointNormal = 48 B with the normal at
  *    +16, common/include/pcl/impl/point_types.hpp:315-321,843-853).  Buffers may live in host OR
  *    device memory -- the library detects which (hipPointerGetAttributes) and stages host data.
+ *    A DEVICE buffer must be complete when it is handed over: the context works on its own stream and
+ *    does not wait for the stream that is still producing the buffer (create the context on that stream
+ *    with pclhip_ctx_create_on_stream, or synchronise the producer first).
  *  - index_t is int32 (common/include/pcl/types.h:110-133); "no neighbour" is -1, distance +inf.
  *  - a handle is not thread-safe, with one exception: the QUERY entry points pclhip_knn and
  *    pclhip_radius_search may be called concurrently on one index / context (PCL calls its `const`

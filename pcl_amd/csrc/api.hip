@@ -816,6 +816,35 @@ pclhip_status pclhip_index_cells(pclhip_index* ix, int level, float* boxes, floa
   return PCLHIP_OK;
 }
 
+// FEW queries against a LARGE index.  A wavefront owns 64 consecutive queries of the sorted batch and walks the tree for
+// the box of all of them: compact when the batch is as dense as the cloud (a source cloud, self-queries), but 64 of a
+// few thousand queries scattered over a 10M-point cloud span a sizeable part of it -- measured (round 6, random queries on
+// the 10M-point sheet): 16 queries 117 ms, 1024 queries 34 ms, 16,384 queries 3.8 ms, 262,144 queries 0.9 ms per call.
+// Such a batch is laid out with FEWER queries per wavefront: `fill` real queries in front of every 64-slot group, the
+// other slots non-finite (they take no part in the search; their rows go to a dump row behind the results).  `fill` keeps
+// the target points a group spans (about fill * n / nq) near SPARSE_SPAN.
+constexpr uint64_t SPARSE_SPAN = 1024;
+static uint32_t sparse_fill(uint64_t nq, uint64_t n_index) {
+  if (n_index == 0 || nq == 0) return WAVE;
+  const uint64_t f = SPARSE_SPAN * nq / n_index;
+  if (f >= uint64_t(WAVE)) return WAVE;
+  // a power of two: the sorted batch is in kd order (every aligned run of 16 * 4^j queries is a cell, and inside a run of
+  // 16 the halves of the last binary cuts), so ALIGNED runs of 2^j queries are compact -- a run of 6 or 26 would straddle
+  // cell boundaries, and the one that straddles the top-level cut spans the whole cloud (measured: 16,384 queries laid
+  // out 6 per wavefront 13 ms, 65,536 queries 26 per wavefront 74 ms per call)
+  uint32_t p = 1;
+  while (uint64_t(p) * 2 <= f) p *= 2;
+  return p;
+}
+__global__ void sparse_expand_kernel(const float4* __restrict__ q, uint32_t nq, uint32_t fill, float4* __restrict__ out,
+                                     uint32_t n_out, uint32_t dump_row) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n_out) return;
+  const uint32_t g = slot / WAVE, l = slot % WAVE, src = g * fill + l;
+  const float qnan = __builtin_nanf("");
+  out[slot] = (l < fill && src < nq) ? q[src] : make_float4(qnan, qnan, qnan, __uint_as_float(dump_row));
+}
+
 // The per-point calls of PCL's search virtuals (Search::nearestKSearch(point, k, ...), one query at a time --
 // impl/correspondence_estimation.hpp:163-175): at most one wavefront of host queries with host results goes through ONE
 // pinned block -- the queries are written into it in the index's space, the kernel reads them and writes its rows there,
@@ -825,14 +854,26 @@ constexpr int KNN_FEW_K = 32;
 static pclhip_status knn_few(pclhip_index* ix, const void* queries, size_t stride, uint32_t nq, int k, int32_t* out_idx,
                              float* out_d2) {
   pclhip_ctx* ctx = ix->ctx;
-  constexpr size_t Q_BYTES = KNN_FEW_QUERIES * sizeof(float4), ROW = KNN_FEW_QUERIES * size_t(KNN_FEW_K);
-  constexpr size_t BYTES = Q_BYTES + ROW * (sizeof(int32_t) + sizeof(float));  // one size: the pinned cache always hits
+  // worst case one query per wavefront (sparse_fill): 64 groups of 64 slots; rows of the queries + the dump row of the pads
+  constexpr size_t Q_BYTES = KNN_FEW_QUERIES * WAVE * sizeof(float4), ROWS = (KNN_FEW_QUERIES + 1) * size_t(KNN_FEW_K);
+  constexpr size_t BYTES = Q_BYTES + ROWS * (sizeof(int32_t) + sizeof(float));  // one size: the pinned cache always hits
   void* blk = nullptr;
   PCLHIP_CHECK_HIP(ctx, pinned_malloc(ctx, &blk, BYTES));
   float4* q = static_cast<float4*>(blk);
   int32_t* ri = reinterpret_cast<int32_t*>(static_cast<char*>(blk) + Q_BYTES);
-  float* rd = reinterpret_cast<float*>(ri + ROW);
-  for (uint32_t i = 0; i < nq; ++i) {
+  float* rd = reinterpret_cast<float*>(ri + ROWS);
+  // (these queries are NOT sorted: against anything but a small index every query gets a wavefront of its own)
+  const uint32_t fill = ix->n <= 65536u ? uint32_t(WAVE) : 1u;
+  const uint32_t ngroups = (nq + fill - 1) / fill, n_slots = ngroups * uint32_t(WAVE);
+  const float qnan = std::nanf("");
+  float dump_w;
+  std::memcpy(&dump_w, &nq, sizeof dump_w);
+  for (uint32_t slot = 0; slot < n_slots; ++slot) {
+    const uint32_t g = slot / uint32_t(WAVE), l = slot % uint32_t(WAVE), i = g * fill + l;
+    if (l >= fill || i >= nq) {
+      q[slot] = make_float4(qnan, qnan, qnan, dump_w);
+      continue;
+    }
     const float* p = reinterpret_cast<const float*>(static_cast<const char*>(queries) + size_t(i) * stride);
     float x = p[0], y = p[1], z = p[2];
     if (ix->scaled) {  // the index's (rescaled) space, as kd_load_kernel maps the records
@@ -842,9 +883,9 @@ static pclhip_status knn_few(pclhip_index* ix, const void* queries, size_t strid
     }
     float w;
     std::memcpy(&w, &i, sizeof(w));
-    q[i] = make_float4(x, y, z, w);
+    q[slot] = make_float4(x, y, z, w);
   }
-  pclhip_status st = launch_knn(ix, q, nq, k, ri, rd);
+  pclhip_status st = launch_knn(ix, q, n_slots, k, ri, rd);
   const hipError_t e = hipStreamSynchronize(ctx->stream);
   if (st == PCLHIP_OK && e == hipSuccess) {
     std::memcpy(out_idx, ri, size_t(nq) * size_t(k) * sizeof(int32_t));
@@ -885,26 +926,47 @@ pclhip_status pclhip_knn(pclhip_index* ix, const void* queries, size_t stride, u
                      ix->scaled ? ix->scale : nullptr);  // queries live in the index's (rescaled) space
   if (st != PCLHIP_OK) return st;
   const size_t cnt = size_t(nq) * size_t(k);
+  // a batch that is sparse against the index: fewer queries per wavefront (sparse_fill), results through buffers with a
+  // dump row for the padding slots
+  const float4* q_run = qs;
+  uint32_t nq_run = uint32_t(nq);
+  const uint32_t fill = sparse_fill(nq, ix->n);
+  const bool sparse = fill <= uint32_t(WAVE) / 2;
+  if (sparse) {
+    const uint64_t ngroups = (nq + fill - 1) / fill;
+    PCLHIP_REQUIRE(ctx, ngroups * WAVE < 0x7FFFFFFFull, "too many queries");
+    float4* qe = nullptr;
+    nq_run = uint32_t(ngroups * WAVE);
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &qe, size_t(nq_run) * sizeof(float4)));
+    guard.add(qe);
+    hipLaunchKernelGGL(sparse_expand_kernel, dim3((nq_run + 255) / 256), dim3(256), 0, ctx->stream, qs, uint32_t(nq), fill, qe,
+                       nq_run, uint32_t(nq));
+    PCLHIP_CHECK_HIP(ctx, hipGetLastError());
+    q_run = qe;
+  }
   int32_t* d_idx = out_idx;
   float* d_d2 = out_d2;
   const bool idx_dev = is_device_pointer(out_idx), d2_dev = is_device_pointer(out_d2);
-  if (!idx_dev) {
-    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &d_idx, cnt * sizeof(int32_t)));
+  const size_t cnt_run = cnt + (sparse ? size_t(k) : 0);   // + the dump row
+  if (!idx_dev || sparse) {
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &d_idx, cnt_run * sizeof(int32_t)));
     guard.add(d_idx);
   }
-  if (!d2_dev) {
-    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &d_d2, cnt * sizeof(float)));
+  if (!d2_dev || sparse) {
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &d_d2, cnt_run * sizeof(float)));
     guard.add(d_d2);
   }
-  st = launch_knn(ix, qs, uint32_t(nq), k, d_idx, d_d2);
+  st = launch_knn(ix, q_run, nq_run, k, d_idx, d_d2);
   if (st != PCLHIP_OK) {
     (void)hipStreamSynchronize(ctx->stream);
     return st;
   }
-  if (!idx_dev)
-    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out_idx, d_idx, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  if (!d2_dev)
-    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out_d2, d_d2, cnt * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (d_idx != out_idx)
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out_idx, d_idx, cnt * sizeof(int32_t), idx_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                         ctx->stream));
+  if (d_d2 != out_d2)
+    PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out_d2, d_d2, cnt * sizeof(float), d2_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                         ctx->stream));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PCLHIP_OK;
 }
@@ -1349,6 +1411,10 @@ pclhip_status pclhip_icp_set_source_indexed(pclhip_icp* icp, const void* points,
   if (st != PCLHIP_OK) return st;
   (void)hipEventRecord(e1, ctx->stream);
   icp->n_finite = nf;
+  for (int d = 0; d < 3; ++d) {  // the source's bounding box: how much of the target it covers (the search's group fill)
+    icp->src_lo[d] = lo[d];
+    icp->src_hi[d] = hi[d];
+  }
   st = pclhip_icp_reset(icp);
   float ms = 0;
   if (st == PCLHIP_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) icp->source_order_ms = ms;

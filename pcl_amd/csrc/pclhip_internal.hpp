@@ -278,6 +278,7 @@ struct pclhip_icp {
   uint64_t src_records_n = 0;
   float4* src_sorted0 = nullptr;   // Morton-ordered input (w = original index), pristine
   float4* src_cur = nullptr;       // working copy (input_transformed)
+  float src_lo[3] = {0, 0, 0}, src_hi[3] = {0, 0, 0};   // bounding box of the finite source points as they were set
   float4* src_nrm_sorted0 = nullptr;  // source normals in the same order (symmetric objective), pristine
   float4* src_nrm_cur = nullptr;      // ... rotated along with the working copy
   bool enforce_same_direction_normals = true;  // icp.h:368

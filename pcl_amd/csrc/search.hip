@@ -752,6 +752,9 @@ pclhip_status launch_gicp_covariances(pclhip_index* ix, int k, double eps, doubl
 
 constexpr int NS = PCLHIP_ICP_NSUMS;
 
+// Queries per wavefront of the ICP search kernels: 64 >> s, s in bits 8-10 of `flags` (0: the full wavefront).
+__host__ __device__ inline uint32_t search_fill_of(int flags) { return uint32_t(WAVE) >> ((uint32_t(flags) >> 8) & 7u); }
+
 // -------------------------------------------------------------------------------------------------
 // The iteration is two kernels: a search-only kernel without the 27 fp64 accumulators of the plane system (fewer
 // registers, room to software-pipeline the next group's loads) followed by a streaming accumulate kernel.  (Round 1's
@@ -800,7 +803,10 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
   load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
-  constexpr uint32_t GROUP = WAVE * Q;  // queries per wavefront: Q per lane
+  // queries per wavefront: Q per lane -- or FEWER (flags bits 8-10, search_fill_of): a source that is sparse against the target
+  // index (a small scan against a large map) gets 64 >> s consecutive queries per wavefront, in its first lanes
+  const uint32_t GROUP = (Q == 1 && !OWNED) ? search_fill_of(flags) : uint32_t(WAVE * Q);
+  const bool lane_in_group = (Q != 1 || OWNED) ? true : uint32_t(threadIdx.x & (WAVE - 1)) < GROUP;
   uint32_t ngroups = (ns + GROUP - 1) / GROUP;
   uint32_t epoch = 0;
   if constexpr (OWNED) {
@@ -835,7 +841,7 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
     t_n[q] = make_float4(0, 0, 0, 0);
     sp_n[q] = NO_INDEX;
     const uint32_t i = gid_n * GROUP + q * WAVE + lane;
-    if (g < ngroups && i < ns) {
+    if (g < ngroups && i < ns && lane_in_group) {
       p_n[q] = (OWNED && st_n == 0u) ? src0[i] : in[i];
       sp_n[q] = restart ? NO_INDEX : match_pos[i];
       if (sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
@@ -863,7 +869,7 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
       p[q] = p_n[q];
       t0[q] = t_n[q];
       seed_pos[q] = sp_n[q];
-      in_range[q] = (gcur * GROUP + q * WAVE + lane) < ns;
+      in_range[q] = lane_in_group && (gcur * GROUP + q * WAVE + lane) < ns;
     }
     // next group: issue its points + seed positions now ...
     const uint32_t g2 = (gl_next != GroupFeed::END) ? sched.global(gl_next) : ngroups;
@@ -879,7 +885,7 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const uint32_t i2 = gid_n * GROUP + q * WAVE + lane;
-      next_ok[q] = g2 < ngroups && i2 < ns;
+      next_ok[q] = g2 < ngroups && i2 < ns && lane_in_group;
       p_n[q] = make_float4(0, 0, 0, 0);
       sp_n[q] = NO_INDEX;
       if (next_ok[q]) {
@@ -1017,7 +1023,9 @@ __device__ __forceinline__ void icp_cold_search_body(const IndexView& ix, float4
   load_top_cache(ix, topbox_s);
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
-  uint32_t ngroups = (ns + WAVE - 1) / WAVE;
+  const uint32_t GF = OWNED ? uint32_t(WAVE) : search_fill_of(flags);   // queries per wavefront (see icp_search_body)
+  const bool lane_in_group = uint32_t(lane) < GF;
+  uint32_t ngroups = (ns + GF - 1) / GF;
   if constexpr (OWNED) ngroups = og.count[0];  // slots of the served list (this body only starts alignments: no replay)
   const auto gid = [&](uint32_t slot) -> uint32_t {
     if constexpr (OWNED) return slot < ngroups ? og.list[slot] : 0u;
@@ -1046,18 +1054,18 @@ __device__ __forceinline__ void icp_cold_search_body(const IndexView& ix, float4
   float4 p_n = make_float4(0, 0, 0, 0);
   {
     const uint32_t g0 = (gl < run_end) ? sched.global(gl) : ngroups;
-    if (g0 < ngroups && gid(g0) * WAVE + lane < ns) p_n = in[gid(g0) * WAVE + lane];
+    if (g0 < ngroups && lane_in_group && gid(g0) * GF + lane < ns) p_n = in[gid(g0) * GF + lane];
   }
   for (; gl < run_end; ++gl) {
     const uint32_t g = sched.global(gl);
     if (g >= ngroups) break;
     float4 p = p_n;
-    const uint32_t i = gid(g) * WAVE + lane;
-    const bool in_range = i < ns;
+    const uint32_t i = gid(g) * GF + lane;
+    const bool in_range = lane_in_group && i < ns;
     {  // the next group's points are in flight while this one is searched
       const uint32_t g2 = (gl + 1u < run_end) ? sched.global(gl + 1u) : ngroups;
       p_n = make_float4(0, 0, 0, 0);
-      if (g2 < ngroups && gid(g2) * WAVE + lane < ns) p_n = in[gid(g2) * WAVE + lane];
+      if (g2 < ngroups && lane_in_group && gid(g2) * GF + lane < ns) p_n = in[gid(g2) * GF + lane];
     }
     if constexpr (OWNED) {
       if (lane == 0) og.stamp[gid(g)] = 1u;  // the alignment's first transform applied; match entries in use
@@ -1906,6 +1914,32 @@ pclhip_status owned_groups_catch_up(pclhip_icp* icp, int mode) {
   return PCLHIP_OK;
 }
 
+// A source that is SPARSE against the target index (a small scan against a large map, spread over it): 64 consecutive
+// points of its kd order span a sizeable part of the target, and a wavefront walks the tree for the box of all of them --
+// measured at 10M target points (round 6): 256 source points 34 ms, 4096 points 6.7 ms, 65,536 points 1.2 ms per iteration
+// (0.07 / 0.08 / 0.43 ms with this).  Such a source gets FEWER points per wavefront -- 64 >> shift, a power of two: aligned
+// runs of the kd order are cells -- so that a group spans about SPARSE_SRC_SPAN target points.
+static int sparse_source_shift(const pclhip_icp* icp) {
+  // the target points UNDER the source: the share of the target's bounding box the source's own box covers (a scan that
+  // covers a patch of the map is dense there although it is small against the whole map)
+  constexpr double SPARSE_SRC_SPAN = 1024.0;
+  // over the target's two widest axes only: the third is the thickness of a surface, where the ratio of two noise
+  // levels says nothing (and leaving an axis out errs towards fewer points per wavefront, the safe side)
+  double share = 1.0, et[3];
+  for (int d = 0; d < 3; ++d) et[d] = double(icp->target->bbox_hi[d]) - double(icp->target->bbox_lo[d]);
+  const int thin = et[0] <= et[1] ? (et[0] <= et[2] ? 0 : 2) : (et[1] <= et[2] ? 1 : 2);
+  for (int d = 0; d < 3; ++d) {
+    const double es = double(icp->src_hi[d]) - double(icp->src_lo[d]);
+    if (d != thin && et[d] > 0.0 && es >= 0.0 && es < et[d]) share *= es / et[d];
+  }
+  const double under = double(icp->target->n) * (share > 1e-9 ? share : 1e-9);
+  const double fd = under > 0.0 ? SPARSE_SRC_SPAN * double(icp->n) / under : double(WAVE);
+  const uint64_t f = fd >= double(WAVE) ? uint64_t(WAVE) : uint64_t(fd);
+  int shift = 0;
+  while (shift < 6 && (uint64_t(WAVE) >> shift) > (f < 1 ? 1 : f)) ++shift;
+  return shift;
+}
+
 // One iteration.  ev == nullptr: the host-driven form (T by value, the caller reads the record back);
 // ev != nullptr: the device-driven form -- transform / restart / stop come from icp->ctl, the iteration is
 // closed by icp_solve_kernel, and ev[0..3] are recorded before the search, after it, after the accumulation
@@ -1924,12 +1958,11 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   const int order = (mode == PCLHIP_ICP_POINT_TO_POINT) ? 0 : 1;
   // candidates must be <= max_d2 (a float): strict bound just above it; +inf when unbounded
   const float bound = use_max ? std::nextafterf(max_d2, __builtin_inff()) : __builtin_inff();
-  const uint32_t ngroups = (icp->n + WAVE - 1) / WAVE;
+  uint32_t ngroups = (icp->n + WAVE - 1) / WAVE;
   const bool filters = icp->reciprocal || !icp->rejectors.empty();
   bool solved = false;
   if (icp->n > 0) {
     auto ks = icp_search_kernel<4, 1, true>;
-    const int gs = resident_blocks(ctx, ks, ngroups);
     // launches without seeds go through the stand-off search when the index carries leaf discs: the host-driven loop
     // knows which launch that is (pclhip_icp_reset cleared the seeds); in the device-driven loop the control block
     // picks the body on the device (icp_search_dual_kernel)
@@ -1971,6 +2004,13 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     const bool lane = !owned && lane_search_available(icp);
     const bool lane_now = lane && (device_loop || !host_restart);
     if (lane && device_loop) kflags |= SEARCH_RESTART_ONLY;
+    // a source that is sparse against the target gets fewer points per wavefront (sparse_source_shift).  Not with the
+    // served-group lists (their groups are the 64-point groups of the source) and not for the per-lane search.
+    if (!owned) {
+      kflags |= sparse_source_shift(icp) << 8;
+      const uint32_t fill = search_fill_of(kflags);
+      ngroups = (icp->n + fill - 1) / fill;
+    }
     (void)hipEventRecord(device_loop ? ev[0] : icp->ev0, s);
     if (lane_now && !device_loop) {
       // nothing of this file
@@ -1995,8 +2035,8 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
                          ctl, icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2,
                          ctx->stats);
     } else {
-      PCLHIP_LAUNCH_FED(ctx, ks, dim3(gs), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl, icp->region,
-                         order, bound, kflags, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+      PCLHIP_LAUNCH_FED(ctx, ks, dim3(resident_blocks(ctx, ks, ngroups)), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0,
+                         icp->n, M, ctl, icp->region, order, bound, kflags, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
     }
     if (lane_now) {
       const pclhip_status lst = launch_lane_search(icp, M.m, ctl, order, bound, use_max);
@@ -2121,13 +2161,15 @@ pclhip_status launch_fitness_score(pclhip_icp* icp, const float T[16], double ma
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(cur, icp->src_sorted0, size_t(n) * sizeof(float4), hipMemcpyDeviceToDevice, s));
   // the last iteration's matches are valid upper bounds for any pose: use them as seeds
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(pos, icp->match_pos, size_t(n) * 4, hipMemcpyDeviceToDevice, s));
-  const uint32_t ngroups = (n + WAVE - 1) / WAVE;
+  const int fit_flags = sparse_source_shift(icp) << 8;   // (a sparse source: fewer points per wavefront, as in the iterations)
+  const uint32_t fit_fill = search_fill_of(fit_flags);
+  const uint32_t ngroups = (n + fit_fill - 1) / fit_fill;
   const int gs = resident_blocks(ctx, icp_search_kernel<4, 1, true>, ngroups);
   // transformPointCloud(cloud, out, Matrix4) is Transformer::se3 (transforms.hpp:109-123): order 1
   // target sharding: this rank scores the source points whose position under T lies in its region (every point has
   // exactly one owner), against its slab + halo index; the (sum, count) pairs are summed over the ranks below
   PCLHIP_LAUNCH_FED(ctx, (icp_search_kernel<4, 1, true>), dim3(gs), dim3(BLOCK), 0, s, v, cur, static_cast<const float4*>(cur), n,
-                     M, static_cast<const IcpControl*>(nullptr), icp->region, 1, __builtin_inff(), 0, pos, id, d2,
+                     M, static_cast<const IcpControl*>(nullptr), icp->region, 1, __builtin_inff(), fit_flags, pos, id, d2,
                      ctx->stats);
   hipLaunchKernelGGL(fitness_partial_kernel, dim3(gr), dim3(BLOCK), 0, s, d2, n, max_range, part);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());

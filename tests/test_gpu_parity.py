@@ -141,6 +141,39 @@ def test_knn_lattice_ties_lowest_index(gpu, orc):
         assert np.array_equal(gd, od), k
 
 
+@pytest.mark.parametrize("nq", [1, 7, 64, 65, 1000, 4000])
+def test_knn_few_queries_against_a_large_index(gpu, orc, nq):
+    # A batch that is SPARSE against the index is laid out with fewer queries per wavefront (api.hip: sparse_fill -- 64
+    # scattered queries would make one wavefront walk the tree for the box of all of them; measured 117 ms for 16 queries
+    # against 10M points).  Same results as any other batch: host and (GPU tier) device buffers, k in registers and in the
+    # heap, non-finite queries in the batch, a subset index.
+    import pcl_amd
+    rng = np.random.default_rng(nq)
+    tgt, _, _ = pcl_amd.synth.icp_pair(120_000)
+    qry = np.ascontiguousarray(tgt[rng.integers(0, len(tgt), nq)] + rng.normal(scale=0.01, size=(nq, 4)).astype(np.float32))
+    if nq >= 7:
+        qry[3, 1] = np.nan
+        qry[nq - 1, 0] = np.inf
+    tree = build_tree(gpu, tgt)
+    otree = orc.KdTree(tgt)
+    for k in (1, 8, 40):
+        gi, gd = tree.nearestKSearch(qry, k)
+        oi, od = otree.knn(qry, k)
+        assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32)), (nq, k)
+    on_device = b"wavesim" not in pcl_amd._lib.load().pclhip_version()   # (the emulation of the CPU tier has no device memory)
+    if on_device:
+        import torch  # device-resident queries and results (the dump row of the padding slots is not the caller's buffer)
+        di, dd = tree.nearestKSearch(torch.from_numpy(qry).cuda(), 8)
+        oi, od = otree.knn(qry, 8)
+        assert di.is_cuda and np.array_equal(di.cpu().numpy(), oi) and np.array_equal(dd.cpu().numpy().view(np.uint32), od.view(np.uint32))
+    sub = np.ascontiguousarray(rng.permutation(len(tgt))[:50_000].astype(np.int32))
+    tree2 = build_tree(gpu, tgt, sub)
+    gi, gd = tree2.nearestKSearch(qry, 3)
+    oi, od = orc.KdTree(tgt[np.sort(sub)]).knn(qry, 3)
+    assert np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    assert np.array_equal(np.sort(sub)[np.where(oi >= 0, oi, 0)] * (oi >= 0) - (oi < 0), gi)
+
+
 def test_tie_policy_where_first_visited_and_lowest_index_differ(gpu, orc, bunny, golden):
     """Exact distance ties are the one place where this library's answer is a POLICY, not the reference's arithmetic:
     FLANN's result set keeps the FIRST-VISITED of tied candidates (strict `<` on insertion; the nearer child of a split is
@@ -521,6 +554,52 @@ def test_icp_synthetic_driven_by_oracle_transforms_bit_exact(gpu, orc, mode):
         # float-sum umeyama (mode 0) carries ~1e-5 noise at 1e5 points; LLS sums are double
         assert np.abs(icp.solve(sums) - ref["per_iter_T"][it]).max() < (2e-5 if mode == 0 else 1e-6), it
         T_prev = ref["per_iter_T"][it]
+
+
+@pytest.mark.parametrize("ns", [1, 5, 64, 300, 2000, 9000])
+def test_icp_sparse_source_against_a_large_target(gpu, orc, ns):
+    # A source that is SPARSE against the target (a small scan against a large map, spread over it) is searched with
+    # fewer points per wavefront (search.hip: search_fill_of -- 64, 32, ... 1 consecutive points of the source's kd order,
+    # so that a wavefront's box stays compact): same correspondences as any other source, in the launch that starts the
+    # alignment and in the seeded ones, host-driven and in the device-driven loop, with a non-finite point in the source.
+    import pcl_amd
+    tgt, src_all, _ = pcl_amd.synth.icp_pair(150_000)
+    rng = np.random.default_rng(ns)
+    src = np.ascontiguousarray(src_all[rng.permutation(len(src_all))[:ns]])
+    if ns >= 64:
+        src[7, 2] = np.nan
+    otree = orc.KdTree(tgt)
+    normals = otree.normals(tgt, 8, viewpoint=(0, 0, 10))[0]
+    for mode in (0, 1):
+        cls = pcl_amd.IterativeClosestPointWithNormals if mode == 1 else pcl_amd.IterativeClosestPoint
+        icp = cls(gpu)
+        icp.setInputTarget(tgt)
+        if mode == 1:
+            icp.setTargetNormals(normals)
+        icp.setInputSource(src)
+        icp.reset()
+        T = np.eye(4, dtype=np.float32)
+        cur = src.copy()
+        for it in range(4):                       # the launch without seeds, then seeded ones
+            sums = icp.iterate(T, max_dist=0.1)
+            cur = orc.transform_cloud(T, cur, order=mode)
+            oq, om, od = otree.correspondences(cur, 0.1)
+            q, m, d = icp.fetchCorrespondences()
+            assert np.array_equal(q, oq) and np.array_equal(m, om), (ns, mode, it)
+            assert np.array_equal(d.view(np.uint32), od.view(np.uint32)), (ns, mode, it)
+            assert int(sums[28]) == len(oq)
+            if len(oq) < 3:
+                break
+            T = icp.solve(sums)
+        if ns >= 300:                             # the device-driven loop: same iteration count, the 4x4 within the contract
+            kw = dict(max_iterations=15, max_correspondence_distance=0.1, transformation_epsilon=1e-10)
+            icp2, ref = run_icp_pair(gpu, orc, tgt, src, mode, normals=normals if mode == 1 else None, **kw)
+            assert icp2.nr_iterations_ == ref["iterations"]
+            assert np.linalg.norm(icp2.getFinalTransformation().astype(np.float64) - ref["T"]) < 1e-5
+            # getFitnessScore searches the same sparse source (impl/registration.hpp:132-168)
+            Tf = icp2.getFinalTransformation()
+            want, _ = otree.fitness_score(src, Tf, 1e-4)
+            assert abs(icp2.getFitnessScore(1e-4) - want) <= 1e-6 * abs(want)
 
 
 def test_icp_guess_and_repeated_align(gpu, orc, bunny):
