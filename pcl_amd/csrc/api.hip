@@ -816,6 +816,8 @@ pclhip_status pclhip_index_cells(pclhip_index* ix, int level, float* boxes, floa
   return PCLHIP_OK;
 }
 
+}  // extern "C"
+
 // FEW queries against a LARGE index.  A wavefront owns 64 consecutive queries of the sorted batch and walks the tree for
 // the box of all of them: compact when the batch is as dense as the cloud (a source cloud, self-queries), but 64 of a
 // few thousand queries scattered over a 10M-point cloud span a sizeable part of it -- measured (round 6, random queries on
@@ -824,7 +826,7 @@ pclhip_status pclhip_index_cells(pclhip_index* ix, int level, float* boxes, floa
 // other slots non-finite (they take no part in the search; their rows go to a dump row behind the results).  `fill` keeps
 // the target points a group spans (about fill * n / nq) near SPARSE_SPAN.
 constexpr uint64_t SPARSE_SPAN = 1024;
-static uint32_t sparse_fill(uint64_t nq, uint64_t n_index) {
+uint32_t pclhip::sparse_fill(uint64_t nq, uint64_t n_index) {
   if (n_index == 0 || nq == 0) return WAVE;
   const uint64_t f = SPARSE_SPAN * nq / n_index;
   if (f >= uint64_t(WAVE)) return WAVE;
@@ -844,6 +846,32 @@ __global__ void sparse_expand_kernel(const float4* __restrict__ q, uint32_t nq, 
   const float qnan = __builtin_nanf("");
   out[slot] = (l < fill && src < nq) ? q[src] : make_float4(qnan, qnan, qnan, __uint_as_float(dump_row));
 }
+// the sparse layout of a sorted batch (device memory of the context; *out == nullptr: the batch is dense enough as it is).
+// Padding slots carry w = nq: a caller that scatters results by w keeps one dump row / slot behind its nq entries.
+pclhip_status pclhip::sparse_layout(pclhip_ctx* ctx, const float4* q_sorted, uint64_t nq, uint64_t n_index, float4** out,
+                                    uint32_t* n_out) {
+  *out = nullptr;
+  *n_out = uint32_t(nq);
+  const uint32_t fill = sparse_fill(nq, n_index);
+  if (fill > uint32_t(WAVE) / 2 || nq == 0) return PCLHIP_OK;
+  const uint64_t ngroups = (nq + fill - 1) / fill;
+  PCLHIP_REQUIRE(ctx, ngroups * WAVE < 0x7FFFFFFFull, "too many queries");
+  float4* qe = nullptr;
+  const uint32_t n_slots = uint32_t(ngroups * WAVE);
+  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &qe, size_t(n_slots) * sizeof(float4)));
+  hipLaunchKernelGGL(sparse_expand_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, ctx->stream, q_sorted, uint32_t(nq), fill, qe,
+                     n_slots, uint32_t(nq));
+  if (hipGetLastError() != hipSuccess) {
+    (void)dev_free(ctx, qe);
+    set_error(ctx, "sparse layout: launch failed");
+    return PCLHIP_ERR_HIP;
+  }
+  *out = qe;
+  *n_out = n_slots;
+  return PCLHIP_OK;
+}
+
+extern "C" {
 
 // The per-point calls of PCL's search virtuals (Search::nearestKSearch(point, k, ...), one query at a time --
 // impl/correspondence_estimation.hpp:163-175): at most one wavefront of host queries with host results goes through ONE
@@ -930,18 +958,12 @@ pclhip_status pclhip_knn(pclhip_index* ix, const void* queries, size_t stride, u
   // dump row for the padding slots
   const float4* q_run = qs;
   uint32_t nq_run = uint32_t(nq);
-  const uint32_t fill = sparse_fill(nq, ix->n);
-  const bool sparse = fill <= uint32_t(WAVE) / 2;
+  float4* qe = nullptr;
+  st = sparse_layout(ctx, qs, nq, ix->n, &qe, &nq_run);
+  if (st != PCLHIP_OK) return st;
+  const bool sparse = qe != nullptr;
   if (sparse) {
-    const uint64_t ngroups = (nq + fill - 1) / fill;
-    PCLHIP_REQUIRE(ctx, ngroups * WAVE < 0x7FFFFFFFull, "too many queries");
-    float4* qe = nullptr;
-    nq_run = uint32_t(ngroups * WAVE);
-    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &qe, size_t(nq_run) * sizeof(float4)));
     guard.add(qe);
-    hipLaunchKernelGGL(sparse_expand_kernel, dim3((nq_run + 255) / 256), dim3(256), 0, ctx->stream, qs, uint32_t(nq), fill, qe,
-                       nq_run, uint32_t(nq));
-    PCLHIP_CHECK_HIP(ctx, hipGetLastError());
     q_run = qe;
   }
   int32_t* d_idx = out_idx;

@@ -488,6 +488,9 @@ pclhip_status sharded_filters_ok(pclhip_icp* icp);
 
 // ---- kernels launched from api.cpp ----------------------------------------------------------
 // timed = false: no events, no wait (k <= 32): the launch is queued and the call returns
+// batches that are sparse against the index: fewer queries per wavefront (api.hip)
+uint32_t sparse_fill(uint64_t nq, uint64_t n_index);
+pclhip_status sparse_layout(pclhip_ctx* ctx, const float4* q_sorted, uint64_t nq, uint64_t n_index, float4** out, uint32_t* n_out);
 pclhip_status launch_knn(pclhip_index* ix, const float4* q_sorted, uint32_t nq, int k,
                          int32_t* out_idx_sorted, float* out_d2_sorted, bool timed = true);
 pclhip_status launch_normals(pclhip_index* ix, int k, const float vp[3], uint64_t* nan_count);

@@ -272,18 +272,31 @@ extern "C" pclhip_status pclhip_radius_search(pclhip_index* ix, const void* quer
   const float r2 = float(radius * radius);  // kdtree_flann.hpp:398
   const IndexView v = ix->view();
   const uint32_t n = uint32_t(nq);
-  const uint32_t ngroups = (n + WAVE - 1) / WAVE;
+  // a batch that is sparse against the index: fewer queries per wavefront (api.hip: sparse_layout); the padding slots count
+  // into counts[n] and fill nothing
+  const float4* q_run = qs;
+  uint32_t n_run = n;
+  {
+    float4* qe = nullptr;
+    st = sparse_layout(ctx, qs, nq, ix->n, &qe, &n_run);
+    if (st != PCLHIP_OK) return st;
+    if (qe != nullptr) {
+      g.p.push_back(qe);
+      q_run = qe;
+    }
+  }
+  const uint32_t ngroups = (n_run + WAVE - 1) / WAVE;
   int grid = int((ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
   const int cap = ctx->num_cus * 4;
   if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
   uint32_t* counts = nullptr;
   unsigned long long *wide = nullptr, *full_off = nullptr, *out_off = nullptr;
-  PCLHIP_CHECK_HIP(ctx, g.alloc(&counts, size_t(n) * 4));
+  PCLHIP_CHECK_HIP(ctx, g.alloc(&counts, size_t(n + 1) * 4));
   PCLHIP_CHECK_HIP(ctx, g.alloc(&wide, size_t(n + 1) * 8));
   PCLHIP_CHECK_HIP(ctx, g.alloc(&full_off, size_t(n + 1) * 8));
   PCLHIP_CHECK_HIP(ctx, g.alloc(&out_off, size_t(n + 1) * 8));
-  PCLHIP_LAUNCH_FED(ctx, radius_kernel<false>, dim3(grid), dim3(BLOCK), 0, s, v, qs, n, r2, counts,
+  PCLHIP_LAUNCH_FED(ctx, radius_kernel<false>, dim3(grid), dim3(BLOCK), 0, s, v, q_run, n_run, r2, counts,
                      (const unsigned long long*)nullptr, (uint64_t*)nullptr);
   // exclusive scans of the full counts (segment starts) and of the clamped counts (output CSR)
   launch_exclusive_scan_u64(s, counts, n, 0u, wide, full_off);
@@ -301,7 +314,7 @@ extern "C" pclhip_status pclhip_radius_search(pclhip_index* ix, const void* quer
   }
   uint64_t* k0 = nullptr;
   PCLHIP_CHECK_HIP(ctx, g.alloc(&k0, size_t(full_total) * 8));
-  PCLHIP_LAUNCH_FED(ctx, radius_kernel<true>, dim3(grid), dim3(BLOCK), 0, s, v, qs, n, r2, counts, full_off, k0);
+  PCLHIP_LAUNCH_FED(ctx, radius_kernel<true>, dim3(grid), dim3(BLOCK), 0, s, v, q_run, n_run, r2, counts, full_off, k0);
   uint32_t* long_list = nullptr;
   PCLHIP_CHECK_HIP(ctx, g.alloc(&long_list, size_t(n + 1) * 4));  // [n]: the counter
   launch_segmented_sort_u64(s, ctx->num_cus, k0, full_off, 0ull, 0u, n, long_list, long_list + n);

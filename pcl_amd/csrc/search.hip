@@ -604,10 +604,22 @@ pclhip_status launch_normals_at(pclhip_index* ix, const float4* queries, uint32_
   int32_t* nb = nullptr;
   float* nd = nullptr;
   PCLHIP_CHECK_HIP(ctx, scope.alloc(&d_nan, sizeof(unsigned long long)));
-  PCLHIP_CHECK_HIP(ctx, scope.alloc(&nb, size_t(nq) * k * sizeof(int32_t)));
-  PCLHIP_CHECK_HIP(ctx, scope.alloc(&nd, size_t(nq) * k * sizeof(float)));
+  PCLHIP_CHECK_HIP(ctx, scope.alloc(&nb, (size_t(nq) + 1) * k * sizeof(int32_t)));   // + the dump row of a sparse layout's padding
+  PCLHIP_CHECK_HIP(ctx, scope.alloc(&nd, (size_t(nq) + 1) * k * sizeof(float)));
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_nan, 0, sizeof(unsigned long long), s));
-  st = launch_knn(ix, qs, nq, k, nb, nd);
+  // few queries against a large surface: fewer of them per wavefront (api.hip: sparse_layout)
+  const float4* q_run = qs;
+  uint32_t nq_run = nq;
+  {
+    float4* qe = nullptr;
+    st = sparse_layout(ctx, qs, nq, ix->n, &qe, &nq_run);
+    if (st != PCLHIP_OK) return st;
+    if (qe != nullptr) {
+      scope.mem.push_back(qe);
+      q_run = qe;
+    }
+  }
+  st = launch_knn(ix, q_run, nq_run, k, nb, nd);
   if (st != PCLHIP_OK) {
     (void)hipStreamSynchronize(s);  // nothing may still use the scope's buffers when they are freed
     return st;

@@ -1022,6 +1022,25 @@ def test_radius_search_vs_bruteforce(gpu):
     assert len(off) == 1 and len(idx) == 0
 
 
+@pytest.mark.parametrize("nq", [1, 40, 700])
+def test_radius_search_few_queries_against_a_large_index(gpu, nq):
+    # the sparse layout of a batch (fewer queries per wavefront, api.hip: sparse_layout) in the radius search: the padding
+    # slots count into a dump slot and fill nothing -- same CSR lists as the brute force, with a non-finite query and max_nn
+    from oracle import rejectors as rej
+    import pcl_amd
+    rng = np.random.default_rng(100 + nq)
+    tgt, _, _ = pcl_amd.synth.icp_pair(60_000)
+    pts = np.ascontiguousarray(tgt[:, :3])
+    qry = (pts[rng.integers(0, len(pts), nq)] + rng.normal(scale=0.005, size=(nq, 3))).astype(np.float32)
+    if nq >= 40:
+        qry[11] = np.nan
+    tree = build_tree(gpu, pts)
+    for radius, max_nn in ((0.02, 0), (0.05, 9)):
+        off, idx, d2 = tree.radiusSearch(qry, radius, max_nn)
+        ooff, oidx, od2 = rej.radius_search_bruteforce(pts, qry, radius, max_nn)
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx) and np.array_equal(d2, od2), (nq, radius, max_nn)
+
+
 # ------------------------------------------------------------------------------------------------
 # Registration::getFitnessScore
 # ------------------------------------------------------------------------------------------------
