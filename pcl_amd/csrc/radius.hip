@@ -358,12 +358,28 @@ static pclhip_status normals_radius_impl(pclhip_index* ix, const float4* queries
     PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(ix->nrm, 0xFF, size_t(ix->n_pad) * sizeof(float4), s));  // NaN pads
   }
   if (nan_count) *nan_count = 0;
-  const uint32_t n = nq;
+  uint32_t n = nq;
   const float4* q = self ? ix->pts : queries;
   float4* dst = self ? ix->nrm : out;
   if (n == 0) {
     if (self) ix->has_normals = true;
     return PCLHIP_OK;
+  }
+  // few queries on a large surface: fewer of them per wavefront (api.hip: sparse_layout).  The padding slots write their NaN
+  // row to a dump row behind the results and are counted as NaN rows by the kernel: both taken back below.
+  uint32_t pads = 0;
+  if (!self) {
+    float4* qe = nullptr;
+    uint32_t n_run = n;
+    const pclhip_status sl = sparse_layout(ctx, queries, nq, ix->n, &qe, &n_run);
+    if (sl != PCLHIP_OK) return sl;
+    if (qe != nullptr) {
+      g.p.push_back(qe);
+      PCLHIP_CHECK_HIP(ctx, g.alloc(&dst, (size_t(nq) + 1) * sizeof(float4)));
+      q = qe;
+      pads = n_run - nq;
+      n = n_run;
+    }
   }
   const float r2 = float(radius * radius);  // kdtree_flann.hpp:398
   const IndexView v = ix->view();
@@ -388,13 +404,14 @@ static pclhip_status normals_radius_impl(pclhip_index* ix, const float4* queries
   (void)hipEventRecord(e1, s);
   PCLHIP_CHECK_HIP(ctx, hipGetLastError());
   unsigned long long h = 0;
+  if (dst != out && !self) PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(out, dst, size_t(nq) * sizeof(float4), hipMemcpyDeviceToDevice, s));
   PCLHIP_CHECK_HIP(ctx, hipMemcpyAsync(&h, d_nan, 8, hipMemcpyDeviceToHost, s));
   PCLHIP_CHECK_HIP(ctx, hipStreamSynchronize(s));
   float ms = 0;
   if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ix->last_kernel_ms = ms;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  if (nan_count) *nan_count = h;
+  if (nan_count) *nan_count = h - pads;
   if (self) ix->has_normals = true;
   return PCLHIP_OK;
 }

@@ -1543,6 +1543,34 @@ def test_normals_search_surface_radius_vs_oracle(gpu, orc, bunny):
         assert np.abs(got[~bad, 3] - want[~bad, 3]).max() < 1e-5
 
 
+def test_normals_radius_few_queries_on_a_large_surface(gpu, orc):
+    # few queries against a large surface go through the sparse layout (fewer queries per wavefront): the padding slots'
+    # NaN rows and their count are taken back -- rows and nan_count equal the oracle's, a non-finite query and a query
+    # without neighbours among them
+    import pcl_amd
+    from oracle import rejectors as rej
+    surface = pcl_amd.synth.gaussian_surface(60_000, pcl_amd.synth.TARGET_SEED)
+    rng = np.random.default_rng(3)
+    queries = surface[rng.integers(0, len(surface), 90)].copy()
+    queries[:, :3] += rng.normal(scale=0.002, size=(90, 3)).astype(np.float32)
+    queries[5, 1] = np.nan
+    queries[6, 2] += np.float32(3.0)          # nothing within the radius
+    for radius in (0.03, 0.06):
+        ne = pcl_amd.NormalEstimation(gpu)
+        ne.setInputCloud(queries)
+        ne.setSearchSurface(surface)
+        ne.setRadiusSearch(radius)
+        ne.setViewPoint(0, 0, 10)
+        got = ne.compute()
+        want, nan = rej.normals_radius_at(orc, surface, queries, radius, viewpoint=(0, 0, 10))
+        assert ne.nan_count == nan and nan >= 2
+        bad = np.isnan(want[:, 0])
+        assert np.array_equal(np.isnan(got[:, 0]), bad)
+        dots = np.sum(got[~bad, :3] * want[~bad, :3], axis=1)
+        assert dots.min() >= 1 - 1e-5
+        assert np.abs(got[~bad, 3] - want[~bad, 3]).max() < 1e-5
+
+
 @pytest.mark.parametrize("field,col,lo,hi", [("x", 0, -0.4, 0.25), ("z", 2, 0.02, 0.11), ("curvature", 8, 0.01, 0.03)])
 @pytest.mark.parametrize("negative", [False, True])
 def test_voxelgrid_filter_field_and_negative_limits(gpu, orc, field, col, lo, hi, negative):
