@@ -846,6 +846,27 @@ __global__ void sparse_expand_kernel(const float4* __restrict__ q, uint32_t nq, 
   const float qnan = __builtin_nanf("");
   out[slot] = (l < fill && src < nq) ? q[src] : make_float4(qnan, qnan, qnan, __uint_as_float(dump_row));
 }
+// one query per wavefront straight from the records (fill == 1: the order of the batch does not matter, so no ordering
+// pass and none of its host waits): slot 64 g holds record g in the index's space, w = g; the other slots are padding
+__global__ void sparse_load_one_per_group_kernel(const void* __restrict__ recs, size_t stride, uint32_t nq, float sx, float sy,
+                                                 float sz, int scaled, float4* __restrict__ out) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= nq * uint32_t(WAVE)) return;
+  const uint32_t g = slot / WAVE;
+  const float qnan = __builtin_nanf("");
+  float4 v = make_float4(qnan, qnan, qnan, __uint_as_float(nq));
+  if (slot % WAVE == 0u) {
+    const float* p = reinterpret_cast<const float*>(static_cast<const char*>(recs) + size_t(g) * stride);
+    float x = p[0], y = p[1], z = p[2];
+    if (scaled) {  // as kd_load_kernel maps the records (an axis with factor 0 does not exist in the representation)
+      x = sx == 0.0f ? 0.0f : __fmul_rn(x, sx);
+      y = sy == 0.0f ? 0.0f : __fmul_rn(y, sy);
+      z = sz == 0.0f ? 0.0f : __fmul_rn(z, sz);
+    }
+    v = make_float4(x, y, z, __uint_as_float(g));
+  }
+  out[slot] = v;
+}
 // the sparse layout of a sorted batch (device memory of the context; *out == nullptr: the batch is dense enough as it is).
 // Padding slots carry w = nq: a caller that scatters results by w keeps one dump row / slot behind its nq entries.
 pclhip_status pclhip::sparse_layout(pclhip_ctx* ctx, const float4* q_sorted, uint64_t nq, uint64_t n_index, float4** out,
@@ -945,26 +966,41 @@ pclhip_status pclhip_knn(pclhip_index* ix, const void* queries, size_t stride, u
   pclhip_status st = to_device(ctx, queries, size_t(nq) * stride, &dq, &owned);
   if (st != PCLHIP_OK) return st;
   guard.add(owned);
-  float4* qs = nullptr;
-  PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &qs, size_t(nq) * sizeof(float4)));
-  guard.add(qs);
-  uint32_t nf = 0;
-  float lo[3], hi[3];
-  st = spatial_order(ctx, dq, stride, nq, nullptr, 0, qs, uint32_t(nq), &nf, lo, hi, true, nullptr,
-                     ix->scaled ? ix->scale : nullptr);  // queries live in the index's (rescaled) space
-  if (st != PCLHIP_OK) return st;
   const size_t cnt = size_t(nq) * size_t(k);
-  // a batch that is sparse against the index: fewer queries per wavefront (sparse_fill), results through buffers with a
-  // dump row for the padding slots
-  const float4* q_run = qs;
+  const float4* q_run = nullptr;
   uint32_t nq_run = uint32_t(nq);
-  float4* qe = nullptr;
-  st = sparse_layout(ctx, qs, nq, ix->n, &qe, &nq_run);
-  if (st != PCLHIP_OK) return st;
-  const bool sparse = qe != nullptr;
-  if (sparse) {
+  bool sparse = false;
+  if (sparse_fill(nq, ix->n) == 1u && nq * WAVE < 0x7FFFFFFFull) {
+    // every query gets a wavefront of its own: the batch needs no order (and none of the ordering pass's host waits)
+    float4* qe = nullptr;
+    nq_run = uint32_t(nq * WAVE);
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &qe, size_t(nq_run) * sizeof(float4)));
     guard.add(qe);
+    hipLaunchKernelGGL(sparse_load_one_per_group_kernel, dim3((nq_run + 255) / 256), dim3(256), 0, ctx->stream, dq, stride,
+                       uint32_t(nq), ix->scale[0], ix->scale[1], ix->scale[2], ix->scaled ? 1 : 0, qe);
+    PCLHIP_CHECK_HIP(ctx, hipGetLastError());
     q_run = qe;
+    sparse = true;
+  } else {
+    float4* qs = nullptr;
+    PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &qs, size_t(nq) * sizeof(float4)));
+    guard.add(qs);
+    uint32_t nf = 0;
+    float lo[3], hi[3];
+    st = spatial_order(ctx, dq, stride, nq, nullptr, 0, qs, uint32_t(nq), &nf, lo, hi, true, nullptr,
+                       ix->scaled ? ix->scale : nullptr);  // queries live in the index's (rescaled) space
+    if (st != PCLHIP_OK) return st;
+    // a batch that is sparse against the index: fewer queries per wavefront (sparse_fill), results through buffers with a
+    // dump row for the padding slots
+    q_run = qs;
+    float4* qe = nullptr;
+    st = sparse_layout(ctx, qs, nq, ix->n, &qe, &nq_run);
+    if (st != PCLHIP_OK) return st;
+    sparse = qe != nullptr;
+    if (sparse) {
+      guard.add(qe);
+      q_run = qe;
+    }
   }
   int32_t* d_idx = out_idx;
   float* d_d2 = out_d2;

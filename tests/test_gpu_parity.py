@@ -166,6 +166,15 @@ def test_knn_few_queries_against_a_large_index(gpu, orc, nq):
         di, dd = tree.nearestKSearch(torch.from_numpy(qry).cuda(), 8)
         oi, od = otree.knn(qry, 8)
         assert di.is_cuda and np.array_equal(di.cpu().numpy(), oi) and np.array_equal(dd.cpu().numpy().view(np.uint32), od.view(np.uint32))
+    if nq in (7, 1000):  # through a rescaling point representation: the queries are mapped into the index's space on the way
+        tree3 = pcl_amd.KdTree(gpu)
+        tree3.setPointRepresentation(rescale_values=(1, 2, 0.5))
+        tree3.setInputCloud(tgt)
+        sc = np.array([1, 2, 0.5, 1], np.float32)
+        ok = np.isfinite(qry).all(axis=1)
+        gi, gd = tree3.nearestKSearch(qry, 5)
+        oi, od = orc.KdTree(tgt * sc).knn(np.ascontiguousarray(qry * sc), 5)
+        assert np.array_equal(gi[ok], oi[ok]) and np.array_equal(gd[ok].view(np.uint32), od[ok].view(np.uint32))
     sub = np.ascontiguousarray(rng.permutation(len(tgt))[:50_000].astype(np.int32))
     tree2 = build_tree(gpu, tgt, sub)
     gi, gd = tree2.nearestKSearch(qry, 3)
