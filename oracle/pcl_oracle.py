@@ -157,8 +157,11 @@ class KdTree:
         self.h = lib().orc_kdtree_build(_f(self.pts), self.n, self.stride)
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_kdtree_free(self.h)
+        if getattr(self, "h", None) and lib is not None:   # (at interpreter exit the module's globals may be gone already)
+            try:
+                lib().orc_kdtree_free(self.h)
+            except Exception:
+                pass
             self.h = None
 
     def size(self):

@@ -209,7 +209,8 @@ struct pclhip_ctx {
   int opt_cell_start = 1;               // start-level test of the seeded descents on kd cells instead of tight boxes (A/B)
   float opt_standoff_thickness = 0.2f;  // launches without seeds: the stand-off search serves indices whose leaves are thinner than this
                                         // against their width (search.hip: the measurements behind the gate) ...
-  int opt_standoff_max_mb = 640;        // ... and no larger than this (points + leaf blocks + boxes, 56 B per point)
+  int opt_standoff_max_mb = 1 << 24;    // ... and no larger than this (points + leaf blocks + boxes, 56 B per point): no limit by
+                                        // default since round 6 (search.hip: the measurements)
   int opt_reseed = 1;                   // seeded search: one fresh seed for a group whose seeds are all far (A/B)
   int opt_lane_max_up = 2;              // ... quad levels the first pass climbs before it hands a query to the second
   float opt_lane_far = 0.25f;           // ... a seed beyond this many mean leaf diagonals (squared) is replaced by a descent

@@ -1983,10 +1983,12 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     // spacing (ratio 0.3 at 100M points of the same surface) every query needs tens of leaves whatever the bound, the
     // lists outgrow the LDS, and the seeded search is the faster one (measured: 76 against 108 ms at 100M).
     const float SO_THICKNESS = ctx->opt_standoff_thickness;   // 0.2 (option "standoff_thickness": A/B on other geometries)
-    // ... and a gate on the index size.  Measured in round 4 with the front-ordered runs (cold launch, stand-off search
-    // against traverse(), ms): 12M points 3.5 / 3.6, 15M 4.7 / 4.5, 20M 8.0 / 7.2 -- beyond ~0.7 GB of index (points + leaf
-    // blocks + boxes, 56 B per point) the leaf blocks no longer stay in the 256 MB last-level cache under either body
-    // (both jump from 2.0 ms at 10M to 3.5 ms at 12M) and the stand-off search's longer lists cost more than they prune.
+    // ... and a gate on the index size, OPEN by default since round 6.  Round 4 measured the two bodies equal at 12M points
+    // and traverse() ahead beyond (3.5 / 3.6, 4.7 / 4.5, 8.0 / 7.2 ms at 12M / 15M / 20M points) and closed the gate at 640 MB
+    // of index; the stand-off body has since become 1.4x faster and the gate had gone stale -- round 6, the same launch with
+    // the gate at 640 MB / open: 12M points 2.96 / 2.07 ms, 16M 4.29 / 2.76, 20M 5.89 / 3.66, 30M 10.0 / 6.7, 50M 19.2 / 14.6
+    // (`ms_per_step` -12 ... -15 % there); at 100M points the thickness gate above decides (noise 1e-4 against a spacing of
+    // 2e-4: ratio 0.3) and nothing changes.  The option "standoff_max_mb" remains.
     const size_t SO_MAX_INDEX_BYTES = size_t(ctx->opt_standoff_max_mb) << 20;   // 640 MB (option "standoff_max_mb")
     const bool standoff = v.disc != nullptr && icp->target->disc_thickness < SO_THICKNESS &&
                           size_t(icp->target->n_pad) * 56u <= SO_MAX_INDEX_BYTES;

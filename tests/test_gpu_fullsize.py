@@ -153,6 +153,34 @@ def test_config3_knn8_and_normals_on_every_point_of_the_10m_cloud(gpu, orc, clou
     assert np.abs(nrm[:, 3] - onrm[:, 3]).max() < 1e-5
 
 
+def test_standoff_search_beyond_the_old_size_gate_at_20m(gpu, orc):
+    # Until round 6 the stand-off search (standoff.hpp) served indices up to 640 MB (12M points); the gate is open now
+    # (search.hip: the measurements).  The launch that starts an alignment and two seeded ones at 20M points -- an index of
+    # 1.1 GB -- against the oracle: every correspondence, index and float distance.
+    import torch
+    import pcl_amd
+    from pcl_amd import synth
+    n = 20_000_000
+    tgt = synth.gaussian_surface_device(n, synth.TARGET_SEED)
+    src = synth.apply_rigid_device(np.linalg.inv(synth.ground_truth_transform()), synth.gaussian_surface_device(n, synth.SOURCE_SEED))
+    torch.cuda.synchronize()
+    tree = pcl_amd.KdTree(gpu)
+    tree.setInputCloud(tgt)
+    tgt_h, src_h = tgt.cpu().numpy(), src.cpu().numpy()
+    otree = orc.KdTree(tgt_h)
+    icp = pcl_amd.IterativeClosestPoint(gpu)
+    icp.setSearchMethodTarget(tree, True)
+    icp.setInputSource(src)
+    icp.reset()
+    T = np.eye(4, dtype=np.float32)
+    cur = src_h.copy()
+    for it in range(3):
+        sums = icp.iterate(T, max_dist=0.1)
+        cur = orc.transform_cloud(T, cur, order=0)
+        assert_same_correspondences(icp.fetchCorrespondences(), otree.correspondences(cur, 0.1), "20M points, launch %d" % it)
+        T = icp.solve(sums)
+
+
 def test_config3_icp_correspondences_bit_exact_at_10m(gpu, orc, clouds10m, tree10m, otree10m):
     import torch
     import pcl_amd
