@@ -96,7 +96,7 @@ PCLHIP_API pclhip_status pclhip_ctx_reserve(pclhip_ctx* ctx, uint64_t bytes);
  *                           separate out); "lane_max_up" n (default 2) quad levels the first pass climbs,
  *                           "lane_far" x (default 0.25) squared mean leaf diagonals beyond which a seed is replaced
  *   "standoff_thickness" x, "standoff_max_mb" n   which indices the launch that starts an alignment searches by the stand-off
- *                           body (leaf discs): leaves thinner than x against their width (default 0.2) and an index of at
+ *                           body (leaf discs): leaves thinner than x against their width (default 0.3) and an index of at
  *                           most n MiB (default: no limit); everything else goes through the seeded body with disc bounds
  * No PCL counterpart (PCL's knobs are the setters of its classes, which the bindings map onto the calls below). */
 PCLHIP_API pclhip_status pclhip_ctx_set_option(pclhip_ctx* ctx, const char* name, double value);

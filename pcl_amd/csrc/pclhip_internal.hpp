@@ -207,7 +207,7 @@ struct pclhip_ctx {
   int opt_lane_search = 0;              // 1: seeded ICP launches one lane per query (lane.hip) -- exact, measured 2.5x SLOWER than the
                                         // wave-cooperative body at 10M points (profiles/r05_lane_search_ab.txt): kept as a tested option
   int opt_cell_start = 1;               // start-level test of the seeded descents on kd cells instead of tight boxes (A/B)
-  float opt_standoff_thickness = 0.2f;  // launches without seeds: the stand-off search serves indices whose leaves are thinner than this
+  float opt_standoff_thickness = 0.3f;  // launches without seeds: the stand-off search serves indices whose leaves are thinner than this
                                         // against their width (search.hip: the measurements behind the gate) ...
   int opt_standoff_max_mb = 1 << 24;    // ... and no larger than this (points + leaf blocks + boxes, 56 B per point): no limit by
                                         // default since round 6 (search.hip: the measurements)

@@ -1982,7 +1982,10 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
     // well above its noise: thickness ratio ~0.1 at the bench's 10M points).  Where the noise is of the order of the point
     // spacing (ratio 0.3 at 100M points of the same surface) every query needs tens of leaves whatever the bound, the
     // lists outgrow the LDS, and the seeded search is the faster one (measured: 76 against 108 ms at 100M).
-    const float SO_THICKNESS = ctx->opt_standoff_thickness;   // 0.2 (option "standoff_thickness": A/B on other geometries)
+    // 0.3 since round 6 (option "standoff_thickness"): the same surface at 70M points (ratio between 0.2 and 0.3) starts an
+    // alignment in 24.4 ms by the stand-off body against 31.8 by traverse(); at 100M points (0.3) the two are equal (54 / 55 ms);
+    // the cube / layers / clusters families lie above 0.3 and are slower by the stand-off body (round 6: gate opened by option)
+    const float SO_THICKNESS = ctx->opt_standoff_thickness;
     // ... and a gate on the index size, OPEN by default since round 6.  Round 4 measured the two bodies equal at 12M points
     // and traverse() ahead beyond (3.5 / 3.6, 4.7 / 4.5, 8.0 / 7.2 ms at 12M / 15M / 20M points) and closed the gate at 640 MB
     // of index; the stand-off body has since become 1.4x faster and the gate had gone stale -- round 6, the same launch with
