@@ -162,8 +162,8 @@ def main():
     icp.setMaximumIterations(20)
     icp.setMaxCorrespondenceDistance(0.1)
     icp.setTransformationEpsilon(1e-10)
-    if comm is not None:
-        icp.setCommunicator(comm)
+    from pcl_amd.dist import attach_collective
+    collective = attach_collective(icp, comm, local_rank, world)   # "native" (RCCL from C), or torch's all-reduce if that failed
     for name in [r for r in args.rejectors.split(",") if r]:
         if name == "median":
             rej = pcl_amd.CorrespondenceRejectorMedianDistance()
@@ -313,7 +313,10 @@ def main():
                        "loop": "device-driven (pclhip_icp_run_steps): search, accumulate, reduce, solve + convergence "
                                "kernels queued back to back",
                        "parallelism": "source slab sharded x%d, target replicated%s" %
-                                      (world, ", ncclAllReduce of the 32-double record per iteration" if world > 1 else "")},
+                                      (world, (", ncclAllReduce of the 32-double record per iteration (%s)" %
+                                               {"native": "issued from C on the context's stream",
+                                                "torch": "torch.distributed on the context's stream"}[collective])
+                                       if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu, "families": families,
             "per_step": [{"iteration": s["iteration"], "search_ms": round(s["search_ms"], 4),
                           "step_ms": round(s["step_ms"], 4), "ended": s["alignment_ended"], "state": s["state"]} for s in steps],
@@ -374,8 +377,8 @@ def run_pipeline(args, ctx, comm, tgt, src, n, rank, world, fence, gen_s):
         icp.setMaximumIterations(20)
         icp.setMaxCorrespondenceDistance(0.1)
         icp.setTransformationEpsilon(1e-10)
-        if comm is not None:
-            icp.setCommunicator(comm)
+        from pcl_amd.dist import attach_collective
+        attach_collective(icp, comm, torch.cuda.current_device(), world)
         icp.align()
         t2 = time.perf_counter()
         stage_ms["voxelgrid"].append((t1 - t0) * 1e3)

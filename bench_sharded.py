@@ -106,8 +106,8 @@ def run_config5(args, ctx, comm, rank, local_rank, world, fence):
     icp.setMaximumIterations(20)
     icp.setMaxCorrespondenceDistance(max_dist)
     icp.setTransformationEpsilon(1e-10)
-    if comm is not None:
-        icp.setCommunicator(comm)
+    from pcl_amd.dist import attach_collective
+    attach_collective(icp, comm, local_rank, world)
     if region is not None:
         icp.setRegion(region)
     from pcl_amd.dist import timed_steps

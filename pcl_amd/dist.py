@@ -39,22 +39,66 @@ def init_ranks(backend="nccl"):
     return rank, local_rank, world
 
 
+def _all_ranks_ok(ok):
+    """True when `ok` holds on EVERY rank (a MIN all-reduce over the default torch group)."""
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def native_communicator(ctx, rank, world):
     """The library's own RCCL communicator (pclhip_comm_*: its all-reduce is issued from C on the context's stream): rank 0
     draws the 128-byte id, the default torch.distributed group broadcasts it once (a device tensor under "nccl", a host tensor
-    under "gloo"), every rank joins.  None for a single rank."""
+    under "gloo"), every rank joins.  None for a single rank -- and None, on EVERY rank, when some rank could not bind RCCL or
+    join (the ranks agree on that through the torch group before anyone depends on the communicator): attach_collective()
+    then sums the record through torch.distributed on the context's stream instead, so an N-rank job still runs."""
     if world <= 1:
         return None
+    import sys
     import torch
     import torch.distributed as dist
     from . import _lib
     from .api import Communicator
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    uid = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
-    if rank == 0:
-        uid = torch.frombuffer(bytearray(Communicator.unique_id()), dtype=torch.uint8).to(dev)
-    dist.broadcast(uid, 0)
-    return Communicator(ctx, rank, world, bytes(uid.cpu().numpy().tobytes()))
+    uid, ok = None, True
+    try:
+        uid = Communicator.unique_id()   # every rank: binds RCCL's entry points (rank 0's id is the one that travels)
+    except Exception as e:  # noqa: BLE001 -- whatever went wrong, the job falls back as a whole
+        print("pcl_amd.dist: rank %d cannot bind RCCL for the native communicator (%s)" % (rank, e), file=sys.stderr)
+        ok = False
+    if not _all_ranks_ok(ok):
+        return None
+    t = torch.frombuffer(bytearray(uid), dtype=torch.uint8).to(dev)
+    dist.broadcast(t, 0)
+    comm = None
+    try:
+        comm = Communicator(ctx, rank, world, bytes(t.cpu().numpy().tobytes()))
+    except Exception as e:  # noqa: BLE001
+        print("pcl_amd.dist: rank %d could not join the native communicator (%s)" % (rank, e), file=sys.stderr)
+    if not _all_ranks_ok(comm is not None):
+        if comm is not None:
+            comm._release()
+        return None
+    return comm
+
+
+def attach_collective(icp, comm, local_rank, world):
+    """Give `icp` its per-iteration all-reduce: the native communicator when there is one, else (world > 1) torch.distributed's
+    all-reduce enqueued on the context's stream (make_allreduce_hook).  Returns "native", "torch" or None (single rank)."""
+    if comm is not None:
+        icp.setCommunicator(comm)
+        return "native"
+    if world > 1:
+        import torch.distributed as dist
+        if dist.get_backend() == "nccl":
+            icp.setAllReduce(make_allreduce_hook(local_rank))
+        else:   # gloo: host tensors (the CPU tests)
+            raise RuntimeError("no native communicator and no device collective under backend %r" % dist.get_backend())
+        return "torch"
+    return None
 
 
 def make_fence(ctx, world):
