@@ -831,31 +831,45 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
   };
   const GroupSchedule sched(ngroups);
   TraverseStats ts;
-  // software pipeline: the next group's points, seed positions and seed target points are already
-  // in flight while the current group is searched
+  // software pipeline, two groups deep: while group g is searched, the points AND the seed target points of g + 1 are in
+  // flight (its seed positions arrived during g - 1), and so are the seed positions of g + 2 -- a group finds everything
+  // it starts with in registers.  (Until round 6 the seed points of g + 1 were asked for after g's traversal, when its seed
+  // positions had just been looked at: a full memory round trip at the head of every group.)  The feed therefore runs two
+  // groups ahead: the ticket asked at the top of g names g + 3's predecessor... i.e. it is read at the bottom of g as g + 3.
   uint32_t gl = sched.first();
   uint32_t g = (gl < sched.end()) ? sched.global(gl) : ngroups;
-  // the group after the one in flight is known one group ahead (its loads are issued under the current search); what
-  // follows it is asked for at the same moment and arrives by the end of the search (GroupFeed)
   GroupFeed feed(sched, ix.sched_ctr);
-  uint32_t gl_next = GroupFeed::END;
-  if (gl < sched.end() && !feed.static_next(gl, gl_next)) {
-    feed.request();
-    gl_next = feed.resolve();
-  }
+  const auto next_now = [&](uint32_t from) -> uint32_t {   // the group after `from`, waiting for the counter if need be
+    uint32_t out = GroupFeed::END;
+    if (from == GroupFeed::END) return out;
+    if (!feed.static_next(from, out)) {
+      feed.request();
+      out = feed.resolve();
+    }
+    return out;
+  };
+  uint32_t gl_next = (gl < sched.end()) ? next_now(gl) : GroupFeed::END;
+  uint32_t gl_nn = next_now(gl_next);
   float4 p_n[Q], t_n[Q];
-  uint32_t sp_n[Q];
+  uint32_t sp_n[Q], sp_nn[Q];
   uint32_t gid_n = gid(g), st_n = 0;  // the group behind slot g; how many launches its working copy has seen
   if constexpr (OWNED) st_n = (g < ngroups && !restart) ? (og.stamp[gid_n] & 0x7FFFFFFFu) : 0u;
+  {
+    const uint32_t g1 = (gl_next != GroupFeed::END) ? sched.global(gl_next) : ngroups;
+    const uint32_t gid1 = gid(g1);
 #pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    p_n[q] = make_float4(0, 0, 0, 0);
-    t_n[q] = make_float4(0, 0, 0, 0);
-    sp_n[q] = NO_INDEX;
-    const uint32_t i = gid_n * GROUP + q * WAVE + lane;
-    if (g < ngroups && i < ns && lane_in_group) {
-      p_n[q] = (OWNED && st_n == 0u) ? src0[i] : in[i];
-      sp_n[q] = restart ? NO_INDEX : match_pos[i];
+    for (int q = 0; q < Q; ++q) {
+      p_n[q] = make_float4(0, 0, 0, 0);
+      t_n[q] = make_float4(0, 0, 0, 0);
+      sp_n[q] = NO_INDEX;
+      sp_nn[q] = NO_INDEX;
+      const uint32_t i = gid_n * GROUP + q * WAVE + lane;
+      if (g < ngroups && i < ns && lane_in_group) {
+        p_n[q] = (OWNED && st_n == 0u) ? src0[i] : in[i];
+        sp_n[q] = restart ? NO_INDEX : match_pos[i];
+      }
+      const uint32_t i1 = gid1 * GROUP + q * WAVE + lane;
+      if (g1 < ngroups && i1 < ns && lane_in_group) sp_nn[q] = restart ? NO_INDEX : match_pos[i1];
       if (sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
     }
   }
@@ -883,27 +897,33 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
       seed_pos[q] = sp_n[q];
       in_range[q] = lane_in_group && (gcur * GROUP + q * WAVE + lane) < ns;
     }
-    // next group: issue its points + seed positions now ...
+    // next group (g2): its points and -- its seed positions are here since the previous group -- its seed target points;
+    // the group after it (g3): its seed positions
     const uint32_t g2 = (gl_next != GroupFeed::END) ? sched.global(gl_next) : ngroups;
+    const uint32_t g3 = (gl_nn != GroupFeed::END) ? sched.global(gl_nn) : ngroups;
     gid_n = gid(g2);
+    const uint32_t gid_nn = gid(g3);
     if constexpr (OWNED) st_n = (g2 < ngroups && !restart) ? (og.stamp[gid_n] & 0x7FFFFFFFu) : 0u;
     uint32_t gl_after = GroupFeed::END;
     bool asked = false;
-    if (gl_next != GroupFeed::END && !feed.static_next(gl_next, gl_after)) {
+    if (gl_nn != GroupFeed::END && !feed.static_next(gl_nn, gl_after)) {
       feed.request();
       asked = true;
     }
-    bool next_ok[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const uint32_t i2 = gid_n * GROUP + q * WAVE + lane;
-      next_ok[q] = g2 < ngroups && i2 < ns && lane_in_group;
+      const bool next_ok = g2 < ngroups && i2 < ns && lane_in_group;
+      sp_n[q] = sp_nn[q];   // (NO_INDEX where the lane has no point in g2: it was loaded under the same conditions)
       p_n[q] = make_float4(0, 0, 0, 0);
-      sp_n[q] = NO_INDEX;
-      if (next_ok[q]) {
+      t_n[q] = make_float4(0, 0, 0, 0);
+      if (next_ok) {
         p_n[q] = (OWNED && st_n == 0u) ? src0[i2] : in[i2];
-        sp_n[q] = restart ? NO_INDEX : match_pos[i2];
+        if (sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
       }
+      const uint32_t i3 = gid_nn * GROUP + q * WAVE + lane;
+      sp_nn[q] = NO_INDEX;
+      if (g3 < ngroups && i3 < ns && lane_in_group) sp_nn[q] = restart ? NO_INDEX : match_pos[i3];
     }
     NN1MinT<Q> fast;
     fast.init(bound);
@@ -966,12 +986,6 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
     traverse<NN1MinT<Q>, SPARSE>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, start_leaf, hm == 0);
     ICP_LAP(6);
     fast.resolve(ix, qx, qy, qz);
-    // ... and their seed target points as soon as the seed positions have arrived
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      t_n[q] = make_float4(0, 0, 0, 0);
-      if (next_ok[q] && sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
-    }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       NN1 pol;
@@ -1004,7 +1018,8 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
       if (lane == 0) og.stamp[gcur] = epoch + 1u;
     }
     g = g2;
-    gl_next = asked ? feed.resolve() : gl_after;
+    gl_next = gl_nn;
+    gl_nn = asked ? feed.resolve() : gl_after;
     ICP_LAP(7);
   }
 #undef ICP_LAP
