@@ -432,6 +432,7 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
   reinterpret_cast<FakeEvent*>(e)->t = std::chrono::steady_clock::now();
   return hipSuccess;
 }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }   // launches are synchronous here
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
