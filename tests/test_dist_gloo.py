@@ -220,3 +220,53 @@ def test_two_rank_sharded_target_matches_single_process():
         assert np.allclose(rec, ref, rtol=1e-11, atol=1e-12)
         assert np.array_equal(T, out[0][3])
         assert np.abs(T - _solve(ref, 1)).max() < 1e-7
+
+
+def _fallback_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pcl_amd.api as api
+        from pcl_amd.dist import attach_collective, native_communicator
+
+        # rank 1 cannot bind RCCL: NO rank may go on to create (and then wait inside) the communicator
+        def broken():
+            raise OSError("librccl.so: cannot open shared object file")
+
+        def working():
+            return bytes(_lib.COMM_ID_BYTES)
+
+        created = []
+
+        class FakeComm:
+            def __init__(self, *a):
+                created.append(a)
+
+        api.Communicator.unique_id = staticmethod(broken if rank == 1 else working)
+        real = api.Communicator.__init__
+        api.Communicator.__init__ = lambda self, *a: created.append(a)
+        try:
+            comm = native_communicator(object(), rank, world)
+        finally:
+            api.Communicator.__init__ = real
+        # ... and a job without a native communicator must not silently run unreduced under a backend with no device collective
+        refused = False
+        try:
+            attach_collective(object(), None, 0, world)
+        except RuntimeError:
+            refused = True
+        out[rank] = (comm is None, len(created), refused)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_to_fall_back_when_one_cannot_bind_rccl():
+    """pcl_amd.dist.native_communicator: one rank failing to bind RCCL makes EVERY rank return None before anyone joins the
+    communicator (bench.py then sums the record through torch.distributed: attach_collective)."""
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_fallback_worker, args=(world, port, out), nprocs=world, join=True)
+        assert [out[r] for r in range(world)] == [(True, 0, True)] * world
