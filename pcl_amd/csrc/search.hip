@@ -763,6 +763,9 @@ pclhip_status launch_gicp_covariances(pclhip_index* ix, int k, double eps, doubl
 // Mat34, xform_row, in_region: icp_xform.hpp (shared with the per-lane search of lane.hip)
 
 constexpr int NS = PCLHIP_ICP_NSUMS;
+#ifndef PCLHIP_DEEP_FROM
+#define PCLHIP_DEEP_FROM 12   // groups per wave from which the seeded body's pipeline runs two groups deep (icp_search_body)
+#endif
 
 // Queries per wavefront of the ICP search kernels: 64 >> s, s in bits 8-10 of `flags` (0: the full wavefront).
 __host__ __device__ inline uint32_t search_fill_of(int flags) { return uint32_t(WAVE) >> ((uint32_t(flags) >> 8) & 7u); }
@@ -793,7 +796,7 @@ __device__ __forceinline__ void own_replay(const OwnedState* st, uint32_t from, 
   }
 }
 
-template <int Q, bool SPARSE, bool OWNED = false, class OG = NoOwnedGroups>
+template <int Q, bool SPARSE, bool OWNED = false, class OG = NoOwnedGroups, bool DEEP = false>
 __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __restrict__ cur,
                                                 const float4* __restrict__ src0, uint32_t ns, Mat34 T,
                                                 const IcpControl* __restrict__ ctl, const RegionBox& region, int order,
@@ -835,7 +838,10 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
   // flight (its seed positions arrived during g - 1), and so are the seed positions of g + 2 -- a group finds everything
   // it starts with in registers.  (Until round 6 the seed points of g + 1 were asked for after g's traversal, when its seed
   // positions had just been looked at: a full memory round trip at the head of every group.)  The feed therefore runs two
-  // groups ahead: the ticket asked at the top of g names g + 3's predecessor... i.e. it is read at the bottom of g as g + 3.
+  // groups ahead: the ticket asked at the top of g is read at the bottom of g as g + 3.
+  // Only where a wave has groups enough (`deep`): a wave that runs two groups ahead also HOLDS two groups while the launch
+  // drains, and with four groups per wave (2^20 points) that imbalance costs more than the round trip (config 2, same box:
+  // 0.1565 ms per step one group ahead, 0.1675 two ahead) -- small launches keep the pipeline of rounds 1-5.
   uint32_t gl = sched.first();
   uint32_t g = (gl < sched.end()) ? sched.global(gl) : ngroups;
   GroupFeed feed(sched, ix.sched_ctr);
@@ -848,8 +854,9 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
     }
     return out;
   };
+  constexpr bool deep = DEEP;   // chosen by the host from the launch's groups per wave (icp_deep_pipeline): one body per depth
   uint32_t gl_next = (gl < sched.end()) ? next_now(gl) : GroupFeed::END;
-  uint32_t gl_nn = next_now(gl_next);
+  uint32_t gl_nn = deep ? next_now(gl_next) : GroupFeed::END;
   float4 p_n[Q], t_n[Q];
   uint32_t sp_n[Q], sp_nn[Q];
   uint32_t gid_n = gid(g), st_n = 0;  // the group behind slot g; how many launches its working copy has seen
@@ -906,24 +913,34 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
     if constexpr (OWNED) st_n = (g2 < ngroups && !restart) ? (og.stamp[gid_n] & 0x7FFFFFFFu) : 0u;
     uint32_t gl_after = GroupFeed::END;
     bool asked = false;
-    if (gl_nn != GroupFeed::END && !feed.static_next(gl_nn, gl_after)) {
+    const uint32_t gl_last = deep ? gl_nn : gl_next;   // the last group this wave knows of
+    if (gl_last != GroupFeed::END && !feed.static_next(gl_last, gl_after)) {
       feed.request();
       asked = true;
     }
+    bool next_ok[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const uint32_t i2 = gid_n * GROUP + q * WAVE + lane;
-      const bool next_ok = g2 < ngroups && i2 < ns && lane_in_group;
-      sp_n[q] = sp_nn[q];   // (NO_INDEX where the lane has no point in g2: it was loaded under the same conditions)
+      next_ok[q] = g2 < ngroups && i2 < ns && lane_in_group;
       p_n[q] = make_float4(0, 0, 0, 0);
       t_n[q] = make_float4(0, 0, 0, 0);
-      if (next_ok) {
-        p_n[q] = (OWNED && st_n == 0u) ? src0[i2] : in[i2];
-        if (sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
+      if (deep) {
+        sp_n[q] = sp_nn[q];   // (NO_INDEX where the lane has no point in g2: it was loaded under the same conditions)
+        if (next_ok[q]) {
+          p_n[q] = (OWNED && st_n == 0u) ? src0[i2] : in[i2];
+          if (sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
+        }
+        const uint32_t i3 = gid_nn * GROUP + q * WAVE + lane;
+        sp_nn[q] = NO_INDEX;
+        if (g3 < ngroups && i3 < ns && lane_in_group) sp_nn[q] = restart ? NO_INDEX : match_pos[i3];
+      } else {
+        sp_n[q] = NO_INDEX;
+        if (next_ok[q]) {
+          p_n[q] = (OWNED && st_n == 0u) ? src0[i2] : in[i2];
+          sp_n[q] = restart ? NO_INDEX : match_pos[i2];
+        }
       }
-      const uint32_t i3 = gid_nn * GROUP + q * WAVE + lane;
-      sp_nn[q] = NO_INDEX;
-      if (g3 < ngroups && i3 < ns && lane_in_group) sp_nn[q] = restart ? NO_INDEX : match_pos[i3];
     }
     NN1MinT<Q> fast;
     fast.init(bound);
@@ -986,6 +1003,11 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
     traverse<NN1MinT<Q>, SPARSE>(ix, qx, qy, qz, valid, fast, wl_s[wave], topbox_s, ts, start_leaf, hm == 0);
     ICP_LAP(6);
     fast.resolve(ix, qx, qy, qz);
+    if (!deep) {   // one group ahead: the next group's seed points, now that its seed positions are here
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+        if (next_ok[q] && sp_n[q] != NO_INDEX) t_n[q] = ix.pts[sp_n[q]];
+    }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       NN1 pol;
@@ -1018,8 +1040,12 @@ __device__ __forceinline__ void icp_search_body(const IndexView& ix, float4* __r
       if (lane == 0) og.stamp[gcur] = epoch + 1u;
     }
     g = g2;
-    gl_next = gl_nn;
-    gl_nn = asked ? feed.resolve() : gl_after;
+    if (deep) {
+      gl_next = gl_nn;
+      gl_nn = asked ? feed.resolve() : gl_after;
+    } else {
+      gl_next = asked ? feed.resolve() : gl_after;
+    }
     ICP_LAP(7);
   }
 #undef ICP_LAP
@@ -1162,7 +1188,7 @@ __device__ __forceinline__ void icp_cold_search_body(const IndexView& ix, float4
 // (host-driven first iteration), and both behind the control block of the device-driven loop -- one launch per
 // iteration, IcpControl::restart picks the body on the device (registers and LDS are the maximum of the two bodies,
 // which is what either needs anyway).
-template <int MINW, int Q, bool SPARSE>
+template <int MINW, int Q, bool SPARSE, bool DEEP = false>
 __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, float4* __restrict__ cur,
                                                                  const float4* __restrict__ src0, uint32_t ns,
                                                                  Mat34 T, const IcpControl* __restrict__ ctl,
@@ -1174,8 +1200,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void icp_search_kernel(IndexView ix, f
                                                                  ) {
   __shared__ IcpWaveLds wl_s[WAVES_PER_BLOCK];
   __shared__ Box topbox_s[TOPCACHE_BOXES];
-  icp_search_body<Q, SPARSE>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
-                             topbox_s);
+  icp_search_body<Q, SPARSE, false, NoOwnedGroups, DEEP>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match,
+                                                         match_d2, gstats, wl_s, topbox_s);
 }
 
 #ifndef PCLHIP_COLD_MINW
@@ -1191,6 +1217,7 @@ __global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_cold_search_kerne
                        wl_s, topbox_s);
 }
 
+template <bool DEEP>
 __global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_search_dual_kernel(
     IndexView ix, float4* __restrict__ cur, const float4* __restrict__ src0, uint32_t ns, Mat34 T,
     const IcpControl* __restrict__ ctl, RegionBox region, int order, float bound, int flags, float so_from,
@@ -1204,8 +1231,8 @@ __global__ __launch_bounds__(BLOCK, PCLHIP_COLD_MINW) void icp_search_dual_kerne
   else if ((flags & 4) != 0)
     return;  // SEARCH_RESTART_ONLY
   else
-    icp_search_body<1, true>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match, match_d2, gstats, wl_s,
-                             topbox_s);
+    icp_search_body<1, true, false, NoOwnedGroups, DEEP>(ix, cur, src0, ns, T, ctl, region, order, bound, flags, match_pos, match,
+                                                         match_d2, gstats, wl_s, topbox_s);
 }
 
 // The same two bodies over the launch's list of SERVED groups (target sharding in the device-driven loop): `standoff`
@@ -1989,7 +2016,11 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
   const bool filters = icp->reciprocal || !icp->rejectors.empty();
   bool solved = false;
   if (icp->n > 0) {
-    auto ks = icp_search_kernel<4, 1, true>;
+    // pipeline depth of the seeded body (icp_search_body: DEEP): two groups ahead from PCLHIP_DEEP_FROM groups per wave on
+    const auto deep_for = [&](int grid_blocks, uint32_t groups) {
+      return uint64_t(groups) >= uint64_t(PCLHIP_DEEP_FROM) * uint64_t(grid_blocks) * uint64_t(WAVES_PER_BLOCK);
+    };
+    auto ks = icp_search_kernel<4, 1, true, false>;
     // launches without seeds go through the stand-off search when the index carries leaf discs: the host-driven loop
     // knows which launch that is (pclhip_icp_reset cleared the seeds); in the device-driven loop the control block
     // picks the body on the device (icp_search_dual_kernel)
@@ -2057,17 +2088,23 @@ pclhip_status launch_icp_iterate(pclhip_icp* icp, const float T[16], float max_d
                          ctl, icp->region, order, bound, kflags, so_from, standoff ? 1 : 0, icp->match_pos, icp->match,
                          icp->match_d2, ctx->stats, og);
     } else if (standoff && device_loop) {
-      const int gd = resident_blocks(ctx, icp_search_dual_kernel, ngroups);
-      PCLHIP_LAUNCH_FED(ctx, icp_search_dual_kernel, dim3(gd), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M, ctl,
-                         icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2,
-                         ctx->stats);
+      const int gd = resident_blocks(ctx, icp_search_dual_kernel<false>, ngroups);
+      if (deep_for(gd, ngroups)) {
+        PCLHIP_LAUNCH_FED(ctx, icp_search_dual_kernel<true>, dim3(gd), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M,
+                           ctl, icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+      } else {
+        PCLHIP_LAUNCH_FED(ctx, icp_search_dual_kernel<false>, dim3(gd), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M,
+                           ctl, icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
+      }
     } else if (cold) {
       const int gc = resident_blocks(ctx, icp_cold_search_kernel, ngroups);
       PCLHIP_LAUNCH_FED(ctx, icp_cold_search_kernel, dim3(gc), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0, icp->n, M,
                          ctl, icp->region, order, bound, kflags, so_from, icp->match_pos, icp->match, icp->match_d2,
                          ctx->stats);
     } else {
-      PCLHIP_LAUNCH_FED(ctx, ks, dim3(resident_blocks(ctx, ks, ngroups)), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0,
+      const int gk = resident_blocks(ctx, ks, ngroups);
+      if (deep_for(gk, ngroups)) ks = icp_search_kernel<4, 1, true, true>;
+      PCLHIP_LAUNCH_FED(ctx, ks, dim3(gk), dim3(BLOCK), 0, s, v, icp->src_cur, icp->src_sorted0,
                          icp->n, M, ctl, icp->region, order, bound, kflags, icp->match_pos, icp->match, icp->match_d2, ctx->stats);
     }
     if (lane_now) {
@@ -2280,7 +2317,9 @@ bool search_built_with_verify_bounds() {
 void preload_search_kernels(pclhip_ctx* ctx) {
   (void)resident_blocks(ctx, icp_search_kernel<4, 1, true>, 1);
   (void)resident_blocks(ctx, icp_cold_search_kernel, 1);
-  (void)resident_blocks(ctx, icp_search_dual_kernel, 1);
+  (void)resident_blocks(ctx, icp_search_dual_kernel<false>, 1);
+  (void)resident_blocks(ctx, icp_search_dual_kernel<true>, 1);
+  (void)resident_blocks(ctx, icp_search_kernel<4, 1, true, true>, 1);
   (void)resident_blocks(ctx, normals_kernel<8>, 1);
   (void)resident_blocks(ctx, knn_reg_kernel<1>, 1);
 }

@@ -1443,6 +1443,8 @@ struct GroupFeed {
   }
   // the wave's first group (local index), END if it has none
   __device__ __forceinline__ uint32_t first(const GroupSchedule& s) const { return s.first() < end_ ? s.first() : END; }
+  // groups per wave of the launch (whole strides of the XCD's window)
+  __device__ __forceinline__ uint32_t strides() const { return end_ / step_; }
   // the group after `gl` when it is known without asking: true and `out` (END: none); false: request() + resolve()
   __device__ __forceinline__ bool static_next(uint32_t gl, uint32_t& out) const {
     if (static_end_ == end_) {
