@@ -394,8 +394,10 @@ __global__ __launch_bounds__(256) void quad_cell_kernel(const Box* __restrict__ 
 // The SMALL quad levels in one launch (a 10M-point index has eleven levels; from the fifth up they hold 2,442, 611, 153, ...
 // nodes: seven box launches and seven cell launches of a few microseconds of work and ~5 us of launch each).  One workgroup:
 // boxes of the levels [q_from, q_top] bottom-up, then the cells of the levels [q_from - 1, q_top - 1] top-down, a barrier
-// between levels (the levels' arrays are global memory written and read by this one workgroup).  qbox / qcell: the
-// arrays of all levels, level q at offset off(q) = sum of the counts below it.
+// between levels (the levels' arrays are global memory written and read by this one workgroup: a WORKGROUP-scope fence orders
+// them -- its waves share one vector cache; the device-scope fence that stood here until late in round 6 wrote the XCD's
+// L2 back fourteen times: 104 -> 62 us at 10M points).  qbox / qcell: the arrays of all levels, level q at offset
+// off(q) = sum of the counts below it.
 __global__ __launch_bounds__(1024) void quad_top_kernel(Box* __restrict__ qbox, Box* __restrict__ qcell, uint32_t nleaf, int q_from,
                                                         int q_top) {
   const auto count = [&](int q) { return lane_tree_count(nleaf, q); };
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(1024) void quad_top_kernel(Box* __restrict__ qbox, 
     const uint32_t cc = count(q - 1), cp = count(q);
     for (uint32_t i = threadIdx.x; i < cp; i += blockDim.x) quad_box_node(qbox + o, cc, qbox + o + cc, i);
     o += cc;
-    __threadfence();
+    __threadfence_block();
     __syncthreads();
   }
   // o = offset of level q_top
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(1024) void quad_top_kernel(Box* __restrict__ qbox, 
     for (uint32_t i = threadIdx.x; i < cp; i += blockDim.x)
       quad_cell_node(qcell + o, q == q_top ? 1 : 0, qbox + coff, cc, qcell + coff, i);
     o = coff;
-    __threadfence();
+    __threadfence_block();
     __syncthreads();
   }
 }
@@ -1019,15 +1021,25 @@ __global__ __launch_bounds__(KP_THREADS) void kp_hist_kernel(const float4* __res
   if (PASS == 1) {
     for (int i = threadIdx.x; i < NH * KP_BINS; i += KP_THREADS) (&h[0][0])[i] = 0u;
     __syncthreads();
-#pragma unroll 4
-    for (int e = 0; e < KP_ROWS; ++e) {
-      const uint32_t i = base + uint32_t(e) * KP_THREADS + threadIdx.x;
-      if (i < n) {
-        const float4 q = pts[i];
-        const float c = p.axis == 0u ? q.x : (p.axis == 1u ? q.y : q.z);
-        const uint32_t v = orderable(c) - p.klo;
-        keys[i] = v;
-        atomicAdd(&h[0][(v >> shift) & mask], 1u);
+    // eight points per batch, their loads in flight together (see kp_count_kernel)
+#pragma unroll
+    for (int e0 = 0; e0 < KP_ROWS; e0 += 8) {
+      float4 qq[8];
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const uint32_t i = base + uint32_t(e0 + f) * KP_THREADS + threadIdx.x;
+        qq[f] = pts[i < n ? i : n - 1u];
+      }
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const uint32_t i = base + uint32_t(e0 + f) * KP_THREADS + threadIdx.x;
+        if (i < n) {
+          const float4 q = qq[f];
+          const float c = p.axis == 0u ? q.x : (p.axis == 1u ? q.y : q.z);
+          const uint32_t v = orderable(c) - p.klo;
+          keys[i] = v;
+          atomicAdd(&h[0][(v >> shift) & mask], 1u);
+        }
       }
     }
   } else {
@@ -1147,14 +1159,20 @@ __global__ __launch_bounds__(KP_THREADS) void kp_count_kernel(const uint32_t* __
   const uint32_t base = blockIdx.x * uint32_t(KP_BLOCK);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   unsigned long long a = 0ull, b = 0ull;
+  // the sixteen keys first, all loads in flight together (a load inside `if (i < n)` is followed by its own wait: sixteen
+  // memory round trips one after the other -- what this kernel's 17 us at 10M points were); rows past the end read key n - 1
+  uint32_t kv[KP_ROWS];
 #pragma unroll
   for (int e = 0; e < KP_ROWS; ++e) {
     const uint32_t i = base + uint32_t(e) * KP_THREADS + threadIdx.x;
-    if (i < n) {
-      const uint32_t cl = kp_class(keys[i], st);
-      a += cl < 4u ? 1ull << (16u * cl) : 0ull;
-      b += cl >= 4u ? 1ull << (16u * (cl - 4u)) : 0ull;
-    }
+    kv[e] = keys[i < n ? i : n - 1u];
+  }
+#pragma unroll
+  for (int e = 0; e < KP_ROWS; ++e) {
+    const uint32_t i = base + uint32_t(e) * KP_THREADS + threadIdx.x;
+    const uint32_t cl = kp_class(kv[e], st);
+    a += (i < n && cl < 4u) ? 1ull << (16u * cl) : 0ull;
+    b += (i < n && cl >= 4u) ? 1ull << (16u * (cl - 4u)) : 0ull;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -1247,10 +1265,16 @@ __global__ __launch_bounds__(KP_THREADS) void kp_scatter_kernel(const float4* __
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t cls[KP_ROWS], rnk[KP_ROWS];
+  // (as in kp_count_kernel: the keys of all rows are asked for before the first is used)
 #pragma unroll
   for (int e = 0; e < KP_ROWS; ++e) {
     const uint32_t i = base + uint32_t(e) * KP_THREADS + threadIdx.x;
-    cls[e] = i < n ? kp_class(keys[i], st) : 7u;
+    cls[e] = keys[i < n ? i : n - 1u];
+  }
+#pragma unroll
+  for (int e = 0; e < KP_ROWS; ++e) {
+    const uint32_t i = base + uint32_t(e) * KP_THREADS + threadIdx.x;
+    cls[e] = i < n ? kp_class(cls[e], st) : 7u;
     rnk[e] = 0u;
 #pragma unroll
     for (uint32_t k = 0; k < 7; ++k) {
@@ -1285,12 +1309,23 @@ __global__ __launch_bounds__(KP_THREADS) void kp_scatter_kernel(const float4* __
       }
   }
   const uint32_t seg_first = sgm * blocks_per_seg * uint32_t(KP_BLOCK);
+  // the points in batches of KP_MOVE rows: every load of a batch is in flight before its first store (load, wait, store per
+  // row made the partition a chain of sixteen memory round trips per wavefront: 97 us per round at 10M points)
+  constexpr int KP_MOVE = 8;
 #pragma unroll
-  for (int e = 0; e < KP_ROWS; ++e) {
+  for (int e0 = 0; e0 < KP_ROWS; e0 += KP_MOVE) {
+  float4 qq[KP_MOVE];
+#pragma unroll
+  for (int f = 0; f < KP_MOVE; ++f) {
+    const uint32_t i = base + uint32_t(e0 + f) * KP_THREADS + threadIdx.x;
+    qq[f] = in[i < n ? i : n - 1u];
+  }
+#pragma unroll
+  for (int f = 0; f < KP_MOVE; ++f) {
+    const int e = e0 + f;
     if (cls[e] < 7u) {
-      const uint32_t i = base + uint32_t(e) * KP_THREADS + threadIdx.x;
       const uint32_t dst = boff[cls[e]] + cell[e * WAVES + int(wave)][cls[e]] + rnk[e];
-      const float4 q = in[i];
+      const float4 q = qq[f];
       out[dst] = q;
       if (BOXES) {
         const uint32_t slab = (dst - seg_first) >> slab_shift;
@@ -1303,6 +1338,7 @@ __global__ __launch_bounds__(KP_THREADS) void kp_scatter_kernel(const float4* __
         }
       }
     }
+  }
   }
   if (BOXES) {
     __shared__ float red[WAVES][4][6];
@@ -1388,23 +1424,45 @@ __global__ __launch_bounds__(KP_THREADS) void kd_load_box_kernel(const void* pts
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   unsigned int mine = 0;
-#pragma unroll 4
-  for (int e = 0; e < KP_ROWS; ++e) {
-    const uint64_t j = base + uint64_t(e) * KP_THREADS + threadIdx.x;
-    if (j < m) {
-      const uint32_t rec = sel ? uint32_t(sel[j]) : uint32_t(j);
-      const float* p = record(pts, stride, rec);
-      float x = p[0], y = p[1], z = p[2];
-      const bool fin = (sc.x == 0.0f || isfinite(x)) && (sc.y == 0.0f || isfinite(y)) && (sc.z == 0.0f || isfinite(z));
-      mine += fin ? 1u : 0u;
-      if (scaled) {  // as kd_load_kernel
-        x = sc.x == 0.0f ? 0.0f : __fmul_rn(x, sc.x);
-        y = sc.y == 0.0f ? 0.0f : __fmul_rn(y, sc.y);
-        z = sc.z == 0.0f ? 0.0f : __fmul_rn(z, sc.z);
+  // eight records per batch, their loads in flight together (see kp_count_kernel); rows past the end read record m - 1
+  constexpr int LB = 8;
+  for (int e0 = 0; e0 < KP_ROWS; e0 += LB) {
+    uint32_t recs[LB];
+    float xs[LB], ys[LB], zs[LB], ws[LB];
+#pragma unroll
+    for (int f = 0; f < LB; ++f) {
+      const uint64_t j = base + uint64_t(e0 + f) * KP_THREADS + threadIdx.x;
+      const uint64_t jc = j < m ? j : m - 1;
+      recs[f] = sel ? uint32_t(sel[jc]) : uint32_t(jc);
+    }
+#pragma unroll
+    for (int f = 0; f < LB; ++f) {
+      const float* p = record(pts, stride, recs[f]);
+      xs[f] = p[0]; ys[f] = p[1]; zs[f] = p[2];
+    }
+    if (ids_from_w) {   // (one branch around the batch, not one per record: a branch ends the run of loads)
+#pragma unroll
+      for (int f = 0; f < LB; ++f) ws[f] = record(pts, stride, recs[f])[3];
+    } else {
+#pragma unroll
+      for (int f = 0; f < LB; ++f) ws[f] = __uint_as_float(recs[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < LB; ++f) {
+      const uint64_t j = base + uint64_t(e0 + f) * KP_THREADS + threadIdx.x;
+      if (j < m) {
+        float x = xs[f], y = ys[f], z = zs[f];
+        const bool fin = (sc.x == 0.0f || isfinite(x)) && (sc.y == 0.0f || isfinite(y)) && (sc.z == 0.0f || isfinite(z));
+        mine += fin ? 1u : 0u;
+        if (scaled) {  // as kd_load_kernel
+          x = sc.x == 0.0f ? 0.0f : __fmul_rn(x, sc.x);
+          y = sc.y == 0.0f ? 0.0f : __fmul_rn(y, sc.y);
+          z = sc.z == 0.0f ? 0.0f : __fmul_rn(z, sc.z);
+        }
+        out[j] = make_float4(x, y, z, ws[f]);
+        lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+        hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
       }
-      out[j] = make_float4(x, y, z, ids_from_w ? p[3] : __uint_as_float(rec));
-      lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
-      hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
     }
   }
   __shared__ float red[KP_THREADS / WAVE][6];
@@ -1777,7 +1835,7 @@ pclhip_status build_index_over(pclhip_ctx* ctx, float4* pts_in_kd_order, uint32_
 pclhip_status build_boxes(pclhip_index* ix, bool with_discs) {
   pclhip_ctx* ctx = ix->ctx;
   hipStream_t s = ctx->stream;
-  constexpr int DIAG_NB = 64;
+  constexpr int DIAG_NB = 512;  // 64 until late in round 6: 16K lanes walking 625K leaves took 27 us at 10M points (now 10)
   double* diag_part = nullptr;   // pinned; released at the final wait
   uint32_t diag_leaves = 0;
   struct PinnedGuard {
