@@ -31,24 +31,46 @@ __device__ __forceinline__ int limit_field(int limits) {
   return f ? f - 1 : 2;
 }
 
+constexpr int VG_BATCH = 4;   // records a thread asks for at a time in the grid-stride passes over the cloud
+
 // getMinMax3D with the optional field filter (voxel_grid.hpp:513-590; limits cast to float, :615)
 __global__ __launch_bounds__(256) void vg_minmax_kernel(const void* pts, size_t stride, uint64_t n, int has_limits,
                                                         float fmin_, float fmax_, float* partial) {
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
-    const float* p = rec(pts, stride, i);
-    const float x = p[0], y = p[1], z = p[2];
-    if (has_limits) {  // voxel_grid.hpp:513-590: the field's value against the limits cast to float
-      const float v = p[limit_field(has_limits)];
-      if (has_limits & 2) {  // filter_limit_negative_: points INSIDE the interval are cut
-        if ((v < fmax_) && (v > fmin_)) continue;
-      } else if ((v > fmax_) || (v < fmin_)) {
-        continue;
+  // VG_BATCH records per trip of the grid-stride loop, their loads in flight together (one record per trip is one memory
+  // round trip per trip: twenty in a row at 10M points); slots past the end re-read the trip's first record and are skipped
+  const uint64_t G = uint64_t(gridDim.x) * blockDim.x;
+  for (uint64_t i0 = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i0 < n; i0 += VG_BATCH * G) {
+    float xs[VG_BATCH], ys[VG_BATCH], zs[VG_BATCH], vs[VG_BATCH];
+#pragma unroll
+    for (int u = 0; u < VG_BATCH; ++u) {
+      const uint64_t i = i0 + uint64_t(u) * G;
+      const float* p = rec(pts, stride, i < n ? i : i0);
+      xs[u] = p[0]; ys[u] = p[1]; zs[u] = p[2];
+    }
+    if (has_limits) {
+#pragma unroll
+      for (int u = 0; u < VG_BATCH; ++u) {
+        const uint64_t i = i0 + uint64_t(u) * G;
+        vs[u] = rec(pts, stride, i < n ? i : i0)[limit_field(has_limits)];
       }
     }
-    if (!(isfinite(x) && isfinite(y) && isfinite(z))) continue;
-    lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
-    hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+#pragma unroll
+    for (int u = 0; u < VG_BATCH; ++u) {
+      if (i0 + uint64_t(u) * G >= n) continue;
+      const float x = xs[u], y = ys[u], z = zs[u];
+      if (has_limits) {  // voxel_grid.hpp:513-590: the field's value against the limits cast to float
+        const float v = vs[u];
+        if (has_limits & 2) {  // filter_limit_negative_: points INSIDE the interval are cut
+          if ((v < fmax_) && (v > fmin_)) continue;
+        } else if ((v > fmax_) || (v < fmin_)) {
+          continue;
+        }
+      }
+      if (!(isfinite(x) && isfinite(y) && isfinite(z))) continue;
+      lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+      hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+    }
   }
   __shared__ float s[4][6];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -83,23 +105,42 @@ __global__ __launch_bounds__(256) void vg_key_kernel(const void* pts, size_t str
                                                      double lim_min, double lim_max, uint32_t* keys,
                                                      unsigned int* n_valid, int sort_bits) {
   unsigned int mine = 0;
-  for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
-    const float* p = rec(pts, stride, i);
-    const float x = p[0], y = p[1], z = p[2];
-    bool ok = isfinite(x) && isfinite(y) && isfinite(z);
-    if (ok && has_limits) {  // :684-695: double limits against the float value
-      const double v = double(p[limit_field(has_limits)]);
-      ok = (has_limits & 2) ? !((v < lim_max) && (v > lim_min)) : !((v > lim_max) || (v < lim_min));
+  const uint64_t G = uint64_t(gridDim.x) * blockDim.x;
+  for (uint64_t i0 = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i0 < n; i0 += VG_BATCH * G) {   // as vg_minmax_kernel
+    float xs[VG_BATCH], ys[VG_BATCH], zs[VG_BATCH], vs[VG_BATCH];
+#pragma unroll
+    for (int u = 0; u < VG_BATCH; ++u) {
+      const uint64_t i = i0 + uint64_t(u) * G;
+      const float* p = rec(pts, stride, i < n ? i : i0);
+      xs[u] = p[0]; ys[u] = p[1]; zs[u] = p[2];
     }
-    uint32_t key = sort_bits >= 32 ? 0xFFFFFFFFu : ((1u << sort_bits) - 1u);  // rejected: after every voxel id
-    if (ok) {  // :713-718
-      const int i0 = int(floorf(__fmul_rn(x, g.inv[0])) - float(g.min_b[0]));
-      const int i1 = int(floorf(__fmul_rn(y, g.inv[1])) - float(g.min_b[1]));
-      const int i2 = int(floorf(__fmul_rn(z, g.inv[2])) - float(g.min_b[2]));
-      key = uint32_t(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
-      ++mine;
+    if (has_limits) {
+#pragma unroll
+      for (int u = 0; u < VG_BATCH; ++u) {
+        const uint64_t i = i0 + uint64_t(u) * G;
+        vs[u] = rec(pts, stride, i < n ? i : i0)[limit_field(has_limits)];
+      }
     }
-    keys[i] = key;
+#pragma unroll
+    for (int u = 0; u < VG_BATCH; ++u) {
+      const uint64_t i = i0 + uint64_t(u) * G;
+      if (i >= n) continue;
+      const float x = xs[u], y = ys[u], z = zs[u];
+      bool ok = isfinite(x) && isfinite(y) && isfinite(z);
+      if (ok && has_limits) {  // :684-695: double limits against the float value
+        const double v = double(vs[u]);
+        ok = (has_limits & 2) ? !((v < lim_max) && (v > lim_min)) : !((v > lim_max) || (v < lim_min));
+      }
+      uint32_t key = sort_bits >= 32 ? 0xFFFFFFFFu : ((1u << sort_bits) - 1u);  // rejected: after every voxel id
+      if (ok) {  // :713-718
+        const int i0v = int(floorf(__fmul_rn(x, g.inv[0])) - float(g.min_b[0]));
+        const int i1v = int(floorf(__fmul_rn(y, g.inv[1])) - float(g.min_b[1]));
+        const int i2v = int(floorf(__fmul_rn(z, g.inv[2])) - float(g.min_b[2]));
+        key = uint32_t(i0v * g.mul[0] + i1v * g.mul[1] + i2v * g.mul[2]);
+        ++mine;
+      }
+      keys[i] = key;
+    }
   }
   // one atomic per block of a grid that is sized to the machine, not to the cloud (39k single-address atomics -- one
   // per 256 points -- took 0.4 ms of this kernel's 0.45 at 10M points)
@@ -120,8 +161,19 @@ __global__ __launch_bounds__(256) void vg_key_kernel(const void* pts, size_t str
 //                        a prefix over the block's 64 (row, wave) cells) and writes run_start[block prefix + rank]
 constexpr int VG_RUN_BLOCK = 4096, VG_RUN_THREADS = 256, VG_RUN_ROWS = VG_RUN_BLOCK / VG_RUN_THREADS;
 
-__device__ __forceinline__ bool vg_is_head(const uint32_t* __restrict__ keys, uint32_t j, uint32_t nv) {
-  return j < nv && (j == 0u || keys[j] != keys[j - 1u]);
+// A thread's sixteen keys and their predecessors, every load in flight before the first comparison (a load inside
+// `j < nv && ...` is followed by its own wait: sixteen memory round trips one after the other).  Rows past the end read key 0.
+__device__ __forceinline__ void vg_load_pairs(const uint32_t* __restrict__ keys, uint32_t base, uint32_t nv,
+                                              uint32_t (&kc)[VG_RUN_ROWS], uint32_t (&kp)[VG_RUN_ROWS]) {
+#pragma unroll
+  for (int e = 0; e < VG_RUN_ROWS; ++e) {
+    const uint32_t j = base + uint32_t(e) * VG_RUN_THREADS + threadIdx.x;
+    kc[e] = keys[j < nv ? j : 0u];
+    kp[e] = keys[(j < nv && j > 0u) ? j - 1u : 0u];
+  }
+}
+__device__ __forceinline__ bool vg_is_head(uint32_t key, uint32_t prev, uint32_t j, uint32_t nv) {
+  return j < nv && (j == 0u || key != prev);
 }
 
 __global__ __launch_bounds__(VG_RUN_THREADS) void vg_runcount_kernel(const uint32_t* __restrict__ keys,
@@ -133,8 +185,10 @@ __global__ __launch_bounds__(VG_RUN_THREADS) void vg_runcount_kernel(const uint3
   const uint32_t nv = *nv_dev;
   const uint32_t base = blockIdx.x * uint32_t(VG_RUN_BLOCK);
   uint32_t mine = 0;
-#pragma unroll 4
-  for (int e = 0; e < VG_RUN_ROWS; ++e) mine += vg_is_head(keys, base + uint32_t(e) * VG_RUN_THREADS + threadIdx.x, nv) ? 1u : 0u;
+  uint32_t kc[VG_RUN_ROWS], kp[VG_RUN_ROWS];
+  vg_load_pairs(keys, base, nv, kc, kp);
+#pragma unroll
+  for (int e = 0; e < VG_RUN_ROWS; ++e) mine += vg_is_head(kc[e], kp[e], base + uint32_t(e) * VG_RUN_THREADS + threadIdx.x, nv) ? 1u : 0u;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
   if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(&total, mine);
@@ -155,9 +209,11 @@ __global__ __launch_bounds__(VG_RUN_THREADS) void vg_runstart_kernel(const uint3
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t rank[VG_RUN_ROWS];
   uint32_t heads = 0;   // bit e: this thread's element of row e starts a run
+  uint32_t kc[VG_RUN_ROWS], kp[VG_RUN_ROWS];
+  vg_load_pairs(keys, base, nv, kc, kp);
 #pragma unroll
   for (int e = 0; e < VG_RUN_ROWS; ++e) {
-    const bool h = vg_is_head(keys, base + uint32_t(e) * VG_RUN_THREADS + threadIdx.x, nv);
+    const bool h = vg_is_head(kc[e], kp[e], base + uint32_t(e) * VG_RUN_THREADS + threadIdx.x, nv);
     const unsigned long long b = __builtin_amdgcn_ballot_w64(h);
     rank[e] = uint32_t(__builtin_popcountll(b & below));
     heads |= h ? (1u << e) : 0u;
@@ -211,10 +267,16 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
   h[threadIdx.x] = 0u;
   __syncthreads();
   const uint32_t base = blockIdx.x * uint32_t(RS_KPB);
-#pragma unroll 4
+  uint32_t kv[RS_ROWS];   // all sixteen loads in flight before the first use (rows past the end read key 0)
+#pragma unroll
   for (int r = 0; r < RS_ROWS; ++r) {
     const uint32_t i = base + uint32_t(r) * RS_THREADS + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    kv[r] = keys[i < n ? i : 0u];
+  }
+#pragma unroll
+  for (int r = 0; r < RS_ROWS; ++r) {
+    const uint32_t i = base + uint32_t(r) * RS_THREADS + threadIdx.x;
+    if (i < n) atomicAdd(&h[(kv[r] >> shift) & 255u], 1u);
   }
   __syncthreads();
   hist[size_t(threadIdx.x) * nblocks + blockIdx.x] = h[threadIdx.x];
@@ -261,7 +323,9 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
   static_assert(RS_THREADS == 256, "one thread per digit");
   __shared__ uint32_t wcnt[WAVES][256];
   __shared__ uint32_t goff[256];
+  __shared__ uint32_t lstart[256];
   __shared__ uint32_t dtot[WAVES];
+  __shared__ uint32_t skey[RS_KPB], sval[RS_KPB];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < WAVES * 256; i += RS_THREADS) (&wcnt[0][0])[i] = 0u;
   {  // keys of smaller digits (exclusive scan of the 256 row totals) + keys of this digit in earlier blocks
@@ -282,12 +346,28 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
   const unsigned long long below = (1ull << lane) - 1ull;
   const uint32_t base = blockIdx.x * uint32_t(RS_KPB) + wave * uint32_t(RS_ROWS * 64);
   uint32_t key[RS_ROWS], val[RS_ROWS], rk[RS_ROWS];
+  // keys and values of all sixteen rows first, every load in flight together (the ranking below has a wave barrier per row,
+  // and a load asked for inside it was waited for inside it); rows past the end read element 0 and are masked below
+#pragma unroll
+  for (int r = 0; r < RS_ROWS; ++r) {
+    const uint32_t i = base + uint32_t(r) * 64u + lane;
+    key[r] = keys_in[i < n ? i : 0u];
+  }
+  if (vals_in) {
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; ++r) {
+      const uint32_t i = base + uint32_t(r) * 64u + lane;
+      val[r] = vals_in[i < n ? i : 0u];
+    }
+  } else {   // first pass: the value is the point index
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; ++r) val[r] = base + uint32_t(r) * 64u + lane;
+  }
 #pragma unroll
   for (int r = 0; r < RS_ROWS; ++r) {
     const uint32_t i = base + uint32_t(r) * 64u + lane;
     const bool ok = i < n;
-    key[r] = ok ? keys_in[i] : 0u;
-    val[r] = ok ? (vals_in ? vals_in[i] : i) : 0u;   // first pass: the value is the point index
+    if (!ok) key[r] = val[r] = 0u;
     const uint32_t d = (key[r] >> shift) & 255u;
     unsigned long long peers = __builtin_amdgcn_ballot_w64(ok);
 #pragma unroll
@@ -310,24 +390,54 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
     __builtin_amdgcn_wave_barrier();  // the next row's leader reads what this row's leader wrote
   }
   __syncthreads();
-  // digit d of this block: waves in order
+  // The block's pairs go out through LDS in their sorted order: a lane that writes its own pair to its final slot sends 64
+  // four-byte stores to 64 places per instruction (a digit holds 16 of the block's keys on average: 1.9 TB/s of pairs at
+  // 10M points); staged, consecutive lanes write consecutive slots of a digit's segment.
+  // digit d of this block: first slot in the staged order (digits ascending, waves in order inside a digit)
   {
     const uint32_t d = threadIdx.x;
-    uint32_t run = goff[d];
+    uint32_t c[WAVES], tot = 0;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) {
-      const uint32_t c = wcnt[w][d];
+      c[w] = wcnt[w][d];
+      tot += c[w];
+    }
+    uint32_t inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o);
+      if (lane >= uint32_t(o)) inc += t;
+    }
+    if (lane == 63u) dtot[wave] = inc;   // (its first use ended at the barrier behind goff)
+    __syncthreads();
+    uint32_t run = inc - tot;
+    for (uint32_t w = 0; w < wave; ++w) run += dtot[w];
+    lstart[d] = run;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
       wcnt[w][d] = run;
-      run += c;
+      run += c[w];
     }
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < RS_ROWS; ++r) {
     if (rk[r] != 0xFFFFFFFFu) {
-      const uint32_t d = rk[r] >> 16, pos = wcnt[wave][d] + (rk[r] & 0xFFFFu);
-      keys_out[pos] = key[r];
-      vals_out[pos] = val[r];
+      const uint32_t d = rk[r] >> 16, lp = wcnt[wave][d] + (rk[r] & 0xFFFFu);
+      skey[lp] = key[r];
+      sval[lp] = val[r];
+    }
+  }
+  __syncthreads();
+  const uint32_t block_first = blockIdx.x * uint32_t(RS_KPB);
+  const uint32_t live = n - block_first < uint32_t(RS_KPB) ? n - block_first : uint32_t(RS_KPB);   // pairs of this block
+#pragma unroll
+  for (int r = 0; r < RS_ROWS; ++r) {
+    const uint32_t j = uint32_t(r) * RS_THREADS + threadIdx.x;
+    if (j < live) {
+      const uint32_t k = skey[j], d = (k >> shift) & 255u, pos = goff[d] + (j - lstart[d]);
+      keys_out[pos] = k;
+      vals_out[pos] = sval[j];
     }
   }
 }
@@ -409,16 +519,32 @@ __global__ __launch_bounds__(256) void vg_centroid_row_kernel(const void* pts, s
     longest = max(longest, uint32_t(__shfl_xor(int(longest), 16)));
     longest = max(longest, uint32_t(__shfl_xor(int(longest), 32)));
     float sx = 0.0f, sy = 0.0f, sz = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f, cv = 0.0f;
-    for (uint32_t c = 0; c < longest; c += 16u) {
-      float px = 0.0f, py = 0.0f, pz = 0.0f, qx = 0.0f, qy = 0.0f, qz = 0.0f, qc = 0.0f;
-      if (c + sub < len) {
-        const float* p = rec(pts, stride, vals[b + c + sub]);
-        px = p[0]; py = p[1]; pz = p[2];
-        if (with_n) {
-          const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + noff);
-          qx = q[0]; qy = q[1]; qz = q[2]; qc = q[4];
-        }
+    // The gather is two dependent loads per chunk of 16 points (the sorted index, then the record it names).  They run two
+    // chunks deep: while chunk c is added up, the records of chunk c + 16 and the indices of chunk c + 32 are on their way
+    // (one after the other they were two memory round trips per chunk and row: 199 us at 10M points).  Slots past the
+    // run's end re-read its first element (always there: position 0 when the row has no run) and never enter a sum.
+    const auto slot = [&](uint32_t c) { return (c + sub < len) ? b + c + sub : b; };
+    float px, py, pz, qx = 0.0f, qy = 0.0f, qz = 0.0f, qc = 0.0f;
+    uint32_t idx_next;
+    {
+      const float* p = rec(pts, stride, vals[slot(0u)]);
+      idx_next = vals[slot(16u)];
+      px = p[0]; py = p[1]; pz = p[2];
+      if (with_n) {
+        const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + noff);
+        qx = q[0]; qy = q[1]; qz = q[2]; qc = q[4];
       }
+    }
+    for (uint32_t c = 0; c < longest; c += 16u) {
+      // chunk c + 16's records, chunk c + 32's indices
+      const float* pn = rec(pts, stride, idx_next);
+      const float npx = pn[0], npy = pn[1], npz = pn[2];
+      float nqx = 0.0f, nqy = 0.0f, nqz = 0.0f, nqc = 0.0f;
+      if (with_n) {
+        const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pn) + noff);
+        nqx = q[0]; nqy = q[1]; nqz = q[2]; nqc = q[4];
+      }
+      idx_next = vals[slot(c + 32u)];
 #pragma unroll
       for (uint32_t j = 0; j < 16u; ++j) {
         const int src = int(rowbase + j);
@@ -435,6 +561,8 @@ __global__ __launch_bounds__(256) void vg_centroid_row_kernel(const void* pts, s
           cv = on ? __fadd_rn(cv, wc) : cv;
         }
       }
+      px = npx; py = npy; pz = npz;
+      qx = nqx; qy = nqy; qz = nqz; qc = nqc;
     }
     if (live && sub == 0u) {
       const float cnt = float(len);
