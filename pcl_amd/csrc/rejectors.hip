@@ -97,14 +97,35 @@ __global__ __launch_bounds__(TB) void rs_hist_kernel(const float* __restrict__ d
   const uint32_t n4 = n / 4;  // four pairs per lane and step: one 16-byte and one 4-byte load
   const float4* d4 = reinterpret_cast<const float4*>(d2);
   const uint32_t* k4 = reinterpret_cast<const uint32_t*>(keep);
-  for (uint32_t j = blockIdx.x * TB + threadIdx.x; j < n4; j += gridDim.x * TB) {
-    const uint32_t k = k4[j];
-    if (k == 0u) continue;
-    const float4 d = d4[j];
-    rs_count<PASS>(h, d.x, (k & 0xFFu) != 0u, dkey, ikey, cur, 4 * j);
-    rs_count<PASS>(h, d.y, (k & 0xFF00u) != 0u, dkey, ikey, cur, 4 * j + 1);
-    rs_count<PASS>(h, d.z, (k & 0xFF0000u) != 0u, dkey, ikey, cur, 4 * j + 2);
-    rs_count<PASS>(h, d.w, (k & 0xFF000000u) != 0u, dkey, ikey, cur, 4 * j + 3);
+  // RS_TRIPS trips of the grid-stride loop at a time: their flag words and distances are asked for together (the distance
+  // load behind `if (k == 0) continue` was a second memory round trip per trip); slots past the end re-read the first
+  constexpr int RS_TRIPS = 4;
+  const uint32_t G = gridDim.x * TB;
+  for (uint32_t j0 = blockIdx.x * TB + threadIdx.x; j0 < n4; j0 += RS_TRIPS * G) {
+    uint32_t kk[RS_TRIPS];
+    float4 dd[RS_TRIPS];
+#pragma unroll
+    for (int u = 0; u < RS_TRIPS; ++u) {
+      const uint64_t j = uint64_t(j0) + uint64_t(u) * G;
+      kk[u] = k4[j < n4 ? uint32_t(j) : j0];
+    }
+#pragma unroll
+    for (int u = 0; u < RS_TRIPS; ++u) {
+      const uint64_t j = uint64_t(j0) + uint64_t(u) * G;
+      dd[u] = d4[j < n4 ? uint32_t(j) : j0];
+    }
+#pragma unroll
+    for (int u = 0; u < RS_TRIPS; ++u) {
+      const uint64_t j64 = uint64_t(j0) + uint64_t(u) * G;
+      if (j64 >= n4) continue;
+      const uint32_t j = uint32_t(j64), k = kk[u];
+      if (k == 0u) continue;
+      const float4 d = dd[u];
+      rs_count<PASS>(h, d.x, (k & 0xFFu) != 0u, dkey, ikey, cur, 4 * j);
+      rs_count<PASS>(h, d.y, (k & 0xFF00u) != 0u, dkey, ikey, cur, 4 * j + 1);
+      rs_count<PASS>(h, d.z, (k & 0xFF0000u) != 0u, dkey, ikey, cur, 4 * j + 2);
+      rs_count<PASS>(h, d.w, (k & 0xFF000000u) != 0u, dkey, ikey, cur, 4 * j + 3);
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {
     const uint32_t i = 4 * n4 + threadIdx.x;

@@ -377,13 +377,17 @@ __global__ __launch_bounds__(BLOCK, (K == 8 && PCLHIP_NRM_WAVES >= 4) ? 4 : 1) v
       NRM_LAP(6);
       const bool redo[1] = {valid && ncand > uint32_t(K)};
       if (valid && ncand <= uint32_t(K)) {
+        // (the candidates' points: all K gathers in flight together, empty slots re-read the query's own point -- see the
+        //  covariance below)
+        float4 tt[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) tt[c] = ix.pts[uint32_t(c) < ncand ? cand[c] : i];
 #pragma unroll
         for (int c = 0; c < K; ++c) {
           if (uint32_t(c) < ncand) {
-            const uint32_t pc = cand[c];
-            const float4 t = ix.pts[pc];
+            const float4 t = tt[c];
             pol.keys[c] = make_key(l2_simple(p.x, p.y, p.z, t.x, t.y, t.z), __float_as_uint(t.w));
-            pol.pos[c] = pc;
+            pol.pos[c] = cand[c];
           }
         }
         // Batcher's odd-even merge sort for 8 keys (19 comparators): ascending (distance, index), empty slots last
@@ -422,14 +426,23 @@ __global__ __launch_bounds__(BLOCK, (K == 8 && PCLHIP_NRM_WAVES >= 4) ? 4 : 1) v
         atomicAdd(nan_count, 1ull);
       } else {
         Cov cv;
-        const float4 p0 = ix.pts[pol.pos[0]];
-        cv.start(p0.x, p0.y, p0.z);
-        cv.add(p0.x, p0.y, p0.z);
+        // the neighbours' coordinates: up to GB gathers in flight together (a gather under `c < found` is waited for where it
+        // stands -- K memory round trips one after the other per wavefront); slots past `found` re-read neighbour 0 and are
+        // not added.  The sums take the neighbours in the order 0, 1, ... as before.
+        constexpr int GB = K < 8 ? K : 8;
+        float4 pc[GB];
 #pragma unroll
-        for (int c = 1; c < K; ++c) {
-          if (c < found) {
-            const float4 pc = ix.pts[pol.pos[c]];
-            cv.add(pc.x, pc.y, pc.z);
+        for (int c0 = 0; c0 < K; c0 += GB) {
+#pragma unroll
+          for (int f = 0; f < GB; ++f) {
+            const int c = c0 + f;
+            pc[f] = ix.pts[(c < K && c < found) ? pol.pos[c < K ? c : 0] : pol.pos[0]];
+          }
+#pragma unroll
+          for (int f = 0; f < GB; ++f) {
+            const int c = c0 + f;
+            if (c == 0) cv.start(pc[0].x, pc[0].y, pc[0].z);
+            if (c < K && c < found) cv.add(pc[f].x, pc[f].y, pc[f].z);
           }
         }
         float cov[9];
@@ -713,15 +726,24 @@ __global__ __launch_bounds__(BLOCK) void gicp_cov_kernel(IndexView ix, int k, do
     }
     if (valid) {
       double mean[3] = {0, 0, 0}, c00 = 0, c10 = 0, c11 = 0, c20 = 0, c21 = 0, c22 = 0;
+      // eight neighbours per batch, their gathers in flight together (slots from k on re-read neighbour 0 and are skipped);
+      // the sums take the neighbours in the order 0, 1, ... as before
 #pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        if (c < k) {  // the index holds >= k points (checked by the caller): all k slots are filled
-          const float4 q = ix.pts[pol.pos[c]];
-          const double ptx = double(__fsub_rn(q.x, p.x)), pty = double(__fsub_rn(q.y, p.y)), ptz = double(__fsub_rn(q.z, p.z));
-          mean[0] += ptx; mean[1] += pty; mean[2] += ptz;
-          c00 += ptx * ptx;
-          c10 += pty * ptx; c11 += pty * pty;
-          c20 += ptz * ptx; c21 += ptz * pty; c22 += ptz * ptz;
+      for (int c0 = 0; c0 < 32; c0 += 8) {
+        if (c0 >= k) break;
+        float4 qq[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) qq[f] = ix.pts[pol.pos[(c0 + f) < k ? c0 + f : 0]];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          if (c0 + f < k) {  // the index holds >= k points (checked by the caller): all k slots are filled
+            const float4 q = qq[f];
+            const double ptx = double(__fsub_rn(q.x, p.x)), pty = double(__fsub_rn(q.y, p.y)), ptz = double(__fsub_rn(q.z, p.z));
+            mean[0] += ptx; mean[1] += pty; mean[2] += ptz;
+            c00 += ptx * ptx;
+            c10 += pty * ptx; c11 += pty * pty;
+            c20 += ptz * ptx; c21 += ptz * pty; c22 += ptz * ptz;
+          }
         }
       }
       const double kk = double(k);
