@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void vg_key_kernel(const void* pts, size_t str
     }
   }
   // one atomic per block of a grid that is sized to the machine, not to the cloud (39k single-address atomics -- one
-  // per 256 points -- took 0.4 ms of this kernel's 0.45 at 10M points)
+  // per 256 points -- took 0.4 ms of this kernel's 0.45 at 10M points; 4096 blocks still 28 us of 64: two blocks per CU now)
   __shared__ unsigned int blk;
   if (threadIdx.x == 0) blk = 0;
   __syncthreads();
@@ -765,7 +765,7 @@ extern "C" pclhip_status pclhip_voxelgrid_ex2(pclhip_ctx* ctx, const void* point
   while (id_bits < 32 && (int64_t(1) << id_bits) < nvox) ++id_bits;
   const int sort_bits = id_bits < 32 ? id_bits + 1 : 32;
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), s));
-  hipLaunchKernelGGL(vg_key_kernel, dim3(unsigned(std::min<uint64_t>((n + 255) / 256, uint64_t(ctx->num_cus) * 16))), dim3(256), 0,
+  hipLaunchKernelGGL(vg_key_kernel, dim3(unsigned(std::min<uint64_t>((n + 255) / 256, uint64_t(ctx->num_cus) * 2))), dim3(256), 0,
                      s, dp, stride, n, g, has_z_limits, z_min, z_max, k0, d_cnt, sort_bits);
   for (int shift = 0; shift < sort_bits; shift += 8) {  // stable LSD passes (rs_* above), ping-pong k0/v0 <-> k1/v1
     hipLaunchKernelGGL(rs_hist_kernel, dim3(sort_blocks), dim3(RS_THREADS), 0, s, k0, uint32_t(n), shift, sort_blocks, hist);
