@@ -275,9 +275,10 @@ pclhip_status radix_select_queued(pclhip_icp* icp, const float* d2, const uint8_
                                   unsigned int min_corr) {
   pclhip_ctx* ctx = icp->ctx;
   int grid = int((n / 4 + TB - 1) / TB);
-  // (every block merges up to 2048 bins into the global histogram: 8 / 4 / 2 / 1 blocks per CU measured at 10M pairs --
-  // 1.278 / 1.236 / 1.236 / 1.291 ms per step with a median + trimmed chain)
-  if (grid > ctx->num_cus * 4) grid = ctx->num_cus * 4;
+  // (every block merges up to 2048 bins into the global histogram, and float distances crowd into a few of them: 8 / 4 / 2 /
+  // 1 blocks per CU measured at 10M pairs -- 1.278 / 1.236 / 1.236 / 1.291 ms per step with a median + trimmed chain in
+  // round 4; with four trips of loads in flight per thread (round 6) four per CU 1.122-1.133, two per CU 1.104)
+  if (grid > ctx->num_cus * 2) grid = ctx->num_cus * 2;
   if (grid < 1) grid = 1;
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(hist_dev, 0, size_t(RS_PASSES) * RS_BINS * sizeof(uint32_t), ctx->stream));
 #define RS_PASS(P)                                                                                                    \
