@@ -20,15 +20,39 @@ namespace {
 
 constexpr int TB = 256;
 
+// The per-pair flag passes take FOUR pairs per thread: one 16-byte load of match positions / distances and one 4-byte word of
+// keep flags (a thread per pair moved one byte per lane and store: 19-20 us per pass at 10M pairs); thread n / 4 takes the
+// n % 4 pairs left over.
+__device__ __forceinline__ uint32_t rej_tail_first(uint32_t n) { return (n / 4u) * 4u; }
+
 __global__ void rej_init_kernel(const uint32_t* __restrict__ match_pos, uint32_t n, uint8_t* __restrict__ keep) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) keep[i] = match_pos[i] != NO_INDEX ? 1 : 0;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, n4 = n / 4u;
+  if (j < n4) {
+    const uint4 m = reinterpret_cast<const uint4*>(match_pos)[j];
+    reinterpret_cast<uint32_t*>(keep)[j] = (m.x != NO_INDEX ? 1u : 0u) | (m.y != NO_INDEX ? 0x100u : 0u) |
+                                           (m.z != NO_INDEX ? 0x10000u : 0u) | (m.w != NO_INDEX ? 0x1000000u : 0u);
+  } else if (j == n4) {
+    for (uint32_t i = rej_tail_first(n); i < n; ++i) keep[i] = match_pos[i] != NO_INDEX ? 1 : 0;
+  }
 }
 
 // registration/src/correspondence_rejection_distance.cpp:55-60: keep if distance < max_distance_^2 (float)
 __global__ void rej_distance_kernel(const float* __restrict__ d2, uint32_t n, float max_d2, uint8_t* __restrict__ keep) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && keep[i] && !(d2[i] < max_d2)) keep[i] = 0;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, n4 = n / 4u;
+  if (j < n4) {
+    const uint32_t k = reinterpret_cast<const uint32_t*>(keep)[j];
+    if (k == 0u) return;
+    const float4 d = reinterpret_cast<const float4*>(d2)[j];
+    uint32_t o = k;
+    if (!(d.x < max_d2)) o &= ~0xFFu;
+    if (!(d.y < max_d2)) o &= ~0xFF00u;
+    if (!(d.z < max_d2)) o &= ~0xFF0000u;
+    if (!(d.w < max_d2)) o &= ~0xFF000000u;
+    if (o != k) reinterpret_cast<uint32_t*>(keep)[j] = o;
+  } else if (j == n4) {
+    for (uint32_t i = rej_tail_first(n); i < n; ++i)
+      if (keep[i] && !(d2[i] < max_d2)) keep[i] = 0;
+  }
 }
 
 // ---- radix selection: ONE order statistic of the kept distances, read where they lie --------------------------
@@ -306,23 +330,51 @@ pclhip_status radix_select_queued(pclhip_icp* icp, const float* d2, const uint8_
 // correspondence_rejection_median_distance.cpp:64-66: keep if double(d) <= median * factor
 __global__ void rej_median_kernel(const float* __restrict__ d2, uint32_t n, const RejState* __restrict__ st,
                                   uint8_t* __restrict__ keep) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, n4 = n / 4u;
   if (st->mode != 1) return;
   const double thr = st->threshold;
-  if (i < n && keep[i] && !(double(d2[i]) <= thr)) keep[i] = 0;
+  if (j < n4) {   // (four pairs per thread: see rej_init_kernel)
+    const uint32_t k = reinterpret_cast<const uint32_t*>(keep)[j];
+    if (k == 0u) return;
+    const float4 d = reinterpret_cast<const float4*>(d2)[j];
+    uint32_t o = k;
+    if (!(double(d.x) <= thr)) o &= ~0xFFu;
+    if (!(double(d.y) <= thr)) o &= ~0xFF00u;
+    if (!(double(d.z) <= thr)) o &= ~0xFF0000u;
+    if (!(double(d.w) <= thr)) o &= ~0xFF000000u;
+    if (o != k) reinterpret_cast<uint32_t*>(keep)[j] = o;
+  } else if (j == n4) {
+    for (uint32_t i = rej_tail_first(n); i < n; ++i)
+      if (keep[i] && !(double(d2[i]) <= thr)) keep[i] = 0;
+  }
 }
 
 // correspondence_rejection_trimmed.cpp:53-58: keep the n smallest (distance, query) keys
+__device__ __forceinline__ bool rej_trim_drops(int mode, uint32_t thr_d, uint32_t thr_q, float d, const float4* __restrict__ cur,
+                                               uint32_t i) {
+  const uint32_t b = __float_as_uint(d);  // the query index is read only where the distance alone does not decide
+  return mode == 2 || b > thr_d || (b == thr_d && thr_q != 0xFFFFFFFFu && __float_as_uint(cur[i].w) > thr_q);
+}
 __global__ void rej_trim_kernel(const float4* __restrict__ cur, const float* __restrict__ d2, uint32_t n,
                                 const RejState* __restrict__ st, uint8_t* __restrict__ keep) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, n4 = n / 4u;
   const int mode = st->mode;
   if (mode == 0) return;  // nv >= count: the list passes unchanged
   const uint64_t thr_key = st->key;
   const uint32_t thr_d = uint32_t(thr_key >> 32), thr_q = uint32_t(thr_key);
-  if (i < n && keep[i]) {
-    const uint32_t b = __float_as_uint(d2[i]);  // the query index is read only where the distance alone does not decide
-    if (mode == 2 || b > thr_d || (b == thr_d && thr_q != 0xFFFFFFFFu && __float_as_uint(cur[i].w) > thr_q)) keep[i] = 0;
+  if (j < n4) {   // (four pairs per thread: see rej_init_kernel)
+    const uint32_t k = reinterpret_cast<const uint32_t*>(keep)[j];
+    if (k == 0u) return;
+    const float4 d = reinterpret_cast<const float4*>(d2)[j];
+    uint32_t o = k;
+    if ((k & 0xFFu) && rej_trim_drops(mode, thr_d, thr_q, d.x, cur, 4u * j)) o &= ~0xFFu;
+    if ((k & 0xFF00u) && rej_trim_drops(mode, thr_d, thr_q, d.y, cur, 4u * j + 1u)) o &= ~0xFF00u;
+    if ((k & 0xFF0000u) && rej_trim_drops(mode, thr_d, thr_q, d.z, cur, 4u * j + 2u)) o &= ~0xFF0000u;
+    if ((k & 0xFF000000u) && rej_trim_drops(mode, thr_d, thr_q, d.w, cur, 4u * j + 3u)) o &= ~0xFF000000u;
+    if (o != k) reinterpret_cast<uint32_t*>(keep)[j] = o;
+  } else if (j == n4) {
+    for (uint32_t i = rej_tail_first(n); i < n; ++i)
+      if (keep[i] && rej_trim_drops(mode, thr_d, thr_q, d2[i], cur, i)) keep[i] = 0;
   }
 }
 
@@ -373,6 +425,7 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
   icp->fetch_order = 0;
   if (n == 0) return PCLHIP_OK;
   const dim3 grid((n + TB - 1) / TB), block(TB);
+  const dim3 grid4((n / 4 + 1 + TB - 1) / TB);   // the per-pair flag passes: four pairs per thread + one thread for the tail
   if (!icp->keep) PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->keep, n));
   if (!icp->rej_state) {
     PCLHIP_CHECK_HIP(ctx, dev_malloc(ctx, &icp->rej_state, sizeof(RejState)));
@@ -380,7 +433,7 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
     std::memset(icp->rej_state_host, 0, sizeof(RejState));
   }
   PCLHIP_CHECK_HIP(ctx, hipMemsetAsync(icp->rej_state, 0, sizeof(RejState), s));
-  hipLaunchKernelGGL(rej_init_kernel, grid, block, 0, s, icp->match_pos, n, icp->keep);
+  hipLaunchKernelGGL(rej_init_kernel, grid4, block, 0, s, icp->match_pos, n, icp->keep);
   Guard g;  // stream-ordered temporaries: released to the context when this returns, re-used only by later work of the stream
   g.ctx = ctx;
   RsState* rs = nullptr;
@@ -416,7 +469,7 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
     switch (r.kind) {
       case PCLHIP_REJ_DISTANCE: {
         const float md = float(r.param);
-        hipLaunchKernelGGL(rej_distance_kernel, grid, block, 0, s, icp->match_d2, n, md * md, icp->keep);
+        hipLaunchKernelGGL(rej_distance_kernel, grid4, block, 0, s, icp->match_d2, n, md * md, icp->keep);
         break;
       }
       case PCLHIP_REJ_MEDIAN_DISTANCE: {
@@ -425,7 +478,7 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
                                                        rs_hist, rs_hist_f64, int(r.kind), r.param, 0u);
           if (sr != PCLHIP_OK) return sr;
         }
-        hipLaunchKernelGGL(rej_median_kernel, grid, block, 0, s, icp->match_d2, n, icp->rej_state, icp->keep);
+        hipLaunchKernelGGL(rej_median_kernel, grid4, block, 0, s, icp->match_d2, n, icp->rej_state, icp->keep);
         break;
       }
       case PCLHIP_REJ_ONE_TO_ONE: {
@@ -456,7 +509,7 @@ pclhip_status apply_correspondence_filters(pclhip_icp* icp, float max_d2, bool u
                                                        rs_hist, rs_hist_f64, int(r.kind), r.param, r.min_correspondences);
           if (sr != PCLHIP_OK) return sr;
         }
-        hipLaunchKernelGGL(rej_trim_kernel, grid, block, 0, s, icp->src_cur, icp->match_d2, n, icp->rej_state, icp->keep);
+        hipLaunchKernelGGL(rej_trim_kernel, grid4, block, 0, s, icp->src_cur, icp->match_d2, n, icp->rej_state, icp->keep);
         trimmed_in_chain = true;  // the list comes back sorted by distance IF it was cut (RejState::trimmed says so)
         break;
       }
